@@ -1,0 +1,207 @@
+"""
+ctypes binding of ``libhbmpc_hip.so`` (C ABI declared in ``include/hbmpc_hip.h``).
+
+This is the thin FFI layer the north star asks for: host code stays Python, the
+arithmetic lives in hand-written HIP for gfx950.  PyTorch is used only as plumbing
+(device buffers, current stream); nothing in the C signatures is a torch type.
+
+There is NO CPU fallback.  If the shared library is missing or no MI355X is
+visible, every entry point raises ``HbmpcBackendError``.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhbmpc_hip.so")
+
+HB_OK, HB_ERR_SINGULAR, HB_ERR_BAD_ARG, HB_ERR_UNSUPPORTED = 0, 1, 2, 3
+HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_MISMATCH = 4, 5, 6
+
+_STATUS_NAMES = {
+    1: "HB_ERR_SINGULAR",
+    2: "HB_ERR_BAD_ARG",
+    3: "HB_ERR_UNSUPPORTED",
+    4: "HB_ERR_NO_DEVICE",
+    5: "HB_ERR_HIP",
+    6: "HB_ERR_MISMATCH",
+}
+
+
+class HbmpcBackendError(RuntimeError):
+    """The HIP backend is unavailable or a HIP call failed."""
+
+
+class HbView(ctypes.Structure):
+    _fields_ = [("stride_c", ctypes.c_int64), ("stride_l", ctypes.c_int64)]
+
+
+# every symbol include/hbmpc_hip.h declares: (restype, argtypes)
+_vp, _i, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+_pp = ctypes.POINTER(ctypes.c_void_p)
+SYMBOLS = {
+    "hb_version": (_i, []),
+    "hb_device_count": (_i, []),
+    "hb_ctx_create": (_i, [_pp, _vp, _i, _i]),
+    "hb_ctx_destroy": (None, [_vp]),
+    "hb_last_error": (ctypes.c_char_p, [_vp]),
+    "hb_elem_bytes": (_i, [_vp]),
+    "hb_malloc": (_i, [_vp, _pp, _sz]),
+    "hb_free": (_i, [_vp, _vp]),
+    "hb_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "hb_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "hb_stream_sync": (_i, [_vp, _vp]),
+    "hb_vand_matrix_create": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
+    "hb_vand_inverse_create": (_i, [_vp, _vp, _i, _pp, _vp]),
+    "hb_matrix_from_host": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
+    "hb_matrix_to_host": (_i, [_vp, _vp, _vp, _vp]),
+    "hb_matrix_destroy": (None, [_vp]),
+    "hb_matvec": (_i, [_vp, _vp, _vp, HbView, _vp, _vp, HbView, _i64, _vp]),
+    "hb_matvec_check": (_i, [_vp, _vp, _vp, HbView, _vp, _vp, HbView, _vp, _i, _vp, _i64, _vp]),
+    "hb_vandermonde_batch_evaluate": (_i, [_vp, _vp, _i, _vp, _i64, _i, _vp, _vp]),
+    "hb_vandermonde_batch_interpolate": (_i, [_vp, _vp, _i, _vp, _i64, _vp, _vp]),
+    "hb_fft_batch_evaluate": (_i, [_vp, _vp, _i, _vp, _i64, _i, _i, _vp, _vp]),
+    "hb_fft_batch_interpolate": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _vp, _vp]),
+    "hb_gao_decode": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "hb_wb_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "hb_open_plan_create": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _pp, _vp]),
+    "hb_open_r1_encode": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "hb_open_r1_decode": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "hb_open_r2_decode": (_i, [_vp, _vp, _i64, _vp, _vp]),
+    "hb_open_status": (_i, [_vp, _vp]),
+    "hb_open_plan_destroy": (None, [_vp]),
+    "hb_selftest_mulmod": (_i, [_vp, _i, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library and type every declared symbol.  Raises loudly if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HbmpcBackendError(
+            f"{LIB_PATH} not found: build it with honeybadgermpc_amd/csrc/build.sh "
+            "(or __graft_entry__.build()).  There is no CPU fallback."
+        )
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise HbmpcBackendError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+# ---------------------------------------------------------------------------
+# int <-> limb marshalling.  The reference's FFI wire format is little-endian
+# bytes per element (hbmpc_ntl_helpers.pyx:20-29); ours is the same bytes at a
+# fixed width, packed into one contiguous buffer per call.
+# ---------------------------------------------------------------------------
+def ints_to_limbs(values, modulus, nbytes=32):
+    """list[int] -> (len, nbytes//8) uint64.  Values are reduced mod p on entry
+    (pyx:31-32); negative ints raise OverflowError like int.to_bytes (pyx:20-22)."""
+    buf = bytearray(len(values) * nbytes)
+    off = 0
+    for v in values:
+        if v < 0:
+            raise OverflowError("can't convert negative int to unsigned")
+        if v >= modulus:
+            v %= modulus
+        buf[off : off + nbytes] = v.to_bytes(nbytes, "little")
+        off += nbytes
+    return np.frombuffer(bytes(buf), dtype=np.uint64).reshape(len(values), nbytes // 8)
+
+
+def limbs_to_ints(arr, nbytes=32):
+    b = np.ascontiguousarray(arr).tobytes()
+    return [int.from_bytes(b[i : i + nbytes], "little") for i in range(0, len(b), nbytes)]
+
+
+def np_ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Context:
+    """One (modulus, device) pair: owns an ``hb_ctx`` and does the torch plumbing."""
+
+    _cache = {}
+
+    @classmethod
+    def get(cls, modulus, device=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise HbmpcBackendError(
+                "honeybadgermpc_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
+                "and there is no CPU fallback."
+            )
+        if device is None:
+            device = torch.cuda.current_device()
+        key = (int(modulus), int(device))
+        ctx = cls._cache.get(key)
+        if ctx is None:
+            ctx = cls(modulus, device)
+            cls._cache[key] = ctx
+        return ctx
+
+    def __init__(self, modulus, device):
+        import torch
+
+        self.torch = torch
+        self.lib = load_library()
+        self.modulus = int(modulus)
+        self.device = int(device)
+        if self.modulus >= 1 << 256:
+            raise ValueError("modulus must be below 2**256")
+        if self.modulus % 2 == 0 or self.modulus < 3:
+            raise ValueError("modulus must be an odd prime")
+        # the wide (4-limb) instantiation serves every modulus; a 1-limb context is
+        # available through the C ABI for 64-bit primes (see tests/test_gpu_parity.py)
+        self.n_limbs = 4
+        self.nbytes = 32
+        p = ints_to_limbs([self.modulus], self.modulus + 1)
+        h = ctypes.c_void_p()
+        rc = self.lib.hb_ctx_create(ctypes.byref(h), np_ptr(p), self.n_limbs, self.device)
+        if rc != HB_OK:
+            raise HbmpcBackendError(f"hb_ctx_create failed: {_STATUS_NAMES.get(rc, rc)}")
+        self.h = h
+        self.tdev = torch.device("cuda", self.device)
+
+    # -- plumbing ----------------------------------------------------------
+    def stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
+
+    def check(self, rc, what):
+        if rc == HB_OK:
+            return
+        msg = self.lib.hb_last_error(self.h)
+        raise HbmpcBackendError(f"{what}: {_STATUS_NAMES.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def empty(self, count):
+        """device buffer of `count` elements, as an int64 tensor of shape (count, n_limbs)"""
+        return self.torch.empty((max(int(count), 0), self.n_limbs), dtype=self.torch.int64, device=self.tdev)
+
+    def to_device(self, limbs):
+        t = self.torch.from_numpy(np.ascontiguousarray(limbs).view(np.int64))
+        return t.to(self.tdev)
+
+    def upload_ints(self, values):
+        return self.to_device(ints_to_limbs(values, self.modulus, self.nbytes))
+
+    def download_ints(self, tensor):
+        return limbs_to_ints(tensor.cpu().numpy().view(np.uint64), self.nbytes)
+
+    def host_elems(self, values):
+        """small host-side element array (points, omega) for by-value C arguments"""
+        return ints_to_limbs(values, self.modulus, self.nbytes)
+
+    @staticmethod
+    def ptr(tensor):
+        return ctypes.c_void_p(tensor.data_ptr())

@@ -1,0 +1,95 @@
+// hb_common.hpp -- host-side context, constants and small helpers shared by the C-ABI
+// translation units of libhbmpc_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/hbmpc_hip.h"
+#include "fp29.cuh"
+
+namespace hb {
+
+// Two instantiations: <NL=9 digits, NW=8 words> for p < 2^256, <3, 2> for p < 2^64.
+struct Wide { static constexpr int NL = 9, NW = 8; };
+struct Narrow { static constexpr int NL = 3, NW = 2; };
+
+constexpr int OT = 4;  // outputs per wave tile in the mat-vec kernel
+
+// word index of digit q of element (i, l) of an n_out x n_in matrix in kernel layout
+// [tile][l][digit][OT], tile = i / OT: the OT outputs of one digit form one aligned uint4
+__host__ __device__ inline size_t m_index(int i, int l, int n_in, int nl, int q) {
+    return (((size_t)((i / OT) * n_in + l) * (size_t)nl + (size_t)q) * OT) + (size_t)(i % OT);
+}
+inline int m_tiles(int n_out) { return (n_out + OT - 1) / OT; }
+
+}  // namespace hb
+
+struct hb_matrix {
+    hb_ctx *ctx;
+    int n_out, n_in;
+    uint32_t *dev;      // Montgomery digits, kernel layout, zero padded to whole tiles
+    size_t words;
+    bool cached;        // owned by the ctx cache: hb_matrix_destroy is a no-op
+};
+
+struct hb_ctx {
+    int device;
+    int n_limbs;        // 1 or 4 (uint64 limbs per element at the ABI)
+    hb::FpParams<9> pw; // valid when n_limbs == 4
+    hb::FpParams<3> pn; // valid when n_limbs == 1
+    uint64_t p_limbs[4];
+    std::string err;
+    std::map<std::string, hb_matrix *> mcache;        // tables keyed by (kind, n, d, point bytes)
+    std::map<std::vector<int32_t>, int32_t *> icache; // small int arrays resident on device
+    int32_t *flag_dev;                                // 64 status words
+    int elem_words() const { return n_limbs == 4 ? 8 : 2; }
+    int nl() const { return n_limbs == 4 ? 9 : 3; }
+};
+
+#define HB_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+            return HB_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define HB_LAUNCH_CHECK(ctx)                                                                      \
+    do {                                                                                          \
+        hipError_t e__ = hipGetLastError();                                                       \
+        if (e__ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string("kernel launch: ") + hipGetErrorString(e__);                 \
+            return HB_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+namespace hb {
+
+inline int fail(hb_ctx *ctx, int code, const char *msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+// nsub for a lazy dot product of length d whose inputs are < 2^(32*NW) and matrix entries < p:
+// REDC output < p * (1 + d * 2^(32 NW) / 2^(29 NL))
+inline int nsub_for(int d, int nl, int nw) {
+    int shift = 29 * nl - 32 * nw;  // 5 (wide) or 23 (narrow)
+    long per = 1L << shift;
+    long n = (d + per - 1) / per;
+    return n < 1 ? 1 : (int)n;
+}
+int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s);
+
+// dispatch on element width
+#define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \
+    do {                                                                                          \
+        if ((ctx)->n_limbs == 4) { EXPR_W; } else { EXPR_N; }                                     \
+    } while (0)
+
+}  // namespace hb

@@ -1,0 +1,157 @@
+/*
+ * hbmpc_hip.h -- C ABI of libhbmpc_hip.so: the MI355X (gfx950) implementation of
+ * HoneyBadgerMPC's batch share-reconstruction arithmetic.
+ *
+ * This is the drop-in boundary for the reference's NTL/Cython extension
+ * `honeybadgermpc.ntl` (reference: honeybadgermpc/ntl/hbmpc_ntl_helpers.pyx,
+ * re-exported by honeybadgermpc/ntl/__init__.py:1).  Each entry point names the
+ * reference interface it replaces.  The reference marshals Python ints to NTL ZZ_p
+ * through little-endian bytes (pyx:20-29); here a field element is the same
+ * little-endian integer in a fixed width:
+ *
+ *     4 x uint64_t (32 bytes) for a context created with n_limbs = 4 (p < 2^256)
+ *     1 x uint64_t ( 8 bytes) for a context created with n_limbs = 1 (p < 2^64)
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures.  `stream` is a
+ *     hipStream_t passed as void* (NULL = the default stream).
+ *   - `*_dev` pointers are DEVICE pointers owned by the caller (e.g. a torch tensor's
+ *     data_ptr()); everything else (points x, exponents zs, omega, the modulus) is a
+ *     small HOST array copied at call time.
+ *   - all element values are canonical residues in [0, p) on output; inputs may be any
+ *     value < 2^(64*n_limbs) ("reduced on entry", pyx:31-32).
+ *   - every function returns an hb_status; nothing throws or aborts.  Work is enqueued
+ *     on `stream`; functions that must report a data-dependent result (singular matrix,
+ *     validation mismatch) synchronise that stream before returning and say so below.
+ *   - a context is bound to one device; one process per GPU is the intended use.
+ */
+#ifndef HBMPC_HIP_H
+#define HBMPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    HB_OK = 0,
+    HB_ERR_SINGULAR = 1,     /* Vandermonde matrix not invertible / repeated point -> InterpolationError (pyx:167-169) */
+    HB_ERR_BAD_ARG = 2,      /* ValueError-class problems (pyx:44,62) */
+    HB_ERR_UNSUPPORTED = 3,  /* even modulus, size beyond a kernel's limits */
+    HB_ERR_NO_DEVICE = 4,    /* no usable gfx950 device: the product path fails loudly, there is no CPU fallback */
+    HB_ERR_HIP = 5,          /* a HIP runtime call failed; see hb_last_error() */
+    HB_ERR_MISMATCH = 6      /* hb_batch_open: re-encoded guess disagrees with a received column (reed_solomon.py:316-326) */
+} hb_status;
+
+typedef struct hb_ctx hb_ctx;        /* modulus + Montgomery constants + device + table cache */
+typedef struct hb_matrix hb_matrix;  /* a device-resident n_out x n_in matrix over GF(p) in kernel layout */
+
+/* element layout selector for batched buffers: element (c, l) of a C x L batch lives at
+ * base + (c*stride_c + l*stride_l) elements.  Chunk-major [C][L] is {L, 1}; party-major /
+ * coefficient-major [L][C] is {1, C} (the layout R1/R2 messages travel in,
+ * batch_reconstruction.py:165-167). */
+typedef struct {
+    int64_t stride_c;
+    int64_t stride_l;
+} hb_view;
+
+/* ---- library / context ------------------------------------------------------------ */
+int hb_version(void);
+int hb_device_count(void);
+/* Replaces ZZ_p::init(modulus) at the top of every pyx entry point (pyx:107,220,250,...). */
+int hb_ctx_create(hb_ctx **out, const uint64_t *p_limbs, int n_limbs, int device);
+void hb_ctx_destroy(hb_ctx *ctx);
+const char *hb_last_error(const hb_ctx *ctx);
+int hb_elem_bytes(const hb_ctx *ctx);
+
+/* device-memory helpers for callers that have no allocator of their own */
+int hb_malloc(hb_ctx *ctx, void **dptr, size_t bytes);
+int hb_free(hb_ctx *ctx, void *dptr);
+int hb_memcpy_h2d(hb_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int hb_memcpy_d2h(hb_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int hb_stream_sync(hb_ctx *ctx, void *stream);
+
+/* ---- tables ------------------------------------------------------------------------ */
+/* V[i][l] = x_i^l, n x d.  Replaces set_vm_matrix (rsdecode_impl.h:23-36). */
+int hb_vand_matrix_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, hb_matrix **out, void *stream);
+/* V(x)^-1, k x k.  Replaces vandermonde_inverse (rsdecode_impl.h:97-122).  Synchronises;
+ * returns HB_ERR_SINGULAR when two points coincide mod p. */
+int hb_vand_inverse_create(hb_ctx *ctx, const uint64_t *x_host, int k, hb_matrix **out, void *stream);
+/* arbitrary matrix from host canonical elements, row-major n_out x n_in */
+int hb_matrix_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, hb_matrix **out, void *stream);
+/* copy a matrix back to host canonical row-major (testing / vandermonde_inverse's legacy dump, pyx:115-132) */
+int hb_matrix_to_host(hb_ctx *ctx, const hb_matrix *m, uint64_t *m_host, void *stream);
+void hb_matrix_destroy(hb_matrix *m);
+
+/* ---- the hot kernel: batched mat-vec over GF(p) ---------------------------------------
+ * out(c, i) = sum_l M[i][l] * in(c, in_rows ? in_rows[l] : l)     c < C, i < n_out
+ * Replaces NTL mat_ZZ_p mul at pyx:183 and pyx:237.  in_rows (host, n_in ints or NULL)
+ * selects which rows of a party-major buffer feed the product (the arrival set z of
+ * IncrementalDecoder, reed_solomon.py:305-313). */
+int hb_matvec(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_view in, const int32_t *in_rows,
+              uint64_t *out_dev, hb_view out, int64_t C, void *stream);
+/* Same product, but instead of storing, compare row i (for every i in check_rows[0..n_check))
+ * with expect(c, i) and OR 1 into *mismatch_dev on any difference.  Replaces the Python
+ * loop reed_solomon.py:316-319.  Asynchronous. */
+int hb_matvec_check(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_view in, const int32_t *in_rows,
+                    const uint64_t *expect_dev, hb_view expect, const int32_t *check_rows, int n_check,
+                    int32_t *mismatch_dev, int64_t C, void *stream);
+
+/* ---- reference-shaped entry points (chunk-major buffers, tables cached in ctx) -------- */
+/* vandermonde_batch_evaluate (pyx:199-244): polys_dev [C][d] -> out_dev [C][n] */
+int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_t *polys_dev,
+                                  int64_t C, int d, uint64_t *out_dev, void *stream);
+/* vandermonde_batch_interpolate (pyx:139-197): data_dev [C][k] -> out_dev [C][k]; HB_ERR_SINGULAR */
+int hb_vandermonde_batch_interpolate(hb_ctx *ctx, const uint64_t *x_host, int k, const uint64_t *data_dev,
+                                     int64_t C, uint64_t *out_dev, void *stream);
+/* fft / partial_fft / fft_batch_evaluate (pyx:246-316, rsdecode_impl.h:125-192):
+ * coeffs_dev [C][d] -> out_dev [C][k], out[c][i] = sum_{j<min(d,order)} coeffs[c][j] * omega^(i*j), i < k <= order */
+int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, const uint64_t *coeffs_dev,
+                          int64_t C, int d, int k, uint64_t *out_dev, void *stream);
+/* fft_interpolate / fft_batch_interpolate (pyx:318-381, rsdecode_impl.h:194-265):
+ * ys_dev [C][k] at points omega^zs[i] -> out_dev [C][k].  HB_ERR_SINGULAR for repeated zs. */
+int hb_fft_batch_interpolate(hb_ctx *ctx, const uint64_t *omega_host, int order, const int32_t *zs_host, int k,
+                             const uint64_t *ys_dev, int64_t C, uint64_t *out_dev, void *stream);
+/* gao_interpolate, batched over C codewords sharing the same points (pyx:389-439,
+ * rsdecode_impl.h:281-405).  ys_dev [C][npts]; coeffs_dev [C][k]; errloc_dev [C][npts+1]
+ * (un-normalised EEA cofactor, errloc_len_dev[c] = deg+1); ok_dev[c] = 1 on success. */
+int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const uint64_t *ys_dev, int64_t C,
+                  uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream);
+/* Welch-Berlekamp (reed_solomon_wb.py:129-151), batched.  ys_dev [C][n], present_dev [C][n]
+ * (0 = erasure).  coeffs_dev [C][k] zero padded, coeff_len_dev[c] = length after stripping
+ * trailing zeros (polynomial.py:14-20), status_dev[c]: 0 ok, 1 "found no divisors!",
+ * 2 "No solution", 3 too few points. */
+int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, const uint64_t *ys_dev,
+                 const uint8_t *present_dev, int64_t C, uint64_t *coeffs_dev, int32_t *coeff_len_dev,
+                 int32_t *status_dev, void *stream);
+
+/* ---- one party's fault-free batch open -------------------------------------------------
+ * The compute of batch_reconstruct (batch_reconstruction.py:158-227) for one party when no
+ * received column is wrong: R1 encode; R1 optimistic decode + validating re-encode + compare
+ * (reed_solomon.py:305-330); constant terms -> R2 message; R2 decode + re-encode + compare;
+ * flatten.  3 batch encodes + 2 batch decodes, all on device.
+ *   plan: created once per (points, arrival set); shares_dev [B]; r1_out_dev [n][C] party-major;
+ *   r1_cols_dev / r2_cols_dev [n][C] party-major received columns; r2_msg_dev [C];
+ *   result_dev [B].  C = ceil(B / d).
+ * hb_open_run is asynchronous; hb_open_status synchronises and returns HB_OK or HB_ERR_MISMATCH. */
+typedef struct hb_open_plan hb_open_plan;
+int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const uint64_t *x_host,
+                        const uint64_t *omega_host, int order, const int32_t *z_host /* d arrivals used to decode */,
+                        const int32_t *zc_host /* later arrivals to validate */, int n_check, int64_t max_B,
+                        hb_open_plan **out, void *stream);
+int hb_open_r1_encode(hb_open_plan *plan, const uint64_t *shares_dev, int64_t B, uint64_t *r1_out_dev, void *stream);
+int hb_open_r1_decode(hb_open_plan *plan, const uint64_t *r1_cols_dev, int64_t B, uint64_t *r2_msg_dev, void *stream);
+int hb_open_r2_decode(hb_open_plan *plan, const uint64_t *r2_cols_dev, int64_t B, uint64_t *result_dev, void *stream);
+int hb_open_status(hb_open_plan *plan, void *stream);
+void hb_open_plan_destroy(hb_open_plan *plan);
+
+/* host-side self test of the radix-2^29 arithmetic templates (no GPU needed):
+ * out = a*b mod p computed with the same code the kernels use. */
+int hb_selftest_mulmod(const uint64_t *p_limbs, int n_limbs, const uint64_t *a, const uint64_t *b, uint64_t *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBMPC_HIP_H */

@@ -1,0 +1,830 @@
+/*
+ * hbmpc_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C CPU restatement of the algorithms on HoneyBadgerMPC's batch
+ * share-reconstruction hot path.  It exists only so that tests/, smoke() and
+ * bench.py's cpu_baseline leg have something to check / time the HIP path
+ * against.  Nothing under honeybadgermpc_amd/ may import, link or call it.
+ *
+ * What it restates (reference paths are relative to /root/reference):
+ *   honeybadgermpc/ntl/rsdecode_impl.h       (set_vm_matrix, vandermonde_inverse,
+ *                                             _fft, fft, fnt_decode_step1/2,
+ *                                             partial_gcd, gao_interpolate[_fft])
+ *   honeybadgermpc/ntl/hbmpc_ntl_helpers.pyx (argument conventions, padding,
+ *                                             truncation, batch loops)
+ *   honeybadgermpc/reed_solomon_wb.py        (Welch-Berlekamp: system, rref,
+ *                                             some_solution, exact division)
+ *
+ * The reference's arithmetic lives in NTL + GMP, which are NOT vendored under
+ * /root/reference (linked with -lntl -lgmp, setup.py:76-86; version pinned only
+ * by a docker image digest, Dockerfile:1-3) and not installed in this image.
+ * The NTL primitives the reference calls (ZZ_p add/sub/mul/inv/power,
+ * mat_ZZ_p mul/inv, ZZ_pX BuildFromRoots/interpolate/MulTrunc/DivRem/eval,
+ * SqrRootMod) are restated here from their published semantics.  Every value
+ * that crosses the reference's boundary is a canonical residue in [0,p), so
+ * those results are algorithm-independent; the places where the *algorithm*
+ * shows through (Gao's un-normalised EEA cofactor, WB's descending-e loop,
+ * trimming rules) follow the reference source line by line.
+ *
+ * Pinning: tests/test_oracle_golden.py checks this file against (i) every
+ * known-answer vector in the reference's tests for this path
+ * (tests/test_ntl.py, test_reed_solomon.py, test_reed_solomon_wb.py,
+ * test_batch_reconstruction.py, fixtures.py roots of unity) and (ii) golden
+ * vectors produced by importing the reference's pure-Python layers
+ * (polynomial.py, reed_solomon_wb.py, field.py) in the build container --
+ * see oracle/gen_golden.py.
+ *
+ * Element format at this API: canonical residues, 4 x uint64 little-endian
+ * limbs (32 bytes), any odd modulus p < 2^256.  Internally Montgomery, R=2^256.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+typedef struct { u64 l[4]; } fe;
+
+typedef struct {
+    u64 p[4];
+    u64 n0;      /* -p^{-1} mod 2^64 */
+    fe r1;       /* R mod p  (Montgomery one) */
+    fe r2;       /* R^2 mod p */
+} field_t;
+
+static int g_threads = 1;
+
+/* ------------------------------------------------------------------ */
+/* multi-precision helpers                                             */
+/* ------------------------------------------------------------------ */
+static inline int ge4(const u64 a[4], const u64 b[4]) {
+    for (int i = 3; i >= 0; i--) { if (a[i] != b[i]) return a[i] > b[i]; }
+    return 1;
+}
+static inline u64 add4(u64 r[4], const u64 a[4], const u64 b[4]) {
+    u128 c = 0;
+    for (int i = 0; i < 4; i++) { c += (u128)a[i] + b[i]; r[i] = (u64)c; c >>= 64; }
+    return (u64)c;
+}
+static inline u64 sub4(u64 r[4], const u64 a[4], const u64 b[4]) {
+    u64 borrow = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 d = (u128)a[i] - b[i] - borrow;
+        r[i] = (u64)d; borrow = (u64)(d >> 64) & 1;
+    }
+    return borrow;
+}
+static inline int is_zero(const fe *a) { return (a->l[0] | a->l[1] | a->l[2] | a->l[3]) == 0; }
+static inline int fe_eq(const fe *a, const fe *b) { return memcmp(a, b, sizeof(fe)) == 0; }
+
+static inline void fe_add(const field_t *F, fe *r, const fe *a, const fe *b) {
+    u64 t[4]; u64 c = add4(t, a->l, b->l);
+    if (c || ge4(t, F->p)) sub4(t, t, F->p);
+    memcpy(r->l, t, 32);
+}
+static inline void fe_sub(const field_t *F, fe *r, const fe *a, const fe *b) {
+    u64 t[4]; if (sub4(t, a->l, b->l)) add4(t, t, F->p);
+    memcpy(r->l, t, 32);
+}
+static inline void fe_neg(const field_t *F, fe *r, const fe *a) {
+    if (is_zero(a)) { memset(r, 0, 32); return; }
+    u64 t[4]; sub4(t, F->p, a->l); memcpy(r->l, t, 32);
+}
+/* Montgomery product a*b/R mod p (CIOS, 4 x 64-bit limbs). */
+static inline void fe_mul(const field_t *F, fe *r, const fe *a, const fe *b) {
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a->l[j] * b->l[i] + t[j]; t[j] = (u64)c; c >>= 64; }
+        c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
+        u64 m = t[0] * F->n0;
+        c = (u128)m * F->p[0] + t[0]; c >>= 64;
+        for (int j = 1; j < 4; j++) { c += (u128)m * F->p[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
+        c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
+    }
+    if (t[4] || ge4(t, F->p)) sub4(t, t, F->p);
+    memcpy(r->l, t, 32);
+}
+static inline void to_mont(const field_t *F, fe *r, const fe *a) { fe_mul(F, r, a, &F->r2); }
+static inline void from_mont(const field_t *F, fe *r, const fe *a) {
+    fe one = {{1, 0, 0, 0}}; fe_mul(F, r, a, &one);
+}
+/* a^e for a 256-bit exponent e (Montgomery in/out) */
+static void fe_pow(const field_t *F, fe *r, const fe *a, const u64 e[4]) {
+    fe acc = F->r1, base = *a;
+    for (int i = 0; i < 256; i++) {
+        if ((e[i >> 6] >> (i & 63)) & 1) fe_mul(F, &acc, &acc, &base);
+        fe_mul(F, &base, &base, &base);
+    }
+    *r = acc;
+}
+static void fe_pow_u64(const field_t *F, fe *r, const fe *a, u64 e) {
+    u64 ee[4] = {e, 0, 0, 0}; fe_pow(F, r, a, ee);
+}
+/* inverse by Fermat (p prime).  NTL's inv() uses an XGCD; the value is the same. */
+static int fe_inv(const field_t *F, fe *r, const fe *a) {
+    if (is_zero(a)) return 1;
+    u64 e[4]; u64 two[4] = {2, 0, 0, 0}; sub4(e, F->p, two);
+    fe_pow(F, r, a, e);
+    return 0;
+}
+static void fe_from_u64(const field_t *F, fe *r, u64 v) {
+    fe t = {{v, 0, 0, 0}};
+    if (F->p[1] == 0 && F->p[2] == 0 && F->p[3] == 0) t.l[0] = v % F->p[0];
+    to_mont(F, r, &t);
+}
+
+static int field_init(field_t *F, const u64 p[4]) {
+    if ((p[0] & 1) == 0) return 1;                       /* Montgomery needs odd p */
+    if (p[1] == 0 && p[2] == 0 && p[3] == 0 && p[0] < 3) return 1;
+    memcpy(F->p, p, 32);
+    u64 inv = 1;                                         /* Newton: inv = p^{-1} mod 2^64 */
+    for (int i = 0; i < 6; i++) inv *= 2 - p[0] * inv;
+    F->n0 = (u64)0 - inv;
+    /* R mod p and R^2 mod p by repeated doubling */
+    u64 t[4] = {1, 0, 0, 0};
+    if (ge4(t, F->p)) sub4(t, t, F->p);
+    fe one = {{t[0], t[1], t[2], t[3]}};
+    fe acc = one;
+    for (int i = 0; i < 512; i++) {
+        fe_add(F, &acc, &acc, &acc);
+        if (i == 255) F->r1 = acc;
+    }
+    F->r2 = acc;
+    return 0;
+}
+/* reduce an arbitrary 256-bit value mod p (inputs are "reduced on entry", pyx:31-32) */
+static void fe_reduce_in(const field_t *F, fe *r, const u64 a[4]) {
+    fe t; memcpy(t.l, a, 32);
+    if (!ge4(t.l, F->p)) { *r = t; return; }
+    /* rare path: a >= p.  a mod p = from_mont(to_mont(a)) works for any a < 2^256
+       because Montgomery multiplication only needs one operand < p. */
+    fe m; fe_mul(F, &m, &t, &F->r2); from_mont(F, r, &m);
+}
+static void load_mont(const field_t *F, fe *dst, const u64 *src, long count) {
+    for (long i = 0; i < count; i++) { fe t; fe_reduce_in(F, &t, src + 4 * i); to_mont(F, &dst[i], &t); }
+}
+static void store_canon(const field_t *F, u64 *dst, const fe *src, long count) {
+    for (long i = 0; i < count; i++) { fe t; from_mont(F, &t, &src[i]); memcpy(dst + 4 * i, t.l, 32); }
+}
+
+/* ------------------------------------------------------------------ */
+/* polynomials (Montgomery coefficients, explicit degree)              */
+/* ------------------------------------------------------------------ */
+typedef struct { fe *c; int deg; int cap; } poly;   /* deg = -1 for the zero polynomial */
+
+static void poly_init(poly *P, int cap) { P->c = (fe *)calloc((size_t)(cap > 0 ? cap : 1), sizeof(fe)); P->deg = -1; P->cap = cap > 0 ? cap : 1; }
+static void poly_free(poly *P) { free(P->c); P->c = NULL; }
+static void poly_reserve(poly *P, int cap) {
+    if (cap <= P->cap) return;
+    P->c = (fe *)realloc(P->c, (size_t)cap * sizeof(fe));
+    memset(P->c + P->cap, 0, (size_t)(cap - P->cap) * sizeof(fe));
+    P->cap = cap;
+}
+static void poly_norm(poly *P) { while (P->deg >= 0 && is_zero(&P->c[P->deg])) P->deg--; }
+static void poly_copy(poly *D, const poly *S) {
+    poly_reserve(D, S->deg + 1);
+    memset(D->c, 0, (size_t)D->cap * sizeof(fe));
+    if (S->deg >= 0) memcpy(D->c, S->c, (size_t)(S->deg + 1) * sizeof(fe));
+    D->deg = S->deg;
+}
+static void poly_swap(poly *A, poly *B) { poly t = *A; *A = *B; *B = t; }
+static void poly_set_const(const field_t *F, poly *P, int one) {
+    memset(P->c, 0, (size_t)P->cap * sizeof(fe));
+    if (one) { P->c[0] = F->r1; P->deg = 0; } else P->deg = -1;
+}
+/* NTL BuildFromRoots: A = prod (X - x_i)  (rsdecode_impl.h:207,330,372) */
+static void poly_from_roots(const field_t *F, poly *A, const fe *xs, int k) {
+    poly_reserve(A, k + 1);
+    memset(A->c, 0, (size_t)A->cap * sizeof(fe));
+    A->c[0] = F->r1; A->deg = 0;
+    for (int i = 0; i < k; i++) {
+        /* A <- A * (X - x_i) */
+        for (int j = A->deg + 1; j >= 1; j--) {
+            fe t; fe_mul(F, &t, &A->c[j], &xs[i]);           /* c[j] currently old c[j] (0 for top) */
+            fe_sub(F, &A->c[j], &A->c[j - 1], &t);
+        }
+        fe t; fe_mul(F, &t, &A->c[0], &xs[i]); fe_neg(F, &A->c[0], &t);
+        A->deg++;
+    }
+}
+/* NTL DivRem: a = q*b + r, deg r < deg b.  b must be non-zero. */
+static void poly_divrem(const field_t *F, poly *q, poly *r, const poly *a, const poly *b) {
+    poly_copy(r, a);
+    int dq = a->deg - b->deg;
+    poly_reserve(q, dq >= 0 ? dq + 1 : 1);
+    memset(q->c, 0, (size_t)q->cap * sizeof(fe));
+    q->deg = -1;
+    if (dq < 0) return;
+    fe lcinv; fe_inv(F, &lcinv, &b->c[b->deg]);
+    for (int i = dq; i >= 0; i--) {
+        fe coef; fe_mul(F, &coef, &r->c[i + b->deg], &lcinv);
+        q->c[i] = coef;
+        if (!is_zero(&coef)) {
+            for (int j = 0; j <= b->deg; j++) {
+                fe t; fe_mul(F, &t, &coef, &b->c[j]);
+                fe_sub(F, &r->c[i + j], &r->c[i + j], &t);
+            }
+        }
+    }
+    q->deg = dq; poly_norm(q);
+    r->deg = b->deg - 1; if (r->deg > a->deg) r->deg = a->deg;
+    poly_norm(r);
+}
+/* D = A - Q*B */
+static void poly_submul(const field_t *F, poly *D, const poly *A, const poly *Q, const poly *B) {
+    int dm = (Q->deg >= 0 && B->deg >= 0) ? Q->deg + B->deg : -1;
+    int dd = A->deg > dm ? A->deg : dm;
+    poly_reserve(D, dd + 1);
+    memset(D->c, 0, (size_t)D->cap * sizeof(fe));
+    for (int i = 0; i <= A->deg; i++) D->c[i] = A->c[i];
+    for (int i = 0; i <= Q->deg; i++)
+        for (int j = 0; j <= B->deg; j++) {
+            fe t; fe_mul(F, &t, &Q->c[i], &B->c[j]);
+            fe_sub(F, &D->c[i + j], &D->c[i + j], &t);
+        }
+    D->deg = dd; poly_norm(D);
+}
+/* NTL eval: Horner (pyx:101-113) */
+static void poly_eval(const field_t *F, fe *y, const fe *c, int len, const fe *x) {
+    fe acc; memset(&acc, 0, sizeof acc);
+    for (int i = len - 1; i >= 0; i--) { fe_mul(F, &acc, &acc, x); fe_add(F, &acc, &acc, &c[i]); }
+    *y = acc;
+}
+/* NTL interpolate(P, x, y): unique P, deg < n, P(x_i) = y_i.  Newton form.
+   returns 1 if two x coincide (NTL raises an error there -- unpinned). */
+static int poly_interpolate(const field_t *F, poly *P, const fe *x, const fe *y, int n) {
+    poly_reserve(P, n > 0 ? n : 1);
+    memset(P->c, 0, (size_t)P->cap * sizeof(fe));
+    P->deg = -1;
+    if (n == 0) return 0;
+    /* basis = prod_{j<i}(X - x_j), kept explicitly */
+    fe *basis = (fe *)calloc((size_t)n + 1, sizeof(fe));
+    basis[0] = F->r1; int bdeg = 0;
+    for (int i = 0; i < n; i++) {
+        fe pv, bv, diff, binv, coef;
+        poly_eval(F, &pv, P->c, i, &x[i]);
+        poly_eval(F, &bv, basis, bdeg + 1, &x[i]);
+        if (fe_inv(F, &binv, &bv)) { free(basis); return 1; }
+        fe_sub(F, &diff, &y[i], &pv);
+        fe_mul(F, &coef, &diff, &binv);
+        for (int j = 0; j <= bdeg; j++) { fe t; fe_mul(F, &t, &coef, &basis[j]); fe_add(F, &P->c[j], &P->c[j], &t); }
+        /* basis *= (X - x_i) */
+        for (int j = bdeg + 1; j >= 1; j--) { fe t; fe_mul(F, &t, &basis[j], &x[i]); fe_sub(F, &basis[j], &basis[j - 1], &t); }
+        { fe t; fe_mul(F, &t, &basis[0], &x[i]); fe_neg(F, &basis[0], &t); }
+        bdeg++;
+    }
+    free(basis);
+    P->deg = n - 1; poly_norm(P);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* rsdecode_impl.h restated                                            */
+/* ------------------------------------------------------------------ */
+
+/* set_vm_matrix (rsdecode_impl.h:23-36): result[i][j] = x_i^j, n x d row-major */
+static void set_vm_matrix(const field_t *F, fe *result, const fe *x, int n, int d) {
+    for (int i = 0; i < n; i++) {
+        fe xp = F->r1;
+        for (int j = 0; j < d; j++) { result[(size_t)i * d + j] = xp; fe_mul(F, &xp, &xp, &x[i]); }
+    }
+}
+/* NTL inv(det, X, A) for mat_ZZ_p: Gauss-Jordan; returns 1 when det == 0
+   (vandermonde_inverse, rsdecode_impl.h:97-122) */
+static int mat_inverse(const field_t *F, fe *inv, fe *m, int n) {
+    memset(inv, 0, (size_t)n * n * sizeof(fe));
+    for (int i = 0; i < n; i++) inv[(size_t)i * n + i] = F->r1;
+    for (int col = 0; col < n; col++) {
+        int piv = -1;
+        for (int r = col; r < n; r++) if (!is_zero(&m[(size_t)r * n + col])) { piv = r; break; }
+        if (piv < 0) return 1;
+        if (piv != col) for (int j = 0; j < n; j++) {
+            fe t = m[(size_t)col * n + j]; m[(size_t)col * n + j] = m[(size_t)piv * n + j]; m[(size_t)piv * n + j] = t;
+            t = inv[(size_t)col * n + j]; inv[(size_t)col * n + j] = inv[(size_t)piv * n + j]; inv[(size_t)piv * n + j] = t;
+        }
+        fe pinv; fe_inv(F, &pinv, &m[(size_t)col * n + col]);
+        for (int j = 0; j < n; j++) {
+            fe_mul(F, &m[(size_t)col * n + j], &m[(size_t)col * n + j], &pinv);
+            fe_mul(F, &inv[(size_t)col * n + j], &inv[(size_t)col * n + j], &pinv);
+        }
+        for (int r = 0; r < n; r++) {
+            if (r == col) continue;
+            fe f = m[(size_t)r * n + col];
+            if (is_zero(&f)) continue;
+            for (int j = 0; j < n; j++) {
+                fe t; fe_mul(F, &t, &f, &m[(size_t)col * n + j]); fe_sub(F, &m[(size_t)r * n + j], &m[(size_t)r * n + j], &t);
+                fe_mul(F, &t, &f, &inv[(size_t)col * n + j]); fe_sub(F, &inv[(size_t)r * n + j], &inv[(size_t)r * n + j], &t);
+            }
+        }
+    }
+    return 0;
+}
+/* mat_ZZ_p mul restricted to what the path uses: OUT[c][i] = sum_l M[i][l] * IN[c][l]
+   (pyx:183,237 compute M * IN^T and read it back transposed; same numbers).
+   NTL parallelises this product internally; here OpenMP over the batch. */
+static void matvec_batch(const field_t *F, fe *out, const fe *M, int rows, int cols, const fe *in, long C) {
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (long c = 0; c < C; c++) {
+        const fe *v = in + (size_t)c * cols;
+        for (int i = 0; i < rows; i++) {
+            fe acc; memset(&acc, 0, sizeof acc);
+            const fe *mr = M + (size_t)i * cols;
+            for (int l = 0; l < cols; l++) { fe t; fe_mul(F, &t, &mr[l], &v[l]); fe_add(F, &acc, &acc, &t); }
+            out[(size_t)c * rows + i] = acc;
+        }
+    }
+}
+
+#define FFT_VAN_THRESHOLD 16   /* rsdecode_impl.h:16 */
+
+/* _fft (rsdecode_impl.h:125-169).  a has n entries; only indices < m are
+   guaranteed on return, exactly as in the reference. */
+static void fft_rec(const field_t *F, fe *a, const fe *omega, int n, int m, const fe *van, int van_threshold) {
+    if (m == -1) m = n;
+    if (n == 1) return;
+    if (van != NULL && van_threshold == n) {             /* mul(a, *van_matrix, a) */
+        fe tmp[FFT_VAN_THRESHOLD];
+        for (int i = 0; i < n; i++) {
+            fe acc; memset(&acc, 0, sizeof acc);
+            for (int j = 0; j < n; j++) { fe t; fe_mul(F, &t, &van[i * n + j], &a[j]); fe_add(F, &acc, &acc, &t); }
+            tmp[i] = acc;
+        }
+        memcpy(a, tmp, (size_t)n * sizeof(fe));
+        return;
+    }
+    int h = n / 2;
+    fe *a0 = (fe *)malloc((size_t)h * sizeof(fe)), *a1 = (fe *)malloc((size_t)h * sizeof(fe));
+    for (int k = 0; k < h; k++) { a0[k] = a[2 * k]; a1[k] = a[2 * k + 1]; }
+    fe omega2; fe_mul(F, &omega2, omega, omega);
+    fft_rec(F, a0, &omega2, h, m, van, van_threshold);
+    fft_rec(F, a1, &omega2, h, m, van, van_threshold);
+    fe w = F->r1;
+    for (int k = 0; k < h; k++) {
+        fe t2; fe_mul(F, &t2, &w, &a1[k]);
+        if (k < m) fe_add(F, &a[k], &a0[k], &t2);
+        if (k + h < m) fe_sub(F, &a[k + h], &a0[k], &t2);
+        fe_mul(F, &w, &w, omega);
+    }
+    free(a0); free(a1);
+}
+/* fft (rsdecode_impl.h:171-192): coefficients truncated to n / zero padded,
+   16-point Vandermonde base case when n >= 16, first k outputs (k=-1: all). */
+static void fft_top(const field_t *F, fe *out, const fe *coeffs, int ncoeffs, const fe *omega, int n, int k) {
+    fe *a = (fe *)calloc((size_t)n, sizeof(fe));
+    for (int i = 0; i < ncoeffs && i < n; i++) a[i] = coeffs[i];
+    fe *van = NULL; fe vanbuf[FFT_VAN_THRESHOLD * FFT_VAN_THRESHOLD];
+    if (n >= FFT_VAN_THRESHOLD) {
+        fe omega_pow; fe_pow_u64(F, &omega_pow, omega, (u64)(n / FFT_VAN_THRESHOLD));
+        fe x[FFT_VAN_THRESHOLD]; x[0] = F->r1;
+        for (int i = 1; i < FFT_VAN_THRESHOLD; i++) fe_mul(F, &x[i], &x[i - 1], &omega_pow);   /* h:38-50 */
+        set_vm_matrix(F, vanbuf, x, FFT_VAN_THRESHOLD, FFT_VAN_THRESHOLD);
+        van = vanbuf;
+    }
+    fft_rec(F, a, omega, n, k, van, FFT_VAN_THRESHOLD);
+    int cnt = (k == -1) ? n : k;
+    memcpy(out, a, (size_t)cnt * sizeof(fe));
+    free(a);
+}
+
+typedef struct { poly A; fe *ad_evals; int k; } fnt_step1_t;
+
+/* fnt_decode_step1 (rsdecode_impl.h:194-224) */
+static int fnt_decode_step1(const field_t *F, fnt_step1_t *S, const int *zs, int k, const fe *omega, int n) {
+    fe *xs = (fe *)malloc((size_t)(k > 0 ? k : 1) * sizeof(fe));
+    for (int i = 0; i < k; i++) fe_pow_u64(F, &xs[i], omega, (u64)zs[i]);
+    poly_init(&S->A, k + 1);
+    poly_from_roots(F, &S->A, xs, k);
+    int d = S->A.deg;
+    fe *adc = (fe *)calloc((size_t)(d > 0 ? d : 1), sizeof(fe));
+    for (int i = 0; i < d; i++) { fe ip1; fe_from_u64(F, &ip1, (u64)(i + 1)); fe_mul(F, &adc[i], &ip1, &S->A.c[i + 1]); }
+    fe *all = (fe *)malloc((size_t)n * sizeof(fe));
+    fft_top(F, all, adc, d, omega, n, -1);
+    S->ad_evals = (fe *)malloc((size_t)(k > 0 ? k : 1) * sizeof(fe));
+    S->k = k;
+    int bad = 0;
+    for (int i = 0; i < k; i++) if (fe_inv(F, &S->ad_evals[i], &all[zs[i]])) bad = 1;   /* repeated z */
+    free(xs); free(adc); free(all);
+    return bad;
+}
+/* fnt_decode_step2 (rsdecode_impl.h:226-265) */
+static void fnt_decode_step2(const field_t *F, fe *P_coeffs, const fnt_step1_t *S, const int *zs, const fe *ys, const fe *omega, int n) {
+    int k = S->k;
+    fe *ncoef = (fe *)calloc((size_t)n, sizeof(fe));
+    for (int i = 0; i < k; i++) fe_mul(F, &ncoef[zs[i]], &ys[i], &S->ad_evals[i]);
+    fe omega_inv; fe_inv(F, &omega_inv, omega);
+    int kk = (k < n) ? k + 1 : n;
+    fe *nrev = (fe *)malloc((size_t)kk * sizeof(fe));
+    fft_top(F, nrev, ncoef, n, &omega_inv, n, kk);
+    fe *Q = (fe *)malloc((size_t)(k > 0 ? k : 1) * sizeof(fe));
+    for (int i = 0; i < k; i++) fe_neg(F, &Q[i], &nrev[(i + 1) % n]);
+    /* MulTrunc(P, Q, A, k) */
+    for (int i = 0; i < k; i++) {
+        fe acc; memset(&acc, 0, sizeof acc);
+        for (int j = 0; j <= i; j++) {
+            if (i - j > S->A.deg) continue;
+            fe t; fe_mul(F, &t, &Q[j], &S->A.c[i - j]); fe_add(F, &acc, &acc, &t);
+        }
+        P_coeffs[i] = acc;
+    }
+    free(ncoef); free(nrev); free(Q);
+}
+static void fnt_step1_free(fnt_step1_t *S) { poly_free(&S->A); free(S->ad_evals); }
+
+/* partial_gcd (rsdecode_impl.h:281-323): only (r, v=t) are consumed by callers */
+static void partial_gcd(const field_t *F, poly *r, poly *v, const poly *p0, const poly *p1, int threshold) {
+    int cap = p0->deg + 2;
+    poly r0, r1, r2, t0, t1, t2, q;
+    poly_init(&r0, cap); poly_init(&r1, cap); poly_init(&r2, cap);
+    poly_init(&t0, cap); poly_init(&t1, cap); poly_init(&t2, cap); poly_init(&q, cap);
+    poly_copy(&r0, p0); poly_copy(&r1, p1);
+    poly_set_const(F, &t0, 0); poly_set_const(F, &t1, 1);
+    if (r0.deg < threshold) { poly_copy(r, &r0); poly_copy(v, &t0); goto done; }
+    if (r1.deg < threshold) { poly_copy(r, &r1); poly_copy(v, &t1); goto done; }
+    for (;;) {
+        poly_divrem(F, &q, &r2, &r0, &r1);
+        poly_submul(F, &t2, &t0, &q, &t1);
+        if (r2.deg < threshold) { poly_copy(r, &r2); poly_copy(v, &t2); goto done; }
+        poly_swap(&r0, &r1); poly_swap(&r1, &r2);
+        poly_swap(&t0, &t1); poly_swap(&t1, &t2);
+    }
+done:
+    poly_free(&r0); poly_free(&r1); poly_free(&r2);
+    poly_free(&t0); poly_free(&t1); poly_free(&t2); poly_free(&q);
+}
+/* gao_interpolate / gao_interpolate_fft (rsdecode_impl.h:325-405).
+   res: k coeffs; err: up to n+1 coeffs, *err_len = deg(v)+1.  returns 1 on success. */
+static int gao_core(const field_t *F, fe *res, fe *err, int *err_len,
+                    const fe *x, const int *z, const fe *y, int k, int n,
+                    int use_fft, const fe *omega, int order) {
+    poly g0, g1, g, v, f1, r;
+    poly_init(&g0, n + 2); poly_init(&g1, n + 2); poly_init(&g, n + 2); poly_init(&v, n + 2);
+    poly_init(&f1, n + 2); poly_init(&r, n + 2);
+    int ok = 0;
+    poly_from_roots(F, &g0, x, n);
+    if (use_fft) {
+        fnt_step1_t S;
+        if (fnt_decode_step1(F, &S, z, n, omega, order)) { fnt_step1_free(&S); goto out; }
+        poly_reserve(&g1, n + 1);
+        fnt_decode_step2(F, g1.c, &S, z, y, omega, order);
+        g1.deg = n - 1; poly_norm(&g1);
+        fnt_step1_free(&S);
+    } else {
+        if (poly_interpolate(F, &g1, x, y, n)) goto out;
+    }
+    partial_gcd(F, &g, &v, &g0, &g1, (n + k) / 2);
+    if (v.deg < 0) goto out;
+    poly_divrem(F, &f1, &r, &g, &v);
+    if (r.deg >= 0 || f1.deg >= k) goto out;
+    for (int i = 0; i < k; i++) { if (i <= f1.deg) res[i] = f1.c[i]; else memset(&res[i], 0, sizeof(fe)); }
+    *err_len = v.deg + 1;
+    for (int i = 0; i <= v.deg; i++) err[i] = v.c[i];
+    ok = 1;
+out:
+    poly_free(&g0); poly_free(&g1); poly_free(&g); poly_free(&v); poly_free(&f1); poly_free(&r);
+    return ok;
+}
+
+/* ------------------------------------------------------------------ */
+/* exported API: canonical 4-limb elements in and out                  */
+/* ------------------------------------------------------------------ */
+#define API __attribute__((visibility("default")))
+
+API void orc_set_num_threads(int n) { g_threads = n > 0 ? n : 1; }
+API int orc_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* vandermonde_batch_evaluate (pyx:199-244): polys [C][d] -> out [C][n] */
+API int orc_vandermonde_batch_evaluate(const u64 *p, const u64 *x, int n, const u64 *polys, long C, int d, u64 *out) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe *xm = (fe *)malloc((size_t)(n > 0 ? n : 1) * sizeof(fe)); load_mont(&F, xm, x, n);
+    fe *V = (fe *)malloc((size_t)(n * d > 0 ? n * d : 1) * sizeof(fe)); set_vm_matrix(&F, V, xm, n, d);
+    fe *in = (fe *)malloc((size_t)(C * d > 0 ? C * d : 1) * sizeof(fe)); load_mont(&F, in, polys, C * d);
+    fe *o = (fe *)malloc((size_t)(C * n > 0 ? C * n : 1) * sizeof(fe));
+    matvec_batch(&F, o, V, n, d, in, C);
+    store_canon(&F, out, o, C * n);
+    free(xm); free(V); free(in); free(o);
+    return 0;
+}
+/* vandermonde_batch_interpolate (pyx:139-197): data [C][k] -> out [C][k]; 1 = singular */
+API int orc_vandermonde_batch_interpolate(const u64 *p, const u64 *x, int k, const u64 *data, long C, u64 *out) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe *xm = (fe *)malloc((size_t)(k > 0 ? k : 1) * sizeof(fe)); load_mont(&F, xm, x, k);
+    fe *V = (fe *)malloc((size_t)(k * k > 0 ? k * k : 1) * sizeof(fe)); set_vm_matrix(&F, V, xm, k, k);
+    fe *Vi = (fe *)malloc((size_t)(k * k > 0 ? k * k : 1) * sizeof(fe));
+    int sing = mat_inverse(&F, Vi, V, k);
+    if (!sing) {
+        fe *in = (fe *)malloc((size_t)(C * k > 0 ? C * k : 1) * sizeof(fe)); load_mont(&F, in, data, C * k);
+        fe *o = (fe *)malloc((size_t)(C * k > 0 ? C * k : 1) * sizeof(fe));
+        matvec_batch(&F, o, Vi, k, k, in, C);
+        store_canon(&F, out, o, C * k);
+        free(in); free(o);
+    }
+    free(xm); free(V); free(Vi);
+    return sing;
+}
+/* vandermonde_inverse (pyx:115-132): row-major k x k canonical; 1 = singular */
+API int orc_vandermonde_inverse(const u64 *p, const u64 *x, int k, u64 *out) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe *xm = (fe *)malloc((size_t)k * sizeof(fe)); load_mont(&F, xm, x, k);
+    fe *V = (fe *)malloc((size_t)k * k * sizeof(fe)); set_vm_matrix(&F, V, xm, k, k);
+    fe *Vi = (fe *)malloc((size_t)k * k * sizeof(fe));
+    int sing = mat_inverse(&F, Vi, V, k);
+    if (!sing) store_canon(&F, out, Vi, (long)k * k);
+    free(xm); free(V); free(Vi);
+    return sing;
+}
+/* fft / partial_fft / fft_batch_evaluate (pyx:246-316): coeffs [C][d] -> out [C][k] */
+API int orc_fft_batch_evaluate(const u64 *p, const u64 *omega, int n, const u64 *coeffs, long C, int d, int k, u64 *out) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe om; load_mont(&F, &om, omega, 1);
+    int err = 0;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (long c = 0; c < C; c++) {
+        fe *in = (fe *)malloc((size_t)(d > 0 ? d : 1) * sizeof(fe));
+        fe *o = (fe *)malloc((size_t)(k > 0 ? k : 1) * sizeof(fe));
+        load_mont(&F, in, coeffs + (size_t)c * d * 4, d);
+        fft_top(&F, o, in, d, &om, n, k);
+        store_canon(&F, out + (size_t)c * k * 4, o, k);
+        free(in); free(o);
+    }
+    return err;
+}
+/* fft_interpolate / fft_batch_interpolate (pyx:318-381): ys [C][k] -> out [C][k]; 1 = repeated z */
+API int orc_fft_batch_interpolate(const u64 *p, const u64 *omega, int n, const int *zs, int k, const u64 *ys, long C, u64 *out) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe om; load_mont(&F, &om, omega, 1);
+    fnt_step1_t S;
+    if (fnt_decode_step1(&F, &S, zs, k, &om, n)) { fnt_step1_free(&S); return 1; }
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (long c = 0; c < C; c++) {
+        fe *y = (fe *)malloc((size_t)(k > 0 ? k : 1) * sizeof(fe));
+        fe *o = (fe *)malloc((size_t)(k > 0 ? k : 1) * sizeof(fe));
+        load_mont(&F, y, ys + (size_t)c * k * 4, k);
+        fnt_decode_step2(&F, o, &S, zs, y, &om, n);
+        store_canon(&F, out + (size_t)c * k * 4, o, k);
+        free(y); free(o);
+    }
+    fnt_step1_free(&S);
+    return 0;
+}
+/* lagrange_interpolate (pyx:73-99, rsdecode_impl.h:67-90): *out_len = deg(P)+1 (trimmed) */
+API int orc_lagrange_interpolate(const u64 *p, const u64 *x, const u64 *y, int n, u64 *out, int *out_len) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe *xm = (fe *)malloc((size_t)(n > 0 ? n : 1) * sizeof(fe)), *ym = (fe *)malloc((size_t)(n > 0 ? n : 1) * sizeof(fe));
+    load_mont(&F, xm, x, n); load_mont(&F, ym, y, n);
+    poly P; poly_init(&P, n + 1);
+    int bad = poly_interpolate(&F, &P, xm, ym, n);
+    if (!bad) { *out_len = P.deg + 1; store_canon(&F, out, P.c, P.deg + 1); }
+    poly_free(&P); free(xm); free(ym);
+    return bad;
+}
+/* evaluate (pyx:101-113) */
+API int orc_evaluate(const u64 *p, const u64 *coeffs, int len, const u64 *x, u64 *out) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe *c = (fe *)malloc((size_t)(len > 0 ? len : 1) * sizeof(fe)); load_mont(&F, c, coeffs, len);
+    fe xm, y; load_mont(&F, &xm, x, 1);
+    poly_eval(&F, &y, c, len, &xm);
+    store_canon(&F, out, &y, 1);
+    free(c);
+    return 0;
+}
+/* gao_interpolate batch form (pyx:389-439 called once per codeword by
+   reed_solomon.py:160-186; here C codewords over the same x/z for timing and
+   batched parity).  ys [C][n]; res [C][k]; err [C][n+1]; err_len[C]; ok[C]. */
+API int orc_gao_interpolate(const u64 *p, const u64 *x, const int *z, int n, int k, const u64 *ys, long C,
+                            int use_fft, const u64 *omega, int order,
+                            u64 *res, u64 *err, int *err_len, unsigned char *ok) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe *xm = (fe *)malloc((size_t)(n > 0 ? n : 1) * sizeof(fe)); load_mont(&F, xm, x, n);
+    fe om; memset(&om, 0, sizeof om); if (use_fft) load_mont(&F, &om, omega, 1);
+#pragma omp parallel for schedule(dynamic, 4) num_threads(g_threads)
+    for (long c = 0; c < C; c++) {
+        fe *y = (fe *)malloc((size_t)(n > 0 ? n : 1) * sizeof(fe));
+        fe *r = (fe *)calloc((size_t)(k > 0 ? k : 1), sizeof(fe));
+        fe *e = (fe *)calloc((size_t)n + 2, sizeof(fe));
+        load_mont(&F, y, ys + (size_t)c * n * 4, n);
+        int el = 0;
+        int good = gao_core(&F, r, e, &el, xm, z, y, k, n, use_fft, &om, order);
+        ok[c] = (unsigned char)good;
+        err_len[c] = good ? el : 0;
+        if (good) {
+            store_canon(&F, res + (size_t)c * k * 4, r, k);
+            store_canon(&F, err + (size_t)c * (n + 1) * 4, e, el);
+        }
+        free(y); free(r); free(e);
+    }
+    free(xm);
+    return 0;
+}
+
+/* sqrt_mod (pyx:441-444, NTL SqrRootMod): Tonelli-Shanks; returns 1 if a is a non-residue.
+   Which of the two roots NTL returns is not pinned by any reference test (tests/test_ntl.py:331-341). */
+API int orc_sqrt_mod(const u64 *p, const u64 *a, u64 *out) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe am; load_mont(&F, &am, a, 1);
+    if (is_zero(&am)) { memset(out, 0, 32); return 0; }
+    u64 pm1[4]; u64 one[4] = {1, 0, 0, 0}; sub4(pm1, F.p, one);
+    u64 half[4]; for (int i = 0; i < 4; i++) half[i] = (pm1[i] >> 1) | (i < 3 ? pm1[i + 1] << 63 : 0);
+    fe leg; fe_pow(&F, &leg, &am, half);
+    if (!fe_eq(&leg, &F.r1)) return 1;
+    /* p-1 = q * 2^s */
+    u64 q[4]; memcpy(q, pm1, 32); int s = 0;
+    while ((q[0] & 1) == 0) { for (int i = 0; i < 4; i++) q[i] = (q[i] >> 1) | (i < 3 ? q[i + 1] << 63 : 0); s++; }
+    fe zc; u64 zv = 2;
+    for (;; zv++) { fe zz; fe_from_u64(&F, &zz, zv); fe l2; fe_pow(&F, &l2, &zz, half); if (!fe_eq(&l2, &F.r1) && !is_zero(&l2)) { zc = zz; break; } }
+    fe c; fe_pow(&F, &c, &zc, q);
+    u64 qp1h[4]; u64 carry = add4(qp1h, q, one); (void)carry;
+    for (int i = 0; i < 4; i++) qp1h[i] = (qp1h[i] >> 1) | (i < 3 ? qp1h[i + 1] << 63 : 0);
+    fe r; fe_pow(&F, &r, &am, qp1h);
+    fe t; fe_pow(&F, &t, &am, q);
+    int m = s;
+    while (!fe_eq(&t, &F.r1)) {
+        int i = 0; fe tt = t;
+        while (!fe_eq(&tt, &F.r1)) { fe_mul(&F, &tt, &tt, &tt); i++; }
+        fe b = c; for (int j = 0; j < m - i - 1; j++) fe_mul(&F, &b, &b, &b);
+        fe_mul(&F, &r, &r, &b); fe_mul(&F, &c, &b, &b); fe_mul(&F, &t, &t, &c); m = i;
+    }
+    store_canon(&F, out, &r, 1);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Welch-Berlekamp (reed_solomon_wb.py) restated                       */
+/* ------------------------------------------------------------------ */
+/* rref (reed_solomon_wb.py:157-197): first-non-zero-row pivoting, full elimination */
+static void wb_rref(const field_t *F, fe *M, int rows, int cols) {
+    int i = 0, j = 0;
+    while (i < rows && j < cols) {
+        if (is_zero(&M[(size_t)i * cols + j])) {
+            int nz = i;
+            while (nz < rows && is_zero(&M[(size_t)nz * cols + j])) nz++;
+            if (nz == rows) { j++; continue; }
+            for (int c = 0; c < cols; c++) { fe t = M[(size_t)i * cols + c]; M[(size_t)i * cols + c] = M[(size_t)nz * cols + c]; M[(size_t)nz * cols + c] = t; }
+        }
+        fe pinv; fe_inv(F, &pinv, &M[(size_t)i * cols + j]);
+        for (int c = 0; c < cols; c++) fe_mul(F, &M[(size_t)i * cols + c], &M[(size_t)i * cols + c], &pinv);
+        for (int r = 0; r < rows; r++) {
+            if (r == i) continue;
+            fe f = M[(size_t)r * cols + j];
+            if (is_zero(&f)) continue;
+            for (int c = 0; c < cols; c++) { fe t; fe_mul(F, &t, &f, &M[(size_t)i * cols + c]); fe_sub(F, &M[(size_t)r * cols + c], &M[(size_t)r * cols + c], &t); }
+        }
+        i++; j++;
+    }
+}
+/* some_solution (reed_solomon_wb.py:240-273).  returns 1 for "No solution". */
+static int wb_some_solution(const field_t *F, fe *M, int rows, int cols, fe *vals) {
+    wb_rref(F, M, rows, cols);
+    /* no_solution (wb:203-214): last non-zero row must not be 0 ... 0 | c */
+    int i = rows - 1;
+    for (;;) {
+        int allz = 1; for (int c = 0; c < cols; c++) if (!is_zero(&M[(size_t)i * cols + c])) { allz = 0; break; }
+        if (!allz) break;
+        i--; if (i < 0) break;
+    }
+    if (i >= 0) { int lhs0 = 1; for (int c = 0; c < cols - 1; c++) if (!is_zero(&M[(size_t)i * cols + c])) { lhs0 = 0; break; } if (lhs0) return 1; }
+    int nv = cols - 1;
+    int *pivot_row = (int *)malloc((size_t)nv * sizeof(int));
+    for (int j = 0; j < nv; j++) {
+        /* is_pivot_column (wb:217-237) */
+        int r = 0; while (r < rows && is_zero(&M[(size_t)r * cols + j])) r++;
+        pivot_row[j] = -1;
+        if (r == rows) continue;
+        if (!fe_eq(&M[(size_t)r * cols + j], &F->r1)) continue;
+        int pr = r, ok = 1;
+        for (r = pr + 1; r < rows; r++) if (!is_zero(&M[(size_t)r * cols + j])) { ok = 0; break; }
+        if (ok) pivot_row[j] = pr;
+    }
+    for (int j = 0; j < nv; j++) if (pivot_row[j] < 0) vals[j] = F->r1; else memset(&vals[j], 0, sizeof(fe));
+    for (int j = 0; j < nv; j++) {
+        if (pivot_row[j] < 0) continue;
+        int r = pivot_row[j];
+        fe acc = M[(size_t)r * cols + cols - 1];
+        for (int f = 0; f < nv; f++) if (pivot_row[f] < 0) { fe t; fe_mul(F, &t, &M[(size_t)r * cols + f], &vals[f]); fe_sub(F, &acc, &acc, &t); }
+        vals[j] = acc;
+    }
+    free(pivot_row);
+    return 0;
+}
+/* decode (reed_solomon_wb.py:129-151) for one codeword.
+   status: 0 ok; 1 "found no divisors!"; 2 "No solution"; 3 precondition (2t+1+c > n).
+   out_len = number of coefficients after stripping trailing zeros (polynomial.py:14-20,36). */
+static int wb_decode_one(const field_t *F, const fe *xs, int n, int k, const fe *ys, const unsigned char *present,
+                         fe *out, int *out_len) {
+    int t = k - 1, c = 0;
+    for (int i = 0; i < n; i++) if (!present[i]) c++;
+    if (2 * t + 1 + c > n) return 3;
+    int e = (n - c - t) / 2;
+    int np = n - c;
+    fe *a = (fe *)malloc((size_t)(np > 0 ? np : 1) * sizeof(fe)), *b = (fe *)malloc((size_t)(np > 0 ? np : 1) * sizeof(fe));
+    for (int i = 0, w = 0; i < n; i++) if (present[i]) { a[w] = xs[i]; b[w] = ys[i]; w++; }
+    int status = 0;
+    if (e == 0) {
+        poly P; poly_init(&P, np + 1);
+        poly_interpolate(F, &P, a, b, np);
+        *out_len = P.deg + 1; for (int i = 0; i <= P.deg; i++) out[i] = P.c[i];
+        poly_free(&P); free(a); free(b);
+        return 0;
+    }
+    status = 1;
+    for (int ee = e; ee >= 1; ee--) {       /* solve_system (wb:79-127) */
+        int env = ee + 1, qnv = ee + k, cols = env + qnv + 1, rows = np + 1;
+        fe *M = (fe *)calloc((size_t)rows * cols, sizeof(fe));
+        for (int r = 0; r < np; r++) {
+            fe ap = F->r1;
+            for (int j = 0; j < qnv; j++) {
+                if (j < env) fe_mul(F, &M[(size_t)r * cols + j], &b[r], &ap);
+                fe_neg(F, &M[(size_t)r * cols + env + j], &ap);
+                fe_mul(F, &ap, &ap, &a[r]);
+            }
+        }
+        M[(size_t)np * cols + env - 1] = F->r1; M[(size_t)np * cols + cols - 1] = F->r1;
+        fe *sol = (fe *)malloc((size_t)(cols - 1) * sizeof(fe));
+        if (wb_some_solution(F, M, rows, cols, sol)) { free(M); free(sol); status = 2; break; }
+        poly E, Q, Pq, R; poly_init(&E, env + 1); poly_init(&Q, qnv + 1); poly_init(&Pq, qnv + 1); poly_init(&R, qnv + 1);
+        for (int j = 0; j < env; j++) E.c[j] = sol[j]; E.deg = env - 1; poly_norm(&E);
+        for (int j = 0; j < qnv; j++) Q.c[j] = sol[env + j]; Q.deg = qnv - 1; poly_norm(&Q);
+        int exact = 0;
+        if (E.deg >= 0) { poly_divrem(F, &Pq, &R, &Q, &E); exact = (R.deg < 0); }
+        if (exact) { *out_len = Pq.deg + 1; for (int i = 0; i <= Pq.deg; i++) out[i] = Pq.c[i]; status = 0; }
+        poly_free(&E); poly_free(&Q); poly_free(&Pq); poly_free(&R); free(M); free(sol);
+        if (exact) break;
+    }
+    free(a); free(b);
+    return status;
+}
+/* batch WB: ys [C][n], present [C][n]; out [C][n] (only out_len[c] valid), status[C] */
+API int orc_wb_decode(const u64 *p, const u64 *x, int n, int k, const u64 *ys, const unsigned char *present, long C,
+                      u64 *out, int *out_len, int *status) {
+    field_t F; if (field_init(&F, p)) return -1;
+    fe *xm = (fe *)malloc((size_t)n * sizeof(fe)); load_mont(&F, xm, x, n);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(g_threads)
+    for (long c = 0; c < C; c++) {
+        fe *y = (fe *)malloc((size_t)n * sizeof(fe)); load_mont(&F, y, ys + (size_t)c * n * 4, n);
+        fe *o = (fe *)calloc((size_t)2 * n + 2, sizeof(fe));
+        int ol = 0;
+        status[c] = wb_decode_one(&F, xm, n, k, y, present + (size_t)c * n, o, &ol);
+        out_len[c] = status[c] == 0 ? ol : 0;
+        if (status[c] == 0) store_canon(&F, out + (size_t)c * n * 4, o, ol);
+        free(y); free(o);
+    }
+    free(xm);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* One party's fault-free batch open (SURVEY 8d / batch_reconstruction.py:158-227
+   with reed_solomon.py:305-330): the 3-encode / 2-decode census, used as the
+   cpu_baseline workload and as the full-pipeline checker.
+     shares      [B]           this party's shares (chunked into C=ceil(B/d) rows, zero padded)
+     r1_cols     [n][C]        column j = what party j sent us in R1 (= its encode row for us)
+     r2_cols     [n][C]        column j = party j's R2 broadcast
+     z           first d arrival indices used for the optimistic decode; the remaining
+                 n_check arrivals (zc) are compared against the re-encoding
+   outputs: r1_out [n][C] our R1 messages (party-major); r2_msg [C]; result [B]; returns
+   0 ok, 1 singular, 2 validation mismatch.
+   ------------------------------------------------------------------ */
+API int orc_batch_open(const u64 *p, int n, int d, int use_fft, const u64 *omega, int order,
+                       const u64 *x, const u64 *shares, long B,
+                       const u64 *r1_cols, const u64 *r2_cols, const int *z, const int *zc, int n_check,
+                       u64 *r1_out, u64 *r2_msg, u64 *result) {
+    field_t F; if (field_init(&F, p)) return -1;
+    long C = (B + d - 1) / d;
+    u64 *chunks = (u64 *)calloc((size_t)C * d * 4, sizeof(u64));
+    memcpy(chunks, shares, (size_t)B * 32);
+    u64 *enc = (u64 *)malloc((size_t)C * n * 32);
+    u64 *xz = (u64 *)malloc((size_t)d * 32);
+    for (int i = 0; i < d; i++) memcpy(xz + 4 * i, x + 4 * z[i], 32);
+    int rc = 0;
+    /* R1 encode + transpose_lists (batch_reconstruction.py:164-167) */
+    if (use_fft) orc_fft_batch_evaluate(p, omega, order, chunks, C, d, n, enc);
+    else orc_vandermonde_batch_evaluate(p, x, n, chunks, C, d, enc);
+    for (long c = 0; c < C; c++) for (int i = 0; i < n; i++) memcpy(r1_out + ((size_t)i * C + c) * 4, enc + ((size_t)c * n + i) * 4, 32);
+    u64 *avail = (u64 *)malloc((size_t)C * d * 32), *dec = (u64 *)malloc((size_t)C * d * 32);
+    for (int round = 0; round < 2 && rc == 0; round++) {
+        const u64 *cols = round == 0 ? r1_cols : r2_cols;
+        /* IncrementalDecoder._optimistic_update (reed_solomon.py:305-330) */
+        for (long c = 0; c < C; c++) for (int l = 0; l < d; l++) memcpy(avail + ((size_t)c * d + l) * 4, cols + ((size_t)z[l] * C + c) * 4, 32);
+        int s = use_fft ? orc_fft_batch_interpolate(p, omega, order, z, d, avail, C, dec)
+                        : orc_vandermonde_batch_interpolate(p, xz, d, avail, C, dec);
+        if (s) { rc = 1; break; }
+        if (use_fft) orc_fft_batch_evaluate(p, omega, order, dec, C, d, n, enc);
+        else orc_vandermonde_batch_evaluate(p, x, n, dec, C, d, enc);
+        for (int j = 0; j < n_check && rc == 0; j++)
+            for (long c = 0; c < C; c++)
+                if (memcmp(cols + ((size_t)zc[j] * C + c) * 4, enc + ((size_t)c * n + zc[j]) * 4, 32) != 0) { rc = 2; break; }
+        if (round == 0) for (long c = 0; c < C; c++) memcpy(r2_msg + (size_t)c * 4, dec + (size_t)c * d * 4, 32);   /* :194 */
+    }
+    if (rc == 0) memcpy(result, dec, (size_t)B * 32);                                /* flatten + truncate :223-227 */
+    free(chunks); free(enc); free(xz); free(avail); free(dec);
+    return rc;
+}
