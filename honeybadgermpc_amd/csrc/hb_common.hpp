@@ -85,6 +85,11 @@ inline int nsub_for(int d, int nl, int nw) {
     return n < 1 ? 1 : (int)n;
 }
 int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s);
+// out(c,i) = sum_l M[i][l] * in(c, rows[l]); CHECK mode when check_mask_dev != nullptr (out = expected values)
+int launch_matvec(hb_ctx *ctx, const hb_matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
+                  uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+                  int64_t C, hipStream_t s);
+int launch_copy_view(hb_ctx *ctx, const uint32_t *src, hb_view sv, uint32_t *dst, hb_view dv, int64_t C, int L, int64_t dst_count, hipStream_t s);
 
 // dispatch on element width
 #define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \

@@ -5,10 +5,4 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *, int, const uint64_t *, 
 int hb_fft_batch_interpolate(hb_ctx *ctx, const uint64_t *, int, const int32_t *, int, const uint64_t *, int64_t, uint64_t *, void *) { return hb::fail(ctx, HB_ERR_UNSUPPORTED, "not implemented"); }
 int hb_gao_decode(hb_ctx *ctx, const uint64_t *, int, int, const uint64_t *, int64_t, uint64_t *, uint64_t *, int32_t *, uint8_t *, void *) { return hb::fail(ctx, HB_ERR_UNSUPPORTED, "not implemented"); }
 int hb_wb_decode(hb_ctx *ctx, const uint64_t *, int, int, const uint64_t *, const uint8_t *, int64_t, uint64_t *, int32_t *, int32_t *, void *) { return hb::fail(ctx, HB_ERR_UNSUPPORTED, "not implemented"); }
-int hb_open_plan_create(hb_ctx *ctx, int, int, int, const uint64_t *, const uint64_t *, int, const int32_t *, const int32_t *, int, int64_t, hb_open_plan **, void *) { return hb::fail(ctx, HB_ERR_UNSUPPORTED, "not implemented"); }
-int hb_open_r1_encode(hb_open_plan *, const uint64_t *, int64_t, uint64_t *, void *) { return HB_ERR_UNSUPPORTED; }
-int hb_open_r1_decode(hb_open_plan *, const uint64_t *, int64_t, uint64_t *, void *) { return HB_ERR_UNSUPPORTED; }
-int hb_open_r2_decode(hb_open_plan *, const uint64_t *, int64_t, uint64_t *, void *) { return HB_ERR_UNSUPPORTED; }
-int hb_open_status(hb_open_plan *, void *) { return HB_ERR_UNSUPPORTED; }
-void hb_open_plan_destroy(hb_open_plan *) {}
 }
