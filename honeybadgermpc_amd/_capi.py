@@ -82,6 +82,13 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64; it must be the one HIP runtime of the
+    # process, so import torch (which loads it) before dlopen'ing our library, whose
+    # libamdhip64 dependency then resolves to the already-loaded SONAME.
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.init()
     if not os.path.exists(LIB_PATH):
         raise HbmpcBackendError(
             f"{LIB_PATH} not found: build it with honeybadgermpc_amd/csrc/build.sh "
@@ -116,7 +123,7 @@ def ints_to_limbs(values, modulus, nbytes=32):
             v %= modulus
         buf[off : off + nbytes] = v.to_bytes(nbytes, "little")
         off += nbytes
-    return np.frombuffer(bytes(buf), dtype=np.uint64).reshape(len(values), nbytes // 8)
+    return np.frombuffer(buf, dtype=np.uint64).reshape(len(values), nbytes // 8)
 
 
 def limbs_to_ints(arr, nbytes=32):

@@ -47,6 +47,7 @@ struct hb_ctx {
     std::string err;
     std::map<std::string, hb_matrix *> mcache;        // tables keyed by (kind, n, d, point bytes)
     std::map<std::vector<int32_t>, int32_t *> icache; // small int arrays resident on device
+    std::map<std::string, void *> dcache;             // other device tables (twiddles, ...), hipFree'd with the ctx
     int32_t *flag_dev;                                // 64 status words
     int elem_words() const { return n_limbs == 4 ? 8 : 2; }
     int nl() const { return n_limbs == 4 ? 9 : 3; }
@@ -85,6 +86,13 @@ inline int nsub_for(int d, int nl, int nw) {
     return n < 1 ? 1 : (int)n;
 }
 int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s);
+int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out);
+int upload_elems(hb_ctx *ctx, const uint64_t *host, size_t count, uint32_t **dev, hipStream_t s);
+std::string table_key(const char *kind, hb_ctx *ctx, const uint64_t *x, int n, int d);
+// out[i] = base^(exps ? exps[i] : i), canonical packed, freshly hipMalloc'ed (caller frees)
+int pow_points_dev(hb_ctx *ctx, const uint64_t *base_host, const int32_t *exps_dev, int count, uint32_t **out_dev, hipStream_t s);
+int vand_matrix_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_dev, int n, int d, hb_matrix **out, hipStream_t s);
+int vinv_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_dev, int k, hb_matrix **out, hipStream_t s);
 // out(c,i) = sum_l M[i][l] * in(c, rows[l]); CHECK mode when check_mask_dev != nullptr (out = expected values)
 int launch_matvec(hb_ctx *ctx, const hb_matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                   uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,

@@ -341,7 +341,7 @@ int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStr
     return HB_OK;
 }
 
-static int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out) {
+int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out) {
     hb_matrix *m = new hb_matrix();
     m->ctx = ctx; m->n_out = n_out; m->n_in = n_in; m->cached = false;
     m->words = (size_t)m_tiles(n_out) * (size_t)n_in * OT * (size_t)ctx->nl();
@@ -353,14 +353,14 @@ static int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out) {
 }
 
 // upload a small host array of elements to a temporary device buffer
-static int upload_elems(hb_ctx *ctx, const uint64_t *host, size_t count, uint32_t **dev, hipStream_t s) {
+int upload_elems(hb_ctx *ctx, const uint64_t *host, size_t count, uint32_t **dev, hipStream_t s) {
     size_t bytes = count * (size_t)ctx->elem_words() * 4;
     HB_HIP(ctx, hipMalloc(dev, bytes ? bytes : 4));
     HB_HIP(ctx, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, s));
     return HB_OK;
 }
 
-static std::string table_key(const char *kind, hb_ctx *ctx, const uint64_t *x, int n, int d) {
+std::string table_key(const char *kind, hb_ctx *ctx, const uint64_t *x, int n, int d) {
     std::string k(kind);
     k += ":" + std::to_string(n) + ":" + std::to_string(d) + ":";
     k.append(reinterpret_cast<const char *>(x), (size_t)n * ctx->n_limbs * 8);
@@ -407,6 +407,7 @@ void hb_ctx_destroy(hb_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     for (auto &kv : ctx->mcache) { (void)hipFree(kv.second->dev); delete kv.second; }
     for (auto &kv : ctx->icache) (void)hipFree(kv.second);
+    for (auto &kv : ctx->dcache) (void)hipFree(kv.second);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
     delete ctx;
 }
@@ -426,61 +427,110 @@ int hb_memcpy_d2h(hb_ctx *ctx, void *dst, const void *src, size_t bytes, void *s
 int hb_stream_sync(hb_ctx *ctx, void *stream) { HB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream)); return HB_OK; }
 
 // ---- tables -------------------------------------------------------------------------
+}  // extern "C"
+
+namespace hb {
+
+// x^e for a list of exponents (or e = index when exps == nullptr): evaluation points omega^z
+template <int NL, int NW>
+__global__ void k_pow_points(const FpParams<NL> P, const uint32_t *__restrict__ base, const int32_t *__restrict__ exps, int count,
+                             uint32_t *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t bd[NL], bm[NL], r[NL], c[NL];
+    load_digits<NL, NW>(bd, base);
+    to_mont(bm, bd, P);
+    fp_pow_u32(r, bm, (uint32_t)(exps ? exps[i] : i), P);
+    from_mont(c, r, P);
+    store_digits<NL, NW>(out + (size_t)i * NW, c);
+}
+
+int pow_points_dev(hb_ctx *ctx, const uint64_t *base_host, const int32_t *exps_dev, int count, uint32_t **out_dev, hipStream_t s) {
+    uint32_t *bd = nullptr;
+    int rc = upload_elems(ctx, base_host, 1, &bd, s); if (rc) return rc;
+    HB_HIP(ctx, hipMalloc(out_dev, (size_t)(count > 0 ? count : 1) * ctx->elem_words() * 4));
+    if (count > 0) {
+        HB_DISPATCH(ctx,
+            (k_pow_points<9, 8><<<(count + 63) / 64, 64, 0, s>>>(ctx->pw, bd, exps_dev, count, *out_dev)),
+            (k_pow_points<3, 2><<<(count + 63) / 64, 64, 0, s>>>(ctx->pn, bd, exps_dev, count, *out_dev)));
+        HB_LAUNCH_CHECK(ctx);
+    }
+    HB_HIP(ctx, hipStreamSynchronize(s));
+    HB_HIP(ctx, hipFree(bd));
+    return HB_OK;
+}
+
+int vand_matrix_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_dev, int n, int d, hb_matrix **out, hipStream_t s) {
+    hb_matrix *m = nullptr;
+    int rc = alloc_matrix(ctx, n, d, &m); if (rc) return rc;
+    HB_HIP(ctx, hipMemsetAsync(m->dev, 0, m->words * 4, s));
+    if (n > 0 && d > 0) {
+        HB_DISPATCH(ctx,
+            (k_vand_table<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, x_dev, n, d, m->dev)),
+            (k_vand_table<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, x_dev, n, d, m->dev)));
+        HB_LAUNCH_CHECK(ctx);
+        HB_HIP(ctx, hipStreamSynchronize(s));
+    }
+    m->cached = true; ctx->mcache[key] = m; *out = m;
+    return HB_OK;
+}
+
+int vinv_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_dev, int k, hb_matrix **out, hipStream_t s) {
+    if (k > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "vandermonde inverse: k > 1023");
+    hb_matrix *m = nullptr;
+    int rc = alloc_matrix(ctx, k, k, &m); if (rc) return rc;
+    HB_HIP(ctx, hipMemsetAsync(m->dev, 0, m->words * 4, s));
+    int singular = 0;
+    if (k > 0) {
+        HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), s));
+        int threads = ((k + 1 + 63) / 64) * 64;
+        size_t lds = (size_t)(k + 2 * (k + 1)) * ctx->nl() * 4;
+        if (ctx->n_limbs == 4) {
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_table<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_vinv_table<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->dev, ctx->flag_dev);
+        } else {
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_table<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_vinv_table<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->dev, ctx->flag_dev);
+        }
+        HB_LAUNCH_CHECK(ctx);
+        HB_HIP(ctx, hipMemcpyAsync(&singular, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        HB_HIP(ctx, hipStreamSynchronize(s));
+    }
+    if (singular) { (void)hipFree(m->dev); delete m; return fail(ctx, HB_ERR_SINGULAR, "Interpolation failed"); }
+    m->cached = true; ctx->mcache[key] = m; *out = m;
+    return HB_OK;
+}
+
+}  // namespace hb
+
+extern "C" {
+
 int hb_vand_matrix_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, hb_matrix **out, void *stream) {
     if (!ctx || !out || n < 0 || d < 0) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     std::string key = table_key("V", ctx, x_host, n, d);
     auto it = ctx->mcache.find(key);
     if (it != ctx->mcache.end()) { *out = it->second; return HB_OK; }
-    hb_matrix *m = nullptr;
-    int rc = alloc_matrix(ctx, n, d, &m); if (rc) return rc;
-    HB_HIP(ctx, hipMemsetAsync(m->dev, 0, m->words * 4, s));
-    if (n > 0 && d > 0) {
-        uint32_t *xd = nullptr;
-        rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
-        HB_DISPATCH(ctx,
-            (k_vand_table<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, xd, n, d, m->dev)),
-            (k_vand_table<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, xd, n, d, m->dev)));
-        HB_LAUNCH_CHECK(ctx);
-        HB_HIP(ctx, hipStreamSynchronize(s));
-        HB_HIP(ctx, hipFree(xd));
-    }
-    m->cached = true; ctx->mcache[key] = m; *out = m;
-    return HB_OK;
+    uint32_t *xd = nullptr;
+    int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
+    rc = vand_matrix_from_dev(ctx, key, xd, n, d, out, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(xd);
+    return rc;
 }
 
 int hb_vand_inverse_create(hb_ctx *ctx, const uint64_t *x_host, int k, hb_matrix **out, void *stream) {
     if (!ctx || !out || k < 0) return HB_ERR_BAD_ARG;
-    if (k > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "vandermonde inverse: k > 1023");
     hipStream_t s = (hipStream_t)stream;
     std::string key = table_key("Vinv", ctx, x_host, k, k);
     auto it = ctx->mcache.find(key);
     if (it != ctx->mcache.end()) { *out = it->second; return HB_OK; }
-    hb_matrix *m = nullptr;
-    int rc = alloc_matrix(ctx, k, k, &m); if (rc) return rc;
-    HB_HIP(ctx, hipMemsetAsync(m->dev, 0, m->words * 4, s));
-    int singular = 0;
-    if (k > 0) {
-        uint32_t *xd = nullptr;
-        rc = upload_elems(ctx, x_host, (size_t)k, &xd, s); if (rc) return rc;
-        HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), s));
-        int threads = ((k + 1 + 63) / 64) * 64;
-        size_t lds = (size_t)(k + 2 * (k + 1)) * ctx->nl() * 4;
-        if (ctx->n_limbs == 4) {
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_table<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_table<9, 8><<<1, threads, lds, s>>>(ctx->pw, xd, k, m->dev, ctx->flag_dev);
-        } else {
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_table<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_table<3, 2><<<1, threads, lds, s>>>(ctx->pn, xd, k, m->dev, ctx->flag_dev);
-        }
-        HB_LAUNCH_CHECK(ctx);
-        HB_HIP(ctx, hipMemcpyAsync(&singular, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-        HB_HIP(ctx, hipStreamSynchronize(s));
-        HB_HIP(ctx, hipFree(xd));
-    }
-    if (singular) { (void)hipFree(m->dev); delete m; return fail(ctx, HB_ERR_SINGULAR, "Interpolation failed"); }
-    m->cached = true; ctx->mcache[key] = m; *out = m;
-    return HB_OK;
+    uint32_t *xd = nullptr;
+    int rc = upload_elems(ctx, x_host, (size_t)k, &xd, s); if (rc) return rc;
+    rc = vinv_from_dev(ctx, key, xd, k, out, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(xd);
+    return rc;
 }
 
 int hb_matrix_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, hb_matrix **out, void *stream) {

@@ -165,9 +165,11 @@ static void fe_reduce_in(const field_t *F, fe *r, const u64 a[4]) {
     fe m; fe_mul(F, &m, &t, &F->r2); from_mont(F, r, &m);
 }
 static void load_mont(const field_t *F, fe *dst, const u64 *src, long count) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (count > 4096)
     for (long i = 0; i < count; i++) { fe t; fe_reduce_in(F, &t, src + 4 * i); to_mont(F, &dst[i], &t); }
 }
 static void store_canon(const field_t *F, u64 *dst, const fe *src, long count) {
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (count > 4096)
     for (long i = 0; i < count; i++) { fe t; from_mont(F, &t, &src[i]); memcpy(dst + 4 * i, t.l, 32); }
 }
 
@@ -808,20 +810,25 @@ API int orc_batch_open(const u64 *p, int n, int d, int use_fft, const u64 *omega
     /* R1 encode + transpose_lists (batch_reconstruction.py:164-167) */
     if (use_fft) orc_fft_batch_evaluate(p, omega, order, chunks, C, d, n, enc);
     else orc_vandermonde_batch_evaluate(p, x, n, chunks, C, d, enc);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
     for (long c = 0; c < C; c++) for (int i = 0; i < n; i++) memcpy(r1_out + ((size_t)i * C + c) * 4, enc + ((size_t)c * n + i) * 4, 32);
     u64 *avail = (u64 *)malloc((size_t)C * d * 32), *dec = (u64 *)malloc((size_t)C * d * 32);
     for (int round = 0; round < 2 && rc == 0; round++) {
         const u64 *cols = round == 0 ? r1_cols : r2_cols;
         /* IncrementalDecoder._optimistic_update (reed_solomon.py:305-330) */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
         for (long c = 0; c < C; c++) for (int l = 0; l < d; l++) memcpy(avail + ((size_t)c * d + l) * 4, cols + ((size_t)z[l] * C + c) * 4, 32);
         int s = use_fft ? orc_fft_batch_interpolate(p, omega, order, z, d, avail, C, dec)
                         : orc_vandermonde_batch_interpolate(p, xz, d, avail, C, dec);
         if (s) { rc = 1; break; }
         if (use_fft) orc_fft_batch_evaluate(p, omega, order, dec, C, d, n, enc);
         else orc_vandermonde_batch_evaluate(p, x, n, dec, C, d, enc);
-        for (int j = 0; j < n_check && rc == 0; j++)
-            for (long c = 0; c < C; c++)
-                if (memcmp(cols + ((size_t)zc[j] * C + c) * 4, enc + ((size_t)c * n + zc[j]) * 4, 32) != 0) { rc = 2; break; }
+        int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(g_threads) reduction(|:bad)
+        for (long c = 0; c < C; c++)
+            for (int j = 0; j < n_check; j++)
+                if (memcmp(cols + ((size_t)zc[j] * C + c) * 4, enc + ((size_t)c * n + zc[j]) * 4, 32) != 0) bad |= 1;
+        if (bad) rc = 2;
         if (round == 0) for (long c = 0; c < C; c++) memcpy(r2_msg + (size_t)c * 4, dec + (size_t)c * d * 4, 32);   /* :194 */
     }
     if (rc == 0) memcpy(result, dec, (size_t)B * 32);                                /* flatten + truncate :223-227 */

@@ -1,0 +1,405 @@
+"""
+GPU parity: the HIP path (through the C ABI / the ntl drop-in) against the CPU oracle on the
+same seeded inputs, against the committed golden vectors, and -- at BASELINE.json's full
+sizes -- through size-independent properties (encode -> erase -> decode round trips,
+linearity, consistency of validation).  Bit-exact everywhere: this is integer work.
+"""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import BLS
+
+pytestmark = pytest.mark.gpu
+
+P = BLS
+PRIMES = [P, 13, 53, (1 << 256) - 189, (1 << 255) - 19, (1 << 64) - 59]
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import torch
+
+    assert torch.cuda.is_available()
+    from honeybadgermpc_amd import ntl
+
+    return ntl
+
+
+def rand_rows(rnd, p, c, d):
+    return [[rnd.randrange(p) for _ in range(d)] for _ in range(c)]
+
+
+# ------------------------------------------------------------------ C ABI sanity
+def test_capi_context_errors():
+    from honeybadgermpc_amd._capi import HB_ERR_BAD_ARG, HB_ERR_UNSUPPORTED, ints_to_limbs, load_library, np_ptr
+
+    lib = load_library()     # imports torch first: one HIP runtime per process (see _capi.load_library)
+    assert lib.hb_device_count() >= 1
+    h = ctypes.c_void_p()
+    even = ints_to_limbs([10], 11)
+    assert lib.hb_ctx_create(ctypes.byref(h), np_ptr(even), 4, 0) == HB_ERR_UNSUPPORTED
+    assert lib.hb_ctx_create(ctypes.byref(h), np_ptr(even), 3, 0) == HB_ERR_BAD_ARG
+    odd = ints_to_limbs([13], 14)
+    assert lib.hb_ctx_create(ctypes.byref(h), np_ptr(odd), 4, 0) == 0
+    assert lib.hb_elem_bytes(h) == 32
+    lib.hb_ctx_destroy(h)
+
+
+def test_narrow_context_matches_wide():
+    """the 1-limb (p < 2^64) instantiation of every kernel against the 4-limb one"""
+    import torch
+
+    from honeybadgermpc_amd._capi import ints_to_limbs, limbs_to_ints, load_library, np_ptr
+
+    lib = load_library()
+    rnd = random.Random(21)
+    for p in (13, 53, (1 << 64) - 59, 0xFFFFFFFF00000001):
+        n, d, c = 20, 7, 150
+        x = [rnd.randrange(1, p) for _ in range(n)] if p > 100 else list(range(1, min(n, p - 1) + 1))
+        n = len(x)
+        polys = rand_rows(rnd, p, c, d)
+        want = oracle.vandermonde_batch_evaluate(x, polys, p)
+        h = ctypes.c_void_p()
+        assert lib.hb_ctx_create(ctypes.byref(h), np_ptr(ints_to_limbs([p], p + 1, 8)), 1, 0) == 0
+        assert lib.hb_elem_bytes(h) == 8
+        din = torch.from_numpy(ints_to_limbs([v for r in polys for v in r], p, 8).view(np.int64).copy()).cuda()
+        dout = torch.empty((c * n, 1), dtype=torch.int64, device="cuda")
+        rc = lib.hb_vandermonde_batch_evaluate(h, np_ptr(ints_to_limbs(x, p, 8)), n, ctypes.c_void_p(din.data_ptr()), c, d,
+                                               ctypes.c_void_p(dout.data_ptr()), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = limbs_to_ints(dout.cpu().numpy().view(np.uint64), 8)
+        assert [got[i * n : (i + 1) * n] for i in range(c)] == want
+        dk = min(d, n)
+        ys = torch.from_numpy(ints_to_limbs([v for r in want for v in r[:dk]], p, 8).view(np.int64).copy()).cuda()
+        dec = torch.empty((c * dk, 1), dtype=torch.int64, device="cuda")
+        rc = lib.hb_vandermonde_batch_interpolate(h, np_ptr(ints_to_limbs(x[:dk], p, 8)), dk, ctypes.c_void_p(ys.data_ptr()), c,
+                                                  ctypes.c_void_p(dec.data_ptr()), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = limbs_to_ints(dec.cpu().numpy().view(np.uint64), 8)
+        if dk == d:
+            assert [got[i * d : (i + 1) * d] for i in range(c)] == polys
+        lib.hb_ctx_destroy(h)
+
+
+# ------------------------------------------------------------------ Vandermonde path
+@pytest.mark.parametrize("p", PRIMES)
+def test_vandermonde_vs_oracle(hip, p):
+    rnd = random.Random(hash(p) & 0xFFFF)
+    for n, d, c in [(4, 2, 256), (16, 6, 70), (64, 22, 130), (100, 34, 9), (7, 7, 64), (1, 1, 1), (65, 3, 5), (33, 33, 3)]:
+        if n >= p:
+            n = p - 1
+            d = min(d, n)
+        x = list(range(1, n + 1))
+        polys = rand_rows(rnd, p, c, d)
+        polys[0] = [0] * d
+        polys[-1] = [p - 1] * d
+        want = oracle.vandermonde_batch_evaluate(x, polys, p)
+        assert hip.vandermonde_batch_evaluate(x, polys, p) == want
+        z = rnd.sample(range(n), d)
+        xz = [x[i] for i in z]
+        ys = [[row[i] for i in z] for row in want]
+        assert hip.vandermonde_batch_interpolate(xz, ys, p) == polys
+        assert hip.vandermonde_batch_interpolate(xz, ys, p) == oracle.vandermonde_batch_interpolate(xz, ys, p)
+
+
+def test_vandermonde_edge_cases(hip):
+    # ragged rows are zero padded to the longest (pyx:217,232-233); tuples accepted; values reduced mod p
+    x = [1, 2, 3]
+    ragged = [[1], (1, 2), [5, 6, 7]]
+    assert hip.vandermonde_batch_evaluate(x, ragged, P) == oracle.vandermonde_batch_evaluate(x, ragged, P)
+    assert hip.vandermonde_batch_evaluate(x, [[P + 1, 2 * P + 3]], P) == [[4, 7, 10]]
+    big_x = [P - 1, P - 2, 5]
+    polys = [[3, 1, 4], [1, 5, 9]]
+    assert hip.vandermonde_batch_evaluate(big_x, polys, P) == oracle.vandermonde_batch_evaluate(big_x, polys, P)
+    with pytest.raises(OverflowError):
+        hip.vandermonde_batch_evaluate(x, [[-1]], P)
+    with pytest.raises(ValueError):
+        hip.vandermonde_batch_evaluate(5, [[1]], P)
+    with pytest.raises(hip.InterpolationError):
+        hip.vandermonde_batch_interpolate([1, 1], [[1, 2]], P)
+    with pytest.raises(hip.InterpolationError):
+        hip.vandermonde_batch_interpolate([1, 1 + P - P, 2][:2] + [1], [[1, 2, 3]], P)
+    assert hip.lagrange_interpolate([1, 2], [1, 2], P) == [0, 1]
+    assert hip.lagrange_interpolate([1, 2, 3], [7, 7, 7], P) == [7]
+    assert hip.lagrange_interpolate([1, 2], [0, 0], P) == []
+    assert hip.evaluate([1, 2, 3, 4], 5, P) == 586
+    assert hip.vandermonde_inverse([1, 2], 13) == oracle.vandermonde_inverse([1, 2], 13)
+
+
+def test_golden_vandermonde_hip(hip, golden):
+    g = golden("vandermonde.json")
+    for case in g["cases"]:
+        p, x = case["p"], case["x"]
+        assert hip.vandermonde_batch_evaluate(x, case["polys"], p) == case["evals"]
+        xz = [x[z] for z in case["z"]]
+        ys = [[row[z] for z in case["z"]] for row in case["evals"]]
+        assert hip.vandermonde_batch_interpolate(xz, ys, p) == case["interp"]
+    ev = g["evaluate"]
+    assert [hip.evaluate(ev["coeffs"], xv, ev["p"]) for xv in ev["xs"]] == ev["ys"]
+
+
+# ------------------------------------------------------------------ strided views + in-kernel validation
+def test_matvec_views_and_check():
+    import torch
+
+    from honeybadgermpc_amd._capi import Context, HbView, np_ptr
+
+    rnd = random.Random(5)
+    ctx = Context.get(P)
+    lib = ctx.lib
+    n, d, c = 10, 4, 333
+    x = list(range(1, n + 1))
+    polys = rand_rows(rnd, P, c, d)
+    want = oracle.vandermonde_batch_evaluate(x, polys, P)
+    V = ctypes.c_void_p()
+    ctx.check(lib.hb_vand_matrix_create(ctx.h, np_ptr(ctx.host_elems(x)), n, d, ctypes.byref(V), ctx.stream()), "V")
+    din = ctx.upload_ints([v for r in polys for v in r])
+    # party-major output: out[i][c]
+    dout = ctx.empty(n * c)
+    ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(din), HbView(d, 1), None, ctx.ptr(dout), HbView(1, c), c, ctx.stream()), "mv")
+    got = ctx.download_ints(dout)
+    assert [got[i * c : (i + 1) * c] for i in range(n)] == [[want[k][i] for k in range(c)] for i in range(n)]
+    # decode from a row subset of the party-major buffer (IncrementalDecoder's arrival set)
+    z = [7, 2, 9, 4]
+    Vi = ctypes.c_void_p()
+    ctx.check(lib.hb_vand_inverse_create(ctx.h, np_ptr(ctx.host_elems([x[i] for i in z])), d, ctypes.byref(Vi), ctx.stream()), "Vi")
+    dec = ctx.empty(d * c)
+    za = np.array(z, dtype=np.int32)
+    ctx.check(lib.hb_matvec(ctx.h, Vi, ctx.ptr(dout), HbView(1, c), np_ptr(za), ctx.ptr(dec), HbView(1, c), c, ctx.stream()), "dec")
+    got = ctx.download_ints(dec)
+    assert [[got[l * c + k] for l in range(d)] for k in range(c)] == polys
+    # validating re-encode: no mismatch on clean data, mismatch when a checked row is corrupted,
+    # and no mismatch when the corrupted row is not in the check set
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    rows = np.array([0, 1, 3, 5], dtype=np.int32)
+
+    def run_check(buf):
+        flag.zero_()
+        ctx.check(lib.hb_matvec_check(ctx.h, V, ctx.ptr(dec), HbView(1, c), None, ctx.ptr(buf), HbView(1, c),
+                                      np_ptr(rows), len(rows), ctx.ptr(flag), c, ctx.stream()), "chk")
+        return int(flag.item())
+
+    assert run_check(dout) == 0
+    bad = dout.clone()
+    bad[5 * c + 77, 0] ^= 1
+    assert run_check(bad) == 1
+    bad = dout.clone()
+    bad[6 * c + 77, 2] ^= 4
+    assert run_check(bad) == 0
+
+
+# ------------------------------------------------------------------ per-party open pipeline
+@pytest.mark.parametrize("n,t,b,use_omega", [(4, 1, 3, False), (16, 5, 100, False), (16, 5, 96, True), (64, 21, 1000, False), (7, 2, 1, False)])
+def test_batch_open_vs_oracle(n, t, b, use_omega):
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+
+    rnd = random.Random(n * 1000 + b)
+    d = t + 1
+    c = (b + d - 1) // d
+    point = EvalPoint(GF(P), n, use_omega_powers=use_omega)
+    x = [point(i).value for i in range(n)]
+    ctx = Context.get(P)
+    shares = [rnd.randrange(P) for _ in range(b)]
+    # consistent received columns: column j = evaluations at x_j of random degree-t chunk polynomials
+    polys1 = rand_rows(rnd, P, c, d)
+    polys2 = rand_rows(rnd, P, c, d)
+    e1 = oracle.vandermonde_batch_evaluate(x, polys1, P)
+    e2 = oracle.vandermonde_batch_evaluate(x, polys2, P)
+    r1_cols = [[e1[k][j] for k in range(c)] for j in range(n)]
+    r2_cols = [[e2[k][j] for k in range(c)] for j in range(n)]
+    order = list(range(n))
+    rnd.shuffle(order)
+    z, zc = order[:d], order[d : d + t]
+    to_limbs = lambda rows: oracle._limbs([v for r in rows for v in r], P)  # noqa: E731
+    rc, o_r1, o_r2msg, o_res = oracle.batch_open_limbs(P, n, d, x, oracle._limbs(shares, P), to_limbs(r1_cols), to_limbs(r2_cols), z, zc)
+    assert rc == 0
+    op = BatchOpen(P, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=b)
+    r1_out = op.r1_encode(ctx.upload_ints(shares))
+    r2_msg = op.r1_decode(ctx.upload_ints([v for col in r1_cols for v in col]), b)
+    result = op.r2_decode(ctx.upload_ints([v for col in r2_cols for v in col]), b)
+    assert op.ok()
+    as_np = lambda tns: tns.cpu().numpy().view(np.uint64)  # noqa: E731
+    assert np.array_equal(as_np(r1_out), o_r1)
+    assert np.array_equal(as_np(r2_msg), o_r2msg)
+    assert np.array_equal(as_np(result), o_res)
+    flat2 = [v for row in polys2 for v in row][:b]
+    assert ctx.download_ints(result) == flat2
+    # a corrupted validated column is detected, a corrupted non-validated one is not
+    if zc:
+        bad = [list(col) for col in r2_cols]
+        bad[zc[-1]][c - 1] = (bad[zc[-1]][c - 1] + 5) % P
+        op.r2_decode(ctx.upload_ints([v for col in bad for v in col]), b)
+        assert not op.ok()
+        assert op.ok()  # flag resets
+    rest = [i for i in range(n) if i not in z and i not in zc]
+    if rest:
+        bad = [list(col) for col in r2_cols]
+        bad[rest[0]][0] = (bad[rest[0]][0] + 1) % P
+        op.r2_decode(ctx.upload_ints([v for col in bad for v in col]), b)
+        assert op.ok()
+
+
+def test_full_size_properties_cfg3():
+    """BASELINE config 3 size (n=64, t=21, 2^20 shares): encode -> erase -> decode round trip on
+    random arrival sets, linearity of the encoder, and validation consistency."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context, HbView, np_ptr
+
+    ctx = Context.get(P)
+    lib = ctx.lib
+    n, t, b = 64, 21, 1 << 20
+    d = t + 1
+    c = (b + d - 1) // d
+    x = list(range(1, n + 1))
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99)
+
+    def rand(count):
+        v = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device="cuda", generator=gen)
+        v[:, 3] &= (1 << 61) - 1
+        return v
+
+    a, bvec = rand(c * d), rand(c * d)
+    V = ctypes.c_void_p()
+    ctx.check(lib.hb_vand_matrix_create(ctx.h, np_ptr(ctx.host_elems(x)), n, d, ctypes.byref(V), ctx.stream()), "V")
+
+    def encode(v):
+        out = ctx.empty(n * c)
+        ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(v), HbView(d, 1), None, ctx.ptr(out), HbView(1, c), c, ctx.stream()), "enc")
+        return out
+
+    ea, eb = encode(a), encode(bvec)
+    rnd = random.Random(3)
+    for trial in range(3):
+        z = rnd.sample(range(n), d)      # any d surviving parties reconstruct (n - d erased)
+        Vi = ctypes.c_void_p()
+        ctx.check(lib.hb_vand_inverse_create(ctx.h, np_ptr(ctx.host_elems([x[i] for i in z])), d, ctypes.byref(Vi), ctx.stream()), "Vi")
+        dec = ctx.empty(c * d)
+        ctx.check(lib.hb_matvec(ctx.h, Vi, ctx.ptr(ea), HbView(1, c), np_ptr(np.array(z, dtype=np.int32)), ctx.ptr(dec), HbView(d, 1), c, ctx.stream()), "dec")
+        assert torch.equal(dec, a)
+    # linearity: enc(a) + enc(b) == enc(a + b)  (mod p), checked on the CPU with Python ints on a sample
+    #   a + b is formed on the host for 200 random chunks only (exact ints)
+    idx = [rnd.randrange(c) for _ in range(200)]
+    ai = ctx.download_ints(a.view(c, d, 4)[idx].reshape(-1, 4))
+    bi = ctx.download_ints(bvec.view(c, d, 4)[idx].reshape(-1, 4))
+    s = ctx.upload_ints([(u + v) % P for u, v in zip(ai, bi)])
+    es = ctx.empty(n * len(idx))
+    ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(s), HbView(d, 1), None, ctx.ptr(es), HbView(1, len(idx)), len(idx), ctx.stream()), "enc")
+    ea_s = ctx.download_ints(ea.view(n, c, 4)[:, idx].reshape(-1, 4))
+    eb_s = ctx.download_ints(eb.view(n, c, 4)[:, idx].reshape(-1, 4))
+    assert ctx.download_ints(es) == [(u + v) % P for u, v in zip(ea_s, eb_s)]
+    # spot check against the oracle on those chunks
+    want = oracle.vandermonde_batch_evaluate(x, [ai[k * d : (k + 1) * d] for k in range(len(idx))], P)
+    assert [ea_s[i * len(idx) + k] for k in range(len(idx)) for i in range(n)] == [v for row in want for v in row]
+    # every output is canonical (< p): top limb bound check on the whole buffer
+    top = ea[:, 3].cpu().numpy().view(np.uint64)
+    assert int(top.max()) <= (P >> 192)
+
+
+# ------------------------------------------------------------------ FFT path
+def test_fft_reference_vectors(hip, golden):
+    assert hip.fft([0, 1], 5, 13, 4) == [1, 5, 12, 8]           # reference tests/test_ntl.py:57-68
+    c = golden("constants.json")
+    omega, n, d, k = c["omega"]["32"], 32, 20, 25
+    rnd = random.Random(77)
+    coeffs = [rnd.randrange(P) for _ in range(d)]
+    want = [sum(cj * pow(pow(omega, i, P), j, P) for j, cj in enumerate(coeffs)) % P for i in range(n)]
+    assert hip.fft(coeffs, omega, P, n) == want                  # test_ntl.py:71-87
+    assert hip.partial_fft(coeffs, omega, P, n, k) == want[:k]   # test_ntl.py:119-136
+    batch = rand_rows(rnd, P, 64, d)
+    assert hip.fft_batch_evaluate(batch, omega, P, n, k) == oracle.fft_batch_evaluate(batch, omega, P, n, k)  # :90-116
+    om8 = c["omega"]["8"]
+    zs = [3, 0, 5]
+    polys = [[1, 2, 0], [3, 2, 1], [3, 4, 2]]
+    ys = [[sum(pl[i] * pow(pow(om8, z, P), i, P) for i in range(3)) % P for z in zs] for pl in polys]
+    assert hip.fft_batch_interpolate(zs, ys, om8, P, 8) == polys  # test_ntl.py:159-179
+    assert hip.fft_interpolate([3, 0], ys[0][:2], om8, P, 8) == [1, 2]  # :139-156 (2x+1 through 2 points)
+
+
+@pytest.mark.parametrize("n,d,k,c", [(2, 1, 2, 3), (4, 2, 4, 70), (16, 6, 16, 300), (16, 16, 11, 5), (32, 20, 25, 64),
+                                     (64, 22, 64, 130), (128, 34, 100, 9), (256, 86, 256, 7), (1024, 300, 1000, 2),
+                                     (4096, 4096, 4096, 1), (8192, 100, 8192, 1), (16, 40, 16, 3)])
+def test_fft_vs_oracle(hip, golden, n, d, k, c):
+    """covers the mat-vec route (small n), the LDS NTT (n <= 4096), the HBM multi-pass NTT
+    (n = 8192) and truncation of coefficient lists longer than n (rsdecode_impl.h:173)"""
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import get_omega
+
+    omega = get_omega(GF(P), n, seed=0).value
+    rnd = random.Random(n * 7 + d)
+    coeffs = rand_rows(rnd, P, c, d)
+    coeffs[0] = [0] * d
+    assert hip.fft_batch_evaluate(coeffs, omega, P, n, k) == oracle.fft_batch_evaluate(coeffs, omega, P, n, k)
+
+
+def test_fft_small_primes(hip):
+    # p = 13: omega = 5 has order 4; p = 97: 2-adicity 5
+    assert hip.fft([1, 2, 3, 4], 5, 13, 4) == oracle.fft([1, 2, 3, 4], 5, 13, 4)
+    p = 97
+    g = 5
+    omega = pow(g, (p - 1) // 32, p)
+    assert pow(omega, 16, p) != 1
+    rnd = random.Random(9)
+    rows = rand_rows(rnd, p, 40, 32)
+    assert hip.fft_batch_evaluate(rows, omega, p, 32, 32) == oracle.fft_batch_evaluate(rows, omega, p, 32, 32)
+    zs = rnd.sample(range(32), 12)
+    ys = rand_rows(rnd, p, 9, 12)
+    assert hip.fft_batch_interpolate(zs, ys, omega, p, 32) == oracle.fft_batch_interpolate(zs, ys, omega, p, 32)
+
+
+def test_fft_golden(hip, golden):
+    for case in golden("fft.json")["cases"]:
+        p, om, n = case["p"], case["omega"], case["n"]
+        assert hip.fft_batch_evaluate(case["coeffs"], om, p, n, n) == case["evals"]
+    for case in golden("fft_interpolate.json")["cases"]:
+        assert hip.fft_batch_interpolate(case["zs"], case["ys"], case["omega"], case["p"], case["n"]) == case["coeffs"]
+
+
+def test_fft_errors(hip, golden):
+    om = golden("constants.json")["omega"]["8"]
+    with pytest.raises(ValueError):
+        hip.fft_batch_evaluate([[1, 2], [1]], om, P, 8, 8)      # ragged (UB in the reference, pyx:295)
+    with pytest.raises(ValueError):
+        hip.fft_batch_interpolate([1, 1], [[1, 2]], om, P, 8)    # repeated z
+    with pytest.raises(ValueError):
+        hip.fft_batch_interpolate([1, 9], [[1, 2]], om, P, 8)    # z out of range
+
+
+def test_fft_roundtrip_full_size_cfg2(golden):
+    """BASELINE config 2 size: 65 536 polynomials, n=16, t=5: evaluate -> erase 10 of 16 -> interpolate"""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context, np_ptr
+
+    ctx = Context.get(P)
+    lib = ctx.lib
+    n, d, c = 16, 6, 65536
+    om = ctx.host_elems([golden("constants.json")["omega"]["16"]])
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    a = torch.randint(-(1 << 63), (1 << 63) - 1, (c * d, 4), dtype=torch.int64, device="cuda", generator=gen)
+    a[:, 3] &= (1 << 61) - 1
+    ev = ctx.empty(c * n)
+    ctx.check(lib.hb_fft_batch_evaluate(ctx.h, np_ptr(om), n, ctx.ptr(a), c, d, n, ctx.ptr(ev), ctx.stream()), "ev")
+    zs = [11, 2, 7, 0, 15, 4]
+    sel = ev.view(c, n, 4)[:, zs].contiguous().view(c * d, 4)
+    back = ctx.empty(c * d)
+    ctx.check(lib.hb_fft_batch_interpolate(ctx.h, np_ptr(om), n, np_ptr(np.array(zs, dtype=np.int32)), d, ctx.ptr(sel), c, ctx.ptr(back), ctx.stream()), "in")
+    assert torch.equal(back, a)
+    # 1 024-polynomial subset bit-exact against the oracle (cfg 2)
+    sub = ctx.download_ints(a[: 1024 * d])
+    want = oracle.fft_batch_evaluate([sub[i * d : (i + 1) * d] for i in range(1024)], golden("constants.json")["omega"]["16"], P, n, n)
+    got = ctx.download_ints(ev[: 1024 * n])
+    assert [got[i * n : (i + 1) * n] for i in range(1024)] == want
