@@ -1,0 +1,305 @@
+// hb_gao.hip -- Gao's Reed-Solomon decoder, batched: one wavefront per codeword.
+//
+// Reference functions replaced (paths under /root/reference):
+//   gao_interpolate / gao_interpolate_fft     honeybadgermpc/ntl/rsdecode_impl.h:325-405
+//   partial_gcd                               honeybadgermpc/ntl/rsdecode_impl.h:281-323
+//   gao_interpolate (python boundary)         honeybadgermpc/ntl/hbmpc_ntl_helpers.pyx:389-439
+// The reference decodes one codeword per call (reed_solomon.py:335-338); here C codewords
+// that share the evaluation points are decoded by one launch.
+//
+//   g0 = prod (X - x_i)                  computed once per point set (k_poly_from_roots)
+//   g1 = interpolant of the codeword     = V(x)^-1 * y, one lazily-reduced mat-vec for the
+//                                          whole batch (the FFT variant of the reference,
+//                                          rsdecode_impl.h:376, yields the same g1)
+//   (r, v) = partial_gcd(g0, g1, (n+k)/2), f = r / v must be exact with deg f < k.
+//
+// The extended Euclid loop is run FRACTION-FREE: a pseudo-division step
+//     r0 <- lc(r1) * r0 - r0[top] * X^j * r1        (and the same combination on t0)
+// needs no field inversion; after the deg(r0)-deg(r1)+1 steps of one division the pair
+// (r0, t0) equals c * (r2, t2) of the reference's true division for the scalar
+// c = lc(r1)^(delta+1) * c0, which is tracked.  At the end ONE inversion (of c * lc(v),
+// Montgomery's trick) recovers both the reference's un-normalised cofactor v = V / c and the
+// monic divisor for the exact division.  Per codeword: O(n * e / 64) mulmods per lane plus
+// one Fermat inversion, instead of one inversion per Euclid step.
+#include "hb_common.hpp"
+
+using namespace hb;
+
+namespace {
+
+// A(X) = prod_{j<k} (X - x_j), Montgomery digits [k+1][NL].  One block.
+template <int NL, int NW>
+__global__ void __launch_bounds__(1024) k_poly_from_roots(const FpParams<NL> P, const uint32_t *__restrict__ x, int k, uint32_t *__restrict__ A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *xs = smem;
+    uint32_t *A0 = xs + (size_t)k * NL;
+    uint32_t *A1 = A0 + (size_t)(k + 1) * NL;
+    const int t = threadIdx.x;
+    if (t < k) {
+        uint32_t xd[NL], xm[NL];
+        load_digits<NL, NW>(xd, x + (size_t)t * NW);
+        to_mont(xm, xd, P);
+#pragma unroll
+        for (int q = 0; q < NL; q++) xs[t * NL + q] = xm[q];
+    }
+    if (t <= k) {
+#pragma unroll
+        for (int q = 0; q < NL; q++) A0[t * NL + q] = (t == 0) ? P.one[q] : 0u;
+    }
+    __syncthreads();
+    uint32_t *cur = A0, *nxt = A1;
+    for (int j = 0; j < k; j++) {
+        if (t <= k) {
+            uint32_t a[NL], am1[NL], xv[NL], prod[NL], r[NL];
+#pragma unroll
+            for (int q = 0; q < NL; q++) { a[q] = cur[t * NL + q]; am1[q] = (t > 0) ? cur[(t - 1) * NL + q] : 0u; xv[q] = xs[j * NL + q]; }
+            mont_mul(prod, xv, a, P);
+            fp_sub(r, am1, prod, P);
+#pragma unroll
+            for (int q = 0; q < NL; q++) nxt[t * NL + q] = r[q];
+        }
+        __syncthreads();
+        uint32_t *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (t <= k) {
+#pragma unroll
+        for (int q = 0; q < NL; q++) A[(size_t)t * NL + q] = cur[t * NL + q];
+    }
+}
+
+template <int NL> __device__ __forceinline__ void lds_get(uint32_t (&d)[NL], const uint32_t *p) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) d[q] = p[q];
+}
+template <int NL> __device__ __forceinline__ void lds_put(uint32_t *p, const uint32_t (&d)[NL]) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) p[q] = d[q];
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = max(v, __shfl_xor(v, m, 64));
+    return v;
+}
+// exact degree of the polynomial in LDS (coefficients 0..hi), -1 for zero
+template <int NL> __device__ int poly_degree(const uint32_t *p, int hi, int lane) {
+    int best = -1;
+    for (int idx = lane; idx <= hi; idx += 64) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int q = 0; q < NL; q++) o |= p[(size_t)idx * NL + q];
+        if (o) best = idx;
+    }
+    return wave_max(best);
+}
+
+template <int NL, int NW>
+__global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
+                                            int npts, int k, int64_t C, uint32_t *__restrict__ coeffs, uint32_t *__restrict__ errloc,
+                                            int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x;
+    const int64_t c = blockIdx.x;
+    const int len = npts + 1;
+    uint32_t *R0 = smem, *R1 = R0 + (size_t)len * NL, *T0 = R1 + (size_t)len * NL, *T1 = T0 + (size_t)len * NL;
+
+    for (int idx = lane; idx < len; idx += 64) {
+        uint32_t a[NL], z[NL], m[NL];
+#pragma unroll
+        for (int q = 0; q < NL; q++) { a[q] = g0[(size_t)idx * NL + q]; z[q] = 0; }
+        lds_put<NL>(R0 + (size_t)idx * NL, a);
+        lds_put<NL>(T0 + (size_t)idx * NL, z);
+        if (idx == 0) lds_put<NL>(T1, P.one); else lds_put<NL>(T1 + (size_t)idx * NL, z);
+        if (idx < npts) {
+            uint32_t yd[NL];
+            load_digits<NL, NW>(yd, g1buf + ((size_t)idx * C + c) * NW);
+            to_mont(m, yd, P);
+            lds_put<NL>(R1 + (size_t)idx * NL, m);
+        } else lds_put<NL>(R1 + (size_t)idx * NL, z);
+    }
+    __syncthreads();
+    int dR0 = npts, dR1 = poly_degree<NL>(R1, npts - 1, lane), dT0 = -1, dT1 = 0;
+    uint32_t c0[NL], c1[NL];
+    fp_set(c0, P.one); fp_set(c1, P.one);
+    const int D = (npts + k) / 2;
+    uint32_t *rp, *vp; int dr, dvb; uint32_t cs[NL];
+    if (dR0 < D) {                     // rsdecode_impl.h:289-294 (cannot fire: deg g0 = n >= D)
+        rp = R0; vp = T0; dr = dR0; dvb = dT0; fp_set(cs, c0);
+    } else if (dR1 < D) {              // rsdecode_impl.h:296-301
+        rp = R1; vp = T1; dr = dR1; dvb = dT1; fp_set(cs, c1);
+    } else {
+        for (;;) {
+            const int delta = dR0 - dR1;
+            uint32_t L[NL];
+            lds_get<NL>(L, R1 + (size_t)dR1 * NL);
+            for (int j = delta; j >= 0; j--) {
+                uint32_t a[NL];
+                lds_get<NL>(a, R0 + (size_t)(dR1 + j) * NL);
+                __syncthreads();
+                const int top = dR1 + j;
+                for (int idx = lane; idx < top; idx += 64) {
+                    uint32_t u[NL], t1[NL], r[NL];
+                    lds_get<NL>(u, R0 + (size_t)idx * NL);
+                    mont_mul(t1, L, u, P);
+                    if (idx >= j) {
+                        uint32_t w[NL], t2[NL];
+                        lds_get<NL>(w, R1 + (size_t)(idx - j) * NL);
+                        mont_mul(t2, a, w, P);
+                        fp_sub(r, t1, t2, P);
+                    } else fp_set(r, t1);
+                    lds_put<NL>(R0 + (size_t)idx * NL, r);
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < NL; q++) R0[(size_t)top * NL + q] = 0;
+                }
+                const int ttop = max(dT0, dT1 + j);
+                for (int idx = lane; idx <= ttop; idx += 64) {
+                    uint32_t u[NL], t1[NL], r[NL];
+                    lds_get<NL>(u, T0 + (size_t)idx * NL);
+                    mont_mul(t1, L, u, P);
+                    if (idx >= j && idx - j <= dT1) {
+                        uint32_t w[NL], t2[NL];
+                        lds_get<NL>(w, T1 + (size_t)(idx - j) * NL);
+                        mont_mul(t2, a, w, P);
+                        fp_sub(r, t1, t2, P);
+                    } else fp_set(r, t1);
+                    lds_put<NL>(T0 + (size_t)idx * NL, r);
+                }
+                dT0 = ttop;
+                __syncthreads();
+                mont_mul(c0, c0, L, P);           // c0 <- lc(r1)^(delta+1) * c0, one factor per step
+            }
+            dR0 = poly_degree<NL>(R0, dR1 - 1, lane);
+            if (dR0 < D) { rp = R0; vp = T0; dr = dR0; dvb = dT0; fp_set(cs, c0); break; }
+            // (r0, r1) <- (r1, r2)
+            uint32_t *tp = R0; R0 = R1; R1 = tp;
+            tp = T0; T0 = T1; T1 = tp;
+            int ti = dR0; dR0 = dR1; dR1 = ti;
+            ti = dT0; dT0 = dT1; dT1 = ti;
+            uint32_t tc[NL]; fp_set(tc, c0); fp_set(c0, c1); fp_set(c1, tc);
+        }
+    }
+    // ---- f = r / v (exact, deg f < k), v = V / cs --------------------------------------
+    const int dv = poly_degree<NL>(vp, dvb, lane);
+    bool ok = dv >= 0;
+    uint32_t inv_c[NL], inv_lc[NL];
+    if (ok) {
+        uint32_t lcv[NL], w[NL], winv[NL];
+        lds_get<NL>(lcv, vp + (size_t)dv * NL);
+        mont_mul(w, cs, lcv, P);
+        fp_inv(winv, w, P);                        // the only inversion
+        mont_mul(inv_c, winv, lcv, P);             // 1 / cs
+        mont_mul(inv_lc, winv, cs, P);             // 1 / lc(V)
+    }
+    uint32_t *F = (vp == T0) ? T1 : T0;            // free array: quotient scratch
+    int df = -1;
+    if (ok) {
+        // error locator (true cofactor v) out, then make V monic in place
+        for (int idx = lane; idx <= dv; idx += 64) {
+            uint32_t u[NL], e[NL], ec[NL], m[NL];
+            lds_get<NL>(u, vp + (size_t)idx * NL);
+            mont_mul(e, u, inv_c, P);
+            from_mont(ec, e, P);
+            store_digits<NL, NW>(errloc + ((size_t)c * (npts + 1) + idx) * NW, ec);
+            mont_mul(m, u, inv_lc, P);
+            lds_put<NL>(vp + (size_t)idx * NL, m);
+        }
+        __syncthreads();
+        if (dr >= 0) {
+            if (dr < dv) ok = false;               // non-zero remainder
+            else {
+                const int dq = dr - dv;
+                for (int i = dq; i >= 0; i--) {
+                    uint32_t coef[NL];
+                    lds_get<NL>(coef, rp + (size_t)(i + dv) * NL);
+                    __syncthreads();
+                    if (lane == 0) lds_put<NL>(F + (size_t)i * NL, coef);
+                    for (int idx = lane; idx < dv; idx += 64) {
+                        uint32_t u[NL], w[NL], t2[NL], r[NL];
+                        lds_get<NL>(u, rp + (size_t)(i + idx) * NL);
+                        lds_get<NL>(w, vp + (size_t)idx * NL);
+                        mont_mul(t2, coef, w, P);
+                        fp_sub(r, u, t2, P);
+                        lds_put<NL>(rp + (size_t)(i + idx) * NL, r);
+                    }
+                    __syncthreads();
+                }
+                if (poly_degree<NL>(rp, dv - 1, lane) >= 0) ok = false;   // remainder must vanish
+                df = poly_degree<NL>(F, dq, lane);
+                if (df >= k) ok = false;
+            }
+        }
+    }
+    if (ok) {
+        for (int i = lane; i < k; i += 64) {
+            uint32_t o[NL];
+            if (i <= df) {
+                uint32_t u[NL], f[NL];
+                lds_get<NL>(u, F + (size_t)i * NL);
+                mont_mul(f, u, inv_lc, P);
+                from_mont(o, f, P);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NL; q++) o[q] = 0;
+            }
+            store_digits<NL, NW>(coeffs + ((size_t)c * k + i) * NW, o);
+        }
+    }
+    if (lane == 0) { okflag[c] = ok ? 1 : 0; errlen[c] = ok ? dv + 1 : 0; }
+}
+
+}  // namespace
+
+extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const uint64_t *ys_dev, int64_t C,
+                             uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream) {
+    if (!ctx || !x_host || npts < 1 || k < 0 || C < 0) return HB_ERR_BAD_ARG;
+    if (C == 0) return HB_OK;
+    if (!ys_dev || !coeffs_dev || !errloc_dev || !errloc_len_dev || !ok_dev) return HB_ERR_BAD_ARG;
+    if (npts > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "gao: more than 1023 points");
+    if (C > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "gao: batch too large");
+    hipStream_t s = (hipStream_t)stream;
+    const int NLr = ctx->nl();
+    // tables for this point set
+    hb_matrix *Vi = nullptr;
+    int rc = hb_vand_inverse_create(ctx, x_host, npts, &Vi, stream); if (rc) return rc;
+    std::string key = table_key("g0", ctx, x_host, npts, 0);
+    uint32_t *g0 = nullptr;
+    auto it = ctx->dcache.find(key);
+    if (it != ctx->dcache.end()) g0 = (uint32_t *)it->second;
+    else {
+        uint32_t *xd = nullptr;
+        rc = upload_elems(ctx, x_host, (size_t)npts, &xd, s); if (rc) return rc;
+        HB_HIP(ctx, hipMalloc(&g0, (size_t)(npts + 1) * NLr * 4));
+        int threads = ((npts + 1 + 63) / 64) * 64;
+        size_t lds = (size_t)(npts + 2 * (npts + 1)) * NLr * 4;
+        if (ctx->n_limbs == 4) {
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_poly_from_roots<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_poly_from_roots<9, 8><<<1, threads, lds, s>>>(ctx->pw, xd, npts, g0);
+        } else {
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_poly_from_roots<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_poly_from_roots<3, 2><<<1, threads, lds, s>>>(ctx->pn, xd, npts, g0);
+        }
+        HB_LAUNCH_CHECK(ctx);
+        HB_HIP(ctx, hipStreamSynchronize(s));
+        HB_HIP(ctx, hipFree(xd));
+        ctx->dcache[key] = g0;
+    }
+    // g1 for every codeword: coefficient-major [npts][C]
+    uint32_t *g1 = nullptr;
+    HB_HIP(ctx, hipMalloc(&g1, (size_t)npts * C * ctx->elem_words() * 4));
+    hb_view iv{npts, 1}, ov{1, C};
+    rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
+    if (rc) { (void)hipFree(g1); return rc; }
+    size_t lds = (size_t)4 * (npts + 1) * NLr * 4;
+    if (ctx->n_limbs == 4) {
+        HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev);
+    } else {
+        HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev);
+    }
+    HB_LAUNCH_CHECK(ctx);
+    HB_HIP(ctx, hipStreamSynchronize(s));
+    HB_HIP(ctx, hipFree(g1));
+    return HB_OK;
+}

@@ -1,0 +1,383 @@
+// hb_wb.hip -- Welch-Berlekamp Reed-Solomon decoding, batched: one workgroup per codeword.
+//
+// Reference functions replaced (pure Python in the reference, paths under /root/reference):
+//   make_wb_encoder_decoder.decode / solve_system   honeybadgermpc/reed_solomon_wb.py:79-151
+//   rref / no_solution / is_pivot_column / some_solution   reed_solomon_wb.py:157-273
+//   Polynomial.__divmod__ (exact division Q / E)            polynomial.py:219-234
+//
+// For e' = e .. 1 (e = (n - c - t) // 2): build the (n'+1) x (2e'+k+2) system
+//     b_i * E(a_i) - Q(a_i) = 0   for every non-erased point,   coefficient of X^e' in E = 1,
+// reduce it, set free variables to 1, and accept the first e' for which E | Q.
+//
+// The reference normalises every pivot row (one field inversion per pivot, ~n of them).
+// Here the elimination is FRACTION-FREE -- row_r <- piv * row_r - row_r[j] * row_piv --
+// which needs no inversion and spans the same row space, so the reduced row echelon form
+// (which is unique) is recovered at the end by scaling each pivot row with the inverse of
+// its pivot; all pivots are inverted together with Montgomery's trick (ONE inversion per
+// attempt).  The classification of columns into pivot / free variables replicates
+// is_pivot_column on that RREF, including its quirk of treating a free column that happens
+// to look like a unit vector as a pivot column, so the solution vector -- and therefore the
+// result outside the unique-decoding radius and the "No solution" / "found no divisors!"
+// outcomes -- is identical to the reference's.
+//
+// Matrix: Montgomery digits in HBM scratch (one slab per resident workgroup; at n = 100 a
+// slab is 371 KB, which does not fit the 160 KB LDS), multipliers and the pivot row staged in
+// LDS for every elimination step.
+#include "hb_common.hpp"
+
+using namespace hb;
+
+namespace {
+
+constexpr int WB_THREADS = 256;
+constexpr int WB_MAXROWS = 256;   // n' + 1 <= 256
+constexpr int WB_MAXCOLS = 264;
+
+template <int NL> __device__ __forceinline__ void mget(uint32_t (&d)[NL], const uint32_t *p) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) d[q] = p[q];
+}
+template <int NL> __device__ __forceinline__ void mput(uint32_t *p, const uint32_t (&d)[NL]) {
+#pragma unroll
+    for (int q = 0; q < NL; q++) p[q] = d[q];
+}
+template <int NL> __device__ __forceinline__ bool mzero(const uint32_t *p) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int q = 0; q < NL; q++) o |= p[q];
+    return o == 0;
+}
+template <int NL> __device__ __forceinline__ bool meq(const uint32_t *a, const uint32_t *b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int q = 0; q < NL; q++) o |= a[q] ^ b[q];
+    return o == 0;
+}
+
+template <int NL, int NW>
+__global__ void __launch_bounds__(WB_THREADS) k_wb(const FpParams<NL> P, const uint32_t *__restrict__ xm /* [n][NL] mont */,
+                                                   const uint32_t *__restrict__ ys, const uint8_t *__restrict__ present,
+                                                   int n, int k, int64_t C, uint32_t *__restrict__ scratch, size_t slab_words,
+                                                   uint32_t *__restrict__ coeffs, int32_t *__restrict__ coeff_len, int32_t *__restrict__ status) {
+    __shared__ uint32_t s_mult[WB_MAXROWS * NL];     // column-j multipliers of every row
+    __shared__ uint32_t s_prow[WB_MAXCOLS * NL];     // pivot row / later: solution vector
+    __shared__ uint32_t s_dinv[WB_MAXROWS * NL];     // inverse pivots
+    __shared__ uint32_t s_wrk[WB_MAXCOLS * NL];      // Q work copy / quotient
+    __shared__ int16_t s_perm[WB_MAXROWS];           // row order -> physical row
+    __shared__ int16_t s_pivcol[WB_MAXROWS];         // pivot column of the row at each position
+    __shared__ int16_t s_idx[WB_MAXROWS];            // present point indices, ascending
+    __shared__ int16_t s_cls[WB_MAXCOLS];            // per variable: -1 free, else the row position of its pivot
+    __shared__ int16_t s_free[WB_MAXCOLS];           // list of true free columns (for elimination range)
+    __shared__ int s_i[8];
+    const int tid = threadIdx.x;
+    uint32_t *M = scratch + (size_t)blockIdx.x * slab_words;
+
+    for (int64_t cw = blockIdx.x; cw < C; cw += gridDim.x) {
+        const uint32_t *y = ys + (size_t)cw * n * NW;
+        const uint8_t *pr = present + (size_t)cw * n;
+        __syncthreads();
+        if (tid == 0) {
+            int np_ = 0;
+            for (int i = 0; i < n; i++) if (pr[i]) s_idx[np_++] = (int16_t)i;
+            s_i[0] = np_;
+        }
+        __syncthreads();
+        const int np = s_i[0];
+        const int t = k - 1, cer = n - np;
+        uint32_t *out = coeffs + (size_t)cw * k * NW;
+        // zero the output row
+        for (int i = tid; i < k * NW; i += WB_THREADS) out[i] = 0;
+        if (2 * t + 1 + cer > n) {                   // assert 2t+1+c <= n  (reed_solomon_wb.py:132)
+            if (tid == 0) { status[cw] = 3; coeff_len[cw] = 0; }
+            continue;
+        }
+        const int e = (np - t) / 2;
+        if (e == 0) {                                // only k == 1, n' == 1: plain interpolation (:142-145)
+            if (tid == 0) {
+                uint32_t w[NW];
+                load_words<NW>(w, y + (size_t)s_idx[0] * NW);
+                uint32_t o = 0;
+                for (int q = 0; q < NW; q++) o |= w[q];
+                store_words<NW>(out, w);
+                status[cw] = 0; coeff_len[cw] = o ? 1 : 0;
+            }
+            continue;
+        }
+        int result_status = 1;                       // "found no divisors!" unless an e' succeeds
+        for (int ee = e; ee >= 1; ee--) {
+            const int env = ee + 1, qnv = ee + k, cols = env + qnv + 1, rows = np + 1;
+            // ---- build the system ---------------------------------------------------
+            if (tid < np) {
+                uint32_t a[NL], bd[NL], b[NL], pw[NL];
+                mget<NL>(a, xm + (size_t)s_idx[tid] * NL);
+                load_digits<NL, NW>(bd, y + (size_t)s_idx[tid] * NW);
+                to_mont(b, bd, P);
+                fp_set(pw, P.one);
+                uint32_t *row = M + (size_t)tid * cols * NL;
+                for (int j = 0; j < qnv; j++) {
+                    if (j < env) { uint32_t v[NL]; mont_mul(v, b, pw, P); mput<NL>(row + (size_t)j * NL, v); }
+                    uint32_t ng[NL]; fp_neg(ng, pw, P); mput<NL>(row + (size_t)(env + j) * NL, ng);
+                    mont_mul(pw, pw, a, P);
+                }
+                uint32_t z[NL];
+#pragma unroll
+                for (int q = 0; q < NL; q++) z[q] = 0;
+                mput<NL>(row + (size_t)(cols - 1) * NL, z);
+            }
+            {
+                uint32_t *row = M + (size_t)np * cols * NL;
+                for (int j = tid; j < cols; j += WB_THREADS) {
+                    uint32_t v[NL];
+#pragma unroll
+                    for (int q = 0; q < NL; q++) v[q] = (j == env - 1 || j == cols - 1) ? P.one[q] : 0u;
+                    mput<NL>(row + (size_t)j * NL, v);
+                }
+            }
+            if (tid < rows) s_perm[tid] = (int16_t)tid;
+            __syncthreads();
+            // ---- fraction-free Gauss-Jordan ----------------------------------------------
+            int ipos = 0, nfree = 0;
+            bool inconsistent = false;
+            for (int j = 0; j < cols && ipos < rows; j++) {
+                if (tid == 0) s_i[1] = rows;
+                __syncthreads();
+                for (int r = ipos + tid; r < rows; r += WB_THREADS)
+                    if (!mzero<NL>(M + ((size_t)s_perm[r] * cols + j) * NL)) atomicMin(&s_i[1], r);
+                __syncthreads();
+                const int found = s_i[1];
+                if (found == rows) {                 // no pivot in this column: free variable
+                    if (tid == 0 && j < cols - 1) s_free[nfree] = (int16_t)j;
+                    if (j < cols - 1) nfree++;
+                    __syncthreads();
+                    continue;
+                }
+                if (j == cols - 1) { inconsistent = true; break; }   // pivot in the constants column
+                if (tid == 0) {
+                    int16_t tmp = s_perm[ipos]; s_perm[ipos] = s_perm[found]; s_perm[found] = tmp;
+                    s_pivcol[ipos] = (int16_t)j;
+                }
+                __syncthreads();
+                const int prow = s_perm[ipos];
+                const int cmin = nfree > 0 ? min((int)s_free[0], j) : j;
+                const int width = cols - cmin;
+                // stage multipliers (column j of every row) and the pivot row
+                for (int r = tid; r < rows; r += WB_THREADS) {
+                    uint32_t v[NL]; mget<NL>(v, M + ((size_t)s_perm[r] * cols + j) * NL); mput<NL>(s_mult + (size_t)r * NL, v);
+                }
+                for (int cc = tid; cc < width; cc += WB_THREADS) {
+                    uint32_t v[NL]; mget<NL>(v, M + ((size_t)prow * cols + cmin + cc) * NL); mput<NL>(s_prow + (size_t)cc * NL, v);
+                }
+                __syncthreads();
+                uint32_t piv[NL];
+                mget<NL>(piv, s_mult + (size_t)ipos * NL);
+                const int tot = rows * width;
+                for (int idx = tid; idx < tot; idx += WB_THREADS) {
+                    const int r = idx / width, cc = idx % width;
+                    if (r == ipos) continue;
+                    uint32_t m[NL];
+                    mget<NL>(m, s_mult + (size_t)r * NL);
+                    if (fp_is_zero(m)) continue;     // rsdecode: rows with a zero in column j are left alone (:187)
+                    uint32_t *cell = M + ((size_t)s_perm[r] * cols + cmin + cc) * NL;
+                    uint32_t v[NL], pv[NL], t1[NL], t2[NL], res[NL];
+                    mget<NL>(v, cell);
+                    mget<NL>(pv, s_prow + (size_t)cc * NL);
+                    mont_mul(t1, piv, v, P);
+                    mont_mul(t2, m, pv, P);
+                    fp_sub(res, t1, t2, P);
+                    mput<NL>(cell, res);
+                }
+                // a scaled row also scales its own (earlier) pivot entry, which lies left of cmin
+                for (int r = tid; r < ipos; r += WB_THREADS) {
+                    const int pc = s_pivcol[r];
+                    if (pc >= cmin) continue;        // already covered by the range update
+                    uint32_t m[NL];
+                    mget<NL>(m, s_mult + (size_t)r * NL);
+                    if (fp_is_zero(m)) continue;
+                    uint32_t *cell = M + ((size_t)s_perm[r] * cols + pc) * NL;
+                    uint32_t v[NL], res[NL];
+                    mget<NL>(v, cell);
+                    mont_mul(res, piv, v, P);
+                    mput<NL>(cell, res);
+                }
+                __syncthreads();
+                ipos++;
+            }
+            __syncthreads();
+            if (inconsistent) { result_status = 2; break; }          // raise Exception("No solution") (:245)
+            const int npiv = ipos;
+            const int nvars = cols - 1;
+            // ---- invert all pivots at once (Montgomery's trick) --------------------------
+            if (tid == 0) {
+                uint32_t acc[NL];
+                fp_set(acc, P.one);
+                for (int r = 0; r < npiv; r++) {      // prefix products into s_dinv
+                    uint32_t pv[NL];
+                    mget<NL>(pv, M + ((size_t)s_perm[r] * cols + s_pivcol[r]) * NL);
+                    mput<NL>(s_dinv + (size_t)r * NL, acc);
+                    mont_mul(acc, acc, pv, P);
+                }
+                uint32_t inv[NL];
+                fp_inv(inv, acc, P);
+                for (int r = npiv - 1; r >= 0; r--) {
+                    uint32_t pv[NL], pre[NL], d[NL];
+                    mget<NL>(pv, M + ((size_t)s_perm[r] * cols + s_pivcol[r]) * NL);
+                    mget<NL>(pre, s_dinv + (size_t)r * NL);
+                    mont_mul(d, inv, pre, P);
+                    mput<NL>(s_dinv + (size_t)r * NL, d);
+                    mont_mul(inv, inv, pv, P);
+                }
+            }
+            // ---- classify the variables like is_pivot_column on the RREF (:217-237) ----------
+            for (int j = tid; j < nvars; j += WB_THREADS) {
+                int first = -1; bool others_zero = true;
+                for (int r = 0; r < npiv; r++) {
+                    if (!mzero<NL>(M + ((size_t)s_perm[r] * cols + j) * NL)) {
+                        if (first < 0) first = r; else { others_zero = false; break; }
+                    }
+                }
+                int cls = -1;
+                if (first >= 0 && others_zero) {
+                    // normalised entry == 1  <=>  entry == the row's pivot entry
+                    const uint32_t *row = M + (size_t)s_perm[first] * cols * NL;
+                    if (meq<NL>(row + (size_t)j * NL, row + (size_t)s_pivcol[first] * NL)) cls = first;
+                }
+                s_cls[j] = (int16_t)cls;
+            }
+            __syncthreads();
+            // ---- solution: free variables = 1, pivot variables from their row (:254-271) -----
+            for (int j = tid; j < nvars; j += WB_THREADS) {
+                uint32_t val[NL];
+                const int r = s_cls[j];
+                if (r < 0) fp_set(val, P.one);
+                else {
+                    const uint32_t *row = M + (size_t)s_perm[r] * cols * NL;
+                    uint32_t acc[NL];
+                    mget<NL>(acc, row + (size_t)(cols - 1) * NL);
+                    for (int f = 0; f < nvars; f++) {
+                        if (s_cls[f] >= 0) continue;
+                        uint32_t v[NL];
+                        mget<NL>(v, row + (size_t)f * NL);
+                        fp_sub(acc, acc, v, P);
+                    }
+                    uint32_t dv[NL];
+                    mget<NL>(dv, s_dinv + (size_t)r * NL);
+                    mont_mul(val, acc, dv, P);
+                }
+                mput<NL>(s_prow + (size_t)j * NL, val);
+            }
+            __syncthreads();
+            // ---- E | Q ?  (E = sol[0..env), Q = sol[env..), both with trailing zeros stripped) --
+            const uint32_t *E = s_prow;
+            const uint32_t *Q = s_prow + (size_t)env * NL;
+            if (tid == 0) {
+                int dE = env - 1; while (dE >= 0 && mzero<NL>(E + (size_t)dE * NL)) dE--;
+                int dQ = qnv - 1; while (dQ >= 0 && mzero<NL>(Q + (size_t)dQ * NL)) dQ--;
+                s_i[2] = dE; s_i[3] = dQ;
+            }
+            for (int j = tid; j < qnv; j += WB_THREADS) { uint32_t v[NL]; mget<NL>(v, Q + (size_t)j * NL); mput<NL>(s_wrk + (size_t)j * NL, v); }
+            __syncthreads();
+            const int dE = s_i[2], dQ = s_i[3];
+            bool exact;
+            int dP = -1;
+            if (dE < 0) exact = false;               // cannot happen: coefficient ee of E is pinned to 1
+            else if (dQ < dE) exact = (dQ < 0);      // quotient 0, remainder Q
+            else {
+                // long division of the work copy by E (leading coefficient lcE, inverted once)
+                uint32_t lcinv[NL];
+                {
+                    uint32_t lc[NL];
+                    mget<NL>(lc, E + (size_t)dE * NL);
+                    if (fp_eq(lc, P.one)) fp_set(lcinv, P.one); else fp_inv(lcinv, lc, P);
+                }
+                uint32_t *quo = s_mult;               // reuse: quotient coefficients
+                for (int i = dQ - dE; i >= 0; i--) {
+                    uint32_t top[NL], coef[NL];
+                    mget<NL>(top, s_wrk + (size_t)(i + dE) * NL);
+                    mont_mul(coef, top, lcinv, P);
+                    __syncthreads();
+                    if (tid == 0) mput<NL>(quo + (size_t)i * NL, coef);
+                    for (int idx = tid; idx <= dE; idx += WB_THREADS) {
+                        uint32_t u[NL], w[NL], t2[NL], r[NL];
+                        mget<NL>(u, s_wrk + (size_t)(i + idx) * NL);
+                        mget<NL>(w, E + (size_t)idx * NL);
+                        mont_mul(t2, coef, w, P);
+                        fp_sub(r, u, t2, P);
+                        mput<NL>(s_wrk + (size_t)(i + idx) * NL, r);
+                    }
+                    __syncthreads();
+                }
+                if (tid == 0) {
+                    int rem = dE - 1; while (rem >= 0 && mzero<NL>(s_wrk + (size_t)rem * NL)) rem--;
+                    int dp = dQ - dE; while (dp >= 0 && mzero<NL>(quo + (size_t)dp * NL)) dp--;
+                    s_i[4] = rem; s_i[5] = dp;
+                }
+                __syncthreads();
+                exact = s_i[4] < 0;
+                dP = s_i[5];
+            }
+            if (exact) {
+                // P = Q / E, coefficients stripped of trailing zeros (polynomial.py:36)
+                for (int i = tid; i <= dP && i < k; i += WB_THREADS) {
+                    uint32_t v[NL], cnn[NL];
+                    mget<NL>(v, s_mult + (size_t)i * NL);
+                    from_mont(cnn, v, P);
+                    store_digits<NL, NW>(out + (size_t)i * NW, cnn);
+                }
+                if (tid == 0) coeff_len[cw] = dP + 1;
+                result_status = 0;
+                __syncthreads();
+                break;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { status[cw] = result_status; if (result_status != 0) coeff_len[cw] = 0; }
+    }
+}
+
+template <int NL, int NW>
+__global__ void k_points_to_mont(const FpParams<NL> P, const uint32_t *__restrict__ x, int n, uint32_t *__restrict__ xm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t d[NL], m[NL];
+    load_digits<NL, NW>(d, x + (size_t)i * NW);
+    to_mont(m, d, P);
+#pragma unroll
+    for (int q = 0; q < NL; q++) xm[(size_t)i * NL + q] = m[q];
+}
+
+}  // namespace
+
+extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, const uint64_t *ys_dev,
+                            const uint8_t *present_dev, int64_t C, uint64_t *coeffs_dev, int32_t *coeff_len_dev,
+                            int32_t *status_dev, void *stream) {
+    if (!ctx || !x_host || n < 1 || k < 1 || k > n || C < 0) return HB_ERR_BAD_ARG;
+    if (C == 0) return HB_OK;
+    if (!ys_dev || !present_dev || !coeffs_dev || !coeff_len_dev || !status_dev) return HB_ERR_BAD_ARG;
+    if (n + 1 > WB_MAXROWS || n + 4 > WB_MAXCOLS) return fail(ctx, HB_ERR_UNSUPPORTED, "welch-berlekamp: n > 255");
+    hipStream_t s = (hipStream_t)stream;
+    const int NLr = ctx->nl();
+    uint32_t *xd = nullptr, *xm = nullptr;
+    int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
+    HB_HIP(ctx, hipMalloc(&xm, (size_t)n * NLr * 4));
+    HB_DISPATCH(ctx,
+        (k_points_to_mont<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, xd, n, xm)),
+        (k_points_to_mont<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, xd, n, xm)));
+    HB_LAUNCH_CHECK(ctx);
+    // worst-case slab: (n+1) rows x (2e+k+2) columns with e <= (n - k + 1) / 2
+    const int emax = (n - (k - 1)) / 2;
+    const size_t slab_words = (size_t)(n + 1) * (size_t)(2 * emax + k + 2) * NLr;
+    int64_t blocks = C < 1024 ? C : 1024;
+    uint32_t *scratch = nullptr;
+    HB_HIP(ctx, hipMalloc(&scratch, slab_words * 4 * (size_t)blocks));
+    HB_DISPATCH(ctx,
+        (k_wb<9, 8><<<(unsigned)blocks, WB_THREADS, 0, s>>>(ctx->pw, xm, (const uint32_t *)ys_dev, present_dev, n, k, C, scratch, slab_words,
+                                                          (uint32_t *)coeffs_dev, coeff_len_dev, status_dev)),
+        (k_wb<3, 2><<<(unsigned)blocks, WB_THREADS, 0, s>>>(ctx->pn, xm, (const uint32_t *)ys_dev, present_dev, n, k, C, scratch, slab_words,
+                                                          (uint32_t *)coeffs_dev, coeff_len_dev, status_dev)));
+    HB_LAUNCH_CHECK(ctx);
+    HB_HIP(ctx, hipStreamSynchronize(s));
+    HB_HIP(ctx, hipFree(scratch));
+    HB_HIP(ctx, hipFree(xd));
+    HB_HIP(ctx, hipFree(xm));
+    return HB_OK;
+}

@@ -403,3 +403,107 @@ def test_fft_roundtrip_full_size_cfg2(golden):
     want = oracle.fft_batch_evaluate([sub[i * d : (i + 1) * d] for i in range(1024)], golden("constants.json")["omega"]["16"], P, n, n)
     got = ctx.download_ints(ev[: 1024 * n])
     assert [got[i * n : (i + 1) * n] for i in range(1024)] == want
+
+
+# ------------------------------------------------------------------ robust decoders
+def _corrupt(rnd, word, ne, nn, p):
+    word = list(word)
+    idx = rnd.sample(range(len(word)), ne + nn)
+    for i in range(ne):
+        new = rnd.randrange(p)
+        while new == word[idx[i]]:
+            new = rnd.randrange(p)
+        word[idx[i]] = new
+    for i in range(nn):
+        word[idx[i + ne]] = None
+    return word, sorted(idx[:ne])
+
+
+def test_gao_reference_vectors(hip):  # reference tests/test_ntl.py:196-265
+    rnd = random.Random(31)
+    for int_msg in ([2, 3, 2, 8, 7, 5, 9, 5], [0] * 8):
+        k, n, p = 8, 22, 53
+        t = k - 1
+        x = list(range(n))
+        encoded = [sum(int_msg[j] * pow(x[i], j, p) for j in range(k)) % p for i in range(n)]
+        cmax, emax = n - 2 * t - 1, (n - 2 * t - 1) // 2
+        for ne, nn in [(0, 0), (0, cmax), (emax, 0), (emax // 2, cmax // 4)]:
+            for _ in range(4):
+                word, _ = _corrupt(rnd, encoded, ne, nn, p)
+                got = hip.gao_interpolate(x, word, k, p)
+                assert got[0] == int_msg
+                assert got == oracle.gao_interpolate(x, word, k, p)     # incl. the un-normalised error locator
+
+
+@pytest.mark.parametrize("p,n,k", [(P, 4, 2), (P, 16, 6), (P, 64, 22), (P, 100, 34), (53, 22, 8), ((1 << 256) - 189, 31, 11)])
+def test_gao_batch_vs_oracle(hip, p, n, k):
+    rnd = random.Random(n * 31 + k)
+    x = list(range(1, n + 1))
+    emax = (n - k) // 2
+    words = []
+    for trial in range(24):
+        msg = [rnd.randrange(p) for _ in range(k)]
+        if trial == 0:
+            msg = [0] * k
+        enc = oracle.vandermonde_batch_evaluate(x, [msg], p)[0]
+        ne = [0, emax, emax // 2, 1 if emax else 0, emax + 1, n][trial % 6]      # the last two are beyond the radius
+        ne = min(ne, n)
+        words.append(_corrupt(rnd, enc, ne, 0, p)[0])
+    got = hip.gao_interpolate_batch(x, words, k, p)
+    want = oracle.gao_interpolate_batch(x, words, k, p)
+    assert got == want
+    assert any(g[0] is None for g in got) or emax == 0 or p == 53
+
+
+def test_gao_omega_and_erasures(hip, golden):  # reference tests/test_ntl.py:268-314
+    rnd = random.Random(33)
+    omega, order, n, k = golden("constants.json")["omega"]["32"], 32, 22, 8
+    z = list(range(n))
+    x = [pow(omega, zi, P) for zi in z]
+    msg = [2, 3, 2, 8, 7, 5, 9, 5]
+    enc = [sum(msg[j] * pow(x[i], j, P) for j in range(k)) % P for i in range(n)]
+    for ne, nn in [(0, 0), (0, 7), (3, 0), (1, 1), (2, 3)]:
+        word, _ = _corrupt(rnd, enc, ne, nn, P)
+        got = hip.gao_interpolate(x, word, k, P, z=z, omega=omega, order=order, use_omega_powers=True)
+        assert got[0] == msg
+        assert got == oracle.gao_interpolate(x, word, k, P, z=z, omega=omega, order=order, use_omega_powers=True)
+
+
+def test_wb_golden_hip(golden):
+    """every reference Welch-Berlekamp outcome (incl. beyond-radius results and both failure
+    messages) through the HIP kernel, batched per (n, k, p)"""
+    from honeybadgermpc_amd.device import wb_decode_batch
+
+    cases = golden("welch_berlekamp.json")["cases"]
+    groups = {}
+    for case in cases:
+        groups.setdefault((case["p"], case["n"], case["k"]), []).append(case)
+    seen = set()
+    for (p, n, k), group in groups.items():
+        res = wb_decode_batch(group[0]["x"], k, [c["word"] for c in group], p)
+        for case, (coeffs, status) in zip(group, res):
+            if case["error"] is None:
+                assert status == 0 and coeffs == case["coeffs"], (p, n, k, case["word"])
+            else:
+                assert coeffs is None and oracle.WB_MESSAGES[status] == case["error"]
+            seen.add(case["error"])
+    assert seen == {None, "No solution", "found no divisors!"}
+
+
+@pytest.mark.parametrize("p,n,k,reps", [(P, 100, 34, 6), (P, 64, 22, 8), (53, 22, 8, 40), (13, 10, 3, 40), (P, 7, 1, 6)])
+def test_wb_batch_vs_oracle(p, n, k, reps):
+    from honeybadgermpc_amd.device import wb_decode_batch
+
+    rnd = random.Random(n + k)
+    x = list(range(1, n + 1))
+    t = k - 1
+    words = []
+    for trial in range(reps):
+        msg = [rnd.randrange(p) for _ in range(k)]
+        enc = oracle.vandermonde_batch_evaluate(x, [msg], p)[0]
+        cmax = n - 2 * t - 1
+        nn = rnd.randrange(0, cmax + 1) if trial % 3 == 0 else 0
+        emax = (n - nn - t) // 2
+        ne = [emax, 0, emax // 2, emax + 1, min(n - nn, 2 * emax + 1)][trial % 5]
+        words.append(_corrupt(rnd, enc, min(ne, n - nn), nn, p)[0])
+    assert wb_decode_batch(x, k, words, p) == oracle.wb_decode_batch(x, k, words, p)
