@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per kernel AND launch geometry, so the
+encode / decode / validate launches of k_matvec are separated.  Usage:
+    python profiles/summarize_rocpd.py gpurun_out/prof_r1/bench_results.db > profiles/r01_....txt"""
+import re
+import sqlite3
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    return name if len(name) < 90 else name[:87] + "..."
+
+
+def main(path):
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, duration from kernels").fetchall()
+    groups = {}
+    for name, gx, wx, vg, av, sg, lds, dur in rows:
+        groups.setdefault((short(name), gx, wx, vg, av, sg, lds), []).append(dur)
+    total = sum(sum(v) for v in groups.values())
+    print(f"{'kernel':<60} {'grid':>9} {'wg':>4} {'vgpr':>5} {'sgpr':>5} {'lds':>6} {'calls':>6} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'total_ms':>9} {'%':>6}")
+    for key, durs in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+        name, gx, wx, vg, av, sg, lds = key
+        n = len(durs)
+        print(f"{name:<60.60} {gx:>9} {wx:>4} {vg + av:>5} {sg:>5} {lds:>6} {n:>6} {sum(durs) / n / 1e3:>10.2f} {min(durs) / 1e3:>10.2f} {max(durs) / 1e3:>10.2f} {sum(durs) / 1e6:>9.3f} {100 * sum(durs) / total:>6.2f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
