@@ -99,6 +99,17 @@ int launch_matvec(hb_ctx *ctx, const hb_matrix *m, const uint32_t *in, hb_view i
                   int64_t C, hipStream_t s);
 int launch_copy_view(hb_ctx *ctx, const uint32_t *src, hb_view sv, uint32_t *dst, hb_view dv, int64_t C, int L, int64_t dst_count, hipStream_t s);
 
+// ---- second-generation (raw small-entry matrix) path, hb_fast.hip ----------------------
+struct FastMatrix;
+void fast_matrix_free(FastMatrix *m);
+int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s);
+int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s);
+int launch_prescale(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_view iv, const int32_t *rows_dev, int64_t in_count,
+                    uint32_t *out_dg, int64_t C, hipStream_t s);
+int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg, uint32_t *out_pk, hb_view ov, int64_t out_count,
+                   int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+                   int64_t C, hipStream_t s);
+
 // dispatch on element width
 #define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \
     do {                                                                                          \

@@ -1,0 +1,413 @@
+// hb_fast.hip -- second-generation batched mat-vec for the per-party open: raw (non-Montgomery)
+// matrices with per-term digit counts, inputs pre-scaled once into Montgomery digit planes.
+//
+// Same reference functions as k_matvec (mat_ZZ_p mul at hbmpc_ntl_helpers.pyx:183,237;
+// set_vm_matrix rsdecode_impl.h:23-36; vandermonde_inverse rsdecode_impl.h:97-122); what
+// changes is how much arithmetic the product costs on this hardware:
+//
+//   * At the production evaluation points x_i = i+1 (EvalPoint without omega powers,
+//     polynomial.py:418-421) the Vandermonde entry (i+1)^l is a SMALL integer: 1 digit for
+//     l <= 4, 2 for l <= 9, ... 5 for l = 21 at n = 64.  Kept raw (not multiplied by R) a term
+//     costs 9 * digits(l) MADs instead of 81 -- 3.3x fewer over a degree-21 row.
+//   * V(x)^-1 factors as  Vinv[m][j] = (-1)^(k-1-m) * N[m][j] / den_j  with
+//     N[m][j] = coeff_m prod_{q != j} (X + x_q)  (non-negative, small when the x are small) and
+//     den_j = prod_{q != j} (x_j - x_q).  The sign is per OUTPUT row and 1/den_j per INPUT
+//     column, so the decode product also runs on small raw entries.
+//   * To use raw matrices the inputs carry the Montgomery factor instead: a pre-pass
+//     (k_prescale) multiplies every input element once by K_l (R^2 for encode, R^3/den_l for
+//     decode) and writes 29-bit digit planes [l][digit][C], so the hot kernel's loads are
+//     perfectly coalesced dword loads with no unpacking.  With K = R^3/den the decode outputs
+//     come out of REDC already in Montgomery form, which is exactly what the validating
+//     re-encode wants as input -- no conversion between the two kernels.
+//   The identities hold mod p for ANY points; when the points are large (omega powers) the
+//   digit counts are simply 9 and the cost equals the first-generation kernel's.
+#include "hb_common.hpp"
+
+using namespace hb;
+
+namespace hb {
+
+struct FastMatrix {
+    int n_out, n_in;
+    uint32_t *M;        // raw canonical digits, [tile][l][digit][OT]
+    int32_t *nd;        // [tile][n_in] digits actually non-zero in that tile/term
+    int32_t *negrow;    // [n_out] 1 => negate the output row (nullptr: none)
+    uint32_t *K;        // [n_in][NL] pre-scale constants (canonical digits; used as a mont_mul factor)
+};
+
+}  // namespace hb
+
+namespace {
+
+// digit-plane addressing: element (l, c), digit q  ->  ((l * NL + q) * C + c)
+__device__ __forceinline__ size_t dg_index(int l, int q, int64_t c, int64_t C, int nl) { return ((size_t)l * nl + q) * (size_t)C + (size_t)c; }
+
+// out(l, c) = in(c, rows[l]) * K_l / R   (zero beyond in_count)
+template <int NL, int NW>
+__global__ void __launch_bounds__(256) k_prescale(const FpParams<NL> P, const uint32_t *__restrict__ in, int64_t in_sc, int64_t in_sl,
+                                                  const int32_t *__restrict__ rows, int64_t in_count, const uint32_t *__restrict__ K,
+                                                  int n_in, int64_t C, uint32_t *__restrict__ out) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (c >= C) return;
+    const int row = rows ? rows[l] : l;
+    const int64_t idx = c * in_sc + (int64_t)row * in_sl;
+    uint32_t r[NL];
+    if (idx < in_count) {
+        uint32_t xd[NL], kd[NL];
+        load_digits<NL, NW>(xd, in + idx * NW);
+#pragma unroll
+        for (int q = 0; q < NL; q++) kd[q] = K[(size_t)l * NL + q];
+        mont_mul(r, xd, kd, P);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NL; q++) r[q] = 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NL; q++) out[dg_index(l, q, c, C, NL)] = r[q];
+}
+
+// V[i][l] = x_i^l as raw canonical digits in kernel layout
+template <int NL, int NW>
+__global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uint32_t *__restrict__ x, int n, int d, uint32_t *__restrict__ M) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t xd[NL], xm[NL], pw[NL];
+    load_digits<NL, NW>(xd, x + (size_t)i * NW);
+    to_mont(xm, xd, P);
+    fp_set(pw, P.one);
+    for (int l = 0; l < d; l++) {
+        uint32_t c[NL];
+        from_mont(c, pw, P);
+#pragma unroll
+        for (int q = 0; q < NL; q++) M[m_index(i, l, d, NL, q)] = c[q];
+        mont_mul(pw, pw, xm, P);
+    }
+}
+
+// factored inverse Vandermonde: N (raw), negrow, K_j = R^3 / den_j.  One block, thread j owns point j.
+template <int NL, int NW>
+__global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const uint32_t *__restrict__ x, int k, uint32_t *__restrict__ M,
+                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, int *__restrict__ singular) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *xs = smem;
+    uint32_t *B0 = xs + (size_t)k * NL;
+    uint32_t *B1 = B0 + (size_t)(k + 1) * NL;
+    const int t = threadIdx.x;
+    uint32_t xj[NL];
+    if (t < k) {
+        uint32_t xd[NL];
+        load_digits<NL, NW>(xd, x + (size_t)t * NW);
+        to_mont(xj, xd, P);
+#pragma unroll
+        for (int q = 0; q < NL; q++) xs[t * NL + q] = xj[q];
+    }
+    if (t <= k) {
+#pragma unroll
+        for (int q = 0; q < NL; q++) B0[t * NL + q] = (t == 0) ? P.one[q] : 0u;
+    }
+    __syncthreads();
+    uint32_t *cur = B0, *nxt = B1;
+    for (int j = 0; j < k; j++) {              // B <- B * (X + x_j): B'[m] = B[m-1] + x_j * B[m]
+        if (t <= k) {
+            uint32_t a[NL], am1[NL], xv[NL], prod[NL], r[NL];
+#pragma unroll
+            for (int q = 0; q < NL; q++) { a[q] = cur[t * NL + q]; am1[q] = (t > 0) ? cur[(t - 1) * NL + q] : 0u; xv[q] = xs[j * NL + q]; }
+            mont_mul(prod, xv, a, P);
+            fp_add(r, am1, prod, P);
+#pragma unroll
+            for (int q = 0; q < NL; q++) nxt[t * NL + q] = r[q];
+        }
+        __syncthreads();
+        uint32_t *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (t < k && negrow) negrow[t] = ((k - 1 - t) & 1) ? 1 : 0;
+    if (t >= k) return;
+    // B_j = B / (X + x_j): b_{k-1} = B_k (= 1), b_{m-1} = B_m - x_j b_m.
+    // den_j = prod_{q != j} (x_j - x_q) = (-1)^(k-1) * B_j(-x_j)   (Horner at -x_j)
+    uint32_t b[NL], ev[NL], nx[NL], a[NL], tmp[NL];
+    fp_neg(nx, xj, P);
+#pragma unroll
+    for (int w = 0; w < NL; w++) b[w] = cur[k * NL + w];
+    fp_set(ev, b);
+    {
+        uint32_t c[NL];
+        from_mont(c, b, P);
+#pragma unroll
+        for (int w = 0; w < NL; w++) M[m_index(k - 1, t, k, NL, w)] = c[w];
+    }
+    for (int m = k - 1; m >= 1; m--) {
+#pragma unroll
+        for (int w = 0; w < NL; w++) a[w] = cur[m * NL + w];
+        mont_mul(tmp, xj, b, P);
+        fp_sub(b, a, tmp, P);                  // b_{m-1}
+        uint32_t c[NL];
+        from_mont(c, b, P);
+#pragma unroll
+        for (int w = 0; w < NL; w++) M[m_index(m - 1, t, k, NL, w)] = c[w];
+        mont_mul(tmp, ev, nx, P);
+        fp_add(ev, tmp, b, P);
+    }
+    uint32_t den[NL];
+    if ((k - 1) & 1) fp_neg(den, ev, P); else fp_set(den, ev);
+    if (fp_is_zero(den)) { atomicOr(singular, 1); return; }
+    uint32_t dinv[NL], t1[NL], t2[NL];
+    fp_inv(dinv, den, P);                      // R / den
+    mont_mul(t1, dinv, P.r2, P);               // R^2 / den
+    mont_mul(t2, t1, P.r2, P);                 // R^3 / den   (canonical digits; mont_mul(y, .) = y R^2 / den)
+#pragma unroll
+    for (int w = 0; w < NL; w++) K[(size_t)t * NL + w] = t2[w];
+}
+
+// nd[tile][l] = 1 + index of the highest non-zero digit over the tile's OT outputs (0 if all zero)
+template <int NL>
+__global__ void k_count_digits(const uint32_t *__restrict__ M, int tiles, int n_in, int32_t *__restrict__ nd) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= tiles * n_in) return;
+    const uint32_t *e = M + (size_t)idx * NL * OT;
+    int top = 0;
+    for (int q = 0; q < NL; q++)
+        for (int o = 0; o < OT; o++) if (e[q * OT + o]) top = q + 1;
+    nd[idx] = top;
+}
+
+// -------------------------------------------------------------------------------------
+// k_matvec2: res(c, i) = REDC( sum_l M[i][l] * in_dg(l, c) ),  optionally negated per row.
+//   in_dg  : Montgomery digit planes [n_in][NL][C] (from k_prescale or a previous k_matvec2)
+//   out_dg : digit planes of res [n_out][NL][C]                       (nullptr: skip)
+//   out_pk : packed canonical; rows i < pk_rows only; value = pk_from_mont ? res / R : res
+//   CHECK  : compare packed res with expect(c, i) for rows in check_mask
+// Mapping as k_matvec (lane = chunk, wave = 64 chunks x 4 outputs, matrix operand in SGPRs,
+// next term's scalar tile + 9 coalesced digit loads in flight during the MAC block).
+// -------------------------------------------------------------------------------------
+template <int NL, int NW, bool CHECK>
+__global__ void __launch_bounds__(256) k_matvec2(const FpParams<NL> P, const uint32_t *__restrict__ M, const int32_t *__restrict__ ndt,
+                                                 const int32_t *__restrict__ negrow, int n_out, int n_in, int nsub,
+                                                 const uint32_t *__restrict__ in_dg,
+                                                 uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
+                                                 int pk_rows, int pk_from_mont, uint32_t *__restrict__ out_dg,
+                                                 const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
+                                                 int64_t C, int tiles, int64_t n_waves) {
+    static_assert(OT == 4, "matrix tile is loaded as uint4 per digit");
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t nb8 = gridDim.x >> 3;
+    const int64_t vb = (int64_t)(blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
+    const int64_t wave = vb * 4 + wib;
+    if (wave >= n_waves) return;
+    const int tile = (int)(wave % tiles);
+    const int64_t g = wave / tiles;
+    const int64_t c = g * 64 + lane;
+    const bool active = c < C;
+    const int64_t cc = active ? c : (C - 1);
+    const int nv = min(OT, n_out - tile * OT);
+    const uint4 *mt = reinterpret_cast<const uint4 *>(M) + (size_t)tile * n_in * NL;
+    const int32_t *ndp = ndt + (size_t)tile * n_in;
+    const uint32_t *xin = in_dg + cc;
+    constexpr int GROUP = Lazy<NL>::GROUP;
+
+    uint64_t col[OT][2 * NL];
+#pragma unroll
+    for (int o = 0; o < OT; o++) col_zero(col[o]);
+
+    uint4 mc[NL], mn[NL];
+    uint32_t xc[NL], xn[NL];
+    int ndc, ndn;
+#pragma unroll
+    for (int q = 0; q < NL; q++) mc[q] = mt[q];
+    ndc = ndp[0];
+#pragma unroll
+    for (int q = 0; q < NL; q++) xc[q] = xin[(size_t)q * C];
+    int gcnt = 0;
+    for (int l = 0; l < n_in; l++) {
+        const int ln = (l + 1 < n_in) ? l + 1 : l;
+#pragma unroll
+        for (int q = 0; q < NL; q++) mn[q] = mt[(size_t)ln * NL + q];
+        ndn = ndp[ln];
+#pragma unroll
+        for (int q = 0; q < NL; q++) xn[q] = xin[((size_t)ln * NL + q) * C];
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t xu[NL];
+#pragma unroll
+        for (int q = 0; q < NL; q++) { xu[q] = xc[q]; asm volatile("" : "+v"(xu[q])); }
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            if (i < ndc) {
+#pragma unroll
+                for (int o = 0; o < OT; o++) {
+                    const uint32_t md = (o == 0) ? mc[i].x : (o == 1) ? mc[i].y : (o == 2) ? mc[i].z : mc[i].w;
+#pragma unroll
+                    for (int j = 0; j < NL; j++) col[o][i + j] += (uint64_t)md * xu[j];
+                }
+            }
+        }
+        if (++gcnt == GROUP) {
+            gcnt = 0;
+#pragma unroll
+            for (int o = 0; o < OT; o++) carry(col[o]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NL; q++) { mc[q] = mn[q]; xc[q] = xn[q]; }
+        ndc = ndn;
+    }
+#pragma unroll
+    for (int o = 0; o < OT; o++) {
+        if (o < nv) {
+            const int i = tile * OT + o;
+            uint32_t r[NL];
+            carry(col[o]);
+            redc(r, col[o], P);
+            for (int s = 0; s < nsub; s++) cond_sub_p(r, P);
+            if (negrow && negrow[i]) fp_neg(r, r, P);
+            if (out_dg && active) {
+#pragma unroll
+                for (int q = 0; q < NL; q++) out_dg[dg_index(i, q, c, C, NL)] = r[q];
+            }
+            if constexpr (CHECK) {
+                if (check_mask[i] && active) {
+                    uint32_t w[NW], e[NW];
+                    pack<NL, NW>(w, r);
+                    load_words<NW>(e, out_pk + (cc * out_sc + (int64_t)i * out_sl) * NW);
+                    uint32_t diff = 0;
+#pragma unroll
+                    for (int q = 0; q < NW; q++) diff |= e[q] ^ w[q];
+                    if (diff) atomicOr(mismatch, 1);
+                }
+            } else {
+                if (out_pk && i < pk_rows && active) {
+                    const int64_t oidx = cc * out_sc + (int64_t)i * out_sl;
+                    if (oidx < out_count) {
+                        uint32_t v[NL], w[NW];
+                        if (pk_from_mont) from_mont(v, r, P); else fp_set(v, r);
+                        pack<NL, NW>(w, v);
+                        store_words<NW>(out_pk + oidx * NW, w);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// =====================================================================================
+// host side
+// =====================================================================================
+namespace hb {
+
+void fast_matrix_free(FastMatrix *m) {
+    if (!m) return;
+    (void)hipFree(m->M); (void)hipFree(m->nd);
+    if (m->negrow) (void)hipFree(m->negrow);
+    if (m->K) (void)hipFree(m->K);
+    delete m;
+}
+
+static int count_digits(hb_ctx *ctx, FastMatrix *m, hipStream_t s) {
+    const int tiles = m_tiles(m->n_out);
+    HB_HIP(ctx, hipMalloc(&m->nd, sizeof(int32_t) * (size_t)(tiles * m->n_in > 0 ? tiles * m->n_in : 1)));
+    const int tot = tiles * m->n_in;
+    if (tot > 0) {
+        if (ctx->n_limbs == 4) k_count_digits<9><<<(tot + 127) / 128, 128, 0, s>>>(m->M, tiles, m->n_in, m->nd);
+        else k_count_digits<3><<<(tot + 127) / 128, 128, 0, s>>>(m->M, tiles, m->n_in, m->nd);
+        HB_LAUNCH_CHECK(ctx);
+    }
+    return HB_OK;
+}
+
+// raw Vandermonde n x d at device points, K = R^2 for every term (outputs canonical)
+int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s) {
+    FastMatrix *m = new FastMatrix();
+    m->n_out = n; m->n_in = d; m->negrow = nullptr; m->K = nullptr; m->nd = nullptr;
+    const int NLr = ctx->nl();
+    size_t words = (size_t)m_tiles(n) * d * OT * NLr; if (!words) words = 1;
+    HB_HIP(ctx, hipMalloc(&m->M, words * 4));
+    HB_HIP(ctx, hipMemsetAsync(m->M, 0, words * 4, s));
+    if (n > 0 && d > 0) {
+        HB_DISPATCH(ctx,
+            (k_vand_raw<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, x_dev, n, d, m->M)),
+            (k_vand_raw<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, x_dev, n, d, m->M)));
+        HB_LAUNCH_CHECK(ctx);
+    }
+    int rc = count_digits(ctx, m, s); if (rc) return rc;
+    // K_l = R^2 for all l
+    std::vector<uint32_t> kh((size_t)(d > 0 ? d : 1) * NLr);
+    for (int l = 0; l < d; l++) for (int q = 0; q < NLr; q++) kh[(size_t)l * NLr + q] = ctx->n_limbs == 4 ? ctx->pw.r2[q] : ctx->pn.r2[q];
+    HB_HIP(ctx, hipMalloc(&m->K, kh.size() * 4));
+    HB_HIP(ctx, hipMemcpyAsync(m->K, kh.data(), kh.size() * 4, hipMemcpyHostToDevice, s));
+    HB_HIP(ctx, hipStreamSynchronize(s));
+    *out = m;
+    return HB_OK;
+}
+
+// factored inverse Vandermonde k x k at device points; HB_ERR_SINGULAR for repeated points
+int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s) {
+    if (k > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "vandermonde inverse: k > 1023");
+    FastMatrix *m = new FastMatrix();
+    m->n_out = k; m->n_in = k; m->nd = nullptr;
+    const int NLr = ctx->nl();
+    size_t words = (size_t)m_tiles(k) * k * OT * NLr; if (!words) words = 1;
+    HB_HIP(ctx, hipMalloc(&m->M, words * 4));
+    HB_HIP(ctx, hipMemsetAsync(m->M, 0, words * 4, s));
+    HB_HIP(ctx, hipMalloc(&m->negrow, sizeof(int32_t) * (size_t)(k > 0 ? k : 1)));
+    HB_HIP(ctx, hipMalloc(&m->K, (size_t)(k > 0 ? k : 1) * NLr * 4));
+    int singular = 0;
+    if (k > 0) {
+        HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), s));
+        int threads = ((k + 1 + 63) / 64) * 64;
+        size_t lds = (size_t)(k + 2 * (k + 1)) * NLr * 4;
+        if (ctx->n_limbs == 4) {
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, ctx->flag_dev);
+        } else {
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, ctx->flag_dev);
+        }
+        HB_LAUNCH_CHECK(ctx);
+        HB_HIP(ctx, hipMemcpyAsync(&singular, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+        HB_HIP(ctx, hipStreamSynchronize(s));
+    }
+    if (singular) { fast_matrix_free(m); return fail(ctx, HB_ERR_SINGULAR, "Interpolation failed"); }
+    int rc = count_digits(ctx, m, s); if (rc) return rc;
+    HB_HIP(ctx, hipStreamSynchronize(s));
+    *out = m;
+    return HB_OK;
+}
+
+// out_dg[l][.][c] = in(c, rows[l]) * K_l / R
+int launch_prescale(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_view iv, const int32_t *rows_dev, int64_t in_count,
+                    uint32_t *out_dg, int64_t C, hipStream_t s) {
+    if (C <= 0 || m->n_in == 0) return HB_OK;
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)m->n_in);
+    if (ctx->n_limbs == 4) k_prescale<9, 8><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K, m->n_in, C, out_dg);
+    else k_prescale<3, 2><<<grid, 256, 0, s>>>(ctx->pn, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K, m->n_in, C, out_dg);
+    HB_LAUNCH_CHECK(ctx);
+    return HB_OK;
+}
+
+int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg, uint32_t *out_pk, hb_view ov, int64_t out_count,
+                   int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+                   int64_t C, hipStream_t s) {
+    if (C <= 0 || m->n_out == 0) return HB_OK;
+    const int tiles = m_tiles(m->n_out);
+    const int64_t groups = (C + 63) / 64;
+    const int64_t n_waves = groups * tiles;
+    int64_t blocks = (n_waves + 3) / 4;
+    blocks = ((blocks + 7) / 8) * 8;
+    if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: batch too large for one launch");
+    const int nsub = nsub_for(m->n_in, ctx->nl(), ctx->elem_words());
+    if (nsub > 64) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: inner dimension too large");
+    const bool check = check_mask_dev != nullptr;
+    if (ctx->n_limbs == 4) {
+        if (check) k_matvec2<9, 8, true><<<(unsigned)blocks, 256, 0, s>>>(ctx->pw, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check_mask_dev, mismatch_dev, C, tiles, n_waves);
+        else k_matvec2<9, 8, false><<<(unsigned)blocks, 256, 0, s>>>(ctx->pw, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, nullptr, nullptr, C, tiles, n_waves);
+    } else {
+        if (check) k_matvec2<3, 2, true><<<(unsigned)blocks, 256, 0, s>>>(ctx->pn, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check_mask_dev, mismatch_dev, C, tiles, n_waves);
+        else k_matvec2<3, 2, false><<<(unsigned)blocks, 256, 0, s>>>(ctx->pn, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, nullptr, nullptr, C, tiles, n_waves);
+    }
+    HB_LAUNCH_CHECK(ctx);
+    return HB_OK;
+}
+
+}  // namespace hb

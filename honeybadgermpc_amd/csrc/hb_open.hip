@@ -17,15 +17,22 @@
 
 using namespace hb;
 
+// Kernel pipeline of one open (hb_fast.hip): raw small-entry matrices, inputs pre-scaled into
+// Montgomery digit planes, decode emitting Montgomery-form coefficients for the validating re-encode:
+//   R1 encode : k_prescale(shares, K=R^2)        -> in_dg ; k_matvec2(V)  -> r1_out (canonical)
+//   decode    : k_prescale(cols[z], K=R^3/den_j) -> in_dg ; k_matvec2(N, negrow) -> coef_dg (Montgomery) [+ canonical rows]
+//   validate  : k_matvec2<CHECK>(V, coef_dg) compared with cols[zc] in the epilogue
 struct hb_open_plan {
     hb_ctx *ctx;
     int n, d, n_check;
     int64_t max_B, max_C;
-    hb_matrix *V;        // n x d  encode matrix at the n party points
-    hb_matrix *Vinv;     // d x d  decode matrix for the arrival set z
+    FastMatrix *V;       // n x d  raw Vandermonde at the n party points
+    FastMatrix *Vinv;    // d x d  factored inverse for the arrival set z
     int32_t *z_dev;      // d row indices
     int32_t *mask_dev;   // n+1 ints: rows to validate
-    uint32_t *coef;      // [d][max_C] decoded coefficients
+    uint32_t *in_dg;     // [d][NL][max_C] pre-scaled inputs (digit planes)
+    uint32_t *coef_dg;   // [d][NL][max_C] decoded coefficients, Montgomery digit planes
+    uint32_t *coef_pk;   // [d][max_C] decoded coefficients, canonical (R2 decode: flattened from here)
     int32_t *mismatch_dev;
 };
 
@@ -40,17 +47,23 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     hb_open_plan *pl = new hb_open_plan();
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
-    pl->coef = nullptr; pl->mismatch_dev = nullptr;
-    int rc = hb_vand_matrix_create(ctx, x_host, n, d, &pl->V, stream);
-    if (rc) { delete pl; return rc; }
+    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr;
     const int L = ctx->n_limbs;
     std::vector<uint64_t> xz((size_t)d * L);
     for (int i = 0; i < d; i++) {
         if (z_host[i] < 0 || z_host[i] >= n) { delete pl; return HB_ERR_BAD_ARG; }
         memcpy(&xz[(size_t)i * L], x_host + (size_t)z_host[i] * L, (size_t)L * 8);
     }
-    rc = hb_vand_inverse_create(ctx, xz.data(), d, &pl->Vinv, stream);
+    uint32_t *xd = nullptr, *xzd = nullptr;
+    int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s);
     if (rc) { delete pl; return rc; }
+    rc = upload_elems(ctx, xz.data(), (size_t)d, &xzd, s);
+    if (rc) { delete pl; return rc; }
+    rc = fast_vand_create(ctx, xd, n, d, &pl->V, s);
+    if (!rc) rc = fast_vinv_create(ctx, xzd, d, &pl->Vinv, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(xd); (void)hipFree(xzd);
+    if (rc) { fast_matrix_free(pl->V); delete pl; return rc; }
     rc = get_int_array(ctx, z_host, d, &pl->z_dev, s);
     if (rc) { delete pl; return rc; }
     std::vector<int32_t> mask((size_t)n + 1, 0);
@@ -61,7 +74,9 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     }
     rc = get_int_array(ctx, mask.data(), n + 1, &pl->mask_dev, s);
     if (rc) { delete pl; return rc; }
-    HB_HIP(ctx, hipMalloc(&pl->coef, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+    HB_HIP(ctx, hipMalloc(&pl->in_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
+    HB_HIP(ctx, hipMalloc(&pl->coef_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
+    HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
     HB_HIP(ctx, hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     HB_HIP(ctx, hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
     *out = pl;
@@ -73,40 +88,42 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
     if (!pl || B < 0 || B > pl->max_B) return HB_ERR_BAD_ARG;
     const int64_t C = (B + pl->d - 1) / pl->d;
     hb_view iv{pl->d, 1}, ov{1, C};
-    return launch_matvec(pl->ctx, pl->V, (const uint32_t *)shares_dev, iv, nullptr, B, (uint32_t *)r1_out_dev, ov, INT64_MAX,
-                         nullptr, nullptr, C, (hipStream_t)stream);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_prescale(pl->ctx, pl->V, (const uint32_t *)shares_dev, iv, nullptr, B, pl->in_dg, C, s);
+    if (rc) return rc;
+    return launch_matvec2(pl->ctx, pl->V, pl->in_dg, (uint32_t *)r1_out_dev, ov, INT64_MAX, pl->n, 0, nullptr, nullptr, nullptr, C, s);
 }
 
-static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64_t C, hipStream_t s) {
+// canonical coefficients of rows < pk_rows go to pk_dst (view pv); Montgomery planes always to coef_dg
+static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64_t C, uint32_t *pk_dst, hb_view pv, int64_t pk_count,
+                               int pk_rows, hipStream_t s) {
     hb_view pm{1, C};
-    int rc = launch_matvec(pl->ctx, pl->Vinv, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->coef, pm, INT64_MAX,
-                           nullptr, nullptr, C, s);
+    int rc = launch_prescale(pl->ctx, pl->Vinv, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg, C, s);
+    if (rc) return rc;
+    rc = launch_matvec2(pl->ctx, pl->Vinv, pl->in_dg, pk_dst, pv, pk_count, pk_rows, 1, pl->coef_dg, nullptr, nullptr, C, s);
     if (rc) return rc;
     // validating re-encode of the guess, compared in the epilogue against the later arrivals
-    return launch_matvec(pl->ctx, pl->V, pl->coef, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX,
-                         pl->mask_dev, pl->mismatch_dev, C, s);
+    return launch_matvec2(pl->ctx, pl->V, pl->coef_dg, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, 0, 0, nullptr,
+                          pl->mask_dev, pl->mismatch_dev, C, s);
 }
 
 int hb_open_r1_decode(hb_open_plan *pl, const uint64_t *r1_cols_dev, int64_t B, uint64_t *r2_msg_dev, void *stream) {
     if (!pl || B < 0 || B > pl->max_B) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t C = (B + pl->d - 1) / pl->d;
-    int rc = decode_and_validate(pl, r1_cols_dev, C, s);
-    if (rc) return rc;
-    // message = [chunk[0] for chunk in recons_r2]  == row 0 of the coefficient-major buffer
-    HB_HIP(pl->ctx, hipMemcpyAsync(r2_msg_dev, pl->coef, (size_t)C * pl->ctx->elem_words() * 4, hipMemcpyDeviceToDevice, s));
-    return HB_OK;
+    // message = [chunk[0] for chunk in recons_r2]: only row 0 (the constant terms) is needed in
+    // canonical form, and the decode kernel writes it straight into the caller's buffer
+    hb_view pv{1, C};
+    return decode_and_validate(pl, r1_cols_dev, C, (uint32_t *)r2_msg_dev, pv, INT64_MAX, 1, s);
 }
 
 int hb_open_r2_decode(hb_open_plan *pl, const uint64_t *r2_cols_dev, int64_t B, uint64_t *result_dev, void *stream) {
     if (!pl || B < 0 || B > pl->max_B) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t C = (B + pl->d - 1) / pl->d;
-    int rc = decode_and_validate(pl, r2_cols_dev, C, s);
-    if (rc) return rc;
-    // flatten_lists(recons_p)[:B]: coefficient-major -> chunk-major, truncated
-    hb_view sv{1, C}, dv{pl->d, 1};
-    return launch_copy_view(pl->ctx, pl->coef, sv, (uint32_t *)result_dev, dv, C, pl->d, B, s);
+    // flatten_lists(recons_p)[:B]: the decode kernel stores chunk-major, truncated at B
+    hb_view dv{pl->d, 1};
+    return decode_and_validate(pl, r2_cols_dev, C, (uint32_t *)result_dev, dv, B, pl->d, s);
 }
 
 int hb_open_status(hb_open_plan *pl, void *stream) {
@@ -124,8 +141,9 @@ int hb_open_status(hb_open_plan *pl, void *stream) {
 
 void hb_open_plan_destroy(hb_open_plan *pl) {
     if (!pl) return;
-    (void)hipFree(pl->coef);
+    (void)hipFree(pl->in_dg); (void)hipFree(pl->coef_dg); (void)hipFree(pl->coef_pk);
     (void)hipFree(pl->mismatch_dev);
+    fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv);
     delete pl;
 }
 
