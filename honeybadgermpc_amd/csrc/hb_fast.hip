@@ -289,6 +289,132 @@ __global__ void __launch_bounds__(256) k_matvec2(const FpParams<NL> P, const uin
     }
 }
 
+
+// -------------------------------------------------------------------------------------
+// k_matvec3: k_matvec2 with the inputs staged in LDS.
+// With small-entry matrices a term is only 36..180 MADs per output tile, too short for a
+// one-term-ahead global prefetch to hide HBM latency.  A workgroup therefore owns ONE group of
+// 64 chunks: it copies that group's n_in x NL digit planes (n_in*NL*256 bytes: 50.7 KB at
+// d = 22) into LDS with every load in flight at once -- each input digit is read from HBM
+// exactly once per launch -- and its W waves then sweep the output tiles (tile = w, w+W, ...)
+// reading x from LDS ([term][digit][lane]: lane-contiguous dwords, conflict-free).
+// -------------------------------------------------------------------------------------
+template <int NL, int NW, bool CHECK>
+__global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uint32_t *__restrict__ M, const int32_t *__restrict__ ndt,
+                                                 const int32_t *__restrict__ negrow, int n_out, int n_in, int nsub,
+                                                 const uint32_t *__restrict__ in_dg,
+                                                 uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
+                                                 int pk_rows, int pk_from_mont, uint32_t *__restrict__ out_dg,
+                                                 const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
+                                                 int64_t C, int tiles, int tiles_per_block, int slices, int64_t n_blocks) {
+    static_assert(OT == 4, "matrix tile is loaded as uint4 per digit");
+    extern __shared__ __attribute__((aligned(16))) uint32_t xs[];
+    const int lane = threadIdx.x & 63;
+    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int W = blockDim.x >> 6;
+    const int64_t nb8 = gridDim.x >> 3;
+    const int64_t vb = (int64_t)(blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
+    if (vb >= n_blocks) return;
+    const int slice = (int)(vb % slices);
+    const int64_t g = vb / slices;
+    const int64_t c = g * 64 + lane;
+    const bool active = c < C;
+    const int64_t cc = active ? c : (C - 1);
+    // ---- stage the group's digit planes ---------------------------------------------------
+    {
+        const int rows = n_in * NL;
+        const uint32_t *src = in_dg + cc;
+        for (int r = wib; r < rows; r += W) xs[r * 64 + lane] = src[(size_t)r * C];
+    }
+    __syncthreads();
+    // A 64-bit column holds 63 products of two 29-bit digits.  A term with nd non-zero matrix
+    // digits adds at most nd products to a column, so carries are scheduled by a digit budget:
+    // never more than BUDGET = 54 since the last carry, which leaves room for REDC's own 9
+    // products per column -- REDC then needs no carry pass of its own.
+    constexpr int BUDGET = 63 - NL;
+    const uint32_t *xl = xs + lane;
+    const int t_end = min(tiles, (slice + 1) * tiles_per_block);
+    for (int tile = slice * tiles_per_block + wib; tile < t_end; tile += W) {
+        const int nv = min(OT, n_out - tile * OT);
+        const uint4 *mt = reinterpret_cast<const uint4 *>(M) + (size_t)tile * n_in * NL;
+        const int32_t *ndp = ndt + (size_t)tile * n_in;
+        uint64_t col[OT][2 * NL];
+#pragma unroll
+        for (int o = 0; o < OT; o++) col_zero(col[o]);
+        uint4 mc[NL], mn[NL];
+        int ndc, ndn;
+#pragma unroll
+        for (int q = 0; q < NL; q++) mc[q] = mt[q];
+        ndc = ndp[0];
+        int used = 0;
+        for (int l = 0; l < n_in; l++) {
+            const int ln = (l + 1 < n_in) ? l + 1 : l;
+#pragma unroll
+            for (int q = 0; q < NL; q++) mn[q] = mt[(size_t)ln * NL + q];      // scalar prefetch of the next tile
+            ndn = ndp[ln];
+            uint32_t xu[NL];
+#pragma unroll
+            for (int q = 0; q < NL; q++) xu[q] = xl[(l * NL + q) * 64];        // LDS, conflict-free
+            if (used + ndc > BUDGET) {
+                used = 0;
+#pragma unroll
+                for (int o = 0; o < OT; o++) carry(col[o]);
+            }
+            used += ndc;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                if (i < ndc) {
+#pragma unroll
+                    for (int o = 0; o < OT; o++) {
+                        const uint32_t md = (o == 0) ? mc[i].x : (o == 1) ? mc[i].y : (o == 2) ? mc[i].z : mc[i].w;
+#pragma unroll
+                        for (int j = 0; j < NL; j++) col[o][i + j] += (uint64_t)md * xu[j];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < NL; q++) mc[q] = mn[q];
+            ndc = ndn;
+        }
+#pragma unroll
+        for (int o = 0; o < OT; o++) {
+            if (o < nv) {
+                const int i = tile * OT + o;
+                uint32_t r[NL];
+                redc(r, col[o], P);                    // columns hold <= BUDGET products each: no pre-carry needed
+                for (int s = 0; s < nsub; s++) cond_sub_p(r, P);
+                if (negrow && negrow[i]) fp_neg(r, r, P);
+                if (out_dg && active) {
+#pragma unroll
+                    for (int q = 0; q < NL; q++) out_dg[dg_index(i, q, c, C, NL)] = r[q];
+                }
+                if constexpr (CHECK) {
+                    if (check_mask[i] && active) {
+                        uint32_t w[NW], e[NW];
+                        pack<NL, NW>(w, r);
+                        load_words<NW>(e, out_pk + (cc * out_sc + (int64_t)i * out_sl) * NW);
+                        uint32_t diff = 0;
+#pragma unroll
+                        for (int q = 0; q < NW; q++) diff |= e[q] ^ w[q];
+                        if (diff) atomicOr(mismatch, 1);
+                    }
+                } else {
+                    if (out_pk && i < pk_rows && active) {
+                        const int64_t oidx = cc * out_sc + (int64_t)i * out_sl;
+                        if (oidx < out_count) {
+                            uint32_t v[NL], w[NW];
+                            if (pk_from_mont) from_mont(v, r, P); else fp_set(v, r);
+                            pack<NL, NW>(w, v);
+                            store_words<NW>(out_pk + oidx * NW, w);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // =====================================================================================
@@ -392,13 +518,35 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg, uint
     if (C <= 0 || m->n_out == 0) return HB_OK;
     const int tiles = m_tiles(m->n_out);
     const int64_t groups = (C + 63) / 64;
+    const int nsub = nsub_for(m->n_in, ctx->nl(), ctx->elem_words());
+    if (nsub > 64) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: inner dimension too large");
+    const bool check = check_mask_dev != nullptr;
+    const size_t lds = (size_t)m->n_in * ctx->nl() * 64 * 4;
+    if (lds <= 72 * 1024 && m->n_in > 0) {
+        // LDS-staged variant: one workgroup per (64-chunk group, slice of <= 16 tiles), two tiles per wave
+        const int slices = (tiles + 15) / 16;
+        const int tpb = (tiles + slices - 1) / slices;
+        // 164 VGPRs => 3 waves per SIMD = 12 per CU; 50 KB of LDS per workgroup => 3 workgroups per CU:
+        // 4-wave workgroups fill both limits
+        int W = (tpb + 1) / 2; if (W < 1) W = 1; if (W > 4) W = 4;
+        const int64_t n_blocks = groups * slices;
+        int64_t blocks = ((n_blocks + 7) / 8) * 8;
+        if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: batch too large for one launch");
+#define HB_MV3(NL_, NW_, CHK_, PP_)                                                                                             \
+        do {                                                                                                                    \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_matvec3<NL_, NW_, CHK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024))); \
+            k_matvec3<NL_, NW_, CHK_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks); \
+        } while (0)
+        if (ctx->n_limbs == 4) { if (check) HB_MV3(9, 8, true, ctx->pw); else HB_MV3(9, 8, false, ctx->pw); }
+        else { if (check) HB_MV3(3, 2, true, ctx->pn); else HB_MV3(3, 2, false, ctx->pn); }
+#undef HB_MV3
+        HB_LAUNCH_CHECK(ctx);
+        return HB_OK;
+    }
     const int64_t n_waves = groups * tiles;
     int64_t blocks = (n_waves + 3) / 4;
     blocks = ((blocks + 7) / 8) * 8;
     if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: batch too large for one launch");
-    const int nsub = nsub_for(m->n_in, ctx->nl(), ctx->elem_words());
-    if (nsub > 64) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: inner dimension too large");
-    const bool check = check_mask_dev != nullptr;
     if (ctx->n_limbs == 4) {
         if (check) k_matvec2<9, 8, true><<<(unsigned)blocks, 256, 0, s>>>(ctx->pw, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check_mask_dev, mismatch_dev, C, tiles, n_waves);
         else k_matvec2<9, 8, false><<<(unsigned)blocks, 256, 0, s>>>(ctx->pw, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, nullptr, nullptr, C, tiles, n_waves);
