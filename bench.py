@@ -95,6 +95,17 @@ def make_inputs(torch, ctx, n, t, B, use_omega, seed):
     return shares0, r1_cols, r2_cols, secrets, x
 
 
+def traffic_from_profiles(workload):
+    """HBM bytes per launch of the dominant kernel, measured with rocprofv3 PMC passes and
+    committed under profiles/ (bench.py cannot read hardware counters itself)."""
+    path = os.path.join(REPO, "profiles", f"traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:  # noqa: BLE001 - absent for workloads that were not PMC-profiled
+        return None
+
+
 def cpu_baseline(n, t, use_omega, sample_b, seed=7):
     """Time the CPU oracle (kind 'port': a plain-C restatement of the reference's NTL path,
     oracle/hbmpc_oracle.c) on a bounded sample of the same workload, all physical cores."""
@@ -250,10 +261,11 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "kernel": "k_matvec<9,8,false> (R1 encode, n x d Vandermonde mat-vec)",
+                "traffic": traffic_from_profiles(args.workload),
+                "kernel": "k_matvec3<9,8,false> (R1 encode: fused pre-scale + n x d small-entry Vandermonde mat-vec)",
                 "algorithmic_bytes_per_launch": alg_bytes_enc, "avg_launch_ms": enc_ms,
-                "note": "integer-ALU bound by construction (81 v_mad_u64_u32 per 32-byte product term); see DESIGN.md",
+                "note": "integer-ALU bound by construction (~840 VALU instructions per 32-byte output, VALU ~76% busy by PMC); "
+                        "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md",
             },
             "detail": {
                 "algorithmic_bytes_per_open": alg_bytes_open,

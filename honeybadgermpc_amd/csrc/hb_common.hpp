@@ -106,7 +106,9 @@ int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatri
 int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s);
 int launch_prescale(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_view iv, const int32_t *rows_dev, int64_t in_count,
                     uint32_t *out_dg, int64_t C, hipStream_t s);
-int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg, uint32_t *out_pk, hb_view ov, int64_t out_count,
+int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
+                   const uint32_t *in_pk, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *scratch_dg,
+                   uint32_t *out_pk, hb_view ov, int64_t out_count,
                    int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                    int64_t C, hipStream_t s);
 

@@ -303,6 +303,8 @@ template <int NL, int NW, bool CHECK>
 __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uint32_t *__restrict__ M, const int32_t *__restrict__ ndt,
                                                  const int32_t *__restrict__ negrow, int n_out, int n_in, int nsub,
                                                  const uint32_t *__restrict__ in_dg,
+                                                 const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl, const int32_t *__restrict__ in_rows,
+                                                 int64_t in_count, const uint32_t *__restrict__ K,
                                                  uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                  int pk_rows, int pk_from_mont, uint32_t *__restrict__ out_dg,
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
@@ -321,7 +323,28 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
     const bool active = c < C;
     const int64_t cc = active ? c : (C - 1);
     // ---- stage the group's digit planes ---------------------------------------------------
-    {
+    if (in_pk) {
+        // fused pre-scale: packed canonical input element (c, rows[l]) * K_l / R -> digits in LDS
+        // (K_l = R^2 for encode, R^3/den_l for decode; see the file header).  Term l is
+        // wave-uniform, so K_l comes through scalar loads.
+        for (int l = wib; l < n_in; l += W) {
+            const int row = in_rows ? in_rows[l] : l;
+            const int64_t idx = cc * in_sc + (int64_t)row * in_sl;
+            uint32_t r[NL];
+            if (idx < in_count) {
+                uint32_t xd[NL], kd[NL];
+                load_digits<NL, NW>(xd, in_pk + idx * NW);
+#pragma unroll
+                for (int q = 0; q < NL; q++) kd[q] = K[(size_t)l * NL + q];
+                mont_mul(r, xd, kd, P);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NL; q++) r[q] = 0;
+            }
+#pragma unroll
+            for (int q = 0; q < NL; q++) xs[(l * NL + q) * 64 + lane] = r[q];
+        }
+    } else {
         const int rows = n_in * NL;
         const uint32_t *src = in_dg + cc;
         for (int r = wib; r < rows; r += W) xs[r * 64 + lane] = src[(size_t)r * C];
@@ -512,7 +535,12 @@ int launch_prescale(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_vie
     return HB_OK;
 }
 
-int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg, uint32_t *out_pk, hb_view ov, int64_t out_count,
+// Input is EITHER Montgomery digit planes (in_dg) OR a packed canonical buffer (in_pk with view / rows /
+// count) that gets pre-scaled by m->K: inside the kernel's staging phase when the LDS variant applies,
+// through k_prescale into `scratch_dg` otherwise.
+int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
+                   const uint32_t *in_pk, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *scratch_dg,
+                   uint32_t *out_pk, hb_view ov, int64_t out_count,
                    int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                    int64_t C, hipStream_t s) {
     if (C <= 0 || m->n_out == 0) return HB_OK;
@@ -535,13 +563,19 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg, uint
 #define HB_MV3(NL_, NW_, CHK_, PP_)                                                                                             \
         do {                                                                                                                    \
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_matvec3<NL_, NW_, CHK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024))); \
-            k_matvec3<NL_, NW_, CHK_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks); \
+            k_matvec3<NL_, NW_, CHK_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, in_pk, iv.stride_c, iv.stride_l, in_rows_dev, in_count, m->K, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks); \
         } while (0)
         if (ctx->n_limbs == 4) { if (check) HB_MV3(9, 8, true, ctx->pw); else HB_MV3(9, 8, false, ctx->pw); }
         else { if (check) HB_MV3(3, 2, true, ctx->pn); else HB_MV3(3, 2, false, ctx->pn); }
 #undef HB_MV3
         HB_LAUNCH_CHECK(ctx);
         return HB_OK;
+    }
+    if (in_pk) {       // no LDS variant: separate pre-scale pass
+        if (!scratch_dg) return fail(ctx, HB_ERR_BAD_ARG, "matvec: scratch required");
+        int rc = launch_prescale(ctx, m, in_pk, iv, in_rows_dev, in_count, scratch_dg, C, s);
+        if (rc) return rc;
+        in_dg = scratch_dg;
     }
     const int64_t n_waves = groups * tiles;
     int64_t blocks = (n_waves + 3) / 4;

@@ -89,21 +89,21 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
     const int64_t C = (B + pl->d - 1) / pl->d;
     hb_view iv{pl->d, 1}, ov{1, C};
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_prescale(pl->ctx, pl->V, (const uint32_t *)shares_dev, iv, nullptr, B, pl->in_dg, C, s);
-    if (rc) return rc;
-    return launch_matvec2(pl->ctx, pl->V, pl->in_dg, (uint32_t *)r1_out_dev, ov, INT64_MAX, pl->n, 0, nullptr, nullptr, nullptr, C, s);
+    return launch_matvec2(pl->ctx, pl->V, nullptr, (const uint32_t *)shares_dev, iv, nullptr, B, pl->in_dg,
+                          (uint32_t *)r1_out_dev, ov, INT64_MAX, pl->n, 0, nullptr, nullptr, nullptr, C, s);
 }
 
 // canonical coefficients of rows < pk_rows go to pk_dst (view pv); Montgomery planes always to coef_dg
 static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64_t C, uint32_t *pk_dst, hb_view pv, int64_t pk_count,
                                int pk_rows, hipStream_t s) {
     hb_view pm{1, C};
-    int rc = launch_prescale(pl->ctx, pl->Vinv, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg, C, s);
-    if (rc) return rc;
-    rc = launch_matvec2(pl->ctx, pl->Vinv, pl->in_dg, pk_dst, pv, pk_count, pk_rows, 1, pl->coef_dg, nullptr, nullptr, C, s);
+    int rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
+                            pk_dst, pv, pk_count, pk_rows, 1, pl->coef_dg, nullptr, nullptr, C, s);
     if (rc) return rc;
     // validating re-encode of the guess, compared in the epilogue against the later arrivals
-    return launch_matvec2(pl->ctx, pl->V, pl->coef_dg, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, 0, 0, nullptr,
+    hb_view none{0, 0};
+    return launch_matvec2(pl->ctx, pl->V, pl->coef_dg, nullptr, none, nullptr, 0, nullptr,
+                          (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, 0, 0, nullptr,
                           pl->mask_dev, pl->mismatch_dev, C, s);
 }
 

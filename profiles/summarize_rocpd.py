@@ -8,6 +8,8 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void ", "", name)
     name = re.sub(r"\(.*", "", name)
     return name if len(name) < 90 else name[:87] + "..."
 
