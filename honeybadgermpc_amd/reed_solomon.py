@@ -19,6 +19,7 @@ from .ntl import (
     fft_batch_interpolate,
     fft_interpolate,
     gao_interpolate,
+    gao_interpolate_batch,
     vandermonde_batch_evaluate,
     vandermonde_batch_interpolate,
 )
@@ -162,6 +163,34 @@ class GaoRobustDecoder(RobustDecoder):
         return decoded, errors
 
 
+    def robust_decode_batch(self, z, rows):
+        """All rows (codewords over the same arrival set z, no erasures) in one launch
+        (SURVEY 8f-1).  Entry i equals robust_decode(z, rows[i])."""
+        if not rows:
+            return []
+        x = [self.point(zi).value for zi in z]
+        decoded = gao_interpolate_batch(x, rows, self.d + 1, self.modulus)
+        need = [i for i, (co, ep) in enumerate(decoded) if co is not None and len(ep) > 1]
+        evals = {}
+        if need:
+            width = max(len(decoded[i][1]) for i in need)
+            polys = [decoded[i][1] + [0] * (width - len(decoded[i][1])) for i in need]
+            if self.use_omega_powers:
+                ev = fft_batch_evaluate(polys, self.point.omega.value, self.modulus, self.point.order, self.point.n)
+            else:
+                xs = [self.point(i).value for i in range(self.point.n)]
+                ev = vandermonde_batch_evaluate(xs, polys, self.modulus)
+            evals = dict(zip(need, ev))
+        out = []
+        for i, (co, _) in enumerate(decoded):
+            if co is None:
+                out.append((None, None))
+            else:
+                ev = evals.get(i)
+                out.append((co, [] if ev is None else [j for j in range(self.point.n) if ev[j] == 0]))
+        return out
+
+
 class WelchBerlekampRobustDecoder(RobustDecoder):
     def __init__(self, d, point):
         self.n = point.n
@@ -190,6 +219,37 @@ class WelchBerlekampRobustDecoder(RobustDecoder):
             if enc_extended[i] is not None and enc_extended[i].value != poly_eval[i]
         ]
         return coeffs, errors
+
+
+    def robust_decode_batch(self, z, rows):
+        """Batched robust_decode.  An entry is (coeffs, errors), (None, None), or an Exception
+        instance standing for what robust_decode would have raised for that row."""
+        if not rows:
+            return []
+        from .device import wb_decode_batch
+
+        where = {zi: i for i, zi in enumerate(z)}
+        xs = [self.point(i).value for i in range(self.n)]
+        extended = [[row[where[i]] % self.modulus if i in where else None for i in range(self.n)] for row in rows]
+        res = wb_decode_batch(xs, self.d + 1, extended, self.modulus)
+        ok = [i for i, (co, st) in enumerate(res) if st == 0]
+        evals = {}
+        if ok:
+            width = max([len(res[i][0]) for i in ok] + [1])
+            ev = vandermonde_batch_evaluate(xs, [res[i][0] + [0] * (width - len(res[i][0])) for i in ok], self.modulus)
+            evals = dict(zip(ok, ev))
+        out = []
+        for i, (co, st) in enumerate(res):
+            if st == 0:
+                ev = evals[i]
+                out.append((co, [j for j in range(self.n) if extended[i][j] is not None and extended[i][j] != ev[j]]))
+            elif st == 1:
+                out.append((None, None))                       # "found no divisors!" is swallowed (reference :205-212)
+            elif st == 2:
+                out.append(Exception("No solution"))           # propagates in the reference
+            else:
+                out.append(AssertionError())                   # assert 2t+1+c <= n (reed_solomon_wb.py:132), no message
+        return out
 
 
 class DecodeValidationError(HoneyBadgerMPCError):
@@ -265,23 +325,45 @@ class IncrementalDecoder(object):
             self._result = self._guess_decoded
         return agree
 
+    def _accept(self, decoded, errors):
+        """Bookkeeping for one robustly decoded polynomial (reference :344-361).  Returns True
+        when the arrival set changed (confirmed errors were dropped)."""
+        self._num_decoded += 1
+        self._available_data = self._available_data[1:]
+        self._partial_result.append(decoded)
+        self._confirmed_errors |= set(errors)
+        self._available_points -= set(errors)
+        for e in errors:
+            pos = self._z.index(e)
+            del self._z[pos]
+            for row in self._available_data:
+                del row[pos]
+        return len(errors) > 0
+
     def _robust_update(self):
-        while self._num_decoded < self.batch_size:
-            decoded, errors = self.robust_decoder.robust_decode(self._z, self._available_data[0])
-            if decoded is None:
-                break  # need more columns
-            if len(self._available_points) - len(errors) < self._min_points_required():
-                break
-            self._num_decoded += 1
-            self._available_data = self._available_data[1:]
-            self._partial_result.append(decoded)
-            self._confirmed_errors |= set(errors)
-            self._available_points -= set(errors)
-            for e in errors:
-                pos = self._z.index(e)
-                del self._z[pos]
-                for row in self._available_data:
-                    del row[pos]
+        batch = getattr(self.robust_decoder, "robust_decode_batch", None)
+        stalled = False
+        while self._num_decoded < self.batch_size and not stalled:
+            if batch is None:
+                # the reference's loop: one robust_decode per polynomial (:335-361)
+                results = [self.robust_decoder.robust_decode(self._z, self._available_data[0])]
+            else:
+                # every remaining polynomial over the current arrival set in ONE launch; the
+                # results stay valid until an accepted polynomial confirms new errors (which
+                # changes the arrival set), at which point the rest is decoded again.
+                results = batch(self._z, self._available_data)
+            for res in results:
+                if isinstance(res, BaseException):
+                    raise res
+                decoded, errors = res
+                if decoded is None:
+                    stalled = True          # need more columns
+                    break
+                if len(self._available_points) - len(errors) < self._min_points_required():
+                    stalled = True
+                    break
+                if self._accept(decoded, errors):
+                    break                   # arrival set changed: re-decode what is left
         if self._num_decoded == self.batch_size:
             self._result = self._partial_result
 

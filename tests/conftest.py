@@ -42,7 +42,7 @@ def golden():
 
 _NTL_NAMES = (
     "lagrange_interpolate", "evaluate", "vandermonde_batch_interpolate", "vandermonde_batch_evaluate",
-    "fft", "partial_fft", "fft_batch_evaluate", "fft_interpolate", "fft_batch_interpolate", "gao_interpolate",
+    "fft", "partial_fft", "fft_batch_evaluate", "fft_interpolate", "fft_batch_interpolate", "gao_interpolate", "gao_interpolate_batch",
     "vandermonde_inverse", "sqrt_mod",
 )
 
