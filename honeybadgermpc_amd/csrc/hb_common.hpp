@@ -14,6 +14,9 @@
 #include "fp29.cuh"
 
 namespace hb {
+struct FastMatrix;
+}
+namespace hb {
 
 // Two instantiations: <NL=9 digits, NW=8 words> for p < 2^256, <3, 2> for p < 2^64.
 struct Wide { static constexpr int NL = 9, NW = 8; };
@@ -48,6 +51,7 @@ struct hb_ctx {
     std::map<std::string, hb_matrix *> mcache;        // tables keyed by (kind, n, d, point bytes)
     std::map<std::vector<int32_t>, int32_t *> icache; // small int arrays resident on device
     std::map<std::string, void *> dcache;             // other device tables (twiddles, ...), hipFree'd with the ctx
+    std::map<std::string, hb::FastMatrix *> fcache;   // second-generation (raw small-entry) tables
     int32_t *flag_dev;                                // 64 status words
     int elem_words() const { return n_limbs == 4 ? 8 : 2; }
     int nl() const { return n_limbs == 4 ? 9 : 3; }
@@ -100,7 +104,6 @@ int launch_matvec(hb_ctx *ctx, const hb_matrix *m, const uint32_t *in, hb_view i
 int launch_copy_view(hb_ctx *ctx, const uint32_t *src, hb_view sv, uint32_t *dst, hb_view dv, int64_t C, int L, int64_t dst_count, hipStream_t s);
 
 // ---- second-generation (raw small-entry matrix) path, hb_fast.hip ----------------------
-struct FastMatrix;
 void fast_matrix_free(FastMatrix *m);
 int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s);
 int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s);

@@ -408,6 +408,7 @@ void hb_ctx_destroy(hb_ctx *ctx) {
     for (auto &kv : ctx->mcache) { (void)hipFree(kv.second->dev); delete kv.second; }
     for (auto &kv : ctx->icache) (void)hipFree(kv.second);
     for (auto &kv : ctx->dcache) (void)hipFree(kv.second);
+    for (auto &kv : ctx->fcache) fast_matrix_free(kv.second);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
     delete ctx;
 }
@@ -645,22 +646,63 @@ int hb_matvec_check(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_
     return launch_matvec(ctx, m, (const uint32_t *)in_dev, in, rows_dev, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(expect_dev), expect, INT64_MAX, mask_dev, mismatch_dev, C, s);
 }
 
+// cached second-generation tables for a host point set
+static int fast_table(hb_ctx *ctx, const char *kind, const uint64_t *x_host, int n, int d, FastMatrix **out, hipStream_t s) {
+    std::string key = table_key(kind, ctx, x_host, n, d);
+    auto it = ctx->fcache.find(key);
+    if (it != ctx->fcache.end()) { *out = it->second; return HB_OK; }
+    uint32_t *xd = nullptr;
+    int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
+    FastMatrix *m = nullptr;
+    rc = (kind[0] == 'V') ? fast_vand_create(ctx, xd, n, d, &m, s) : fast_vinv_create(ctx, xd, n, &m, s);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(xd);
+    if (rc) return rc;
+    ctx->fcache[key] = m;
+    *out = m;
+    return HB_OK;
+}
+
+// scratch digit planes for shapes that do not fit the LDS-staged kernel
+static int fast_scratch(hb_ctx *ctx, int n_in, int64_t C, uint32_t **scratch) {
+    *scratch = nullptr;
+    const size_t lds = (size_t)n_in * ctx->nl() * 64 * 4;
+    if (lds <= 72 * 1024) return HB_OK;
+    HB_HIP(ctx, hipMalloc(scratch, (size_t)n_in * ctx->nl() * (size_t)C * 4));
+    return HB_OK;
+}
+
 int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_t *polys_dev,
                                   int64_t C, int d, uint64_t *out_dev, void *stream) {
-    if (!ctx) return HB_ERR_BAD_ARG;
-    hb_matrix *V = nullptr;
-    int rc = hb_vand_matrix_create(ctx, x_host, n, d, &V, stream); if (rc) return rc;
+    if (!ctx || n < 0 || d < 0 || C < 0) return HB_ERR_BAD_ARG;
+    if (C == 0 || n == 0) return HB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (d == 0) { HB_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)C * n * ctx->elem_words() * 4, s)); return HB_OK; }
+    FastMatrix *V = nullptr;
+    int rc = fast_table(ctx, "Vf", x_host, n, d, &V, s); if (rc) return rc;
+    uint32_t *scratch = nullptr;
+    rc = fast_scratch(ctx, d, C, &scratch); if (rc) return rc;
     hb_view iv{d, 1}, ov{n, 1};
-    return hb_matvec(ctx, V, polys_dev, iv, nullptr, out_dev, ov, C, stream);
+    rc = launch_matvec2(ctx, V, nullptr, (const uint32_t *)polys_dev, iv, nullptr, INT64_MAX, scratch,
+                        (uint32_t *)out_dev, ov, INT64_MAX, n, 0, nullptr, nullptr, nullptr, C, s);
+    if (scratch) { (void)hipStreamSynchronize(s); (void)hipFree(scratch); }
+    return rc;
 }
 
 int hb_vandermonde_batch_interpolate(hb_ctx *ctx, const uint64_t *x_host, int k, const uint64_t *data_dev,
                                      int64_t C, uint64_t *out_dev, void *stream) {
-    if (!ctx) return HB_ERR_BAD_ARG;
-    hb_matrix *Vi = nullptr;
-    int rc = hb_vand_inverse_create(ctx, x_host, k, &Vi, stream); if (rc) return rc;
+    if (!ctx || k < 0 || C < 0) return HB_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    FastMatrix *Vi = nullptr;
+    int rc = fast_table(ctx, "Nf", x_host, k, k, &Vi, s); if (rc) return rc;     // HB_ERR_SINGULAR: repeated point
+    if (C == 0 || k == 0) return HB_OK;
+    uint32_t *scratch = nullptr;
+    rc = fast_scratch(ctx, k, C, &scratch); if (rc) return rc;
     hb_view v{k, 1};
-    return hb_matvec(ctx, Vi, data_dev, v, nullptr, out_dev, v, C, stream);
+    rc = launch_matvec2(ctx, Vi, nullptr, (const uint32_t *)data_dev, v, nullptr, INT64_MAX, scratch,
+                        (uint32_t *)out_dev, v, INT64_MAX, k, 1, nullptr, nullptr, nullptr, C, s);
+    if (scratch) { (void)hipStreamSynchronize(s); (void)hipFree(scratch); }
+    return rc;
 }
 
 // host self-test of the arithmetic templates (runs the same code as the kernels on the CPU)

@@ -328,14 +328,50 @@ static int mat_inverse(const field_t *F, fe *inv, fe *m, int n) {
 /* mat_ZZ_p mul restricted to what the path uses: OUT[c][i] = sum_l M[i][l] * IN[c][l]
    (pyx:183,237 compute M * IN^T and read it back transposed; same numbers).
    NTL parallelises this product internally; here OpenMP over the batch. */
+/* sum of Montgomery products with ONE reduction: acc (9 x 64-bit words) += a * b per term, then
+   REDC.  NTL's mat_ZZ_p multiplication also delays reductions; the values are identical. */
+static inline void wide_mac(u64 acc[10], const fe *a, const fe *b) {
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)a->l[j] * b->l[i] + acc[i + j]; acc[i + j] = (u64)c; c >>= 64; }
+        for (int k = i + 4; c && k < 10; k++) { c += acc[k]; acc[k] = (u64)c; c >>= 64; }
+    }
+}
+static inline void wide_redc(const field_t *F, fe *r, u64 acc[10]) {
+    for (int i = 0; i < 4; i++) {
+        u64 m = acc[i] * F->n0;
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) { c += (u128)m * F->p[j] + acc[i + j]; acc[i + j] = (u64)c; c >>= 64; }
+        for (int k = i + 4; c && k < 10; k++) { c += acc[k]; acc[k] = (u64)c; c >>= 64; }
+    }
+    /* value = acc[4..9] < (terms + 1) * p: subtract p until canonical */
+    u64 t[6]; for (int i = 0; i < 6; i++) t[i] = acc[4 + i];
+    for (;;) {
+        int ge = (t[4] | t[5]) != 0 || ge4(t, F->p);
+        if (!ge) break;
+        u64 borrow = 0;
+        for (int i = 0; i < 6; i++) {
+            u128 d = (u128)t[i] - (i < 4 ? F->p[i] : 0) - borrow;
+            t[i] = (u64)d; borrow = (u64)(d >> 64) & 1;
+        }
+    }
+    memcpy(r->l, t, 32);
+}
 static void matvec_batch(const field_t *F, fe *out, const fe *M, int rows, int cols, const fe *in, long C) {
 #pragma omp parallel for schedule(static) num_threads(g_threads)
     for (long c = 0; c < C; c++) {
         const fe *v = in + (size_t)c * cols;
         for (int i = 0; i < rows; i++) {
-            fe acc; memset(&acc, 0, sizeof acc);
             const fe *mr = M + (size_t)i * cols;
-            for (int l = 0; l < cols; l++) { fe t; fe_mul(F, &t, &mr[l], &v[l]); fe_add(F, &acc, &acc, &t); }
+            fe acc; memset(&acc, 0, sizeof acc);
+            int l = 0;
+            while (l < cols) {                       /* <= 1024 terms per wide accumulator: no overflow of 10 words */
+                u64 w[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                int end = l + 1024 < cols ? l + 1024 : cols;
+                for (; l < end; l++) wide_mac(w, &mr[l], &v[l]);
+                fe part; wide_redc(F, &part, w);
+                fe_add(F, &acc, &acc, &part);
+            }
             out[(size_t)c * rows + i] = acc;
         }
     }
