@@ -21,6 +21,8 @@
 //     re-encode wants as input -- no conversion between the two kernels.
 //   The identities hold mod p for ANY points; when the points are large (omega powers) the
 //   digit counts are simply 9 and the cost equals the first-generation kernel's.
+#include <stdlib.h>
+
 #include "hb_common.hpp"
 
 using namespace hb;
@@ -552,11 +554,13 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
     const size_t lds = (size_t)m->n_in * ctx->nl() * 64 * 4;
     if (lds <= 72 * 1024 && m->n_in > 0) {
         // LDS-staged variant: one workgroup per (64-chunk group, slice of <= 16 tiles), two tiles per wave
-        const int slices = (tiles + 15) / 16;
+        int slices = (tiles + 15) / 16;
+        if (const char *e = getenv("HB_MV3_SLICES")) { int v = atoi(e); if (v >= 1 && v <= tiles) slices = v; }
         const int tpb = (tiles + slices - 1) / slices;
         // 164 VGPRs => 3 waves per SIMD = 12 per CU; 50 KB of LDS per workgroup => 3 workgroups per CU:
         // 4-wave workgroups fill both limits
-        int W = (tpb + 1) / 2; if (W < 1) W = 1; if (W > 4) W = 4;
+        int W = tpb < 4 ? tpb : 4;   // measured: 4 waves per workgroup beats 3 even for 6 tiles (staging is split 4 ways)
+        if (const char *e = getenv("HB_MV3_W")) { int w = atoi(e); if (w >= 1 && w <= 8) W = w; }          // tuning hooks
         const int64_t n_blocks = groups * slices;
         int64_t blocks = ((n_blocks + 7) / 8) * 8;
         if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: batch too large for one launch");
