@@ -113,7 +113,7 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
                    const uint32_t *in_pk, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *scratch_dg,
                    uint32_t *out_pk, hb_view ov, int64_t out_count,
                    int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                   int64_t C, hipStream_t s);
+                   int64_t C, hipStream_t s, int check_skip = 0);
 
 // dispatch on element width
 #define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \

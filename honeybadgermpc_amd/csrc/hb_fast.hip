@@ -310,7 +310,7 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
                                                  uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                  int pk_rows, int pk_from_mont, uint32_t *__restrict__ out_dg,
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
-                                                 int64_t C, int tiles, int tiles_per_block, int slices, int64_t n_blocks) {
+                                                 int64_t C, int tiles, int tiles_per_block, int slices, int64_t n_blocks, int check_skip) {
     static_assert(OT == 4, "matrix tile is loaded as uint4 per digit");
     extern __shared__ __attribute__((aligned(16))) uint32_t xs[];
     const int lane = threadIdx.x & 63;
@@ -361,6 +361,14 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
     const int t_end = min(tiles, (slice + 1) * tiles_per_block);
     for (int tile = slice * tiles_per_block + wib; tile < t_end; tile += W) {
         const int nv = min(OT, n_out - tile * OT);
+        if constexpr (CHECK) {
+            // optional: skip tiles none of whose rows is compared (plan option, off by default)
+            if (check_skip) {
+                int any = 0;
+                for (int o = 0; o < nv; o++) any |= check_mask[tile * OT + o];
+                if (!any) continue;
+            }
+        }
         const uint4 *mt = reinterpret_cast<const uint4 *>(M) + (size_t)tile * n_in * NL;
         const int32_t *ndp = ndt + (size_t)tile * n_in;
         uint64_t col[OT][2 * NL];
@@ -544,7 +552,7 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
                    const uint32_t *in_pk, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *scratch_dg,
                    uint32_t *out_pk, hb_view ov, int64_t out_count,
                    int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                   int64_t C, hipStream_t s) {
+                   int64_t C, hipStream_t s, int check_skip) {
     if (C <= 0 || m->n_out == 0) return HB_OK;
     const int tiles = m_tiles(m->n_out);
     const int64_t groups = (C + 63) / 64;
@@ -567,7 +575,7 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
 #define HB_MV3(NL_, NW_, CHK_, PP_)                                                                                             \
         do {                                                                                                                    \
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_matvec3<NL_, NW_, CHK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024))); \
-            k_matvec3<NL_, NW_, CHK_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, in_pk, iv.stride_c, iv.stride_l, in_rows_dev, in_count, m->K, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks); \
+            k_matvec3<NL_, NW_, CHK_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, in_pk, iv.stride_c, iv.stride_l, in_rows_dev, in_count, m->K, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks, check_skip); \
         } while (0)
         if (ctx->n_limbs == 4) { if (check) HB_MV3(9, 8, true, ctx->pw); else HB_MV3(9, 8, false, ctx->pw); }
         else { if (check) HB_MV3(3, 2, true, ctx->pn); else HB_MV3(3, 2, false, ctx->pn); }

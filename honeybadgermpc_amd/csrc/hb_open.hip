@@ -34,6 +34,7 @@ struct hb_open_plan {
     uint32_t *coef_dg;   // [d][NL][max_C] decoded coefficients, Montgomery digit planes
     uint32_t *coef_pk;   // [d][max_C] decoded coefficients, canonical (R2 decode: flattened from here)
     int32_t *mismatch_dev;
+    int validate_arrived_only;   // option: re-encode only the tiles that contain compared rows
 };
 
 extern "C" {
@@ -48,6 +49,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
     pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr;
+    pl->validate_arrived_only = 0;
     const int L = ctx->n_limbs;
     std::vector<uint64_t> xz((size_t)d * L);
     for (int i = 0; i < d; i++) {
@@ -76,7 +78,6 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     if (rc) { delete pl; return rc; }
     HB_HIP(ctx, hipMalloc(&pl->in_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
     HB_HIP(ctx, hipMalloc(&pl->coef_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
-    HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
     HB_HIP(ctx, hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     HB_HIP(ctx, hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
     *out = pl;
@@ -104,7 +105,7 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
     hb_view none{0, 0};
     return launch_matvec2(pl->ctx, pl->V, pl->coef_dg, nullptr, none, nullptr, 0, nullptr,
                           (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, 0, 0, nullptr,
-                          pl->mask_dev, pl->mismatch_dev, C, s);
+                          pl->mask_dev, pl->mismatch_dev, C, s, pl->validate_arrived_only);
 }
 
 int hb_open_r1_decode(hb_open_plan *pl, const uint64_t *r1_cols_dev, int64_t B, uint64_t *r2_msg_dev, void *stream) {
@@ -137,6 +138,12 @@ int hb_open_status(hb_open_plan *pl, void *stream) {
         return fail(pl->ctx, HB_ERR_MISMATCH, "Optimistic decoding failed");   // reed_solomon.py:323
     }
     return HB_OK;
+}
+
+int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
+    if (!pl) return HB_ERR_BAD_ARG;
+    if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { pl->validate_arrived_only = value ? 1 : 0; return HB_OK; }
+    return HB_ERR_BAD_ARG;
 }
 
 void hb_open_plan_destroy(hb_open_plan *pl) {

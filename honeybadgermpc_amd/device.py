@@ -82,6 +82,13 @@ class BatchOpen:
         ctx.check(rc, "hb_open_plan_create")
         self.h = h
 
+    VALIDATE_ARRIVED_ONLY = 1
+
+    def set_validate_arrived_only(self, on):
+        """Re-encode only the output tiles that contain a compared (later-arrived) row instead of
+        all n rows as the reference's encode_batch does (reed_solomon.py:313).  Same decision."""
+        self.ctx.check(self.ctx.lib.hb_open_plan_set_option(self.h, self.VALIDATE_ARRIVED_ONLY, 1 if on else 0), "set_option")
+
     def chunks(self, b):
         return (b + self.d - 1) // self.d
 

@@ -145,6 +145,12 @@ int hb_open_r1_encode(hb_open_plan *plan, const uint64_t *shares_dev, int64_t B,
 int hb_open_r1_decode(hb_open_plan *plan, const uint64_t *r1_cols_dev, int64_t B, uint64_t *r2_msg_dev, void *stream);
 int hb_open_r2_decode(hb_open_plan *plan, const uint64_t *r2_cols_dev, int64_t B, uint64_t *result_dev, void *stream);
 int hb_open_status(hb_open_plan *plan, void *stream);
+/* Options.  HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY (default 0): the reference re-encodes the guess at ALL n
+ * points (encoder.encode_batch, reed_solomon.py:313) and then compares the columns that arrive; with
+ * the option on, only output tiles containing a compared row are re-encoded.  Same accept/reject
+ * decision, less arithmetic; off by default so that an open performs the reference's 3 full encodes. */
+#define HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY 1
+int hb_open_plan_set_option(hb_open_plan *plan, int option, int value);
 void hb_open_plan_destroy(hb_open_plan *plan);
 
 /* host-side self test of the radix-2^29 arithmetic templates (no GPU needed):

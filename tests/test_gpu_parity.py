@@ -242,6 +242,16 @@ def test_batch_open_vs_oracle(n, t, b, use_omega):
         op.r2_decode(ctx.upload_ints([v for col in bad for v in col]), b)
         assert not op.ok()
         assert op.ok()  # flag resets
+    # opt-in: re-encode only tiles holding compared rows -- identical decisions
+    op.set_validate_arrived_only(True)
+    res2 = op.r2_decode(ctx.upload_ints([v for col in r2_cols for v in col]), b)
+    assert op.ok() and np.array_equal(as_np(res2), o_res)
+    if zc:
+        bad = [list(col) for col in r2_cols]
+        bad[zc[0]][0] = (bad[zc[0]][0] + 1) % P
+        op.r2_decode(ctx.upload_ints([v for col in bad for v in col]), b)
+        assert not op.ok()
+    op.set_validate_arrived_only(False)
     rest = [i for i in range(n) if i not in z and i not in zc]
     if rest:
         bad = [list(col) for col in r2_cols]
