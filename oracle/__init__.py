@@ -343,18 +343,21 @@ def wb_decode(x, k, encoded, modulus):
 # ---------------------------------------------------------------------------
 # whole fault-free per-party open on packed limb arrays (cpu_baseline workload)
 # ---------------------------------------------------------------------------
-def batch_open_limbs(modulus, n, d, x, shares, r1_cols, r2_cols, z, zc, use_fft=False, omega=0, order=0):
+def batch_open_limbs(modulus, n, d, x, shares, r1_cols, r2_cols, z, zc, use_fft=False, omega=0, order=0, out=None):
     """All array arguments are (count, 4) uint64 canonical limb arrays.
-    Returns (rc, r1_out[n*C], r2_msg[C], result[B])."""
+    Returns (rc, r1_out[n*C], r2_msg[C], result[B]).  `out` = a previous return's three arrays to reuse."""
     b = shares.shape[0]
     c = (b + d - 1) // d
     xa = _limbs(x, modulus)
     oa = _limbs([omega], modulus)
     za = np.array(z, dtype=np.int32)
     zca = np.array(list(zc) if len(zc) else [0], dtype=np.int32)
-    r1_out = np.zeros((n * c, 4), dtype=np.uint64)
-    r2_msg = np.zeros((c, 4), dtype=np.uint64)
-    result = np.zeros((b, 4), dtype=np.uint64)
+    if out is not None:
+        r1_out, r2_msg, result = out
+    else:
+        r1_out = np.zeros((n * c, 4), dtype=np.uint64)
+        r2_msg = np.zeros((c, 4), dtype=np.uint64)
+        result = np.zeros((b, 4), dtype=np.uint64)
     rc = lib().orc_batch_open(
         _ptr(_p(modulus)), n, d, 1 if use_fft else 0, _ptr(oa), int(order), _ptr(xa),
         _ptr(np.ascontiguousarray(shares)), ctypes.c_long(b),
