@@ -204,13 +204,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # test hook for 1-GPU boxes: HB_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo for the
+    # barrier / max-time reduction (RCCL cannot place two ranks on one device).  Never set by the driver.
+    share_gpu = os.environ.get("HB_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
+    backend = "gloo" if share_gpu else "nccl"
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
     else:
         torch.cuda.set_device(local_rank)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -259,7 +268,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert ok, "validation mismatch in timed region"
