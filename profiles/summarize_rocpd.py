@@ -20,6 +20,21 @@ def main(path):
     groups = {}
     for name, gx, wx, vg, av, sg, lds, dur in rows:
         groups.setdefault((short(name), gx, wx, vg, av, sg, lds), []).append(dur)
+    # a kernel launched with the same geometry for different jobs (encode vs decode) is split where its
+    # durations are clearly bimodal
+    split = {}
+    for key, durs in groups.items():
+        lo, hi = min(durs), max(durs)
+        if len(durs) >= 6 and hi > 1.45 * lo:
+            mid = (lo + hi) / 2
+            a = [d for d in durs if d < mid]
+            b = [d for d in durs if d >= mid]
+            if len(a) >= 2 and len(b) >= 2:
+                split[(key[0] + " [short launches]",) + key[1:]] = a
+                split[(key[0] + " [long launches]",) + key[1:]] = b
+                continue
+        split[key] = durs
+    groups = split
     total = sum(sum(v) for v in groups.values())
     print(f"{'kernel':<60} {'grid':>9} {'wg':>4} {'vgpr':>5} {'sgpr':>5} {'lds':>6} {'calls':>6} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'total_ms':>9} {'%':>6}")
     for key, durs in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
