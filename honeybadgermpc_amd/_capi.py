@@ -65,6 +65,7 @@ SYMBOLS = {
     "hb_fft_batch_interpolate": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _vp, _vp]),
     "hb_gao_decode": (_i, [_vp, _vp, _i, _i, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "hb_wb_decode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "hb_sqrt_mod": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "hb_open_plan_create": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i64, _pp, _vp]),
     "hb_open_r1_encode": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "hb_open_r1_decode": (_i, [_vp, _vp, _i64, _vp, _vp]),

@@ -19,7 +19,7 @@ __all__ = [
     "lagrange_interpolate", "evaluate", "vandermonde_inverse", "InterpolationError",
     "vandermonde_batch_interpolate", "vandermonde_batch_evaluate", "fft", "partial_fft",
     "fft_batch_evaluate", "fft_interpolate", "fft_batch_interpolate", "gao_interpolate",
-    "sqrt_mod", "SetNTLNumThreads", "AvailableNTLThreads", "SetNumThreads", "GetMaxThreads",
+    "sqrt_mod", "sqrt_mod_batch", "SetNTLNumThreads", "AvailableNTLThreads", "SetNumThreads", "GetMaxThreads",
 ]
 
 
@@ -233,34 +233,24 @@ def gao_interpolate(x, y, k, modulus, z=None, omega=None, order=None, use_omega_
 # ---------------------------------------------------------------------------
 # misc
 # ---------------------------------------------------------------------------
-def sqrt_mod(a, n):
-    """Some r with r*r = a (mod n), n an odd prime (pyx:441-444, NTL SqrRootMod).
-    Which root is unpinned by the reference (tests/test_ntl.py:331-341 checks r^2 only).
-    Scalar utility that is not on the batch path: Tonelli-Shanks on host ints."""
-    a %= n
-    if a == 0:
-        return 0
-    if pow(a, (n - 1) // 2, n) != 1:
+def sqrt_mod_batch(values, modulus):
+    """Square roots of a list of residues in one launch; ValueError if any is a non-residue."""
+    ctx = Context.get(modulus)
+    t = ctx.torch
+    c = len(values)
+    din = ctx.upload_ints(list(values))
+    dout = ctx.empty(c)
+    dok = t.zeros(c, dtype=t.uint8, device=ctx.tdev)
+    ctx.check(ctx.lib.hb_sqrt_mod(ctx.h, ctx.ptr(din), c, ctx.ptr(dout), ctx.ptr(dok), ctx.stream()), "sqrt_mod")
+    if not bool(dok.all().item()):
         raise ValueError("sqrt_mod: not a quadratic residue")
-    if n % 4 == 3:
-        return pow(a, (n + 1) // 4, n)
-    q, s = n - 1, 0
-    while q % 2 == 0:
-        q //= 2
-        s += 1
-    z = 2
-    while pow(z, (n - 1) // 2, n) != n - 1:
-        z += 1
-    m, c, t, r = s, pow(z, q, n), pow(a, q, n), pow(a, (q + 1) // 2, n)
-    while t != 1:
-        i, tt = 0, t
-        while tt != 1:
-            tt = tt * tt % n
-            i += 1
-        b = pow(c, 1 << (m - i - 1), n)
-        m, c = i, b * b % n
-        t, r = t * c % n, r * b % n
-    return r
+    return ctx.download_ints(dout)
+
+
+def sqrt_mod(a, n):
+    """Some r with r*r = a (mod n), n an odd prime (pyx:441-444, NTL SqrRootMod).  Which root is
+    unpinned by the reference (tests/test_ntl.py:331-341 checks r^2 only).  Tonelli-Shanks on the GPU."""
+    return sqrt_mod_batch([a], n)[0]
 
 
 # Thread knobs exist only for API parity: the GPU launch geometry is not a user setting.

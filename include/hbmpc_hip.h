@@ -127,6 +127,10 @@ int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, const uint64
                  const uint8_t *present_dev, int64_t C, uint64_t *coeffs_dev, int32_t *coeff_len_dev,
                  int32_t *status_dev, void *stream);
 
+/* sqrt_mod (pyx:441-444, NTL SqrRootMod), batched: out[i]^2 == a[i] (mod p), ok[i] = 0 for a non-residue.
+ * Which of the two roots is returned is not pinned by the reference (tests/test_ntl.py:331-341). */
+int hb_sqrt_mod(hb_ctx *ctx, const uint64_t *a_dev, int64_t C, uint64_t *out_dev, uint8_t *ok_dev, void *stream);
+
 /* ---- one party's fault-free batch open -------------------------------------------------
  * The compute of batch_reconstruct (batch_reconstruction.py:158-227) for one party when no
  * received column is wrong: R1 encode; R1 optimistic decode + validating re-encode + compare

@@ -517,3 +517,51 @@ def test_wb_batch_vs_oracle(p, n, k, reps):
         ne = [emax, 0, emax // 2, emax + 1, min(n - nn, 2 * emax + 1)][trial % 5]
         words.append(_corrupt(rnd, enc, min(ne, n - nn), nn, p)[0])
     assert wb_decode_batch(x, k, words, p) == oracle.wb_decode_batch(x, k, words, p)
+
+
+def test_sqrt_mod(hip):  # reference tests/test_ntl.py:331-341
+    rnd = random.Random(0)
+    for p in (P, 53, 13, (1 << 255) - 19, 0xFFFFFFFF00000001):
+        xs = [rnd.randrange(p) for _ in range(200)] + [0, 1, p - 1]
+        sq = [x * x % p for x in xs]
+        roots = hip.sqrt_mod_batch(sq, p)
+        assert [r * r % p for r in roots] == sq
+        assert hip.sqrt_mod(sq[5], p) in (xs[5] % p, (p - xs[5]) % p)
+    # a non-residue is reported, not silently mis-answered
+    nr = next(v for v in range(2, 100) if pow(v, (P - 1) // 2, P) == P - 1)
+    with pytest.raises(ValueError):
+        hip.sqrt_mod(nr, P)
+
+
+def test_capi_degenerate_shapes():
+    """empty batches and zero-width operands through the C ABI: no launch, no error"""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context, np_ptr
+
+    ctx = Context.get(P)
+    lib = ctx.lib
+    x = ctx.host_elems([1, 2, 3])
+    buf = ctx.empty(8)
+    s = ctx.stream()
+    assert lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(x), 3, ctx.ptr(buf), 0, 2, ctx.ptr(buf), s) == 0
+    assert lib.hb_vandermonde_batch_interpolate(ctx.h, np_ptr(x), 3, ctx.ptr(buf), 0, ctx.ptr(buf), s) == 0
+    om = ctx.host_elems([1])
+    assert lib.hb_fft_batch_evaluate(ctx.h, np_ptr(om), 1, ctx.ptr(buf), 0, 1, 1, ctx.ptr(buf), s) == 0
+    t = torch
+    z = t.zeros(1, dtype=t.int32, device="cuda")
+    z8 = t.zeros(1, dtype=t.uint8, device="cuda")
+    assert lib.hb_gao_decode(ctx.h, np_ptr(x), 3, 1, ctx.ptr(buf), 0, ctx.ptr(buf), ctx.ptr(buf), ctx.ptr(z), ctx.ptr(z8), s) == 0
+    assert lib.hb_wb_decode(ctx.h, np_ptr(x), 3, 1, ctx.ptr(buf), ctx.ptr(z8), 0, ctx.ptr(buf), ctx.ptr(z), ctx.ptr(z), s) == 0
+    assert lib.hb_sqrt_mod(ctx.h, ctx.ptr(buf), 0, ctx.ptr(buf), ctx.ptr(z8), s) == 0
+    # d = 0 coefficients: every evaluation is zero
+    out = ctx.empty(6)
+    out.fill_(7)
+    assert lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(x), 3, ctx.ptr(buf), 2, 0, ctx.ptr(out), s) == 0
+    torch.cuda.synchronize()
+    assert int(out.abs().sum().item()) == 0
+    # bad arguments are reported, not crashed on
+    from honeybadgermpc_amd._capi import HB_ERR_BAD_ARG
+
+    assert lib.hb_fft_batch_evaluate(ctx.h, np_ptr(om), 3, ctx.ptr(buf), 1, 1, 1, ctx.ptr(buf), s) == HB_ERR_BAD_ARG   # order not a power of two
+    assert lib.hb_wb_decode(ctx.h, np_ptr(x), 3, 5, ctx.ptr(buf), ctx.ptr(z8), 1, ctx.ptr(buf), ctx.ptr(z), ctx.ptr(z), s) == HB_ERR_BAD_ARG  # k > n

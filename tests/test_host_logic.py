@@ -441,3 +441,24 @@ def test_batched_robust_update_equals_sequential(backend, robust, use_omega):
                 assert inc.get_results()[0] == msgs
         assert traces[0] == traces[1]
         assert robust != "gao" or traces[0][-1][1] is True
+
+
+def test_wire_format_roundtrip():
+    import numpy as np
+
+    from honeybadgermpc_amd import wire
+
+    rnd = random.Random(1)
+    vals = [rnd.randrange(BLS) for _ in range(37)] + [0, BLS - 1]
+    blob = wire.pack_ints(vals, BLS)
+    assert len(blob) == 16 + 32 * len(vals) and blob[:4] == b"HBFE"
+    assert wire.unpack_ints(blob) == vals
+    assert wire.unpack_ints(wire.pack_ints([BLS + 5], BLS)) == [5]
+    a = wire.unpack_limbs(blob)
+    assert a.shape == (len(vals), 4) and wire.pack_limbs(a) == blob
+    t = wire.wire_to_tensor(blob)
+    assert wire.tensor_to_wire(t) == blob
+    for bad in (blob[:10], b"XXXX" + blob[4:], blob + b"\0"):
+        with pytest.raises(ValueError):
+            wire.unpack_limbs(bad)
+    assert wire.unpack_ints(wire.pack_limbs(np.zeros((0, 4), dtype=np.uint64))) == []
