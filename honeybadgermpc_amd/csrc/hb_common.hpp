@@ -103,6 +103,12 @@ int launch_matvec(hb_ctx *ctx, const hb_matrix *m, const uint32_t *in, hb_view i
                   int64_t C, hipStream_t s);
 int launch_copy_view(hb_ctx *ctx, const uint32_t *src, hb_view sv, uint32_t *dst, hb_view dv, int64_t C, int L, int64_t dst_count, hipStream_t s);
 
+// ---- NTT (hb_ntt.hip) ---------------------------------------------------------------------
+int get_twiddles(hb_ctx *ctx, const uint64_t *omega_host, int n, uint32_t **tw, hipStream_t s);
+int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, hb_view iv, int64_t in_count, int d, int k,
+                   uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+                   int64_t C, hipStream_t s);
+
 // ---- second-generation (raw small-entry matrix) path, hb_fast.hip ----------------------
 void fast_matrix_free(FastMatrix *m);
 int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s);

@@ -66,27 +66,38 @@ __device__ __forceinline__ void butterfly(uint32_t *a0, uint32_t *a1, const uint
     for (int q = 0; q < NL; q++) { a0[q] = s0[q]; a1[q] = s1[q]; }
 }
 
-// whole transform in LDS; PB polynomials per block
-template <int NL, int NW>
-__global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uint32_t *__restrict__ tw, const uint32_t *__restrict__ in, int d,
-                                                 int n, int logn, int k, uint32_t *__restrict__ out, int64_t C, int PB) {
+// whole transform in LDS; PB polynomials per block.  Strided views on both sides:
+//   in(c, j)  at in  + (c*in_sc  + j*in_sl ) elements, zero beyond in_count (chunk_data padding)
+//   out(c, i) at out + (c*out_sc + i*out_sl) elements, i < k, skipped beyond out_count
+// `*_poly_fast` picks the thread->element map so that consecutive lanes touch consecutive
+// addresses for coefficient-major / party-major buffers (stride_c == 1).
+// CHECK: instead of storing, compare out(c, i) with the buffer for rows i in check_mask
+// (the validating re-encode of IncrementalDecoder, reed_solomon.py:313-326).
+template <int NL, int NW, bool CHECK>
+__global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uint32_t *__restrict__ tw,
+                                                 const uint32_t *__restrict__ in, int64_t in_sc, int64_t in_sl, int64_t in_count, int d,
+                                                 int n, int logn, int k,
+                                                 uint32_t *__restrict__ out, int64_t out_sc, int64_t out_sl, int64_t out_count,
+                                                 const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
+                                                 int64_t C, int PB, int in_poly_fast, int out_poly_fast) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int64_t c0 = (int64_t)blockIdx.x * PB;
     const int npoly = (int)min((int64_t)PB, C - c0);
     const int dd = min(d, n);
-    // load, bit-reversed, zero padded
-    for (int idx = threadIdx.x; idx < npoly * n; idx += blockDim.x) {
-        const int pl = idx / n, pos = idx % n;
-        const int j = (int)bitrev((uint32_t)pos, logn);
-        uint32_t dg[NL];
-        if (j < dd) {
-            load_digits<NL, NW>(dg, in + ((c0 + pl) * (int64_t)d + j) * NW);
-        } else {
+    for (int idx = threadIdx.x; idx < npoly * n * NL; idx += blockDim.x) lds[idx] = 0;
+    __syncthreads();
+    // load the dd coefficients of every polynomial into bit-reversed positions
+    for (int idx = threadIdx.x; idx < npoly * dd; idx += blockDim.x) {
+        const int pl = in_poly_fast ? idx % npoly : idx / dd;
+        const int j = in_poly_fast ? idx / npoly : idx % dd;
+        const int64_t e = (c0 + pl) * in_sc + (int64_t)j * in_sl;
+        if (e < in_count) {
+            uint32_t dg[NL];
+            load_digits<NL, NW>(dg, in + e * NW);
+            uint32_t *dst = lds + ((size_t)pl * n + bitrev((uint32_t)j, logn)) * NL;
 #pragma unroll
-            for (int q = 0; q < NL; q++) dg[q] = 0;
+            for (int q = 0; q < NL; q++) dst[q] = dg[q];
         }
-#pragma unroll
-        for (int q = 0; q < NL; q++) lds[(size_t)idx * NL + q] = dg[q];
     }
     __syncthreads();
     const int half = n >> 1;
@@ -103,11 +114,25 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
         __syncthreads();
     }
     for (int idx = threadIdx.x; idx < npoly * k; idx += blockDim.x) {
-        const int pl = idx / k, i = idx % k;
+        const int pl = out_poly_fast ? idx % npoly : idx / k;
+        const int i = out_poly_fast ? idx / npoly : idx % k;
+        const int64_t e = (c0 + pl) * out_sc + (int64_t)i * out_sl;
         uint32_t dg[NL];
 #pragma unroll
         for (int q = 0; q < NL; q++) dg[q] = lds[((size_t)pl * n + i) * NL + q];
-        store_digits<NL, NW>(out + ((c0 + pl) * (int64_t)k + i) * NW, dg);
+        if constexpr (CHECK) {
+            if (check_mask[i]) {
+                uint32_t w[NW], ex[NW];
+                pack<NL, NW>(w, dg);
+                load_words<NW>(ex, out + e * NW);
+                uint32_t diff = 0;
+#pragma unroll
+                for (int q = 0; q < NW; q++) diff |= ex[q] ^ w[q];
+                if (diff) atomicOr(mismatch, 1);
+            }
+        } else {
+            if (e < out_count) store_digits<NL, NW>(out + e * NW, dg);
+        }
     }
 }
 
@@ -149,6 +174,10 @@ __global__ void k_ntt_g_store(const uint32_t *__restrict__ buf, int n, int k, ui
     store_digits<NL, NW>(out + (size_t)idx * NW, dg);
 }
 
+}  // namespace
+
+namespace hb {
+
 int get_twiddles(hb_ctx *ctx, const uint64_t *omega_host, int n, uint32_t **tw, hipStream_t s) {
     std::string key = "tw:" + std::to_string(n) + ":";
     key.append(reinterpret_cast<const char *>(omega_host), (size_t)ctx->n_limbs * 8);
@@ -169,6 +198,36 @@ int get_twiddles(hb_ctx *ctx, const uint64_t *omega_host, int n, uint32_t **tw, 
     return HB_OK;
 }
 
+// LDS NTT launcher with views; returns HB_ERR_UNSUPPORTED when the order does not fit LDS
+int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, hb_view iv, int64_t in_count, int d, int k,
+                   uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+                   int64_t C, hipStream_t s) {
+    if (C <= 0 || k <= 0) return HB_OK;
+    int logn = 0; while ((1 << logn) < n) logn++;
+    const size_t elem_lds = (size_t)ctx->nl() * 4;
+    if ((size_t)n * elem_lds > 160 * 1024) return fail(ctx, HB_ERR_UNSUPPORTED, "ntt: order does not fit LDS");
+    int PB = (int)((40 * 1024) / ((size_t)n * elem_lds)); if (PB < 1) PB = 1; if (PB > 64) PB = 64;
+    if ((int64_t)PB > C) PB = (int)C;
+    const size_t lds = (size_t)PB * n * elem_lds;
+    const int64_t blocks = (C + PB - 1) / PB;
+    if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "fft: batch too large");
+    const int ipf = iv.stride_c == 1 ? 1 : 0, opf = ov.stride_c == 1 ? 1 : 0;
+    const bool check = check_mask_dev != nullptr;
+#define HB_NTT(NL_, NW_, CHK_, PP_)                                                                                                       \
+    do {                                                                                                                                  \
+        HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds<NL_, NW_, CHK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024))); \
+        k_ntt_lds<NL_, NW_, CHK_><<<(unsigned)blocks, 256, lds, s>>>(PP_, tw, in, iv.stride_c, iv.stride_l, in_count, d, n, logn, k, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev, C, PB, ipf, opf); \
+    } while (0)
+    if (ctx->n_limbs == 4) { if (check) HB_NTT(9, 8, true, ctx->pw); else HB_NTT(9, 8, false, ctx->pw); }
+    else { if (check) HB_NTT(3, 2, true, ctx->pn); else HB_NTT(3, 2, false, ctx->pn); }
+#undef HB_NTT
+    HB_LAUNCH_CHECK(ctx);
+    return HB_OK;
+}
+
+}  // namespace hb
+
+namespace {
 }  // namespace
 
 extern "C" {
@@ -209,20 +268,8 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, co
     int rc = get_twiddles(ctx, omega_host, n, &tw, s); if (rc) return rc;
     const size_t elem_lds = (size_t)NLr * 4;
     if ((size_t)n * elem_lds <= 160 * 1024) {
-        int PB = (int)((40 * 1024) / ((size_t)n * elem_lds)); if (PB < 1) PB = 1; if (PB > 64) PB = 64;
-        if ((int64_t)PB > C) PB = (int)C;
-        const size_t lds = (size_t)PB * n * elem_lds;
-        const int64_t blocks = (C + PB - 1) / PB;
-        if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "fft: batch too large");
-        if (ctx->n_limbs == 4) {
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-            k_ntt_lds<9, 8><<<(unsigned)blocks, 256, lds, s>>>(ctx->pw, tw, (const uint32_t *)coeffs_dev, d, n, logn, k, (uint32_t *)out_dev, C, PB);
-        } else {
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-            k_ntt_lds<3, 2><<<(unsigned)blocks, 256, lds, s>>>(ctx->pn, tw, (const uint32_t *)coeffs_dev, d, n, logn, k, (uint32_t *)out_dev, C, PB);
-        }
-        HB_LAUNCH_CHECK(ctx);
-        return HB_OK;
+        hb_view iv{d, 1}, ov{k, 1};
+        return launch_ntt_lds(ctx, tw, n, (const uint32_t *)coeffs_dev, iv, INT64_MAX, d, k, (uint32_t *)out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
     }
     // large order: stage-by-stage over a digit buffer in HBM
     if ((double)C * n * elem_lds > 64.0e9) return fail(ctx, HB_ERR_UNSUPPORTED, "fft: scratch too large");

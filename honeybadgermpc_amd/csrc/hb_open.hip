@@ -32,9 +32,13 @@ struct hb_open_plan {
     int32_t *mask_dev;   // n+1 ints: rows to validate
     uint32_t *in_dg;     // [d][NL][max_C] pre-scaled inputs (digit planes)
     uint32_t *coef_dg;   // [d][NL][max_C] decoded coefficients, Montgomery digit planes
-    uint32_t *coef_pk;   // [d][max_C] decoded coefficients, canonical (R2 decode: flattened from here)
     int32_t *mismatch_dev;
     int validate_arrived_only;   // option: re-encode only the tiles that contain compared rows
+    // omega-power points with a transform large enough to pay: encodes run as radix-2 NTTs
+    // (hb_ntt.hip) on canonical coefficients instead of n x d products
+    int ntt_order;               // 0 = mat-vec encodes
+    uint32_t *tw;                // twiddles (ctx-owned cache)
+    uint32_t *coef_pk;           // [d][max_C] canonical decoded coefficients (NTT input), NTT mode only
 };
 
 extern "C" {
@@ -42,7 +46,6 @@ extern "C" {
 int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const uint64_t *x_host,
                         const uint64_t *omega_host, int order, const int32_t *z_host, const int32_t *zc_host,
                         int n_check, int64_t max_B, hb_open_plan **out, void *stream) {
-    (void)use_omega_powers; (void)omega_host; (void)order;   // the points x already carry the policy
     if (!ctx || !out || n <= 0 || d <= 0 || d > n || !x_host || !z_host || max_B < 0) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     hb_open_plan *pl = new hb_open_plan();
@@ -50,6 +53,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
     pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr;
     pl->validate_arrived_only = 0;
+    pl->ntt_order = 0; pl->tw = nullptr;
     const int L = ctx->n_limbs;
     std::vector<uint64_t> xz((size_t)d * L);
     for (int i = 0; i < d; i++) {
@@ -78,6 +82,18 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     if (rc) { delete pl; return rc; }
     HB_HIP(ctx, hipMalloc(&pl->in_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
     HB_HIP(ctx, hipMalloc(&pl->coef_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
+    if (use_omega_powers && omega_host && order >= n && order > 0 && (order & (order - 1)) == 0) {
+        // MADs per chunk: full-digit mat-vec n*d*NL^2 vs butterflies (order/2)*log2(order)*(2 NL^2 + 4 NL)
+        int logn = 0; while ((1 << logn) < order) logn++;
+        const double nl2 = (double)ctx->nl() * ctx->nl();
+        const double mv = (double)n * d * nl2, ntt = 0.5 * order * logn * (2.0 * nl2 + 4.0 * ctx->nl());
+        if (ntt < mv && (size_t)order * ctx->nl() * 4 <= 40 * 1024) {
+            rc = get_twiddles(ctx, omega_host, order, &pl->tw, s);
+            if (rc) { delete pl; return rc; }
+            pl->ntt_order = order;
+            HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+        }
+    }
     HB_HIP(ctx, hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     HB_HIP(ctx, hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
     *out = pl;
@@ -90,6 +106,9 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
     const int64_t C = (B + pl->d - 1) / pl->d;
     hb_view iv{pl->d, 1}, ov{1, C};
     hipStream_t s = (hipStream_t)stream;
+    if (pl->ntt_order)
+        return launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, (const uint32_t *)shares_dev, iv, B, pl->d, pl->n,
+                              (uint32_t *)r1_out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
     return launch_matvec2(pl->ctx, pl->V, nullptr, (const uint32_t *)shares_dev, iv, nullptr, B, pl->in_dg,
                           (uint32_t *)r1_out_dev, ov, INT64_MAX, pl->n, 0, nullptr, nullptr, nullptr, C, s);
 }
@@ -98,6 +117,17 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
 static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64_t C, uint32_t *pk_dst, hb_view pv, int64_t pk_count,
                                int pk_rows, hipStream_t s) {
     hb_view pm{1, C};
+    if (pl->ntt_order) {
+        // decode to canonical coefficient-major coefficients, validate with an NTT in CHECK mode,
+        // then hand the caller the rows it asked for
+        int rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
+                                pl->coef_pk, pm, INT64_MAX, pl->d, 1, nullptr, nullptr, nullptr, C, s);
+        if (rc) return rc;
+        rc = launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, pl->coef_pk, pm, INT64_MAX, pl->d, pl->n,
+                            (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s);
+        if (rc) return rc;
+        return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
+    }
     int rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
                             pk_dst, pv, pk_count, pk_rows, 1, pl->coef_dg, nullptr, nullptr, C, s);
     if (rc) return rc;
@@ -148,7 +178,7 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
 
 void hb_open_plan_destroy(hb_open_plan *pl) {
     if (!pl) return;
-    (void)hipFree(pl->in_dg); (void)hipFree(pl->coef_dg); (void)hipFree(pl->coef_pk);
+    (void)hipFree(pl->in_dg); (void)hipFree(pl->coef_dg); if (pl->coef_pk) (void)hipFree(pl->coef_pk);
     (void)hipFree(pl->mismatch_dev);
     fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv);
     delete pl;
