@@ -195,7 +195,8 @@ def test_matvec_views_and_check():
 
 
 # ------------------------------------------------------------------ per-party open pipeline
-@pytest.mark.parametrize("n,t,b,use_omega", [(4, 1, 3, False), (16, 5, 100, False), (16, 5, 96, True), (64, 21, 1000, False), (7, 2, 1, False)])
+@pytest.mark.parametrize("n,t,b,use_omega", [(4, 1, 3, False), (16, 5, 100, False), (16, 5, 96, True), (64, 21, 1000, False), (7, 2, 1, False),
+                                             (64, 21, 700, True), (256, 85, 300, True), (100, 33, 150, True), (4, 1, 5, True)])
 def test_batch_open_vs_oracle(n, t, b, use_omega):
     import torch
 
