@@ -113,9 +113,30 @@ def load_library():
 # bytes per element (hbmpc_ntl_helpers.pyx:20-29); ours is the same bytes at a
 # fixed width, packed into one contiguous buffer per call.
 # ---------------------------------------------------------------------------
+def _load_marshal():
+    """optional C helper (csrc/hb_pymarshal.c); marshalling is plumbing, so a pure-Python
+    fallback for it is fine -- unlike arithmetic, which has none"""
+    try:
+        import importlib.util
+
+        path = os.path.join(_HERE, "lib", "_hbmarshal.so")
+        spec = importlib.util.spec_from_file_location("_hbmarshal", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    except Exception:  # noqa: BLE001
+        return None
+
+
+_marshal = _load_marshal()
+
+
 def ints_to_limbs(values, modulus, nbytes=32):
     """list[int] -> (len, nbytes//8) uint64.  Values are reduced mod p on entry
     (pyx:31-32); negative ints raise OverflowError like int.to_bytes (pyx:20-22)."""
+    if _marshal is not None:
+        raw = _marshal.pack(values, modulus, nbytes)
+        return np.frombuffer(bytearray(raw), dtype=np.uint64).reshape(len(values), nbytes // 8)
     buf = bytearray(len(values) * nbytes)
     off = 0
     for v in values:
@@ -129,6 +150,8 @@ def ints_to_limbs(values, modulus, nbytes=32):
 
 
 def limbs_to_ints(arr, nbytes=32):
+    if _marshal is not None:
+        return _marshal.unpack(np.ascontiguousarray(arr), nbytes)
     b = np.ascontiguousarray(arr).tobytes()
     return [int.from_bytes(b[i : i + nbytes], "little") for i in range(0, len(b), nbytes)]
 

@@ -19,3 +19,8 @@ done
 for p in $pids; do wait $p; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libhbmpc_hip.so" $objs
 echo "built $OUT/libhbmpc_hip.so"
+# CPython helper for list[int] <-> limb marshalling (plumbing only)
+PYINC="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')"
+if [ ! -f "$OUT/_hbmarshal.so" ] || [ "$HERE/hb_pymarshal.c" -nt "$OUT/_hbmarshal.so" ]; then
+  gcc -O2 -shared -fPIC -I"$PYINC" "$HERE/hb_pymarshal.c" -o "$OUT/_hbmarshal.so"
+fi
