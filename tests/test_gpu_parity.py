@@ -566,3 +566,15 @@ def test_capi_degenerate_shapes():
 
     assert lib.hb_fft_batch_evaluate(ctx.h, np_ptr(om), 3, ctx.ptr(buf), 1, 1, 1, ctx.ptr(buf), s) == HB_ERR_BAD_ARG   # order not a power of two
     assert lib.hb_wb_decode(ctx.h, np_ptr(x), 3, 5, ctx.ptr(buf), ctx.ptr(z8), 1, ctx.ptr(buf), ctx.ptr(z), ctx.ptr(z), s) == HB_ERR_BAD_ARG  # k > n
+
+
+def test_interpolation_points_including_zero(hip):
+    """refine_triples interpolates at x = 0..d (reference progs/triple_refinement.py:43-44)"""
+    rnd = random.Random(2)
+    for d in (1, 4, 11):
+        x = list(range(d + 1))
+        rows = rand_rows(rnd, P, 5, d + 1)
+        want = oracle.vandermonde_batch_interpolate(x, rows, P)
+        assert hip.vandermonde_batch_interpolate(x, rows, P) == want
+        more = list(range(d + 1, 2 * d + 1))
+        assert hip.vandermonde_batch_evaluate(more, want, P) == oracle.vandermonde_batch_evaluate(more, want, P)

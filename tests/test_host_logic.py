@@ -462,3 +462,26 @@ def test_wire_format_roundtrip():
         with pytest.raises(ValueError):
             wire.unpack_limbs(bad)
     assert wire.unpack_ints(wire.pack_limbs(np.zeros((0, 4), dtype=np.uint64))) == []
+
+
+@pytest.mark.parametrize("n,t,k", [(4, 1, 3), (4, 1, 4), (7, 2, 5), (16, 5, 13)])
+def test_random_refinement(backend, n, t, k):  # reference tests/progs/test_random_refinement.py
+    """refine_randoms is linear, so refined share vectors of the n parties must again be
+    consistent degree-t sharings: every subset of t+1 parties reconstructs the same values,
+    and those values are the refinement of the secrets."""
+    from honeybadgermpc_amd.progs.random_refinement import refine_randoms
+
+    rnd = random.Random(n * 100 + k)
+    fp = GF(BLS)
+    poly = polynomials_over(fp)
+    point = EvalPoint(fp, n)
+    secrets = [rnd.randrange(BLS) for _ in range(k)]
+    sharings = [poly([s] + [rnd.randrange(BLS) for _ in range(t)]) for s in secrets]
+    per_party = [[sharings[j](point(i)).value for j in range(k)] for i in range(n)]
+    refined = [refine_randoms(n, t, fp, per_party[i]) for i in range(n)]
+    assert all(len(r) == k - t for r in refined)
+    want = refine_randoms(n, t, fp, secrets)
+    for subset in ([0, 1, 2, 3, 4, 5][: t + 1], list(range(n - t - 1, n))):
+        for j in range(k - t):
+            got = poly.interpolate_at([(point(i), fp(refined[i][j])) for i in subset], 0)
+            assert got == want[j]
