@@ -31,6 +31,7 @@ namespace hb {
 
 struct FastMatrix {
     int n_out, n_in;
+    int ot;             // outputs per tile in this matrix's layout (2 or 4)
     uint32_t *M;        // raw canonical digits, [tile][l][digit][OT]
     int32_t *nd;        // [tile][n_in] digits actually non-zero in that tile/term
     int32_t *negrow;    // [n_out] 1 => negate the output row (nullptr: none)
@@ -41,6 +42,10 @@ struct FastMatrix {
 
 namespace {
 
+// word index of digit q of matrix element (i, l): [tile][l][digit][ot], tile = i / ot
+__host__ __device__ inline size_t mf_index(int i, int l, int n_in, int nl, int q, int ot) {
+    return (((size_t)((i / ot) * n_in + l) * (size_t)nl + (size_t)q) * ot) + (size_t)(i % ot);
+}
 // digit-plane addressing: element (l, c), digit q  ->  ((l * NL + q) * C + c)
 __device__ __forceinline__ size_t dg_index(int l, int q, int64_t c, int64_t C, int nl) { return ((size_t)l * nl + q) * (size_t)C + (size_t)c; }
 
@@ -71,7 +76,7 @@ __global__ void __launch_bounds__(256) k_prescale(const FpParams<NL> P, const ui
 
 // V[i][l] = x_i^l as raw canonical digits in kernel layout
 template <int NL, int NW>
-__global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uint32_t *__restrict__ x, int n, int d, uint32_t *__restrict__ M) {
+__global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uint32_t *__restrict__ x, int n, int d, uint32_t *__restrict__ M, int ot) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t xd[NL], xm[NL], pw[NL];
@@ -82,7 +87,7 @@ __global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uin
         uint32_t c[NL];
         from_mont(c, pw, P);
 #pragma unroll
-        for (int q = 0; q < NL; q++) M[m_index(i, l, d, NL, q)] = c[q];
+        for (int q = 0; q < NL; q++) M[mf_index(i, l, d, NL, q, ot)] = c[q];
         mont_mul(pw, pw, xm, P);
     }
 }
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uin
 // factored inverse Vandermonde: N (raw), negrow, K_j = R^3 / den_j.  One block, thread j owns point j.
 template <int NL, int NW>
 __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const uint32_t *__restrict__ x, int k, uint32_t *__restrict__ M,
-                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, int *__restrict__ singular) {
+                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, int *__restrict__ singular, int ot) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *xs = smem;
     uint32_t *B0 = xs + (size_t)k * NL;
@@ -136,7 +141,7 @@ __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const 
         uint32_t c[NL];
         from_mont(c, b, P);
 #pragma unroll
-        for (int w = 0; w < NL; w++) M[m_index(k - 1, t, k, NL, w)] = c[w];
+        for (int w = 0; w < NL; w++) M[mf_index(k - 1, t, k, NL, w, ot)] = c[w];
     }
     for (int m = k - 1; m >= 1; m--) {
 #pragma unroll
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const 
         uint32_t c[NL];
         from_mont(c, b, P);
 #pragma unroll
-        for (int w = 0; w < NL; w++) M[m_index(m - 1, t, k, NL, w)] = c[w];
+        for (int w = 0; w < NL; w++) M[mf_index(m - 1, t, k, NL, w, ot)] = c[w];
         mont_mul(tmp, ev, nx, P);
         fp_add(ev, tmp, b, P);
     }
@@ -163,13 +168,13 @@ __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const 
 
 // nd[tile][l] = 1 + index of the highest non-zero digit over the tile's OT outputs (0 if all zero)
 template <int NL>
-__global__ void k_count_digits(const uint32_t *__restrict__ M, int tiles, int n_in, int32_t *__restrict__ nd) {
+__global__ void k_count_digits(const uint32_t *__restrict__ M, int tiles, int n_in, int32_t *__restrict__ nd, int ot) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= tiles * n_in) return;
-    const uint32_t *e = M + (size_t)idx * NL * OT;
+    const uint32_t *e = M + (size_t)idx * NL * ot;
     int top = 0;
     for (int q = 0; q < NL; q++)
-        for (int o = 0; o < OT; o++) if (e[q * OT + o]) top = q + 1;
+        for (int o = 0; o < ot; o++) if (e[q * ot + o]) top = q + 1;
     nd[idx] = top;
 }
 
@@ -301,7 +306,13 @@ __global__ void __launch_bounds__(256) k_matvec2(const FpParams<NL> P, const uin
 // exactly once per launch -- and its W waves then sweep the output tiles (tile = w, w+W, ...)
 // reading x from LDS ([term][digit][lane]: lane-contiguous dwords, conflict-free).
 // -------------------------------------------------------------------------------------
-template <int NL, int NW, bool CHECK>
+template <int OTT> struct MVec;
+template <> struct MVec<2> { using type = uint2; };
+template <> struct MVec<4> { using type = uint4; };
+__device__ __forceinline__ uint32_t mcomp(const uint2 &v, int o) { return o == 0 ? v.x : v.y; }
+__device__ __forceinline__ uint32_t mcomp(const uint4 &v, int o) { return o == 0 ? v.x : (o == 1 ? v.y : (o == 2 ? v.z : v.w)); }
+
+template <int NL, int NW, bool CHECK, int OTT>
 __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uint32_t *__restrict__ M, const int32_t *__restrict__ ndt,
                                                  const int32_t *__restrict__ negrow, int n_out, int n_in, int nsub,
                                                  const uint32_t *__restrict__ in_dg,
@@ -311,7 +322,8 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
                                                  int pk_rows, int pk_from_mont, uint32_t *__restrict__ out_dg,
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
                                                  int64_t C, int tiles, int tiles_per_block, int slices, int64_t n_blocks, int check_skip) {
-    static_assert(OT == 4, "matrix tile is loaded as uint4 per digit");
+    static_assert(OTT == 2 || OTT == 4, "matrix tile is loaded as one uint2 / uint4 per digit");
+    using MV = typename MVec<OTT>::type;
     extern __shared__ __attribute__((aligned(16))) uint32_t xs[];
     const int lane = threadIdx.x & 63;
     const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -360,21 +372,21 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
     const uint32_t *xl = xs + lane;
     const int t_end = min(tiles, (slice + 1) * tiles_per_block);
     for (int tile = slice * tiles_per_block + wib; tile < t_end; tile += W) {
-        const int nv = min(OT, n_out - tile * OT);
+        const int nv = min(OTT, n_out - tile * OTT);
         if constexpr (CHECK) {
             // optional: skip tiles none of whose rows is compared (plan option, off by default)
             if (check_skip) {
                 int any = 0;
-                for (int o = 0; o < nv; o++) any |= check_mask[tile * OT + o];
+                for (int o = 0; o < nv; o++) any |= check_mask[tile * OTT + o];
                 if (!any) continue;
             }
         }
-        const uint4 *mt = reinterpret_cast<const uint4 *>(M) + (size_t)tile * n_in * NL;
+        const MV *mt = reinterpret_cast<const MV *>(M) + (size_t)tile * n_in * NL;
         const int32_t *ndp = ndt + (size_t)tile * n_in;
-        uint64_t col[OT][2 * NL];
+        uint64_t col[OTT][2 * NL];
 #pragma unroll
-        for (int o = 0; o < OT; o++) col_zero(col[o]);
-        uint4 mc[NL], mn[NL];
+        for (int o = 0; o < OTT; o++) col_zero(col[o]);
+        MV mc[NL], mn[NL];
         int ndc, ndn;
 #pragma unroll
         for (int q = 0; q < NL; q++) mc[q] = mt[q];
@@ -391,15 +403,15 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
             if (used + ndc > BUDGET) {
                 used = 0;
 #pragma unroll
-                for (int o = 0; o < OT; o++) carry(col[o]);
+                for (int o = 0; o < OTT; o++) carry(col[o]);
             }
             used += ndc;
 #pragma unroll
             for (int i = 0; i < NL; i++) {
                 if (i < ndc) {
 #pragma unroll
-                    for (int o = 0; o < OT; o++) {
-                        const uint32_t md = (o == 0) ? mc[i].x : (o == 1) ? mc[i].y : (o == 2) ? mc[i].z : mc[i].w;
+                    for (int o = 0; o < OTT; o++) {
+                        const uint32_t md = mcomp(mc[i], o);
 #pragma unroll
                         for (int j = 0; j < NL; j++) col[o][i + j] += (uint64_t)md * xu[j];
                     }
@@ -411,9 +423,9 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
             ndc = ndn;
         }
 #pragma unroll
-        for (int o = 0; o < OT; o++) {
+        for (int o = 0; o < OTT; o++) {
             if (o < nv) {
-                const int i = tile * OT + o;
+                const int i = tile * OTT + o;
                 uint32_t r[NL];
                 redc(r, col[o], P);                    // columns hold <= BUDGET products each: no pre-carry needed
                 for (int s = 0; s < nsub; s++) cond_sub_p(r, P);
@@ -463,13 +475,28 @@ void fast_matrix_free(FastMatrix *m) {
     delete m;
 }
 
+static inline int f_tiles(int n_out, int ot) { return (n_out + ot - 1) / ot; }
+
+// Outputs per wave tile.  A lone wave can issue a v_mad_u64_u32 only every ~10 cycles
+// (scratch/ubench_occ.hip), so occupancy matters: 2 outputs per tile need 92 VGPRs (5 waves/SIMD)
+// against 164 (3 waves/SIMD) for 4.  Measured on config 3 the two are within noise (the 50 KB of LDS
+// per workgroup caps residency at 3 workgroups per CU either way, and 2-output tiles halve the
+// MADs per LDS read), so 4 stays the default; HB_FAST_OT=2 selects the other instantiation.
+static int pick_ot(hb_ctx *ctx, int n_in) {
+    const size_t lds = (size_t)n_in * ctx->nl() * 64 * 4;
+    if (lds > 72 * 1024) return 4;
+    int ot = 4;
+    if (const char *e = getenv("HB_FAST_OT")) { int v = atoi(e); if (v == 2 || v == 4) ot = v; }
+    return ot;
+}
+
 static int count_digits(hb_ctx *ctx, FastMatrix *m, hipStream_t s) {
-    const int tiles = m_tiles(m->n_out);
+    const int tiles = f_tiles(m->n_out, m->ot);
     HB_HIP(ctx, hipMalloc(&m->nd, sizeof(int32_t) * (size_t)(tiles * m->n_in > 0 ? tiles * m->n_in : 1)));
     const int tot = tiles * m->n_in;
     if (tot > 0) {
-        if (ctx->n_limbs == 4) k_count_digits<9><<<(tot + 127) / 128, 128, 0, s>>>(m->M, tiles, m->n_in, m->nd);
-        else k_count_digits<3><<<(tot + 127) / 128, 128, 0, s>>>(m->M, tiles, m->n_in, m->nd);
+        if (ctx->n_limbs == 4) k_count_digits<9><<<(tot + 127) / 128, 128, 0, s>>>(m->M, tiles, m->n_in, m->nd, m->ot);
+        else k_count_digits<3><<<(tot + 127) / 128, 128, 0, s>>>(m->M, tiles, m->n_in, m->nd, m->ot);
         HB_LAUNCH_CHECK(ctx);
     }
     return HB_OK;
@@ -479,14 +506,15 @@ static int count_digits(hb_ctx *ctx, FastMatrix *m, hipStream_t s) {
 int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s) {
     FastMatrix *m = new FastMatrix();
     m->n_out = n; m->n_in = d; m->negrow = nullptr; m->K = nullptr; m->nd = nullptr;
+    m->ot = pick_ot(ctx, d);
     const int NLr = ctx->nl();
-    size_t words = (size_t)m_tiles(n) * d * OT * NLr; if (!words) words = 1;
+    size_t words = (size_t)f_tiles(n, m->ot) * d * m->ot * NLr; if (!words) words = 1;
     HB_HIP(ctx, hipMalloc(&m->M, words * 4));
     HB_HIP(ctx, hipMemsetAsync(m->M, 0, words * 4, s));
     if (n > 0 && d > 0) {
         HB_DISPATCH(ctx,
-            (k_vand_raw<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, x_dev, n, d, m->M)),
-            (k_vand_raw<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, x_dev, n, d, m->M)));
+            (k_vand_raw<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, x_dev, n, d, m->M, m->ot)),
+            (k_vand_raw<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, x_dev, n, d, m->M, m->ot)));
         HB_LAUNCH_CHECK(ctx);
     }
     int rc = count_digits(ctx, m, s); if (rc) return rc;
@@ -505,8 +533,9 @@ int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out
     if (k > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "vandermonde inverse: k > 1023");
     FastMatrix *m = new FastMatrix();
     m->n_out = k; m->n_in = k; m->nd = nullptr;
+    m->ot = pick_ot(ctx, k);
     const int NLr = ctx->nl();
-    size_t words = (size_t)m_tiles(k) * k * OT * NLr; if (!words) words = 1;
+    size_t words = (size_t)f_tiles(k, m->ot) * k * m->ot * NLr; if (!words) words = 1;
     HB_HIP(ctx, hipMalloc(&m->M, words * 4));
     HB_HIP(ctx, hipMemsetAsync(m->M, 0, words * 4, s));
     HB_HIP(ctx, hipMalloc(&m->negrow, sizeof(int32_t) * (size_t)(k > 0 ? k : 1)));
@@ -518,10 +547,10 @@ int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out
         size_t lds = (size_t)(k + 2 * (k + 1)) * NLr * 4;
         if (ctx->n_limbs == 4) {
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, ctx->flag_dev);
+            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, ctx->flag_dev, m->ot);
         } else {
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, ctx->flag_dev);
+            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, ctx->flag_dev, m->ot);
         }
         HB_LAUNCH_CHECK(ctx);
         HB_HIP(ctx, hipMemcpyAsync(&singular, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -554,7 +583,7 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
                    int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                    int64_t C, hipStream_t s, int check_skip) {
     if (C <= 0 || m->n_out == 0) return HB_OK;
-    const int tiles = m_tiles(m->n_out);
+    const int tiles = f_tiles(m->n_out, m->ot);
     const int64_t groups = (C + 63) / 64;
     const int nsub = nsub_for(m->n_in, ctx->nl(), ctx->elem_words());
     if (nsub > 64) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: inner dimension too large");
@@ -562,7 +591,8 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
     const size_t lds = (size_t)m->n_in * ctx->nl() * 64 * 4;
     if (lds <= 72 * 1024 && m->n_in > 0) {
         // LDS-staged variant: one workgroup per (64-chunk group, slice of <= 16 tiles), two tiles per wave
-        int slices = (tiles + 15) / 16;
+        const int max_tpb = 64 / m->ot;          // one workgroup sweeps at most 64 outputs
+        int slices = (tiles + max_tpb - 1) / max_tpb;
         if (const char *e = getenv("HB_MV3_SLICES")) { int v = atoi(e); if (v >= 1 && v <= tiles) slices = v; }
         const int tpb = (tiles + slices - 1) / slices;
         // 164 VGPRs => 3 waves per SIMD = 12 per CU; 50 KB of LDS per workgroup => 3 workgroups per CU:
@@ -574,15 +604,21 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
         if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: batch too large for one launch");
 #define HB_MV3(NL_, NW_, CHK_, PP_)                                                                                             \
         do {                                                                                                                    \
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_matvec3<NL_, NW_, CHK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024))); \
-            k_matvec3<NL_, NW_, CHK_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, in_pk, iv.stride_c, iv.stride_l, in_rows_dev, in_count, m->K, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks, check_skip); \
+            if (m->ot == 2) HB_MV3O(NL_, NW_, CHK_, PP_, 2); else HB_MV3O(NL_, NW_, CHK_, PP_, 4);                               \
+        } while (0)
+#define HB_MV3O(NL_, NW_, CHK_, PP_, OT_)                                                                                       \
+        do {                                                                                                                    \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_matvec3<NL_, NW_, CHK_, OT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024))); \
+            k_matvec3<NL_, NW_, CHK_, OT_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, in_pk, iv.stride_c, iv.stride_l, in_rows_dev, in_count, m->K, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks, check_skip); \
         } while (0)
         if (ctx->n_limbs == 4) { if (check) HB_MV3(9, 8, true, ctx->pw); else HB_MV3(9, 8, false, ctx->pw); }
         else { if (check) HB_MV3(3, 2, true, ctx->pn); else HB_MV3(3, 2, false, ctx->pn); }
 #undef HB_MV3
+#undef HB_MV3O
         HB_LAUNCH_CHECK(ctx);
         return HB_OK;
     }
+    if (m->ot != 4) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: layout mismatch");
     if (in_pk) {       // no LDS variant: separate pre-scale pass
         if (!scratch_dg) return fail(ctx, HB_ERR_BAD_ARG, "matvec: scratch required");
         int rc = launch_prescale(ctx, m, in_pk, iv, in_rows_dev, in_count, scratch_dg, C, s);
