@@ -121,6 +121,10 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
                    int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                    int64_t C, hipStream_t s, int check_skip = 0);
 
+int launch_decode_check(hb_ctx *ctx, const FastMatrix *dec, const FastMatrix *enc, const uint32_t *cols, hb_view cv,
+                        const int32_t *z_dev, uint32_t *pk_dst, hb_view pv, int64_t pk_count, int pk_rows, uint32_t *coef_dg,
+                        const int32_t *mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, int check_skip);
+
 // dispatch on element width
 #define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \
     do {                                                                                          \

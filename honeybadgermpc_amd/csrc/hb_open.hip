@@ -128,8 +128,12 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
         if (rc) return rc;
         return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
     }
-    int rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
-                            pk_dst, pv, pk_count, pk_rows, 1, pl->coef_dg, nullptr, nullptr, C, s);
+    // one launch when the shapes allow it (decode + validating re-encode of the same 64-chunk group)
+    int rc = launch_decode_check(pl->ctx, pl->Vinv, pl->V, (const uint32_t *)cols_dev, pm, pl->z_dev, pk_dst, pv, pk_count, pk_rows,
+                                 pl->coef_dg, pl->mask_dev, pl->mismatch_dev, C, s, pl->validate_arrived_only);
+    if (rc != HB_ERR_UNSUPPORTED) return rc;
+    rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
+                        pk_dst, pv, pk_count, pk_rows, 1, pl->coef_dg, nullptr, nullptr, C, s);
     if (rc) return rc;
     // validating re-encode of the guess, compared in the epilogue against the later arrivals
     hb_view none{0, 0};
