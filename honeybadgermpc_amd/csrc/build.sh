@@ -6,6 +6,7 @@ OUT="$HERE/../lib"
 mkdir -p "$OUT" "$HERE/.obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -Wno-unused-result"
+python3 "$HERE/gen_fused.py" > /dev/null
 objs=""
 pids=""
 for src in "$HERE"/*.hip; do

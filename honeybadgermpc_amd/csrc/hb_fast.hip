@@ -340,23 +340,34 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
     if (in_pk) {
         // fused pre-scale: packed canonical input element (c, rows[l]) * K_l / R -> digits in LDS
         // (K_l = R^2 for encode, R^3/den_l for decode; see the file header).  Term l is
-        // wave-uniform, so K_l comes through scalar loads.
-        for (int l = wib; l < n_in; l += W) {
-            const int row = in_rows ? in_rows[l] : l;
-            const int64_t idx = cc * in_sc + (int64_t)row * in_sl;
-            uint32_t r[NL];
-            if (idx < in_count) {
-                uint32_t xd[NL], kd[NL];
-                load_digits<NL, NW>(xd, in_pk + idx * NW);
+        // wave-uniform, so K_l comes through scalar loads.  The wave's loads are issued SB at a
+        // time before any of them is consumed: one HBM latency per batch instead of per element.
+        constexpr int SB = 3;
+        for (int l0 = wib; l0 < n_in; l0 += W * SB) {
+            uint32_t wds[SB][NW];
+            bool valid[SB];
 #pragma unroll
-                for (int q = 0; q < NL; q++) kd[q] = K[(size_t)l * NL + q];
-                mont_mul(r, xd, kd, P);
-            } else {
-#pragma unroll
-                for (int q = 0; q < NL; q++) r[q] = 0;
+            for (int b = 0; b < SB; b++) {
+                const int l = l0 + b * W;
+                const int lc = l < n_in ? l : l0;
+                const int row = in_rows ? in_rows[lc] : lc;
+                const int64_t idx = cc * in_sc + (int64_t)row * in_sl;
+                valid[b] = idx < in_count;
+                load_words<NW>(wds[b], in_pk + (valid[b] ? idx : 0) * NW);
             }
 #pragma unroll
-            for (int q = 0; q < NL; q++) xs[(l * NL + q) * 64 + lane] = r[q];
+            for (int b = 0; b < SB; b++) {
+                const int l = l0 + b * W;
+                if (l < n_in) {
+                    uint32_t xd[NL], kd[NL], r[NL];
+                    unpack<NL, NW>(xd, wds[b]);
+#pragma unroll
+                    for (int q = 0; q < NL; q++) kd[q] = K[(size_t)l * NL + q];
+                    mont_mul(r, xd, kd, P);
+#pragma unroll
+                    for (int q = 0; q < NL; q++) xs[(l * NL + q) * 64 + lane] = valid[b] ? r[q] : 0u;
+                }
+            }
         }
     } else {
         const int rows = n_in * NL;
@@ -461,290 +472,8 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
 }
 
 
-// decode + validating re-encode of one 64-chunk group in ONE launch (IncrementalDecoder's optimistic
-// step, reed_solomon.py:305-326).  Phase 1 (d_*) is k_matvec3's body with the factored inverse: it
-// decodes and writes the Montgomery coefficient planes; phase 2 (e_*) re-stages them -- the
-// workgroup's own writes, visible after the fence + barrier -- and re-encodes with the comparison
-// in the epilogue.  Saves one launch's ramp-up / drain per decode.  (The two phases are the same
-// text as k_matvec3 with renamed parameters; a shared device function cost 70 extra VGPRs.)
-template <int NL, int NW, int OTT>
-__global__ void __launch_bounds__(256, 3) k_decode_check(const FpParams<NL> P,
-        const uint32_t *__restrict__ d_M, const int32_t *__restrict__ d_ndt, const int32_t *__restrict__ d_negrow,
-        int d_n_out, int d_n_in, int d_nsub, const uint32_t *d_in_dg,
-        const uint32_t *__restrict__ d_in_pk, int64_t d_in_sc, int64_t d_in_sl, const int32_t *__restrict__ d_in_rows, int64_t d_in_count, const uint32_t *__restrict__ d_K,
-        uint32_t *d_out_pk, int64_t d_out_sc, int64_t d_out_sl, int64_t d_out_count, int d_pk_rows, int d_pk_from_mont, uint32_t *d_out_dg,
-        const int32_t *__restrict__ d_check_mask, int32_t *__restrict__ d_mismatch, int d_tiles, int d_tiles_per_block, int d_check_skip,
-        const uint32_t *__restrict__ e_M, const int32_t *__restrict__ e_ndt, const int32_t *__restrict__ e_negrow,
-        int e_n_out, int e_n_in, int e_nsub, const uint32_t *e_in_dg,
-        const uint32_t *__restrict__ e_in_pk, int64_t e_in_sc, int64_t e_in_sl, const int32_t *__restrict__ e_in_rows, int64_t e_in_count, const uint32_t *__restrict__ e_K,
-        uint32_t *e_out_pk, int64_t e_out_sc, int64_t e_out_sl, int64_t e_out_count, int e_pk_rows, int e_pk_from_mont, uint32_t *e_out_dg,
-        const int32_t *__restrict__ e_check_mask, int32_t *__restrict__ e_mismatch, int e_tiles, int e_tiles_per_block, int e_check_skip,
-        int64_t C, int64_t n_blocks) {
-    static_assert(OTT == 2 || OTT == 4, "matrix tile is loaded as one uint2 / uint4 per digit");
-    using MV = typename MVec<OTT>::type;
-    extern __shared__ __attribute__((aligned(16))) uint32_t xs[];
-    const int lane = threadIdx.x & 63;
-    const int wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int W = blockDim.x >> 6;
-    const int64_t nb8 = gridDim.x >> 3;
-    const int64_t vb = (int64_t)(blockIdx.x & 7) * nb8 + (blockIdx.x >> 3);
-    if (vb >= n_blocks) return;
-    const int64_t c = vb * 64 + lane;
-    const bool active = c < C;
-    const int64_t cc = active ? c : (C - 1);
-    {
-        constexpr int d_slice = 0;
-    // ---- stage the group's digit planes ---------------------------------------------------
-    if (d_in_pk) {
-        // fused pre-scale: packed canonical input element (c, rows[l]) * K_l / R -> digits in LDS
-        // (K_l = R^2 for encode, R^3/den_l for decode; see the file header).  Term l is
-        // wave-uniform, so K_l comes through scalar loads.
-        for (int l = wib; l < d_n_in; l += W) {
-            const int row = d_in_rows ? d_in_rows[l] : l;
-            const int64_t idx = cc * d_in_sc + (int64_t)row * d_in_sl;
-            uint32_t r[NL];
-            if (idx < d_in_count) {
-                uint32_t xd[NL], kd[NL];
-                load_digits<NL, NW>(xd, d_in_pk + idx * NW);
-#pragma unroll
-                for (int q = 0; q < NL; q++) kd[q] = d_K[(size_t)l * NL + q];
-                mont_mul(r, xd, kd, P);
-            } else {
-#pragma unroll
-                for (int q = 0; q < NL; q++) r[q] = 0;
-            }
-#pragma unroll
-            for (int q = 0; q < NL; q++) xs[(l * NL + q) * 64 + lane] = r[q];
-        }
-    } else {
-        const int rows = d_n_in * NL;
-        const uint32_t *src = d_in_dg + cc;
-        for (int r = wib; r < rows; r += W) xs[r * 64 + lane] = src[(size_t)r * C];
-    }
-    __syncthreads();
-    // A 64-bit column holds 63 products of two 29-bit digits.  A term with nd non-zero matrix
-    // digits adds at most nd products to a column, so carries are scheduled by a digit budget:
-    // never more than BUDGET = 54 since the last carry, which leaves room for REDC's own 9
-    // products per column -- REDC then needs no carry pass of its own.
-    constexpr int BUDGET = 63 - NL;
-    const uint32_t *xl = xs + lane;
-    const int t_end = min(d_tiles, (d_slice + 1) * d_tiles_per_block);
-    for (int tile = d_slice * d_tiles_per_block + wib; tile < t_end; tile += W) {
-        const int nv = min(OTT, d_n_out - tile * OTT);
-        if constexpr (false) {
-            // optional: skip d_tiles none of whose rows is compared (plan option, off by default)
-            if (d_check_skip) {
-                int any = 0;
-                for (int o = 0; o < nv; o++) any |= d_check_mask[tile * OTT + o];
-                if (!any) continue;
-            }
-        }
-        const MV *mt = reinterpret_cast<const MV *>(d_M) + (size_t)tile * d_n_in * NL;
-        const int32_t *ndp = d_ndt + (size_t)tile * d_n_in;
-        uint64_t col[OTT][2 * NL];
-#pragma unroll
-        for (int o = 0; o < OTT; o++) col_zero(col[o]);
-        MV mc[NL], mn[NL];
-        int ndc, ndn;
-#pragma unroll
-        for (int q = 0; q < NL; q++) mc[q] = mt[q];
-        ndc = ndp[0];
-        int used = 0;
-        for (int l = 0; l < d_n_in; l++) {
-            const int ln = (l + 1 < d_n_in) ? l + 1 : l;
-#pragma unroll
-            for (int q = 0; q < NL; q++) mn[q] = mt[(size_t)ln * NL + q];      // scalar prefetch of the next tile
-            ndn = ndp[ln];
-            uint32_t xu[NL];
-#pragma unroll
-            for (int q = 0; q < NL; q++) xu[q] = xl[(l * NL + q) * 64];        // LDS, conflict-free
-            if (used + ndc > BUDGET) {
-                used = 0;
-#pragma unroll
-                for (int o = 0; o < OTT; o++) carry(col[o]);
-            }
-            used += ndc;
-#pragma unroll
-            for (int i = 0; i < NL; i++) {
-                if (i < ndc) {
-#pragma unroll
-                    for (int o = 0; o < OTT; o++) {
-                        const uint32_t md = mcomp(mc[i], o);
-#pragma unroll
-                        for (int j = 0; j < NL; j++) col[o][i + j] += (uint64_t)md * xu[j];
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NL; q++) mc[q] = mn[q];
-            ndc = ndn;
-        }
-#pragma unroll
-        for (int o = 0; o < OTT; o++) {
-            if (o < nv) {
-                const int i = tile * OTT + o;
-                uint32_t r[NL];
-                redc(r, col[o], P);                    // columns hold <= BUDGET products each: no pre-carry needed
-                for (int s = 0; s < d_nsub; s++) cond_sub_p(r, P);
-                if (d_negrow && d_negrow[i]) fp_neg(r, r, P);
-                if (d_out_dg && active) {
-#pragma unroll
-                    for (int q = 0; q < NL; q++) d_out_dg[dg_index(i, q, c, C, NL)] = r[q];
-                }
-                if constexpr (false) {
-                    if (d_check_mask[i] && active) {
-                        uint32_t w[NW], e[NW];
-                        pack<NL, NW>(w, r);
-                        load_words<NW>(e, d_out_pk + (cc * d_out_sc + (int64_t)i * d_out_sl) * NW);
-                        uint32_t diff = 0;
-#pragma unroll
-                        for (int q = 0; q < NW; q++) diff |= e[q] ^ w[q];
-                        if (diff) atomicOr(d_mismatch, 1);
-                    }
-                } else {
-                    if (d_out_pk && i < d_pk_rows && active) {
-                        const int64_t oidx = cc * d_out_sc + (int64_t)i * d_out_sl;
-                        if (oidx < d_out_count) {
-                            uint32_t v[NL], w[NW];
-                            if (d_pk_from_mont) from_mont(v, r, P); else fp_set(v, r);
-                            pack<NL, NW>(w, v);
-                            store_words<NW>(d_out_pk + oidx * NW, w);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    }
-    __threadfence_block();
-    __syncthreads();
-    {
-        constexpr int e_slice = 0;
-    // ---- stage the group's digit planes ---------------------------------------------------
-    if (e_in_pk) {
-        // fused pre-scale: packed canonical input element (c, rows[l]) * K_l / R -> digits in LDS
-        // (K_l = R^2 for encode, R^3/den_l for decode; see the file header).  Term l is
-        // wave-uniform, so K_l comes through scalar loads.
-        for (int l = wib; l < e_n_in; l += W) {
-            const int row = e_in_rows ? e_in_rows[l] : l;
-            const int64_t idx = cc * e_in_sc + (int64_t)row * e_in_sl;
-            uint32_t r[NL];
-            if (idx < e_in_count) {
-                uint32_t xd[NL], kd[NL];
-                load_digits<NL, NW>(xd, e_in_pk + idx * NW);
-#pragma unroll
-                for (int q = 0; q < NL; q++) kd[q] = e_K[(size_t)l * NL + q];
-                mont_mul(r, xd, kd, P);
-            } else {
-#pragma unroll
-                for (int q = 0; q < NL; q++) r[q] = 0;
-            }
-#pragma unroll
-            for (int q = 0; q < NL; q++) xs[(l * NL + q) * 64 + lane] = r[q];
-        }
-    } else {
-        const int rows = e_n_in * NL;
-        const uint32_t *src = e_in_dg + cc;
-        for (int r = wib; r < rows; r += W) xs[r * 64 + lane] = src[(size_t)r * C];
-    }
-    __syncthreads();
-    // A 64-bit column holds 63 products of two 29-bit digits.  A term with nd non-zero matrix
-    // digits adds at most nd products to a column, so carries are scheduled by a digit budget:
-    // never more than BUDGET = 54 since the last carry, which leaves room for REDC's own 9
-    // products per column -- REDC then needs no carry pass of its own.
-    constexpr int BUDGET = 63 - NL;
-    const uint32_t *xl = xs + lane;
-    const int t_end = min(e_tiles, (e_slice + 1) * e_tiles_per_block);
-    for (int tile = e_slice * e_tiles_per_block + wib; tile < t_end; tile += W) {
-        const int nv = min(OTT, e_n_out - tile * OTT);
-        if constexpr (true) {
-            // optional: skip e_tiles none of whose rows is compared (plan option, off by default)
-            if (e_check_skip) {
-                int any = 0;
-                for (int o = 0; o < nv; o++) any |= e_check_mask[tile * OTT + o];
-                if (!any) continue;
-            }
-        }
-        const MV *mt = reinterpret_cast<const MV *>(e_M) + (size_t)tile * e_n_in * NL;
-        const int32_t *ndp = e_ndt + (size_t)tile * e_n_in;
-        uint64_t col[OTT][2 * NL];
-#pragma unroll
-        for (int o = 0; o < OTT; o++) col_zero(col[o]);
-        MV mc[NL], mn[NL];
-        int ndc, ndn;
-#pragma unroll
-        for (int q = 0; q < NL; q++) mc[q] = mt[q];
-        ndc = ndp[0];
-        int used = 0;
-        for (int l = 0; l < e_n_in; l++) {
-            const int ln = (l + 1 < e_n_in) ? l + 1 : l;
-#pragma unroll
-            for (int q = 0; q < NL; q++) mn[q] = mt[(size_t)ln * NL + q];      // scalar prefetch of the next tile
-            ndn = ndp[ln];
-            uint32_t xu[NL];
-#pragma unroll
-            for (int q = 0; q < NL; q++) xu[q] = xl[(l * NL + q) * 64];        // LDS, conflict-free
-            if (used + ndc > BUDGET) {
-                used = 0;
-#pragma unroll
-                for (int o = 0; o < OTT; o++) carry(col[o]);
-            }
-            used += ndc;
-#pragma unroll
-            for (int i = 0; i < NL; i++) {
-                if (i < ndc) {
-#pragma unroll
-                    for (int o = 0; o < OTT; o++) {
-                        const uint32_t md = mcomp(mc[i], o);
-#pragma unroll
-                        for (int j = 0; j < NL; j++) col[o][i + j] += (uint64_t)md * xu[j];
-                    }
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < NL; q++) mc[q] = mn[q];
-            ndc = ndn;
-        }
-#pragma unroll
-        for (int o = 0; o < OTT; o++) {
-            if (o < nv) {
-                const int i = tile * OTT + o;
-                uint32_t r[NL];
-                redc(r, col[o], P);                    // columns hold <= BUDGET products each: no pre-carry needed
-                for (int s = 0; s < e_nsub; s++) cond_sub_p(r, P);
-                if (e_negrow && e_negrow[i]) fp_neg(r, r, P);
-                if (e_out_dg && active) {
-#pragma unroll
-                    for (int q = 0; q < NL; q++) e_out_dg[dg_index(i, q, c, C, NL)] = r[q];
-                }
-                if constexpr (true) {
-                    if (e_check_mask[i] && active) {
-                        uint32_t w[NW], e[NW];
-                        pack<NL, NW>(w, r);
-                        load_words<NW>(e, e_out_pk + (cc * e_out_sc + (int64_t)i * e_out_sl) * NW);
-                        uint32_t diff = 0;
-#pragma unroll
-                        for (int q = 0; q < NW; q++) diff |= e[q] ^ w[q];
-                        if (diff) atomicOr(e_mismatch, 1);
-                    }
-                } else {
-                    if (e_out_pk && i < e_pk_rows && active) {
-                        const int64_t oidx = cc * e_out_sc + (int64_t)i * e_out_sl;
-                        if (oidx < e_out_count) {
-                            uint32_t v[NL], w[NW];
-                            if (e_pk_from_mont) from_mont(v, r, P); else fp_set(v, r);
-                            pack<NL, NW>(w, v);
-                            store_words<NW>(e_out_pk + oidx * NW, w);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    }
-}
+// k_decode_check: generated from k_matvec3's body by gen_fused.py (run by build.sh)
+#include "hb_fast_fused.inc"
 
 }  // namespace
 
@@ -966,3 +695,16 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
 }
 
 }  // namespace hb
+
+// diagnostics: resident workgroups per CU the runtime reports for the hot kernels at the config-3 shape
+extern "C" int hb_debug_occupancy(int n_in, int nl, int *mv3, int *dc) {
+    int a = -1, b = -1;
+    const size_t lds = (size_t)n_in * nl * 64 * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_matvec3<9, 8, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_decode_check<9, 8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024));
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_matvec3<9, 8, false, 4>, 256, lds);
+    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_decode_check<9, 8, 4>, 256, lds);
+    *mv3 = a; *dc = b;
+    return (e1 == hipSuccess && e2 == hipSuccess) ? 0 : 5;
+}
+
