@@ -15,6 +15,7 @@
 
 namespace hb {
 struct FastMatrix;
+struct Mm8Matrix;
 }
 namespace hb {
 
@@ -110,6 +111,18 @@ int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, h
                    int64_t C, hipStream_t s);
 
 // ---- second-generation (raw small-entry matrix) path, hb_fast.hip ----------------------
+struct FastMatrix {
+    int n_out, n_in;
+    int ot;             // outputs per tile in this matrix's layout (2 or 4)
+    uint32_t *M;        // raw canonical digits, [tile][l][digit][OT]
+    int32_t *nd;        // [tile][n_in] digits actually non-zero in that tile/term
+    int32_t *negrow;    // [n_out] 1 => negate the output row (nullptr: none)
+    uint32_t *K;        // [n_in][NL] pre-scale constants (canonical digits; used as a mont_mul factor)
+};
+// word index of digit q of raw matrix element (i, l): [tile][l][digit][ot], tile = i / ot
+__host__ __device__ inline size_t mf_index(int i, int l, int n_in, int nl, int q, int ot) {
+    return (((size_t)((i / ot) * n_in + l) * (size_t)nl + (size_t)q) * ot) + (size_t)(i % ot);
+}
 void fast_matrix_free(FastMatrix *m);
 int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s);
 int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s);
@@ -124,6 +137,13 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
 int launch_decode_check(hb_ctx *ctx, const FastMatrix *dec, const FastMatrix *enc, const uint32_t *cols, hb_view cv,
                         const int32_t *z_dev, uint32_t *pk_dst, hb_view pv, int64_t pk_count, int pk_rows, uint32_t *coef_dg,
                         const int32_t *mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, int check_skip);
+
+// ---- third generation: int8 matrix-core mat-vec for small-entry matrices, hb_mfma.hip ----------
+int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t s);
+void mm8_free(Mm8Matrix *m);
+int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
+               uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+               int64_t C, hipStream_t s);
 
 // dispatch on element width
 #define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \

@@ -27,25 +27,8 @@
 
 using namespace hb;
 
-namespace hb {
-
-struct FastMatrix {
-    int n_out, n_in;
-    int ot;             // outputs per tile in this matrix's layout (2 or 4)
-    uint32_t *M;        // raw canonical digits, [tile][l][digit][OT]
-    int32_t *nd;        // [tile][n_in] digits actually non-zero in that tile/term
-    int32_t *negrow;    // [n_out] 1 => negate the output row (nullptr: none)
-    uint32_t *K;        // [n_in][NL] pre-scale constants (canonical digits; used as a mont_mul factor)
-};
-
-}  // namespace hb
-
 namespace {
 
-// word index of digit q of matrix element (i, l): [tile][l][digit][ot], tile = i / ot
-__host__ __device__ inline size_t mf_index(int i, int l, int n_in, int nl, int q, int ot) {
-    return (((size_t)((i / ot) * n_in + l) * (size_t)nl + (size_t)q) * ot) + (size_t)(i % ot);
-}
 // digit-plane addressing: element (l, c), digit q  ->  ((l * NL + q) * C + c)
 __device__ __forceinline__ size_t dg_index(int l, int q, int64_t c, int64_t C, int nl) { return ((size_t)l * nl + q) * (size_t)C + (size_t)c; }
 

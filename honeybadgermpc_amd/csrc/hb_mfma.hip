@@ -40,8 +40,9 @@ struct BarrettParams {
 
 struct Mm8Matrix {
     int n_out, d, nkb, n_rt;
-    int4 *a8;          // [n_rt][nkb][64 lanes] 16 signed digits each
-    uint32_t *crow;    // [n_rt * 16][MM8_CW]
+    int4 *a8;          // [n_rt][nkb][64 lanes] 16 balanced digits each: lane (r, g) = row 16 rt + r, term 4 kb + g, digit 15 - j
+    uint32_t *crow;    // [n_rt * 16][16] radix-2^29 digits of the per-row constant (14 used)
+    uint32_t *zero;    // 32 zero bytes: DMA source for inputs beyond in_count (zero padding of the last chunk)
     BarrettParams bp;
 };
 
@@ -64,11 +65,15 @@ constexpr int MM8_BIAS = 5800000;   // > 352 * 128 * 128 >= |column|, and 2 * BI
 //   E_j = col_2j + (col_2j+1 << 8) < 2^32,  t = E_j + cy,  halfword_j = t & 0xffff,  cy = t >> 16
 // The low half's words are parked (7 registers per output).  The bias, the XOR-0x80 correction and a
 // multiple of p are one per-row constant (crowd), added digit-wise (radix 2^29) after the chain.
-template <int NKB>
+// CHECK: out_pk holds the expected values; rows with check_mask[i] != 0 are compared, any difference
+// sets *mismatch (the validating re-encode of reed_solomon.py:316-326).
+template <int NKB, bool CHECK>
 __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
+                                                const uint32_t *__restrict__ zero_src,
                                                 const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
                                                 const int32_t *__restrict__ in_rows, int64_t in_count, int d,
                                                 uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
+                                                const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
                                                 int n_out, int n_rt, int tpw, int64_t n_chunks, int64_t n_units, BarrettParams bp) {
     extern __shared__ uint4 mm8_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -88,6 +93,10 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     // l -> input row table (arrival order for decodes), clamped to d - 1
     int32_t *rowl = reinterpret_cast<int32_t *>(xbuf + 2 * bufsz);
     if (threadIdx.x < 32) { const int lc = (int)threadIdx.x < d ? (int)threadIdx.x : d - 1; rowl[threadIdx.x] = in_rows ? in_rows[lc] : lc; }
+    int32_t *maskl = rowl + 32;   // CHECK: rows to compare
+    if constexpr (CHECK) {
+        for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = (i < n_out) ? check_mask[i] : 0;
+    }
     __syncthreads();
     const int n_slots = tpw * NKB * 2;
     // slot s = (t * NKB + kb) * 2 + h, dealt round-robin to the 4 waves; all of it wave-uniform
@@ -96,9 +105,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
             const int h = s & 1, q = s >> 1, t = q / NKB, kb = q - t * NKB;
             int64_t chunk = (unit * tpw + t) * 16 + n;
             if (chunk >= n_chunks) chunk = n_chunks - 1;
-            int64_t idx = chunk * in_sc + (int64_t)rowl[4 * kb + g] * in_sl;
-            if (idx >= in_count) idx = 0;
-            const uint4 *src = reinterpret_cast<const uint4 *>(in_pk) + idx * 2 + h;
+            const int64_t idx = chunk * in_sc + (int64_t)rowl[4 * kb + g] * in_sl;
+            const uint4 *src = (idx < in_count) ? reinterpret_cast<const uint4 *>(in_pk) + idx * 2 + h
+                                                : reinterpret_cast<const uint4 *>(zero_src) + h;
             // issued from asm so that hipcc does not drain it at the next LDS read (its vmcnt bookkeeping only
             // over-waits for ops it cannot see); the wait is the explicit vmcnt(0) before the epilogue
             const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
         const uint4 *xs = xbuf + (size_t)buf * bufsz + (size_t)tl * NKB * 2 * 64 + lane;
         for (int rt = rt0; rt < n_rt; rt += rstep) {
             const int4 *as = abuf + (size_t)rt * NKB * 64 + lane;
-            uint32_t wlo[4][6];   // parked low words
+            uint32_t wlo[4][6], whi[4][6];   // chain words of the two halves
             uint32_t cyp[4];      // parked carry
 #pragma unroll
             for (int half = 0; half < 2; half++) {
@@ -133,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 if (half == 0) { MM8_MFMA_HALF0(NKB, xs, as, acc, biasv) } else { MM8_MFMA_HALF1(NKB, xs, as, acc, biasv) }
                 if (half == 1 && rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next unit's DMA (issued a pass ago)
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
+                for (int reg = 0; reg < 4; reg++) {   // carry chains of this half: the accumulators die here
                     uint32_t cy = half ? cyp[reg] : 0u;
                     uint32_t t[12];
 #pragma unroll
@@ -144,16 +153,28 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         t[j] = e + cy;
                         cy = t[j] >> 16;
                     }
-                    if (half == 0) {
 #pragma unroll
-                        for (int k = 0; k < 6; k++) wlo[reg][k] = __builtin_amdgcn_perm(t[2 * k + 1], t[2 * k], 0x05040100u);
-                        cyp[reg] = cy;
-                    } else {
+                    for (int k = 0; k < 6; k++) (half ? whi : wlo)[reg][k] = __builtin_amdgcn_perm(t[2 * k + 1], t[2 * k], 0x05040100u);
+                    cyp[reg] = cy;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (half == 0) continue;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {
+                    {
+                        uint32_t ew[8];
+                        bool cmp = false;
+                        if constexpr (CHECK) {   // expected value: in flight while this output is reduced
+                            const int i = 16 * rt + 4 * g + reg;
+                            cmp = (chunk < n_chunks) && maskl[i];
+                            if (cmp) load_words<8>(ew, out_pk + (chunk * out_sc + (int64_t)i * out_sl) * 8);
+                        }
+                        (void)ew; (void)cmp;
                         uint32_t w[MM8_CW];
 #pragma unroll
-                        for (int k = 0; k < 6; k++) w[k] = wlo[reg][k];
-#pragma unroll
-                        for (int k = 0; k < 6; k++) w[6 + k] = __builtin_amdgcn_perm(t[2 * k + 1], t[2 * k], 0x05040100u);
+                        for (int k = 0; k < 6; k++) { w[k] = wlo[reg][k]; w[6 + k] = whi[reg][k]; }
+                        const uint32_t cy = cyp[reg];
                         w[12] = cy;
                         const int i = 16 * rt + 4 * g + reg;
                         uint32_t sd[MM8_SD];
@@ -171,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                             sd[8] += c2v.x; sd[9] += c2v.y; sd[10] += c2v.z; sd[11] += c2v.w;
                             sd[12] += c3v.x; sd[13] += c3v.y;
                         }
-                        // Barrett: qhat = floor(floor(S / 2^232) * mu / 2^174) >= floor(S / p) - 2
+                        // Barrett.  S_hi = sum_{k>=8} digit_k 2^(29(k-8)) >= S / 2^232 - 2 (lazy low digits < 2^30) and
+                        // mu > 2^406 / p - 1, so S_hi mu / 2^174 > S/p - S/2^406 - 2^233/p > S/p - 2^-11:
+                        // qhat = floor(S_hi mu / 2^174) is floor(S/p) or one less, and r = S - qhat p < 2p
                         uint64_t pc[12];
                         col_zero(pc);
 #pragma unroll
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                             br = tt >> LB;
                         }
 #pragma unroll
-                        for (int rep = 0; rep < 2; rep++) {
+                        for (int rep = 0; rep < 1; rep++) {   // qhat >= floor(S / p) - 1 (see above): r < 2p
                             uint32_t tsub[9];
                             int32_t bw = 0;
 #pragma unroll
@@ -213,7 +236,16 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         uint32_t ow[8];
                         pack<9, 8>(ow, r);
                         const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
-                        if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow);
+                        if constexpr (CHECK) {
+                            if (cmp) {
+                                uint32_t diff = 0;
+#pragma unroll
+                                for (int k = 0; k < 8; k++) diff |= ew[k] ^ ow[k];
+                                if (diff) atomicOr(mismatch, 1);
+                            }
+                        } else {
+                            if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow);
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);   // one output at a time: interleaving them only costs registers
                 }
@@ -226,8 +258,10 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
 
 using namespace hb;
 
-// ---- prototype C entry points (digits and row constants supplied by the caller) ----------------
-static int mm8_num_cus() {
+// ---- host side -----------------------------------------------------------------------------------
+namespace {
+
+int mm8_num_cus() {
     static int n = 0;
     if (!n) {
         int dev = 0;
@@ -237,48 +271,178 @@ static int mm8_num_cus() {
     return n;
 }
 
-extern "C" int hb_mm8_create(hb_ctx *ctx, int n_out, int d, const int8_t *limbs /* [n_out][d][16] */,
-                             const uint32_t *crowd /* [n_out][16] */, const uint32_t *mu6, void **out) {
-    if (!ctx || ctx->n_limbs != 4 || d < 1 || d > 32 || n_out < 1) return HB_ERR_BAD_ARG;
-    Mm8Matrix *m = new Mm8Matrix();
-    m->n_out = n_out; m->d = d; m->nkb = (d + 3) / 4; m->n_rt = (n_out + 15) / 16;
-    std::vector<int8_t> a((size_t)m->n_rt * m->nkb * 64 * 16, 0);
-    for (int rt = 0; rt < m->n_rt; rt++)
-        for (int kb = 0; kb < m->nkb; kb++)
-            for (int lane = 0; lane < 64; lane++) {
-                int i = 16 * rt + (lane & 15), l = 4 * kb + (lane >> 4);
-                if (i >= n_out || l >= d) continue;
-                for (int j = 0; j < 16; j++)
-                    a[(((size_t)rt * m->nkb + kb) * 64 + lane) * 16 + j] = limbs[((size_t)i * d + l) * 16 + (15 - j)];
+// little multi-word helpers for the one-time table build (32-bit words, little endian)
+typedef std::vector<uint32_t> Big;
+Big big_mul(const Big &a, const Big &b) {
+    Big r(a.size() + b.size(), 0);
+    for (size_t i = 0; i < a.size(); i++) {
+        uint64_t cy = 0;
+        for (size_t j = 0; j < b.size(); j++) {
+            uint64_t t = (uint64_t)a[i] * b[j] + r[i + j] + cy;
+            r[i + j] = (uint32_t)t; cy = t >> 32;
+        }
+        r[i + b.size()] = (uint32_t)cy;
+    }
+    return r;
+}
+bool big_ge(const Big &a, const Big &b) {   // same length
+    for (size_t i = a.size(); i-- > 0;) if (a[i] != b[i]) return a[i] > b[i];
+    return true;
+}
+void big_sub(Big &a, const Big &b) {        // a -= b, same length, a >= b
+    int64_t br = 0;
+    for (size_t i = 0; i < a.size(); i++) {
+        int64_t t = (int64_t)a[i] - (i < b.size() ? b[i] : 0) + br;
+        a[i] = (uint32_t)t; br = t >> 32;
+    }
+}
+void big_add(Big &a, const Big &b) {        // a += b (a at least as long; final carry dropped)
+    uint64_t cy = 0;
+    for (size_t i = 0; i < a.size(); i++) {
+        uint64_t t = (uint64_t)a[i] + (i < b.size() ? b[i] : 0) + cy;
+        a[i] = (uint32_t)t; cy = t >> 32;
+    }
+}
+// binary long division of x by p (p padded to np words): quotient into q (same length as x), remainder returned
+Big big_divmod(const Big &x, const Big &p, Big *q) {
+    Big r(p.size() + 1, 0), pp(p); pp.push_back(0);
+    if (q) q->assign(x.size(), 0);
+    for (int bit = (int)x.size() * 32 - 1; bit >= 0; bit--) {
+        uint32_t in = (x[bit >> 5] >> (bit & 31)) & 1u;
+        for (size_t i = r.size(); i-- > 0;) r[i] = (r[i] << 1) | (i ? r[i - 1] >> 31 : in);
+        if (big_ge(r, pp)) { big_sub(r, pp); if (q) (*q)[bit >> 5] |= 1u << (bit & 31); }
+    }
+    r.pop_back();
+    return r;
+}
+Big big_shl(const Big &a, int bits, size_t words) {
+    Big r(words, 0);
+    for (size_t i = 0; i < a.size(); i++) {
+        const size_t w = i + bits / 32; const int s = bits % 32;
+        if (w < words) r[w] |= a[i] << s;
+        if (s && w + 1 < words) r[w + 1] |= a[i] >> (32 - s);
+    }
+    return r;
+}
+
+}  // namespace
+
+namespace hb {
+
+void mm8_free(Mm8Matrix *m) {
+    if (!m) return;
+    (void)hipFree(m->a8); (void)hipFree(m->crow); (void)hipFree(m->zero);
+    delete m;
+}
+
+// Build the int8 operand image of a raw small-entry matrix (hb_fast.hip tables: canonical digits of
+// |M[i][l]| plus a per-row sign).  HB_ERR_UNSUPPORTED when the path does not apply: an entry of
+// 2^126 or more, more than 32 terms, a modulus outside [2^254, 2^256), or tables that exceed the LDS budget.
+int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t s) {
+    *out = nullptr;
+    if (getenv("HB_NO_MFMA")) return HB_ERR_UNSUPPORTED;
+    if (ctx->n_limbs != 4 || f->n_in < 1 || f->n_in > 32 || f->n_out < 1) return HB_ERR_UNSUPPORTED;
+    if ((ctx->p_limbs[3] >> 62) == 0) return HB_ERR_UNSUPPORTED;      // Barrett constants assume 2^254 <= p
+    const int n_out = f->n_out, d = f->n_in, nkb = (d + 3) / 4, n_rt = (n_out + 15) / 16;
+    const int tpw = (n_rt == 1) ? 4 : (n_rt == 2) ? 2 : 1;
+    const size_t lds = ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 64 + (size_t)2 * tpw * nkb * 2 * 64) * 16 + 128 + (size_t)n_rt * 64;
+    if (lds > 76 * 1024) return HB_ERR_UNSUPPORTED;
+    const int tiles = (n_out + f->ot - 1) / f->ot;
+    std::vector<uint32_t> Mh((size_t)tiles * d * f->ot * 9);
+    std::vector<int32_t> neg((size_t)n_out, 0);
+    HB_HIP(ctx, hipMemcpyAsync(Mh.data(), f->M, Mh.size() * 4, hipMemcpyDeviceToHost, s));
+    if (f->negrow) HB_HIP(ctx, hipMemcpyAsync(neg.data(), f->negrow, neg.size() * 4, hipMemcpyDeviceToHost, s));
+    HB_HIP(ctx, hipStreamSynchronize(s));
+
+    Big p(8);
+    for (int k = 0; k < 4; k++) { p[2 * k] = (uint32_t)ctx->p_limbs[k]; p[2 * k + 1] = (uint32_t)(ctx->p_limbs[k] >> 32); }
+    Big c80(8, 0x80808080u);
+    c80 = big_divmod(c80, p, nullptr);                                   // 0x80..80 mod p
+    // K0 = (p << 137) - sum_c BIAS 2^(8c), c < 47: positive, below 2^394
+    Big K0 = big_shl(p, 137, 14);
+    { Big bt(14, 0); for (int c = 0; c < MM8_NC; c++) { Big t(1, (uint32_t)MM8_BIAS); big_add(bt, big_shl(t, 8 * c, 14)); } big_sub(K0, bt); }
+    Big two406(13, 0); two406[12] = 1u << 22;                            // 2^406
+    Big mu; big_divmod(two406, p, &mu);
+
+    std::vector<int8_t> a((size_t)n_rt * nkb * 64 * 16, 0);
+    std::vector<uint32_t> cr((size_t)n_rt * 16 * 16, 0);
+    for (int i = 0; i < n_out; i++) {
+        Big pos(5, 0), ngs(5, 0);   // sums of the positive / negated entries of the row (each < 32 * 2^127)
+        int64_t colsum = 0;         // 128 * sum |digit| bounds every int32 column of this row
+        for (int l = 0; l < d; l++) {
+            uint32_t dg[9], w8[8];
+            for (int q = 0; q < 9; q++) dg[q] = Mh[mf_index(i, l, d, 9, q, f->ot)];
+            pack<9, 8>(w8, dg);
+            if (w8[4] | w8[5] | w8[6] | w8[7]) return HB_ERR_UNSUPPORTED;   // does not fit 16 balanced digits
+            const int sgn = neg[i] ? -1 : 1;
+            int carry = 0;
+            int8_t *dst = &a[(((size_t)(i / 16) * nkb + l / 4) * 64 + (size_t)(i % 16) + 16 * (l % 4)) * 16];
+            for (int b = 0; b < 16; b++) {
+                int t = sgn * (int)((w8[b >> 2] >> (8 * (b & 3))) & 0xffu) + carry;
+                if (t > 127) { t -= 256; carry = 1; } else if (t < -128) { t += 256; carry = -1; } else carry = 0;
+                dst[15 - b] = (int8_t)t;
+                colsum += (t < 0) ? -t : t;
             }
-    std::vector<uint32_t> cr((size_t)m->n_rt * 16 * 16, 0);
-    memcpy(cr.data(), crowd, (size_t)n_out * 16 * 4);
+            if (carry) return HB_ERR_UNSUPPORTED;                           // |entry| >= 127 * 256^15 or so
+            Big e(w8, w8 + 4);
+            big_add(neg[i] ? ngs : pos, e);
+        }
+        if (colsum * 128 > MM8_BIAS) return HB_ERR_UNSUPPORTED;
+        // corr = 0x80..80 * (pos - ngs) mod p  (the XOR-0x80 bias of the input bytes)
+        Big cp = big_divmod(big_mul(c80, pos), p, nullptr), cn = big_divmod(big_mul(c80, ngs), p, nullptr);
+        if (!big_ge(cp, cn)) big_add(cp, p);
+        big_sub(cp, cn);
+        Big tot(K0);
+        big_add(tot, cp);
+        for (int k = 0; k < MM8_SD; k++) {
+            const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
+            uint64_t v = tot[j] | ((uint64_t)(j + 1 < 14 ? tot[j + 1] : 0) << 32);
+            cr[(size_t)i * 16 + k] = (uint32_t)(v >> sft) & DMASK;
+        }
+    }
+    Mm8Matrix *m = new Mm8Matrix();
+    m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr;
+    for (int k = 0; k < 9; k++) m->bp.p[k] = ctx->pw.p[k];
+    for (int k = 0; k < 6; k++) {
+        const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
+        uint64_t v = mu[j] | ((uint64_t)(j + 1 < (int)mu.size() ? mu[j + 1] : 0) << 32);
+        m->bp.mu[k] = (uint32_t)(v >> sft) & DMASK;
+    }
     HB_HIP(ctx, hipMalloc(&m->a8, a.size()));
     HB_HIP(ctx, hipMalloc(&m->crow, cr.size() * 4));
-    HB_HIP(ctx, hipMemcpy(m->a8, a.data(), a.size(), hipMemcpyHostToDevice));
-    HB_HIP(ctx, hipMemcpy(m->crow, cr.data(), cr.size() * 4, hipMemcpyHostToDevice));
-    for (int k = 0; k < 9; k++) m->bp.p[k] = ctx->pw.p[k];
-    for (int k = 0; k < 6; k++) m->bp.mu[k] = mu6[k];
+    HB_HIP(ctx, hipMalloc(&m->zero, 64));
+    HB_HIP(ctx, hipMemcpyAsync(m->a8, a.data(), a.size(), hipMemcpyHostToDevice, s));
+    HB_HIP(ctx, hipMemcpyAsync(m->crow, cr.data(), cr.size() * 4, hipMemcpyHostToDevice, s));
+    HB_HIP(ctx, hipMemsetAsync(m->zero, 0, 64, s));
+    HB_HIP(ctx, hipStreamSynchronize(s));
     *out = m;
     return HB_OK;
 }
 
-extern "C" int hb_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, int64_t in_sc, int64_t in_sl, int64_t in_count,
-                            void *out_dev, int64_t out_sc, int64_t out_sl, int64_t out_count, int64_t n_chunks) {
-    Mm8Matrix *m = (Mm8Matrix *)mat;
+// out(c, i) = sum_l M[i][l] * in(c, rows[l]) mod p, canonical; CHECK mode when check_mask_dev != nullptr
+int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
+               uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+               int64_t C, hipStream_t s) {
+    if (C <= 0) return HB_OK;
     const int tpw = (m->n_rt == 1) ? 4 : (m->n_rt == 2) ? 2 : 1;
-    const int64_t n_tiles = (n_chunks + 15) / 16;
+    const int64_t n_tiles = (C + 15) / 16;
     const int64_t n_units = (n_tiles + tpw - 1) / tpw;
     int64_t blocks = 2 * (int64_t)mm8_num_cus();
     if (blocks > n_units) blocks = n_units;
-    const size_t lds = ((size_t)m->n_rt * 64 + (size_t)m->n_rt * m->nkb * 64 + (size_t)2 * tpw * m->nkb * 2 * 64) * 16 + 128;
-#define MM8_LAUNCH(NKB)                                                                                          \
+    const size_t lds = ((size_t)m->n_rt * 64 + (size_t)m->n_rt * m->nkb * 64 + (size_t)2 * tpw * m->nkb * 2 * 64) * 16 + 128 + (size_t)m->n_rt * 64;
+    const bool check = check_mask_dev != nullptr;
+#define MM8_LAUNCH_(NKB, CHK)                                                                                     \
     do {                                                                                                          \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((k_mm8<NKB>), dim3((unsigned)blocks), dim3(256), lds, 0, m->a8, m->crow, (const uint32_t *)in_dev, in_sc,  \
-                           in_sl, (const int32_t *)nullptr, in_count, m->d, (uint32_t *)out_dev, out_sc, out_sl, out_count, \
-                           m->n_out, m->n_rt, tpw, n_chunks, n_units, m->bp);                                    \
+        static bool attr_done = false;                                                                            \
+        if (!attr_done) {                                                                                         \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8<NKB, CHK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+            attr_done = true;                                                                                     \
+        }                                                                                                         \
+        hipLaunchKernelGGL((k_mm8<NKB, CHK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, \
+                           iv.stride_l, in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count,   \
+                           check_mask_dev, mismatch_dev, m->n_out, m->n_rt, tpw, C, n_units, m->bp);             \
     } while (0)
+#define MM8_LAUNCH(NKB) do { if (check) MM8_LAUNCH_(NKB, true); else MM8_LAUNCH_(NKB, false); } while (0)
     switch (m->nkb) {
         case 1: MM8_LAUNCH(1); break;
         case 2: MM8_LAUNCH(2); break;
@@ -288,9 +452,35 @@ extern "C" int hb_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, int64_t 
         case 6: MM8_LAUNCH(6); break;
         case 7: MM8_LAUNCH(7); break;
         case 8: MM8_LAUNCH(8); break;
-        default: return HB_ERR_BAD_ARG;
+        default: return fail(ctx, HB_ERR_UNSUPPORTED, "mm8: more than 32 terms");
     }
 #undef MM8_LAUNCH
+#undef MM8_LAUNCH_
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;
+}
+
+}  // namespace hb
+
+// ---- diagnostic entry points (scratch/test_mm8.py): the matrix-core mat-vec on its own ----------
+extern "C" int hb_debug_mm8_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, void **out) {
+    uint32_t *xd = nullptr;
+    int rc = upload_elems(ctx, x_host, (size_t)n, &xd, 0);
+    if (rc) return rc;
+    FastMatrix *V = nullptr;
+    rc = fast_vand_create(ctx, xd, n, d, &V, 0);
+    (void)hipFree(xd);
+    if (rc) return rc;
+    Mm8Matrix *m = nullptr;
+    rc = mm8_from_fast(ctx, V, &m, 0);
+    fast_matrix_free(V);
+    *out = m;
+    return rc;
+}
+extern "C" int hb_debug_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, int64_t in_sc, int64_t in_sl, int64_t in_count,
+                                  void *out_dev, int64_t out_sc, int64_t out_sl, int64_t out_count, int64_t n_chunks,
+                                  const int32_t *check_mask_dev, int32_t *mismatch_dev) {
+    hb_view iv{in_sc, in_sl}, ov{out_sc, out_sl};
+    return launch_mm8(ctx, (const Mm8Matrix *)mat, (const uint32_t *)in_dev, iv, nullptr, in_count, (uint32_t *)out_dev, ov, out_count,
+                      check_mask_dev, mismatch_dev, n_chunks, 0);
 }

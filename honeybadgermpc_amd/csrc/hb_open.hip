@@ -28,6 +28,7 @@ struct hb_open_plan {
     int64_t max_B, max_C;
     FastMatrix *V;       // n x d  raw Vandermonde at the n party points
     FastMatrix *Vinv;    // d x d  factored inverse for the arrival set z
+    Mm8Matrix *V8;       // int8 matrix-core image of V (hb_mfma.hip); nullptr when that path does not apply
     int32_t *z_dev;      // d row indices
     int32_t *mask_dev;   // n+1 ints: rows to validate
     uint32_t *in_dg;     // [d][NL][max_C] pre-scaled inputs (digit planes)
@@ -51,7 +52,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     hb_open_plan *pl = new hb_open_plan();
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
-    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr;
+    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr; pl->V8 = nullptr;
     pl->validate_arrived_only = 0;
     pl->ntt_order = 0; pl->tw = nullptr;
     const int L = ctx->n_limbs;
@@ -94,6 +95,13 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
             HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
         }
     }
+    if (!pl->ntt_order) {
+        // third generation: the encode and the validating re-encode on the int8 matrix cores when the
+        // Vandermonde entries are small enough (hb_mfma.hip); otherwise V8 stays null
+        rc = mm8_from_fast(ctx, pl->V, &pl->V8, s);
+        if (rc && rc != HB_ERR_UNSUPPORTED) { delete pl; return rc; }
+        if (pl->V8) HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+    }
     HB_HIP(ctx, hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     HB_HIP(ctx, hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
     *out = pl;
@@ -109,6 +117,9 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
     if (pl->ntt_order)
         return launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, (const uint32_t *)shares_dev, iv, B, pl->d, pl->n,
                               (uint32_t *)r1_out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
+    if (pl->V8)
+        return launch_mm8(pl->ctx, pl->V8, (const uint32_t *)shares_dev, iv, nullptr, B, (uint32_t *)r1_out_dev, ov, INT64_MAX,
+                          nullptr, nullptr, C, s);
     return launch_matvec2(pl->ctx, pl->V, nullptr, (const uint32_t *)shares_dev, iv, nullptr, B, pl->in_dg,
                           (uint32_t *)r1_out_dev, ov, INT64_MAX, pl->n, 0, nullptr, nullptr, nullptr, C, s);
 }
@@ -125,6 +136,17 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
         if (rc) return rc;
         rc = launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, pl->coef_pk, pm, INT64_MAX, pl->d, pl->n,
                             (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s);
+        if (rc) return rc;
+        return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
+    }
+    if (pl->V8) {
+        // decode to canonical coefficients (VALU path, d outputs), validate on the matrix cores: the
+        // re-encode of all n points compared with the received columns in the kernel's epilogue
+        int rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
+                                pl->coef_pk, pm, INT64_MAX, pl->d, 1, nullptr, nullptr, nullptr, C, s);
+        if (rc) return rc;
+        rc = launch_mm8(pl->ctx, pl->V8, pl->coef_pk, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm,
+                        INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s);
         if (rc) return rc;
         return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
     }
@@ -184,7 +206,7 @@ void hb_open_plan_destroy(hb_open_plan *pl) {
     if (!pl) return;
     (void)hipFree(pl->in_dg); (void)hipFree(pl->coef_dg); if (pl->coef_pk) (void)hipFree(pl->coef_pk);
     (void)hipFree(pl->mismatch_dev);
-    fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv);
+    fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8);
     delete pl;
 }
 
