@@ -139,7 +139,14 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 const int c0 = half ? 24 : 0, c1 = half ? MM8_NC : 24;
                 v4i acc[24];
                 asm volatile("" ::: "memory");
-                if (half == 0) { MM8_MFMA_HALF0(NKB, xs, as, acc, biasv) } else { MM8_MFMA_HALF1(NKB, xs, as, acc, biasv) }
+                {
+                    const uint32_t xs_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)xs;
+                    const uint32_t as_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)as;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (half == 0) Mm8Phase<NKB, 0>::run(acc, xs_addr, as_addr, biasv);
+                    else Mm8Phase<NKB, 1>::run(acc, xs_addr, as_addr, biasv);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if (half == 1 && rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next unit's DMA (issued a pass ago)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {   // carry chains of this half: the accumulators die here
@@ -156,6 +163,11 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
 #pragma unroll
                     for (int k = 0; k < 6; k++) (half ? whi : wlo)[reg][k] = __builtin_amdgcn_perm(t[2 * k + 1], t[2 * k], 0x05040100u);
                     cyp[reg] = cy;
+                    // pin the chain here: without a use ordered against the asm phases hipcc sinks the low half's
+                    // chain below the high half's MFMA block and keeps both sets of accumulators alive
+                    if (half == 0)
+                        asm volatile("" ::"v"(wlo[reg][0]), "v"(wlo[reg][1]), "v"(wlo[reg][2]), "v"(wlo[reg][3]), "v"(wlo[reg][4]),
+                                     "v"(wlo[reg][5]), "v"(cyp[reg]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (half == 0) continue;
