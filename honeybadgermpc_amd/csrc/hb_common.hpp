@@ -118,6 +118,7 @@ struct FastMatrix {
     int32_t *nd;        // [tile][n_in] digits actually non-zero in that tile/term
     int32_t *negrow;    // [n_out] 1 => negate the output row (nullptr: none)
     uint32_t *K;        // [n_in][NL] pre-scale constants (canonical digits; used as a mont_mul factor)
+    uint32_t *K2;       // factored inverses only: R^2 / den_j, the pre-scale that makes the outputs canonical (else nullptr)
 };
 // word index of digit q of raw matrix element (i, l): [tile][l][digit][ot], tile = i / ot
 __host__ __device__ inline size_t mf_index(int i, int l, int n_in, int nl, int q, int ot) {
@@ -132,7 +133,7 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
                    const uint32_t *in_pk, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *scratch_dg,
                    uint32_t *out_pk, hb_view ov, int64_t out_count,
                    int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                   int64_t C, hipStream_t s, int check_skip = 0);
+                   int64_t C, hipStream_t s, int check_skip = 0, const uint32_t *K_override = nullptr);
 
 int launch_decode_check(hb_ctx *ctx, const FastMatrix *dec, const FastMatrix *enc, const uint32_t *cols, hb_view cv,
                         const int32_t *z_dev, uint32_t *pk_dst, hb_view pv, int64_t pk_count, int pk_rows, uint32_t *coef_dg,
@@ -143,7 +144,8 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
 void mm8_free(Mm8Matrix *m);
 int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-               int64_t C, hipStream_t s);
+               int64_t C, hipStream_t s, uint32_t *copy_dst = nullptr, hb_view cpv = hb_view{0, 0}, int64_t copy_count = 0,
+               int copy_rows = 0);
 
 // dispatch on element width
 #define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \

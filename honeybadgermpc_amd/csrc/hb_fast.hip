@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uin
 // factored inverse Vandermonde: N (raw), negrow, K_j = R^3 / den_j.  One block, thread j owns point j.
 template <int NL, int NW>
 __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const uint32_t *__restrict__ x, int k, uint32_t *__restrict__ M,
-                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, int *__restrict__ singular, int ot) {
+                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, uint32_t *__restrict__ K2, int *__restrict__ singular, int ot) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *xs = smem;
     uint32_t *B0 = xs + (size_t)k * NL;
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const 
     mont_mul(t1, dinv, P.r2, P);               // R^2 / den
     mont_mul(t2, t1, P.r2, P);                 // R^3 / den   (canonical digits; mont_mul(y, .) = y R^2 / den)
 #pragma unroll
-    for (int w = 0; w < NL; w++) K[(size_t)t * NL + w] = t2[w];
+    for (int w = 0; w < NL; w++) { K[(size_t)t * NL + w] = t2[w]; K2[(size_t)t * NL + w] = t1[w]; }   // K2: outputs come out canonical
 }
 
 // nd[tile][l] = 1 + index of the highest non-zero digit over the tile's OT outputs (0 if all zero)
@@ -470,6 +470,7 @@ void fast_matrix_free(FastMatrix *m) {
     (void)hipFree(m->M); (void)hipFree(m->nd);
     if (m->negrow) (void)hipFree(m->negrow);
     if (m->K) (void)hipFree(m->K);
+    if (m->K2) (void)hipFree(m->K2);
     delete m;
 }
 
@@ -503,7 +504,7 @@ static int count_digits(hb_ctx *ctx, FastMatrix *m, hipStream_t s) {
 // raw Vandermonde n x d at device points, K = R^2 for every term (outputs canonical)
 int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s) {
     FastMatrix *m = new FastMatrix();
-    m->n_out = n; m->n_in = d; m->negrow = nullptr; m->K = nullptr; m->nd = nullptr;
+    m->n_out = n; m->n_in = d; m->negrow = nullptr; m->K = nullptr; m->K2 = nullptr; m->nd = nullptr;
     m->ot = pick_ot(ctx, d);
     const int NLr = ctx->nl();
     size_t words = (size_t)f_tiles(n, m->ot) * d * m->ot * NLr; if (!words) words = 1;
@@ -530,7 +531,7 @@ int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatri
 int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s) {
     if (k > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "vandermonde inverse: k > 1023");
     FastMatrix *m = new FastMatrix();
-    m->n_out = k; m->n_in = k; m->nd = nullptr;
+    m->n_out = k; m->n_in = k; m->nd = nullptr; m->K2 = nullptr;
     m->ot = pick_ot(ctx, k);
     const int NLr = ctx->nl();
     size_t words = (size_t)f_tiles(k, m->ot) * k * m->ot * NLr; if (!words) words = 1;
@@ -538,6 +539,7 @@ int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out
     HB_HIP(ctx, hipMemsetAsync(m->M, 0, words * 4, s));
     HB_HIP(ctx, hipMalloc(&m->negrow, sizeof(int32_t) * (size_t)(k > 0 ? k : 1)));
     HB_HIP(ctx, hipMalloc(&m->K, (size_t)(k > 0 ? k : 1) * NLr * 4));
+    HB_HIP(ctx, hipMalloc(&m->K2, (size_t)(k > 0 ? k : 1) * NLr * 4));
     int singular = 0;
     if (k > 0) {
         HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), s));
@@ -545,10 +547,10 @@ int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out
         size_t lds = (size_t)(k + 2 * (k + 1)) * NLr * 4;
         if (ctx->n_limbs == 4) {
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, ctx->flag_dev, m->ot);
+            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, m->K2, ctx->flag_dev, m->ot);
         } else {
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, ctx->flag_dev, m->ot);
+            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, m->K2, ctx->flag_dev, m->ot);
         }
         HB_LAUNCH_CHECK(ctx);
         HB_HIP(ctx, hipMemcpyAsync(&singular, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -618,8 +620,9 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
                    const uint32_t *in_pk, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *scratch_dg,
                    uint32_t *out_pk, hb_view ov, int64_t out_count,
                    int pk_rows, int pk_from_mont, uint32_t *out_dg, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                   int64_t C, hipStream_t s, int check_skip) {
+                   int64_t C, hipStream_t s, int check_skip, const uint32_t *K_override) {
     if (C <= 0 || m->n_out == 0) return HB_OK;
+    const uint32_t *Kp = K_override ? K_override : m->K;   // pre-scale constants (K2 of a factored inverse: canonical outputs)
     const int tiles = f_tiles(m->n_out, m->ot);
     const int64_t groups = (C + 63) / 64;
     const int nsub = nsub_for(m->n_in, ctx->nl(), ctx->elem_words());
@@ -646,7 +649,7 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
 #define HB_MV3O(NL_, NW_, CHK_, PP_, OT_)                                                                                       \
         do {                                                                                                                    \
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_matvec3<NL_, NW_, CHK_, OT_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(80 * 1024))); \
-            k_matvec3<NL_, NW_, CHK_, OT_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, in_pk, iv.stride_c, iv.stride_l, in_rows_dev, in_count, m->K, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks, check_skip); \
+            k_matvec3<NL_, NW_, CHK_, OT_><<<(unsigned)blocks, 64 * W, lds, s>>>(PP_, m->M, m->nd, m->negrow, m->n_out, m->n_in, nsub, in_dg, in_pk, iv.stride_c, iv.stride_l, in_rows_dev, in_count, Kp, out_pk, ov.stride_c, ov.stride_l, out_count, pk_rows, pk_from_mont, out_dg, check ? check_mask_dev : nullptr, check ? mismatch_dev : nullptr, C, tiles, tpb, slices, n_blocks, check_skip); \
         } while (0)
         if (ctx->n_limbs == 4) { if (check) HB_MV3(9, 8, true, ctx->pw); else HB_MV3(9, 8, false, ctx->pw); }
         else { if (check) HB_MV3(3, 2, true, ctx->pn); else HB_MV3(3, 2, false, ctx->pn); }
@@ -658,7 +661,9 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
     if (m->ot != 4) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: layout mismatch");
     if (in_pk) {       // no LDS variant: separate pre-scale pass
         if (!scratch_dg) return fail(ctx, HB_ERR_BAD_ARG, "matvec: scratch required");
-        int rc = launch_prescale(ctx, m, in_pk, iv, in_rows_dev, in_count, scratch_dg, C, s);
+        FastMatrix mk = *m;
+        mk.K = const_cast<uint32_t *>(Kp);
+        int rc = launch_prescale(ctx, &mk, in_pk, iv, in_rows_dev, in_count, scratch_dg, C, s);
         if (rc) return rc;
         in_dg = scratch_dg;
     }

@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                                                 const int32_t *__restrict__ in_rows, int64_t in_count, int d,
                                                 uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                 const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
+                                                uint32_t *__restrict__ copy_dst, int64_t copy_sc, int64_t copy_sl, int64_t copy_count, int copy_rows,
                                                 int n_out, int n_rt, int tpw, int64_t n_chunks, int64_t n_units, BarrettParams bp) {
     extern __shared__ uint4 mm8_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -128,6 +129,22 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
         // done reading the other buffer; no vmcnt wait here, so the output stores stay in flight
         __builtin_amdgcn_s_barrier();
         if (unit + gridDim.x < n_units) issue_loads(unit + gridDim.x, buf ^ 1);
+        if constexpr (CHECK) {
+            // hand the caller its rows of the input (the decoded coefficients) in its own layout while they are in LDS
+            if (copy_dst) {
+                for (int e = wave; e < tpw * NKB; e += 4) {
+                    const int t = e / NKB, kb = e - t * NKB, l = 4 * kb + g;
+                    const int64_t ch = (unit * tpw + t) * 16 + n;
+                    const int64_t idx = ch * copy_sc + (int64_t)l * copy_sl;
+                    if (l < copy_rows && l < d && ch < n_chunks && idx < copy_count) {
+                        const uint4 *src = xbuf + (size_t)buf * bufsz + (size_t)e * 2 * 64 + lane;
+                        uint4 *dst = reinterpret_cast<uint4 *>(copy_dst) + idx * 2;
+                        dst[0] = src[0];
+                        dst[1] = src[64];
+                    }
+                }
+            }
+        }
         const int64_t chunk = (unit * tpw + tl) * 16 + n;
         const uint4 *xs = xbuf + (size_t)buf * bufsz + (size_t)tl * NKB * 2 * 64 + lane;
         for (int rt = rt0; rt < n_rt; rt += rstep) {
@@ -431,10 +448,11 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     return HB_OK;
 }
 
-// out(c, i) = sum_l M[i][l] * in(c, rows[l]) mod p, canonical; CHECK mode when check_mask_dev != nullptr
+// out(c, i) = sum_l M[i][l] * in(c, rows[l]) mod p, canonical; CHECK mode when check_mask_dev != nullptr.
+// CHECK mode can also hand rows < copy_rows of the input to copy_dst (view cpv, clipped at copy_count).
 int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-               int64_t C, hipStream_t s) {
+               int64_t C, hipStream_t s, uint32_t *copy_dst, hb_view cpv, int64_t copy_count, int copy_rows) {
     if (C <= 0) return HB_OK;
     const int tpw = (m->n_rt == 1) ? 4 : (m->n_rt == 2) ? 2 : 1;
     const int64_t n_tiles = (C + 15) / 16;
@@ -452,7 +470,8 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
         }                                                                                                         \
         hipLaunchKernelGGL((k_mm8<NKB, CHK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, \
                            iv.stride_l, in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count,   \
-                           check_mask_dev, mismatch_dev, m->n_out, m->n_rt, tpw, C, n_units, m->bp);             \
+                           check_mask_dev, mismatch_dev, copy_dst, cpv.stride_c, cpv.stride_l, copy_count, copy_rows,         \
+                           m->n_out, m->n_rt, tpw, C, n_units, m->bp);             \
     } while (0)
 #define MM8_LAUNCH(NKB) do { if (check) MM8_LAUNCH_(NKB, true); else MM8_LAUNCH_(NKB, false); } while (0)
     switch (m->nkb) {
@@ -494,5 +513,5 @@ extern "C" int hb_debug_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, in
                                   const int32_t *check_mask_dev, int32_t *mismatch_dev) {
     hb_view iv{in_sc, in_sl}, ov{out_sc, out_sl};
     return launch_mm8(ctx, (const Mm8Matrix *)mat, (const uint32_t *)in_dev, iv, nullptr, in_count, (uint32_t *)out_dev, ov, out_count,
-                      check_mask_dev, mismatch_dev, n_chunks, 0);
+                      check_mask_dev, mismatch_dev, n_chunks, 0, nullptr, hb_view{0, 0}, 0, 0);
 }

@@ -141,14 +141,13 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
     }
     if (pl->V8) {
         // decode to canonical coefficients (VALU path, d outputs), validate on the matrix cores: the
-        // re-encode of all n points compared with the received columns in the kernel's epilogue
+        // re-encode of all n points compared with the received columns in the kernel's epilogue; the
+        // same kernel hands the caller its rows of the coefficients while they sit in LDS
         int rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
-                                pl->coef_pk, pm, INT64_MAX, pl->d, 1, nullptr, nullptr, nullptr, C, s);
+                                pl->coef_pk, pm, INT64_MAX, pl->d, 0, nullptr, nullptr, nullptr, C, s, 0, pl->Vinv->K2);
         if (rc) return rc;
-        rc = launch_mm8(pl->ctx, pl->V8, pl->coef_pk, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm,
-                        INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s);
-        if (rc) return rc;
-        return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
+        return launch_mm8(pl->ctx, pl->V8, pl->coef_pk, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm,
+                          INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s, pk_dst, pv, pk_count, pk_rows);
     }
     // one launch when the shapes allow it (decode + validating re-encode of the same 64-chunk group)
     int rc = launch_decode_check(pl->ctx, pl->Vinv, pl->V, (const uint32_t *)cols_dev, pm, pl->z_dev, pk_dst, pv, pk_count, pk_rows,
