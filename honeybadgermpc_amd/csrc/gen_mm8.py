@@ -97,12 +97,18 @@ def asm_half(half, nkb):
     ncol = c1 - c0
     xs_op, as_op, bias = f"%{ncol}", f"%{ncol + 1}", f"{ncol + 2}"
     lines = []
-    # the never-written positions of the E files are zero
-    for eset in range(2):
-        for r in list(range(EA[eset], EA[eset] + 10)) + list(range(EB[eset], EB[eset] + 8)):
-            lines.append(f"v_mov_b32 v{r}, 0")
-    lines += lds_loads(0, xs_op, as_op)
+    # the positions of the E files that are read but never written (k <= -2, k >= 8) are zero
     grp = groups(half)
+    read_k = {k for (_, _, qs, _) in grp for q in qs for k in range(q, q + 4)}
+    for eset in range(2):
+        for k in sorted(read_k):
+            if -1 <= k <= 7:
+                continue
+            if 0 <= k - KA0[half] < 10:
+                lines.append(f"v_mov_b32 v{EA[eset] + k - KA0[half]}, 0")
+            if 0 <= k - KB0[half] < 8:
+                lines.append(f"v_mov_b32 v{EB[eset] + k - KB0[half]}, 0")
+    lines += lds_loads(0, xs_op, as_op)
     seq = [(kb, g) for kb in range(nkb) for g in grp]       # g = (rho, cols, qs, used)
     pending_mfma = []                                         # MFMAs of the previous group, to interleave with this prep
     for idx, (kb, (rho, cols, qs, used)) in enumerate(seq):

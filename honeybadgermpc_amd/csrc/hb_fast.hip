@@ -365,7 +365,11 @@ __global__ void __launch_bounds__(512) k_matvec3(const FpParams<NL> P, const uin
     constexpr int BUDGET = 63 - NL;
     const uint32_t *xl = xs + lane;
     const int t_end = min(tiles, (slice + 1) * tiles_per_block);
-    for (int tile = slice * tiles_per_block + wib; tile < t_end; tile += W) {
+    // When the tiles do not divide evenly among the waves, which wave takes the extra one rotates with
+    // the group (hashed): wave w of every workgroup lands on SIMD w % 4, so a fixed assignment would
+    // load SIMDs 0/1 with all the long waves of the CU's three resident workgroups.
+    const int wrot = (int)((uint32_t)(wib + (((uint32_t)g * 0x9E3779B1u) >> 20)) % (uint32_t)W);
+    for (int tile = slice * tiles_per_block + wrot; tile < t_end; tile += W) {
         const int nv = min(OTT, n_out - tile * OTT);
         if constexpr (CHECK) {
             // optional: skip tiles none of whose rows is compared (plan option, off by default)

@@ -49,6 +49,13 @@ struct Mm8Matrix {
 typedef int v16i __attribute__((ext_vector_type(16)));
 #include "hb_mm8_body.inc"
 
+// e + (t >> 16): the carry-chain step as a single VALU op (SDWA selects the high half of t)
+__device__ __forceinline__ uint32_t add_hi16(uint32_t e, uint32_t t) {
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(e), "v"(t));
+    return r;
+}
+
 constexpr int MM8_BIAS = 5800000;   // > 352 * 128 * 128 >= |column|, and 2 * BIAS * 257 < 2^32
 
 // Persistent workgroups of 4 waves, 2 workgroups per CU (2 waves per SIMD, <= 256 registers each,
@@ -167,16 +174,17 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 if (half == 1 && rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next unit's DMA (issued a pass ago)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {   // carry chains of this half: the accumulators die here
-                    uint32_t cy = half ? cyp[reg] : 0u;
+                    uint32_t tp = half ? cyp[reg] : 0u;   // previous chain value: its high half is the carry
                     uint32_t t[12];
 #pragma unroll
                     for (int j = 0; j < 12; j++) {
                         const int ca = c0 + 2 * j, cb = ca + 1;
                         uint32_t e = (uint32_t)acc[ca - c0][reg];
                         if (cb < c1) e += (uint32_t)acc[cb - c0][reg] << 8;
-                        t[j] = e + cy;
-                        cy = t[j] >> 16;
+                        t[j] = add_hi16(e, tp);            // e + (tp >> 16) in one SDWA add
+                        tp = t[j];
                     }
+                    const uint32_t cy = tp;
 #pragma unroll
                     for (int k = 0; k < 6; k++) (half ? whi : wlo)[reg][k] = __builtin_amdgcn_perm(t[2 * k + 1], t[2 * k], 0x05040100u);
                     cyp[reg] = cy;
@@ -203,8 +211,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         uint32_t w[MM8_CW];
 #pragma unroll
                         for (int k = 0; k < 6; k++) { w[k] = wlo[reg][k]; w[6 + k] = whi[reg][k]; }
-                        const uint32_t cy = cyp[reg];
-                        w[12] = cy;
+                        w[12] = cyp[reg] >> 16;
                         const int i = 16 * rt + 4 * g + reg;
                         uint32_t sd[MM8_SD];
 #pragma unroll
