@@ -72,6 +72,7 @@ SYMBOLS = {
     "hb_open_r2_decode": (_i, [_vp, _vp, _i64, _vp, _vp]),
     "hb_open_status": (_i, [_vp, _vp]),
     "hb_open_plan_set_option": (_i, [_vp, _i, _i]),
+    "hb_open_plan_get_option": (_i, [_vp, _i, _vp]),
     "hb_open_plan_destroy": (None, [_vp]),
     "hb_selftest_mulmod": (_i, [_vp, _i, _vp, _vp, _vp]),
 }

@@ -29,6 +29,7 @@ struct hb_open_plan {
     FastMatrix *V;       // n x d  raw Vandermonde at the n party points
     FastMatrix *Vinv;    // d x d  factored inverse for the arrival set z
     Mm8Matrix *V8;       // int8 matrix-core image of V (hb_mfma.hip); nullptr when that path does not apply
+    int use_v8;          // option HB_OPEN_OPT_MATRIX_CORES (default 1)
     int32_t *z_dev;      // d row indices
     int32_t *mask_dev;   // n+1 ints: rows to validate
     uint32_t *in_dg;     // [d][NL][max_C] pre-scaled inputs (digit planes)
@@ -52,7 +53,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     hb_open_plan *pl = new hb_open_plan();
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
-    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr; pl->V8 = nullptr;
+    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr; pl->V8 = nullptr; pl->use_v8 = 1;
     pl->validate_arrived_only = 0;
     pl->ntt_order = 0; pl->tw = nullptr;
     const int L = ctx->n_limbs;
@@ -117,7 +118,7 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
     if (pl->ntt_order)
         return launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, (const uint32_t *)shares_dev, iv, B, pl->d, pl->n,
                               (uint32_t *)r1_out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
-    if (pl->V8)
+    if (pl->V8 && pl->use_v8)
         return launch_mm8(pl->ctx, pl->V8, (const uint32_t *)shares_dev, iv, nullptr, B, (uint32_t *)r1_out_dev, ov, INT64_MAX,
                           nullptr, nullptr, C, s);
     return launch_matvec2(pl->ctx, pl->V, nullptr, (const uint32_t *)shares_dev, iv, nullptr, B, pl->in_dg,
@@ -139,7 +140,7 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
         if (rc) return rc;
         return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
     }
-    if (pl->V8) {
+    if (pl->V8 && pl->use_v8) {
         // decode to canonical coefficients (VALU path, d outputs), validate on the matrix cores: the
         // re-encode of all n points compared with the received columns in the kernel's epilogue; the
         // same kernel hands the caller its rows of the coefficients while they sit in LDS
@@ -198,6 +199,14 @@ int hb_open_status(hb_open_plan *pl, void *stream) {
 int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
     if (!pl) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { pl->validate_arrived_only = value ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_MATRIX_CORES) { pl->use_v8 = value ? 1 : 0; return HB_OK; }
+    return HB_ERR_BAD_ARG;
+}
+
+int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) {
+    if (!pl || !value) return HB_ERR_BAD_ARG;
+    if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { *value = pl->validate_arrived_only; return HB_OK; }
+    if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = (pl->V8 && pl->use_v8) ? 1 : 0; return HB_OK; }
     return HB_ERR_BAD_ARG;
 }
 

@@ -89,6 +89,19 @@ class BatchOpen:
         all n rows as the reference's encode_batch does (reed_solomon.py:313).  Same decision."""
         self.ctx.check(self.ctx.lib.hb_open_plan_set_option(self.h, self.VALIDATE_ARRIVED_ONLY, 1 if on else 0), "set_option")
 
+    MATRIX_CORES = 2
+
+    def set_matrix_cores(self, on):
+        """Allow (default) or forbid the int8 matrix-core kernels for the encode and the validating
+        re-encode; results are bit-identical either way."""
+        self.ctx.check(self.ctx.lib.hb_open_plan_set_option(self.h, self.MATRIX_CORES, 1 if on else 0), "set_option")
+
+    def uses_matrix_cores(self):
+        """True when this plan's encode / validation run on the matrix cores (shapes qualify and not disabled)."""
+        v = ctypes.c_int(0)
+        self.ctx.check(self.ctx.lib.hb_open_plan_get_option(self.h, self.MATRIX_CORES, ctypes.byref(v)), "get_option")
+        return bool(v.value)
+
     def chunks(self, b):
         return (b + self.d - 1) // self.d
 

@@ -152,9 +152,16 @@ int hb_open_status(hb_open_plan *plan, void *stream);
 /* Options.  HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY (default 0): the reference re-encodes the guess at ALL n
  * points (encoder.encode_batch, reed_solomon.py:313) and then compares the columns that arrive; with
  * the option on, only output tiles containing a compared row are re-encoded.  Same accept/reject
- * decision, less arithmetic; off by default so that an open performs the reference's 3 full encodes. */
+ * decision, less arithmetic; off by default so that an open performs the reference's 3 full encodes.
+ * HB_OPEN_OPT_MATRIX_CORES (default 1): when the Vandermonde entries fit 16 signed base-256 digits and
+ * 2^254 <= p < 2^256 (the reference's BLS12-381 scalar field with the default points 1..n), the R1 encode
+ * and the validating re-encode run as an exact int8 GEMM on the matrix cores (csrc/hb_mfma.hip); 0 forces
+ * the integer-VALU kernels.  Results are bit-identical either way.  get_option reports whether the
+ * matrix-core path is in use for this plan (0 when the plan's shapes do not qualify). */
 #define HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY 1
+#define HB_OPEN_OPT_MATRIX_CORES 2
 int hb_open_plan_set_option(hb_open_plan *plan, int option, int value);
+int hb_open_plan_get_option(hb_open_plan *plan, int option, int *value);
 void hb_open_plan_destroy(hb_open_plan *plan);
 
 /* host-side self test of the radix-2^29 arithmetic templates (no GPU needed):

@@ -195,9 +195,11 @@ def test_matvec_views_and_check():
 
 
 # ------------------------------------------------------------------ per-party open pipeline
+@pytest.mark.parametrize("matrix_cores", [True, False])
 @pytest.mark.parametrize("n,t,b,use_omega", [(4, 1, 3, False), (16, 5, 100, False), (16, 5, 96, True), (64, 21, 1000, False), (7, 2, 1, False),
-                                             (64, 21, 700, True), (256, 85, 300, True), (100, 33, 150, True), (4, 1, 5, True)])
-def test_batch_open_vs_oracle(n, t, b, use_omega):
+                                             (64, 21, 700, True), (256, 85, 300, True), (100, 33, 150, True), (4, 1, 5, True),
+                                             (64, 21, 22 * 16 * 3 + 5, False), (40, 13, 333, False), (48, 31, 200, False), (128, 42, 260, False)])
+def test_batch_open_vs_oracle(n, t, b, use_omega, matrix_cores):
     import torch
 
     from honeybadgermpc_amd._capi import Context
@@ -226,6 +228,10 @@ def test_batch_open_vs_oracle(n, t, b, use_omega):
     rc, o_r1, o_r2msg, o_res = oracle.batch_open_limbs(P, n, d, x, oracle._limbs(shares, P), to_limbs(r1_cols), to_limbs(r2_cols), z, zc)
     assert rc == 0
     op = BatchOpen(P, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=b)
+    op.set_matrix_cores(matrix_cores)
+    # the int8 matrix-core kernels serve the points 1..n while every power fits 16 signed base-256 digits and t < 32
+    eligible = (not use_omega) and t + 1 <= 32 and n ** t < 127 * 256 ** 15
+    assert op.uses_matrix_cores() == (matrix_cores and eligible)
     r1_out = op.r1_encode(ctx.upload_ints(shares))
     r2_msg = op.r1_decode(ctx.upload_ints([v for col in r1_cols for v in col]), b)
     result = op.r2_decode(ctx.upload_ints([v for col in r2_cols for v in col]), b)
@@ -317,6 +323,58 @@ def test_full_size_properties_cfg3():
     # every output is canonical (< p): top limb bound check on the whole buffer
     top = ea[:, 3].cpu().numpy().view(np.uint64)
     assert int(top.max()) <= (P >> 192)
+
+
+def test_full_size_open_matrix_cores_vs_valu_cfg3():
+    """BASELINE config 3 size through the open plan: the matrix-core kernels and the integer-VALU kernels
+    give bit-identical encodes and reconstructions, the reconstruction returns the encoded chunks, and a
+    single flipped bit in a validated column is caught by both."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+
+    ctx = Context.get(P)
+    n, t, b = 64, 21, (1 << 20) - 3          # ragged last chunk
+    d = t + 1
+    c = (b + d - 1) // d
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234)
+    shares = torch.randint(-(1 << 63), (1 << 63) - 1, (b, 4), dtype=torch.int64, device="cuda", generator=gen)
+    shares[:, 3] &= (1 << 61) - 1            # canonical values (< p)
+    rnd = random.Random(8)
+    order = list(range(n))
+    rnd.shuffle(order)
+    z, zc = order[:d], order[d : d + t]
+    op = BatchOpen(P, n, t, z=z, zc=zc, max_shares=b)
+    assert op.uses_matrix_cores()
+    enc_m = op.r1_encode(shares)
+    op.set_matrix_cores(False)
+    assert not op.uses_matrix_cores()
+    enc_v = op.r1_encode(shares)
+    assert torch.equal(enc_m, enc_v)
+    assert int(enc_m[:, 3].cpu().numpy().view(np.uint64).max()) <= (P >> 192)     # canonical outputs
+    # the encode of the shares IS a consistent set of received columns: decoding it returns the shares
+    for on in (True, False):
+        op.set_matrix_cores(on)
+        msg = op.r1_decode(enc_m, b)
+        res = op.r2_decode(enc_m, b)
+        assert op.ok()
+        assert torch.equal(res, shares)
+        assert torch.equal(msg, shares.view(-1, 4)[0::d][:c]) if b % d == 0 else torch.equal(msg[: c - 1], shares[0 : (c - 1) * d : d])
+        bad = enc_m.clone()
+        bad[zc[3] * c + (c - 1), 1] ^= 1 << 17          # last (ragged) chunk of a validated column
+        op.r2_decode(bad, b)
+        assert not op.ok()
+        bad = enc_m.clone()
+        bad[zc[0] * c + 12345, 0] ^= 1
+        op.r1_decode(bad, b)
+        assert not op.ok()
+        rest = [i for i in range(n) if i not in z and i not in zc]
+        bad = enc_m.clone()
+        bad[rest[0] * c + 5, 0] ^= 1                     # never-arrived column: not looked at
+        op.r2_decode(bad, b)
+        assert op.ok()
 
 
 # ------------------------------------------------------------------ FFT path
