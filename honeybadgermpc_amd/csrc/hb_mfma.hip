@@ -21,8 +21,8 @@
 // together with a multiple of p that keeps the total non-negative (crow[]).
 //
 // Epilogue per output: 47 int32 columns -> 13 carried 32-bit words -> 14 radix-2^29 digits ->
-// Barrett (quotient from the top 6 digits x mu, 36 + 35 v_mad_u64_u32) -> two conditional
-// subtractions -> packed 4 x u64.  No Montgomery form anywhere on this path.
+// Barrett (quotient from the top 6 digits x mu, 30 + 35 v_mad_u64_u32) -> one conditional
+// subtraction -> packed 4 x u64.  No Montgomery form anywhere on this path.
 #include "hb_common.hpp"
 
 namespace hb {
@@ -34,7 +34,7 @@ constexpr int MM8_CW = 13;       // 32-bit words of the per-row constant / the c
 constexpr int MM8_SD = 14;       // radix-2^29 digits of the carried sum (S < 2^388)
 
 struct BarrettParams {
-    uint32_t p[9];    // modulus digits
+    uint32_t pbar[9]; // 2^261 - p, digits
     uint32_t mu[6];   // floor(2^406 / p) digits
 };
 
@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
         }
         const int64_t chunk = (unit * tpw + tl) * 16 + n;
         const uint4 *xs = xbuf + (size_t)buf * bufsz + (size_t)tl * NKB * 2 * 64 + lane;
+        if (rt0 >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a wave without a row tile still owns part of the DMA
         for (int rt = rt0; rt < n_rt; rt += rstep) {
             const int4 *as = abuf + (size_t)rt * NKB * 64 + lane;
             uint32_t wlo[4][6], whi[4][6];   // chain words of the two halves
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                     else Mm8Phase<NKB, 1>::run(acc, xs_addr, as_addr, biasv);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (half == 1 && rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next unit's DMA (issued a pass ago)
+                // next unit's DMA (issued a pass ago) must have landed before this wave reaches the barrier; waiting
+                // here, ahead of the epilogue, keeps this pass's output stores out of the wait
+                if (half == 1 && rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {   // carry chains of this half: the accumulators die here
                     uint32_t tp = half ? cyp[reg] : 0u;   // previous chain value: its high half is the carry
@@ -228,46 +231,49 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                             sd[8] += c2v.x; sd[9] += c2v.y; sd[10] += c2v.z; sd[11] += c2v.w;
                             sd[12] += c3v.x; sd[13] += c3v.y;
                         }
-                        // Barrett.  S_hi = sum_{k>=8} digit_k 2^(29(k-8)) >= S / 2^232 - 2 (lazy low digits < 2^30) and
-                        // mu > 2^406 / p - 1, so S_hi mu / 2^174 > S/p - S/2^406 - 2^233/p > S/p - 2^-11:
-                        // qhat = floor(S_hi mu / 2^174) is floor(S/p) or one less, and r = S - qhat p < 2p
-                        uint64_t pc[12];
-                        col_zero(pc);
+                        // Barrett.  S_hi = sum_{k>=8} digit_k 2^(29(k-8)) >= S / 2^232 - 2 (lazy low digits < 2^30),
+                        // mu > 2^406 / p - 1, and the three lowest product columns (< 2^120 in all) are dropped, so
+                        // S_hi mu / 2^174 > S/p - S/2^406 - 2^233/p - 2^-54 > S/p - 2^-10: qhat is floor(S/p) or one less.
+                        uint64_t pc[11];
+#pragma unroll
+                        for (int k = 0; k < 11; k++) pc[k] = 0;
 #pragma unroll
                         for (int aa = 0; aa < 6; aa++)
 #pragma unroll
-                            for (int bb = 0; bb < 6; bb++) pc[aa + bb] += (uint64_t)sd[8 + aa] * bp.mu[bb];
-                        carry(pc);
+                            for (int bb = 0; bb < 6; bb++)
+                                if (aa + bb >= 3) pc[aa + bb] += (uint64_t)sd[8 + aa] * bp.mu[bb];
+#pragma unroll
+                        for (int k = 3; k < 10; k++) pc[k + 1] += pc[k] >> LB;
                         uint32_t qd[5];
 #pragma unroll
-                        for (int k = 0; k < 5; k++) qd[k] = (uint32_t)pc[6 + k];
-                        uint64_t qp[9];
-                        col_zero(qp);
+                        for (int k = 0; k < 5; k++) qd[k] = (uint32_t)pc[6 + k] & (k < 4 ? DMASK : 0xffffffffu);
+                        // r = S - qhat p = S + qhat (2^261 - p)  (mod 2^261), r < 2p: additions only, the low digits of S
+                        // are the MADs' addend
+                        uint64_t dc[9];
+#pragma unroll
+                        for (int k = 0; k < 9; k++) dc[k] = sd[k];
 #pragma unroll
                         for (int aa = 0; aa < 5; aa++)
 #pragma unroll
                             for (int bb = 0; bb < 9; bb++)
-                                if (aa + bb < 9) qp[aa + bb] += (uint64_t)qd[aa] * bp.p[bb];
+                                if (aa + bb < 9) dc[aa + bb] += (uint64_t)qd[aa] * bp.pbar[bb];
                         uint32_t r[9];
-                        int64_t br = 0;
 #pragma unroll
                         for (int k = 0; k < 9; k++) {
-                            int64_t tt = (int64_t)(uint64_t)sd[k] - (int64_t)qp[k] + br;
-                            r[k] = (uint32_t)tt & DMASK;
-                            br = tt >> LB;
+                            r[k] = (uint32_t)dc[k] & DMASK;
+                            if (k < 8) dc[k + 1] += dc[k] >> LB;
                         }
-#pragma unroll
-                        for (int rep = 0; rep < 1; rep++) {   // qhat >= floor(S / p) - 1 (see above): r < 2p
-                            uint32_t tsub[9];
-                            int32_t bw = 0;
+                        // r >= p  <=>  r + (2^261 - p) carries out of digit 8
+                        {
+                            uint32_t u[9], cy2 = 0;
 #pragma unroll
                             for (int k = 0; k < 9; k++) {
-                                const int32_t v = (int32_t)r[k] - (int32_t)bp.p[k] + bw;
-                                bw = v >> 31;
-                                tsub[k] = (k < 8) ? ((uint32_t)v & DMASK) : (uint32_t)v;
+                                const uint32_t v = r[k] + bp.pbar[k] + cy2;
+                                u[k] = v & DMASK;
+                                cy2 = v >> LB;
                             }
 #pragma unroll
-                            for (int k = 0; k < 9; k++) r[k] = bw ? r[k] : tsub[k];
+                            for (int k = 0; k < 9; k++) r[k] = cy2 ? u[k] : r[k];
                         }
                         uint32_t ow[8];
                         pack<9, 8>(ow, r);
@@ -438,7 +444,16 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     }
     Mm8Matrix *m = new Mm8Matrix();
     m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr;
-    for (int k = 0; k < 9; k++) m->bp.p[k] = ctx->pw.p[k];
+    {   // 2^261 - p, radix 2^29
+        Big pb(9, 0); pb[8] = 1u << 5;            // 2^261
+        Big pw9(p); pw9.push_back(0);
+        big_sub(pb, pw9);
+        for (int k = 0; k < 9; k++) {
+            const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
+            uint64_t v = pb[j] | ((uint64_t)(j + 1 < 9 ? pb[j + 1] : 0) << 32);
+            m->bp.pbar[k] = (uint32_t)(v >> sft) & DMASK;
+        }
+    }
     for (int k = 0; k < 6; k++) {
         const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
         uint64_t v = mu[j] | ((uint64_t)(j + 1 < (int)mu.size() ? mu[j + 1] : 0) << 32);
