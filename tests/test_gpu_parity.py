@@ -325,6 +325,50 @@ def test_full_size_properties_cfg3():
     assert int(top.max()) <= (P >> 192)
 
 
+@pytest.mark.parametrize("prime", [(1 << 255) - 19, (1 << 256) - (1 << 32) - 977, (1 << 254) + 79, (1 << 254) - 245, (1 << 61) - 1])
+def test_batch_open_other_moduli(prime):
+    """The matrix-core path sizes its Barrett constants for 2^254 <= p < 2^256; other moduli must fall back.
+    Either way the open equals the oracle's."""
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+
+    n, t, b = 64, 21, 22 * 40 + 7
+    d = t + 1
+    c = (b + d - 1) // d
+    rnd = random.Random(prime % 1000003)
+    x = list(range(1, n + 1))
+    ctx = Context.get(prime)
+    shares = [rnd.randrange(prime) for _ in range(b)]
+    polys1 = rand_rows(rnd, prime, c, d)
+    polys2 = rand_rows(rnd, prime, c, d)
+    e1 = oracle.vandermonde_batch_evaluate(x, polys1, prime)
+    e2 = oracle.vandermonde_batch_evaluate(x, polys2, prime)
+    r1_cols = [[e1[k][j] for k in range(c)] for j in range(n)]
+    r2_cols = [[e2[k][j] for k in range(c)] for j in range(n)]
+    order = list(range(n))
+    rnd.shuffle(order)
+    z, zc = order[:d], order[d : d + t]
+    to_limbs = lambda rows: oracle._limbs([v for r in rows for v in r], prime)  # noqa: E731
+    rc, o_r1, o_r2msg, o_res = oracle.batch_open_limbs(prime, n, d, x, oracle._limbs(shares, prime), to_limbs(r1_cols), to_limbs(r2_cols), z, zc)
+    assert rc == 0
+    op = BatchOpen(prime, n, t, z=z, zc=zc, max_shares=b)
+    assert op.uses_matrix_cores() == (prime >= 1 << 254)
+    as_np = lambda tns: tns.cpu().numpy().view(np.uint64)  # noqa: E731
+    for on in (True, False):
+        op.set_matrix_cores(on)
+        r1_out = op.r1_encode(ctx.upload_ints(shares))
+        r2_msg = op.r1_decode(ctx.upload_ints([v for col in r1_cols for v in col]), b)
+        result = op.r2_decode(ctx.upload_ints([v for col in r2_cols for v in col]), b)
+        assert op.ok()
+        assert np.array_equal(as_np(r1_out), o_r1)
+        assert np.array_equal(as_np(r2_msg), o_r2msg)
+        assert np.array_equal(as_np(result), o_res)
+        bad = [list(col) for col in r2_cols]
+        bad[zc[1]][c - 1] = (bad[zc[1]][c - 1] + 1) % prime
+        op.r2_decode(ctx.upload_ints([v for col in bad for v in col]), b)
+        assert not op.ok()
+
+
 def test_full_size_open_matrix_cores_vs_valu_cfg3():
     """BASELINE config 3 size through the open plan: the matrix-core kernels and the integer-VALU kernels
     give bit-identical encodes and reconstructions, the reconstruction returns the encoded chunks, and a
