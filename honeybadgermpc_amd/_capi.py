@@ -74,6 +74,9 @@ SYMBOLS = {
     "hb_open_plan_set_option": (_i, [_vp, _i, _i]),
     "hb_open_plan_get_option": (_i, [_vp, _i, _vp]),
     "hb_open_plan_destroy": (None, [_vp]),
+    "hb_debug_mm8_create": (_i, [_vp, _vp, _i, _i, _pp]),
+    "hb_debug_mm8_apply": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "hb_debug_occupancy": (_i, [_i, _i, _vp, _vp]),
     "hb_selftest_mulmod": (_i, [_vp, _i, _vp, _vp, _vp]),
 }
 

@@ -46,7 +46,6 @@ struct Mm8Matrix {
     BarrettParams bp;
 };
 
-typedef int v16i __attribute__((ext_vector_type(16)));
 #include "hb_mm8_body.inc"
 
 // e + (t >> 16): the carry-chain step as a single VALU op (SDWA selects the high half of t)

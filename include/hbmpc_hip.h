@@ -164,6 +164,17 @@ int hb_open_plan_set_option(hb_open_plan *plan, int option, int value);
 int hb_open_plan_get_option(hb_open_plan *plan, int option, int *value);
 void hb_open_plan_destroy(hb_open_plan *plan);
 
+/* ---- diagnostics (scratch/ scripts only; not part of the drop-in surface) ---------------------------
+ * hb_debug_mm8_*: the int8 matrix-core mat-vec of csrc/hb_mfma.hip on its own -- table for the points
+ * x_host (n points, d terms), then out(c, i) = sum_l x_i^l in(c, l) with explicit views; HB_ERR_UNSUPPORTED
+ * when the shapes do not qualify.  hb_debug_occupancy: resident workgroups per CU the runtime reports for
+ * the second-generation kernels at a given inner dimension. */
+int hb_debug_mm8_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, void **out);
+int hb_debug_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, int64_t in_sc, int64_t in_sl, int64_t in_count,
+                       void *out_dev, int64_t out_sc, int64_t out_sl, int64_t out_count, int64_t n_chunks,
+                       const int32_t *check_mask_dev, int32_t *mismatch_dev);
+int hb_debug_occupancy(int n_in, int nl, int *mv3, int *dc);
+
 /* host-side self test of the radix-2^29 arithmetic templates (no GPU needed):
  * out = a*b mod p computed with the same code the kernels use. */
 int hb_selftest_mulmod(const uint64_t *p_limbs, int n_limbs, const uint64_t *a, const uint64_t *b, uint64_t *out);

@@ -15,11 +15,6 @@ P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 
 def make(ctx, xs, d):
     lib = ctx.lib
-    lib.hb_debug_mm8_create.restype = ctypes.c_int
-    lib.hb_debug_mm8_create.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    lib.hb_debug_mm8_apply.restype = ctypes.c_int
-    lib.hb_debug_mm8_apply.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
-                                       ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
     xh = ctx.host_elems(xs)
     h = ctypes.c_void_p()
     rc = lib.hb_debug_mm8_create(ctx.h, xh.ctypes.data, len(xs), d, ctypes.byref(h))
