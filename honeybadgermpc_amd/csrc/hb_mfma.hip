@@ -479,6 +479,7 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
     const int64_t n_tiles = (C + 15) / 16;
     const int64_t n_units = (n_tiles + tpw - 1) / tpw;
     int64_t blocks = 2 * (int64_t)mm8_num_cus();
+    if (const char *e = getenv("HB_MM8_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) blocks = (int64_t)v * mm8_num_cus(); }   // experiment hook
     if (blocks > n_units) blocks = n_units;
     const size_t lds = ((size_t)m->n_rt * 64 + (size_t)m->n_rt * m->nkb * 64 + (size_t)2 * tpw * m->nkb * 2 * 64) * 16 + 128 + (size_t)m->n_rt * 64;
     const bool check = check_mask_dev != nullptr;
