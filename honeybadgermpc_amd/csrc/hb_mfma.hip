@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
         }
     };
     const v4i biasv = v4i{MM8_BIAS, MM8_BIAS, MM8_BIAS, MM8_BIAS};
+    uint32_t k256 = 256u, k16m = 1u << 24;      // opaque, so that the word assembly stays two v_mad_u64_u32 per word
+    asm volatile("" : "+s"(k256), "+s"(k16m));
 
     int buf = 0;
     int64_t unit = blockIdx.x;
@@ -156,49 +158,60 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
         if (rt0 >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a wave without a row tile still owns part of the DMA
         for (int rt = rt0; rt < n_rt; rt += rstep) {
             const int4 *as = abuf + (size_t)rt * NKB * 64 + lane;
-            uint32_t wlo[4][6], whi[4][6];   // chain words of the two halves
-            uint32_t cyp[4];      // parked carry
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int c0 = half ? 24 : 0, c1 = half ? MM8_NC : 24;
+            uint32_t eap[4][11], c0p[4];     // half 0's column pairs, parked across the second MFMA block
+            uint32_t wd[4][MM8_CW];          // the 13 words of each biased sum
+            const uint32_t xs_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)xs;
+            const uint32_t as_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)as;
+            {   // ---- half 0: c = 0 and the pairs (4j+3, 4j+4); E_j = col_4j+3 + col_4j+4 2^8 sits at bit 32j + 24
                 v4i acc[24];
                 asm volatile("" ::: "memory");
-                {
-                    const uint32_t xs_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)xs;
-                    const uint32_t as_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)as;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (half == 0) Mm8Phase<NKB, 0>::run(acc, xs_addr, as_addr, biasv);
-                    else Mm8Phase<NKB, 1>::run(acc, xs_addr, as_addr, biasv);
+                __builtin_amdgcn_sched_barrier(0);
+                Mm8Phase<NKB, 0>::run(acc, xs_addr, as_addr, biasv);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int reg = 0; reg < 4; reg++) {   // the accumulators die here
+                    c0p[reg] = (uint32_t)acc[0][reg];
+#pragma unroll
+                    for (int j = 0; j < 11; j++) eap[reg][j] = (uint32_t)acc[1 + 2 * j][reg] + ((uint32_t)acc[2 + 2 * j][reg] << 8);
+                    // pin the values here: without a use ordered against the asm phases hipcc sinks this below the
+                    // second MFMA block and keeps both sets of accumulators alive
+                    asm volatile("" ::"v"(c0p[reg]), "v"(eap[reg][0]), "v"(eap[reg][1]), "v"(eap[reg][2]), "v"(eap[reg][3]), "v"(eap[reg][4]),
+                                 "v"(eap[reg][5]), "v"(eap[reg][6]), "v"(eap[reg][7]), "v"(eap[reg][8]), "v"(eap[reg][9]), "v"(eap[reg][10]));
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            }
+            {   // ---- half 1: the pairs (4k+1, 4k+2) at bit 32k + 8.  S = col_0 + sum_k (F_k 2^8 + E_k 2^24) 2^(32k)
+                v4i acc[24];
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                Mm8Phase<NKB, 1>::run(acc, xs_addr, as_addr, biasv);
+                __builtin_amdgcn_sched_barrier(0);
                 // next unit's DMA (issued a pass ago) must have landed before this wave reaches the barrier; waiting
                 // here, ahead of the epilogue, keeps this pass's output stores out of the wait
-                if (half == 1 && rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int reg = 0; reg < 4; reg++) {   // carry chains of this half: the accumulators die here
-                    uint32_t tp = half ? cyp[reg] : 0u;   // previous chain value: its high half is the carry
-                    uint32_t t[12];
+                for (int reg = 0; reg < 4; reg++) {
+                    // G_k = F_k 2^8 + E_k 2^24 < 2^56: the even and the odd G_k tile two multiword numbers without
+                    // carries; their sum is one add-with-carry per 32-bit word
+                    uint32_t glo[12], ghi[12];
 #pragma unroll
-                    for (int j = 0; j < 12; j++) {
-                        const int ca = c0 + 2 * j, cb = ca + 1;
-                        uint32_t e = (uint32_t)acc[ca - c0][reg];
-                        if (cb < c1) e += (uint32_t)acc[cb - c0][reg] << 8;
-                        t[j] = add_hi16(e, tp);            // e + (tp >> 16) in one SDWA add
-                        tp = t[j];
+                    for (int k = 0; k < 12; k++) {
+                        const uint32_t f = (uint32_t)acc[2 * k][reg] + ((uint32_t)acc[2 * k + 1][reg] << 8);
+                        uint64_t gk = (uint64_t)f * k256 + (k == 0 ? (uint64_t)c0p[reg] : 0ull);
+                        if (k < 11) gk += (uint64_t)eap[reg][k] * k16m;
+                        glo[k] = (uint32_t)gk;
+                        ghi[k] = (uint32_t)(gk >> 32);
                     }
-                    const uint32_t cy = tp;
+                    unsigned cyw = 0;
+                    wd[reg][0] = glo[0];
 #pragma unroll
-                    for (int k = 0; k < 6; k++) (half ? whi : wlo)[reg][k] = __builtin_amdgcn_perm(t[2 * k + 1], t[2 * k], 0x05040100u);
-                    cyp[reg] = cy;
-                    // pin the chain here: without a use ordered against the asm phases hipcc sinks the low half's
-                    // chain below the high half's MFMA block and keeps both sets of accumulators alive
-                    if (half == 0)
-                        asm volatile("" ::"v"(wlo[reg][0]), "v"(wlo[reg][1]), "v"(wlo[reg][2]), "v"(wlo[reg][3]), "v"(wlo[reg][4]),
-                                     "v"(wlo[reg][5]), "v"(cyp[reg]));
+                    for (int k = 1; k < 12; k++) wd[reg][k] = __builtin_addc(glo[k], ghi[k - 1], cyw, &cyw);
+                    wd[reg][12] = ghi[11] + cyw;
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (half == 0) continue;
-                __builtin_amdgcn_sched_barrier(0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     {
@@ -212,8 +225,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         (void)ew; (void)cmp;
                         uint32_t w[MM8_CW];
 #pragma unroll
-                        for (int k = 0; k < 6; k++) { w[k] = wlo[reg][k]; w[6 + k] = whi[reg][k]; }
-                        w[12] = cyp[reg] >> 16;
+                        for (int k = 0; k < MM8_CW; k++) w[k] = wd[reg][k];
                         const int i = 16 * rt + 4 * g + reg;
                         uint32_t sd[MM8_SD];
 #pragma unroll
@@ -285,6 +297,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                                 if (diff) atomicOr(mismatch, 1);
                             }
                         } else {
+                            // keep the reduction outside the store's exec mask: hipcc otherwise wraps the whole output in a
+                            // divergent branch, and the register copies at its join spill
+                            asm volatile("" ::"v"(ow[0]), "v"(ow[1]), "v"(ow[2]), "v"(ow[3]), "v"(ow[4]), "v"(ow[5]), "v"(ow[6]), "v"(ow[7]));
                             if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow);
                         }
                     }
