@@ -119,6 +119,7 @@ struct FastMatrix {
     int32_t *negrow;    // [n_out] 1 => negate the output row (nullptr: none)
     uint32_t *K;        // [n_in][NL] pre-scale constants (canonical digits; used as a mont_mul factor)
     uint32_t *K2;       // factored inverses only: R^2 / den_j, the pre-scale that makes the outputs canonical (else nullptr)
+    uint32_t *K1;       // factored inverses only: R / den_j, mont_mul(x, K1_j) = x / den_j (plain), for the matrix-core decode
 };
 // word index of digit q of raw matrix element (i, l): [tile][l][digit][ot], tile = i / ot
 __host__ __device__ inline size_t mf_index(int i, int l, int n_in, int nl, int q, int ot) {
@@ -129,6 +130,8 @@ int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatri
 int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s);
 int launch_prescale(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_view iv, const int32_t *rows_dev, int64_t in_count,
                     uint32_t *out_dg, int64_t C, hipStream_t s);
+int launch_prescale_pk(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_view iv, const int32_t *rows_dev, int64_t in_count,
+                       uint32_t *out_pk, int64_t C, hipStream_t s);
 int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
                    const uint32_t *in_pk, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *scratch_dg,
                    uint32_t *out_pk, hb_view ov, int64_t out_count,

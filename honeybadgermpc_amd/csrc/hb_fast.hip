@@ -57,6 +57,31 @@ __global__ void __launch_bounds__(256) k_prescale(const FpParams<NL> P, const ui
     for (int q = 0; q < NL; q++) out[dg_index(l, q, c, C, NL)] = r[q];
 }
 
+// packed canonical variant: out_pk[l * C + c] = in(c, rows[l]) * K_l / R  (K_l = R / den_l: the input of the matrix-core decode)
+template <int NL, int NW>
+__global__ void __launch_bounds__(256) k_prescale_pk(const FpParams<NL> P, const uint32_t *__restrict__ in, int64_t in_sc, int64_t in_sl,
+                                                     const int32_t *__restrict__ rows, int64_t in_count, const uint32_t *__restrict__ K,
+                                                     int n_in, int64_t C, uint32_t *__restrict__ out_pk) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = blockIdx.y;
+    if (c >= C) return;
+    const int row = rows ? rows[l] : l;
+    const int64_t idx = c * in_sc + (int64_t)row * in_sl;
+    uint32_t r[NL], w[NW];
+    if (idx < in_count) {
+        uint32_t xd[NL], kd[NL];
+        load_digits<NL, NW>(xd, in + idx * NW);
+#pragma unroll
+        for (int q = 0; q < NL; q++) kd[q] = K[(size_t)l * NL + q];
+        mont_mul(r, xd, kd, P);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NL; q++) r[q] = 0;
+    }
+    pack<NL, NW>(w, r);
+    store_words<NW>(out_pk + ((size_t)l * (size_t)C + (size_t)c) * NW, w);
+}
+
 // V[i][l] = x_i^l as raw canonical digits in kernel layout
 template <int NL, int NW>
 __global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uint32_t *__restrict__ x, int n, int d, uint32_t *__restrict__ M, int ot) {
@@ -78,7 +103,7 @@ __global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uin
 // factored inverse Vandermonde: N (raw), negrow, K_j = R^3 / den_j.  One block, thread j owns point j.
 template <int NL, int NW>
 __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const uint32_t *__restrict__ x, int k, uint32_t *__restrict__ M,
-                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, uint32_t *__restrict__ K2, int *__restrict__ singular, int ot) {
+                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, uint32_t *__restrict__ K2, uint32_t *__restrict__ K1, int *__restrict__ singular, int ot) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *xs = smem;
     uint32_t *B0 = xs + (size_t)k * NL;
@@ -146,7 +171,7 @@ __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const 
     mont_mul(t1, dinv, P.r2, P);               // R^2 / den
     mont_mul(t2, t1, P.r2, P);                 // R^3 / den   (canonical digits; mont_mul(y, .) = y R^2 / den)
 #pragma unroll
-    for (int w = 0; w < NL; w++) { K[(size_t)t * NL + w] = t2[w]; K2[(size_t)t * NL + w] = t1[w]; }   // K2: outputs come out canonical
+    for (int w = 0; w < NL; w++) { K[(size_t)t * NL + w] = t2[w]; K2[(size_t)t * NL + w] = t1[w]; K1[(size_t)t * NL + w] = dinv[w]; }   // K2: canonical outputs; K1: x -> x / den
 }
 
 // nd[tile][l] = 1 + index of the highest non-zero digit over the tile's OT outputs (0 if all zero)
@@ -475,6 +500,7 @@ void fast_matrix_free(FastMatrix *m) {
     if (m->negrow) (void)hipFree(m->negrow);
     if (m->K) (void)hipFree(m->K);
     if (m->K2) (void)hipFree(m->K2);
+    if (m->K1) (void)hipFree(m->K1);
     delete m;
 }
 
@@ -508,7 +534,7 @@ static int count_digits(hb_ctx *ctx, FastMatrix *m, hipStream_t s) {
 // raw Vandermonde n x d at device points, K = R^2 for every term (outputs canonical)
 int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s) {
     FastMatrix *m = new FastMatrix();
-    m->n_out = n; m->n_in = d; m->negrow = nullptr; m->K = nullptr; m->K2 = nullptr; m->nd = nullptr;
+    m->n_out = n; m->n_in = d; m->negrow = nullptr; m->K = nullptr; m->K2 = nullptr; m->K1 = nullptr; m->nd = nullptr;
     m->ot = pick_ot(ctx, d);
     const int NLr = ctx->nl();
     size_t words = (size_t)f_tiles(n, m->ot) * d * m->ot * NLr; if (!words) words = 1;
@@ -535,7 +561,7 @@ int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatri
 int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s) {
     if (k > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "vandermonde inverse: k > 1023");
     FastMatrix *m = new FastMatrix();
-    m->n_out = k; m->n_in = k; m->nd = nullptr; m->K2 = nullptr;
+    m->n_out = k; m->n_in = k; m->nd = nullptr; m->K2 = nullptr; m->K1 = nullptr;
     m->ot = pick_ot(ctx, k);
     const int NLr = ctx->nl();
     size_t words = (size_t)f_tiles(k, m->ot) * k * m->ot * NLr; if (!words) words = 1;
@@ -544,6 +570,7 @@ int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out
     HB_HIP(ctx, hipMalloc(&m->negrow, sizeof(int32_t) * (size_t)(k > 0 ? k : 1)));
     HB_HIP(ctx, hipMalloc(&m->K, (size_t)(k > 0 ? k : 1) * NLr * 4));
     HB_HIP(ctx, hipMalloc(&m->K2, (size_t)(k > 0 ? k : 1) * NLr * 4));
+    HB_HIP(ctx, hipMalloc(&m->K1, (size_t)(k > 0 ? k : 1) * NLr * 4));
     int singular = 0;
     if (k > 0) {
         HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), s));
@@ -551,10 +578,10 @@ int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out
         size_t lds = (size_t)(k + 2 * (k + 1)) * NLr * 4;
         if (ctx->n_limbs == 4) {
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, m->K2, ctx->flag_dev, m->ot);
+            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, m->K2, m->K1, ctx->flag_dev, m->ot);
         } else {
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, m->K2, ctx->flag_dev, m->ot);
+            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, m->K2, m->K1, ctx->flag_dev, m->ot);
         }
         HB_LAUNCH_CHECK(ctx);
         HB_HIP(ctx, hipMemcpyAsync(&singular, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -574,6 +601,19 @@ int launch_prescale(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_vie
     dim3 grid((unsigned)((C + 255) / 256), (unsigned)m->n_in);
     if (ctx->n_limbs == 4) k_prescale<9, 8><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K, m->n_in, C, out_dg);
     else k_prescale<3, 2><<<grid, 256, 0, s>>>(ctx->pn, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K, m->n_in, C, out_dg);
+    HB_LAUNCH_CHECK(ctx);
+    return HB_OK;
+}
+
+// out_pk[l][c] = in(c, rows[l]) / den_l, canonical packed, row-major [n_in][C]: the pre-scale of a factored inverse as a pass
+// of its own (the matrix-core decode reads plain elements)
+int launch_prescale_pk(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_view iv, const int32_t *rows_dev, int64_t in_count,
+                       uint32_t *out_pk, int64_t C, hipStream_t s) {
+    if (C <= 0 || m->n_in == 0) return HB_OK;
+    if (!m->K1) return fail(ctx, HB_ERR_BAD_ARG, "prescale: not a factored inverse");
+    dim3 grid((unsigned)((C + 255) / 256), (unsigned)m->n_in);
+    if (ctx->n_limbs == 4) k_prescale_pk<9, 8><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
+    else k_prescale_pk<3, 2><<<grid, 256, 0, s>>>(ctx->pn, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;
 }

@@ -29,6 +29,8 @@ struct hb_open_plan {
     FastMatrix *V;       // n x d  raw Vandermonde at the n party points
     FastMatrix *Vinv;    // d x d  factored inverse for the arrival set z
     Mm8Matrix *V8;       // int8 matrix-core image of V (hb_mfma.hip); nullptr when that path does not apply
+    Mm8Matrix *Vinv8;    // same for the numerators N of the factored inverse (decode on the matrix cores); may be nullptr
+    uint32_t *scaled_pk; // [d][max_C] received columns / den_j, the matrix-core decode's input
     int use_v8;          // option HB_OPEN_OPT_MATRIX_CORES (default 1)
     int32_t *z_dev;      // d row indices
     int32_t *mask_dev;   // n+1 ints: rows to validate
@@ -53,7 +55,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     hb_open_plan *pl = new hb_open_plan();
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
-    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr; pl->V8 = nullptr; pl->use_v8 = 1;
+    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr; pl->V8 = nullptr; pl->Vinv8 = nullptr; pl->scaled_pk = nullptr; pl->use_v8 = 1;
     pl->validate_arrived_only = 0;
     pl->ntt_order = 0; pl->tw = nullptr;
     const int L = ctx->n_limbs;
@@ -101,7 +103,12 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         // Vandermonde entries are small enough (hb_mfma.hip); otherwise V8 stays null
         rc = mm8_from_fast(ctx, pl->V, &pl->V8, s);
         if (rc && rc != HB_ERR_UNSUPPORTED) { delete pl; return rc; }
-        if (pl->V8) HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+        if (pl->V8) {
+            HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+            rc = getenv("HB_NO_MFMA_DECODE") ? HB_ERR_UNSUPPORTED : mm8_from_fast(ctx, pl->Vinv, &pl->Vinv8, s);
+            if (rc && rc != HB_ERR_UNSUPPORTED) { delete pl; return rc; }
+            if (pl->Vinv8) HB_HIP(ctx, hipMalloc(&pl->scaled_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+        }
     }
     HB_HIP(ctx, hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     HB_HIP(ctx, hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
@@ -144,8 +151,16 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
         // decode to canonical coefficients (VALU path, d outputs), validate on the matrix cores: the
         // re-encode of all n points compared with the received columns in the kernel's epilogue; the
         // same kernel hands the caller its rows of the coefficients while they sit in LDS
-        int rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
+        int rc;
+        if (pl->Vinv8) {
+            // c = N (x / den): the division as an elementwise pass, the small-integer mat-vec on the matrix cores
+            rc = launch_prescale_pk(pl->ctx, pl->Vinv, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->scaled_pk, C, s);
+            if (rc) return rc;
+            rc = launch_mm8(pl->ctx, pl->Vinv8, pl->scaled_pk, pm, nullptr, INT64_MAX, pl->coef_pk, pm, INT64_MAX, nullptr, nullptr, C, s);
+        } else {
+            rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
                                 pl->coef_pk, pm, INT64_MAX, pl->d, 0, nullptr, nullptr, nullptr, C, s, 0, pl->Vinv->K2);
+        }
         if (rc) return rc;
         return launch_mm8(pl->ctx, pl->V8, pl->coef_pk, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm,
                           INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s, pk_dst, pv, pk_count, pk_rows);
@@ -214,7 +229,8 @@ void hb_open_plan_destroy(hb_open_plan *pl) {
     if (!pl) return;
     (void)hipFree(pl->in_dg); (void)hipFree(pl->coef_dg); if (pl->coef_pk) (void)hipFree(pl->coef_pk);
     (void)hipFree(pl->mismatch_dev);
-    fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8);
+    fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8); mm8_free(pl->Vinv8);
+    if (pl->scaled_pk) (void)hipFree(pl->scaled_pk);
     delete pl;
 }
 
