@@ -385,7 +385,7 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic_from_profiles(args.workload if mfma else args.workload + "_valu"),
                 "kernel": ("k_mm8<NKB,false> (R1 encode: n x d small-entry Vandermonde mat-vec as a byte-split int8 GEMM + Barrett; "
-                           "the validating re-encodes are the same kernel in CHECK mode)" if mfma else
+                           "the validating re-encodes are the same kernel in CHECK mode, the decodes the same kernel over the factored inverse's numerators)" if mfma else
                            "k_matvec3<9,8,false> (R1 encode: fused pre-scale + n x d small-entry Vandermonde mat-vec)"),
                 "algorithmic_bytes_per_launch": alg_bytes_enc, "avg_launch_ms": enc_ms,
                 "copy_GBps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
