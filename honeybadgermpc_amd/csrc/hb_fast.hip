@@ -57,29 +57,37 @@ __global__ void __launch_bounds__(256) k_prescale(const FpParams<NL> P, const ui
     for (int q = 0; q < NL; q++) out[dg_index(l, q, c, C, NL)] = r[q];
 }
 
-// packed canonical variant: out_pk[l * C + c] = in(c, rows[l]) * K_l / R  (K_l = R / den_l: the input of the matrix-core decode)
-template <int NL, int NW>
+// packed canonical variant: out_pk[l * C + c] = in(c, rows[l]) * K_l / R  (K_l = R / den_l: the input of the matrix-core decode).
+// EPT elements per thread, loads issued together: the kernel is a 32-byte-in / 32-byte-out stream with ~330 VALU ops per element.
+template <int NL, int NW, int EPT>
 __global__ void __launch_bounds__(256) k_prescale_pk(const FpParams<NL> P, const uint32_t *__restrict__ in, int64_t in_sc, int64_t in_sl,
                                                      const int32_t *__restrict__ rows, int64_t in_count, const uint32_t *__restrict__ K,
                                                      int n_in, int64_t C, uint32_t *__restrict__ out_pk) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int l = blockIdx.y;
-    if (c >= C) return;
     const int row = rows ? rows[l] : l;
-    const int64_t idx = c * in_sc + (int64_t)row * in_sl;
-    uint32_t r[NL], w[NW];
-    if (idx < in_count) {
-        uint32_t xd[NL], kd[NL];
-        load_digits<NL, NW>(xd, in + idx * NW);
+    uint32_t kd[NL];
 #pragma unroll
-        for (int q = 0; q < NL; q++) kd[q] = K[(size_t)l * NL + q];
-        mont_mul(r, xd, kd, P);
-    } else {
+    for (int q = 0; q < NL; q++) kd[q] = K[(size_t)l * NL + q];
+    uint32_t xw[EPT][NW];
+    bool ok[EPT];
 #pragma unroll
-        for (int q = 0; q < NL; q++) r[q] = 0;
+    for (int e = 0; e < EPT; e++) {
+        const int64_t c = ((int64_t)blockIdx.x * EPT + e) * blockDim.x + threadIdx.x;
+        const int64_t idx = c * in_sc + (int64_t)row * in_sl;
+        ok[e] = c < C && idx < in_count;
+        load_words<NW>(xw[e], in + (ok[e] ? idx : 0) * NW);
     }
-    pack<NL, NW>(w, r);
-    store_words<NW>(out_pk + ((size_t)l * (size_t)C + (size_t)c) * NW, w);
+#pragma unroll
+    for (int e = 0; e < EPT; e++) {
+        const int64_t c = ((int64_t)blockIdx.x * EPT + e) * blockDim.x + threadIdx.x;
+        uint32_t xd[NL], r[NL], w[NW];
+        unpack<NL, NW>(xd, xw[e]);
+        mont_mul(r, xd, kd, P);
+#pragma unroll
+        for (int q = 0; q < NL; q++) r[q] = ok[e] ? r[q] : 0u;
+        pack<NL, NW>(w, r);
+        if (c < C) store_words<NW>(out_pk + ((size_t)l * (size_t)C + (size_t)c) * NW, w);
+    }
 }
 
 // V[i][l] = x_i^l as raw canonical digits in kernel layout
@@ -611,9 +619,14 @@ int launch_prescale_pk(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_
                        uint32_t *out_pk, int64_t C, hipStream_t s) {
     if (C <= 0 || m->n_in == 0) return HB_OK;
     if (!m->K1) return fail(ctx, HB_ERR_BAD_ARG, "prescale: not a factored inverse");
-    dim3 grid((unsigned)((C + 255) / 256), (unsigned)m->n_in);
-    if (ctx->n_limbs == 4) k_prescale_pk<9, 8><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
-    else k_prescale_pk<3, 2><<<grid, 256, 0, s>>>(ctx->pn, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
+    int ept = 1;   // measured on config 3: 19.6 / 20.1 / 23.0 us for 1 / 2 / 4 elements per thread
+    if (const char *e = getenv("HB_PRESCALE_EPT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) ept = v; }   // tuning hook
+    dim3 grid((unsigned)((C + 256 * ept - 1) / (256 * ept)), (unsigned)m->n_in);
+    if (ctx->n_limbs == 4) {
+        if (ept == 1) k_prescale_pk<9, 8, 1><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
+        else if (ept == 2) k_prescale_pk<9, 8, 2><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
+        else k_prescale_pk<9, 8, 4><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
+    } else k_prescale_pk<3, 2, 1><<<dim3((unsigned)((C + 255) / 256), (unsigned)m->n_in), 256, 0, s>>>(ctx->pn, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;
 }
