@@ -53,6 +53,7 @@ struct hb_ctx {
     std::map<std::vector<int32_t>, int32_t *> icache; // small int arrays resident on device
     std::map<std::string, void *> dcache;             // other device tables (twiddles, ...), hipFree'd with the ctx
     std::map<std::string, hb::FastMatrix *> fcache;   // second-generation (raw small-entry) tables
+    std::map<std::string, hb::Mm8Matrix *> m8cache;   // their int8 matrix-core images (nullptr: does not qualify)
     int32_t *flag_dev;                                // 64 status words
     int elem_words() const { return n_limbs == 4 ? 8 : 2; }
     int nl() const { return n_limbs == 4 ? 9 : 3; }

@@ -409,6 +409,7 @@ void hb_ctx_destroy(hb_ctx *ctx) {
     for (auto &kv : ctx->icache) (void)hipFree(kv.second);
     for (auto &kv : ctx->dcache) (void)hipFree(kv.second);
     for (auto &kv : ctx->fcache) fast_matrix_free(kv.second);
+    for (auto &kv : ctx->m8cache) mm8_free(kv.second);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
     delete ctx;
 }
@@ -647,10 +648,16 @@ int hb_matvec_check(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_
 }
 
 // cached second-generation tables for a host point set
-static int fast_table(hb_ctx *ctx, const char *kind, const uint64_t *x_host, int n, int d, FastMatrix **out, hipStream_t s) {
+static int fast_table(hb_ctx *ctx, const char *kind, const uint64_t *x_host, int n, int d, FastMatrix **out, hipStream_t s,
+                      Mm8Matrix **out8 = nullptr) {
     std::string key = table_key(kind, ctx, x_host, n, d);
+    if (out8) *out8 = nullptr;
     auto it = ctx->fcache.find(key);
-    if (it != ctx->fcache.end()) { *out = it->second; return HB_OK; }
+    if (it != ctx->fcache.end()) {
+        *out = it->second;
+        if (out8) { auto i8 = ctx->m8cache.find(key); if (i8 != ctx->m8cache.end()) *out8 = i8->second; }
+        return HB_OK;
+    }
     uint32_t *xd = nullptr;
     int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
     FastMatrix *m = nullptr;
@@ -660,6 +667,12 @@ static int fast_table(hb_ctx *ctx, const char *kind, const uint64_t *x_host, int
     if (rc) return rc;
     ctx->fcache[key] = m;
     *out = m;
+    // the matrix-core image of the same table, when it qualifies (hb_mfma.hip); nullptr is cached too
+    Mm8Matrix *m8 = nullptr;
+    rc = mm8_from_fast(ctx, m, &m8, s);
+    if (rc && rc != HB_ERR_UNSUPPORTED) return rc;
+    ctx->m8cache[key] = m8;
+    if (out8) *out8 = m8;
     return HB_OK;
 }
 
@@ -679,10 +692,12 @@ int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, co
     hipStream_t s = (hipStream_t)stream;
     if (d == 0) { HB_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)C * n * ctx->elem_words() * 4, s)); return HB_OK; }
     FastMatrix *V = nullptr;
-    int rc = fast_table(ctx, "Vf", x_host, n, d, &V, s); if (rc) return rc;
+    Mm8Matrix *V8 = nullptr;
+    int rc = fast_table(ctx, "Vf", x_host, n, d, &V, s, &V8); if (rc) return rc;
+    hb_view iv{d, 1}, ov{n, 1};
+    if (V8) return launch_mm8(ctx, V8, (const uint32_t *)polys_dev, iv, nullptr, INT64_MAX, (uint32_t *)out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
     uint32_t *scratch = nullptr;
     rc = fast_scratch(ctx, d, C, &scratch); if (rc) return rc;
-    hb_view iv{d, 1}, ov{n, 1};
     rc = launch_matvec2(ctx, V, nullptr, (const uint32_t *)polys_dev, iv, nullptr, INT64_MAX, scratch,
                         (uint32_t *)out_dev, ov, INT64_MAX, n, 0, nullptr, nullptr, nullptr, C, s);
     if (scratch) { (void)hipStreamSynchronize(s); (void)hipFree(scratch); }
@@ -694,11 +709,23 @@ int hb_vandermonde_batch_interpolate(hb_ctx *ctx, const uint64_t *x_host, int k,
     if (!ctx || k < 0 || C < 0) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     FastMatrix *Vi = nullptr;
-    int rc = fast_table(ctx, "Nf", x_host, k, k, &Vi, s); if (rc) return rc;     // HB_ERR_SINGULAR: repeated point
+    Mm8Matrix *Vi8 = nullptr;
+    int rc = fast_table(ctx, "Nf", x_host, k, k, &Vi, s, &Vi8); if (rc) return rc;     // HB_ERR_SINGULAR: repeated point
     if (C == 0 || k == 0) return HB_OK;
+    hb_view v{k, 1};
+    if (Vi8) {
+        // c = N (y / den): elementwise division into a row-major temporary, then the small-integer mat-vec on the matrix cores
+        uint32_t *scaled = nullptr;
+        HB_HIP(ctx, hipMalloc(&scaled, (size_t)k * (size_t)C * ctx->elem_words() * 4));
+        hb_view rm{1, C};
+        rc = launch_prescale_pk(ctx, Vi, (const uint32_t *)data_dev, v, nullptr, INT64_MAX, scaled, C, s);
+        if (!rc) rc = launch_mm8(ctx, Vi8, scaled, rm, nullptr, INT64_MAX, (uint32_t *)out_dev, v, INT64_MAX, nullptr, nullptr, C, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(scaled);
+        return rc;
+    }
     uint32_t *scratch = nullptr;
     rc = fast_scratch(ctx, k, C, &scratch); if (rc) return rc;
-    hb_view v{k, 1};
     rc = launch_matvec2(ctx, Vi, nullptr, (const uint32_t *)data_dev, v, nullptr, INT64_MAX, scratch,
                         (uint32_t *)out_dev, v, INT64_MAX, k, 1, nullptr, nullptr, nullptr, C, s);
     if (scratch) { (void)hipStreamSynchronize(s); (void)hipFree(scratch); }

@@ -5,6 +5,7 @@ sizes -- through size-independent properties (encode -> erase -> decode round tr
 linearity, consistency of validation).  Bit-exact everywhere: this is integer work.
 """
 import ctypes
+import os
 import random
 
 import numpy as np
@@ -230,7 +231,7 @@ def test_batch_open_vs_oracle(n, t, b, use_omega, matrix_cores):
     op = BatchOpen(P, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=b)
     op.set_matrix_cores(matrix_cores)
     # the int8 matrix-core kernels serve the points 1..n while every power fits 16 signed base-256 digits and t < 32
-    eligible = (not use_omega) and t + 1 <= 32 and n ** t < 127 * 256 ** 15
+    eligible = (not use_omega) and t + 1 <= 32 and n ** t < 127 * 256 ** 15 and not os.environ.get("HB_NO_MFMA")
     assert op.uses_matrix_cores() == (matrix_cores and eligible)
     r1_out = op.r1_encode(ctx.upload_ints(shares))
     r2_msg = op.r1_decode(ctx.upload_ints([v for col in r1_cols for v in col]), b)
@@ -352,7 +353,7 @@ def test_batch_open_other_moduli(prime):
     rc, o_r1, o_r2msg, o_res = oracle.batch_open_limbs(prime, n, d, x, oracle._limbs(shares, prime), to_limbs(r1_cols), to_limbs(r2_cols), z, zc)
     assert rc == 0
     op = BatchOpen(prime, n, t, z=z, zc=zc, max_shares=b)
-    assert op.uses_matrix_cores() == (prime >= 1 << 254)
+    assert op.uses_matrix_cores() == (prime >= 1 << 254 and not os.environ.get("HB_NO_MFMA"))
     as_np = lambda tns: tns.cpu().numpy().view(np.uint64)  # noqa: E731
     for on in (True, False):
         op.set_matrix_cores(on)
@@ -391,6 +392,8 @@ def test_full_size_open_matrix_cores_vs_valu_cfg3():
     rnd.shuffle(order)
     z, zc = order[:d], order[d : d + t]
     op = BatchOpen(P, n, t, z=z, zc=zc, max_shares=b)
+    if os.environ.get("HB_NO_MFMA"):
+        pytest.skip("matrix-core path disabled by HB_NO_MFMA")
     assert op.uses_matrix_cores()
     enc_m = op.r1_encode(shares)
     op.set_matrix_cores(False)
