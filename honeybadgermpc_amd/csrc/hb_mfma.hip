@@ -40,7 +40,7 @@ struct BarrettParams {
 
 struct Mm8Matrix {
     int n_out, d, nkb, n_rt;
-    int4 *a8;          // [n_rt][nkb][64 lanes] 16 balanced digits each: lane (r, g) = row 16 rt + r, term 4 kb + g, digit 15 - j
+    int4 *a8;          // [n_rt][nkb][64 lanes] 16 balanced digits each: lane (r, g) = row 16 rt + 4 (r % 4) + r / 4, term 4 kb + g, digit 15 - j
     uint32_t *crow;    // [n_rt * 16][16] radix-2^29 digits of the per-row constant (14 used)
     uint32_t *zero;    // 32 zero bytes: DMA source for inputs beyond in_count (zero padding of the last chunk)
     BarrettParams bp;
@@ -73,7 +73,7 @@ constexpr int MM8_BIAS = 5800000;   // > 352 * 128 * 128 >= |column|, and 2 * BI
 // multiple of p are one per-row constant (crowd), added digit-wise (radix 2^29) after the chain.
 // CHECK: out_pk holds the expected values; rows with check_mask[i] != 0 are compared, any difference
 // sets *mismatch (the validating re-encode of reed_solomon.py:316-326).
-template <int NKB, bool CHECK>
+template <int NKB, bool CHECK, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
                                                 const uint32_t *__restrict__ zero_src,
                                                 const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
@@ -160,6 +160,10 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
             const int4 *as = abuf + (size_t)rt * NKB * 64 + lane;
             uint32_t eap[4][11], c0p[4];     // half 0's column pairs, parked across the second MFMA block
             uint32_t wd[4][MM8_CW];          // the 13 words of each biased sum
+            // Output `reg` of lane (n, g) is row 16 rt + 4 reg + g (the host places matrix row 16 rt + j at tile row
+            // 4 (j % 4) + j / 4), so the rows beyond n_out of a ragged last tile fill whole outputs from the top: when
+            // outputs 2 and 3 are all padding (22 rows: the decode's second tile) their reduction is skipped
+            const bool pair1 = !RAGGED || 16 * rt + 8 < n_out;   // RAGGED is instantiated only where it pays (launch_mm8)
             const uint32_t xs_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)xs;
             const uint32_t as_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)as;
             {   // ---- half 0: c = 0 and the pairs (4j+3, 4j+4); E_j = col_4j+3 + col_4j+4 2^8 sits at bit 32j + 24
@@ -170,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {   // the accumulators die here
+                    if (reg == 2 && !pair1) break;
                     c0p[reg] = (uint32_t)acc[0][reg];
 #pragma unroll
                     for (int j = 0; j < 11; j++) eap[reg][j] = (uint32_t)acc[1 + 2 * j][reg] + ((uint32_t)acc[2 + 2 * j][reg] << 8);
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 if (rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
+                    if (reg == 2 && !pair1) break;
                     // G_k = F_k 2^8 + E_k 2^24 < 2^56: the even and the odd G_k tile two multiword numbers without
                     // carries; their sum is one add-with-carry per 32-bit word
                     uint32_t glo[12], ghi[12];
@@ -214,11 +220,12 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
             {
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
+                    if (reg == 2 && !pair1) break;
                     {
                         uint32_t ew[8];
                         bool cmp = false;
                         if constexpr (CHECK) {   // expected value: in flight while this output is reduced
-                            const int i = 16 * rt + 4 * g + reg;
+                            const int i = 16 * rt + 4 * reg + g;
                             cmp = (chunk < n_chunks) && maskl[i];
                             if (cmp) load_words<8>(ew, out_pk + (chunk * out_sc + (int64_t)i * out_sl) * 8);
                         }
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         uint32_t w[MM8_CW];
 #pragma unroll
                         for (int k = 0; k < MM8_CW; k++) w[k] = wd[reg][k];
-                        const int i = 16 * rt + 4 * g + reg;
+                        const int i = 16 * rt + 4 * reg + g;
                         uint32_t sd[MM8_SD];
 #pragma unroll
                         for (int k = 0; k < MM8_SD; k++) {   // digit k = bits [29k, 29k + 29) of the 13 words
@@ -432,7 +439,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
             if (w8[4] | w8[5] | w8[6] | w8[7]) return HB_ERR_UNSUPPORTED;   // does not fit 16 balanced digits
             const int sgn = neg[i] ? -1 : 1;
             int carry = 0;
-            int8_t *dst = &a[(((size_t)(i / 16) * nkb + l / 4) * 64 + (size_t)(i % 16) + 16 * (l % 4)) * 16];
+            int8_t *dst = &a[(((size_t)(i / 16) * nkb + l / 4) * 64 + (size_t)(4 * ((i % 16) % 4) + (i % 16) / 4) + 16 * (l % 4)) * 16];
             for (int b = 0; b < 16; b++) {
                 int t = sgn * (int)((w8[b >> 2] >> (8 * (b & 3))) & 0xffu) + carry;
                 if (t > 127) { t -= 256; carry = 1; } else if (t < -128) { t += 256; carry = -1; } else carry = 0;
@@ -498,19 +505,21 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
     if (blocks > n_units) blocks = n_units;
     const size_t lds = ((size_t)m->n_rt * 64 + (size_t)m->n_rt * m->nkb * 64 + (size_t)2 * tpw * m->nkb * 2 * 64) * 16 + 128 + (size_t)m->n_rt * 64;
     const bool check = check_mask_dev != nullptr;
-#define MM8_LAUNCH_(NKB, CHK)                                                                                     \
+    // the last row tile holds at most 8 rows: its outputs 2 and 3 are padding and their reduction can be skipped
+    const bool ragged = !check && (m->n_out % 16) >= 1 && (m->n_out % 16) <= 8;
+#define MM8_LAUNCH_(NKB, CHK, RG)                                                                                     \
     do {                                                                                                          \
         static bool attr_done = false;                                                                            \
         if (!attr_done) {                                                                                         \
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8<NKB, CHK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8<NKB, CHK, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
             attr_done = true;                                                                                     \
         }                                                                                                         \
-        hipLaunchKernelGGL((k_mm8<NKB, CHK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, \
+        hipLaunchKernelGGL((k_mm8<NKB, CHK, RG>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, \
                            iv.stride_l, in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count,   \
                            check_mask_dev, mismatch_dev, copy_dst, cpv.stride_c, cpv.stride_l, copy_count, copy_rows,         \
                            m->n_out, m->n_rt, tpw, C, n_units, m->bp);             \
     } while (0)
-#define MM8_LAUNCH(NKB) do { if (check) MM8_LAUNCH_(NKB, true); else MM8_LAUNCH_(NKB, false); } while (0)
+#define MM8_LAUNCH(NKB) do { if (check) MM8_LAUNCH_(NKB, true, false); else if (ragged) MM8_LAUNCH_(NKB, false, true); else MM8_LAUNCH_(NKB, false, false); } while (0)
     switch (m->nkb) {
         case 1: MM8_LAUNCH(1); break;
         case 2: MM8_LAUNCH(2); break;
