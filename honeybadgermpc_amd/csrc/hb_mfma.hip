@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
             // Output `reg` of lane (n, g) is row 16 rt + 4 reg + g (the host places matrix row 16 rt + j at tile row
             // 4 (j % 4) + j / 4), so the rows beyond n_out of a ragged last tile fill whole outputs from the top: when
             // outputs 2 and 3 are all padding (22 rows: the decode's second tile) their reduction is skipped
+            const int64_t obase = chunk * out_sc + (int64_t)(16 * rt + g) * out_sl, ostep = 4 * out_sl;   // element index of output reg
             const bool pair1 = !RAGGED || 16 * rt + 8 < n_out;   // RAGGED is instantiated only where it pays (launch_mm8)
             const uint32_t xs_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)xs;
             const uint32_t as_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)as;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         if constexpr (CHECK) {   // expected value: in flight while this output is reduced
                             const int i = 16 * rt + 4 * reg + g;
                             cmp = (chunk < n_chunks) && maskl[i];
-                            if (cmp) load_words<8>(ew, out_pk + (chunk * out_sc + (int64_t)i * out_sl) * 8);
+                            if (cmp) load_words<8>(ew, out_pk + (obase + reg * ostep) * 8);
                         }
                         (void)ew; (void)cmp;
                         uint32_t w[MM8_CW];
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         }
                         uint32_t ow[8];
                         pack<9, 8>(ow, r);
-                        const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
+                        const int64_t oidx = obase + reg * ostep;
                         if constexpr (CHECK) {
                             if (cmp) {
                                 uint32_t diff = 0;

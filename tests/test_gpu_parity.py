@@ -370,6 +370,42 @@ def test_batch_open_other_moduli(prime):
         assert not op.ok()
 
 
+@pytest.mark.parametrize("n,d,chunks,kind", [(64, 22, 37, "random"), (64, 22, 16, "extreme"), (64, 22, 19, "short"), (16, 6, 50, "random"),
+                                             (21, 9, 19, "random"), (40, 11, 16 * 70 + 3, "random"), (22, 22, 33, "extreme"), (1, 1, 5, "random")])
+def test_matrix_core_matvec_vs_python_ints(n, d, chunks, kind):
+    """The int8 matrix-core mat-vec on its own (hb_debug_mm8_*) against exact Python integers: random inputs, inputs
+    at the edges of the byte-split arithmetic (0, 1, p-1, 2^256-1, 0x80.., 0x7f..), a zero-padded tail, ragged tiles."""
+    from honeybadgermpc_amd._capi import Context, np_ptr
+
+    if os.environ.get("HB_NO_MFMA"):
+        pytest.skip("matrix-core path disabled by HB_NO_MFMA")
+    ctx = Context.get(P)
+    lib = ctx.lib
+    rnd = random.Random(n * 131 + d)
+    pts = list(range(1, n + 1))
+    h = ctypes.c_void_p()
+    ctx.check(lib.hb_debug_mm8_create(ctx.h, np_ptr(ctx.host_elems(pts)), n, d, ctypes.byref(h)), "mm8 table")
+    if kind == "extreme":
+        pool = [0, 1, P - 1, (1 << 256) - 1, 1 << 255, int("80" * 32, 16), int("7f" * 32, 16), int("ff00" * 16, 16)]
+        xs = [rnd.choice(pool) for _ in range(chunks * d)]
+        arr = np.zeros((chunks * d, 4), dtype=np.uint64)
+        for k, v in enumerate(xs):
+            for j in range(4):
+                arr[k, j] = (v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF
+        x_dev = ctx.to_device(arr)
+    else:
+        xs = [rnd.randrange(P) for _ in range(chunks * d)]
+        x_dev = ctx.upload_ints(xs)
+    in_count = chunks * d - (7 if kind == "short" and chunks * d > 7 else 0)
+    out = ctx.empty(chunks * n)
+    ctx.check(lib.hb_debug_mm8_apply(ctx.h, h, ctx.ptr(x_dev), d, 1, in_count, ctx.ptr(out), n, 1, chunks * n, chunks, None, None), "mm8 apply")
+    got = ctx.download_ints(out)
+    for c in range(chunks):
+        for i in range(n):
+            want = sum(pow(pts[i], l, P) * (xs[c * d + l] if c * d + l < in_count else 0) for l in range(d)) % P
+            assert got[c * n + i] == want, (c, i)
+
+
 def test_full_size_open_matrix_cores_vs_valu_cfg3():
     """BASELINE config 3 size through the open plan: the matrix-core kernels and the integer-VALU kernels
     give bit-identical encodes and reconstructions, the reconstruction returns the encoded chunks, and a
