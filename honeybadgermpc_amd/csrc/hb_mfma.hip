@@ -10,19 +10,22 @@
 //   M   = sum_b M_b 2^(8b)   b < 16   (balanced signed digits, precomputed)
 //   S   = sum_c 2^(8c) col_c,   col_c = sum_l sum_b M_b[i][l] * X_{c-b}[l]        c < 47
 // so that for a fixed column c the sum over (l, b) is ONE int8 dot product of length 16*d between a
-// constant row (the digits of M, register resident) and a 16-byte sliding window of every input
-// element.  v_mfma_i32_16x16x64_i8 takes 16 rows i x 16 chunks x (4 elements l x 16 digits b) per
-// instruction.  The window for column c is bytes [c-15, c] of the element; it is dword aligned for
-// c = 3 mod 4 and otherwise built with v_alignbyte from the element's registers, once per residue
-// class of c (27 ops per element per wave pass instead of 4 per MFMA).
+// constant row (the digits of M) and a 16-byte sliding window of every input element.
+// v_mfma_i32_16x16x64_i8 takes 16 rows i x 16 chunks x (4 elements l x 16 digits b) per instruction.
+// The window for column c is bytes [c-15, c] of the element, i.e. dwords q .. q+3 of the element
+// shifted right by rho bytes (c - 15 = 4q + rho); how the shifted copies are kept in aligned register
+// files so that no operand is ever assembled per MFMA is gen_mm8.py's business (it emits the MFMA
+// phases as inline asm, hb_mm8_body.inc).
 //
 // int8 operands are signed: M uses balanced digits; the input bytes are biased by XOR 0x80
 // (u = s + 128) and the constant 128 * sum_a 2^(8a) * sum_l M[i][l] is added back per row, mod p,
-// together with a multiple of p that keeps the total non-negative (crow[]).
+// together with a multiple of p that keeps the total non-negative and minus the accumulator bias
+// (crow[], radix-2^29 digits).
 //
-// Epilogue per output: 47 int32 columns -> 13 carried 32-bit words -> 14 radix-2^29 digits ->
-// Barrett (quotient from the top 6 digits x mu, 30 + 35 v_mad_u64_u32) -> one conditional
-// subtraction -> packed 4 x u64.  No Montgomery form anywhere on this path.
+// Epilogue per output: 47 int32 columns -> pairs E = col + col' 2^8 (< 2^32) -> 13 words by one
+// add-with-carry each -> 14 radix-2^29 digits + row constant -> Barrett (quotient from the top 6
+// digits x mu, 30 + 35 v_mad_u64_u32) -> one conditional subtraction -> packed 4 x u64.  No
+// Montgomery form anywhere on this path.
 #include "hb_common.hpp"
 
 namespace hb {
@@ -48,14 +51,7 @@ struct Mm8Matrix {
 
 #include "hb_mm8_body.inc"
 
-// e + (t >> 16): the carry-chain step as a single VALU op (SDWA selects the high half of t)
-__device__ __forceinline__ uint32_t add_hi16(uint32_t e, uint32_t t) {
-    uint32_t r;
-    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(e), "v"(t));
-    return r;
-}
-
-constexpr int MM8_BIAS = 5800000;   // > 352 * 128 * 128 >= |column|, and 2 * BIAS * 257 < 2^32
+constexpr int MM8_BIAS = 5800000;   // >= 128 * sum |digit| >= |column| (checked per matrix when it is built), and 2 * BIAS * 257 < 2^32
 
 // Persistent workgroups of 4 waves, 2 workgroups per CU (2 waves per SIMD, <= 256 registers each,
 // so that one wave's MFMA stream overlaps its neighbour's VALU epilogue).
@@ -66,11 +62,12 @@ constexpr int MM8_BIAS = 5800000;   // > 352 * 128 * 128 >= |column|, and 2 * BI
 // row tile rt (16 output rows) of tile tl: (tl, rt) = (w / n_rt, w % n_rt) when n_rt divides 4,
 // otherwise tl = 0 and rt = w, w + 4, ...
 //
-// Per (tile, rt) the 47 columns are produced in two halves (24 + 23 accumulators).  Accumulators
-// start from BIAS so that every column is non-negative and the carry chain is unsigned 32-bit:
-//   E_j = col_2j + (col_2j+1 << 8) < 2^32,  t = E_j + cy,  halfword_j = t & 0xffff,  cy = t >> 16
-// The low half's words are parked (7 registers per output).  The bias, the XOR-0x80 correction and a
-// multiple of p are one per-row constant (crowd), added digit-wise (radix 2^29) after the chain.
+// Per (tile, rt) the 47 columns are produced in two halves by byte shift (rho in {0,1}: 23 columns, rho in
+// {2,3}: 24).  Accumulators start from BIAS so that every column is non-negative; a pair of adjacent
+// columns then fits 32 bits, and the pairs of the two halves interleave into the 13 words of the sum with
+// one add-with-carry per word.  Half 0's twelve values per output are parked across the second MFMA block.
+// The bias, the XOR-0x80 correction and a multiple of p are one per-row constant (crowd), added digit-wise
+// (radix 2^29) before the Barrett reduction.
 // CHECK: out_pk holds the expected values; rows with check_mask[i] != 0 are compared, any difference
 // sets *mismatch (the validating re-encode of reed_solomon.py:316-326).
 template <int NKB, bool CHECK, bool RAGGED>
