@@ -247,6 +247,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="shares in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-two-streams-extra", dest="two_streams_extra", action="store_false",
+                    help="skip the secondary (untimed for `value`) two-opens-in-flight measurement")
     ap.add_argument("--no-matrix-cores", action="store_true", help="time the integer-VALU kernels instead of the int8 matrix-core path")
     args = ap.parse_args()
 
@@ -349,6 +351,42 @@ def main():
         step()
         assert op.ok()
 
+    # ---- secondary (untimed for `value`): two independent opens in flight ------------------------
+    # A party opens many share arrays concurrently (Mpc.open_share_array under asyncio); with a second plan
+    # on a second stream consecutive opens overlap (kernel tails, the elementwise pass, and co-resident
+    # workgroups of different launches are not phase-locked).  Throughput only; each open is unchanged.
+    dt_two = None
+    if args.two_streams_extra and world == 1:
+        s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
+        lanes = []
+        for k in range(2):
+            with torch.cuda.stream(s2[k]):
+                opk = op if k == 0 else BatchOpen(BLS, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=B, device=local_rank)
+                if args.no_matrix_cores:
+                    opk.set_matrix_cores(False)
+                lanes.append((opk, ctx.empty(n * C), ctx.empty(C), ctx.empty(B)))
+        torch.cuda.synchronize()
+
+        def step2(i):
+            k = i & 1
+            with torch.cuda.stream(s2[k]):
+                o, a, b_, c_ = lanes[k]
+                o.r1_encode(shares0, out=a)
+                o.r1_decode(r1_cols, B, out=b_)
+                o.r2_decode(r2_cols, B, out=c_)
+
+        for i in range(6):
+            step2(i)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(args.steps):
+            step2(i)
+        oks = [lane[0].ok() for lane in lanes]
+        torch.cuda.synchronize()
+        dt_two = time.perf_counter() - t2
+        assert all(oks) and all(torch.equal(lane[3], secrets) for lane in lanes)
+        del lanes
+
     # ---- correctness of what was timed (untimed) --------------------------------------
     assert torch.equal(result, secrets), "reconstructed shares differ from the secrets"
     sec_pad = secrets
@@ -402,6 +440,9 @@ def main():
                 "mulmod_per_s": world * mulmods_open * args.steps / dt,
                 "bit_exact_vs_secrets": True,
                 "matrix_core_path": bool(mfma),
+                "shares_per_s_per_gpu_two_opens_in_flight": (B * args.steps / dt_two) if dt_two else None,
+                "two_opens_in_flight_note": "same opens issued alternately on two streams with two plans (independent batches overlap); "
+                                            "`value` is one open at a time on one stream",
                 "shares_per_s_per_gpu_integer_valu_path": (B * args.steps / dt_other) if dt_other else None,
                 "integer_valu_path_note": "same open with HB_OPEN_OPT_MATRIX_CORES = 0 (second-generation integer-VALU kernels), same validation; bit-identical results",
             },
