@@ -357,35 +357,36 @@ def main():
     # workgroups of different launches are not phase-locked).  Throughput only; each open is unchanged.
     dt_two = None
     if args.two_streams_extra and world == 1:
-        s2 = [torch.cuda.Stream(), torch.cuda.Stream()]
-        lanes = []
-        for k in range(2):
-            with torch.cuda.stream(s2[k]):
-                opk = op if k == 0 else BatchOpen(BLS, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=B, device=local_rank)
-                if args.no_matrix_cores:
-                    opk.set_matrix_cores(False)
-                lanes.append((opk, ctx.empty(n * C), ctx.empty(C), ctx.empty(B)))
+        from honeybadgermpc_amd.device import BatchOpenPipeline
+
+        pipe = BatchOpenPipeline(BLS, n, t, depth=2, z=z, zc=zc, use_omega_powers=use_omega, max_shares=B, device=local_rank)
+        outs = []
+        for lane in pipe.lanes:
+            if args.no_matrix_cores:
+                lane.op.set_matrix_cores(False)
+            with lane.on_stream():
+                outs.append((ctx.empty(n * C), ctx.empty(C), ctx.empty(B)))
         torch.cuda.synchronize()
 
-        def step2(i):
-            k = i & 1
-            with torch.cuda.stream(s2[k]):
-                o, a, b_, c_ = lanes[k]
-                o.r1_encode(shares0, out=a)
-                o.r1_decode(r1_cols, B, out=b_)
-                o.r2_decode(r2_cols, B, out=c_)
+        def step2():
+            lane = pipe.next()
+            a, b_, c_ = outs[pipe.lanes.index(lane)]
+            with lane.on_stream():
+                lane.op.r1_encode(shares0, out=a)
+                lane.op.r1_decode(r1_cols, B, out=b_)
+                lane.op.r2_decode(r2_cols, B, out=c_)
 
-        for i in range(6):
-            step2(i)
+        for _ in range(6):
+            step2()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        for i in range(args.steps):
-            step2(i)
-        oks = [lane[0].ok() for lane in lanes]
+        for _ in range(args.steps):
+            step2()
+        ok3 = pipe.ok()
         torch.cuda.synchronize()
         dt_two = time.perf_counter() - t2
-        assert all(oks) and all(torch.equal(lane[3], secrets) for lane in lanes)
-        del lanes
+        assert ok3 and all(torch.equal(o[2], secrets) for o in outs)
+        del pipe, outs
 
     # ---- correctness of what was timed (untimed) --------------------------------------
     assert torch.equal(result, secrets), "reconstructed shares differ from the secrets"

@@ -460,6 +460,53 @@ def test_full_size_open_matrix_cores_vs_valu_cfg3():
         assert op.ok()
 
 
+def test_batch_open_pipeline_two_in_flight():
+    """Two plans on two streams used round-robin give the same results as one open at a time."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen, BatchOpenPipeline
+
+    ctx = Context.get(P)
+    n, t, b = 64, 21, 22 * 500 + 9
+    d = t + 1
+    c = (b + d - 1) // d
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(77)
+    batches = []
+    for _ in range(4):
+        v = torch.randint(-(1 << 63), (1 << 63) - 1, (b, 4), dtype=torch.int64, device="cuda", generator=gen)
+        v[:, 3] &= (1 << 61) - 1
+        batches.append(v)
+    z, zc = list(range(5, 5 + d)), list(range(30, 30 + t))
+    ref = BatchOpen(P, n, t, z=z, zc=zc, max_shares=b)
+    want = []
+    for v in batches:
+        enc = ref.r1_encode(v)
+        want.append((enc.clone(), ref.r1_decode(enc, b).clone(), ref.r2_decode(enc, b).clone()))
+    assert ref.ok()
+    torch.cuda.synchronize()
+    pipe = BatchOpenPipeline(P, n, t, depth=2, z=z, zc=zc, max_shares=b)
+    got = []
+    for v in batches:
+        lane = pipe.next()
+        with lane.on_stream():
+            enc = lane.op.r1_encode(v)
+            got.append((enc, lane.op.r1_decode(enc, b), lane.op.r2_decode(enc, b)))
+    assert pipe.ok()
+    torch.cuda.synchronize()
+    for (a0, a1, a2), (b0, b1, b2), v in zip(want, got, batches):
+        assert torch.equal(a0, b0) and torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(b2, v)
+    # a corrupted validated column on one lane is reported
+    lane = pipe.next()
+    with lane.on_stream():
+        enc = lane.op.r1_encode(batches[0])
+        enc[zc[2] * c + 3, 0] ^= 2
+        lane.op.r2_decode(enc, b)
+    assert not pipe.ok()
+    assert pipe.ok()
+
+
 # ------------------------------------------------------------------ FFT path
 def test_fft_reference_vectors(hip, golden):
     assert hip.fft([0, 1], 5, 13, 4) == [1, 5, 12, 8]           # reference tests/test_ntl.py:57-68
