@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhbmpc_hip.so")
+# HBMPC_HIP_LIB: load another build of the same library (A/B timing of kernel revisions on one GPU box)
+LIB_PATH = os.environ.get("HBMPC_HIP_LIB") or os.path.join(_HERE, "lib", "libhbmpc_hip.so")
 
 HB_OK, HB_ERR_SINGULAR, HB_ERR_BAD_ARG, HB_ERR_UNSUPPORTED = 0, 1, 2, 3
 HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_MISMATCH = 4, 5, 6

@@ -86,8 +86,6 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     int4 *abuf = reinterpret_cast<int4 *>(mm8_lds + n_rt * 64);   // [n_rt][NKB][64] matrix digits
     uint4 *xbuf = mm8_lds + n_rt * 64 + n_rt * NKB * 64;        // 2 x [tpw][NKB][2][64] uint4
     const int bufsz = tpw * NKB * 2 * 64;
-    for (int i = threadIdx.x; i < n_rt * 64; i += 256) mm8_lds[i] = reinterpret_cast<const uint4 *>(crowd)[i];
-    for (int i = threadIdx.x; i < n_rt * NKB * 64; i += 256) abuf[i] = a8[i];
 
     const bool single = (tpw * n_rt == 4);
     const int tl = single ? wave / n_rt : 0;
@@ -128,7 +126,10 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     int buf = 0;
     int64_t unit = blockIdx.x;
     if (unit < n_units) issue_loads(unit, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the constant tables ride behind the first unit's DMA instead of in front of it
+    for (int i = threadIdx.x; i < n_rt * 64; i += 256) mm8_lds[i] = reinterpret_cast<const uint4 *>(crowd)[i];
+    for (int i = threadIdx.x; i < n_rt * NKB * 64; i += 256) abuf[i] = a8[i];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     for (; unit < n_units; unit += gridDim.x, buf ^= 1) {
         // every wave has waited for its share of this unit's DMA (below, before its epilogue) and is
         // done reading the other buffer; no vmcnt wait here, so the output stores stay in flight
