@@ -351,6 +351,20 @@ def main():
         step()
         assert op.ok()
 
+    # ---- secondary (untimed for `value`): validation restricted to the compared points -----------
+    op.set_validate_arrived_only(True)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ok4 = op.ok()
+    torch.cuda.synchronize()
+    dt_arrived = time.perf_counter() - t1
+    op.set_validate_arrived_only(False)
+    assert ok4 and torch.equal(result, secrets)
+
     # ---- secondary (untimed for `value`): two independent opens in flight ------------------------
     # A party opens many share arrays concurrently (Mpc.open_share_array under asyncio); with a second plan
     # on a second stream consecutive opens overlap (kernel tails, the elementwise pass, and co-resident
@@ -441,6 +455,9 @@ def main():
                 "mulmod_per_s": world * mulmods_open * args.steps / dt,
                 "bit_exact_vs_secrets": True,
                 "matrix_core_path": bool(mfma),
+                "shares_per_s_per_gpu_validate_arrived_only": B * args.steps / dt_arrived,
+                "validate_arrived_only_note": "opt-in plan option: the guess is re-evaluated at the t compared points only (same accept/reject); "
+                                              "NOT the headline, which re-encodes all n rows like the reference",
                 "shares_per_s_per_gpu_two_opens_in_flight": (B * args.steps / dt_two) if dt_two else None,
                 "two_opens_in_flight_note": "same opens issued alternately on two streams with two plans (independent batches overlap); "
                                             "`value` is one open at a time on one stream",

@@ -144,12 +144,12 @@ int launch_decode_check(hb_ctx *ctx, const FastMatrix *dec, const FastMatrix *en
                         const int32_t *mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, int check_skip);
 
 // ---- third generation: int8 matrix-core mat-vec for small-entry matrices, hb_mfma.hip ----------
-int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t s);
+int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t s, const int32_t *rows = nullptr, int n_rows = 0);
 void mm8_free(Mm8Matrix *m);
 int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                int64_t C, hipStream_t s, uint32_t *copy_dst = nullptr, hb_view cpv = hb_view{0, 0}, int64_t copy_count = 0,
-               int copy_rows = 0);
+               int copy_rows = 0, const int32_t *check_rows_dev = nullptr);
 
 // dispatch on element width
 #define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                                                 const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
                                                 const int32_t *__restrict__ in_rows, int64_t in_count, int d,
                                                 uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
-                                                const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
+                                                const int32_t *__restrict__ check_mask, const int32_t *__restrict__ check_rows, int32_t *__restrict__ mismatch,
                                                 uint32_t *__restrict__ copy_dst, int64_t copy_sc, int64_t copy_sl, int64_t copy_count, int copy_rows,
                                                 int n_out, int n_rt, int tpw, int64_t n_chunks, int64_t n_units, BarrettParams bp) {
     extern __shared__ uint4 mm8_lds[];
@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     if (threadIdx.x < 32) { const int lc = (int)threadIdx.x < d ? (int)threadIdx.x : d - 1; rowl[threadIdx.x] = in_rows ? in_rows[lc] : lc; }
     int32_t *maskl = rowl + 32;   // CHECK: rows to compare
     if constexpr (CHECK) {
-        for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = (i < n_out) ? check_mask[i] : 0;
+        // maskl[i] != 0: compare output row i; with a row map (compact check matrices) it holds 1 + the row of the
+        // expected buffer that output i is compared with
+        for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = (i < n_out && check_mask[i]) ? (check_rows ? check_rows[i] + 1 : i + 1) : 0;
     }
     __syncthreads();
     const int n_slots = tpw * NKB * 2;
@@ -225,8 +227,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         bool cmp = false;
                         if constexpr (CHECK) {   // expected value: in flight while this output is reduced
                             const int i = 16 * rt + 4 * reg + g;
-                            cmp = (chunk < n_chunks) && maskl[i];
-                            if (cmp) load_words<8>(ew, out_pk + (obase + reg * ostep) * 8);
+                            const int erow = maskl[i];
+                            cmp = (chunk < n_chunks) && erow;
+                            if (cmp) load_words<8>(ew, out_pk + (chunk * out_sc + (int64_t)(erow - 1) * out_sl) * 8);
                         }
                         (void)ew; (void)cmp;
                         uint32_t w[MM8_CW];
@@ -400,18 +403,20 @@ void mm8_free(Mm8Matrix *m) {
 // Build the int8 operand image of a raw small-entry matrix (hb_fast.hip tables: canonical digits of
 // |M[i][l]| plus a per-row sign).  HB_ERR_UNSUPPORTED when the path does not apply: an entry of
 // 2^126 or more, more than 32 terms, a modulus outside [2^254, 2^256), or tables that exceed the LDS budget.
-int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t s) {
+int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t s, const int32_t *rows, int n_rows) {
     *out = nullptr;
     if (getenv("HB_NO_MFMA")) return HB_ERR_UNSUPPORTED;
     if (ctx->n_limbs != 4 || f->n_in < 1 || f->n_in > 32 || f->n_out < 1) return HB_ERR_UNSUPPORTED;
     if ((ctx->p_limbs[3] >> 62) == 0) return HB_ERR_UNSUPPORTED;      // Barrett constants assume 2^254 <= p
-    const int n_out = f->n_out, d = f->n_in, nkb = (d + 3) / 4, n_rt = (n_out + 15) / 16;
+    // rows != nullptr: the matrix made of rows[0 .. n_rows) of f (a compact check matrix)
+    const int n_out = rows ? n_rows : f->n_out, d = f->n_in, nkb = (d + 3) / 4, n_rt = (n_out + 15) / 16;
+    if (n_out < 1) return HB_ERR_UNSUPPORTED;
     const int tpw = (n_rt == 1) ? 4 : (n_rt == 2) ? 2 : 1;
     const size_t lds = ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 64 + (size_t)2 * tpw * nkb * 2 * 64) * 16 + 128 + (size_t)n_rt * 64;
     if (lds > 76 * 1024) return HB_ERR_UNSUPPORTED;
-    const int tiles = (n_out + f->ot - 1) / f->ot;
+    const int tiles = (f->n_out + f->ot - 1) / f->ot;
     std::vector<uint32_t> Mh((size_t)tiles * d * f->ot * 9);
-    std::vector<int32_t> neg((size_t)n_out, 0);
+    std::vector<int32_t> neg((size_t)f->n_out, 0);
     HB_HIP(ctx, hipMemcpyAsync(Mh.data(), f->M, Mh.size() * 4, hipMemcpyDeviceToHost, s));
     if (f->negrow) HB_HIP(ctx, hipMemcpyAsync(neg.data(), f->negrow, neg.size() * 4, hipMemcpyDeviceToHost, s));
     HB_HIP(ctx, hipStreamSynchronize(s));
@@ -431,12 +436,14 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     for (int i = 0; i < n_out; i++) {
         Big pos(5, 0), ngs(5, 0);   // sums of the positive / negated entries of the row (each < 32 * 2^127)
         int64_t colsum = 0;         // 128 * sum |digit| bounds every int32 column of this row
+        const int src = rows ? rows[i] : i;
+        if (src < 0 || src >= f->n_out) return HB_ERR_BAD_ARG;
         for (int l = 0; l < d; l++) {
             uint32_t dg[9], w8[8];
-            for (int q = 0; q < 9; q++) dg[q] = Mh[mf_index(i, l, d, 9, q, f->ot)];
+            for (int q = 0; q < 9; q++) dg[q] = Mh[mf_index(src, l, d, 9, q, f->ot)];
             pack<9, 8>(w8, dg);
             if (w8[4] | w8[5] | w8[6] | w8[7]) return HB_ERR_UNSUPPORTED;   // does not fit 16 balanced digits
-            const int sgn = neg[i] ? -1 : 1;
+            const int sgn = neg[src] ? -1 : 1;
             int carry = 0;
             int8_t *dst = &a[(((size_t)(i / 16) * nkb + l / 4) * 64 + (size_t)(4 * ((i % 16) % 4) + (i % 16) / 4) + 16 * (l % 4)) * 16];
             for (int b = 0; b < 16; b++) {
@@ -447,7 +454,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
             }
             if (carry) return HB_ERR_UNSUPPORTED;                           // |entry| >= 127 * 256^15 or so
             Big e(w8, w8 + 4);
-            big_add(neg[i] ? ngs : pos, e);
+            big_add(neg[src] ? ngs : pos, e);
         }
         if (colsum * 128 > MM8_BIAS) return HB_ERR_UNSUPPORTED;
         // corr = 0x80..80 * (pos - ngs) mod p  (the XOR-0x80 bias of the input bytes)
@@ -494,7 +501,8 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
 // CHECK mode can also hand rows < copy_rows of the input to copy_dst (view cpv, clipped at copy_count).
 int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-               int64_t C, hipStream_t s, uint32_t *copy_dst, hb_view cpv, int64_t copy_count, int copy_rows) {
+               int64_t C, hipStream_t s, uint32_t *copy_dst, hb_view cpv, int64_t copy_count, int copy_rows,
+               const int32_t *check_rows_dev) {
     if (C <= 0) return HB_OK;
     const int tpw = (m->n_rt == 1) ? 4 : (m->n_rt == 2) ? 2 : 1;
     const int64_t n_tiles = (C + 15) / 16;
@@ -515,7 +523,7 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
         }                                                                                                         \
         hipLaunchKernelGGL((k_mm8<NKB, CHK, RG>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, \
                            iv.stride_l, in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count,   \
-                           check_mask_dev, mismatch_dev, copy_dst, cpv.stride_c, cpv.stride_l, copy_count, copy_rows,         \
+                           check_mask_dev, check_rows_dev, mismatch_dev, copy_dst, cpv.stride_c, cpv.stride_l, copy_count, copy_rows,         \
                            m->n_out, m->n_rt, tpw, C, n_units, m->bp);             \
     } while (0)
 #define MM8_LAUNCH(NKB) do { if (check) MM8_LAUNCH_(NKB, true, false); else if (ragged) MM8_LAUNCH_(NKB, false, true); else MM8_LAUNCH_(NKB, false, false); } while (0)
@@ -558,5 +566,5 @@ extern "C" int hb_debug_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, in
                                   const int32_t *check_mask_dev, int32_t *mismatch_dev) {
     hb_view iv{in_sc, in_sl}, ov{out_sc, out_sl};
     return launch_mm8(ctx, (const Mm8Matrix *)mat, (const uint32_t *)in_dev, iv, nullptr, in_count, (uint32_t *)out_dev, ov, out_count,
-                      check_mask_dev, mismatch_dev, n_chunks, 0, nullptr, hb_view{0, 0}, 0, 0);
+                      check_mask_dev, mismatch_dev, n_chunks, 0, nullptr, hb_view{0, 0}, 0, 0, nullptr);
 }

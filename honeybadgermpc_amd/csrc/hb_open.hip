@@ -29,6 +29,9 @@ struct hb_open_plan {
     FastMatrix *V;       // n x d  raw Vandermonde at the n party points
     FastMatrix *Vinv;    // d x d  factored inverse for the arrival set z
     Mm8Matrix *V8;       // int8 matrix-core image of V (hb_mfma.hip); nullptr when that path does not apply
+    Mm8Matrix *Vzc8;     // rows zc of V only: the validating re-encode under HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY (built on demand)
+    int32_t *zc_dev, *ones_dev;   // its expected-row map and compare mask
+    std::vector<int32_t> zc;
     Mm8Matrix *Vinv8;    // same for the numerators N of the factored inverse (decode on the matrix cores); may be nullptr
     uint32_t *scaled_pk; // [d][max_C] received columns / den_j, the matrix-core decode's input
     int use_v8;          // option HB_OPEN_OPT_MATRIX_CORES (default 1)
@@ -55,7 +58,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     hb_open_plan *pl = new hb_open_plan();
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
-    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr; pl->V8 = nullptr; pl->Vinv8 = nullptr; pl->scaled_pk = nullptr; pl->use_v8 = 1;
+    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr; pl->V8 = nullptr; pl->Vzc8 = nullptr; pl->zc_dev = pl->ones_dev = nullptr; pl->Vinv8 = nullptr; pl->scaled_pk = nullptr; pl->use_v8 = 1;
     pl->validate_arrived_only = 0;
     pl->ntt_order = 0; pl->tw = nullptr;
     const int L = ctx->n_limbs;
@@ -81,6 +84,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     for (int j = 0; j < n_check; j++) {
         if (zc_host[j] < 0 || zc_host[j] >= n) { delete pl; return HB_ERR_BAD_ARG; }
         mask[zc_host[j]] = 1;
+        pl->zc.push_back(zc_host[j]);
     }
     rc = get_int_array(ctx, mask.data(), n + 1, &pl->mask_dev, s);
     if (rc) { delete pl; return rc; }
@@ -162,6 +166,10 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
                                 pl->coef_pk, pm, INT64_MAX, pl->d, 0, nullptr, nullptr, nullptr, C, s, 0, pl->Vinv->K2);
         }
         if (rc) return rc;
+        if (pl->validate_arrived_only && pl->Vzc8)
+            // option: evaluate the guess at the compared points only (a compact matrix of the rows zc of V)
+            return launch_mm8(pl->ctx, pl->Vzc8, pl->coef_pk, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm,
+                              INT64_MAX, pl->ones_dev, pl->mismatch_dev, C, s, pk_dst, pv, pk_count, pk_rows, pl->zc_dev);
         return launch_mm8(pl->ctx, pl->V8, pl->coef_pk, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm,
                           INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s, pk_dst, pv, pk_count, pk_rows);
     }
@@ -213,7 +221,22 @@ int hb_open_status(hb_open_plan *pl, void *stream) {
 
 int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
     if (!pl) return HB_ERR_BAD_ARG;
-    if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { pl->validate_arrived_only = value ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) {
+        pl->validate_arrived_only = value ? 1 : 0;
+        if (value && pl->V8 && !pl->Vzc8 && !pl->zc.empty()) {
+            // matrix-core path: a compact check matrix (the rows zc of V) compared with the received rows zc
+            int rc = mm8_from_fast(pl->ctx, pl->V, &pl->Vzc8, 0, pl->zc.data(), (int)pl->zc.size());
+            if (rc && rc != HB_ERR_UNSUPPORTED) return rc;
+            if (pl->Vzc8) {
+                std::vector<int32_t> ones(pl->zc.size() + 2, 1);
+                ones.back() = -2;   // keeps this array apart from other cached int arrays of the same length
+                rc = get_int_array(pl->ctx, pl->zc.data(), (int)pl->zc.size(), &pl->zc_dev, 0);
+                if (!rc) rc = get_int_array(pl->ctx, ones.data(), (int)ones.size(), &pl->ones_dev, 0);
+                if (rc) return rc;
+            }
+        }
+        return HB_OK;
+    }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { pl->use_v8 = value ? 1 : 0; return HB_OK; }
     return HB_ERR_BAD_ARG;
 }
@@ -229,7 +252,7 @@ void hb_open_plan_destroy(hb_open_plan *pl) {
     if (!pl) return;
     (void)hipFree(pl->in_dg); (void)hipFree(pl->coef_dg); if (pl->coef_pk) (void)hipFree(pl->coef_pk);
     (void)hipFree(pl->mismatch_dev);
-    fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8); mm8_free(pl->Vinv8);
+    fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8); mm8_free(pl->Vinv8); mm8_free(pl->Vzc8);
     if (pl->scaled_pk) (void)hipFree(pl->scaled_pk);
     delete pl;
 }
