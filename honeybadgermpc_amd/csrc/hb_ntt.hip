@@ -104,12 +104,26 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
     for (int s = 0; s < logn; s++) {
         const int h = 1 << s;
         const int tstride = half >> s;          // twiddle index step: n / (2h)
+        // Input pruning.  After s stages the block at positions [m 2^s, (m+1) 2^s) holds the sub-transform of the
+        // coefficients j = r (mod n / 2^s), r = bitrev(m); with only dd < n coefficients present it is identically zero
+        // when r >= dd.  The blocks of a stage are visited in bit-reversed order q (butterflies of a stage are
+        // independent), which makes that test monotone: the lower operand's class is r_v = nblk + q, so butterflies with
+        // q >= dd - nblk have v = 0 and degenerate to a copy (u, u) -- whole waves take one side of the branch.
+        const int lb = logn - s - 1, nblk = n >> (s + 1);
+        const int live = dd - nblk;             // blocks q < live have a non-zero lower operand
         for (int b = threadIdx.x; b < npoly * half; b += blockDim.x) {
             const int pl = b / half, bb = b % half;
             const int j = bb & (h - 1);
-            const int i0 = ((bb >> s) << (s + 1)) + j;
+            const int q = bb >> s;
+            const int m = lb > 0 ? (int)bitrev((uint32_t)q, lb) : 0;
+            const int i0 = (m << (s + 1)) + j;
             uint32_t *base = lds + (size_t)pl * n * NL;
-            butterfly<NL>(base + (size_t)i0 * NL, base + (size_t)(i0 + h) * NL, tw + (size_t)j * tstride * NL, j == 0, P);
+            if (q < live) {
+                butterfly<NL>(base + (size_t)i0 * NL, base + (size_t)(i0 + h) * NL, tw + (size_t)j * tstride * NL, j == 0, P);
+            } else {
+#pragma unroll
+                for (int qd = 0; qd < NL; qd++) base[(size_t)(i0 + h) * NL + qd] = base[(size_t)i0 * NL + qd];
+            }
         }
         __syncthreads();
     }
@@ -207,6 +221,8 @@ int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, h
     const size_t elem_lds = (size_t)ctx->nl() * 4;
     if ((size_t)n * elem_lds > 160 * 1024) return fail(ctx, HB_ERR_UNSUPPORTED, "ntt: order does not fit LDS");
     int PB = (int)((40 * 1024) / ((size_t)n * elem_lds)); if (PB < 1) PB = 1; if (PB > 64) PB = 64;
+    // whole rounds of butterflies: PB * n/2 a multiple of the 256 threads (17 polynomials of order 64 would run 3 rounds, the third 12 % full)
+    { const int q = n >= 2 ? 256 / (n / 2) : 1; if (q > 1 && PB > q) PB -= PB % q; }
     if ((int64_t)PB > C) PB = (int)C;
     const size_t lds = (size_t)PB * n * elem_lds;
     const int64_t blocks = (C + PB - 1) / PB;
