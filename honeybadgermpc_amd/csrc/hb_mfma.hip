@@ -38,6 +38,7 @@ constexpr int MM8_SD = 14;       // radix-2^29 digits of the carried sum (S < 2^
 
 struct BarrettParams {
     uint32_t pbar[9]; // 2^261 - p, digits
+    uint32_t pneg[8]; // 2^256 - p, 32-bit words
     uint32_t mu[6];   // floor(2^406 / p) digits
 };
 
@@ -70,6 +71,13 @@ constexpr int MM8_BIAS = 5800000;   // >= 128 * sum |digit| >= |column| (checked
 // (radix 2^29) before the Barrett reduction.
 // CHECK: out_pk holds the expected values; rows with check_mask[i] != 0 are compared, any difference
 // sets *mismatch (the validating re-encode of reed_solomon.py:316-326).
+#ifdef HB_MM8_TIMING
+// debug build only (scratch/mm8_phase_timing.py): per-wave cycle sums of the phases of a pass
+__device__ unsigned long long g_mm8_t[2048 * 8];
+#define MM8_T(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define MM8_T(k) do { } while (0)
+#endif
 template <int NKB, bool CHECK, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
                                                 const uint32_t *__restrict__ zero_src,
@@ -94,17 +102,45 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
 
     // l -> input row table (arrival order for decodes), clamped to d - 1
     int32_t *rowl = reinterpret_cast<int32_t *>(xbuf + 2 * bufsz);
-    if (threadIdx.x < 32) { const int lc = (int)threadIdx.x < d ? (int)threadIdx.x : d - 1; rowl[threadIdx.x] = in_rows ? in_rows[lc] : lc; }
-    int32_t *maskl = rowl + 32;   // CHECK: rows to compare
+    uint32_t *rowoff = reinterpret_cast<uint32_t *>(rowl + 32);   // byte offset of row l from the chunk's first element (fast DMA path)
+    if (threadIdx.x < 32) {
+        const int lc = (int)threadIdx.x < d ? (int)threadIdx.x : d - 1;
+        const int row = in_rows ? in_rows[lc] : lc;
+        rowl[threadIdx.x] = row;
+        rowoff[threadIdx.x] = (uint32_t)((int64_t)row * in_sl * 32);
+        int m = row;
+        for (int o = 16; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 32));
+        if (threadIdx.x == 0) rowl[64] = m;
+    }
+    int32_t *maskl = rowl + 96;   // CHECK: rows to compare
     if constexpr (CHECK) {
         // maskl[i] != 0: compare output row i; with a row map (compact check matrices) it holds 1 + the row of the
         // expected buffer that output i is compared with
         for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = (i < n_out && check_mask[i]) ? (check_rows ? check_rows[i] + 1 : i + 1) : 0;
     }
     __syncthreads();
+    const int rowmax = __builtin_amdgcn_readfirstlane(rowl[64]);
+    // interior units (every element present, offsets within 32 bits) take their addresses from one scalar base per slot
+    // plus a per-lane 32-bit offset: the general form below costs ~40 VALU instructions per slot
+    const bool fast_dma = in_sc >= 0 && in_sl >= 0 && in_count < (1ll << 27);
+    const uint32_t lane_off = (uint32_t)((int64_t)n * in_sc * 32);
     const int n_slots = tpw * NKB * 2;
     // slot s = (t * NKB + kb) * 2 + h, dealt round-robin to the 4 waves; all of it wave-uniform
     auto issue_loads = [&](int64_t unit, int buf) {
+        const int64_t c_last = (unit * tpw + tpw) * 16 - 1;
+        if (fast_dma && c_last < n_chunks && c_last * in_sc + (int64_t)rowmax * in_sl < in_count) {
+            for (int s = wave; s < n_slots; s += 4) {
+                const int h = s & 1, q = s >> 1, t = q / NKB, kb = q - t * NKB;
+                const uint64_t sbase = (uint64_t)(uintptr_t)in_pk + (uint64_t)((unit * tpw + t) * 16 * in_sc) * 32 + h * 16;
+                const uint32_t voff = lane_off + rowoff[4 * kb + g];
+                const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(xbuf + (size_t)buf * bufsz + s * 64));
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+            }
+            return;
+        }
         for (int s = wave; s < n_slots; s += 4) {
             const int h = s & 1, q = s >> 1, t = q / NKB, kb = q - t * NKB;
             int64_t chunk = (unit * tpw + t) * 16 + n;
@@ -127,16 +163,33 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
 
     int buf = 0;
     int64_t unit = blockIdx.x;
+#ifdef HB_MM8_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
     if (unit < n_units) issue_loads(unit, 0);
     // the constant tables ride behind the first unit's DMA instead of in front of it
-    for (int i = threadIdx.x; i < n_rt * 64; i += 256) mm8_lds[i] = reinterpret_cast<const uint4 *>(crowd)[i];
-    for (int i = threadIdx.x; i < n_rt * NKB * 64; i += 256) abuf[i] = a8[i];
+    // (crowd and the digits are adjacent in LDS; LDS-DMA like the elements, 1 KB per instruction, all in flight at once --
+    // a load / wait / ds_write loop cost one round trip per 4 KB, 3 us per launch)
+    {
+        const int n_cr = n_rt, n_blk = n_rt * (1 + NKB);      // in 64-lane blocks of uint4
+        for (int blk = wave; blk < n_blk; blk += 4) {
+            const uint4 *src = (blk < n_cr ? reinterpret_cast<const uint4 *>(crowd) + blk * 64
+                                           : reinterpret_cast<const uint4 *>(a8) + (blk - n_cr) * 64) + lane;
+            const uint32_t lds_dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(mm8_lds + blk * 64));
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    MM8_T(0);   // prologue
     for (; unit < n_units; unit += gridDim.x, buf ^= 1) {
         // every wave has waited for its share of this unit's DMA (below, before its epilogue) and is
         // done reading the other buffer; no vmcnt wait here, so the output stores stay in flight
         __builtin_amdgcn_s_barrier();
+        MM8_T(1);   // barrier wait
         if (unit + gridDim.x < n_units) issue_loads(unit + gridDim.x, buf ^ 1);
+        MM8_T(2);   // DMA issue
         if constexpr (CHECK) {
             // hand the caller its rows of the input (the decoded coefficients) in its own layout while they are in LDS
             if (copy_dst) {
@@ -173,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 __builtin_amdgcn_sched_barrier(0);
                 Mm8Phase<NKB, 0>::run(acc, xs_addr, as_addr, biasv);
                 __builtin_amdgcn_sched_barrier(0);
+                MM8_T(3);   // MFMA half 0
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {   // the accumulators die here
                     if (reg == 2 && !pair1) break;
@@ -190,11 +244,14 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 v4i acc[24];
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                MM8_T(4);   // parking of half 0
                 Mm8Phase<NKB, 1>::run(acc, xs_addr, as_addr, biasv);
                 __builtin_amdgcn_sched_barrier(0);
+                MM8_T(5);   // MFMA half 1
                 // next unit's DMA (issued a pass ago) must have landed before this wave reaches the barrier; waiting
                 // here, ahead of the epilogue, keeps this pass's output stores out of the wait
                 if (rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                MM8_T(6);   // wait for the next unit's DMA (and the previous pass's stores)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     if (reg == 2 && !pair1) break;
@@ -252,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                             sd[12] += c3v.x; sd[13] += c3v.y;
                         }
                         // Barrett.  S_hi = sum_{k>=8} digit_k 2^(29(k-8)) >= S / 2^232 - 2 (lazy low digits < 2^30),
-                        // mu > 2^406 / p - 1, and the three lowest product columns (< 2^120 in all) are dropped, so
-                        // S_hi mu / 2^174 > S/p - S/2^406 - 2^233/p - 2^-54 > S/p - 2^-10: qhat is floor(S/p) or one less.
+                        // mu > 2^406 / p - 1, and the four lowest product columns (10 terms < 2^59 2^(29 * 3): < 2^150 in all)
+                        // are dropped, so S_hi mu / 2^174 > S/p - S/2^406 - 2^233/p - 2^-24 > S/p - 2^-10: qhat is floor(S/p) or one less.
                         uint64_t pc[11];
 #pragma unroll
                         for (int k = 0; k < 11; k++) pc[k] = 0;
@@ -261,9 +318,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         for (int aa = 0; aa < 6; aa++)
 #pragma unroll
                             for (int bb = 0; bb < 6; bb++)
-                                if (aa + bb >= 3) pc[aa + bb] += (uint64_t)sd[8 + aa] * bp.mu[bb];
+                                if (aa + bb >= 4) pc[aa + bb] += (uint64_t)sd[8 + aa] * bp.mu[bb];
 #pragma unroll
-                        for (int k = 3; k < 10; k++) pc[k + 1] += pc[k] >> LB;
+                        for (int k = 4; k < 10; k++) pc[k + 1] += pc[k] >> LB;
                         uint32_t qd[5];
 #pragma unroll
                         for (int k = 0; k < 5; k++) qd[k] = (uint32_t)pc[6 + k] & (k < 4 ? DMASK : 0xffffffffu);
@@ -283,20 +340,17 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                             r[k] = (uint32_t)dc[k] & DMASK;
                             if (k < 8) dc[k + 1] += dc[k] >> LB;
                         }
-                        // r >= p  <=>  r + (2^261 - p) carries out of digit 8
-                        {
-                            uint32_t u[9], cy2 = 0;
-#pragma unroll
-                            for (int k = 0; k < 9; k++) {
-                                const uint32_t v = r[k] + bp.pbar[k] + cy2;
-                                u[k] = v & DMASK;
-                                cy2 = v >> LB;
-                            }
-#pragma unroll
-                            for (int k = 0; k < 9; k++) r[k] = cy2 ? u[k] : r[k];
-                        }
                         uint32_t ow[8];
                         pack<9, 8>(ow, r);
+                        // r < 2p < 2^256;  r >= p  <=>  r + (2^256 - p) carries out of word 7
+                        {
+                            uint32_t u[8];
+                            unsigned cy2 = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) u[k] = __builtin_addc(ow[k], bp.pneg[k], cy2, &cy2);
+#pragma unroll
+                            for (int k = 0; k < 8; k++) ow[k] = cy2 ? u[k] : ow[k];
+                        }
                         const int64_t oidx = obase + reg * ostep;
                         if constexpr (CHECK) {
                             if (cmp) {
@@ -315,8 +369,12 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                     if (reg & 1) __builtin_amdgcn_sched_barrier(0);   // two reductions at a time: ILP for the carry chains (measured: 1 -> 70.2, 2 -> 68.9, 4 -> 69.9+ us)
                 }
             }
+            MM8_T(7);   // word assembly + reduction + stores
         }
     }
+#ifdef HB_MM8_TIMING
+    if (lane == 0 && blockIdx.x < 512) for (int k = 0; k < 8; k++) g_mm8_t[(blockIdx.x * 4 + wave) * 8 + k] = tacc[k];
+#endif
 }
 
 }  // namespace hb
@@ -325,6 +383,12 @@ using namespace hb;
 
 // ---- host side -----------------------------------------------------------------------------------
 namespace {
+
+// dynamic LDS of k_mm8: row constants, matrix digits, two element buffers, then the int tables of the prologue
+// (rowl[32], rowoff[32], rowmax + padding [32], maskl[16 n_rt])
+size_t mm8_lds_bytes(int n_rt, int nkb, int tpw) {
+    return ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 64 + (size_t)2 * tpw * nkb * 2 * 64) * 16 + 96 * 4 + (size_t)n_rt * 16 * 4;
+}
 
 int mm8_num_cus() {
     static int n = 0;
@@ -412,7 +476,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     const int n_out = rows ? n_rows : f->n_out, d = f->n_in, nkb = (d + 3) / 4, n_rt = (n_out + 15) / 16;
     if (n_out < 1) return HB_ERR_UNSUPPORTED;
     const int tpw = (n_rt == 1) ? 4 : (n_rt == 2) ? 2 : 1;
-    const size_t lds = ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 64 + (size_t)2 * tpw * nkb * 2 * 64) * 16 + 128 + (size_t)n_rt * 64;
+    const size_t lds = mm8_lds_bytes(n_rt, nkb, tpw);
     if (lds > 76 * 1024) return HB_ERR_UNSUPPORTED;
     const int tiles = (f->n_out + f->ot - 1) / f->ot;
     std::vector<uint32_t> Mh((size_t)tiles * d * f->ot * 9);
@@ -481,6 +545,12 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
             m->bp.pbar[k] = (uint32_t)(v >> sft) & DMASK;
         }
     }
+    {   // 2^256 - p, 32-bit words
+        Big pn(9, 0); pn[8] = 1;
+        Big pw9(p); pw9.push_back(0);
+        big_sub(pn, pw9);
+        for (int k = 0; k < 8; k++) m->bp.pneg[k] = pn[k];
+    }
     for (int k = 0; k < 6; k++) {
         const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
         uint64_t v = mu[j] | ((uint64_t)(j + 1 < (int)mu.size() ? mu[j + 1] : 0) << 32);
@@ -510,7 +580,7 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
     int64_t blocks = 2 * (int64_t)mm8_num_cus();
     if (const char *e = getenv("HB_MM8_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) blocks = (int64_t)v * mm8_num_cus(); }   // experiment hook
     if (blocks > n_units) blocks = n_units;
-    const size_t lds = ((size_t)m->n_rt * 64 + (size_t)m->n_rt * m->nkb * 64 + (size_t)2 * tpw * m->nkb * 2 * 64) * 16 + 128 + (size_t)m->n_rt * 64;
+    const size_t lds = mm8_lds_bytes(m->n_rt, m->nkb, tpw);
     const bool check = check_mask_dev != nullptr;
     // the last row tile holds at most 8 rows: its outputs 2 and 3 are padding and their reduction can be skipped
     const bool ragged = !check && (m->n_out % 16) >= 1 && (m->n_out % 16) <= 8;
@@ -568,3 +638,9 @@ extern "C" int hb_debug_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, in
     return launch_mm8(ctx, (const Mm8Matrix *)mat, (const uint32_t *)in_dev, iv, nullptr, in_count, (uint32_t *)out_dev, ov, out_count,
                       check_mask_dev, mismatch_dev, n_chunks, 0, nullptr, hb_view{0, 0}, 0, 0, nullptr);
 }
+
+#ifdef HB_MM8_TIMING
+extern "C" int hb_debug_mm8_timing(unsigned long long *out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hb::g_mm8_t), sizeof(unsigned long long) * (size_t)count) == hipSuccess ? 0 : 1;
+}
+#endif
