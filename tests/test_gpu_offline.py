@@ -1,0 +1,178 @@
+"""
+GPU parity for the offline-phase encodes: honeybadgermpc_amd.offline and
+progs.triple_refinement against exact Python integers / the oracle.  Bit-exact.
+"""
+import asyncio
+import random
+
+import pytest
+
+import oracle
+from conftest import BLS
+
+pytestmark = pytest.mark.gpu
+
+P = BLS
+
+
+def lagrange_at_zero(points, values, p):
+    acc = 0
+    for i, (xi, yi) in enumerate(zip(points, values)):
+        num = den = 1
+        for j, xj in enumerate(points):
+            if j != i:
+                num = num * (-xj) % p
+                den = den * (xi - xj) % p
+        acc = (acc + yi * num * pow(den, -1, p)) % p
+    return acc
+
+
+def test_random_elements_uniform_range():
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.offline import random_elements
+
+    for p in (P, (1 << 255) - 19, (1 << 64) - 59, 13):
+        g = torch.Generator(device="cuda")
+        g.manual_seed(5)
+        vals = Context.get(p).download_ints(random_elements(p, 5000, g))
+        assert len(vals) == 5000 and all(0 <= v < p for v in vals)
+        if p > 1 << 60:
+            assert len(set(vals)) == 5000
+            assert max(vals) > p - p // 50 and min(vals) < p // 50     # both ends of the range are reached
+        else:
+            assert set(vals) == set(range(p))
+        g.manual_seed(5)
+        assert Context.get(p).download_ints(random_elements(p, 5000, g)) == vals   # reproducible from the seed
+
+
+@pytest.mark.parametrize("n, t, k", [(4, 1, 9), (7, 2, 50), (16, 5, 333), (64, 21, 100)])
+def test_share_dealer_vs_python_ints(n, t, k):
+    import torch
+
+    from honeybadgermpc_amd.offline import ShareDealer
+
+    rnd = random.Random(n * 100 + t)
+    dealer = ShareDealer(P, n, t, max_polys=k)
+    ctx = dealer.ctx
+    secrets = [rnd.randrange(P) for _ in range(k)]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    shares, coeffs = dealer.deal_secrets(ctx.upload_ints(secrets), g)
+    cf = ctx.download_ints(coeffs)
+    sh = ctx.download_ints(shares)
+    assert len(sh) == n * k and len(cf) == k * (t + 1)
+    assert [cf[j * (t + 1)] for j in range(k)] == secrets
+    # party-major: row i holds party i's share of every value; the oracle evaluates the same polynomials
+    want = oracle.vandermonde_batch_evaluate(list(range(1, n + 1)), [cf[j * (t + 1) : (j + 1) * (t + 1)] for j in range(k)], P)
+    for i in range(n):
+        assert sh[i * k : (i + 1) * k] == [want[j][i] for j in range(k)]
+    # any t + 1 parties reconstruct
+    parties = rnd.sample(range(n), t + 1)
+    for j in rnd.sample(range(k), min(k, 5)):
+        assert lagrange_at_zero([i + 1 for i in parties], [sh[i * k + j] for i in parties], P) == secrets[j]
+
+
+@pytest.mark.parametrize("n, t, k", [(4, 1, 6), (7, 2, 40), (16, 5, 64)])
+def test_hyperinvertible_refine_and_check(n, t, k):
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.offline import HyperInvertible
+
+    rnd = random.Random(n + 1000 * t)
+    ctx = Context.get(P)
+    hi = HyperInvertible(P, n)
+    received = [[rnd.randrange(P) for _ in range(k)] for _ in range(n)]          # [sender][value index]
+    out = ctx.download_ints(hi.refine(ctx.upload_ints([v for row in received for v in row])))
+    for i in range(n):
+        for j in range(k):
+            assert out[i * k + j] == sum(received[s][j] * pow(i + 1, s, P) for s in range(n)) % P
+    # the checkers' test: sharings of exact degree `deg` pass and yield their secrets; any other degree fails
+    for deg in (t, 2 * t):
+        polys = [[rnd.randrange(P) for _ in range(deg)] + [rnd.randrange(1, P)] for _ in range(k)]
+        shares = [[sum(c * pow(i + 1, e, P) for e, c in enumerate(poly)) % P for poly in polys] for i in range(n)]
+        flat = ctx.upload_ints([v for row in shares for v in row])
+        ok, secrets = hi.check(flat, deg)
+        assert ok and ctx.download_ints(secrets) == [poly[0] for poly in polys]
+        assert not hi.check(flat, deg + 1)[0]
+        if deg > 0:
+            assert not hi.check(flat, deg - 1)[0]
+        shares[rnd.randrange(n)][rnd.randrange(k)] ^= 1                            # one corrupted share raises the degree
+        assert not hi.check(ctx.upload_ints([v for row in shares for v in row]), deg)[0]
+
+
+class _Bus:
+    """In-process stand-in for the MPC runtime's open: collects every party's shares and interpolates at 0."""
+
+    def __init__(self, n, t, field):
+        self.n, self.t, self.field = n, t, field
+        self.pending = {}
+
+    async def open(self, open_id, party, values):
+        slot = self.pending.setdefault(open_id, {"shares": {}, "done": asyncio.get_running_loop().create_future()})
+        slot["shares"][party] = values
+        if len(slot["shares"]) == self.n:
+            p = self.field.modulus
+            parties = sorted(slot["shares"])[: self.t + 1]
+            pts = [i + 1 for i in parties]
+            res = [lagrange_at_zero(pts, [slot["shares"][i][j] for i in parties], p) for j in range(len(values))]
+            slot["done"].set_result([self.field(v) for v in res])
+        return await slot["done"]
+
+
+class _ShareArray:
+    def __init__(self, ctx, values):
+        self.ctx, self.values = ctx, [int(v) % ctx.field.modulus for v in values]
+
+    def __sub__(self, other):
+        p = self.ctx.field.modulus
+        return _ShareArray(self.ctx, [(a - b) % p for a, b in zip(self.values, other.values)])
+
+    def open(self):
+        self.ctx.opens += 1
+        return self.ctx.bus.open(self.ctx.opens, self.ctx.myid, self.values)
+
+
+class _Context:
+    def __init__(self, n, t, field, myid, bus):
+        self.N, self.t, self.field, self.myid, self.bus, self.opens = n, t, field, myid, bus, 0
+
+    def ShareArray(self, values):  # noqa: N802 (the reference's name)
+        return _ShareArray(self, values)
+
+
+@pytest.mark.parametrize("n, t, k", [(4, 1, 3), (4, 1, 4), (7, 2, 5), (7, 2, 7)])   # reference tests/progs/test_triple_refinement.py:9
+def test_triple_refinement(n, t, k):
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.progs.triple_refinement import refine_triples
+
+    rnd = random.Random(n * 10 + k)
+    field = GF(P)
+
+    def share(secret):
+        poly = [secret] + [rnd.randrange(P) for _ in range(t)]
+        return [sum(c * pow(i + 1, e, P) for e, c in enumerate(poly)) % P for i in range(n)]
+
+    triples = [(a, b, a * b % P) for a, b in ((rnd.randrange(P), rnd.randrange(P)) for _ in range(k))]
+    sh = [[share(v) for v in tr] for tr in triples]          # [triple][a|b|c][party]
+
+    async def main():
+        bus = _Bus(n, t, field)
+        ctxs = [_Context(n, t, field, i, bus) for i in range(n)]
+        return await asyncio.gather(*[
+            refine_triples(ctxs[i], [sh[j][0][i] for j in range(k)], [sh[j][1][i] for j in range(k)], [sh[j][2][i] for j in range(k)])
+            for i in range(n)
+        ])
+
+    outs = asyncio.run(main())                                 # [party] -> (p, q, pq) share lists
+    count = (k - 2 * t + 1) // 2
+    assert all(len(o[0]) == len(o[1]) == len(o[2]) == count for o in outs)
+    pts = list(range(1, t + 2))
+    for idx in range(count):
+        vals = [lagrange_at_zero(pts, [outs[i][part][idx] for i in range(t + 1)], P) for part in range(3)]
+        assert vals[0] * vals[1] % P == vals[2]
+        # the refined values are shared with degree t: every party's share lies on the same polynomial
+        for part in range(3):
+            for extra in range(t + 1, n):
+                sub = list(range(1, t + 1)) + [extra]
+                assert lagrange_at_zero([i + 1 for i in sub], [outs[i][part][idx] for i in sub], P) == vals[part]
