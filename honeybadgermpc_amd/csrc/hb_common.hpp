@@ -42,6 +42,14 @@ struct hb_matrix {
     bool cached;        // owned by the ctx cache: hb_matrix_destroy is a no-op
 };
 
+namespace hb {
+// constants of the table pre-scale (k_prescale_tab): 2^261 - p in digits, 2^256 - p in words, floor(2^290 / p) in digits
+struct PrescaleParams {
+    uint32_t pbar[9];
+    uint32_t pneg[8];
+    uint32_t m0, m1;
+};
+}
 struct hb_ctx {
     int device;
     int n_limbs;        // 1 or 4 (uint64 limbs per element at the ABI)
@@ -55,6 +63,8 @@ struct hb_ctx {
     std::map<std::string, hb::FastMatrix *> fcache;   // second-generation (raw small-entry) tables
     std::map<std::string, hb::Mm8Matrix *> m8cache;   // their int8 matrix-core images (nullptr: does not qualify)
     int32_t *flag_dev;                                // 64 status words
+    hb::PrescaleParams psc;                           // valid when psc_state == 1
+    int psc_state = 0;                                // 0 not computed yet, 1 valid, -1 modulus outside [2^254, 2^256)
     int elem_words() const { return n_limbs == 4 ? 8 : 2; }
     int nl() const { return n_limbs == 4 ? 9 : 3; }
 };
@@ -121,6 +131,7 @@ struct FastMatrix {
     uint32_t *K;        // [n_in][NL] pre-scale constants (canonical digits; used as a mont_mul factor)
     uint32_t *K2;       // factored inverses only: R^2 / den_j, the pre-scale that makes the outputs canonical (else nullptr)
     uint32_t *K1;       // factored inverses only: R / den_j, mont_mul(x, K1_j) = x / den_j (plain), for the matrix-core decode
+    uint32_t *KT;       // factored inverses, 9-digit contexts: [n_in][9][9] canonical digits of 2^(29 q) / den_j (table pre-scale)
 };
 // word index of digit q of raw matrix element (i, l): [tile][l][digit][ot], tile = i / ot
 __host__ __device__ inline size_t mf_index(int i, int l, int n_in, int nl, int q, int ot) {
@@ -144,6 +155,7 @@ int launch_decode_check(hb_ctx *ctx, const FastMatrix *dec, const FastMatrix *en
                         const int32_t *mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, int check_skip);
 
 // ---- third generation: int8 matrix-core mat-vec for small-entry matrices, hb_mfma.hip ----------
+bool prescale_params(hb_ctx *ctx);   // fills ctx->psc on first use; false when the table pre-scale does not apply
 int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t s, const int32_t *rows = nullptr, int n_rows = 0);
 void mm8_free(Mm8Matrix *m);
 int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,

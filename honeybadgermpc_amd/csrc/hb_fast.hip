@@ -90,6 +90,63 @@ __global__ void __launch_bounds__(256) k_prescale_pk(const FpParams<NL> P, const
     }
 }
 
+// The same pass without Montgomery arithmetic: x / den_l = sum_q x_q T_q with T_q = 2^(29 q) / den_l mod p tabulated per row
+// (uniform per block: scalar loads).  81 MADs give V < 9 2^29 p; the quotient floor(V / p) < 2^33 comes from the two top digits
+// and mu = floor(2^290 / p) (4 MADs), r = V + qhat (2^261 - p) mod 2^261 < 2p (17 MADs), one conditional subtraction on words.
+// 102 MADs against the 171 of mont_mul: the pass goes from VALU-bound to the rate of its traffic.
+__global__ void __launch_bounds__(256) k_prescale_tab(const PrescaleParams PP, const uint32_t *__restrict__ in, int64_t in_sc, int64_t in_sl,
+                                                      const int32_t *__restrict__ rows, int64_t in_count, const uint32_t *__restrict__ KT,
+                                                      int64_t C, uint32_t *__restrict__ out_pk) {
+    constexpr int NL = 9, NW = 8;
+    const int l = blockIdx.y;
+    const int row = rows ? rows[l] : l;
+    const uint32_t *__restrict__ T = KT + (size_t)l * (NL * NL);
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t idx = c * in_sc + (int64_t)row * in_sl;
+    const bool ok = c < C && idx < in_count;
+    uint32_t xw[NW], xd[NL];
+    load_words<NW>(xw, in + (ok ? idx : 0) * NW);
+    unpack<NL, NW>(xd, xw);
+    uint64_t col[NL + 1];
+#pragma unroll
+    for (int j = 0; j <= NL; j++) col[j] = 0;
+#pragma unroll
+    for (int q = 0; q < NL; q++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[j] += (uint64_t)xd[q] * T[q * NL + j];      // <= 9 products of 58 bits per column
+    uint32_t v[NL + 1];
+#pragma unroll
+    for (int k = 0; k < NL; k++) { v[k] = (uint32_t)col[k] & DMASK; col[k + 1] += col[k] >> LB; }
+    v[NL] = (uint32_t)col[NL];                                                        // V < 2^288: below 2^27
+    // qhat = floor(floor(V / 2^232) mu / 2^58) is floor(V / p) or one less (V / 2^290 + 2^232 / p < 0.3)
+    const uint64_t mid = (uint64_t)v[9] * PP.m0 + (uint64_t)v[8] * PP.m1 + (((uint64_t)v[8] * PP.m0) >> LB);
+    const uint64_t qh = (uint64_t)v[9] * PP.m1 + (mid >> LB);
+    const uint32_t q0 = (uint32_t)qh & DMASK, q1 = (uint32_t)(qh >> LB);
+    uint64_t dc[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        dc[k] = v[k] + (uint64_t)q0 * PP.pbar[k];
+        if (k > 0) dc[k] += (uint64_t)q1 * PP.pbar[k - 1];
+    }
+    uint32_t r[NL];
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+        r[k] = (uint32_t)dc[k] & DMASK;
+        if (k < NL - 1) dc[k + 1] += dc[k] >> LB;
+    }
+    uint32_t w[NW];
+    pack<NL, NW>(w, r);
+    {
+        uint32_t u[NW];
+        unsigned cy = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) u[k] = __builtin_addc(w[k], PP.pneg[k], cy, &cy);
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] = ok ? (cy ? u[k] : w[k]) : 0u;
+    }
+    if (c < C) store_words<NW>(out_pk + ((size_t)l * (size_t)C + (size_t)c) * NW, w);
+}
+
 // V[i][l] = x_i^l as raw canonical digits in kernel layout
 template <int NL, int NW>
 __global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uint32_t *__restrict__ x, int n, int d, uint32_t *__restrict__ M, int ot) {
@@ -111,7 +168,7 @@ __global__ void __launch_bounds__(64) k_vand_raw(const FpParams<NL> P, const uin
 // factored inverse Vandermonde: N (raw), negrow, K_j = R^3 / den_j.  One block, thread j owns point j.
 template <int NL, int NW>
 __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const uint32_t *__restrict__ x, int k, uint32_t *__restrict__ M,
-                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, uint32_t *__restrict__ K2, uint32_t *__restrict__ K1, int *__restrict__ singular, int ot) {
+                                                    int32_t *__restrict__ negrow, uint32_t *__restrict__ K, uint32_t *__restrict__ K2, uint32_t *__restrict__ K1, uint32_t *__restrict__ KT, int *__restrict__ singular, int ot) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *xs = smem;
     uint32_t *B0 = xs + (size_t)k * NL;
@@ -180,6 +237,19 @@ __global__ void __launch_bounds__(1024) k_vinv_fact(const FpParams<NL> P, const 
     mont_mul(t2, t1, P.r2, P);                 // R^3 / den   (canonical digits; mont_mul(y, .) = y R^2 / den)
 #pragma unroll
     for (int w = 0; w < NL; w++) { K[(size_t)t * NL + w] = t2[w]; K2[(size_t)t * NL + w] = t1[w]; K1[(size_t)t * NL + w] = dinv[w]; }   // K2: canonical outputs; K1: x -> x / den
+    if (KT) {   // KT[t][q] = 2^(29 q) / den, canonical: x / den = sum_q x_q KT[t][q] without a Montgomery pass (k_prescale_tab)
+        uint32_t tq[NL], two29[NL], c29[NL];
+#pragma unroll
+        for (int w = 0; w < NL; w++) two29[w] = (w == 1) ? 1u : 0u;
+        to_mont(c29, two29, P);
+        from_mont(tq, dinv, P);
+        for (int q = 0; q < NL; q++) {
+            for (int w = 0; w < NL; w++) KT[((size_t)t * NL + q) * NL + w] = tq[w];
+            uint32_t nx2[NL];
+            mont_mul(nx2, tq, c29, P);
+            fp_set(tq, nx2);
+        }
+    }
 }
 
 // nd[tile][l] = 1 + index of the highest non-zero digit over the tile's OT outputs (0 if all zero)
@@ -509,6 +579,7 @@ void fast_matrix_free(FastMatrix *m) {
     if (m->K) (void)hipFree(m->K);
     if (m->K2) (void)hipFree(m->K2);
     if (m->K1) (void)hipFree(m->K1);
+    if (m->KT) (void)hipFree(m->KT);
     delete m;
 }
 
@@ -542,7 +613,7 @@ static int count_digits(hb_ctx *ctx, FastMatrix *m, hipStream_t s) {
 // raw Vandermonde n x d at device points, K = R^2 for every term (outputs canonical)
 int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatrix **out, hipStream_t s) {
     FastMatrix *m = new FastMatrix();
-    m->n_out = n; m->n_in = d; m->negrow = nullptr; m->K = nullptr; m->K2 = nullptr; m->K1 = nullptr; m->nd = nullptr;
+    m->n_out = n; m->n_in = d; m->negrow = nullptr; m->K = nullptr; m->K2 = nullptr; m->K1 = nullptr; m->KT = nullptr; m->nd = nullptr;
     m->ot = pick_ot(ctx, d);
     const int NLr = ctx->nl();
     size_t words = (size_t)f_tiles(n, m->ot) * d * m->ot * NLr; if (!words) words = 1;
@@ -569,7 +640,7 @@ int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatri
 int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out, hipStream_t s) {
     if (k > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "vandermonde inverse: k > 1023");
     FastMatrix *m = new FastMatrix();
-    m->n_out = k; m->n_in = k; m->nd = nullptr; m->K2 = nullptr; m->K1 = nullptr;
+    m->n_out = k; m->n_in = k; m->nd = nullptr; m->K2 = nullptr; m->K1 = nullptr; m->KT = nullptr;
     m->ot = pick_ot(ctx, k);
     const int NLr = ctx->nl();
     size_t words = (size_t)f_tiles(k, m->ot) * k * m->ot * NLr; if (!words) words = 1;
@@ -579,6 +650,8 @@ int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out
     HB_HIP(ctx, hipMalloc(&m->K, (size_t)(k > 0 ? k : 1) * NLr * 4));
     HB_HIP(ctx, hipMalloc(&m->K2, (size_t)(k > 0 ? k : 1) * NLr * 4));
     HB_HIP(ctx, hipMalloc(&m->K1, (size_t)(k > 0 ? k : 1) * NLr * 4));
+    m->KT = nullptr;
+    if (NLr == 9) HB_HIP(ctx, hipMalloc(&m->KT, (size_t)(k > 0 ? k : 1) * 81 * 4));
     int singular = 0;
     if (k > 0) {
         HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), s));
@@ -586,10 +659,10 @@ int fast_vinv_create(hb_ctx *ctx, const uint32_t *x_dev, int k, FastMatrix **out
         size_t lds = (size_t)(k + 2 * (k + 1)) * NLr * 4;
         if (ctx->n_limbs == 4) {
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, m->K2, m->K1, ctx->flag_dev, m->ot);
+            k_vinv_fact<9, 8><<<1, threads, lds, s>>>(ctx->pw, x_dev, k, m->M, m->negrow, m->K, m->K2, m->K1, m->KT, ctx->flag_dev, m->ot);
         } else {
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_vinv_fact<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, m->K2, m->K1, ctx->flag_dev, m->ot);
+            k_vinv_fact<3, 2><<<1, threads, lds, s>>>(ctx->pn, x_dev, k, m->M, m->negrow, m->K, m->K2, m->K1, m->KT, ctx->flag_dev, m->ot);
         }
         HB_LAUNCH_CHECK(ctx);
         HB_HIP(ctx, hipMemcpyAsync(&singular, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -622,7 +695,9 @@ int launch_prescale_pk(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_
     int ept = 1;   // measured on config 3: 19.6 / 20.1 / 23.0 us for 1 / 2 / 4 elements per thread
     if (const char *e = getenv("HB_PRESCALE_EPT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) ept = v; }   // tuning hook
     dim3 grid((unsigned)((C + 256 * ept - 1) / (256 * ept)), (unsigned)m->n_in);
-    if (ctx->n_limbs == 4) {
+    if (ctx->n_limbs == 4 && m->KT && !getenv("HB_PRESCALE_MONT") && prescale_params(ctx)) {
+        k_prescale_tab<<<dim3((unsigned)((C + 255) / 256), (unsigned)m->n_in), 256, 0, s>>>(ctx->psc, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->KT, C, out_pk);
+    } else if (ctx->n_limbs == 4) {
         if (ept == 1) k_prescale_pk<9, 8, 1><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
         else if (ept == 2) k_prescale_pk<9, 8, 2><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
         else k_prescale_pk<9, 8, 4><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);

@@ -458,6 +458,32 @@ Big big_shl(const Big &a, int bits, size_t words) {
 
 namespace hb {
 
+bool prescale_params(hb_ctx *ctx) {
+    if (ctx->psc_state) return ctx->psc_state > 0;
+    ctx->psc_state = -1;
+    if (ctx->n_limbs != 4 || (ctx->p_limbs[3] >> 62) == 0) return false;       // 2^254 <= p is what the quotient bound assumes
+    Big p(8);
+    for (int i = 0; i < 4; i++) { p[2 * i] = (uint32_t)ctx->p_limbs[i]; p[2 * i + 1] = (uint32_t)(ctx->p_limbs[i] >> 32); }
+    Big pw9(p); pw9.push_back(0);
+    Big pb(9, 0); pb[8] = 1u << 5;            // 2^261
+    big_sub(pb, pw9);
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
+        const uint64_t v = pb[j] | ((uint64_t)(j + 1 < 9 ? pb[j + 1] : 0) << 32);
+        ctx->psc.pbar[k] = (uint32_t)(v >> sft) & DMASK;
+    }
+    Big pn(9, 0); pn[8] = 1;                   // 2^256
+    big_sub(pn, pw9);
+    for (int k = 0; k < 8; k++) ctx->psc.pneg[k] = pn[k];
+    Big two290(10, 0); two290[9] = 1u << 2;    // 2^290
+    Big mu; big_divmod(two290, p, &mu);        // < 2^37
+    const uint64_t muv = mu[0] | ((uint64_t)mu[1] << 32);
+    ctx->psc.m0 = (uint32_t)muv & DMASK;
+    ctx->psc.m1 = (uint32_t)(muv >> LB);
+    ctx->psc_state = 1;
+    return true;
+}
+
 void mm8_free(Mm8Matrix *m) {
     if (!m) return;
     (void)hipFree(m->a8); (void)hipFree(m->crow); (void)hipFree(m->zero);
