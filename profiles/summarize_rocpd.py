@@ -16,10 +16,13 @@ def short(name):
 
 def main(path):
     db = sqlite3.connect(path)
-    rows = db.execute("select name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, duration from kernels").fetchall()
+    rows = db.execute("select name, grid_x, workgroup_x, vgpr_count, accum_vgpr_count, sgpr_count, lds_size, duration, stream_id from kernels").fetchall()
+    main_stream = min(r[8] for r in rows) if rows else 0
     groups = {}
-    for name, gx, wx, vg, av, sg, lds, dur in rows:
-        groups.setdefault((short(name), gx, wx, vg, av, sg, lds), []).append(dur)
+    for name, gx, wx, vg, av, sg, lds, dur, stream in rows:
+        # launches on the secondary streams (bench.py's two-opens-in-flight loop) share the GPU with each other: kept apart
+        tag = "" if stream == main_stream else " [2 streams]"
+        groups.setdefault((short(name) + tag, gx, wx, vg, av, sg, lds), []).append(dur)
     # a kernel launched with the same geometry for different jobs (encode vs decode) is split where its
     # durations are clearly bimodal
     split = {}
