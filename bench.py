@@ -443,7 +443,7 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes_enc, "avg_launch_ms": enc_ms,
                 "copy_GBps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
                 "note": ("neither HBM nor the matrix pipe binds: per 16x16 tile 47 int32 columns x (d/4) MFMAs are followed by a 390-bit "
-                         "reduction + Barrett per output on the VALU (~1740 VALU ops per wave pass, VALU ~68% busy, matrix pipe ~39% busy by PMC); "
+                         "reduction + Barrett per output on the VALU (~1550 VALU ops per wave pass, VALU ~67% busy, matrix pipe ~41% busy by PMC); "
                          if mfma else
                          "integer-ALU bound by construction (~840 VALU instructions per 32-byte output, VALU ~76% busy by PMC); ") +
                         "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md",
