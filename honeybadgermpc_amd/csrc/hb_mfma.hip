@@ -24,8 +24,8 @@
 //
 // Epilogue per output: 47 int32 columns -> pairs E = col + col' 2^8 (< 2^32) -> 13 words by one
 // add-with-carry each -> 14 radix-2^29 digits + row constant -> Barrett (quotient from the top 6
-// digits x mu, 30 + 35 v_mad_u64_u32) -> one conditional subtraction -> packed 4 x u64.  No
-// Montgomery form anywhere on this path.
+// digits x mu, 26 + 35 v_mad_u64_u32) -> packed 4 x u64 -> one conditional subtraction on the words.
+// No Montgomery form anywhere on this path.
 #include "hb_common.hpp"
 
 namespace hb {
