@@ -191,3 +191,163 @@ class BatchOpenPipeline:
             with lane.on_stream():
                 res = lane.op.ok() and res
         return res
+
+
+class DeviceIncrementalDecoder:
+    """IncrementalDecoder (reference reed_solomon.py:232-403) on device tensors: columns arrive as (C, 4) limb
+    tensors and stay in HBM; the guess, its validation and the robust fallback are launches over all C
+    polynomials.  Same state machine and the same decisions as `reed_solomon.IncrementalDecoder` with the Gao
+    robust decoder (what batch_reconstruct uses, batch_reconstruction.py:85-90):
+
+      * degree+1 columns: optimistic decode + re-encode (the guess);
+      * every later column is compared with its row of the guess; degree+1+max_errors-|confirmed| agreeing
+        columns finish the batch;
+      * the first disagreement switches to robust mode for good: every remaining polynomial is Gao-decoded over
+        the current arrival set in one launch, polynomials are accepted in order, and the first one that
+        confirms erroneous senders drops their columns and has the rest decoded again (reference :334-365).
+
+    get_results() -> ((C, degree+1, 4) coefficient tensor, set of confirmed erroneous senders) or (None, None).
+    """
+
+    def __init__(self, modulus, n, t, degree=None, batch_size=1, use_omega_powers=False, confirmed_errors=None, device=None):
+        from .field import GF
+        from .polynomial import EvalPoint
+
+        self.ctx = ctx = Context.get(modulus, device)
+        self.n, self.max_errors = n, t
+        self.degree = t if degree is None else degree
+        self.batch_size = int(batch_size)
+        point = EvalPoint(GF(modulus), n, use_omega_powers=use_omega_powers)
+        self.x = [point(i).value for i in range(n)]
+        self._xh_all = ctx.host_elems(self.x)
+        self._cols = ctx.empty(n * self.batch_size).view(n, self.batch_size, 4)
+        self._confirmed_errors = set() if confirmed_errors is None else confirmed_errors
+        self._available_points = set()
+        self._z = []
+        self._optimistic = True
+        self._guess_decoded = None      # (C, d, 4)
+        self._guess_encoded = None      # (n, C, 4)
+        self._num_decoded = 0
+        self._partial = ctx.empty(self.batch_size * (self.degree + 1)).view(self.batch_size, self.degree + 1, 4)
+        self._result = None
+        self.launches = 0               # robust-decode launches so far (diagnostic)
+
+    # -- kernels ---------------------------------------------------------------------------------
+    def _rows(self, lo):
+        """the arrived columns of polynomials lo.. as (C - lo, npts, 4), one codeword per row"""
+        idx = self.ctx.torch.tensor(self._z, dtype=self.ctx.torch.int64, device=self.ctx.tdev)
+        return self._cols.index_select(0, idx)[:, lo:, :].transpose(0, 1).contiguous()
+
+    def _decode_and_encode(self):
+        ctx, c, d, n = self.ctx, self.batch_size, self.degree + 1, self.n
+        rows = self._rows(0)
+        dec = ctx.empty(c * d)
+        xz = ctx.host_elems([self.x[i] for i in self._z])
+        ctx.check(ctx.lib.hb_vandermonde_batch_interpolate(ctx.h, np_ptr(xz), d, ctx.ptr(rows), c, ctx.ptr(dec), ctx.stream()), "interpolate")
+        enc = ctx.empty(c * n)
+        ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), n, ctx.ptr(dec), c, d, ctx.ptr(enc), ctx.stream()), "evaluate")
+        self._guess_decoded = dec.view(c, d, 4)
+        self._guess_encoded = enc.view(c, n, 4).transpose(0, 1).contiguous()
+
+    def _robust_batch(self, limit=None):
+        """Gao over the remaining polynomials (the first `limit` of them) and the current arrival set:
+        -> ok (Crem,) bool, coeffs (Crem, d, 4), errs (Crem, n) bool: the senders the error locator points at."""
+        ctx, t = self.ctx, self.ctx.torch
+        lo, d, n, npts = self._num_decoded, self.degree + 1, self.n, len(self._z)
+        crem = self.batch_size - lo if limit is None else min(limit, self.batch_size - lo)
+        rows = self._rows(lo)[:crem].contiguous()
+        co = ctx.empty(crem * d)
+        el = t.zeros((crem * (npts + 1), 4), dtype=t.int64, device=ctx.tdev)
+        ln = t.zeros(crem, dtype=t.int32, device=ctx.tdev)
+        ok = t.zeros(crem, dtype=t.uint8, device=ctx.tdev)
+        xz = ctx.host_elems([self.x[i] for i in self._z])
+        ctx.check(ctx.lib.hb_gao_decode(ctx.h, np_ptr(xz), npts, d, ctx.ptr(rows), crem, ctx.ptr(co), ctx.ptr(el), ctx.ptr(ln), ctx.ptr(ok), ctx.stream()), "gao")
+        self.launches += 1
+        ok = ok.bool()
+        # roots of the error locator among ALL party points are the faulty senders (reference :174-184); a locator of
+        # length <= 1 names nobody.  Entries past the locator's length are not part of it.
+        keep = t.arange(npts + 1, device=ctx.tdev).unsqueeze(0) < ln.unsqueeze(1)
+        el = (el.view(crem, npts + 1, 4) * keep.unsqueeze(2)).contiguous()
+        ev = ctx.empty(crem * n)
+        ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), n, ctx.ptr(el), crem, npts + 1, ctx.ptr(ev), ctx.stream()), "evaluate")
+        errs = (ev.view(crem, n, 4) == 0).all(dim=2) & (ln > 1).unsqueeze(1) & ok.unsqueeze(1)
+        return ok, co.view(crem, d, 4), errs
+
+    # -- the state machine (reference :288-372) ------------------------------------------------------
+    def _min_points_required(self):
+        return self.degree + 1 + self.max_errors - len(self._confirmed_errors)
+
+    def _optimistic_update(self, idx):
+        agree = True
+        if len(self._available_points) == self.degree + 1:
+            self._decode_and_encode()
+        else:
+            agree = bool(self.ctx.torch.equal(self._cols[idx], self._guess_encoded[idx]))
+            if not agree:
+                self._guess_decoded = self._guess_encoded = None
+                self._optimistic = False
+        if agree and len(self._available_points) >= self._min_points_required():
+            self._result = self._guess_decoded
+        return agree
+
+    def _robust_update(self):
+        t = self.ctx.torch
+        while self._num_decoded < self.batch_size:
+            # the reference's next robust_decode, alone: while it stalls (undecodable, or too few points once its errors
+            # are dropped) nothing else can be accepted either, and an arrival costs one codeword instead of all of them
+            ok, coeffs, errs = self._robust_batch(1)
+            if not bool(ok[0].item()):
+                return
+            if len(self._available_points) - int(errs[0].sum().item()) < self._min_points_required():
+                return
+            ok, coeffs, errs = self._robust_batch()
+            has_err = errs.any(dim=1)
+            stop = (~ok) | has_err                       # the first polynomial that is not a plain accept
+            first = int(t.nonzero(stop)[0].item()) if bool(stop.any().item()) else int(ok.shape[0])
+            if len(self._available_points) < self._min_points_required():
+                return                                   # even an error-free polynomial cannot be accepted yet
+            if first:                                    # error-free polynomials before it: accepted as they are
+                self._partial[self._num_decoded : self._num_decoded + first] = coeffs[:first]
+                self._num_decoded += first
+            if first == ok.shape[0]:
+                break
+            if not bool(ok[first].item()):
+                return                                   # (None, None): more columns needed
+            errors = [i for i in t.nonzero(errs[first]).flatten().tolist()]
+            if len(self._available_points) - len(errors) < self._min_points_required():
+                return
+            self._partial[self._num_decoded] = coeffs[first]
+            self._num_decoded += 1
+            self._confirmed_errors |= set(errors)
+            self._available_points -= set(errors)
+            self._z = [i for i in self._z if i not in errors]
+        if self._num_decoded == self.batch_size:
+            self._result = self._partial
+
+    def add(self, idx, column):
+        """column: (C, 4) limb tensor on the device, or a list of C ints."""
+        if self.done() or idx in self._available_points or idx in self._confirmed_errors:
+            return
+        if not hasattr(column, "shape"):
+            if len(column) != self.batch_size:
+                raise ValueError("Incorrect length of data")
+            column = self.ctx.upload_ints(column)
+        if tuple(column.shape) != (self.batch_size, 4):
+            raise ValueError("Incorrect length of data")
+        self._available_points.add(idx)
+        self._z.append(idx)
+        self._cols[idx] = column
+        if len(self._available_points) <= self.degree:
+            return
+        if self._optimistic and self._optimistic_update(idx):
+            return
+        if len(self._available_points) >= self._min_points_required():
+            self._robust_update()
+
+    def done(self):
+        return self._result is not None
+
+    def get_results(self):
+        if self._result is not None:
+            return self._result, self._confirmed_errors
+        return None, None

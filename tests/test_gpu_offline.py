@@ -176,3 +176,51 @@ def test_triple_refinement(n, t, k):
             for extra in range(t + 1, n):
                 sub = list(range(1, t + 1)) + [extra]
                 assert lagrange_at_zero([i + 1 for i in sub], [outs[i][part][idx] for i in sub], P) == vals[part]
+
+
+# ---- device-resident IncrementalDecoder against the host mirror of the reference's ----------
+@pytest.mark.parametrize("n, t, c, seed", [(4, 1, 1, 1), (4, 1, 7, 2), (7, 2, 5, 3), (7, 2, 40, 4), (10, 3, 33, 5), (16, 5, 64, 6), (16, 5, 9, 7), (13, 4, 300, 8)])
+def test_device_incremental_decoder_trajectory(n, t, c, seed):
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+    from honeybadgermpc_amd.reed_solomon import Algorithm, DecoderFactory, EncoderFactory, IncrementalDecoder, RobustDecoderFactory
+
+    rnd = random.Random(seed)
+    ctx = Context.get(P)
+    point = EvalPoint(GF(P), n, use_omega_powers=False)
+    robust_launches = 0
+    for trial in range(6):
+        polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+        cols = [[sum(co * pow(i + 1, e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+        liars = rnd.sample(range(n), rnd.randrange(trial % 2, t + 1))         # odd trials: at least one liar
+        for i in liars:
+            kind = rnd.randrange(4)
+            hit = {0: range(c), 1: [c - 1], 2: [rnd.randrange(c)], 3: rnd.sample(range(c), max(1, c // 3))}[kind]
+            for j in hit:
+                cols[i][j] = (cols[i][j] + 1 + rnd.randrange(P - 1)) % P
+        order = list(range(n))
+        rnd.shuffle(order)
+        if trial % 2:                                   # ... who is among the first arrivals, so that it cannot be missed
+            order.remove(liars[0])
+            order.insert(rnd.randrange(0, t + 1), liars[0])
+        host = IncrementalDecoder(EncoderFactory.get(point, Algorithm.VANDERMONDE), DecoderFactory.get(point, Algorithm.VANDERMONDE),
+                                  RobustDecoderFactory.get(t, point, algorithm=Algorithm.GAO), degree=t, batch_size=c, max_errors=t)
+        dev = DeviceIncrementalDecoder(P, n, t, batch_size=c)
+        for step, idx in enumerate(order):
+            host.add(idx, cols[idx])
+            dev.add(idx, ctx.upload_ints(cols[idx]) if step % 2 else list(cols[idx]))
+            assert dev.done() == host.done(), (trial, step)
+            assert dev._confirmed_errors == host._confirmed_errors, (trial, step)
+            assert dev._z == host._z and dev._num_decoded == host._num_decoded, (trial, step)
+            if host.done():
+                hres, herr = host.get_results()
+                dres, derr = dev.get_results()
+                assert derr == herr
+                assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in hres for v in row]
+                assert [list(r) for r in hres] == polys            # and both recovered what was shared
+                break
+        assert host.done() and set(host.get_results()[1]) <= set(liars)
+        robust_launches += dev.launches
+    assert robust_launches > 0          # the seeds above all reach the robust path at least once
