@@ -66,3 +66,87 @@ def wire_to_tensor(blob, device=None):
     a = unpack_limbs(blob)
     t = torch.from_numpy(a.view(np.int64).copy())
     return t.to(device) if device is not None else t
+
+
+# ---- share files (reference preprocessing.py:106-169) -----------------------------------------------
+# The reference's `.share` file is decimal text, one integer per line: modulus, degree, party id, then the
+# values.  read_share_file / write_share_file speak that format (interoperability with files the reference's
+# dealer wrote); the *_packed variants keep the three metadata fields but store the values in the kernels' layout,
+# so that a file is read straight into a device buffer.
+SHARE_MAGIC = b"HBSH"
+SHARE_HEADER = struct.Struct("<4sI32sqq")       # magic, limbs, modulus (32 bytes LE), degree, party id
+
+
+def share_filename(prefix, n, t, context_id):
+    """reference build_filename (preprocessing.py:150-169)"""
+    return f"{prefix}_{n}_{t}-{context_id}.share"
+
+
+def write_share_file(file_name, modulus, degree, context_id, values, append=False):
+    """The reference's text format (preprocessing.py:125-148), including its append rule: appending to an existing file
+    requires identical metadata; appending to a missing file creates it."""
+    import os
+
+    if not os.path.isfile(file_name):
+        append = False
+    if append:
+        with open(file_name, "r") as f:
+            meta = tuple(int(f.readline()) for _ in range(3))
+        expected = (modulus, degree, context_id)
+        assert meta == expected, f"File {file_name} expected to have metadata {expected}, but had {meta}"
+    with open(file_name, "a" if append else "w") as f:
+        if not append:
+            print(modulus, degree, context_id, file=f, sep="\n")
+        print(*values, file=f, sep="\n")
+
+
+def read_share_file(file_name, modulus):
+    """-> (degree, context_id, values) from the reference's text format (preprocessing.py:106-123)."""
+    with open(file_name, "r") as f:
+        values = list(map(int, f.read().splitlines()))
+    assert len(values) >= 3
+    assert values[0] == modulus, f"Expected file to have modulus {modulus}, but found {values[0]}"
+    return values[1], values[2], values[3:]
+
+
+def write_share_file_packed(file_name, modulus, degree, context_id, limbs, append=False):
+    """limbs: (count, 4) uint64 ndarray or int64 tensor (any device).  Same metadata and append rule as the text format."""
+    import os
+
+    if hasattr(limbs, "detach"):
+        limbs = limbs.detach().cpu().numpy().view(np.uint64)
+    a = np.ascontiguousarray(limbs, dtype=np.uint64)
+    if a.ndim != 2:
+        raise ValueError("expected a (count, limbs) array")
+    header = SHARE_HEADER.pack(SHARE_MAGIC, a.shape[1], int(modulus).to_bytes(32, "little"), degree, context_id)
+    if not os.path.isfile(file_name):
+        append = False
+    if append:
+        with open(file_name, "rb") as f:
+            have = f.read(SHARE_HEADER.size)
+        assert have == header, f"File {file_name} has different metadata"
+    with open(file_name, "ab" if append else "wb") as f:
+        if not append:
+            f.write(header)
+        f.write(a.tobytes())
+
+
+def read_share_file_packed(file_name, modulus, device=None):
+    """-> (degree, context_id, limbs); limbs is a (count, n_limbs) uint64 ndarray, or an int64 tensor on `device`."""
+    with open(file_name, "rb") as f:
+        blob = f.read()
+    if len(blob) < SHARE_HEADER.size:
+        raise ValueError("truncated share file")
+    magic, limbs, mod, degree, context_id = SHARE_HEADER.unpack_from(blob, 0)
+    if magic != SHARE_MAGIC or limbs not in (1, 4):
+        raise ValueError("not a packed share file")
+    assert int.from_bytes(mod, "little") == modulus, f"Expected file to have modulus {modulus}"
+    body = len(blob) - SHARE_HEADER.size
+    if body % (limbs * 8):
+        raise ValueError("share file length is not a whole number of elements")
+    a = np.frombuffer(blob, dtype=np.uint64, offset=SHARE_HEADER.size).reshape(-1, limbs)
+    if device is None:
+        return degree, context_id, a
+    import torch
+
+    return degree, context_id, torch.from_numpy(a.view(np.int64).copy()).to(device)

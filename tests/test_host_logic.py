@@ -485,3 +485,45 @@ def test_random_refinement(backend, n, t, k):  # reference tests/progs/test_rand
         for j in range(k - t):
             got = poly.interpolate_at([(point(i), fp(refined[i][j])) for i in subset], 0)
             assert got == want[j]
+
+
+def test_share_files_text_and_packed(tmp_path):
+    """reference preprocessing.py:106-169: the text format (round trip, append rule, metadata checks) and its packed twin."""
+    import random
+
+    from honeybadgermpc_amd import wire
+    from honeybadgermpc_amd._capi import ints_to_limbs, limbs_to_ints
+
+    rnd = random.Random(3)
+    vals = [rnd.randrange(BLS) for _ in range(50)] + [0, 1, BLS - 1]
+    name = wire.share_filename(str(tmp_path / "triples"), 4, 1, 2)
+    assert name.endswith("triples_4_1-2.share")
+    wire.write_share_file(name, BLS, 1, 2, vals[:20])
+    lines = open(name).read().splitlines()
+    assert lines[:3] == [str(BLS), "1", "2"] and [int(v) for v in lines[3:]] == vals[:20]      # the reference's layout, line by line
+    wire.write_share_file(name, BLS, 1, 2, vals[20:], append=True)
+    assert wire.read_share_file(name, BLS) == (1, 2, vals)
+    with pytest.raises(AssertionError):
+        wire.write_share_file(name, BLS, 2, 2, [1], append=True)                                # different degree
+    with pytest.raises(AssertionError):
+        wire.read_share_file(name, 13)
+    wire.write_share_file(name, BLS, 1, 2, vals[:5])                                            # overwrite
+    assert wire.read_share_file(name, BLS) == (1, 2, vals[:5])
+    fresh = str(tmp_path / "fresh_4_1-0.share")
+    wire.write_share_file(fresh, BLS, 1, 0, vals[:3], append=True)                              # append to a missing file creates it
+    assert wire.read_share_file(fresh, BLS) == (1, 0, vals[:3])
+
+    packed = str(tmp_path / "rands_4_1-3.shareb")
+    limbs = ints_to_limbs(vals, BLS, 32)
+    wire.write_share_file_packed(packed, BLS, 1, 3, limbs[:10])
+    wire.write_share_file_packed(packed, BLS, 1, 3, limbs[10:], append=True)
+    degree, ctx_id, got = wire.read_share_file_packed(packed, BLS)
+    assert (degree, ctx_id) == (1, 3) and limbs_to_ints(got, 32) == vals
+    with pytest.raises(AssertionError):
+        wire.write_share_file_packed(packed, BLS, 1, 1, limbs[:1], append=True)                 # different party
+    with pytest.raises(AssertionError):
+        wire.read_share_file_packed(packed, (1 << 255) - 19)
+    with open(packed, "ab") as f:
+        f.write(b"\x00" * 5)
+    with pytest.raises(ValueError):
+        wire.read_share_file_packed(packed, BLS)
