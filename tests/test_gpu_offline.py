@@ -224,3 +224,32 @@ def test_device_incremental_decoder_trajectory(n, t, c, seed):
         assert host.done() and set(host.get_results()[1]) <= set(liars)
         robust_launches += dev.launches
     assert robust_launches > 0          # the seeds above all reach the robust path at least once
+
+
+def test_device_incremental_decoder_reference_transcripts(golden):
+    """The transcripts tests/golden/incremental_decoder.json recorded from the reference's own IncrementalDecoder
+    (done / result / confirmed errors after every add), replayed on the device decoder.  Gao transcripts only: the
+    device decoder's fallback is Gao, batch_reconstruct's default (batch_reconstruction.py:85-90)."""
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+
+    replayed = 0
+    for tr in golden("incremental_decoder.json")["transcripts"]:
+        if tr["robust"] != "gao":
+            continue
+        ctx = Context.get(tr["p"])
+        dec = DeviceIncrementalDecoder(tr["p"], tr["n"], tr["t"], batch_size=tr["batch"], use_omega_powers=tr["use_omega_powers"])
+        for step in tr["steps"]:
+            dec.add(step["idx"], tr["columns"][step["idx"]])
+            res, errs = dec.get_results()
+            assert dec.done() == step["done"]
+            if step["result"] is None:
+                assert res is None and errs is None
+            else:
+                got = ctx.download_ints(res.reshape(-1, 4))
+                d = tr["t"] + 1
+                assert [got[i * d : (i + 1) * d] for i in range(tr["batch"])] == step["result"]
+                assert sorted(errs) == step["errors"]
+        assert dec.done()
+        replayed += 1
+    assert replayed >= 5
