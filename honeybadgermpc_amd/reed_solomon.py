@@ -31,13 +31,15 @@ def _is_batch(data):
 
 
 # ---------------------------------------------------------------------------
-# interfaces (reference :21-85)
+# interfaces (reference :21-85): `encode` / `decode` look at the first entry to tell one
+# polynomial from a batch of them
 # ---------------------------------------------------------------------------
 class Encoder(ABC):
     """message coefficients -> n evaluations"""
 
     def encode(self, data):
-        return self.encode_batch(data) if _is_batch(data) else self.encode_one(data)
+        handler = self.encode_batch if _is_batch(data) else self.encode_one
+        return handler(data)
 
     @abstractmethod
     def encode_one(self, data):
@@ -52,7 +54,8 @@ class Decoder(ABC):
     """evaluations at the points indexed by z -> message coefficients (no error tolerance)"""
 
     def decode(self, z, encoded):
-        return self.decode_batch(z, encoded) if _is_batch(encoded) else self.decode_one(z, encoded)
+        handler = self.decode_batch if _is_batch(encoded) else self.decode_one
+        return handler(z, encoded)
 
     @abstractmethod
     def decode_one(self, z, encoded):
@@ -71,65 +74,63 @@ class RobustDecoder(ABC):
 
 
 # ---------------------------------------------------------------------------
-# plain codecs (reference :88-148)
+# plain codecs (reference :88-148).  What a codec keeps of its EvalPoint is gathered in one place.
 # ---------------------------------------------------------------------------
+def _bind_point(codec, point, needs_omega):
+    if needs_omega:
+        assert point.use_omega_powers is True, "FFTEncoder only usable with roots of unity evaluation points"
+        codec.order, codec.omega = point.order, point.omega.value
+    codec.n, codec.modulus, codec.point = point.n, point.field.modulus, point
+
+
 class VandermondeEncoder(Encoder):
     def __init__(self, point):
-        self.n = point.n
+        _bind_point(self, point, needs_omega=False)
         self.x = [point(i).value for i in range(self.n)]
-        self.modulus = point.field.modulus
-
-    def encode_one(self, data):
-        return vandermonde_batch_evaluate(self.x, [data], self.modulus)[0]
 
     def encode_batch(self, data):
         return vandermonde_batch_evaluate(self.x, data, self.modulus)
 
+    def encode_one(self, data):
+        (row,) = self.encode_batch([data])
+        return row
+
 
 class FFTEncoder(Encoder):
     def __init__(self, point):
-        assert point.use_omega_powers is True, "FFTEncoder only usable with roots of unity evaluation points"
-        self.order = point.order
-        self.omega = point.omega.value
-        self.modulus = point.field.modulus
-        self.n = point.n
-
-    def encode_one(self, data):
-        return fft(data, self.omega, self.modulus, self.order)[: self.n]
+        _bind_point(self, point, needs_omega=True)
 
     def encode_batch(self, data):
         return fft_batch_evaluate(data, self.omega, self.modulus, self.order, self.n)
 
+    def encode_one(self, data):
+        return fft(data, self.omega, self.modulus, self.order)[: self.n]
+
 
 class VandermondeDecoder(Decoder):
     def __init__(self, point):
-        self.n = point.n
-        self.modulus = point.field.modulus
-        self.point = point
+        _bind_point(self, point, needs_omega=False)
 
     def _x(self, z):
-        return [self.point(zi).value for zi in z]
-
-    def decode_one(self, z, encoded):
-        return vandermonde_batch_interpolate(self._x(z), [encoded], self.modulus)[0]
+        return [self.point(zi).value for zi in z]     # recomputed per call, like the reference (:126,130)
 
     def decode_batch(self, z, encoded):
         return vandermonde_batch_interpolate(self._x(z), encoded, self.modulus)
 
+    def decode_one(self, z, encoded):
+        (row,) = self.decode_batch(z, [encoded])
+        return row
+
 
 class FFTDecoder(Decoder):
     def __init__(self, point):
-        assert point.use_omega_powers is True, "FFTEncoder only usable with roots of unity evaluation points"
-        self.order = point.order
-        self.omega = point.omega.value
-        self.modulus = point.field.modulus
-        self.n = point.n
-
-    def decode_one(self, z, encoded):
-        return fft_interpolate(z, encoded, self.omega, self.modulus, self.order)
+        _bind_point(self, point, needs_omega=True)
 
     def decode_batch(self, z, encoded):
         return fft_batch_interpolate(z, encoded, self.omega, self.modulus, self.order)
+
+    def decode_one(self, z, encoded):
+        return fft_interpolate(z, encoded, self.omega, self.modulus, self.order)
 
 
 # ---------------------------------------------------------------------------
@@ -402,74 +403,75 @@ class IncrementalDecoder(object):
 # model and are pinned by its tests (tests/test_reed_solomon.py:186-277), so they are kept
 # verbatim for API parity; DESIGN.md gives the GPU-derived policy the device path uses.
 # ---------------------------------------------------------------------------
+def _use_physical_cores(k):
+    """the reference's thread policy: one thread per polynomial, up to the physical cores (:412-414)"""
+    SetNumThreads(min(k, psutil.cpu_count(logical=False)))
+
+
 class EncoderSelector(object):
     LOW_VAN_THRESHOLD = 8     # n below this: always Vandermonde
     HIGH_VAN_THRESHOLD = 128  # n at or above this: always FFT
 
-    @staticmethod
-    def set_optimal_thread_count(k):
-        SetNumThreads(min(k, psutil.cpu_count(logical=False)))
+    set_optimal_thread_count = staticmethod(_use_physical_cores)
 
     @staticmethod
     def select(point, k):
         assert point.use_omega_powers is True
         n = point.n
-        if n < EncoderSelector.LOW_VAN_THRESHOLD:
-            return VandermondeEncoder(point)
-        if n >= EncoderSelector.HIGH_VAN_THRESHOLD:
-            return FFTEncoder(point)
-        # FFT only pays when n is within 25% below the transform size
-        npow2 = n if n & (n - 1) == 0 else 2 ** n.bit_length()
-        if npow2 - n > npow2 // 4 and n < 128:
-            return VandermondeEncoder(point)
-        return FFTEncoder(point)
+        transform = 1 << (n - 1).bit_length()          # the order an FFT over n points runs at
+        small = n < EncoderSelector.LOW_VAN_THRESHOLD
+        # between the thresholds the FFT only pays when n is within 25 % below the transform size
+        padded = n < EncoderSelector.HIGH_VAN_THRESHOLD and transform - n > transform // 4
+        return VandermondeEncoder(point) if small or padded else FFTEncoder(point)
 
 
 class DecoderSelector(object):
     LOW_VAN_THRESHOLD = 8
     BATCH_SIZE_THRESH_SLOPE = 0.5  # batch > slope * n * threads -> Vandermonde
 
-    @staticmethod
-    def set_optimal_thread_count(k):
-        SetNumThreads(min(k, psutil.cpu_count(logical=False)))
+    set_optimal_thread_count = staticmethod(_use_physical_cores)
 
     @staticmethod
     def select(point, k):
         assert point.use_omega_powers is True
         n = point.n
-        if n < DecoderSelector.LOW_VAN_THRESHOLD:
-            return VandermondeDecoder(point)
-        if k > DecoderSelector.BATCH_SIZE_THRESH_SLOPE * n * AvailableNTLThreads():
-            return VandermondeDecoder(point)
-        return FFTDecoder(point)
+        small = n < DecoderSelector.LOW_VAN_THRESHOLD
+        wide_batch = k > DecoderSelector.BATCH_SIZE_THRESH_SLOPE * n * AvailableNTLThreads()
+        return VandermondeDecoder(point) if small or wide_batch else FFTDecoder(point)
 
 
-class OptimalEncoder(Encoder):
+class _Selected:
+    """picks the codec per call from the batch size (reference :462-491)"""
+
+    selector = None
+
     def __init__(self, point):
         assert point.use_omega_powers is True
         self.point = point
+
+    def _pick(self, k):
+        self.selector.set_optimal_thread_count(k)
+        return self.selector.select(self.point, k)
+
+
+class OptimalEncoder(_Selected, Encoder):
+    selector = EncoderSelector
 
     def encode_one(self, data):
-        EncoderSelector.set_optimal_thread_count(1)
-        return EncoderSelector.select(self.point, 1).encode_one(data)
+        return self._pick(1).encode_one(data)
 
     def encode_batch(self, data):
-        EncoderSelector.set_optimal_thread_count(len(data))
-        return EncoderSelector.select(self.point, len(data)).encode_batch(data)
+        return self._pick(len(data)).encode_batch(data)
 
 
-class OptimalDecoder(Decoder):
-    def __init__(self, point):
-        assert point.use_omega_powers is True
-        self.point = point
+class OptimalDecoder(_Selected, Decoder):
+    selector = DecoderSelector
 
     def decode_one(self, z, data):
-        DecoderSelector.set_optimal_thread_count(1)
-        return DecoderSelector.select(self.point, 1).decode_one(z, data)
+        return self._pick(1).decode_one(z, data)
 
     def decode_batch(self, z, data):
-        DecoderSelector.set_optimal_thread_count(len(data))
-        return DecoderSelector.select(self.point, len(data)).decode_batch(z, data)
+        return self._pick(len(data)).decode_batch(z, data)
 
 
 class Algorithm:
@@ -479,44 +481,33 @@ class Algorithm:
     WELCH_BERLEKAMP = "welch-berlekamp"
 
 
-def _bad_algorithm(kind):
-    return ValueError(
-        f"Incorrect algorithm. Supported algorithms are {[Algorithm.VANDERMONDE, Algorithm.FFT]}\n"
-        f"Pass algorithm=None with FFT Enabled for automatic selection of {kind}"
-    )
+def _plain_codec(point, algorithm, by_name, automatic, kind):
+    if algorithm is None:
+        return automatic(point) if point.use_omega_powers else by_name[Algorithm.VANDERMONDE](point)
+    if algorithm not in by_name:
+        raise ValueError(
+            f"Incorrect algorithm. Supported algorithms are {[Algorithm.VANDERMONDE, Algorithm.FFT]}\n"
+            f"Pass algorithm=None with FFT Enabled for automatic selection of {kind}"
+        )
+    return by_name[algorithm](point)
 
 
 class EncoderFactory:
     @staticmethod
     def get(point, algorithm=None):
-        if algorithm == Algorithm.VANDERMONDE:
-            return VandermondeEncoder(point)
-        if algorithm == Algorithm.FFT:
-            return FFTEncoder(point)
-        if algorithm is None:
-            return OptimalEncoder(point) if point.use_omega_powers else VandermondeEncoder(point)
-        raise _bad_algorithm("encoder")
+        return _plain_codec(point, algorithm, {Algorithm.VANDERMONDE: VandermondeEncoder, Algorithm.FFT: FFTEncoder}, OptimalEncoder, "encoder")
 
 
 class DecoderFactory:
     @staticmethod
     def get(point, algorithm=None):
-        if algorithm == Algorithm.VANDERMONDE:
-            return VandermondeDecoder(point)
-        if algorithm == Algorithm.FFT:
-            return FFTDecoder(point)
-        if algorithm is None:
-            return OptimalDecoder(point) if point.use_omega_powers else VandermondeDecoder(point)
-        raise _bad_algorithm("decoder")
+        return _plain_codec(point, algorithm, {Algorithm.VANDERMONDE: VandermondeDecoder, Algorithm.FFT: FFTDecoder}, OptimalDecoder, "decoder")
 
 
 class RobustDecoderFactory:
     @staticmethod
     def get(t, point, algorithm=Algorithm.GAO):
-        if algorithm == Algorithm.GAO:
-            return GaoRobustDecoder(t, point)
-        if algorithm == Algorithm.WELCH_BERLEKAMP:
-            return WelchBerlekampRobustDecoder(t, point)
-        raise ValueError(
-            f"Invalid algorithm. Supported algorithms are [{Algorithm.GAO}, {Algorithm.WELCH_BERLEKAMP}]"
-        )
+        robust = {Algorithm.GAO: GaoRobustDecoder, Algorithm.WELCH_BERLEKAMP: WelchBerlekampRobustDecoder}
+        if algorithm not in robust:
+            raise ValueError(f"Invalid algorithm. Supported algorithms are [{Algorithm.GAO}, {Algorithm.WELCH_BERLEKAMP}]")
+        return robust[algorithm](t, point)
