@@ -60,8 +60,7 @@ constexpr int MM8_BIAS = 5800000;   // >= 128 * sum |digit| >= |column| (checked
 // A unit is TPW tiles of 16 chunks.  Its input elements are DMA'd (global_load_lds_dwordx4) into one
 // of two LDS buffers in MFMA-operand order -- slot (tile, kb, half)[lane] x 16 B, lane (n, g) owning
 // element l = 4 kb + g of chunk n -- one unit ahead of the arithmetic.  Wave w of the workgroup takes
-// row tile rt (16 output rows) of tile tl: (tl, rt) = (w / n_rt, w % n_rt) when n_rt divides 4,
-// otherwise tl = 0 and rt = w, w + 4, ...
+// (tile tl, row tile rt) pairs w, w + 4, ... of the unit's TPW x n_rt, pair index = tl n_rt + rt (rt: 16 output rows).
 //
 // Per (tile, rt) the 47 columns are produced in two halves by byte shift (rho in {0,1}: 23 columns, rho in
 // {2,3}: 24).  Accumulators start from BIAS so that every column is non-negative; a pair of adjacent
@@ -95,10 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     uint4 *xbuf = mm8_lds + n_rt * 64 + n_rt * NKB * 64;        // 2 x [tpw][NKB][2][64] uint4
     const int bufsz = tpw * NKB * 2 * 64;
 
-    const bool single = (tpw * n_rt == 4);
-    const int tl = single ? wave / n_rt : 0;
-    const int rt0 = single ? wave % n_rt : wave;
-    const int rstep = single ? 1024 : 4;
+    const int n_pairs = tpw * n_rt;      // (tile, row tile) pairs of a unit, dealt to the 4 waves: wave w takes w, w + 4, ...
 
     // l -> input row table (arrival order for decodes), clamped to d - 1
     int32_t *rowl = reinterpret_cast<int32_t *>(xbuf + 2 * bufsz);
@@ -206,10 +202,11 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 }
             }
         }
-        const int64_t chunk = (unit * tpw + tl) * 16 + n;
-        const uint4 *xs = xbuf + (size_t)buf * bufsz + (size_t)tl * NKB * 2 * 64 + lane;
-        if (rt0 >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a wave without a row tile still owns part of the DMA
-        for (int rt = rt0; rt < n_rt; rt += rstep) {
+        if (wave >= n_pairs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // a wave without a row tile still owns part of the DMA
+        for (int pidx = wave; pidx < n_pairs; pidx += 4) {
+            const int tl = pidx / n_rt, rt = pidx - tl * n_rt;
+            const int64_t chunk = (unit * tpw + tl) * 16 + n;
+            const uint4 *xs = xbuf + (size_t)buf * bufsz + (size_t)tl * NKB * 2 * 64 + lane;
             const int4 *as = abuf + (size_t)rt * NKB * 64 + lane;
             uint32_t eap[4][11], c0p[4];     // half 0's column pairs, parked across the second MFMA block
             uint32_t wd[4][MM8_CW];          // the 13 words of each biased sum
@@ -250,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 MM8_T(5);   // MFMA half 1
                 // next unit's DMA (issued a pass ago) must have landed before this wave reaches the barrier; waiting
                 // here, ahead of the epilogue, keeps this pass's output stores out of the wait
-                if (rt + rstep >= n_rt) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (pidx + 4 >= n_pairs) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 MM8_T(6);   // wait for the next unit's DMA (and the previous pass's stores)
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
@@ -386,6 +383,15 @@ namespace {
 
 // dynamic LDS of k_mm8: row constants, matrix digits, two element buffers, then the int tables of the prologue
 // (rowl[32], rowoff[32], rowmax + padding [32], maskl[16 n_rt])
+constexpr size_t MM8_LDS_LIMIT = 78 * 1024;   // two workgroups per CU share 160 KB
+size_t mm8_lds_bytes(int n_rt, int nkb, int tpw);
+// tiles of 16 chunks per unit: enough (tile, row tile) pairs for the 4 waves.  (Two tiles per unit with four row tiles --
+// two passes per barrier -- measured the same 65 us as one: the barrier is not what the kernel waits for.)
+int mm8_tpw(int n_rt, int nkb) {
+    int tpw = (n_rt == 1) ? 4 : (n_rt == 2) ? 2 : 1;
+    if (const char *e = getenv("HB_MM8_TPW")) { int v = atoi(e); if (v >= 1 && v <= 4 && v * n_rt >= 4 && mm8_lds_bytes(n_rt, nkb, v) <= MM8_LDS_LIMIT) tpw = v; }   // experiment hook
+    return tpw;
+}
 size_t mm8_lds_bytes(int n_rt, int nkb, int tpw) {
     return ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 64 + (size_t)2 * tpw * nkb * 2 * 64) * 16 + 96 * 4 + (size_t)n_rt * 16 * 4;
 }
@@ -501,9 +507,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     // rows != nullptr: the matrix made of rows[0 .. n_rows) of f (a compact check matrix)
     const int n_out = rows ? n_rows : f->n_out, d = f->n_in, nkb = (d + 3) / 4, n_rt = (n_out + 15) / 16;
     if (n_out < 1) return HB_ERR_UNSUPPORTED;
-    const int tpw = (n_rt == 1) ? 4 : (n_rt == 2) ? 2 : 1;
-    const size_t lds = mm8_lds_bytes(n_rt, nkb, tpw);
-    if (lds > 76 * 1024) return HB_ERR_UNSUPPORTED;
+    if (mm8_lds_bytes(n_rt, nkb, (n_rt == 1) ? 4 : (n_rt == 2) ? 2 : 1) > MM8_LDS_LIMIT) return HB_ERR_UNSUPPORTED;
     const int tiles = (f->n_out + f->ot - 1) / f->ot;
     std::vector<uint32_t> Mh((size_t)tiles * d * f->ot * 9);
     std::vector<int32_t> neg((size_t)f->n_out, 0);
@@ -600,7 +604,7 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
                int64_t C, hipStream_t s, uint32_t *copy_dst, hb_view cpv, int64_t copy_count, int copy_rows,
                const int32_t *check_rows_dev) {
     if (C <= 0) return HB_OK;
-    const int tpw = (m->n_rt == 1) ? 4 : (m->n_rt == 2) ? 2 : 1;
+    const int tpw = mm8_tpw(m->n_rt, m->nkb);
     const int64_t n_tiles = (C + 15) / 16;
     const int64_t n_units = (n_tiles + tpw - 1) / tpw;
     int64_t blocks = 2 * (int64_t)mm8_num_cus();
