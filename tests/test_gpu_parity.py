@@ -371,7 +371,8 @@ def test_batch_open_other_moduli(prime):
 
 
 @pytest.mark.parametrize("n,d,chunks,kind", [(64, 22, 37, "random"), (64, 22, 16, "extreme"), (64, 22, 19, "short"), (16, 6, 50, "random"),
-                                             (21, 9, 19, "random"), (40, 11, 16 * 70 + 3, "random"), (22, 22, 33, "extreme"), (1, 1, 5, "random")])
+                                             (21, 9, 19, "random"), (40, 11, 16 * 70 + 3, "random"), (22, 22, 33, "extreme"), (1, 1, 5, "random"),
+                                             (100, 10, 16 * 40 + 5, "random"), (128, 8, 33, "extreme"), (80, 16, 16 * 33 + 1, "short")])
 def test_matrix_core_matvec_vs_python_ints(n, d, chunks, kind):
     """The int8 matrix-core mat-vec on its own (hb_debug_mm8_*) against exact Python integers: random inputs, inputs
     at the edges of the byte-split arithmetic (0, 1, p-1, 2^256-1, 0x80.., 0x7f..), a zero-padded tail, ragged tiles."""
