@@ -199,7 +199,8 @@ def test_matvec_views_and_check():
 @pytest.mark.parametrize("matrix_cores", [True, False])
 @pytest.mark.parametrize("n,t,b,use_omega", [(4, 1, 3, False), (16, 5, 100, False), (16, 5, 96, True), (64, 21, 1000, False), (7, 2, 1, False),
                                              (64, 21, 700, True), (256, 85, 300, True), (100, 33, 150, True), (4, 1, 5, True),
-                                             (64, 21, 22 * 16 * 3 + 5, False), (40, 13, 333, False), (48, 31, 200, False), (128, 42, 260, False)])
+                                             (64, 21, 22 * 16 * 3 + 5, False), (40, 13, 333, False), (48, 31, 200, False), (128, 42, 260, False),
+                                             (100, 9, 10 * 16 * 5 + 3, False), (128, 7, 999, False), (80, 15, 640, False)])
 def test_batch_open_vs_oracle(n, t, b, use_omega, matrix_cores):
     import torch
 
