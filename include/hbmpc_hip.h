@@ -139,7 +139,7 @@ int hb_sqrt_mod(hb_ctx *ctx, const uint64_t *a_dev, int64_t C, uint64_t *out_dev
  *   plan: created once per (points, arrival set); shares_dev [B]; r1_out_dev [n][C] party-major;
  *   r1_cols_dev / r2_cols_dev [n][C] party-major received columns; r2_msg_dev [C];
  *   result_dev [B].  C = ceil(B / d).
- * hb_open_run is asynchronous; hb_open_status synchronises and returns HB_OK or HB_ERR_MISMATCH. */
+ * The hb_open_r* calls are asynchronous; hb_open_status synchronises and returns HB_OK or HB_ERR_MISMATCH. */
 typedef struct hb_open_plan hb_open_plan;
 int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const uint64_t *x_host,
                         const uint64_t *omega_host, int order, const int32_t *z_host /* d arrivals used to decode */,
