@@ -1,0 +1,100 @@
+"""
+batch_reconstruct on device tensors: the reference's two-round open
+(honeybadgermpc/batch_reconstruction.py:88-227) with the shares, every message and the result kept in the
+kernels' packed layout.
+
+Same coroutine shape as `batch_reconstruction.batch_reconstruct` -- same tags, same send / recv callables,
+same optimistic-then-robust decoding (device.DeviceIncrementalDecoder, Gao fallback) -- but
+
+  * `shares` is a (B, 4) limb tensor on the GPU and the result is one too;
+  * an R1 / R2 payload is `wire.tensor_to_wire(column)`: 16 bytes of header + 32 bytes per element, instead of
+    a pickled list of Python ints (ipc.py:111): no per-element marshalling on either side.
+
+The transport (router, sockets, authentication) is the caller's, as in the reference.
+"""
+import asyncio
+import logging
+
+from . import wire
+from ._capi import Context
+from .batch_reconstruction import fetch_one, recv_each_party
+from .device import BatchOpen, DeviceIncrementalDecoder
+from .utils.misc import subscribe_recv
+
+
+async def _incremental_decode_device(receivers, make_decoder, device):
+    """reference :43-61 with packed payloads; a payload that is not a well-formed column of the right length is that
+    sender's problem: it is dropped (the reference's `_validate` raises on a wrong length; here the sender is simply
+    never counted, which is what a confirmed error amounts to)."""
+    inc = make_decoder()
+    async for idx, blob in fetch_one(receivers):
+        try:
+            column = wire.wire_to_tensor(blob, device)
+            inc.add(idx, column)
+        except ValueError:
+            logging.error("[BatchReconstructDevice] malformed column from %d dropped", idx)
+            continue
+        if inc.done():
+            result, _ = inc.get_results()
+            return result
+    return None
+
+
+async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_powers=False, degree=None, device=None):
+    """Open the B shared secrets of which `shares` ((B, 4) tensor) are party `myid`'s shares.
+    -> (B, 4) tensor of the reconstructed values, or None when reconstruction fails."""
+    if degree is None:
+        degree = t
+    ctx = Context.get(p, device)
+    b = int(shares.shape[0])
+    d = degree + 1
+
+    subscribe_task, subscribe = subscribe_recv(recv)
+    del recv
+    task_r1, recvs_r1 = recv_each_party(subscribe("R1"), n)
+    data_r1 = [asyncio.create_task(r()) for r in recvs_r1]
+    task_r2, recvs_r2 = recv_each_party(subscribe("R2"), n)
+    data_r2 = [asyncio.create_task(r()) for r in recvs_r2]
+    del subscribe
+    background = [task_r1, task_r2, subscribe_task, *data_r1, *data_r2]
+
+    def cancel_all():
+        for task in background:
+            task.cancel()
+
+    op = BatchOpen(p, n, t, use_omega_powers=use_omega_powers, degree=degree, max_shares=max(b, 1), device=ctx.device)
+    c = op.chunks(b)
+
+    def make_decoder():
+        return DeviceIncrementalDecoder(p, n, t, degree=degree, batch_size=c, use_omega_powers=use_omega_powers, device=ctx.device)
+
+    # R1: every chunk evaluated at the n points; row j of the party-major result is party j's message
+    encoded = op.r1_encode(shares).view(n, c, 4).cpu()
+    for dest in range(n):
+        send(dest, ("R1", wire.tensor_to_wire(encoded[dest])))
+
+    recons_r2 = None
+    try:
+        recons_r2 = await _incremental_decode_device(data_r1, make_decoder, ctx.tdev)
+    except asyncio.CancelledError:
+        cancel_all()
+    if recons_r2 is None:
+        logging.error("[BatchReconstructDevice] P1 reconstruction failed!")
+        cancel_all()
+        return None
+
+    # R2: the constant terms to everybody
+    message = wire.tensor_to_wire(recons_r2[:, 0, :].contiguous())
+    for dest in range(n):
+        send(dest, ("R2", message))
+
+    recons_p = None
+    try:
+        recons_p = await _incremental_decode_device(data_r2, make_decoder, ctx.tdev)
+    except asyncio.CancelledError:
+        cancel_all()
+    cancel_all()
+    if recons_p is None:
+        logging.error("[BatchReconstructDevice] P2 reconstruction failed!")
+        return None
+    return recons_p.reshape(c * d, 4)[:b].contiguous()

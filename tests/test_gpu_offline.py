@@ -253,3 +253,78 @@ def test_device_incremental_decoder_reference_transcripts(golden):
         assert dec.done()
         replayed += 1
     assert replayed >= 5
+
+
+# ---- batch_reconstruct on device tensors, n parties in one process ---------------------------------------
+class _Net:
+    """queues standing in for the reference's router (router.py:66-107): send(dest, msg) / recv() -> (sender, msg)"""
+
+    def __init__(self, n):
+        self.q = [asyncio.Queue() for _ in range(n)]
+
+    def send(self, i, tamper=None):
+        def _send(dest, msg):
+            self.q[dest].put_nowait((i, tamper(dest, msg) if tamper else msg))
+
+        return _send
+
+    def recv(self, i):
+        return self.q[i].get
+
+
+@pytest.mark.parametrize("n, t, b, use_omega, liars", [(4, 1, 7, False, 0), (4, 1, 7, False, 1), (7, 2, 50, False, 2), (7, 2, 31, True, 2),
+                                                       (16, 5, 200, False, 5), (10, 3, 1, False, 3)])
+def test_batch_reconstruct_device(n, t, b, use_omega, liars):
+    """Every honest party opens the same secrets although `liars` parties send random columns in both rounds, one of
+    them malformed bytes; the packed R1 messages of an honest party are the int lists the host batch_reconstruct sends."""
+    import torch
+
+    from honeybadgermpc_amd import wire
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device_reconstruction import batch_reconstruct_device
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+    from honeybadgermpc_amd.reed_solomon import EncoderFactory
+
+    rnd = random.Random(n * 1000 + b)
+    ctx = Context.get(P)
+    point = EvalPoint(GF(P), n, use_omega_powers=use_omega)
+    xs = [point(i).value for i in range(n)]
+    secrets = [rnd.randrange(P) for _ in range(b)]
+    polys = [[s] + [rnd.randrange(P) for _ in range(t)] for s in secrets]
+    shares = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+    bad = set(rnd.sample(range(n), liars))
+    sent = {}
+
+    def tamper_for(i):
+        def tamper(dest, msg):
+            tag, blob = msg
+            if i == min(bad) and tag == "R1" and dest % 2:
+                return (tag, blob[:-3])                                   # truncated message
+            count = wire.unpack_limbs(blob).shape[0]
+            return (tag, wire.pack_ints([rnd.randrange(P) for _ in range(count)], P))
+
+        def record(dest, msg):
+            sent.setdefault((i, msg[0]), {})[dest] = msg[1]
+            return msg
+
+        return tamper if i in bad else record
+
+    async def main():
+        net = _Net(n)
+        tasks = [batch_reconstruct_device(ctx.upload_ints(shares[i]), P, t, n, i, net.send(i, tamper_for(i)), net.recv(i), use_omega_powers=use_omega)
+                 for i in range(n)]
+        return await asyncio.gather(*tasks)
+
+    results = asyncio.run(main())
+    for i in range(n):
+        if i not in bad:
+            assert results[i] is not None and ctx.download_ints(results[i]) == secrets, i
+    # the wire content of an honest party = what the host-level batch_reconstruct would have sent as int lists
+    honest = min(set(range(n)) - bad)
+    d = t + 1
+    chunks = [shares[honest][k : k + d] + [0] * (d - len(shares[honest][k : k + d])) for k in range(0, b, d)]
+    enc = EncoderFactory.get(point).encode(chunks)
+    for dest in range(n):
+        assert wire.unpack_ints(sent[(honest, "R1")][dest]) == [row[dest] for row in enc]
+    torch.cuda.synchronize()
