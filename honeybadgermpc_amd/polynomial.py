@@ -202,79 +202,114 @@ def polynomials_over(field):
     return Polynomial
 
 
+def _is_pow2(n):
+    return n >= 1 and (n & (n - 1)) == 0
+
+
 def get_omega(field, n, seed=None):
-    """An n-th root of unity, n a power of two; deterministic for a given seed
-    (reference :253-268, including its seed-less retry)."""
-    assert n & n - 1 == 0, "n must be a power of 2"
-    x = field.random(seed)
-    y = pow(x, (field.modulus - 1) // n)
-    if y == 1 or pow(y, n // 2) == 1:
-        return get_omega(field, n)
-    assert pow(y, n) == 1, "omega must be 2n'th root of unity"
-    assert pow(y, n // 2) != 1, "omega must be primitive 2n'th root of unity"
-    return y
+    """A primitive n-th root of unity of the field, n a power of two.
+
+    Behaviour pinned by the reference (polynomial.py:253-268) and by tests/golden/constants.json:
+    the candidate is field.random(seed) ** ((p - 1) / n); with seed=0 every party derives the same
+    root.  A candidate whose order is a proper divisor of n is thrown away and the draw is repeated
+    WITHOUT a seed, exactly as the reference's retry does."""
+    if not _is_pow2(n):
+        raise AssertionError("n must be a power of 2")
+    cofactor, rem = divmod(field.modulus - 1, n)
+    if rem:
+        raise AssertionError("the field has no element of order n")
+    draw_seed = seed
+    while True:
+        cand = field.random(draw_seed) ** cofactor
+        # cand ** n == 1 always; cand is primitive iff its (n/2)-th power is -1 (or n == 1)
+        if n == 1 or (cand != 1 and cand ** (n // 2) != 1):
+            return cand
+        draw_seed = None
 
 
 def fft_helper(a, omega, field):
-    """Recursive radix-2 transform of the coefficient list a at omega^0..omega^(n-1)
-    (reference :271-292).  Host Python: the independent check for the kernels."""
+    """[sum_j a[j] omega^(i j) for i < len(a)], len(a) a power of two: iterative decimation in time
+    over a bit-reversed copy with one table of the n/2 twiddles (same values as the reference's recursive
+    helper, polynomial.py:271-292; this is the host-side check of the device NTT, hb_ntt.hip)."""
     n = len(a)
-    assert not (n & (n - 1)), "n must be a power of 2"
+    if not _is_pow2(n):
+        raise AssertionError("n must be a power of 2")
     if n == 1:
-        return a
-    even = fft_helper(a[0::2], pow(omega, 2), field)
-    odd = fft_helper(a[1::2], pow(omega, 2), field)
-    half = n // 2
-    out = [field(1)] * n
-    for j in range(n):
-        out[j] = even[j % half] + pow(omega, j) * odd[j % half]
-    return out
+        return list(a)
+    bits = n.bit_length() - 1
+    vals = [None] * n
+    for j, coeff in enumerate(a):
+        vals[int(format(j, "0%db" % bits)[::-1], 2)] = coeff if isinstance(coeff, GFElement) else field(coeff)
+    tw = [field(1)]
+    for _ in range(n // 2 - 1):
+        tw.append(tw[-1] * omega)
+    span = 1
+    while span < n:
+        step = n // (2 * span)
+        for start in range(0, n, 2 * span):
+            for j in range(span):
+                lo, hi = start + j, start + j + span
+                t = vals[hi] * tw[j * step]
+                vals[hi] = vals[lo] - t
+                vals[lo] = vals[lo] + t
+        span *= 2
+    return vals
 
 
 def fft(poly, omega, n):
-    assert n & n - 1 == 0, "n must be a power of 2"
-    assert len(poly.coeffs) <= n
-    assert pow(omega, n) == 1
-    assert pow(omega, n // 2) != 1
-    padded = poly.coeffs + [poly.field(0)] * (n - len(poly.coeffs))
-    return fft_helper(padded, omega, poly.field)
+    """Evaluations of poly at omega^0 .. omega^(n-1), omega a primitive n-th root (reference :295-302)."""
+    if not _is_pow2(n):
+        raise AssertionError("n must be a power of 2")
+    field = poly.field
+    if len(poly.coeffs) > n or omega ** n != 1 or (n > 1 and omega ** (n // 2) == 1):
+        raise AssertionError("need deg < n and omega a primitive n-th root of unity")
+    return fft_helper(list(poly.coeffs) + [field(0)] * (n - len(poly.coeffs)), omega, field)
 
 
 def fnt_decode_step1(poly, zs, omega2, n):
-    """Per-point-set precomputation of Soro-Lacan FNT decoding, Python version
-    (reference :305-344): A(X) at the 2n powers of omega2 and A_i(x_i) = prod_{j!=i}(x_i-x_j)."""
-    k = len(zs)
-    omega = omega2 ** 2
-    xs = [omega ** z for z in zs]
-    a_ = poly([1])
-    for x in xs:
-        a_ *= poly([-x, 1])
-    as_ = [a_(omega2 ** i) for i in range(2 * n)]
-    ais_ = []
-    for i in range(k):
-        prod = a_.field(1)
-        for j in range(k):
-            if i != j:
-                prod *= xs[i] - xs[j]
-        ais_.append(prod)
-    return as_, ais_
+    """Point-set half of the Soro-Lacan FNT interpolation (reference :305-344; C++ twin
+    rsdecode_impl.h:194-222).  With x_i = omega^zs[i], omega = omega2^2 and A(X) = prod (X - x_i):
+    returns (A evaluated at the 2n powers of omega2, [A'(x_i)]) -- A'(x_i) = prod_{j != i}(x_i - x_j).
+    A is built coefficient-wise, transformed once (deg A = k <= n < 2n) and differentiated formally."""
+    field = omega2.field
+    points = [omega2 ** (2 * z) for z in zs]
+    coeffs = [field(1)]
+    for x in points:                                  # multiply by (X - x)
+        nxt = [field(0)] * (len(coeffs) + 1)
+        for j, c in enumerate(coeffs):
+            nxt[j + 1] = nxt[j + 1] + c
+            nxt[j] = nxt[j] - x * c
+        coeffs = nxt
+    a_evals = fft_helper(coeffs + [field(0)] * (2 * n - len(coeffs)), omega2, field)
+    deriv = [coeffs[j] * j for j in range(1, len(coeffs))]
+    a_prime = []
+    for x in points:
+        acc = field(0)
+        for c in reversed(deriv):                     # Horner
+            acc = acc * x + c
+        a_prime.append(acc)
+    return a_evals, a_prime
 
 
 def fnt_decode_step2(poly, zs, ys, as_, ais_, omega2, n):
-    """P with P(omega^zs[i]) = ys[i], O(n log n) given step 1 (reference :347-382)."""
+    """Value half (reference :347-382; rsdecode_impl.h:226-265): the P of degree < k with
+    P(omega^zs[i]) = ys[i].  P / A = sum_i w_i / (X - x_i) with w_i = y_i / A'(x_i), whose power series at 0 has
+    coefficients -N(omega^-(m+1)), N(X) = sum_i w_i X^zs[i]; so P = (that series, truncated) * A mod X^k.  One size-n
+    transform gives the series, the product is taken through the 2n evaluation points of step 1."""
+    field = omega2.field
     k = len(ys)
-    assert len(ys) == len(ais_)
-    assert len(as_) == 2 * n
-    omega = omega2 ** 2
-    ncoeffs = [0] * n
-    for i in range(k):
-        ncoeffs[zs[i]] = ys[i] / ais_[i]
-    nevals = poly(ncoeffs).evaluate_fft(omega, n)
-    power_a = -poly(nevals[::-1])
-    pas = power_a.evaluate_fft(omega2, 2 * n)
-    prec = poly.interpolate_fft([p * a for p, a in zip(pas, as_)], omega2)
-    prec.coeffs = prec.coeffs[:k]
-    return prec
+    if k != len(ais_) or len(as_) != 2 * n:
+        raise AssertionError("step-1 tables do not match these points")
+    omega = omega2 * omega2
+    weights = [field(0)] * n
+    for z, y, d in zip(zs, ys, ais_):
+        weights[z] = y / d
+    n_at = fft_helper(weights, omega, field)                  # N(omega^j), j < n
+    series = [-n_at[(n - 1 - m) % n] for m in range(n)]       # -N(omega^-(m+1))
+    s_evals = fft_helper(series + [field(0)] * n, omega2, field)
+    prod = fft_helper([s * a for s, a in zip(s_evals, as_)], 1 / omega2, field)
+    scale = 1 / field(2 * n)
+    return poly([c * scale for c in prod[:k]])
 
 
 class EvalPoint(object):
