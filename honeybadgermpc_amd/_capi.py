@@ -47,6 +47,8 @@ SYMBOLS = {
     "hb_ctx_create": (_i, [_pp, _vp, _i, _i]),
     "hb_ctx_destroy": (None, [_vp]),
     "hb_last_error": (ctypes.c_char_p, [_vp]),
+    "hb_ctx_cache_clear": (_i, [_vp]),
+    "hb_ctx_cache_entries": (_i, [_vp]),
     "hb_elem_bytes": (_i, [_vp]),
     "hb_malloc": (_i, [_vp, _pp, _sz]),
     "hb_free": (_i, [_vp, _vp]),
@@ -75,10 +77,13 @@ SYMBOLS = {
     "hb_open_plan_set_option": (_i, [_vp, _i, _i]),
     "hb_open_plan_get_option": (_i, [_vp, _i, _vp]),
     "hb_open_plan_destroy": (None, [_vp]),
+    "hb_selftest_mulmod": (_i, [_vp, _i, _vp, _vp, _vp]),
+}
+# include/hbmpc_hip_debug.h: diagnostics for scratch/ scripts and white-box tests, not part of the drop-in surface
+DEBUG_SYMBOLS = {
     "hb_debug_mm8_create": (_i, [_vp, _vp, _i, _i, _pp]),
     "hb_debug_mm8_apply": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "hb_debug_occupancy": (_i, [_i, _i, _vp, _vp]),
-    "hb_selftest_mulmod": (_i, [_vp, _i, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -105,7 +110,7 @@ def load_library():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover - depends on the host
         raise HbmpcBackendError(f"cannot load {LIB_PATH}: {e}") from e
-    for name, (restype, argtypes) in SYMBOLS.items():
+    for name, (restype, argtypes) in list(SYMBOLS.items()) + list(DEBUG_SYMBOLS.items()):
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.restype = restype
         fn.argtypes = argtypes
@@ -171,7 +176,8 @@ class Context:
     _cache = {}
 
     @classmethod
-    def get(cls, modulus, device=None):
+    def get(cls, modulus, device=None, n_limbs=None):
+        """n_limbs: 1 (8-byte elements, p < 2^64) or 4 (32-byte elements); default = the narrowest that holds p."""
         import torch
 
         if not torch.cuda.is_available():
@@ -181,14 +187,16 @@ class Context:
             )
         if device is None:
             device = torch.cuda.current_device()
-        key = (int(modulus), int(device))
+        if n_limbs is None:
+            n_limbs = 1 if int(modulus) < (1 << 64) else 4
+        key = (int(modulus), int(device), int(n_limbs))
         ctx = cls._cache.get(key)
         if ctx is None:
-            ctx = cls(modulus, device)
+            ctx = cls(modulus, device, n_limbs)
             cls._cache[key] = ctx
         return ctx
 
-    def __init__(self, modulus, device):
+    def __init__(self, modulus, device, n_limbs=4):
         import torch
 
         self.torch = torch
@@ -199,11 +207,13 @@ class Context:
             raise ValueError("modulus must be below 2**256")
         if self.modulus % 2 == 0 or self.modulus < 3:
             raise ValueError("modulus must be an odd prime")
-        # the wide (4-limb) instantiation serves every modulus; a 1-limb context is
-        # available through the C ABI for 64-bit primes (see tests/test_gpu_parity.py)
-        self.n_limbs = 4
-        self.nbytes = 32
-        p = ints_to_limbs([self.modulus], self.modulus + 1)
+        # two instantiations of every kernel: 9 x 29-bit digits / 32-byte elements for p < 2^256 and
+        # 3 digits / 8-byte elements for p < 2^64 (the "64/256-bit prime" of the north star)
+        if n_limbs not in (1, 4) or (n_limbs == 1 and self.modulus >= 1 << 64):
+            raise ValueError("n_limbs must be 4, or 1 for a modulus below 2**64")
+        self.n_limbs = int(n_limbs)
+        self.nbytes = 8 * self.n_limbs
+        p = ints_to_limbs([self.modulus], self.modulus + 1, self.nbytes)
         h = ctypes.c_void_p()
         rc = self.lib.hb_ctx_create(ctypes.byref(h), np_ptr(p), self.n_limbs, self.device)
         if rc != HB_OK:
@@ -242,3 +252,26 @@ class Context:
     @staticmethod
     def ptr(tensor):
         return ctypes.c_void_p(tensor.data_ptr())
+
+    def elems(self, tensor, count=None, what="tensor"):
+        """Validate a caller-supplied element buffer before its data_ptr() goes to C: int64, trailing dimension
+        n_limbs, on this context's device, `count` elements (when given); returns it contiguous."""
+        t = self.torch
+        if not isinstance(tensor, t.Tensor):
+            raise TypeError(f"{what}: expected a torch tensor, got {type(tensor).__name__}")
+        if tensor.dtype != t.int64:
+            raise TypeError(f"{what}: dtype must be int64 (4 x u64 limbs viewed as int64), got {tensor.dtype}")
+        if tensor.dim() < 1 or tensor.shape[-1] != self.n_limbs:
+            raise ValueError(f"{what}: last dimension must be {self.n_limbs} limbs, got shape {tuple(tensor.shape)}")
+        if not tensor.is_cuda or tensor.device.index != self.device:
+            raise ValueError(f"{what}: must live on cuda:{self.device}, is on {tensor.device}")
+        if count is not None and tensor.numel() != int(count) * self.n_limbs:
+            raise ValueError(f"{what}: expected {int(count)} elements, got {tensor.numel() // self.n_limbs}")
+        return tensor if tensor.is_contiguous() else tensor.contiguous()
+
+    def cache_clear(self):
+        """drop every cached table of this context (hb_ctx_cache_clear)"""
+        self.check(self.lib.hb_ctx_cache_clear(self.h), "hb_ctx_cache_clear")
+
+    def cache_entries(self):
+        return int(self.lib.hb_ctx_cache_entries(self.h))

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -39,7 +40,8 @@ struct hb_matrix {
     int n_out, n_in;
     uint32_t *dev;      // Montgomery digits, kernel layout, zero padded to whole tiles
     size_t words;
-    bool cached;        // owned by the ctx cache: hb_matrix_destroy is a no-op
+    bool cached;        // created through the ctx cache (hb_vand_matrix_create / hb_vand_inverse_create)
+    int refs;           // handles outstanding: one per create call that returned it, plus one while the cache holds it
 };
 
 namespace hb {
@@ -62,6 +64,15 @@ struct hb_ctx {
     std::map<std::string, void *> dcache;             // other device tables (twiddles, ...), hipFree'd with the ctx
     std::map<std::string, hb::FastMatrix *> fcache;   // second-generation (raw small-entry) tables
     std::map<std::string, hb::Mm8Matrix *> m8cache;   // their int8 matrix-core images (nullptr: does not qualify)
+    // Every cached table is also an entry of `lru` (key = "<map>|<map key>"): looked-up entries are touched, and cache_trim,
+    // called on entry to the API functions that use tables, drops the least recently used ones above `cache_cap`
+    // (after a device synchronise, so that no kernel in flight still reads them).  Pinned entries (twiddles, the sqrt
+    // constants: a handful per modulus) are never dropped.  Nothing outside a single API call may keep a pointer into a
+    // cache: plans own copies of their tables.
+    struct CacheSlot { uint64_t tick; bool pinned; std::function<void()> drop; };
+    std::map<std::string, CacheSlot> lru;
+    uint64_t lru_clock = 0;
+    size_t cache_cap = 192;                           // entries; HB_CACHE_CAP overrides (tests)
     int32_t *flag_dev;                                // 64 status words
     hb::PrescaleParams psc;                           // valid when psc_state == 1
     int psc_state = 0;                                // 0 not computed yet, 1 valid, -1 modulus outside [2^254, 2^256)
@@ -101,7 +112,12 @@ inline int nsub_for(int d, int nl, int nw) {
     long n = (d + per - 1) / per;
     return n < 1 ? 1 : (int)n;
 }
-int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s);
+int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s);   // cached: valid for the current API call only
+int own_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s);   // caller hipFree's it
+void cache_note(hb_ctx *ctx, const std::string &rk, std::function<void()> drop, bool pinned = false);
+void cache_touch(hb_ctx *ctx, const std::string &rk);
+void cache_trim(hb_ctx *ctx);
+void matrix_unref(hb_matrix *m);
 int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out);
 int upload_elems(hb_ctx *ctx, const uint64_t *host, size_t count, uint32_t **dev, hipStream_t s);
 std::string table_key(const char *kind, hb_ctx *ctx, const uint64_t *x, int n, int d);

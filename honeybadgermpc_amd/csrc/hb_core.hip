@@ -9,6 +9,8 @@
 //   vandermonde_batch_interpolate     hbmpc_ntl_helpers.pyx:139-197
 //   IncrementalDecoder's O(C) compare reed_solomon.py:316-319                       -> k_matvec<CHECK>
 //   chunk_data / transpose / flatten  utils/misc.py:33-73                           -> hb_view strides, k_copy_view
+#include <algorithm>
+
 #include "hb_common.hpp"
 
 using namespace hb;
@@ -328,22 +330,68 @@ __global__ void k_copy_view(const uint32_t *__restrict__ src, int64_t s_sc, int6
 // =====================================================================================
 namespace hb {
 
-int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s) {
-    std::vector<int32_t> key(host, host + n);
-    auto it = ctx->icache.find(key);
-    if (it != ctx->icache.end()) { *dev = it->second; return HB_OK; }
+// ---- bounded table caches ---------------------------------------------------------------------------
+void cache_note(hb_ctx *ctx, const std::string &rk, std::function<void()> drop, bool pinned) {
+    ctx->lru[rk] = hb_ctx::CacheSlot{++ctx->lru_clock, pinned, std::move(drop)};
+}
+void cache_touch(hb_ctx *ctx, const std::string &rk) {
+    auto it = ctx->lru.find(rk);
+    if (it != ctx->lru.end()) it->second.tick = ++ctx->lru_clock;
+}
+static void cache_drop_down_to(hb_ctx *ctx, size_t keep) {
+    std::vector<std::pair<uint64_t, std::string>> order;
+    for (auto &kv : ctx->lru) if (!kv.second.pinned) order.emplace_back(kv.second.tick, kv.first);
+    if (order.size() <= keep) return;
+    std::sort(order.begin(), order.end());
+    (void)hipDeviceSynchronize();                       // nothing in flight may still read a table that goes
+    for (size_t i = 0; i + keep < order.size(); i++) {
+        auto it = ctx->lru.find(order[i].second);
+        if (it == ctx->lru.end()) continue;
+        auto drop = std::move(it->second.drop);
+        ctx->lru.erase(it);
+        drop();
+    }
+}
+void cache_trim(hb_ctx *ctx) {
+    size_t unpinned = 0;
+    for (auto &kv : ctx->lru) if (!kv.second.pinned) unpinned++;
+    if (unpinned > ctx->cache_cap) cache_drop_down_to(ctx, ctx->cache_cap / 2);
+}
+void matrix_unref(hb_matrix *m) {
+    if (!m) return;
+    if (--m->refs > 0) return;
+    (void)hipFree(m->dev);
+    delete m;
+}
+
+static std::string int_key(const int32_t *host, int n) {
+    return std::string("i|") + std::string(reinterpret_cast<const char *>(host), (size_t)(n > 0 ? n : 0) * 4);
+}
+int own_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s) {
     int32_t *d = nullptr;
     HB_HIP(ctx, hipMalloc(&d, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
-    HB_HIP(ctx, hipMemcpyAsync(d, host, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s));
-    HB_HIP(ctx, hipStreamSynchronize(s));
+    hipError_t e = hipMemcpyAsync(d, host, sizeof(int32_t) * (size_t)(n > 0 ? n : 0), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { (void)hipFree(d); ctx->err = std::string("int array upload: ") + hipGetErrorString(e); return HB_ERR_HIP; }
+    *dev = d;
+    return HB_OK;
+}
+int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s) {
+    std::vector<int32_t> key(host, host + n);
+    const std::string rk = int_key(host, n);
+    auto it = ctx->icache.find(key);
+    if (it != ctx->icache.end()) { cache_touch(ctx, rk); *dev = it->second; return HB_OK; }
+    int32_t *d = nullptr;
+    int rc = own_int_array(ctx, host, n, &d, s); if (rc) return rc;
     ctx->icache[key] = d;
+    cache_note(ctx, rk, [ctx, key]() { auto f = ctx->icache.find(key); if (f != ctx->icache.end()) { (void)hipFree(f->second); ctx->icache.erase(f); } });
     *dev = d;
     return HB_OK;
 }
 
 int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out) {
     hb_matrix *m = new hb_matrix();
-    m->ctx = ctx; m->n_out = n_out; m->n_in = n_in; m->cached = false;
+    m->ctx = ctx; m->n_out = n_out; m->n_in = n_in; m->cached = false; m->refs = 1;
     m->words = (size_t)m_tiles(n_out) * (size_t)n_in * OT * (size_t)ctx->nl();
     if (m->words == 0) m->words = 1;
     hipError_t e = hipMalloc(&m->dev, m->words * sizeof(uint32_t));
@@ -395,6 +443,7 @@ int hb_ctx_create(hb_ctx **out, const uint64_t *p_limbs, int n_limbs, int device
     memset(ctx->p_limbs, 0, sizeof ctx->p_limbs);
     memcpy(ctx->p_limbs, p_limbs, (size_t)n_limbs * 8);
     if (n_limbs == 4) make_params<9>(ctx->pw, p_limbs, 4); else make_params<3>(ctx->pn, p_limbs, 1);
+    if (const char *e = getenv("HB_CACHE_CAP")) { long v = atol(e); if (v >= 8) ctx->cache_cap = (size_t)v; }
     ctx->flag_dev = nullptr;
     if (hipMalloc(&ctx->flag_dev, 64 * sizeof(int32_t)) != hipSuccess) { delete ctx; return HB_ERR_HIP; }
     (void)hipMemset(ctx->flag_dev, 0, 64 * sizeof(int32_t));
@@ -405,7 +454,8 @@ int hb_ctx_create(hb_ctx **out, const uint64_t *p_limbs, int n_limbs, int device
 void hb_ctx_destroy(hb_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    for (auto &kv : ctx->mcache) { (void)hipFree(kv.second->dev); delete kv.second; }
+    ctx->lru.clear();
+    for (auto &kv : ctx->mcache) matrix_unref(kv.second);      // handles still held by the caller stay valid until destroyed
     for (auto &kv : ctx->icache) (void)hipFree(kv.second);
     for (auto &kv : ctx->dcache) (void)hipFree(kv.second);
     for (auto &kv : ctx->fcache) fast_matrix_free(kv.second);
@@ -474,6 +524,7 @@ int vand_matrix_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_
         HB_HIP(ctx, hipStreamSynchronize(s));
     }
     m->cached = true; ctx->mcache[key] = m; *out = m;
+    cache_note(ctx, "m|" + key, [ctx, key]() { auto f = ctx->mcache.find(key); if (f != ctx->mcache.end()) { hb_matrix *mm = f->second; ctx->mcache.erase(f); matrix_unref(mm); } });
     return HB_OK;
 }
 
@@ -500,6 +551,7 @@ int vinv_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_dev, in
     }
     if (singular) { (void)hipFree(m->dev); delete m; return fail(ctx, HB_ERR_SINGULAR, "Interpolation failed"); }
     m->cached = true; ctx->mcache[key] = m; *out = m;
+    cache_note(ctx, "m|" + key, [ctx, key]() { auto f = ctx->mcache.find(key); if (f != ctx->mcache.end()) { hb_matrix *mm = f->second; ctx->mcache.erase(f); matrix_unref(mm); } });
     return HB_OK;
 }
 
@@ -510,28 +562,32 @@ extern "C" {
 int hb_vand_matrix_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, hb_matrix **out, void *stream) {
     if (!ctx || !out || n < 0 || d < 0) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    cache_trim(ctx);
     std::string key = table_key("V", ctx, x_host, n, d);
     auto it = ctx->mcache.find(key);
-    if (it != ctx->mcache.end()) { *out = it->second; return HB_OK; }
+    if (it != ctx->mcache.end()) { cache_touch(ctx, "m|" + key); it->second->refs++; *out = it->second; return HB_OK; }
     uint32_t *xd = nullptr;
     int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
     rc = vand_matrix_from_dev(ctx, key, xd, n, d, out, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(xd);
+    if (!rc) (*out)->refs++;                              // the caller's handle, beside the cache's own reference
     return rc;
 }
 
 int hb_vand_inverse_create(hb_ctx *ctx, const uint64_t *x_host, int k, hb_matrix **out, void *stream) {
     if (!ctx || !out || k < 0) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
+    cache_trim(ctx);
     std::string key = table_key("Vinv", ctx, x_host, k, k);
     auto it = ctx->mcache.find(key);
-    if (it != ctx->mcache.end()) { *out = it->second; return HB_OK; }
+    if (it != ctx->mcache.end()) { cache_touch(ctx, "m|" + key); it->second->refs++; *out = it->second; return HB_OK; }
     uint32_t *xd = nullptr;
     int rc = upload_elems(ctx, x_host, (size_t)k, &xd, s); if (rc) return rc;
     rc = vinv_from_dev(ctx, key, xd, k, out, s);
     (void)hipStreamSynchronize(s);
     (void)hipFree(xd);
+    if (!rc) (*out)->refs++;
     return rc;
 }
 
@@ -574,11 +630,7 @@ int hb_matrix_to_host(hb_ctx *ctx, const hb_matrix *m, uint64_t *m_host, void *s
     return HB_OK;
 }
 
-void hb_matrix_destroy(hb_matrix *m) {
-    if (!m || m->cached) return;
-    (void)hipFree(m->dev);
-    delete m;
-}
+void hb_matrix_destroy(hb_matrix *m) { matrix_unref(m); }   // cached tables live on until the cache lets go of them too
 
 }  // extern "C"
 
@@ -626,6 +678,7 @@ extern "C" {
 int hb_matvec(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_view in, const int32_t *in_rows,
               uint64_t *out_dev, hb_view out, int64_t C, void *stream) {
     if (!ctx || !m || (C > 0 && (!in_dev || !out_dev))) return HB_ERR_BAD_ARG;
+    cache_trim(ctx);
     hipStream_t s = (hipStream_t)stream;
     int32_t *rows_dev = nullptr;
     if (in_rows) { int rc = get_int_array(ctx, in_rows, m->n_in, &rows_dev, s); if (rc) return rc; }
@@ -636,6 +689,8 @@ int hb_matvec_check(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_
                     const uint64_t *expect_dev, hb_view expect, const int32_t *check_rows, int n_check,
                     int32_t *mismatch_dev, int64_t C, void *stream) {
     if (!ctx || !m || !mismatch_dev || (C > 0 && (!in_dev || !expect_dev))) return HB_ERR_BAD_ARG;
+    if (n_check < 0 || (n_check > 0 && !check_rows)) return HB_ERR_BAD_ARG;
+    cache_trim(ctx);
     hipStream_t s = (hipStream_t)stream;
     int32_t *rows_dev = nullptr;
     if (in_rows) { int rc = get_int_array(ctx, in_rows, m->n_in, &rows_dev, s); if (rc) return rc; }
@@ -654,6 +709,7 @@ static int fast_table(hb_ctx *ctx, const char *kind, const uint64_t *x_host, int
     if (out8) *out8 = nullptr;
     auto it = ctx->fcache.find(key);
     if (it != ctx->fcache.end()) {
+        cache_touch(ctx, "f|" + key);
         *out = it->second;
         if (out8) { auto i8 = ctx->m8cache.find(key); if (i8 != ctx->m8cache.end()) *out8 = i8->second; }
         return HB_OK;
@@ -666,6 +722,10 @@ static int fast_table(hb_ctx *ctx, const char *kind, const uint64_t *x_host, int
     (void)hipFree(xd);
     if (rc) return rc;
     ctx->fcache[key] = m;
+    cache_note(ctx, "f|" + key, [ctx, key]() {
+        auto f = ctx->fcache.find(key); if (f != ctx->fcache.end()) { fast_matrix_free(f->second); ctx->fcache.erase(f); }
+        auto g = ctx->m8cache.find(key); if (g != ctx->m8cache.end()) { mm8_free(g->second); ctx->m8cache.erase(g); }
+    });
     *out = m;
     // the matrix-core image of the same table, when it qualifies (hb_mfma.hip); nullptr is cached too
     Mm8Matrix *m8 = nullptr;
@@ -689,6 +749,7 @@ int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, co
                                   int64_t C, int d, uint64_t *out_dev, void *stream) {
     if (!ctx || n < 0 || d < 0 || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0 || n == 0) return HB_OK;
+    cache_trim(ctx);
     hipStream_t s = (hipStream_t)stream;
     if (d == 0) { HB_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)C * n * ctx->elem_words() * 4, s)); return HB_OK; }
     FastMatrix *V = nullptr;
@@ -706,19 +767,40 @@ int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, co
 
 int hb_vandermonde_batch_interpolate(hb_ctx *ctx, const uint64_t *x_host, int k, const uint64_t *data_dev,
                                      int64_t C, uint64_t *out_dev, void *stream) {
-    if (!ctx || k < 0 || C < 0) return HB_ERR_BAD_ARG;
+    if (!ctx || k < 0 || C < 0 || (k > 0 && !x_host)) return HB_ERR_BAD_ARG;
+    cache_trim(ctx);
     hipStream_t s = (hipStream_t)stream;
+    // The inverse is tabulated for the SORTED point set and the columns are fed through a permutation: the arrival
+    // order of an asynchronous open changes from call to call, the set far less often (IncrementalDecoder,
+    // reed_solomon.py:305-313, calls this with the points in arrival order).
+    const int L = ctx->n_limbs;
+    std::vector<int32_t> perm((size_t)k);
+    for (int i = 0; i < k; i++) perm[i] = i;
+    auto less = [&](int a, int b) {
+        for (int q = L - 1; q >= 0; q--) {
+            const uint64_t va = x_host[(size_t)a * L + q], vb = x_host[(size_t)b * L + q];
+            if (va != vb) return va < vb;
+        }
+        return false;
+    };
+    std::stable_sort(perm.begin(), perm.end(), less);
+    bool ident = true;
+    for (int i = 0; i < k; i++) if (perm[i] != i) ident = false;
+    std::vector<uint64_t> xs((size_t)k * L);
+    for (int i = 0; i < k; i++) memcpy(&xs[(size_t)i * L], x_host + (size_t)perm[i] * L, (size_t)L * 8);
     FastMatrix *Vi = nullptr;
     Mm8Matrix *Vi8 = nullptr;
-    int rc = fast_table(ctx, "Nf", x_host, k, k, &Vi, s, &Vi8); if (rc) return rc;     // HB_ERR_SINGULAR: repeated point
+    int rc = fast_table(ctx, "Nf", xs.data(), k, k, &Vi, s, &Vi8); if (rc) return rc;     // HB_ERR_SINGULAR: repeated point
     if (C == 0 || k == 0) return HB_OK;
+    int32_t *perm_dev = nullptr;
+    if (!ident) { rc = get_int_array(ctx, perm.data(), k, &perm_dev, s); if (rc) return rc; }
     hb_view v{k, 1};
     if (Vi8) {
         // c = N (y / den): elementwise division into a row-major temporary, then the small-integer mat-vec on the matrix cores
         uint32_t *scaled = nullptr;
         HB_HIP(ctx, hipMalloc(&scaled, (size_t)k * (size_t)C * ctx->elem_words() * 4));
         hb_view rm{1, C};
-        rc = launch_prescale_pk(ctx, Vi, (const uint32_t *)data_dev, v, nullptr, INT64_MAX, scaled, C, s);
+        rc = launch_prescale_pk(ctx, Vi, (const uint32_t *)data_dev, v, perm_dev, INT64_MAX, scaled, C, s);
         if (!rc) rc = launch_mm8(ctx, Vi8, scaled, rm, nullptr, INT64_MAX, (uint32_t *)out_dev, v, INT64_MAX, nullptr, nullptr, C, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(scaled);
@@ -726,11 +808,23 @@ int hb_vandermonde_batch_interpolate(hb_ctx *ctx, const uint64_t *x_host, int k,
     }
     uint32_t *scratch = nullptr;
     rc = fast_scratch(ctx, k, C, &scratch); if (rc) return rc;
-    rc = launch_matvec2(ctx, Vi, nullptr, (const uint32_t *)data_dev, v, nullptr, INT64_MAX, scratch,
+    rc = launch_matvec2(ctx, Vi, nullptr, (const uint32_t *)data_dev, v, perm_dev, INT64_MAX, scratch,
                         (uint32_t *)out_dev, v, INT64_MAX, k, 1, nullptr, nullptr, nullptr, C, s);
     if (scratch) { (void)hipStreamSynchronize(s); (void)hipFree(scratch); }
     return rc;
 }
+
+// Drop every cached table of the context (synchronises the device).  Handles returned by hb_vand_*_create stay valid
+// until hb_matrix_destroy.  The caches also bound themselves (least recently used entries go once more than
+// `cache_cap` are resident), so calling this is never required.
+int hb_ctx_cache_clear(hb_ctx *ctx) {
+    if (!ctx) return HB_ERR_BAD_ARG;
+    (void)hipSetDevice(ctx->device);
+    cache_drop_down_to(ctx, 0);
+    return HB_OK;
+}
+// number of table-cache entries currently resident (pinned ones included)
+int hb_ctx_cache_entries(const hb_ctx *ctx) { return ctx ? (int)ctx->lru.size() : 0; }
 
 // host self-test of the arithmetic templates (runs the same code as the kernels on the CPU)
 int hb_selftest_mulmod(const uint64_t *p_limbs, int n_limbs, const uint64_t *a, const uint64_t *b, uint64_t *out) {

@@ -21,6 +21,8 @@
 // Montgomery's trick) recovers both the reference's un-normalised cofactor v = V / c and the
 // monic divisor for the exact division.  Per codeword: O(n * e / 64) mulmods per lane plus
 // one Fermat inversion, instead of one inversion per Euclid step.
+#include <algorithm>
+
 #include "hb_common.hpp"
 
 using namespace hb;
@@ -259,13 +261,20 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     if (C > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "gao: batch too large");
     hipStream_t s = (hipStream_t)stream;
     const int NLr = ctx->nl();
+    cache_trim(ctx);
     // tables for this point set
     hb_matrix *Vi = nullptr;
     int rc = hb_vand_inverse_create(ctx, x_host, npts, &Vi, stream); if (rc) return rc;
-    std::string key = table_key("g0", ctx, x_host, npts, 0);
+    struct Unref { hb_matrix *m; ~Unref() { matrix_unref(m); } } unref_vi{Vi};   // this call's handle; the cache keeps its own
+    // g0 = prod (X - x_i) does not depend on the order of the points: keyed by the sorted set
+    std::vector<std::string> pts((size_t)npts);
+    for (int i = 0; i < npts; i++) pts[i].assign(reinterpret_cast<const char *>(x_host + (size_t)i * ctx->n_limbs), (size_t)ctx->n_limbs * 8);
+    std::sort(pts.begin(), pts.end());
+    std::string key = "g0:" + std::to_string(npts) + ":";
+    for (auto &pt : pts) key += pt;
     uint32_t *g0 = nullptr;
     auto it = ctx->dcache.find(key);
-    if (it != ctx->dcache.end()) g0 = (uint32_t *)it->second;
+    if (it != ctx->dcache.end()) { g0 = (uint32_t *)it->second; cache_touch(ctx, "d|" + key); }
     else {
         uint32_t *xd = nullptr;
         rc = upload_elems(ctx, x_host, (size_t)npts, &xd, s); if (rc) return rc;
@@ -283,6 +292,7 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
         HB_HIP(ctx, hipStreamSynchronize(s));
         HB_HIP(ctx, hipFree(xd));
         ctx->dcache[key] = g0;
+        cache_note(ctx, "d|" + key, [ctx, key]() { auto f = ctx->dcache.find(key); if (f != ctx->dcache.end()) { (void)hipFree(f->second); ctx->dcache.erase(f); } });
     }
     // g1 for every codeword: coefficient-major [npts][C]
     uint32_t *g1 = nullptr;

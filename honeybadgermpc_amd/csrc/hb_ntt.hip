@@ -22,6 +22,8 @@
 // reduced): for the party counts of this path (k <= a few hundred) that is fewer MADs than
 // scale + n-point NTT + MulTrunc(Q, A, k) (see DESIGN.md cost table); results are
 // identical because every output is a canonical residue.
+#include <algorithm>
+
 #include "hb_common.hpp"
 
 using namespace hb;
@@ -253,6 +255,7 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, co
     if (!ctx || !omega_host || order <= 0 || (order & (order - 1)) || k < 0 || k > order || d < 0 || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0 || k == 0) return HB_OK;
     if (!coeffs_dev || !out_dev) return HB_ERR_BAD_ARG;
+    cache_trim(ctx);
     hipStream_t s = (hipStream_t)stream;
     const int n = order;
     int logn = 0; while ((1 << logn) < n) logn++;
@@ -269,7 +272,7 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, co
         key.append(reinterpret_cast<const char *>(omega_host), (size_t)ctx->n_limbs * 8);
         hb_matrix *W = nullptr;
         auto it = ctx->mcache.find(key);
-        if (it != ctx->mcache.end()) W = it->second;
+        if (it != ctx->mcache.end()) { W = it->second; cache_touch(ctx, "m|" + key); }
         else {
             uint32_t *xd = nullptr;
             int rc = pow_points_dev(ctx, omega_host, nullptr, k, &xd, s); if (rc) return rc;
@@ -313,23 +316,32 @@ int hb_fft_batch_interpolate(hb_ctx *ctx, const uint64_t *omega_host, int order,
     if (!ys_dev || !out_dev) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     for (int i = 0; i < k; i++) if (zs_host[i] < 0 || zs_host[i] >= order) return fail(ctx, HB_ERR_BAD_ARG, "zs out of range");
+    cache_trim(ctx);
+    // table for the sorted exponent set, columns fed through a permutation (arrival orders vary, sets less so)
+    std::vector<int32_t> perm((size_t)k), zsorted((size_t)k);
+    for (int i = 0; i < k; i++) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return zs_host[a] < zs_host[b]; });
+    bool ident = true;
+    for (int i = 0; i < k; i++) { zsorted[i] = zs_host[perm[i]]; if (perm[i] != i) ident = false; }
     std::string key = "WinvZ:" + std::to_string(order) + ":";
     key.append(reinterpret_cast<const char *>(omega_host), (size_t)ctx->n_limbs * 8);
-    key.append(reinterpret_cast<const char *>(zs_host), (size_t)k * 4);
+    key.append(reinterpret_cast<const char *>(zsorted.data()), (size_t)k * 4);
     hb_matrix *Wi = nullptr;
     auto it = ctx->mcache.find(key);
-    if (it != ctx->mcache.end()) Wi = it->second;
+    if (it != ctx->mcache.end()) { Wi = it->second; cache_touch(ctx, "m|" + key); }
     else {
         int32_t *zd = nullptr;
-        int rc = get_int_array(ctx, zs_host, k, &zd, s); if (rc) return rc;
+        int rc = get_int_array(ctx, zsorted.data(), k, &zd, s); if (rc) return rc;
         uint32_t *xd = nullptr;
         rc = pow_points_dev(ctx, omega_host, zd, k, &xd, s); if (rc) return rc;
         rc = vinv_from_dev(ctx, key, xd, k, &Wi, s);      // HB_ERR_SINGULAR <=> repeated z
         (void)hipFree(xd);
         if (rc) return rc;
     }
+    int32_t *perm_dev = nullptr;
+    if (!ident) { int rc = get_int_array(ctx, perm.data(), k, &perm_dev, s); if (rc) return rc; }
     hb_view v{k, 1};
-    return launch_matvec(ctx, Wi, (const uint32_t *)ys_dev, v, nullptr, INT64_MAX, (uint32_t *)out_dev, v, INT64_MAX, nullptr, nullptr, C, s);
+    return launch_matvec(ctx, Wi, (const uint32_t *)ys_dev, v, perm_dev, INT64_MAX, (uint32_t *)out_dev, v, INT64_MAX, nullptr, nullptr, C, s);
 }
 
 }  // extern "C"

@@ -54,68 +54,71 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
                         const uint64_t *omega_host, int order, const int32_t *z_host, const int32_t *zc_host,
                         int n_check, int64_t max_B, hb_open_plan **out, void *stream) {
     if (!ctx || !out || n <= 0 || d <= 0 || d > n || !x_host || !z_host || max_B < 0) return HB_ERR_BAD_ARG;
+    if (n_check < 0 || n_check > n || (n_check > 0 && !zc_host)) return HB_ERR_BAD_ARG;
+    for (int i = 0; i < d; i++) if (z_host[i] < 0 || z_host[i] >= n) return HB_ERR_BAD_ARG;
+    for (int j = 0; j < n_check; j++) if (zc_host[j] < 0 || zc_host[j] >= n) return HB_ERR_BAD_ARG;
+    *out = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    hb_open_plan *pl = new hb_open_plan();
+    hb_open_plan *pl = new hb_open_plan();      // value-initialised: every pointer null, so destroy is safe at any point
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
-    pl->in_dg = pl->coef_dg = pl->coef_pk = nullptr; pl->mismatch_dev = nullptr; pl->V = pl->Vinv = nullptr; pl->V8 = nullptr; pl->Vzc8 = nullptr; pl->zc_dev = pl->ones_dev = nullptr; pl->Vinv8 = nullptr; pl->scaled_pk = nullptr; pl->use_v8 = 1;
-    pl->validate_arrived_only = 0;
-    pl->ntt_order = 0; pl->tw = nullptr;
+    pl->use_v8 = 1;
     const int L = ctx->n_limbs;
-    std::vector<uint64_t> xz((size_t)d * L);
-    for (int i = 0; i < d; i++) {
-        if (z_host[i] < 0 || z_host[i] >= n) { delete pl; return HB_ERR_BAD_ARG; }
-        memcpy(&xz[(size_t)i * L], x_host + (size_t)z_host[i] * L, (size_t)L * 8);
-    }
     uint32_t *xd = nullptr, *xzd = nullptr;
-    int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s);
-    if (rc) { delete pl; return rc; }
-    rc = upload_elems(ctx, xz.data(), (size_t)d, &xzd, s);
-    if (rc) { delete pl; return rc; }
-    rc = fast_vand_create(ctx, xd, n, d, &pl->V, s);
-    if (!rc) rc = fast_vinv_create(ctx, xzd, d, &pl->Vinv, s);
-    (void)hipStreamSynchronize(s);
-    (void)hipFree(xd); (void)hipFree(xzd);
-    if (rc) { fast_matrix_free(pl->V); delete pl; return rc; }
-    rc = get_int_array(ctx, z_host, d, &pl->z_dev, s);
-    if (rc) { delete pl; return rc; }
-    std::vector<int32_t> mask((size_t)n + 1, 0);
-    mask[n] = -1;
-    for (int j = 0; j < n_check; j++) {
-        if (zc_host[j] < 0 || zc_host[j] >= n) { delete pl; return HB_ERR_BAD_ARG; }
-        mask[zc_host[j]] = 1;
-        pl->zc.push_back(zc_host[j]);
+    int rc = HB_OK;
+    // every failure leaves through `done`, which releases whatever the plan owns by then
+#define PLAN_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e__); rc = HB_ERR_HIP; goto done; } } while (0)
+    {
+        std::vector<uint64_t> xz((size_t)d * L);
+        for (int i = 0; i < d; i++) memcpy(&xz[(size_t)i * L], x_host + (size_t)z_host[i] * L, (size_t)L * 8);
+        rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) goto done;
+        rc = upload_elems(ctx, xz.data(), (size_t)d, &xzd, s); if (rc) goto done;
+        rc = fast_vand_create(ctx, xd, n, d, &pl->V, s);
+        if (!rc) rc = fast_vinv_create(ctx, xzd, d, &pl->Vinv, s);
+        (void)hipStreamSynchronize(s);
+        if (rc) goto done;
     }
-    rc = get_int_array(ctx, mask.data(), n + 1, &pl->mask_dev, s);
-    if (rc) { delete pl; return rc; }
-    HB_HIP(ctx, hipMalloc(&pl->in_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
-    HB_HIP(ctx, hipMalloc(&pl->coef_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
+    rc = own_int_array(ctx, z_host, d, &pl->z_dev, s); if (rc) goto done;
+    {
+        std::vector<int32_t> mask((size_t)n + 1, 0);
+        mask[n] = -1;
+        for (int j = 0; j < n_check; j++) { mask[zc_host[j]] = 1; pl->zc.push_back(zc_host[j]); }
+        rc = own_int_array(ctx, mask.data(), n + 1, &pl->mask_dev, s); if (rc) goto done;
+    }
+    PLAN_HIP(hipMalloc(&pl->in_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
+    PLAN_HIP(hipMalloc(&pl->coef_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
     if (use_omega_powers && omega_host && order >= n && order > 0 && (order & (order - 1)) == 0) {
         // MADs per chunk: full-digit mat-vec n*d*NL^2 vs butterflies (order/2)*log2(order)*(2 NL^2 + 4 NL)
         int logn = 0; while ((1 << logn) < order) logn++;
         const double nl2 = (double)ctx->nl() * ctx->nl();
         const double mv = (double)n * d * nl2, ntt = 0.5 * order * logn * (2.0 * nl2 + 4.0 * ctx->nl());
         if (ntt < mv && (size_t)order * ctx->nl() * 4 <= 40 * 1024) {
-            rc = get_twiddles(ctx, omega_host, order, &pl->tw, s);
-            if (rc) { delete pl; return rc; }
+            rc = get_twiddles(ctx, omega_host, order, &pl->tw, s); if (rc) goto done;     // pinned in the ctx cache
             pl->ntt_order = order;
-            HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+            PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
         }
     }
     if (!pl->ntt_order) {
         // third generation: the encode and the validating re-encode on the int8 matrix cores when the
         // Vandermonde entries are small enough (hb_mfma.hip); otherwise V8 stays null
         rc = mm8_from_fast(ctx, pl->V, &pl->V8, s);
-        if (rc && rc != HB_ERR_UNSUPPORTED) { delete pl; return rc; }
+        if (rc && rc != HB_ERR_UNSUPPORTED) goto done;
+        rc = HB_OK;
         if (pl->V8) {
-            HB_HIP(ctx, hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+            PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
             rc = getenv("HB_NO_MFMA_DECODE") ? HB_ERR_UNSUPPORTED : mm8_from_fast(ctx, pl->Vinv, &pl->Vinv8, s);
-            if (rc && rc != HB_ERR_UNSUPPORTED) { delete pl; return rc; }
-            if (pl->Vinv8) HB_HIP(ctx, hipMalloc(&pl->scaled_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+            if (rc && rc != HB_ERR_UNSUPPORTED) goto done;
+            rc = HB_OK;
+            if (pl->Vinv8) PLAN_HIP(hipMalloc(&pl->scaled_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
         }
     }
-    HB_HIP(ctx, hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
-    HB_HIP(ctx, hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
+    PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
+    PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
+#undef PLAN_HIP
+done:
+    if (xd) (void)hipFree(xd);
+    if (xzd) (void)hipFree(xzd);
+    if (rc) { hb_open_plan_destroy(pl); return rc; }
     *out = pl;
     return HB_OK;
 }
@@ -229,9 +232,8 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
             if (rc && rc != HB_ERR_UNSUPPORTED) return rc;
             if (pl->Vzc8) {
                 std::vector<int32_t> ones(pl->zc.size() + 2, 1);
-                ones.back() = -2;   // keeps this array apart from other cached int arrays of the same length
-                rc = get_int_array(pl->ctx, pl->zc.data(), (int)pl->zc.size(), &pl->zc_dev, 0);
-                if (!rc) rc = get_int_array(pl->ctx, ones.data(), (int)ones.size(), &pl->ones_dev, 0);
+                rc = own_int_array(pl->ctx, pl->zc.data(), (int)pl->zc.size(), &pl->zc_dev, 0);
+                if (!rc) rc = own_int_array(pl->ctx, ones.data(), (int)ones.size(), &pl->ones_dev, 0);
                 if (rc) return rc;
             }
         }
@@ -250,8 +252,14 @@ int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) {
 
 void hb_open_plan_destroy(hb_open_plan *pl) {
     if (!pl) return;
-    (void)hipFree(pl->in_dg); (void)hipFree(pl->coef_dg); if (pl->coef_pk) (void)hipFree(pl->coef_pk);
-    (void)hipFree(pl->mismatch_dev);
+    if (pl->in_dg) (void)hipFree(pl->in_dg);
+    if (pl->coef_dg) (void)hipFree(pl->coef_dg);
+    if (pl->coef_pk) (void)hipFree(pl->coef_pk);
+    if (pl->mismatch_dev) (void)hipFree(pl->mismatch_dev);
+    if (pl->z_dev) (void)hipFree(pl->z_dev);
+    if (pl->mask_dev) (void)hipFree(pl->mask_dev);
+    if (pl->zc_dev) (void)hipFree(pl->zc_dev);
+    if (pl->ones_dev) (void)hipFree(pl->ones_dev);
     fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8); mm8_free(pl->Vinv8); mm8_free(pl->Vzc8);
     if (pl->scaled_pk) (void)hipFree(pl->scaled_pk);
     delete pl;

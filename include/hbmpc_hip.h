@@ -64,6 +64,13 @@ int hb_device_count(void);
 int hb_ctx_create(hb_ctx **out, const uint64_t *p_limbs, int n_limbs, int device);
 void hb_ctx_destroy(hb_ctx *ctx);
 const char *hb_last_error(const hb_ctx *ctx);
+/* Tables derived from point sets (V, V^-1, error-locator bases, index maps) are cached per context, keyed by the
+ * sorted point set, and bounded: once more than a cap of entries (192; HB_CACHE_CAP in the environment) are
+ * resident, the least recently used ones are dropped on entry to the next call.  hb_ctx_cache_clear drops them all
+ * (synchronises the device); hb_ctx_cache_entries reports how many are resident.  The reference keeps one
+ * process-global FFT base-case cache flushed on modulus change (rsdecode_impl.h:18-20,52-65). */
+int hb_ctx_cache_clear(hb_ctx *ctx);
+int hb_ctx_cache_entries(const hb_ctx *ctx);
 int hb_elem_bytes(const hb_ctx *ctx);
 
 /* device-memory helpers for callers that have no allocator of their own */
@@ -74,7 +81,8 @@ int hb_memcpy_d2h(hb_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes
 int hb_stream_sync(hb_ctx *ctx, void *stream);
 
 /* ---- tables ------------------------------------------------------------------------ */
-/* V[i][l] = x_i^l, n x d.  Replaces set_vm_matrix (rsdecode_impl.h:23-36). */
+/* V[i][l] = x_i^l, n x d.  Replaces set_vm_matrix (rsdecode_impl.h:23-36).  The two point-set constructors hand out
+ * shared, reference-counted tables: release every handle with hb_matrix_destroy. */
 int hb_vand_matrix_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, hb_matrix **out, void *stream);
 /* V(x)^-1, k x k.  Replaces vandermonde_inverse (rsdecode_impl.h:97-122).  Synchronises;
  * returns HB_ERR_SINGULAR when two points coincide mod p. */
@@ -163,17 +171,6 @@ int hb_open_status(hb_open_plan *plan, void *stream);
 int hb_open_plan_set_option(hb_open_plan *plan, int option, int value);
 int hb_open_plan_get_option(hb_open_plan *plan, int option, int *value);
 void hb_open_plan_destroy(hb_open_plan *plan);
-
-/* ---- diagnostics (scratch/ scripts only; not part of the drop-in surface) ---------------------------
- * hb_debug_mm8_*: the int8 matrix-core mat-vec of csrc/hb_mfma.hip on its own -- table for the points
- * x_host (n points, d terms), then out(c, i) = sum_l x_i^l in(c, l) with explicit views; HB_ERR_UNSUPPORTED
- * when the shapes do not qualify.  hb_debug_occupancy: resident workgroups per CU the runtime reports for
- * the second-generation kernels at a given inner dimension. */
-int hb_debug_mm8_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, void **out);
-int hb_debug_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, int64_t in_sc, int64_t in_sl, int64_t in_count,
-                       void *out_dev, int64_t out_sc, int64_t out_sl, int64_t out_count, int64_t n_chunks,
-                       const int32_t *check_mask_dev, int32_t *mismatch_dev);
-int hb_debug_occupancy(int n_in, int nl, int *mv3, int *dc);
 
 /* host-side self test of the radix-2^29 arithmetic templates (no GPU needed):
  * out = a*b mod p computed with the same code the kernels use. */

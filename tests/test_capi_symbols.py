@@ -10,21 +10,26 @@ import pytest
 from conftest import BLS, REPO
 
 
-def declared_functions():
-    text = open(os.path.join(REPO, "include", "hbmpc_hip.h")).read()
+def declared_functions(header="hbmpc_hip.h"):
+    text = open(os.path.join(REPO, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(hb_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
-    from honeybadgermpc_amd._capi import LIB_PATH, SYMBOLS, load_library
+    from honeybadgermpc_amd._capi import DEBUG_SYMBOLS, LIB_PATH, SYMBOLS, load_library
 
+    headers = sorted(f for f in os.listdir(os.path.join(REPO, "include")) if f.endswith(".h"))
+    assert headers == ["hbmpc_hip.h", "hbmpc_hip_debug.h"]
     names = declared_functions()
     assert len(names) >= 30
     assert sorted(SYMBOLS) == names, "ctypes table and header disagree"
+    debug = declared_functions("hbmpc_hip_debug.h")
+    assert sorted(DEBUG_SYMBOLS) == debug, "ctypes debug table and debug header disagree"
+    assert not any(n.startswith("hb_debug") for n in names), "diagnostics do not belong in the public header"
     lib = load_library()
     raw = ctypes.CDLL(LIB_PATH)
-    for name in names:
+    for name in names + debug:
         assert getattr(raw, name) is not None
     assert lib.hb_version() >= 100
 
