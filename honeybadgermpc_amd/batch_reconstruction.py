@@ -104,7 +104,10 @@ async def batch_reconstruct(secret_shares, p, t, n, myid, send, recv, config=Non
     try:
         recons_r2 = await incremental_decode(data_r1, enc, dec, robust_dec, num_chunks, t, degree, n)
     except asyncio.CancelledError:
+        # deliberate divergence: the reference swallows the cancellation and falls through with recons_r2 unbound
+        # (batch_reconstruction.py:178-183); here the background tasks are cancelled and the cancellation propagates
         cancel_all()
+        raise
     if recons_r2 is None:
         logging.error("[BatchReconstruct] P1 reconstruction failed!")
         return None
@@ -123,6 +126,7 @@ async def batch_reconstruct(secret_shares, p, t, n, myid, send, recv, config=Non
         recons_p = await incremental_decode(data_r2, enc, dec, robust_dec, num_chunks, t, degree, n)
     except asyncio.CancelledError:
         cancel_all()
+        raise
     if recons_p is None:
         logging.error("[BatchReconstruct] P2 reconstruction failed!")
         return None

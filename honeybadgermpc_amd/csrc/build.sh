@@ -8,6 +8,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -Wno-unused-result"
 python3 "$HERE/gen_fused.py" > /dev/null
 python3 "$HERE/gen_mm8.py" > /dev/null
+python3 "$HERE/gen_mm8w.py" > /dev/null
 objs=""
 pids=""
 for src in "$HERE"/*.hip; do

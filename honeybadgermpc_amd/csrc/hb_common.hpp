@@ -17,6 +17,7 @@
 namespace hb {
 struct FastMatrix;
 struct Mm8Matrix;
+struct Mm8wMatrix;
 }
 namespace hb {
 
@@ -42,6 +43,8 @@ struct hb_matrix {
     size_t words;
     bool cached;        // created through the ctx cache (hb_vand_matrix_create / hb_vand_inverse_create)
     int refs;           // handles outstanding: one per create call that returned it, plus one while the cache holds it
+    hb::Mm8wMatrix *wide;   // int8 matrix-core image (hb_mfma_wide.hip), built on first use; nullptr when it does not apply
+    bool wide_tried;
 };
 
 namespace hb {
@@ -178,6 +181,15 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
                uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                int64_t C, hipStream_t s, uint32_t *copy_dst = nullptr, hb_view cpv = hb_view{0, 0}, int64_t copy_count = 0,
                int copy_rows = 0, const int32_t *check_rows_dev = nullptr);
+
+// ---- matrix-core mat-vec for full-size entries, hb_mfma_wide.hip ----------------------------------------
+int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8wMatrix **out, hipStream_t s);
+void mm8w_free(Mm8wMatrix *m);
+int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
+                uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+                int64_t C, hipStream_t s);
+// the wide image of a generic matrix, built on first use (nullptr when the path does not apply)
+const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *m, hipStream_t s);
 
 // dispatch on element width
 #define HB_DISPATCH(ctx, EXPR_W, EXPR_N)                                                          \

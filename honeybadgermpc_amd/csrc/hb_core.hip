@@ -361,6 +361,7 @@ void matrix_unref(hb_matrix *m) {
     if (!m) return;
     if (--m->refs > 0) return;
     (void)hipFree(m->dev);
+    mm8w_free(m->wide);
     delete m;
 }
 
@@ -391,7 +392,7 @@ int get_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStr
 
 int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out) {
     hb_matrix *m = new hb_matrix();
-    m->ctx = ctx; m->n_out = n_out; m->n_in = n_in; m->cached = false; m->refs = 1;
+    m->ctx = ctx; m->n_out = n_out; m->n_in = n_in; m->cached = false; m->refs = 1; m->wide = nullptr; m->wide_tried = false;
     m->words = (size_t)m_tiles(n_out) * (size_t)n_in * OT * (size_t)ctx->nl();
     if (m->words == 0) m->words = 1;
     hipError_t e = hipMalloc(&m->dev, m->words * sizeof(uint32_t));
@@ -549,7 +550,7 @@ int vinv_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_dev, in
         HB_HIP(ctx, hipMemcpyAsync(&singular, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost, s));
         HB_HIP(ctx, hipStreamSynchronize(s));
     }
-    if (singular) { (void)hipFree(m->dev); delete m; return fail(ctx, HB_ERR_SINGULAR, "Interpolation failed"); }
+    if (singular) { m->refs = 1; matrix_unref(m); return fail(ctx, HB_ERR_SINGULAR, "Interpolation failed"); }
     m->cached = true; ctx->mcache[key] = m; *out = m;
     cache_note(ctx, "m|" + key, [ctx, key]() { auto f = ctx->mcache.find(key); if (f != ctx->mcache.end()) { hb_matrix *mm = f->second; ctx->mcache.erase(f); matrix_unref(mm); } });
     return HB_OK;
@@ -641,6 +642,11 @@ int launch_matvec(hb_ctx *ctx, const hb_matrix *m, const uint32_t *in, hb_view i
                   uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                   int64_t C, hipStream_t s) {
     if (C <= 0 || m->n_out == 0) return HB_OK;
+    // full-size entries on the matrix cores when the shape pays for a wave pass of 16 chunks x 16 rows
+    if (C >= 256 && m->n_in >= 4 && m->n_out >= 4) {
+        const Mm8wMatrix *w = matrix_wide(ctx, m, s);
+        if (w) return launch_mm8w(ctx, w, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s);
+    }
     const int tiles = m_tiles(m->n_out);
     const int64_t groups = (C + 63) / 64;
     const int64_t n_waves = groups * tiles;
@@ -659,6 +665,19 @@ int launch_matvec(hb_ctx *ctx, const hb_matrix *m, const uint32_t *in, hb_view i
     }
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;
+}
+
+const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *cm, hipStream_t s) {
+    hb_matrix *m = const_cast<hb_matrix *>(cm);
+    if (m->wide_tried) return m->wide;
+    m->wide_tried = true;
+    if (ctx->n_limbs != 4 || getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE")) return nullptr;
+    std::vector<uint64_t> host((size_t)m->n_out * m->n_in * 4);
+    if (hb_matrix_to_host(ctx, m, host.data(), (void *)s) != HB_OK) return nullptr;
+    Mm8wMatrix *w = nullptr;
+    if (mm8w_from_host(ctx, host.data(), m->n_out, m->n_in, &w, s) != HB_OK) return nullptr;
+    m->wide = w;
+    return w;
 }
 
 int launch_copy_view(hb_ctx *ctx, const uint32_t *src, hb_view sv, uint32_t *dst, hb_view dv, int64_t C, int L, int64_t dst_count, hipStream_t s) {
@@ -757,6 +776,16 @@ int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, co
     int rc = fast_table(ctx, "Vf", x_host, n, d, &V, s, &V8); if (rc) return rc;
     hb_view iv{d, 1}, ov{n, 1};
     if (V8) return launch_mm8(ctx, V8, (const uint32_t *)polys_dev, iv, nullptr, INT64_MAX, (uint32_t *)out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
+    if (C >= 256 && n >= 4 && d >= 4 && ctx->n_limbs == 4) {
+        // powers too large for 16 digits (e.g. n = 100, t = 33): the full-size matrix-core kernel over the plain Vandermonde table
+        hb_matrix *Vm = nullptr;
+        rc = hb_vand_matrix_create(ctx, x_host, n, d, &Vm, stream); if (rc) return rc;
+        const Mm8wMatrix *w = matrix_wide(ctx, Vm, s);
+        if (w) rc = launch_mm8w(ctx, w, (const uint32_t *)polys_dev, iv, nullptr, INT64_MAX, (uint32_t *)out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
+        if (w) (void)hipStreamSynchronize(s);          // the handle goes back before the tables could be evicted under the launch
+        matrix_unref(Vm);
+        if (w) return rc;
+    }
     uint32_t *scratch = nullptr;
     rc = fast_scratch(ctx, d, C, &scratch); if (rc) return rc;
     rc = launch_matvec2(ctx, V, nullptr, (const uint32_t *)polys_dev, iv, nullptr, INT64_MAX, scratch,
@@ -805,6 +834,16 @@ int hb_vandermonde_batch_interpolate(hb_ctx *ctx, const uint64_t *x_host, int k,
         (void)hipStreamSynchronize(s);
         (void)hipFree(scaled);
         return rc;
+    }
+    if (C >= 256 && k >= 4 && ctx->n_limbs == 4) {
+        // numerators too large for 16 digits: the full inverse (sorted points) on the full-size matrix-core kernel
+        hb_matrix *Vm = nullptr;
+        rc = hb_vand_inverse_create(ctx, xs.data(), k, &Vm, stream); if (rc) return rc;
+        const Mm8wMatrix *w = matrix_wide(ctx, Vm, s);
+        if (w) rc = launch_mm8w(ctx, w, (const uint32_t *)data_dev, v, perm_dev, INT64_MAX, (uint32_t *)out_dev, v, INT64_MAX, nullptr, nullptr, C, s);
+        if (w) (void)hipStreamSynchronize(s);
+        matrix_unref(Vm);
+        if (w) return rc;
     }
     uint32_t *scratch = nullptr;
     rc = fast_scratch(ctx, k, C, &scratch); if (rc) return rc;

@@ -46,6 +46,12 @@ struct hb_open_plan {
     int ntt_order;               // 0 = mat-vec encodes
     uint32_t *tw;                // twiddles (ctx-owned cache)
     uint32_t *coef_pk;           // [d][max_C] canonical decoded coefficients (NTT input), NTT mode only
+    // entries that are not small integers (omega-power points; powers beyond 2^127 such as n = 100, t = 33): the
+    // full-size matrix-core kernel (hb_mfma_wide.hip) over the plain tables; the plan holds references to ctx tables
+    hb_matrix *Winv;             // full d x d inverse at the arrival set
+    const Mm8wMatrix *Winv8;     // its int8 image, owned by Winv; nullptr: integer-VALU decode
+    hb_matrix *Vw;               // full n x d Vandermonde table (only when the encodes are not NTTs)
+    const Mm8wMatrix *Vw8;       // its int8 image; nullptr: integer-VALU encodes
 };
 
 extern "C" {
@@ -112,6 +118,18 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
             if (pl->Vinv8) PLAN_HIP(hipMalloc(&pl->scaled_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
         }
     }
+    if (!pl->V8 && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
+        // not small integers: full tables on the full-size matrix-core kernel (decode always, encodes unless they are NTTs)
+        std::vector<uint64_t> xz((size_t)d * L);
+        for (int i = 0; i < d; i++) memcpy(&xz[(size_t)i * L], x_host + (size_t)z_host[i] * L, (size_t)L * 8);
+        rc = hb_vand_inverse_create(ctx, xz.data(), d, &pl->Winv, stream); if (rc) goto done;
+        pl->Winv8 = matrix_wide(ctx, pl->Winv, s);
+        if (!pl->ntt_order) {
+            rc = hb_vand_matrix_create(ctx, x_host, n, d, &pl->Vw, stream); if (rc) goto done;
+            pl->Vw8 = matrix_wide(ctx, pl->Vw, s);
+        }
+        if ((pl->Winv8 || pl->Vw8) && !pl->coef_pk) PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+    }
     PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
 #undef PLAN_HIP
@@ -135,6 +153,9 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
     if (pl->V8 && pl->use_v8)
         return launch_mm8(pl->ctx, pl->V8, (const uint32_t *)shares_dev, iv, nullptr, B, (uint32_t *)r1_out_dev, ov, INT64_MAX,
                           nullptr, nullptr, C, s);
+    if (pl->Vw8 && pl->use_v8)
+        return launch_mm8w(pl->ctx, pl->Vw8, (const uint32_t *)shares_dev, iv, nullptr, B, (uint32_t *)r1_out_dev, ov, INT64_MAX,
+                           nullptr, nullptr, C, s);
     return launch_matvec2(pl->ctx, pl->V, nullptr, (const uint32_t *)shares_dev, iv, nullptr, B, pl->in_dg,
                           (uint32_t *)r1_out_dev, ov, INT64_MAX, pl->n, 0, nullptr, nullptr, nullptr, C, s);
 }
@@ -146,8 +167,10 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
     if (pl->ntt_order) {
         // decode to canonical coefficient-major coefficients, validate with an NTT in CHECK mode,
         // then hand the caller the rows it asked for
-        int rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
-                                pl->coef_pk, pm, INT64_MAX, pl->d, 1, nullptr, nullptr, nullptr, C, s);
+        int rc = pl->Winv8 && pl->use_v8
+                     ? launch_mm8w(pl->ctx, pl->Winv8, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->coef_pk, pm, INT64_MAX, nullptr, nullptr, C, s)
+                     : launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
+                                      pl->coef_pk, pm, INT64_MAX, pl->d, 1, nullptr, nullptr, nullptr, C, s);
         if (rc) return rc;
         rc = launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, pl->coef_pk, pm, INT64_MAX, pl->d, pl->n,
                             (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s);
@@ -175,6 +198,15 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
                               INT64_MAX, pl->ones_dev, pl->mismatch_dev, C, s, pk_dst, pv, pk_count, pk_rows, pl->zc_dev);
         return launch_mm8(pl->ctx, pl->V8, pl->coef_pk, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm,
                           INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s, pk_dst, pv, pk_count, pk_rows);
+    }
+    if (pl->Vw8 && pl->Winv8 && pl->use_v8) {
+        // full-size entries, mat-vec encodes: decode, validating re-encode of all n points compared in the epilogue, hand-off
+        int rc = launch_mm8w(pl->ctx, pl->Winv8, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->coef_pk, pm, INT64_MAX, nullptr, nullptr, C, s);
+        if (rc) return rc;
+        rc = launch_mm8w(pl->ctx, pl->Vw8, pl->coef_pk, pm, nullptr, INT64_MAX, (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX,
+                         pl->mask_dev, pl->mismatch_dev, C, s);
+        if (rc) return rc;
+        return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
     }
     // one launch when the shapes allow it (decode + validating re-encode of the same 64-chunk group)
     int rc = launch_decode_check(pl->ctx, pl->Vinv, pl->V, (const uint32_t *)cols_dev, pm, pl->z_dev, pk_dst, pv, pk_count, pk_rows,
@@ -246,7 +278,7 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
 int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) {
     if (!pl || !value) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { *value = pl->validate_arrived_only; return HB_OK; }
-    if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = (pl->V8 && pl->use_v8) ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = ((pl->V8 || pl->Winv8 || pl->Vw8) && pl->use_v8) ? 1 : 0; return HB_OK; }
     return HB_ERR_BAD_ARG;
 }
 
@@ -262,6 +294,8 @@ void hb_open_plan_destroy(hb_open_plan *pl) {
     if (pl->ones_dev) (void)hipFree(pl->ones_dev);
     fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8); mm8_free(pl->Vinv8); mm8_free(pl->Vzc8);
     if (pl->scaled_pk) (void)hipFree(pl->scaled_pk);
+    if (pl->Winv) matrix_unref(pl->Winv);
+    if (pl->Vw) matrix_unref(pl->Vw);
     delete pl;
 }
 

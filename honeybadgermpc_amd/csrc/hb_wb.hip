@@ -58,7 +58,8 @@ template <int NL, int NW>
 __global__ void __launch_bounds__(WB_THREADS) k_wb(const FpParams<NL> P, const uint32_t *__restrict__ xm /* [n][NL] mont */,
                                                    const uint32_t *__restrict__ ys, const uint8_t *__restrict__ present,
                                                    int n, int k, int64_t C, uint32_t *__restrict__ scratch, size_t slab_words,
-                                                   uint32_t *__restrict__ coeffs, int32_t *__restrict__ coeff_len, int32_t *__restrict__ status) {
+                                                   uint32_t *__restrict__ coeffs, int32_t *__restrict__ coeff_len, int32_t *__restrict__ status,
+                                                   const uint8_t *__restrict__ done /* codewords already decoded (Gao inside the radius) */) {
     __shared__ uint32_t s_mult[WB_MAXROWS * NL];     // column-j multipliers of every row
     __shared__ uint32_t s_prow[WB_MAXCOLS * NL];     // pivot row / later: solution vector
     __shared__ uint32_t s_dinv[WB_MAXROWS * NL];     // inverse pivots
@@ -73,6 +74,7 @@ __global__ void __launch_bounds__(WB_THREADS) k_wb(const FpParams<NL> P, const u
     uint32_t *M = scratch + (size_t)blockIdx.x * slab_words;
 
     for (int64_t cw = blockIdx.x; cw < C; cw += gridDim.x) {
+        if (done && done[cw]) continue;              // block-uniform
         const uint32_t *y = ys + (size_t)cw * n * NW;
         const uint8_t *pr = present + (size_t)cw * n;
         __syncthreads();
@@ -347,6 +349,30 @@ __global__ void k_points_to_mont(const FpParams<NL> P, const uint32_t *__restric
 
 }  // namespace
 
+// any erasure in the batch?
+__global__ void k_wb_any_erasure(const uint8_t *__restrict__ present, int64_t total, int32_t *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total && present[i] == 0) atomicOr(flag, 1);
+}
+// Gao's coefficient rows -> the reference's outcome for the codewords it decoded: status 0 and the length after
+// stripping trailing zeros (polynomial.py:14-20); the others are left to k_wb
+template <int NW>
+__global__ void k_wb_take_gao(const uint8_t *__restrict__ ok, const uint32_t *__restrict__ coeffs, int k, int64_t C,
+                              int32_t *__restrict__ coeff_len, int32_t *__restrict__ status) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C || !ok[c]) return;
+    int len = k;
+    while (len > 0) {
+        const uint32_t *e = coeffs + ((size_t)c * k + (len - 1)) * NW;
+        uint32_t o = 0;
+        for (int q = 0; q < NW; q++) o |= e[q];
+        if (o) break;
+        len--;
+    }
+    coeff_len[c] = len;
+    status[c] = 0;
+}
+
 extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, const uint64_t *ys_dev,
                             const uint8_t *present_dev, int64_t C, uint64_t *coeffs_dev, int32_t *coeff_len_dev,
                             int32_t *status_dev, void *stream) {
@@ -366,16 +392,45 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
     // worst-case slab: (n+1) rows x (2e+k+2) columns with e <= (n - k + 1) / 2
     const int emax = (n - (k - 1)) / 2;
     const size_t slab_words = (size_t)(n + 1) * (size_t)(2 * emax + k + 2) * NLr;
+    // Inside the unique-decoding radius the reference's answer is the closest codeword's polynomial whatever the solver
+    // (SURVEY appendix C): a codeword with at most floor((n' - k) / 2) errors is decoded by the Gao kernel (hb_gao.hip),
+    // three orders of magnitude cheaper than an (n+1) x (2e+k+2) elimination, and only what it rejects -- where the
+    // reference's particular solution, its descending-e' loop and its two failure messages matter -- goes through the
+    // row reduction below.  Batches with erasures (per-codeword point sets) take the row reduction throughout.
+    uint8_t *gao_ok = nullptr;
+    if (!getenv("HB_WB_NO_GAO") && n - k >= 1 && 2 * (k - 1) + 1 <= n) {
+        int32_t erased = 0;
+        HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), s));
+        const int64_t tot = C * n;
+        k_wb_any_erasure<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(present_dev, tot, ctx->flag_dev);
+        HB_LAUNCH_CHECK(ctx);
+        HB_HIP(ctx, hipMemcpyAsync(&erased, ctx->flag_dev, sizeof erased, hipMemcpyDeviceToHost, s));
+        HB_HIP(ctx, hipStreamSynchronize(s));
+        if (!erased) {
+            uint32_t *errloc = nullptr;
+            int32_t *errlen = nullptr;
+            HB_HIP(ctx, hipMalloc(&gao_ok, (size_t)C));
+            HB_HIP(ctx, hipMalloc(&errloc, (size_t)C * (n + 1) * ctx->elem_words() * 4));
+            HB_HIP(ctx, hipMalloc(&errlen, (size_t)C * sizeof(int32_t)));
+            rc = hb_gao_decode(ctx, x_host, n, k, ys_dev, C, coeffs_dev, (uint64_t *)errloc, errlen, gao_ok, stream);
+            (void)hipFree(errloc); (void)hipFree(errlen);
+            if (rc) { (void)hipFree(gao_ok); (void)hipFree(xd); (void)hipFree(xm); return rc; }
+            if (ctx->n_limbs == 4) k_wb_take_gao<8><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev);
+            else k_wb_take_gao<2><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev);
+            HB_LAUNCH_CHECK(ctx);
+        }
+    }
     int64_t blocks = C < 1024 ? C : 1024;
     uint32_t *scratch = nullptr;
     HB_HIP(ctx, hipMalloc(&scratch, slab_words * 4 * (size_t)blocks));
     HB_DISPATCH(ctx,
         (k_wb<9, 8><<<(unsigned)blocks, WB_THREADS, 0, s>>>(ctx->pw, xm, (const uint32_t *)ys_dev, present_dev, n, k, C, scratch, slab_words,
-                                                          (uint32_t *)coeffs_dev, coeff_len_dev, status_dev)),
+                                                          (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, gao_ok)),
         (k_wb<3, 2><<<(unsigned)blocks, WB_THREADS, 0, s>>>(ctx->pn, xm, (const uint32_t *)ys_dev, present_dev, n, k, C, scratch, slab_words,
-                                                          (uint32_t *)coeffs_dev, coeff_len_dev, status_dev)));
+                                                          (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, gao_ok)));
     HB_LAUNCH_CHECK(ctx);
     HB_HIP(ctx, hipStreamSynchronize(s));
+    if (gao_ok) HB_HIP(ctx, hipFree(gao_ok));
     HB_HIP(ctx, hipFree(scratch));
     HB_HIP(ctx, hipFree(xd));
     HB_HIP(ctx, hipFree(xm));

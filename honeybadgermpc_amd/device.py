@@ -220,7 +220,8 @@ class DeviceIncrementalDecoder:
         point = EvalPoint(GF(modulus), n, use_omega_powers=use_omega_powers)
         self.x = [point(i).value for i in range(n)]
         self._xh_all = ctx.host_elems(self.x)
-        self._cols = ctx.empty(n * self.batch_size).view(n, self.batch_size, 4)
+        self.L = ctx.n_limbs
+        self._cols = ctx.empty(n * self.batch_size).view(n, self.batch_size, self.L)
         self._confirmed_errors = set() if confirmed_errors is None else confirmed_errors
         self._available_points = set()
         self._z = []
@@ -228,7 +229,7 @@ class DeviceIncrementalDecoder:
         self._guess_decoded = None      # (C, d, 4)
         self._guess_encoded = None      # (n, C, 4)
         self._num_decoded = 0
-        self._partial = ctx.empty(self.batch_size * (self.degree + 1)).view(self.batch_size, self.degree + 1, 4)
+        self._partial = ctx.empty(self.batch_size * (self.degree + 1)).view(self.batch_size, self.degree + 1, self.L)
         self._result = None
         self.launches = 0               # robust-decode launches so far (diagnostic)
 
@@ -246,8 +247,8 @@ class DeviceIncrementalDecoder:
         ctx.check(ctx.lib.hb_vandermonde_batch_interpolate(ctx.h, np_ptr(xz), d, ctx.ptr(rows), c, ctx.ptr(dec), ctx.stream()), "interpolate")
         enc = ctx.empty(c * n)
         ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), n, ctx.ptr(dec), c, d, ctx.ptr(enc), ctx.stream()), "evaluate")
-        self._guess_decoded = dec.view(c, d, 4)
-        self._guess_encoded = enc.view(c, n, 4).transpose(0, 1).contiguous()
+        self._guess_decoded = dec.view(c, d, self.L)
+        self._guess_encoded = enc.view(c, n, self.L).transpose(0, 1).contiguous()
 
     def _robust_batch(self, limit=None):
         """Gao over the remaining polynomials (the first `limit` of them) and the current arrival set:
@@ -257,7 +258,7 @@ class DeviceIncrementalDecoder:
         crem = self.batch_size - lo if limit is None else min(limit, self.batch_size - lo)
         rows = self._rows(lo)[:crem].contiguous()
         co = ctx.empty(crem * d)
-        el = t.zeros((crem * (npts + 1), 4), dtype=t.int64, device=ctx.tdev)
+        el = t.zeros((crem * (npts + 1), self.L), dtype=t.int64, device=ctx.tdev)
         ln = t.zeros(crem, dtype=t.int32, device=ctx.tdev)
         ok = t.zeros(crem, dtype=t.uint8, device=ctx.tdev)
         xz = ctx.host_elems([self.x[i] for i in self._z])
@@ -267,11 +268,11 @@ class DeviceIncrementalDecoder:
         # roots of the error locator among ALL party points are the faulty senders (reference :174-184); a locator of
         # length <= 1 names nobody.  Entries past the locator's length are not part of it.
         keep = t.arange(npts + 1, device=ctx.tdev).unsqueeze(0) < ln.unsqueeze(1)
-        el = (el.view(crem, npts + 1, 4) * keep.unsqueeze(2)).contiguous()
+        el = (el.view(crem, npts + 1, self.L) * keep.unsqueeze(2)).contiguous()
         ev = ctx.empty(crem * n)
         ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), n, ctx.ptr(el), crem, npts + 1, ctx.ptr(ev), ctx.stream()), "evaluate")
-        errs = (ev.view(crem, n, 4) == 0).all(dim=2) & (ln > 1).unsqueeze(1) & ok.unsqueeze(1)
-        return ok, co.view(crem, d, 4), errs
+        errs = (ev.view(crem, n, self.L) == 0).all(dim=2) & (ln > 1).unsqueeze(1) & ok.unsqueeze(1)
+        return ok, co.view(crem, d, self.L), errs
 
     # -- the state machine (reference :288-372) ------------------------------------------------------
     def _min_points_required(self):
@@ -332,7 +333,7 @@ class DeviceIncrementalDecoder:
             if len(column) != self.batch_size:
                 raise ValueError("Incorrect length of data")
             column = self.ctx.upload_ints(column)
-        if tuple(column.shape) != (self.batch_size, 4):
+        if tuple(column.shape) != (self.batch_size, self.L):
             raise ValueError("Incorrect length of data")
         self._available_points.add(idx)
         self._z.append(idx)

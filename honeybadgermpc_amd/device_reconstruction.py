@@ -14,6 +14,7 @@ The transport (router, sockets, authentication) is the caller's, as in the refer
 """
 import asyncio
 import logging
+import struct
 
 from . import wire
 from ._capi import Context
@@ -29,9 +30,15 @@ async def _incremental_decode_device(receivers, make_decoder, device):
     inc = make_decoder()
     async for idx, blob in fetch_one(receivers):
         try:
-            column = wire.wire_to_tensor(blob, device)
-            inc.add(idx, column)
-        except ValueError:
+            if isinstance(blob, (list, tuple)):
+                # a reference-style party in a mixed deployment: a list of Python ints (batch_reconstruction.py:165-167)
+                if not all(type(v) is int and v >= 0 for v in blob):
+                    raise ValueError("column of non-integers")
+                inc.add(idx, list(blob))
+            else:
+                inc.add(idx, wire.wire_to_tensor(blob, device))
+        except (ValueError, TypeError, OverflowError, struct.error):
+            # one Byzantine sender must not abort an honest party's open: whatever it sent, it is not a column
             logging.error("[BatchReconstructDevice] malformed column from %d dropped", idx)
             continue
         if inc.done():
@@ -69,7 +76,7 @@ async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_
         return DeviceIncrementalDecoder(p, n, t, degree=degree, batch_size=c, use_omega_powers=use_omega_powers, device=ctx.device)
 
     # R1: every chunk evaluated at the n points; row j of the party-major result is party j's message
-    encoded = op.r1_encode(shares).view(n, c, 4).cpu()
+    encoded = op.r1_encode(shares).view(n, c, ctx.n_limbs).cpu()
     for dest in range(n):
         send(dest, ("R1", wire.tensor_to_wire(encoded[dest])))
 
@@ -77,7 +84,10 @@ async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_
     try:
         recons_r2 = await _incremental_decode_device(data_r1, make_decoder, ctx.tdev)
     except asyncio.CancelledError:
+        # the reference falls through here with recons_r2 unbound (batch_reconstruction.py:178-183); cancelling the
+        # open must cancel it: clean up and let the cancellation propagate
         cancel_all()
+        raise
     if recons_r2 is None:
         logging.error("[BatchReconstructDevice] P1 reconstruction failed!")
         cancel_all()
@@ -93,8 +103,9 @@ async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_
         recons_p = await _incremental_decode_device(data_r2, make_decoder, ctx.tdev)
     except asyncio.CancelledError:
         cancel_all()
+        raise
     cancel_all()
     if recons_p is None:
         logging.error("[BatchReconstructDevice] P2 reconstruction failed!")
         return None
-    return recons_p.reshape(c * d, 4)[:b].contiguous()
+    return recons_p.reshape(c * d, ctx.n_limbs)[:b].contiguous()

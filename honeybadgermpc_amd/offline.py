@@ -26,7 +26,8 @@ def random_elements(modulus, count, generator=None, device=None):
     bits = modulus.bit_length()
     top = (bits - 1) // 64                    # highest limb in use
     top_mask = (1 << (bits - 64 * top)) - 1
-    p_limbs = [(modulus >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)]
+    nl = ctx.n_limbs
+    p_limbs = [(modulus >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(nl)]
     sign = 1 << 63
 
     def as_i64(v):                            # the int64 with the same bits
@@ -35,14 +36,14 @@ def random_elements(modulus, count, generator=None, device=None):
     out, have = [], 0
     while have < count:
         want = max(1024, int((count - have) * 1.3) + 16)
-        cand = t.randint(-(1 << 63), (1 << 63) - 1, (want, 4), dtype=t.int64, device=ctx.tdev, generator=generator)
+        cand = t.randint(-(1 << 63), (1 << 63) - 1, (want, nl), dtype=t.int64, device=ctx.tdev, generator=generator)
         cand[:, top] &= as_i64(top_mask)
-        for j in range(top + 1, 4):
+        for j in range(top + 1, nl):
             cand[:, j] = 0
         # unsigned lexicographic cand < p from the top limb down (x ^ sign turns unsigned order into signed order)
         less = t.zeros(want, dtype=t.bool, device=ctx.tdev)
         equal = t.ones(want, dtype=t.bool, device=ctx.tdev)
-        for j in range(3, -1, -1):
+        for j in range(nl - 1, -1, -1):
             cj = cand[:, j] ^ as_i64(sign)
             pj = as_i64(p_limbs[j] ^ sign)
             less |= equal & (cj < pj)
@@ -70,9 +71,9 @@ class ShareDealer:
     def deal_secrets(self, secrets, generator=None):
         """Random degree-t polynomials with the given constant terms (a (k, 4) tensor) -> ([n][k] shares, coeffs)."""
         k = secrets.shape[0]
-        coeffs = random_elements(self.ctx.modulus, k * self.d, generator, self.ctx.device).view(k, self.d, 4)
+        coeffs = random_elements(self.ctx.modulus, k * self.d, generator, self.ctx.device).view(k, self.d, self.ctx.n_limbs)
         coeffs[:, 0, :] = secrets
-        coeffs = coeffs.reshape(k * self.d, 4).contiguous()
+        coeffs = coeffs.reshape(k * self.d, self.ctx.n_limbs).contiguous()
         return self.deal(coeffs), coeffs
 
 
@@ -111,13 +112,13 @@ class HyperInvertible:
     def check(self, shares, degree):
         t = self.ctx.torch
         n, k = self.n, shares.shape[0] // self.n
-        rows = shares.view(n, k, 4).transpose(0, 1).contiguous().view(k * n, 4)     # [k][n]: one polynomial's points per row
+        rows = shares.view(n, k, self.ctx.n_limbs).transpose(0, 1).contiguous().view(k * n, self.ctx.n_limbs)     # [k][n]: one polynomial's points per row
         coeffs = self.ctx.empty(k * n)
         rc = self.ctx.lib.hb_vandermonde_batch_interpolate(self.ctx.h, np_ptr(self._xh), n, self.ctx.ptr(rows), k, self.ctx.ptr(coeffs), self.ctx.stream())
         self.ctx.check(rc, "hb_vandermonde_batch_interpolate")
-        nz = (coeffs.view(k, n, 4) != 0).any(dim=2)                                 # [k][n] coefficient is non-zero
+        nz = (coeffs.view(k, n, self.ctx.n_limbs) != 0).any(dim=2)                                 # [k][n] coefficient is non-zero
         ok = bool(nz[:, degree].all().item()) and not bool(nz[:, degree + 1 :].any().item())
-        return ok, coeffs.view(k, n, 4)[:, 0, :].contiguous()
+        return ok, coeffs.view(k, n, self.ctx.n_limbs)[:, 0, :].contiguous()
 
     def __del__(self):
         try:

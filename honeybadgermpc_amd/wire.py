@@ -29,7 +29,13 @@ def pack_limbs(limbs):
 
 
 def unpack_limbs(blob):
-    """bytes -> (count, n_limbs) uint64 ndarray (a view on the message body)"""
+    """bytes -> (count, n_limbs) uint64 ndarray (a view on the message body).
+    Anything that is not a well-formed message -- including a payload that is not bytes-like at all, which an
+    untrusted peer behind an unpickling transport can send -- raises ValueError."""
+    if not isinstance(blob, (bytes, bytearray, memoryview)):
+        raise ValueError(f"packed message must be bytes-like, got {type(blob).__name__}")
+    if isinstance(blob, memoryview):
+        blob = blob.tobytes()
     if len(blob) < HEADER.size:
         raise ValueError("truncated message")
     magic, limbs, count = HEADER.unpack_from(blob, 0)

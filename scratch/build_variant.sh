@@ -9,6 +9,7 @@ OBJ="$SRC/.obj_$NAME"
 mkdir -p "$OBJ"
 python3 "$SRC/gen_fused.py" > /dev/null
 python3 "$SRC/gen_mm8.py" > /dev/null
+python3 "$SRC/gen_mm8w.py" > /dev/null
 pids=""
 for src in "$SRC"/*.hip; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -Wno-unused-result "$@" -c "$src" -o "$OBJ/$(basename "${src%.hip}").o" &

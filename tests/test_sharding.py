@@ -26,6 +26,94 @@ def test_shard_bounds_cover_exactly():
     assert abs((hi - lo) - (1 << 20) / 8) <= 22
 
 
+class OracleOpener:
+    """CPU stand-in with device.BatchOpen's interface (tensors of 4 x u64 limbs viewed as int64), computing with the oracle:
+    lets the gloo test run honeybadgermpc_amd.sharding.ShardedOpen -- the code bench.py --workload cfg5 runs -- without a GPU."""
+
+    def __init__(self, p, n, t, max_shares=0, z=None, zc=None, use_omega_powers=False, degree=None, device=None):
+        import oracle
+
+        assert not use_omega_powers
+        self.o, self.p, self.n, self.t = oracle, p, n, t
+        self.d = (t if degree is None else degree) + 1
+        self.x = list(range(1, n + 1))
+        self.z = list(range(self.d)) if z is None else list(z)
+        self.zc = [i for i in range(n) if i not in self.z][:t] if zc is None else list(zc)
+        self.fine = True
+
+    def _ints(self, tensor):
+        import numpy as np
+
+        return self.o._ints(tensor.numpy().view(np.uint64))
+
+    def _tensor(self, values):
+        import numpy as np
+
+        return torch.from_numpy(self.o._limbs(values, self.p).view(np.int64).copy())
+
+    def r1_encode(self, shares, out=None):
+        vals = self._ints(shares)
+        c = (len(vals) + self.d - 1) // self.d
+        rows = [(vals[i * self.d : (i + 1) * self.d] + [0] * self.d)[: self.d] for i in range(c)]
+        enc = self.o.vandermonde_batch_evaluate(self.x, rows, self.p)                # [c][n]
+        return self._tensor([enc[k][j] for j in range(self.n) for k in range(c)])    # party-major [n][c]
+
+    def _decode(self, cols, b):
+        vals = self._ints(cols)
+        c = (b + self.d - 1) // self.d
+        col = lambda j: vals[j * c : (j + 1) * c]  # noqa: E731
+        data = [[col(j)[k] for j in self.z] for k in range(c)]
+        coef = self.o.vandermonde_batch_interpolate([self.x[j] for j in self.z], data, self.p)
+        enc = self.o.vandermonde_batch_evaluate(self.x, coef, self.p)
+        for j in self.zc:
+            if any(enc[k][j] != col(j)[k] for k in range(c)):
+                self.fine = False
+        return coef
+
+    def r1_decode(self, r1_cols, b, out=None):
+        return self._tensor([row[0] for row in self._decode(r1_cols, b)])
+
+    def r2_decode(self, r2_cols, b, out=None):
+        return self._tensor([v for row in self._decode(r2_cols, b) for v in row][:b])
+
+    def ok(self):
+        fine, self.fine = self.fine, True
+        return fine
+
+
+def _worker_sharded_open(rank, world, port, b, n, t, shares, r1_cols, r2_cols, expect, mode, ret):
+    """rank's slice through sharding.ShardedOpen (stand-in opener), then the data-path gather"""
+    import numpy as np
+
+    import oracle
+    from honeybadgermpc_amd.sharding import ShardedOpen
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = t + 1
+    z, zc = list(range(1, d + 1)), list(range(d + 1, min(n, d + 1 + t)))
+    so = ShardedOpen(BLS, n, t, b, gather_mode=mode, make_opener=OracleOpener, z=z, zc=zc)
+    to_t = lambda vals: torch.from_numpy(oracle._limbs(vals, BLS).view(np.int64).copy())  # noqa: E731
+    clo, chi = so.chunk_lo, so.chunk_lo + so.chunks
+    mine = to_t(shares[so.lo : so.hi])
+    r1 = so.r1_encode(mine)
+    assert r1.shape[0] == n * so.chunks
+    msg = so.r1_decode(to_t([v for col in r1_cols for v in col[clo:chi]]))
+    res = so.r2_decode(to_t([v for col in r2_cols for v in col[clo:chi]]))
+    ok = so.ok() and msg.shape[0] == so.chunks and res.shape[0] == so.hi - so.lo
+    full = so.gather(res)
+    got = oracle._ints(full.numpy().view(np.uint64))
+    # a corrupted validated column on ONE rank is reported by that rank only
+    bad = [list(col) for col in r2_cols]
+    if rank == 1 and so.chunks:
+        bad[zc[0]][clo] = (bad[zc[0]][clo] + 1) % BLS
+    so.r2_decode(to_t([v for col in bad for v in col[clo:chi]]))
+    flagged = not so.ok()
+    ret[rank] = bool(ok and got == expect and flagged == (rank == 1 and so.chunks > 0))
+    dist.destroy_process_group()
+
+
 def _worker(rank, world, port, b, d, n, t, shares, r1_cols, r2_cols, expect, ret):
     import numpy as np
 
@@ -81,3 +169,36 @@ def test_two_rank_sharded_open_matches_unsharded():
         p.join(120)
         assert p.exitcode == 0
     assert ret[0] and ret[1]
+
+
+@pytest.mark.parametrize("mode,world,b", [("direct", 2, 50), ("collective", 2, 50), ("direct", 3, 31), ("collective", 3, 31), ("direct", 2, 48)])
+def test_sharded_open_class_on_gloo(mode, world, b):
+    """the class bench.py --workload cfg5 and the GPU test drive, with a CPU stand-in opener: uneven slices, both gathers"""
+    import oracle
+
+    rnd = random.Random(9 + b)
+    n, t = 7, 2
+    d = t + 1
+    c = (b + d - 1) // d
+    x = list(range(1, n + 1))
+    polys1 = [[rnd.randrange(BLS) for _ in range(d)] for _ in range(c)]
+    polys2 = [[rnd.randrange(BLS) for _ in range(d)] for _ in range(c)]
+    e1 = oracle.vandermonde_batch_evaluate(x, polys1, BLS)
+    e2 = oracle.vandermonde_batch_evaluate(x, polys2, BLS)
+    r1_cols = [[e1[k][j] for k in range(c)] for j in range(n)]
+    r2_cols = [[e2[k][j] for k in range(c)] for j in range(n)]
+    shares = [rnd.randrange(BLS) for _ in range(b)]
+    expect = [v for row in polys2 for v in row][:b]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_sharded_open, args=(r, world, port, b, n, t, shares, r1_cols, r2_cols, expect, mode, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret[r] for r in range(world))
