@@ -23,6 +23,10 @@ import os
 import sys
 import time
 
+# the CPU baseline's OpenMP threads: pinned, one per core (must be set before the OpenMP runtime starts)
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 import numpy as np
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -37,8 +41,11 @@ WORKLOADS = {
     "cfg3-omega": (64, 21, 1 << 20, True),   # same with omega-power evaluation points
     "cfg2": (16, 5, 65536 * 6, True),        # 65 536 polynomials x 6 coefficients
     "cfg5-shard": (256, 85, (1 << 22) // 8, True),  # one GPU's 1/8 shard of config 5
+    "cfg5": (256, 85, 1 << 22, True),        # BASELINE config 5: ONE 2^22-share open sharded over the ranks (strong scaling) + all-gather
+    "cfg5-mini": (256, 85, 1 << 16, True),   # the sharded mode at test size
     "tiny": (4, 1, 256, False),
 }
+SHARDED = {"cfg5", "cfg5-mini"}                           # total work fixed: the batch is split with sharding.shard_bounds, the opened shares are all-gathered
 
 
 def rand_elements(torch, count, gen):
@@ -92,6 +99,42 @@ def make_inputs(torch, ctx, n, t, B, use_omega, seed):
     ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(sec_pad), HbView(d, 1), None, ctx.ptr(r2_cols), HbView(1, C), C, ctx.stream()), "r2cols")
     torch.cuda.synchronize()
     del shares_all, coef
+    return shares0, r1_cols, r2_cols, secrets, x
+
+
+def make_inputs_light(torch, ctx, n, t, B, use_omega, seed):
+    """Consistent inputs for one party in O(n C) memory (make_inputs builds all n parties' share vectors, O(n B): 34 GB at
+    config 5).  What the open consumes is fixed by two families of degree-t polynomials per chunk c:
+        S_c = the chunk of the secrets as coefficients      -> r2_cols[j][c] = S_c(x_j)   (party j's R2 broadcast)
+        G_c with G_c(0) = S_c(x_0)                          -> r1_cols[j][c] = G_c(x_j)   (party j's R1 message to party 0;
+                                                                G_c(x_i) = sum_m share_i[c d + m] x_0^m in the protocol)
+    and by this party's own shares, which only feed the R1 encode.  Same arithmetic, same checks as make_inputs."""
+    from honeybadgermpc_amd._capi import HbView, np_ptr
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+
+    lib = ctx.lib
+    d = t + 1
+    C = (B + d - 1) // d
+    point = EvalPoint(GF(BLS), n, use_omega_powers=use_omega)
+    x = [point(i).value for i in range(n)]
+    xh = ctx.host_elems(x)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    secrets = rand_elements(torch, B, gen)
+    shares0 = rand_elements(torch, B, gen)
+    pad = C * d - B
+    sec_pad = secrets if not pad else torch.cat([secrets, torch.zeros((pad, 4), dtype=torch.int64, device="cuda")])
+    V = ctypes.c_void_p()
+    ctx.check(lib.hb_vand_matrix_create(ctx.h, np_ptr(xh), n, d, ctypes.byref(V), ctx.stream()), "V")
+    r2_cols = ctx.empty(n * C)
+    ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(sec_pad), HbView(d, 1), None, ctx.ptr(r2_cols), HbView(1, C), C, ctx.stream()), "r2cols")
+    g = rand_elements(torch, d * C, gen)                 # coefficient-major [d][C]
+    g[:C] = r2_cols[:C]                                  # constant terms: G_c(0) = S_c(x_0) = party 0's own R2 broadcast
+    r1_cols = ctx.empty(n * C)
+    ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(g), HbView(1, C), None, ctx.ptr(r1_cols), HbView(1, C), C, ctx.stream()), "r1cols")
+    torch.cuda.synchronize()
+    lib.hb_matrix_destroy(V)
     return shares0, r1_cols, r2_cols, secrets, x
 
 
@@ -175,6 +218,7 @@ def cpu_baseline(n, t, use_omega, sample_b, seed=7):
     while th >= 1:
         tried.append(th)
         th //= 2
+    scaling = {}
     for th in tried:
         oracle.SetNumThreads(th)
         el = None
@@ -184,9 +228,14 @@ def cpu_baseline(n, t, use_omega, sample_b, seed=7):
                                                         ctypes.c_long(cal_c), cal_d, oracle._ptr(cal_out))
             e1 = time.perf_counter() - t0
             el = e1 if el is None else min(el, e1)
+        scaling[th] = cal_c * n * cal_d / el / 1e6        # M modular multiplications per second of the calibration encode
         if best is None or el < best:
             best, cores = el, th
     oracle.SetNumThreads(cores)
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None
+    scaling_txt = ("thread scaling of a 32768-chunk encode, threads -> M mulmod/s: " + ", ".join(f"{th} -> {scaling[th]:.0f}" for th in sorted(scaling))
+                   + f"; 1 thread = {scaling[1]:.0f} M mulmod/s; sched_getaffinity = {affinity} CPUs, {phys} physical cores reported, "
+                   + f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}")
     d = t + 1
     C = (sample_b + d - 1) // d
     point = EvalPoint(GF(BLS), n, use_omega_powers=use_omega)
@@ -232,12 +281,132 @@ def cpu_baseline(n, t, use_omega, sample_b, seed=7):
         return {
             "value": sample_b / ntl, "unit": "shares/s", "cores": int(phys), "kind": "port",
             "sample": f"one fault-free per-party open of {sample_b} shares (n={n}, t={t}): the reference's NTL calls (mat_ZZ_p mul / inv, SetNumThreads({phys})) "
-                      f"through our own driver oracle/ntl_open_baseline.cpp, {ntl:.2f} s wall; own C backend for comparison: {sample_b / dt:.0f} shares/s on {cores} threads",
+                      f"through our own driver oracle/ntl_open_baseline.cpp, {ntl:.2f} s wall; own C backend for comparison: {sample_b / dt:.0f} shares/s on {cores} threads; {scaling_txt}",
+            "thread_scaling_Mmulmod_per_s": {str(k): v for k, v in sorted(scaling.items())}, "affinity_cpus": affinity,
         }
     return {
         "value": sample_b / dt, "unit": "shares/s", "cores": int(cores), "kind": "port",
-        "sample": f"one fault-free per-party open of {sample_b} shares (n={n}, t={t}) by oracle/hbmpc_oracle.c (own plain-C + OpenMP backend, {cores} threads = fastest of {tried} on {phys} physical cores), {dt:.2f} s wall; {ntl}",
+        "sample": f"one fault-free per-party open of {sample_b} shares (n={n}, t={t}) by oracle/hbmpc_oracle.c (own plain-C + OpenMP backend, {cores} threads = fastest of {tried} on {phys} physical cores), {dt:.2f} s wall; {ntl}; {scaling_txt}",
+        "thread_scaling_Mmulmod_per_s": {str(k): v for k, v in sorted(scaling.items())}, "affinity_cpus": affinity,
+        "one_thread_shares_per_s_estimate": sample_b / dt * scaling[1] / scaling[cores],
     }
+
+
+def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, use_omega):
+    """BASELINE config 5: ONE open of B shares split over the ranks by chunk (sharding.ShardedOpen), each rank opens its
+    slice, then the opened shares are all-gathered to every rank -- the data-path collective, inside the timed region.
+    Strong scaling: total work is fixed as N grows."""
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.sharding import ShardedOpen
+
+    d = t + 1
+    ctx = Context.get(BLS, local_rank)
+    order = np.random.Generator(np.random.PCG64(2024)).permutation(n).tolist()     # one arrival order: it is one party's open
+    z, zc = order[:d], order[d : d + t]
+    so = ShardedOpen(BLS, n, t, B, gather_mode=args.gather, z=z, zc=zc, use_omega_powers=use_omega, device=local_rank)
+    b_loc, c_loc = so.local_shares, so.chunks
+    shares0, r1_cols, r2_cols, secrets, _ = make_inputs_light(torch, ctx, n, t, b_loc, use_omega, seed=1000 + rank)
+    r1_out, r2_msg, result = ctx.empty(n * c_loc), ctx.empty(c_loc), ctx.empty(b_loc)
+    full = ctx.empty(B)
+
+    def gather(local, out):
+        if world == 1:
+            return local
+        if backend == "gloo":                       # HB_BENCH_SHARE_GPU test hook: stage through the host
+            return so.gather(local.cpu(), out=None).to(local.device)
+        return so.gather(local, out=out)
+
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] for _ in range(4)]
+
+    def step(i=None):
+        if i is not None:
+            evs[0][i].record()
+        so.r1_encode(shares0, out=r1_out)
+        if i is not None:
+            evs[1][i].record()
+        so.r1_decode(r1_cols, out=r2_msg)
+        so.r2_decode(r2_cols, out=result)
+        if i is not None:
+            evs[2][i].record()
+        res = gather(result, full)
+        if i is not None:
+            evs[3][i].record()
+        return res
+
+    for _ in range(args.warmup):
+        step()
+    assert so.ok(), "validation mismatch during warmup"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        got = step(i)
+    ok = so.ok()
+    barrier()
+    dt = time.perf_counter() - t0
+    times = torch.tensor([dt,
+                          sum(a.elapsed_time(b) for a, b in zip(evs[0], evs[2])) / args.steps,
+                          sum(a.elapsed_time(b) for a, b in zip(evs[2], evs[3])) / args.steps,
+                          sum(a.elapsed_time(b) for a, b in zip(evs[0], evs[1])) / args.steps], dtype=torch.float64)
+    if dist is not None:
+        tt = times.to("cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        times = tt.cpu()
+    dt, compute_ms, gather_ms, enc_ms = (float(v) for v in times)
+    assert ok, "validation mismatch in timed region"
+    # what was timed is right: the gathered vector is every rank's secrets in rank order (untimed check)
+    assert torch.equal(result, secrets), "this rank's reconstructed slice differs from its secrets"
+    assert torch.equal(r2_msg, r2_cols[:c_loc]), "R2 message != what party 0 would broadcast"
+    all_secrets = gather(secrets, ctx.empty(B))
+    assert torch.equal(got if world > 1 else result, all_secrets if world > 1 else secrets), "gathered result differs from the gathered secrets"
+
+    if rank == 0:
+        C = (B + d - 1) // d
+        alg_bytes_open = 32 * C * (3 * n + 7 * d)
+        alg_bytes_enc = 32 * c_loc * (d + n)
+        achieved = alg_bytes_enc / (enc_ms * 1e-3) / 1e9
+        out = {
+            "metric": f"shares reconstructed/sec (batch open, n={n} t={t})", "value": B * args.steps / dt, "unit": "shares/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": "u256 (integer mod p): NTT encodes on 29-bit digits, decodes as an exact int8 x int8 -> int32 byte-split GEMM on the matrix cores",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: ONE batch_reconstruct per-party open of B={B} shares, n={n}, t={t}, points=omega^i, p=BLS12-381 r, "
+                            f"chunk-sharded over {world} rank(s) (sharding.shard_bounds), opened shares all-gathered to every rank inside the timed region",
+                "n": n, "t": t, "shares_total": B, "shares_this_rank": b_loc, "chunks_this_rank": c_loc,
+                "parallelism": f"chunk-sharded x{world}; data-path collective = all-gather of the opened shares ({args.gather}: "
+                               + ("one isend/irecv pair per peer, all posted at once" if args.gather == "direct" else "all_gather_into_tensor") + ")",
+                "arrival_order": "seeded random permutation of the parties (first t+1 decode, next t validate), the same on every rank",
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic_from_profiles(args.workload),
+                "kernel": "k_ntt_lds (R1 encode of this rank's slice: order-256 NTT per chunk in LDS)",
+                "algorithmic_bytes_per_launch": alg_bytes_enc, "avg_launch_ms": enc_ms,
+                "note": "integer-ALU bound (radix-2^29 Montgomery butterflies); the decodes run on the matrix cores (k_mm8w)",
+            },
+            "detail": {
+                "compute_ms_per_step_max_over_ranks": compute_ms, "allgather_ms_per_step_max_over_ranks": gather_ms,
+                "allgather_bytes_received_per_rank": 32 * (B - b_loc), "gather_mode": args.gather,
+                "algorithmic_bytes_per_open": alg_bytes_open, "open_algorithmic_GBps": alg_bytes_open / (dt / args.steps) / 1e9,
+                "bit_exact_vs_secrets": True, "matrix_core_path": bool(so.op.uses_matrix_cores()),
+            },
+        }
+        if args.cpu_sample > 0 and world == 1:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, t, use_omega, min(args.cpu_sample, 1 << 17))
+                out["detail"]["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "unit": "shares/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main():
@@ -250,6 +419,8 @@ def main():
     ap.add_argument("--no-two-streams-extra", dest="two_streams_extra", action="store_false",
                     help="skip the secondary (untimed for `value`) two-opens-in-flight measurement")
     ap.add_argument("--no-matrix-cores", action="store_true", help="time the integer-VALU kernels instead of the int8 matrix-core path")
+    ap.add_argument("--gather", default="direct", choices=["direct", "collective"],
+                    help="sharded workloads (cfg5): how the opened slices are all-gathered (per-peer sends on the xGMI mesh / RCCL all_gather)")
     args = ap.parse_args()
 
     import torch
@@ -283,6 +454,8 @@ def main():
 
     n, t, B, use_omega = WORKLOADS[args.workload]
     d = t + 1
+    if args.workload in SHARDED:
+        return main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, use_omega)
     C = (B + d - 1) // d
     ctx = Context.get(BLS, local_rank)
     shares0, r1_cols, r2_cols, secrets, x = make_inputs(torch, ctx, n, t, B, use_omega, seed=1000 + rank)
