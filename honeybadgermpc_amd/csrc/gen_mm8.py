@@ -1,60 +1,60 @@
 #!/usr/bin/env python3
 """Emits hb_mm8_body.inc: the MFMA phases of k_mm8 (hb_mfma.hip) as inline-asm blocks.
 
-Column c of an output is an int8 dot product between the matrix digits (A operand, 16 digits of 4
-terms per K-block) and bytes [c-15, c] of every input element (B operand).  With c - 15 = 4q + rho the
-B operand is dwords q .. q+3 of the element shifted right by rho bytes.
+Column c of an output is an int8 dot product between matrix digits (A operand) and a window of input bytes
+(B operand): col_c = sum_l sum_b M_b[l] X_{c-b}[l].  One v_mfma_i32_16x16x64_i8 contracts 64 products per
+(row, chunk); a lane's 16 B-operand bytes are cut as
 
-The columns are produced in two halves BY SHIFT: half 0 = the columns with rho in {0, 1} (c = 3, 0 mod
-4; 23 of them), half 1 = rho in {2, 3} (c = 1, 2 mod 4; 24).  Within a half each (term block kb, rho)
-group covers the whole element (q = -4 .. 7), so its nine shifted dwords SH_rho[k], k = -1 .. 7, are
-computed exactly once, and consecutive shifts are derived from each other IN PLACE:
-    EA[k] = X[k] ^ 0x80808080                 (rho = 0, or the base of half 1; doubles as the copy out of
-                                               the LDS prefetch buffer)
-    EA'[k] = alignbyte(EA[k+1], EA[k], s)     s = 1 (rho 0 -> 1, rho 2 -> 3) or 2 (base -> rho 2)
-(the next shift is written into the OTHER of two EA sets, so that it can be built while the MFMAs of
-the current group are still reading this one).  A 128-bit MFMA operand must start on an even VGPR, so
-the file exists twice, one register apart: EA (k = -4 .. 9) serves the even q, EB (k = -3 .. 10) the odd
-q; EB is refreshed by 9 v_mov per group.  Every window is then an aligned sub-range of a file and no
-operand is ever assembled per MFMA -- which is what hipcc could not be talked into (3-4 v_mov per
-MFMA), hence the asm.
+    8 TERMS x 8 DIGITS per K-block:  lane (n, g) feeds terms t0 = 8 kb + 2 g and t1 = t0 + 1 of chunk n, the 16 digits of
+    an entry are two groups G (b in [8 G, 8 G + 8)), and with s = c - 7 - 8 G = 4 q + rho the operand is the 8-byte
+    windows [s, s + 7] of both elements: dwords q, q + 1 of each element shifted right by rho bytes.
 
-Schedule of one group: its odd-q MFMAs (EB) interleaved with building the next group's EA set, then its
-even-q MFMAs (EA) interleaved with copying that set into EB (free by then).  Registers v198..v255 are
-reserved for this (clobbers): XB (LDS prefetch of the next term block's element), two A-operand
-buffers, two EA sets, EB.  The accumulators are ordinary "=&v" outputs.
+Why 8 x 8 and not 4 terms x 16 digits (the first version of this kernel): a 16-byte window per element slides over 47
+positions per term block (47 MFMAs per 4 terms = 11.75 per term, 68 % of the K slots useful); 8-byte windows take
+39 positions x 2 groups per 8 terms = 9.75 per term -- 17 % fewer MFMAs -- and, more important for a kernel bound by
+VALU issue, the operand files shrink to one: with the register file laid out [dword k][element e] the operand of window q
+is registers 2 q .. 2 q + 3, ALWAYS even-aligned, so the second copy of the file one register apart (9 v_mov per group)
+is gone, and a lane prepares two elements per group for eight terms instead of one for four: 270 preparation ops per wave
+pass instead of 520.
 
-Hazards handled here (nothing inside an asm string is padded by the compiler): VALU write -> MFMA
-operand needs 2 wait states (every preparation op of a group precedes the last MFMA of the previous
-one, plus s_nop 0); a file is only rewritten after every MFMA that reads it has been issued, the
-registers rewritten first being the ones read by the earliest of those MFMAs; MFMA result -> VALU read
-after the block (s_nop 7 x2 at the end).
+The columns are produced in two halves BY SHIFT: half 0 = rho in {0, 1} (c = 3, 0 mod 4; 23 columns), half 1 = rho in
+{2, 3} (c = 1, 2 mod 4; 24).  Within a half each (K-block, rho) group covers every window of that shift, so its shifted
+dwords SH_rho[k], k = -1 .. 7, are computed once per element:
+    F[k][e] = X_e[k] ^ 0x80808080                       (rho = 0: also the copy out of the LDS prefetch registers)
+    F[k][e] = alignbyte(F[k+1][e], F[k][e], 2)          (rho = 2: in place on that copy)
+    F'[k][e] = alignbyte(F[k+1][e], F[k][e], 1)         (rho 0 -> 1, 2 -> 3: into the OTHER of two file sets, built while the
+                                                          MFMAs of the current group still read this one)
+Registers v180..v255 are reserved (clobbers): XB (LDS prefetch of the next K-block's two elements), two pairs of A-operand
+buffers, two file sets.  The accumulators are ordinary "=&v" outputs.
+
+Hazards handled here (nothing inside an asm string is padded by the compiler): VALU write -> MFMA operand needs 2 wait
+states (every preparation op of a group precedes the last MFMA of the previous one, plus s_nop 0); a file set is only
+rewritten after every MFMA that reads it has been issued; MFMA result -> VALU read after the block (s_nop 7 x2).
 """
 import os
 
 NC = 47
-MAXKB = 8
-XB = 198                   # 8 dwords: LDS prefetch of the next term block's element
-ABUF = [206, 210]          # 4 dwords each
-EA_SETS = [214, 228]       # 14 registers each, k = -4 .. 9; alternate between consecutive groups
-EA_KMIN = -4
-EB0, EB_KMIN = 242, -3     # 14 registers, k = -3 .. 10
-CLOBBER_LO, CLOBBER_HI = 198, 255
+MAXKB = 4                   # K-blocks of 8 terms: d <= 32
+XB = 180                    # 16 dwords: element e dword k at XB + 8 e + k
+ABUF = [[196, 200], [204, 208]]   # [K-block parity][digit group], 4 dwords each
+F_SETS = [212, 234]         # 22 registers each: dword k = -2 .. 8 of element e at base + 2 (k + 2) + e
+F_KMIN = -2
+CLOBBER_LO, CLOBBER_HI = 180, 255
 HALF_RHOS = [(0, 1), (2, 3)]
 
 
-def ea(s, k):
-    assert -4 <= k <= 9
-    return EA_SETS[s] + k - EA_KMIN
+def f(s, k, e):
+    assert -2 <= k <= 8 and e in (0, 1)
+    return F_SETS[s] + 2 * (k - F_KMIN) + e
 
 
-def eb(k):
-    assert -3 <= k <= 10
-    return EB0 + k - EB_KMIN
+def windows(rho):
+    """dword offsets q of the windows s = 4 q + rho in [-7, 31]"""
+    return [q for q in range(-2, 8) if -7 <= 4 * q + rho <= 31]
 
 
 def cols_of(rho):
-    return [c for c in range(NC) if (c - 15) % 4 == rho]
+    return sorted({4 * q + rho + 7 + 8 * g for q in windows(rho) for g in (0, 1)})
 
 
 def half_columns(half):
@@ -62,12 +62,15 @@ def half_columns(half):
 
 
 def lds_loads(kb, xs_op, as_op):
-    ab = ABUF[kb & 1]
-    return [
-        f"ds_read_b128 v[{XB}:{XB + 3}], {xs_op} offset:{(2 * kb) * 1024}",
-        f"ds_read_b128 v[{XB + 4}:{XB + 7}], {xs_op} offset:{(2 * kb + 1) * 1024}",
-        f"ds_read_b128 v[{ab}:{ab + 3}], {as_op} offset:{kb * 1024}",
-    ]
+    """K-block kb: both elements of the lane (2 x 32 bytes) and both digit groups"""
+    a0, a1 = ABUF[kb & 1]
+    out = []
+    for e in (0, 1):
+        for h in (0, 1):
+            out.append(f"ds_read_b128 v[{XB + 8 * e + 4 * h}:{XB + 8 * e + 4 * h + 3}], {xs_op} offset:{((kb * 2 + e) * 2 + h) * 1024}")
+    out.append(f"ds_read_b128 v[{a0}:{a0 + 3}], {as_op} offset:{(kb * 2) * 1024}")
+    out.append(f"ds_read_b128 v[{a1}:{a1 + 3}], {as_op} offset:{(kb * 2 + 1) * 1024}")
+    return out
 
 
 def interleave(mfmas, ops):
@@ -95,69 +98,67 @@ def asm_half(half, nkb):
     ncol = len(cols)
     xs_op, as_op, bias = f"%{ncol}", f"%{ncol + 1}", f"%{ncol + 2}"
     L = []
-    # positions that are read but never written stay zero: k <= -2 and k >= 8
+    # positions that are read but never written stay zero: k = -2 and k = 8
     for s in range(2):
-        for k in (-4, -3, -2, 8, 9):
-            L.append(f"v_mov_b32 v{ea(s, k)}, 0")
-    for k in (-3, -2, 8, 9, 10):
-        L.append(f"v_mov_b32 v{eb(k)}, 0")
+        for k in (-2, 8):
+            for e in (0, 1):
+                L.append(f"v_mov_b32 v{f(s, k, e)}, 0")
     L += lds_loads(0, xs_op, as_op)
     groups = [(kb, rho) for kb in range(nkb) for rho in HALF_RHOS[half]]
 
-    def prep_a(gi):
-        """fill EA set gi & 1 for group gi (reads the other set, or XB for the first shift of a term block)"""
+    def prep(gi):
+        """fill file set gi & 1 for group gi"""
         kb, rho = groups[gi]
         s = gi & 1
         ops = []
-        first = rho == HALF_RHOS[half][0]
-        if first:
+        if rho == HALF_RHOS[half][0]:
             ops.append("s_waitcnt lgkmcnt(0)")
-            for k in range(8):
-                ops.append(f"v_xor_b32 v{ea(s, k)}, 0x80808080, v{XB + k}")
-            ops.append(f"v_mov_b32 v{ea(s, -1)}, 0")
+            for e in (0, 1):
+                for k in range(8):
+                    ops.append(f"v_xor_b32 v{f(s, k, e)}, 0x80808080, v{XB + 8 * e + k}")
+                ops.append(f"v_mov_b32 v{f(s, -1, e)}, 0")
             if rho != 0:                                    # half 1 starts at shift 2: in place, nobody reads this set yet
-                for k in range(-1, 8):
-                    ops.append(f"v_alignbyte_b32 v{ea(s, k)}, v{ea(s, k + 1)}, v{ea(s, k)}, {rho}")
+                for e in (0, 1):
+                    for k in range(-1, 8):
+                        ops.append(f"v_alignbyte_b32 v{f(s, k, e)}, v{f(s, k + 1, e)}, v{f(s, k, e)}, {rho}")
         else:
-            prev = HALF_RHOS[half][0]
-            for k in range(-1, 8):
-                hi = f"v{ea(1 - s, k + 1)}"
-                ops.append(f"v_alignbyte_b32 v{ea(s, k)}, {hi}, v{ea(1 - s, k)}, {rho - prev}")
+            for e in (0, 1):
+                for k in range(-1, 8):
+                    ops.append(f"v_alignbyte_b32 v{f(s, k, e)}, v{f(1 - s, k + 1, e)}, v{f(1 - s, k, e)}, 1")
         return ops
 
-    def prep_b(gi):
-        s = gi & 1
-        return [f"v_mov_b32 v{eb(k)}, v{ea(s, k)}" for k in range(-1, 8)]
+    started = set()
 
-    def mfmas(gi, parity):
+    def mfmas(gi):
         kb, rho = groups[gi]
-        s, ab = gi & 1, ABUF[kb & 1]
+        s = gi & 1
         out = []
-        for c in cols_of(rho):
-            q = (c - 15 - rho) // 4
-            if q % 2 != parity:
-                continue
-            r = ea(s, q) if parity == 0 else eb(q)
+        for q in windows(rho):
+            r = f(s, q, 0)
             assert r % 2 == 0
-            cin = bias if kb == 0 else f"%{pos[c]}"
-            out.append(f"v_mfma_i32_16x16x64_i8 %{pos[c]}, v[{ab}:{ab + 3}], v[{r}:{r + 3}], {cin}")
+            for grp in (0, 1):
+                c = 4 * q + rho + 7 + 8 * grp
+                ab = ABUF[kb & 1][grp]
+                cin = f"%{pos[c]}"
+                if c not in started:
+                    assert kb == 0
+                    cin = bias
+                    started.add(c)
+                out.append(f"v_mfma_i32_16x16x64_i8 %{pos[c]}, v[{ab}:{ab + 3}], v[{r}:{r + 3}], {cin}")
         return out
 
-    # group 0 has nothing to hide behind
-    L += prep_a(0) + prep_b(0) + ["s_nop 1"]
+    L += prep(0) + ["s_nop 1"]
     for gi in range(len(groups)):
         nxt = gi + 1 < len(groups)
         kb, rho = groups[gi]
         if rho == HALF_RHOS[half][0] and kb + 1 < nkb:
-            # XB was consumed by this group's preparation and every MFMA of term block kb - 1 (the last reader of
-            # the other A buffer) has been issued: fetch term block kb + 1
+            # XB was consumed by this group's preparation and every MFMA of K-block kb - 1 (the last reader of the other A
+            # buffers) has been issued: fetch K-block kb + 1
             L += lds_loads(kb + 1, xs_op, as_op)
-        # odd windows (EB) first; meanwhile the next group's EA set is built from this one's
-        L += interleave(mfmas(gi, 1), prep_a(gi + 1) if nxt else [])
-        # then the even windows (EA); EB is free now and is refreshed for the next group
-        L += interleave(mfmas(gi, 0), prep_b(gi + 1) if nxt else [])
+        L += interleave(mfmas(gi), prep(gi + 1) if nxt else [])
         if nxt:
             L.append("s_nop 0")
+    assert started == set(cols)
     L += ["s_nop 7", "s_nop 7"]
     return L, ncol
 
@@ -168,6 +169,7 @@ def emit():
     for half in range(2):
         cols = half_columns(half)
         out.append(f"// half {half}: {cols}")
+    assert half_columns(0) == [c for c in range(NC) if c % 4 in (0, 3)] and half_columns(1) == [c for c in range(NC) if c % 4 in (1, 2)]
     out.append("template <int NKB, int HALF> struct Mm8Phase;")
     clob = ", ".join(f'"v{r}"' for r in range(CLOBBER_LO, CLOBBER_HI + 1))
     for nkb in range(1, MAXKB + 1):

@@ -9,13 +9,13 @@
 //   in  = sum_a X_a 2^(8a)   a < 32   (the bytes of the packed element as they lie in HBM)
 //   M   = sum_b M_b 2^(8b)   b < 16   (balanced signed digits, precomputed)
 //   S   = sum_c 2^(8c) col_c,   col_c = sum_l sum_b M_b[i][l] * X_{c-b}[l]        c < 47
-// so that for a fixed column c the sum over (l, b) is ONE int8 dot product of length 16*d between a
-// constant row (the digits of M) and a 16-byte sliding window of every input element.
-// v_mfma_i32_16x16x64_i8 takes 16 rows i x 16 chunks x (4 elements l x 16 digits b) per instruction.
-// The window for column c is bytes [c-15, c] of the element, i.e. dwords q .. q+3 of the element
-// shifted right by rho bytes (c - 15 = 4q + rho); how the shifted copies are kept in aligned register
-// files so that no operand is ever assembled per MFMA is gen_mm8.py's business (it emits the MFMA
-// phases as inline asm, hb_mm8_body.inc).
+// so that for a fixed column c the sum over (l, b) is an int8 dot product between a constant row (the digits of M)
+// and a sliding window of bytes of every input element.
+// v_mfma_i32_16x16x64_i8 takes 16 rows i x 16 chunks x 64 products per instruction, cut here as 8 elements l x 8 digits b:
+// the 16 digits are two groups G, and for column c and group G the window is bytes [s, s + 7], s = c - 7 - 8 G, of the
+// element, i.e. dwords q, q + 1 of the element shifted right by rho bytes (s = 4q + rho).  How the shifted copies are kept
+// in an aligned register file so that no operand is ever assembled per MFMA is gen_mm8.py's business (it emits the
+// MFMA phases as inline asm, hb_mm8_body.inc, and says why 8 x 8 beats 4 elements x 16 digits).
 //
 // int8 operands are signed: M uses balanced digits; the input bytes are biased by XOR 0x80
 // (u = s + 128) and the constant 128 * sum_a 2^(8a) * sum_l M[i][l] is added back per row, mod p,
@@ -44,7 +44,8 @@ struct BarrettParams {
 
 struct Mm8Matrix {
     int n_out, d, nkb, n_rt;
-    int4 *a8;          // [n_rt][nkb][64 lanes] 16 balanced digits each: lane (r, g) = row 16 rt + 4 (r % 4) + r / 4, term 4 kb + g, digit 15 - j
+    int4 *a8;          // [n_rt][nkb][2 digit groups][64 lanes] 16 balanced digits each: lane (r, g) = row 16 rt + 4 (r % 4) + r / 4;
+                       // byte j = 4 dd + bi is digit 7 + 8 G - 4 (dd >> 1) - bi of term 8 kb + 2 g + (dd & 1)
     uint32_t *crow;    // [n_rt * 16][16] radix-2^29 digits of the per-row constant (14 used)
     uint32_t *zero;    // 32 zero bytes: DMA source for inputs beyond in_count (zero padding of the last chunk)
     BarrettParams bp;
@@ -58,8 +59,8 @@ constexpr int MM8_BIAS = 5800000;   // >= 128 * sum |digit| >= |column| (checked
 // so that one wave's MFMA stream overlaps its neighbour's VALU epilogue).
 //
 // A unit is TPW tiles of 16 chunks.  Its input elements are DMA'd (global_load_lds_dwordx4) into one
-// of two LDS buffers in MFMA-operand order -- slot (tile, kb, half)[lane] x 16 B, lane (n, g) owning
-// element l = 4 kb + g of chunk n -- one unit ahead of the arithmetic.  Wave w of the workgroup takes
+// of two LDS buffers in MFMA-operand order -- slot (tile, kb, e, half)[lane] x 16 B, lane (n, g) owning
+// elements l = 8 kb + 2 g + e, e = 0, 1, of chunk n -- one unit ahead of the arithmetic.  Wave w of the workgroup takes
 // (tile tl, row tile rt) pairs w, w + 4, ... of the unit's TPW x n_rt, pair index = tl n_rt + rt (rt: 16 output rows).
 //
 // Per (tile, rt) the 47 columns are produced in two halves by byte shift (rho in {0,1}: 23 columns, rho in
@@ -90,9 +91,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
     uint32_t *crl = reinterpret_cast<uint32_t *>(mm8_lds);     // [n_rt * 16][16] digits
-    int4 *abuf = reinterpret_cast<int4 *>(mm8_lds + n_rt * 64);   // [n_rt][NKB][64] matrix digits
-    uint4 *xbuf = mm8_lds + n_rt * 64 + n_rt * NKB * 64;        // 2 x [tpw][NKB][2][64] uint4
-    const int bufsz = tpw * NKB * 2 * 64;
+    int4 *abuf = reinterpret_cast<int4 *>(mm8_lds + n_rt * 64);   // [n_rt][NKB][2][64] matrix digits
+    uint4 *xbuf = mm8_lds + n_rt * 64 + n_rt * NKB * 2 * 64;    // 2 x [tpw][NKB][2 elements][2 halves][64] uint4
+    const int bufsz = tpw * NKB * 4 * 64;
 
     const int n_pairs = tpw * n_rt;      // (tile, row tile) pairs of a unit, dealt to the 4 waves: wave w takes w, w + 4, ...
 
@@ -120,15 +121,15 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     // plus a per-lane 32-bit offset: the general form below costs ~40 VALU instructions per slot
     const bool fast_dma = in_sc >= 0 && in_sl >= 0 && in_count < (1ll << 27);
     const uint32_t lane_off = (uint32_t)((int64_t)n * in_sc * 32);
-    const int n_slots = tpw * NKB * 2;
-    // slot s = (t * NKB + kb) * 2 + h, dealt round-robin to the 4 waves; all of it wave-uniform
+    const int n_slots = tpw * NKB * 4;
+    // slot s = ((t * NKB + kb) * 2 + e) * 2 + h, dealt round-robin to the 4 waves; all of it wave-uniform
     auto issue_loads = [&](int64_t unit, int buf) {
         const int64_t c_last = (unit * tpw + tpw) * 16 - 1;
         if (fast_dma && c_last < n_chunks && c_last * in_sc + (int64_t)rowmax * in_sl < in_count) {
             for (int s = wave; s < n_slots; s += 4) {
-                const int h = s & 1, q = s >> 1, t = q / NKB, kb = q - t * NKB;
+                const int h = s & 1, e = (s >> 1) & 1, q = s >> 2, t = q / NKB, kb = q - t * NKB;
                 const uint64_t sbase = (uint64_t)(uintptr_t)in_pk + (uint64_t)((unit * tpw + t) * 16 * in_sc) * 32 + h * 16;
-                const uint32_t voff = lane_off + rowoff[4 * kb + g];
+                const uint32_t voff = lane_off + rowoff[8 * kb + 2 * g + e];
                 const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
                     (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(xbuf + (size_t)buf * bufsz + s * 64));
                 uint32_t keep;
@@ -138,10 +139,10 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
             return;
         }
         for (int s = wave; s < n_slots; s += 4) {
-            const int h = s & 1, q = s >> 1, t = q / NKB, kb = q - t * NKB;
+            const int h = s & 1, e = (s >> 1) & 1, q = s >> 2, t = q / NKB, kb = q - t * NKB;
             int64_t chunk = (unit * tpw + t) * 16 + n;
             if (chunk >= n_chunks) chunk = n_chunks - 1;
-            const int64_t idx = chunk * in_sc + (int64_t)rowl[4 * kb + g] * in_sl;
+            const int64_t idx = chunk * in_sc + (int64_t)rowl[8 * kb + 2 * g + e] * in_sl;
             const uint4 *src = (idx < in_count) ? reinterpret_cast<const uint4 *>(in_pk) + idx * 2 + h
                                                 : reinterpret_cast<const uint4 *>(zero_src) + h;
             // issued from asm so that hipcc does not drain it at the next LDS read (its vmcnt bookkeeping only
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     // (crowd and the digits are adjacent in LDS; LDS-DMA like the elements, 1 KB per instruction, all in flight at once --
     // a load / wait / ds_write loop cost one round trip per 4 KB, 3 us per launch)
     {
-        const int n_cr = n_rt, n_blk = n_rt * (1 + NKB);      // in 64-lane blocks of uint4
+        const int n_cr = n_rt, n_blk = n_rt * (1 + 2 * NKB);  // in 64-lane blocks of uint4
         for (int blk = wave; blk < n_blk; blk += 4) {
             const uint4 *src = (blk < n_cr ? reinterpret_cast<const uint4 *>(crowd) + blk * 64
                                            : reinterpret_cast<const uint4 *>(a8) + (blk - n_cr) * 64) + lane;
@@ -189,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
         if constexpr (CHECK) {
             // hand the caller its rows of the input (the decoded coefficients) in its own layout while they are in LDS
             if (copy_dst) {
-                for (int e = wave; e < tpw * NKB; e += 4) {
-                    const int t = e / NKB, kb = e - t * NKB, l = 4 * kb + g;
+                for (int e = wave; e < tpw * NKB * 2; e += 4) {
+                    const int t = e / (NKB * 2), kb = (e >> 1) - t * NKB, l = 8 * kb + 2 * g + (e & 1);
                     const int64_t ch = (unit * tpw + t) * 16 + n;
                     const int64_t idx = ch * copy_sc + (int64_t)l * copy_sl;
                     if (l < copy_rows && l < d && ch < n_chunks && idx < copy_count) {
@@ -206,8 +207,8 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
         for (int pidx = wave; pidx < n_pairs; pidx += 4) {
             const int tl = pidx / n_rt, rt = pidx - tl * n_rt;
             const int64_t chunk = (unit * tpw + tl) * 16 + n;
-            const uint4 *xs = xbuf + (size_t)buf * bufsz + (size_t)tl * NKB * 2 * 64 + lane;
-            const int4 *as = abuf + (size_t)rt * NKB * 64 + lane;
+            const uint4 *xs = xbuf + (size_t)buf * bufsz + (size_t)tl * NKB * 4 * 64 + lane;
+            const int4 *as = abuf + (size_t)rt * NKB * 2 * 64 + lane;
             uint32_t eap[4][11], c0p[4];     // half 0's column pairs, parked across the second MFMA block
             uint32_t wd[4][MM8_CW];          // the 13 words of each biased sum
             // Output `reg` of lane (n, g) is row 16 rt + 4 reg + g (the host places matrix row 16 rt + j at tile row
@@ -393,7 +394,7 @@ int mm8_tpw(int n_rt, int nkb) {
     return tpw;
 }
 size_t mm8_lds_bytes(int n_rt, int nkb, int tpw) {
-    return ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 64 + (size_t)2 * tpw * nkb * 2 * 64) * 16 + 96 * 4 + (size_t)n_rt * 16 * 4;
+    return ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 2 * 64 + (size_t)2 * tpw * nkb * 4 * 64) * 16 + 96 * 4 + (size_t)n_rt * 16 * 4;
 }
 
 int mm8_num_cus() {
@@ -505,7 +506,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     if (ctx->n_limbs != 4 || f->n_in < 1 || f->n_in > 32 || f->n_out < 1) return HB_ERR_UNSUPPORTED;
     if ((ctx->p_limbs[3] >> 62) == 0) return HB_ERR_UNSUPPORTED;      // Barrett constants assume 2^254 <= p
     // rows != nullptr: the matrix made of rows[0 .. n_rows) of f (a compact check matrix)
-    const int n_out = rows ? n_rows : f->n_out, d = f->n_in, nkb = (d + 3) / 4, n_rt = (n_out + 15) / 16;
+    const int n_out = rows ? n_rows : f->n_out, d = f->n_in, nkb = (d + 7) / 8, n_rt = (n_out + 15) / 16;
     if (n_out < 1) return HB_ERR_UNSUPPORTED;
     if (mm8_lds_bytes(n_rt, nkb, (n_rt == 1) ? 4 : (n_rt == 2) ? 2 : 1) > MM8_LDS_LIMIT) return HB_ERR_UNSUPPORTED;
     const int tiles = (f->n_out + f->ot - 1) / f->ot;
@@ -525,7 +526,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     Big two406(13, 0); two406[12] = 1u << 22;                            // 2^406
     Big mu; big_divmod(two406, p, &mu);
 
-    std::vector<int8_t> a((size_t)n_rt * nkb * 64 * 16, 0);
+    std::vector<int8_t> a((size_t)n_rt * nkb * 2 * 64 * 16, 0);
     std::vector<uint32_t> cr((size_t)n_rt * 16 * 16, 0);
     for (int i = 0; i < n_out; i++) {
         Big pos(5, 0), ngs(5, 0);   // sums of the positive / negated entries of the row (each < 32 * 2^127)
@@ -539,11 +540,14 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
             if (w8[4] | w8[5] | w8[6] | w8[7]) return HB_ERR_UNSUPPORTED;   // does not fit 16 balanced digits
             const int sgn = neg[src] ? -1 : 1;
             int carry = 0;
-            int8_t *dst = &a[(((size_t)(i / 16) * nkb + l / 4) * 64 + (size_t)(4 * ((i % 16) % 4) + (i % 16) / 4) + 16 * (l % 4)) * 16];
+            // lane (r, g) of K-block kb = l / 8 holds terms 8 kb + 2 g and 8 kb + 2 g + 1: g = (l % 8) / 2, element e = l % 2
+            const int lane_ = (4 * ((i % 16) % 4) + (i % 16) / 4) + 16 * ((l % 8) / 2), el = l & 1;
             for (int b = 0; b < 16; b++) {
                 int t = sgn * (int)((w8[b >> 2] >> (8 * (b & 3))) & 0xffu) + carry;
                 if (t > 127) { t -= 256; carry = 1; } else if (t < -128) { t += 256; carry = -1; } else carry = 0;
-                dst[15 - b] = (int8_t)t;
+                // digit b = 7 + 8 G - 4 hi - bi  sits at byte j = 4 (2 hi + el) + bi of the lane's 16 bytes of group G
+                const int grp = b >> 3, r7 = 7 - (b & 7), hi = r7 >> 2, bi = r7 & 3;
+                a[((((size_t)(i / 16) * nkb + l / 8) * 2 + grp) * 64 + (size_t)lane_) * 16 + 4 * (2 * hi + el) + bi] = (int8_t)t;
                 colsum += (t < 0) ? -t : t;
             }
             if (carry) return HB_ERR_UNSUPPORTED;                           // |entry| >= 127 * 256^15 or so
@@ -632,10 +636,6 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
         case 2: MM8_LAUNCH(2); break;
         case 3: MM8_LAUNCH(3); break;
         case 4: MM8_LAUNCH(4); break;
-        case 5: MM8_LAUNCH(5); break;
-        case 6: MM8_LAUNCH(6); break;
-        case 7: MM8_LAUNCH(7); break;
-        case 8: MM8_LAUNCH(8); break;
         default: return fail(ctx, HB_ERR_UNSUPPORTED, "mm8: more than 32 terms");
     }
 #undef MM8_LAUNCH

@@ -23,6 +23,7 @@
 // scale + n-point NTT + MulTrunc(Q, A, k) (see DESIGN.md cost table); results are
 // identical because every output is a canonical residue.
 #include <algorithm>
+#include <type_traits>
 
 #include "hb_common.hpp"
 
@@ -68,6 +69,68 @@ __device__ __forceinline__ void butterfly(uint32_t *a0, uint32_t *a1, const uint
     for (int q = 0; q < NL; q++) { a0[q] = s0[q]; a1[q] = s1[q]; }
 }
 
+// One radix-2^R pass (R stages s .. s+R-1 of the decimation-in-time transform) of one unit: the 2^R elements at
+// positions hi 2^(s+R) + q 2^s + lo, q < 2^R, are read once, transformed in registers and written back.
+// Stage s+u pairs the elements whose q differ in bit u; the twiddle of the pair is omega^(j n / 2^(s+u+1)) with
+// j = (q mod 2^u) 2^s + lo, read from the LDS table.
+// Input pruning: after S stages the block at positions [m 2^S, (m+1) 2^S) holds the sub-transform of the coefficients
+// j = r (mod n / 2^S), r = bitrev(m); with dd < n coefficients present it is identically zero when r >= dd.  A butterfly
+// whose lower operand lies in such a block is a copy (u, u); the upper operand's class is smaller, so it is the only case.
+template <int NL, int R>
+__device__ __forceinline__ void ntt_unit(uint32_t *__restrict__ base /* polynomial in LDS */, const uint32_t *__restrict__ twl, int n, int logn,
+                                         int s, int hi, int lo, int dd, bool first, const FpParams<NL> &P) {
+    constexpr int M = 1 << R;
+    uint32_t e[M][NL];
+    const int p0 = (hi << (s + R)) + lo;
+#pragma unroll
+    for (int q = 0; q < M; q++) {
+        const int pos = p0 + (q << s);
+        // the first pass reads positions that the loader never wrote (classes >= dd) as zero instead of clearing LDS
+        const bool present = !first || (int)(__brev((uint32_t)pos) >> (32 - logn)) < dd;
+#pragma unroll
+        for (int w = 0; w < NL; w++) e[q][w] = present ? base[(size_t)pos * NL + w] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < R; u++) {
+        const int S = s + u;                             // global stage
+        const int lb = logn - S;                         // bits of a block index at this stage
+#pragma unroll
+        for (int q = 0; q < M; q++) {
+            if (q & (1 << u)) continue;
+            const int qb = q | (1 << u);
+            const int posb = p0 + (qb << s);
+            const int rb = lb > 0 ? (int)(__brev((uint32_t)(posb >> S)) >> (32 - lb)) : 0;
+            if (rb >= dd) {                              // lower operand identically zero: (u, u)
+#pragma unroll
+                for (int w = 0; w < NL; w++) e[qb][w] = e[q][w];
+                continue;
+            }
+            const int j = ((q & ((1 << u) - 1)) << s) + lo;
+            uint32_t t[NL];
+            if (j == 0) {
+                fp_set(t, e[qb]);
+            } else {
+                const uint32_t *wp = twl + (size_t)(j * (n >> (S + 1))) * NL;
+                uint32_t wd[NL];
+#pragma unroll
+                for (int w = 0; w < NL; w++) wd[w] = wp[w];
+                mont_mul(t, wd, e[qb], P);
+            }
+            uint32_t s0[NL], s1[NL];
+            fp_add(s0, e[q], t, P);
+            fp_sub(s1, e[q], t, P);
+            fp_set(e[q], s0);
+            fp_set(e[qb], s1);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < M; q++) {
+        const int pos = p0 + (q << s);
+#pragma unroll
+        for (int w = 0; w < NL; w++) base[(size_t)pos * NL + w] = e[q][w];
+    }
+}
+
 // whole transform in LDS; PB polynomials per block.  Strided views on both sides:
 //   in(c, j)  at in  + (c*in_sc  + j*in_sl ) elements, zero beyond in_count (chunk_data padding)
 //   out(c, i) at out + (c*out_sc + i*out_sl) elements, i < k, skipped beyond out_count
@@ -75,6 +138,8 @@ __device__ __forceinline__ void butterfly(uint32_t *a0, uint32_t *a1, const uint
 // addresses for coefficient-major / party-major buffers (stride_c == 1).
 // CHECK: instead of storing, compare out(c, i) with the buffer for rows i in check_mask
 // (the validating re-encode of IncrementalDecoder, reed_solomon.py:313-326).
+// The log2(n) stages run as radix-8 passes in registers (a remainder of one or two stages first): 3 LDS round trips and
+// barriers for n = 256 instead of 8, twiddles (Montgomery form) staged in LDS once per block.
 template <int NL, int NW, bool CHECK>
 __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uint32_t *__restrict__ tw,
                                                  const uint32_t *__restrict__ in, int64_t in_sc, int64_t in_sl, int64_t in_count, int d,
@@ -86,56 +151,58 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
     const int64_t c0 = (int64_t)blockIdx.x * PB;
     const int npoly = (int)min((int64_t)PB, C - c0);
     const int dd = min(d, n);
-    for (int idx = threadIdx.x; idx < npoly * n * NL; idx += blockDim.x) lds[idx] = 0;
-    __syncthreads();
+    const int half = n >> 1;
+    uint32_t *twl = lds;                                  // [max(n/2, 1)][NL]
+    uint32_t *data = lds + (size_t)(half > 0 ? half : 1) * NL;   // [PB][n][NL]
+    for (int idx = threadIdx.x; idx < half * NL; idx += blockDim.x) twl[idx] = tw[idx];
     // load the dd coefficients of every polynomial into bit-reversed positions
     for (int idx = threadIdx.x; idx < npoly * dd; idx += blockDim.x) {
         const int pl = in_poly_fast ? idx % npoly : idx / dd;
         const int j = in_poly_fast ? idx / npoly : idx % dd;
         const int64_t e = (c0 + pl) * in_sc + (int64_t)j * in_sl;
-        if (e < in_count) {
-            uint32_t dg[NL];
-            load_digits<NL, NW>(dg, in + e * NW);
-            uint32_t *dst = lds + ((size_t)pl * n + bitrev((uint32_t)j, logn)) * NL;
+        uint32_t dg[NL];
+        if (e < in_count) load_digits<NL, NW>(dg, in + e * NW);
+        else {
 #pragma unroll
-            for (int q = 0; q < NL; q++) dst[q] = dg[q];
+            for (int q = 0; q < NL; q++) dg[q] = 0;
         }
+        uint32_t *dst = data + ((size_t)pl * n + bitrev((uint32_t)j, logn)) * NL;
+#pragma unroll
+        for (int q = 0; q < NL; q++) dst[q] = dg[q];
     }
     __syncthreads();
-    const int half = n >> 1;
-    for (int s = 0; s < logn; s++) {
-        const int h = 1 << s;
-        const int tstride = half >> s;          // twiddle index step: n / (2h)
-        // Input pruning.  After s stages the block at positions [m 2^s, (m+1) 2^s) holds the sub-transform of the
-        // coefficients j = r (mod n / 2^s), r = bitrev(m); with only dd < n coefficients present it is identically zero
-        // when r >= dd.  The blocks of a stage are visited in bit-reversed order q (butterflies of a stage are
-        // independent), which makes that test monotone: the lower operand's class is r_v = nblk + q, so butterflies with
-        // q >= dd - nblk have v = 0 and degenerate to a copy (u, u) -- whole waves take one side of the branch.
-        const int lb = logn - s - 1, nblk = n >> (s + 1);
-        const int live = dd - nblk;             // blocks q < live have a non-zero lower operand
-        for (int b = threadIdx.x; b < npoly * half; b += blockDim.x) {
-            const int pl = b / half, bb = b % half;
-            const int j = bb & (h - 1);
-            const int q = bb >> s;
-            const int m = lb > 0 ? (int)bitrev((uint32_t)q, lb) : 0;
-            const int i0 = (m << (s + 1)) + j;
-            uint32_t *base = lds + (size_t)pl * n * NL;
-            if (q < live) {
-                butterfly<NL>(base + (size_t)i0 * NL, base + (size_t)(i0 + h) * NL, tw + (size_t)j * tstride * NL, j == 0, P);
-            } else {
-#pragma unroll
-                for (int qd = 0; qd < NL; qd++) base[(size_t)(i0 + h) * NL + qd] = base[(size_t)i0 * NL + qd];
-            }
+    // passes: the remainder (1 or 2 stages) first, then radix-8
+    int s = 0;
+    bool first = true;
+    const int rem = logn % 3;
+    auto run_pass = [&](auto rtag) {
+        constexpr int R = decltype(rtag)::value;
+        const int units = n >> R;                         // per polynomial
+        const int lo_bits = s, hi_bits = logn - s - R;
+        for (int uidx = threadIdx.x; uidx < npoly * units; uidx += blockDim.x) {
+            const int pl = uidx / units, u = uidx - pl * units;
+            // hi in bit-reversed order: units whose lower operands are pruned end up next to each other
+            const int lo = u & ((1 << lo_bits) - 1);
+            const int hr = u >> lo_bits;
+            const int hi = hi_bits > 0 ? (int)(__brev((uint32_t)hr) >> (32 - hi_bits)) : 0;
+            ntt_unit<NL, R>(data + (size_t)pl * n * NL, twl, n, logn, s, hi, lo, dd, first, P);
         }
         __syncthreads();
-    }
+        s += R;
+        first = false;
+    };
+    if (logn == 0) { /* order 1: the coefficient itself */ }
+    if (rem == 1) run_pass(std::integral_constant<int, 1>{});
+    if (rem == 2) run_pass(std::integral_constant<int, 2>{});
+    while (s < logn) run_pass(std::integral_constant<int, 3>{});
     for (int idx = threadIdx.x; idx < npoly * k; idx += blockDim.x) {
         const int pl = out_poly_fast ? idx % npoly : idx / k;
         const int i = out_poly_fast ? idx / npoly : idx % k;
         const int64_t e = (c0 + pl) * out_sc + (int64_t)i * out_sl;
         uint32_t dg[NL];
+        const bool present = logn > 0 || dd > 0;         // order 1 with no coefficient: zero
 #pragma unroll
-        for (int q = 0; q < NL; q++) dg[q] = lds[((size_t)pl * n + i) * NL + q];
+        for (int q = 0; q < NL; q++) dg[q] = present ? data[((size_t)pl * n + i) * NL + q] : 0u;
         if constexpr (CHECK) {
             if (check_mask[i]) {
                 uint32_t w[NW], ex[NW];
@@ -221,12 +288,13 @@ int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, h
     if (C <= 0 || k <= 0) return HB_OK;
     int logn = 0; while ((1 << logn) < n) logn++;
     const size_t elem_lds = (size_t)ctx->nl() * 4;
-    if ((size_t)n * elem_lds > 160 * 1024) return fail(ctx, HB_ERR_UNSUPPORTED, "ntt: order does not fit LDS");
-    int PB = (int)((40 * 1024) / ((size_t)n * elem_lds)); if (PB < 1) PB = 1; if (PB > 64) PB = 64;
-    // whole rounds of butterflies: PB * n/2 a multiple of the 256 threads (17 polynomials of order 64 would run 3 rounds, the third 12 % full)
-    { const int q = n >= 2 ? 256 / (n / 2) : 1; if (q > 1 && PB > q) PB -= PB % q; }
+    // radix-8 units: n / 8 per polynomial and pass; 2048 / n polynomials give the 256 threads one unit each (72 KB of data:
+    // two workgroups per CU)
+    int PB = n <= 2048 ? 2048 / n : 1; if (PB > 256) PB = 256;
+    if (const char *e = getenv("HB_NTT_PB")) { int v = atoi(e); if (v >= 1 && (size_t)v * n * elem_lds <= 150 * 1024) PB = v; }   // experiment hook
     if ((int64_t)PB > C) PB = (int)C;
-    const size_t lds = (size_t)PB * n * elem_lds;
+    const size_t lds = ((size_t)PB * n + (size_t)(n > 1 ? n / 2 : 1)) * elem_lds;
+    if (lds > 160 * 1024) return fail(ctx, HB_ERR_UNSUPPORTED, "ntt: order does not fit LDS");
     const int64_t blocks = (C + PB - 1) / PB;
     if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "fft: batch too large");
     const int ipf = iv.stride_c == 1 ? 1 : 0, opf = ov.stride_c == 1 ? 1 : 0;
@@ -286,7 +354,7 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, co
     uint32_t *tw = nullptr;
     int rc = get_twiddles(ctx, omega_host, n, &tw, s); if (rc) return rc;
     const size_t elem_lds = (size_t)NLr * 4;
-    if ((size_t)n * elem_lds <= 160 * 1024) {
+    if (((size_t)n + n / 2) * elem_lds <= 160 * 1024) {     // data + twiddles in LDS
         hb_view iv{d, 1}, ov{k, 1};
         return launch_ntt_lds(ctx, tw, n, (const uint32_t *)coeffs_dev, iv, INT64_MAX, d, k, (uint32_t *)out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
     }

@@ -328,3 +328,143 @@ def test_batch_reconstruct_device(n, t, b, use_omega, liars):
     for dest in range(n):
         assert wire.unpack_ints(sent[(honest, "R1")][dest]) == [row[dest] for row in enc]
     torch.cuda.synchronize()
+
+
+# ---- Mpc.open_share_array on the device: many concurrent small opens in one launch -------------------
+class _TaggedNet:
+    """the runtime's per-share-id channels (mpc.py:196-205): get_send_recv(tag) -> (send, recv) for party i"""
+
+    def __init__(self, n):
+        self.n, self.q = n, [dict() for _ in range(n)]
+
+    def _queue(self, party, tag):
+        return self.q[party].setdefault(tag, asyncio.Queue())
+
+    def get_send_recv(self, i, tamper=None):
+        def factory(tag):
+            def send(dest, msg):
+                self._queue(dest, tag).put_nowait((i, tamper(msg) if tamper else msg))
+
+            return send, self._queue(i, tag).get
+
+        return factory
+
+
+@pytest.mark.parametrize("n, t, liars", [(4, 1, 0), (7, 2, 2), (16, 5, 1)])
+def test_open_coalescer_many_small_opens(n, t, liars):
+    """>= 64 concurrent opens of 1..40 shares each, issued like Mpc.open_share_array: one coalesced reconstruction per
+    program step, results equal to opening each array on its own (= the secrets), also with liars sending garbage."""
+    from honeybadgermpc_amd import wire
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.open_coalescer import OpenCoalescer
+
+    rnd = random.Random(n * 31 + liars)
+    ctx = Context.get(P)
+    xs = list(range(1, n + 1))
+    sizes = [rnd.randrange(1, 41) for _ in range(64)] + [0, 1] + [rnd.randrange(1, 41) for _ in range(6)]
+    secrets = [[rnd.randrange(P) for _ in range(sz)] for sz in sizes]
+
+    def share_all(vals):
+        polys = [[s] + [rnd.randrange(P) for _ in range(t)] for s in vals]
+        return [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+
+    shares = [share_all(vals) for vals in secrets]          # [open][party][share]
+    bad = set(rnd.sample(range(n), liars))
+
+    def garble(msg):
+        tag, blob = msg
+        count = wire.unpack_limbs(blob).shape[0]
+        return (tag, wire.pack_ints([rnd.randrange(P) for _ in range(count)], P))
+
+    async def party(i, net, counters):
+        co = OpenCoalescer(P, n, t, i, net.get_send_recv(i, garble if i in bad else None))
+        # step 1: the first 66 opens are issued before anything is awaited -> one batch
+        first = [co.open_share_array(ctx.upload_ints(shares[k][i]) if sizes[k] else ctx.empty(0)) for k in range(66)]
+        got = [await h for h in first]
+        # step 2: six more, awaited out of order -> a second batch
+        second = [co.open_share_array(shares[k][i]) for k in range(66, 72)]
+        got += [await h for h in reversed(second)][::-1]
+        counters[i] = (co.opens, co.batches)
+        return got
+
+    async def main():
+        net = _TaggedNet(n)
+        counters = {}
+        res = await asyncio.gather(*[party(i, net, counters) for i in range(n)])
+        return res, counters
+
+    results, counters = asyncio.run(main())
+    for i in range(n):
+        assert counters[i] == (72, 2), counters[i]
+        if i in bad:
+            continue
+        for k in range(72):
+            assert ctx.download_ints(results[i][k]) == secrets[k], (i, k)
+
+
+def test_batch_reconstruct_device_survives_non_bytes_payloads():
+    """a Byzantine sender behind an unpickling transport can send anything -- None, an int, a str, a list with
+    a non-integer -- and must not abort an honest party's open; a well-formed list of ints (a reference-style party in a
+    mixed deployment) is accepted as a column."""
+    from honeybadgermpc_amd import wire
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device_reconstruction import batch_reconstruct_device
+
+    n, t, b = 7, 2, 20
+    rnd = random.Random(77)
+    ctx = Context.get(P)
+    xs = list(range(1, n + 1))
+    secrets = [rnd.randrange(P) for _ in range(b)]
+    polys = [[s] + [rnd.randrange(P) for _ in range(t)] for s in secrets]
+    shares = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+    junk = {0: None, 1: 12345}
+
+    def tamper_for(i):
+        def tamper(dest, msg):
+            tag, blob = msg
+            if i in junk:
+                return (tag, junk[i] if tag == "R1" else ["x", 1.5] if i == 0 else "R2?")
+            if i == 2:                                   # honest, but speaks the reference's format: a list of Python ints
+                return (tag, wire.unpack_ints(blob))
+            return msg
+
+        return tamper
+
+    async def main():
+        net = _Net(n)
+        tasks = [batch_reconstruct_device(ctx.upload_ints(shares[i]), P, t, n, i, net.send(i, tamper_for(i)), net.recv(i)) for i in range(n)]
+        return await asyncio.gather(*tasks)
+
+    results = asyncio.run(main())
+    for i in range(2, n):
+        assert results[i] is not None and ctx.download_ints(results[i]) == secrets, i
+
+
+def test_robust_reconstruct_device_single_share():
+    """robust_reconstruction.py:14-30 on the device decoder: batch size 1, t liars among n = 3t + 1"""
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.open_coalescer import robust_reconstruct_device
+
+    n, t = 10, 3
+    rnd = random.Random(5)
+    ctx = Context.get(P)
+    poly = [rnd.randrange(P) for _ in range(t + 1)]
+    vals = [sum(co * pow(i + 1, e, P) for e, co in enumerate(poly)) % P for i in range(n)]
+    liars = {1, 4, 8}
+    for i in liars:
+        vals[i] = rnd.randrange(P)
+
+    async def main():
+        loop = asyncio.get_event_loop()
+        futs = []
+        for i in [4, 1, 0, 2, 8, 3, 5, 6, 7, 9]:           # liars arrive early
+            f = loop.create_future()
+            f.set_result(vals[i])
+            futs.append((i, f))
+        ordered = [None] * n
+        for i, f in futs:
+            ordered[i] = f
+        return await robust_reconstruct_device(ordered, P, n, t)
+
+    coeffs, errors = asyncio.run(main())
+    assert coeffs is not None and ctx.download_ints(coeffs) == poly and errors <= liars
