@@ -162,15 +162,41 @@ def measured_copy_gbps():
     return 2 * n * 8 / (best * 1e-3) / 1e9
 
 
-def traffic_from_profiles(workload):
-    """HBM bytes per launch of the dominant kernel, measured with rocprofv3 PMC passes and
-    committed under profiles/ (bench.py cannot read hardware counters itself)."""
+def profile_counters(workload):
+    """what the committed rocprofv3 PMC passes say about the dominant kernel of a workload (profiles/traffic_<workload>.json):
+    bench.py cannot read hardware counters itself"""
     path = os.path.join(REPO, "profiles", f"traffic_{workload}.json")
     try:
         with open(path) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
+            return json.load(f)
     except Exception:  # noqa: BLE001 - absent for workloads that were not PMC-profiled
+        return {}
+
+
+def traffic_from_profiles(workload):
+    """HBM bytes per launch of the dominant kernel (FETCH_SIZE / WRITE_SIZE passes, gfx950 correction)"""
+    v = profile_counters(workload).get("hbm_bytes_per_launch")
+    return float(v) if v is not None else None
+
+
+SIMDS, NOMINAL_HZ = 1024, 2.4e9       # 256 CUs x 4 SIMDs; nominal shader clock (MI355X_MICROARCH.md)
+
+
+def valu_roofline(workload, launch_ms):
+    """Second roofline of a kernel that HBM does not bind: VALU issue.  Instructions per launch come from the committed PMC
+    pass (SQ_INSTS_VALU: VALU + MFMA wave-instructions), the duration is this run's; the ceiling is one wave-instruction per
+    4 cycles per SIMD, which is what the PMC pass itself measures for this mix (SQ_ACTIVE_INST_VALU quad-cycles = SQ_INSTS_VALU)."""
+    pc = profile_counters(workload)
+    n_instr = pc.get("valu_wave_instr_per_launch")
+    if not n_instr:
         return None
+    achieved = n_instr / (launch_ms * 1e-3) / 1e9
+    peak = SIMDS * NOMINAL_HZ / 4 / 1e9
+    return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "G wave-instr/s", "frac": achieved / peak,
+            "wave_instr_per_launch": n_instr, "mfma_per_launch": pc.get("mfma_per_launch"),
+            "pmc_valu_busy_frac_of_kernel_cycles": pc.get("valu_busy_frac"), "pmc_matrix_pipe_busy_frac": pc.get("mfma_busy_frac"),
+            "note": "frac is against the nominal 2.4 GHz; under this kernel the shader clock averages ~2.06 GHz (busy cycles / duration in the PMC pass), "
+                    "where the same instruction stream is the pmc_valu_busy fraction of the kernel's cycles"}
 
 
 def ntl_baseline(n, t, sample_b, threads):
@@ -615,6 +641,7 @@ def main():
                            "k_matvec3<9,8,false> (R1 encode: fused pre-scale + n x d small-entry Vandermonde mat-vec)"),
                 "algorithmic_bytes_per_launch": alg_bytes_enc, "avg_launch_ms": enc_ms,
                 "copy_GBps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
+                "second": valu_roofline(args.workload if mfma else args.workload + "_valu", enc_ms),
                 "note": ("neither HBM nor the matrix pipe binds: per 16x16 tile 47 int32 columns x (d/4) MFMAs are followed by a 390-bit "
                          "reduction + Barrett per output on the VALU (~1550 VALU ops per wave pass, VALU ~67% busy, matrix pipe ~41% busy by PMC); "
                          if mfma else

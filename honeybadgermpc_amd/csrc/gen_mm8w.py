@@ -132,15 +132,23 @@ def mfmas(gi, parity, par, seen):
 
 def pair(first):
     """two term blocks (8 groups): digits of the even one in ABUF[0], of the odd one in ABUF[1].  On entry the first
-    group's EA / EB files are ready, XB has been consumed and the even block's digits are in flight."""
+    group's EA / EB files are ready, XB has been consumed and the even block's digits are in flight.
+    The odd block of the LAST pair must not prefetch: nothing waits for a load issued there, and one that lands after the
+    asm statement would overwrite registers the compiler has taken back (it did, once per ~10^4 launches, when L2 was cold)."""
     L = []
     seen = set() if first else None
+    tag = "p" if first else "l"
     for gi in range(8):
         par = gi // 4
         if gi % 4 == 0:
             # the digits of this block were requested one block ago; every MFMA reading the other buffer has been issued
             L.append("s_waitcnt vmcnt(0)")
+            if gi == 4:
+                # remaining pairs after this one: the counter itself in the peeled pair, counter - 1 in the loop body
+                L += [f"s_cmp_eq_u32 {OP_CNT}, {0 if first else 1}", f"s_cbranch_scc1 .Lmm8w_nopf_{tag}_%="]
             L += loads(1 - par)
+            if gi == 4:
+                L.append(f".Lmm8w_nopf_{tag}_%=:")
         L += interleave(mfmas(gi, 1, par, seen), prep_a(gi + 1))
         L += interleave(mfmas(gi, 0, par, seen), prep_b(gi + 1))
         L.append("s_nop 0")

@@ -123,6 +123,7 @@ void cache_trim(hb_ctx *ctx);
 void matrix_unref(hb_matrix *m);
 int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out);
 int upload_elems(hb_ctx *ctx, const uint64_t *host, size_t count, uint32_t **dev, hipStream_t s);
+int upload_table(hb_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, hipStream_t s);   // synchronises; last write by a kernel
 std::string table_key(const char *kind, hb_ctx *ctx, const uint64_t *x, int n, int d);
 // out[i] = base^(exps ? exps[i] : i), canonical packed, freshly hipMalloc'ed (caller frees)
 int pow_points_dev(hb_ctx *ctx, const uint64_t *base_host, const int32_t *exps_dev, int count, uint32_t **out_dev, hipStream_t s);

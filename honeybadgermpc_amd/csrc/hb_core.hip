@@ -371,9 +371,8 @@ static std::string int_key(const int32_t *host, int n) {
 int own_int_array(hb_ctx *ctx, const int32_t *host, int n, int32_t **dev, hipStream_t s) {
     int32_t *d = nullptr;
     HB_HIP(ctx, hipMalloc(&d, sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
-    hipError_t e = hipMemcpyAsync(d, host, sizeof(int32_t) * (size_t)(n > 0 ? n : 0), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) { (void)hipFree(d); ctx->err = std::string("int array upload: ") + hipGetErrorString(e); return HB_ERR_HIP; }
+    const int rc = upload_table(ctx, d, host, sizeof(int32_t) * (size_t)(n > 0 ? n : 0), s);
+    if (rc) { (void)hipFree(d); return rc; }
     *dev = d;
     return HB_OK;
 }
@@ -401,12 +400,38 @@ int alloc_matrix(hb_ctx *ctx, int n_out, int n_in, hb_matrix **out) {
     return HB_OK;
 }
 
+// Table upload that ends in a KERNEL write: host -> staging buffer (copy engine), staging -> destination (copy kernel on the
+// stream), synchronised.  A table image is read by kernels for the rest of its life, often at an address a freed table
+// occupied a moment ago; written by a kernel it is coherent with every later kernel's reads by construction, whatever
+// the copy engine's path around the L2s is.
+__global__ void k_upload_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+int upload_table(hb_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return HB_OK;
+    const size_t n16 = (bytes + 15) / 16;
+    void *stage = nullptr;
+    HB_HIP(ctx, hipMalloc(&stage, n16 * 16));
+    hipError_t e = hipMemcpy(stage, src_host, bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (bytes % 16 == 0) k_upload_copy<<<(unsigned)((n16 + 255) / 256), 256, 0, s>>>((const uint4 *)stage, (uint4 *)dst_dev, n16);
+        else e = hipMemcpyAsync(dst_dev, stage, bytes, hipMemcpyDeviceToDevice, s);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(stage);
+    if (e != hipSuccess) { ctx->err = std::string("table upload: ") + hipGetErrorString(e); return HB_ERR_HIP; }
+    return HB_OK;
+}
+
 // upload a small host array of elements to a temporary device buffer
 int upload_elems(hb_ctx *ctx, const uint64_t *host, size_t count, uint32_t **dev, hipStream_t s) {
     size_t bytes = count * (size_t)ctx->elem_words() * 4;
     HB_HIP(ctx, hipMalloc(dev, bytes ? bytes : 4));
-    HB_HIP(ctx, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, s));
-    return HB_OK;
+    const int rc = upload_table(ctx, *dev, host, bytes, s);
+    if (rc) { (void)hipFree(*dev); *dev = nullptr; }
+    return rc;
 }
 
 std::string table_key(const char *kind, hb_ctx *ctx, const uint64_t *x, int n, int d) {

@@ -630,8 +630,7 @@ int fast_vand_create(hb_ctx *ctx, const uint32_t *x_dev, int n, int d, FastMatri
     std::vector<uint32_t> kh((size_t)(d > 0 ? d : 1) * NLr);
     for (int l = 0; l < d; l++) for (int q = 0; q < NLr; q++) kh[(size_t)l * NLr + q] = ctx->n_limbs == 4 ? ctx->pw.r2[q] : ctx->pn.r2[q];
     HB_HIP(ctx, hipMalloc(&m->K, kh.size() * 4));
-    HB_HIP(ctx, hipMemcpyAsync(m->K, kh.data(), kh.size() * 4, hipMemcpyHostToDevice, s));
-    HB_HIP(ctx, hipStreamSynchronize(s));
+    rc = upload_table(ctx, m->K, kh.data(), kh.size() * 4, s); if (rc) return rc;
     *out = m;
     return HB_OK;
 }

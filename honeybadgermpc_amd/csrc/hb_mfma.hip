@@ -593,10 +593,13 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     HB_HIP(ctx, hipMalloc(&m->a8, a.size()));
     HB_HIP(ctx, hipMalloc(&m->crow, cr.size() * 4));
     HB_HIP(ctx, hipMalloc(&m->zero, 64));
-    HB_HIP(ctx, hipMemcpyAsync(m->a8, a.data(), a.size(), hipMemcpyHostToDevice, s));
-    HB_HIP(ctx, hipMemcpyAsync(m->crow, cr.data(), cr.size() * 4, hipMemcpyHostToDevice, s));
-    HB_HIP(ctx, hipMemsetAsync(m->zero, 0, 64, s));
-    HB_HIP(ctx, hipStreamSynchronize(s));
+    {
+        std::vector<uint8_t> zero64(64, 0);
+        int rc = upload_table(ctx, m->a8, a.data(), a.size(), s);
+        if (!rc) rc = upload_table(ctx, m->crow, cr.data(), cr.size() * 4, s);
+        if (!rc) rc = upload_table(ctx, m->zero, zero64.data(), 64, s);
+        if (rc) { mm8_free(m); return rc; }
+    }
     *out = m;
     return HB_OK;
 }

@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         }
     };
     const int n_pairs = tpw * n_rt;
-    uint32_t k256 = 256u, k64k = 1u << 16, k16m = 1u << 24;      // opaque, so that the word assembly stays one v_mad_u64_u32 per column
-    asm volatile("" : "+s"(k256), "+s"(k64k), "+s"(k16m));
+    int32_t k1 = 1, k256 = 256, k64k = 1 << 16, k16m = 1 << 24;  // opaque, so that the word assembly stays one v_mad_i64_i32 per column
+    asm volatile("" : "+s"(k1), "+s"(k256), "+s"(k64k), "+s"(k16m));
+    const int64_t bias4 = (int64_t)bias * 0x01010101ll, bias3 = (int64_t)bias * 0x00010101ll;   // the accumulator bias of 4 (3) columns
     int buf = 0;
     int64_t unit = blockIdx.x;
 #ifdef HB_MM8_TIMING
@@ -141,6 +142,11 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             // and ahead of the epilogue, which hides their latency
             if (nbuf == 2 && !dma_issued) { if (next < n_units) issue_loads(next, buf ^ 1); dma_issued = true; }
             MM8W_T(2);   // DMA issue
+            // T_k for the four reductions of this pass: LDS broadcast reads into registers once (the asm phase has released its
+            // 66 reserved registers; 90 scalars would not fit the SGPR file beside the rest)
+            uint4 tk[30];
+#pragma unroll
+            for (int q = 0; q < 30; q++) tk[q] = tlds[q];
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
                 if (16 * rt + 4 * reg >= n_out) break;               // whole outputs of padding rows (wave-uniform)
@@ -157,19 +163,21 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                     if (cmp) load_words<8>(ew, out_pk + (chunk * out_sc + (int64_t)(erow - 1) * out_sl) * 8);
                 }
                 (void)ew; (void)cmp;
-                // S = sum_c (col_c + bias) 2^(8c): four columns per 32-bit step, then one add-with-carry per word
+                // S = sum_c (col_c + bias) 2^(8c): four SIGNED columns per 32-bit step go into one 64-bit accumulator that starts
+                // from bias (1 + 2^8 + 2^16 + 2^24) -- four v_mad_i64_i32, no per-column bias add -- then one add-with-carry per word
                 uint32_t w[MM8W_WORDS + 1];
                 {
                     uint32_t hi_prev = 0;
                     unsigned cy = 0;
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        uint64_t a64 = (uint64_t)((uint32_t)acc[4 * j + 1][reg] + bias) * k256 + (uint64_t)((uint32_t)acc[4 * j][reg] + bias);
-                        a64 += (uint64_t)((uint32_t)acc[4 * j + 2][reg] + bias) * k64k;
-                        if (4 * j + 3 < MM8W_NC) a64 += (uint64_t)((uint32_t)acc[4 * j + 3][reg] + bias) * k16m;
+                        int64_t a64 = (int64_t)acc[4 * j][reg] * k1 + (4 * j + 3 < MM8W_NC ? bias4 : bias3);
+                        a64 += (int64_t)acc[4 * j + 1][reg] * k256;
+                        a64 += (int64_t)acc[4 * j + 2][reg] * k64k;
+                        if (4 * j + 3 < MM8W_NC) a64 += (int64_t)acc[4 * j + 3][reg] * k16m;
                         if (j == 0) w[0] = (uint32_t)a64;
                         else w[j] = __builtin_addc((uint32_t)a64, hi_prev, cy, &cy);
-                        hi_prev = (uint32_t)(a64 >> 32);
+                        hi_prev = (uint32_t)((uint64_t)a64 >> 32);
                     }
                     w[16] = hi_prev + cy;
                     w[17] = 0;
@@ -190,8 +198,8 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                     col[8] = (uint64_t)sd[8] + c2v.x; col[9] = 0;
                 }
 #pragma unroll
-                for (int k = 0; k < 10; k++) {      // T_k from LDS (broadcast reads): 90 scalars would not fit the SGPR file beside the rest
-                    const uint4 t0 = tlds[3 * k], t1 = tlds[3 * k + 1], t2 = tlds[3 * k + 2];
+                for (int k = 0; k < 10; k++) {
+                    const uint4 t0 = tk[3 * k], t1 = tk[3 * k + 1], t2 = tk[3 * k + 2];
                     const uint32_t sk = sd[9 + k];
                     col[0] += (uint64_t)sk * t0.x; col[1] += (uint64_t)sk * t0.y; col[2] += (uint64_t)sk * t0.z; col[3] += (uint64_t)sk * t0.w;
                     col[4] += (uint64_t)sk * t1.x; col[5] += (uint64_t)sk * t1.y; col[6] += (uint64_t)sk * t1.z; col[7] += (uint64_t)sk * t1.w;
@@ -428,14 +436,19 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     wph.m0 = ctx->psc.m0; wph.m1 = ctx->psc.m1;
     hipError_t e = hipMalloc(&m->a8, a.size());
     if (e == hipSuccess) e = hipMalloc(&m->wp, sizeof(WideParams));
-    if (e == hipSuccess) e = hipMemcpyAsync(m->wp, &wph, sizeof wph, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMalloc(&m->crow, cr.size() * 4);
     if (e == hipSuccess) e = hipMalloc(&m->zero, 64);
-    if (e == hipSuccess) e = hipMemcpyAsync(m->a8, a.data(), a.size(), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(m->crow, cr.data(), cr.size() * 4, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemsetAsync(m->zero, 0, 64, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { mm8w_free(m); ctx->err = std::string("mm8w tables: ") + hipGetErrorString(e); return HB_ERR_HIP; }
+    {
+        static_assert(sizeof(WideParams) % 4 == 0, "WideParams is a dword array");
+        std::vector<uint8_t> zero64(64, 0), wpb((sizeof(WideParams) + 15) / 16 * 16, 0);
+        memcpy(wpb.data(), &wph, sizeof wph);
+        int rc = upload_table(ctx, m->a8, a.data(), a.size(), s);
+        if (!rc) rc = upload_table(ctx, m->crow, cr.data(), cr.size() * 4, s);
+        if (!rc) rc = upload_table(ctx, m->zero, zero64.data(), 64, s);
+        if (!rc) { void *w16 = nullptr; if (hipMalloc(&w16, wpb.size()) != hipSuccess) rc = HB_ERR_HIP; else { (void)hipFree(m->wp); m->wp = (WideParams *)w16; rc = upload_table(ctx, m->wp, wpb.data(), wpb.size(), s); } }
+        if (rc) { mm8w_free(m); return rc; }
+    }
     *out = m;
     return HB_OK;
 }

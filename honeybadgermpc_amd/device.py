@@ -194,29 +194,37 @@ class BatchOpenPipeline:
 
 
 class DeviceIncrementalDecoder:
-    """IncrementalDecoder (reference reed_solomon.py:232-403) on device tensors: columns arrive as (C, 4) limb
-    tensors and stay in HBM; the guess, its validation and the robust fallback are launches over all C
-    polynomials.  Same state machine and the same decisions as `reed_solomon.IncrementalDecoder` with the Gao
-    robust decoder (what batch_reconstruct uses, batch_reconstruction.py:85-90):
+    """IncrementalDecoder (reference reed_solomon.py:232-403) on device tensors: columns arrive as (C, limbs) tensors
+    and stay in one party-major buffer in HBM; the guess, its validation and the robust fallback are launches over all
+    C polynomials.  Same state machine and the same decisions as `reed_solomon.IncrementalDecoder`:
 
-      * degree+1 columns: optimistic decode + re-encode (the guess);
-      * every later column is compared with its row of the guess; degree+1+max_errors-|confirmed| agreeing
-        columns finish the batch;
-      * the first disagreement switches to robust mode for good: every remaining polynomial is Gao-decoded over
-        the current arrival set in one launch, polynomials are accepted in order, and the first one that
-        confirms erroneous senders drops their columns and has the rest decoded again (reference :334-365).
+      * degree+1 columns: optimistic decode + re-encode (the guess) -- an open plan (BatchOpen) over the arrival set reads
+        the arrived rows of the party-major buffer in place and writes the guess party-major: no gather, no transpose;
+      * every later column is compared with its row of the guess; degree+1+max_errors-|confirmed| agreeing columns finish;
+      * the first disagreement switches to robust mode for good (reference :334-365).  The reference then robust-decodes
+        polynomial after polynomial.  Here the next polynomial is robust-decoded alone (Gao or Welch-Berlekamp, one
+        codeword); when it shows no error over the current arrival set, ONE plan interpolates every remaining polynomial
+        from degree+1 of the arrived columns and checks it against all the other arrived columns: if that passes, every one
+        of them would have robust-decoded without errors to exactly these coefficients (the interpolant is unique), and they
+        are all accepted at once.  Only a batch in which some later polynomial still hides an error goes through the
+        batched robust decode (`_robust_batch`, one launch over the remaining codewords, accepted in order).
 
-    get_results() -> ((C, degree+1, 4) coefficient tensor, set of confirmed erroneous senders) or (None, None).
+    robust: "gao" (what batch_reconstruct uses, batch_reconstruction.py:85-90) or "wb".
+    get_results() -> ((C, degree+1, limbs) coefficient tensor, set of confirmed erroneous senders) or (None, None).
     """
 
-    def __init__(self, modulus, n, t, degree=None, batch_size=1, use_omega_powers=False, confirmed_errors=None, device=None):
+    def __init__(self, modulus, n, t, degree=None, batch_size=1, use_omega_powers=False, confirmed_errors=None, device=None, robust="gao"):
         from .field import GF
         from .polynomial import EvalPoint
 
+        if robust not in ("gao", "wb"):
+            raise ValueError("robust must be 'gao' or 'wb'")
         self.ctx = ctx = Context.get(modulus, device)
         self.n, self.max_errors = n, t
         self.degree = t if degree is None else degree
         self.batch_size = int(batch_size)
+        self.robust = robust
+        self.use_omega_powers = use_omega_powers
         point = EvalPoint(GF(modulus), n, use_omega_powers=use_omega_powers)
         self.x = [point(i).value for i in range(n)]
         self._xh_all = ctx.host_elems(self.x)
@@ -226,44 +234,79 @@ class DeviceIncrementalDecoder:
         self._available_points = set()
         self._z = []
         self._optimistic = True
-        self._guess_decoded = None      # (C, d, 4)
-        self._guess_encoded = None      # (n, C, 4)
+        self._guess_decoded = None      # (C, d, limbs)
+        self._guess_encoded = None      # (n, C, limbs)
         self._num_decoded = 0
         self._partial = ctx.empty(self.batch_size * (self.degree + 1)).view(self.batch_size, self.degree + 1, self.L)
         self._result = None
-        self.launches = 0               # robust-decode launches so far (diagnostic)
+        self._last_status = None
+        self.probes = 0                 # single-codeword robust decodes so far (diagnostic)
+        self.launches = 0               # batched robust-decode launches so far (diagnostic)
+        self.plan_accepts = 0           # batches accepted by one interpolate-and-check plan (diagnostic)
 
     # -- kernels ---------------------------------------------------------------------------------
-    def _rows(self, lo):
-        """the arrived columns of polynomials lo.. as (C - lo, npts, 4), one codeword per row"""
-        idx = self.ctx.torch.tensor(self._z, dtype=self.ctx.torch.int64, device=self.ctx.tdev)
-        return self._cols.index_select(0, idx)[:, lo:, :].transpose(0, 1).contiguous()
+    def _plan(self, z, zc):
+        return BatchOpen(self.ctx.modulus, self.n, self.max_errors, z=z, zc=zc, use_omega_powers=self.use_omega_powers,
+                         degree=self.degree, max_shares=self.batch_size * (self.degree + 1), device=self.ctx.device)
+
+    def _interpolate_and_check(self, z, zc):
+        """coefficients of every polynomial from the arrived rows z of the party-major buffer, validated against rows zc:
+        -> ((C, d, limbs), all agreed?)"""
+        d = self.degree + 1
+        plan = self._plan(z, zc)
+        dec = plan.r2_decode(self._cols.view(self.n * self.batch_size, self.L), self.batch_size * d)
+        ok = plan.ok() if zc else True
+        return dec.view(self.batch_size, d, self.L), ok, plan
+
+    def _rows(self, lo, count=None, order=None):
+        """the arrived columns of polynomials lo.. as (count, npts, limbs), one codeword per row (robust decodes only)"""
+        idx = self.ctx.torch.tensor(self._z if order is None else order, dtype=self.ctx.torch.int64, device=self.ctx.tdev)
+        hi = self.batch_size if count is None else min(self.batch_size, lo + count)
+        return self._cols[:, lo:hi, :].index_select(0, idx).transpose(0, 1).contiguous()
 
     def _decode_and_encode(self):
-        ctx, c, d, n = self.ctx, self.batch_size, self.degree + 1, self.n
-        rows = self._rows(0)
-        dec = ctx.empty(c * d)
-        xz = ctx.host_elems([self.x[i] for i in self._z])
-        ctx.check(ctx.lib.hb_vandermonde_batch_interpolate(ctx.h, np_ptr(xz), d, ctx.ptr(rows), c, ctx.ptr(dec), ctx.stream()), "interpolate")
-        enc = ctx.empty(c * n)
-        ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), n, ctx.ptr(dec), c, d, ctx.ptr(enc), ctx.stream()), "evaluate")
-        self._guess_decoded = dec.view(c, d, self.L)
-        self._guess_encoded = enc.view(c, n, self.L).transpose(0, 1).contiguous()
+        c, d, n = self.batch_size, self.degree + 1, self.n
+        dec, _, plan = self._interpolate_and_check(list(self._z), [])
+        enc = plan.r1_encode(dec.view(c * d, self.L))                 # the guess as a share vector: chunk c = its coefficients
+        self._guess_decoded = dec
+        self._guess_encoded = enc.view(n, c, self.L)
 
     def _robust_batch(self, limit=None):
-        """Gao over the remaining polynomials (the first `limit` of them) and the current arrival set:
-        -> ok (Crem,) bool, coeffs (Crem, d, 4), errs (Crem, n) bool: the senders the error locator points at."""
+        """robust decode of the remaining polynomials (the first `limit` of them) over the current arrival set:
+        -> ok (Crem,) bool, coeffs (Crem, d, limbs), errs (Crem, n) bool: the senders in error."""
         ctx, t = self.ctx, self.ctx.torch
         lo, d, n, npts = self._num_decoded, self.degree + 1, self.n, len(self._z)
         crem = self.batch_size - lo if limit is None else min(limit, self.batch_size - lo)
-        rows = self._rows(lo)[:crem].contiguous()
         co = ctx.empty(crem * d)
+        if limit is None:
+            self.launches += 1
+        else:
+            self.probes += 1
+        if self.robust == "wb":
+            # reed_solomon.py:203-224: decode over the arrived points (in party order, as the reference enumerates them),
+            # re-encode, the disagreeing positions are the errors
+            zs = sorted(self._z)
+            rows = self._rows(lo, crem, zs)
+            xz = ctx.host_elems([self.x[i] for i in zs])
+            present = t.ones(crem * npts, dtype=t.uint8, device=ctx.tdev)
+            ln = t.zeros(crem, dtype=t.int32, device=ctx.tdev)
+            st = t.zeros(crem, dtype=t.int32, device=ctx.tdev)
+            ctx.check(ctx.lib.hb_wb_decode(ctx.h, np_ptr(xz), npts, d, ctx.ptr(rows), ctx.ptr(present), crem, ctx.ptr(co), ctx.ptr(ln), ctx.ptr(st), ctx.stream()), "wb")
+            ok = st == 0
+            self._last_status = st
+            ev = ctx.empty(crem * npts)
+            ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(xz), npts, ctx.ptr(co), crem, d, ctx.ptr(ev), ctx.stream()), "evaluate")
+            differs = (ev.view(crem, npts, self.L) != rows).any(dim=2) & ok.unsqueeze(1)
+            errs = t.zeros((crem, n), dtype=t.bool, device=ctx.tdev)
+            errs[:, t.tensor(zs, dtype=t.int64, device=ctx.tdev)] = differs
+            return ok, co.view(crem, d, self.L), errs
+        rows = self._rows(lo, crem)
+        xz = ctx.host_elems([self.x[i] for i in self._z])
+        self._last_status = None
         el = t.zeros((crem * (npts + 1), self.L), dtype=t.int64, device=ctx.tdev)
         ln = t.zeros(crem, dtype=t.int32, device=ctx.tdev)
         ok = t.zeros(crem, dtype=t.uint8, device=ctx.tdev)
-        xz = ctx.host_elems([self.x[i] for i in self._z])
         ctx.check(ctx.lib.hb_gao_decode(ctx.h, np_ptr(xz), npts, d, ctx.ptr(rows), crem, ctx.ptr(co), ctx.ptr(el), ctx.ptr(ln), ctx.ptr(ok), ctx.stream()), "gao")
-        self.launches += 1
         ok = ok.bool()
         # roots of the error locator among ALL party points are the faulty senders (reference :174-184); a locator of
         # length <= 1 names nobody.  Entries past the locator's length are not part of it.
@@ -273,6 +316,16 @@ class DeviceIncrementalDecoder:
         ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), n, ctx.ptr(el), crem, npts + 1, ctx.ptr(ev), ctx.stream()), "evaluate")
         errs = (ev.view(crem, n, self.L) == 0).all(dim=2) & (ln > 1).unsqueeze(1) & ok.unsqueeze(1)
         return ok, co.view(crem, d, self.L), errs
+
+    def _undecodable(self, pos):
+        """polynomial `pos` of the last robust batch did not decode: (None, None) for the reference's swallowed failures,
+        its other exceptions re-raised as the reference's robust decoder does (reed_solomon.py:205-212)"""
+        if self._last_status is not None:
+            st = int(self._last_status[pos].item())
+            if st == 2:
+                raise Exception("No solution")           # reed_solomon_wb.py:245
+            if st == 3:
+                raise AssertionError("2 * t + 1 + c <= n")   # reed_solomon_wb.py:132
 
     # -- the state machine (reference :288-372) ------------------------------------------------------
     def _min_points_required(self):
@@ -291,42 +344,61 @@ class DeviceIncrementalDecoder:
             self._result = self._guess_decoded
         return agree
 
+    def _accept(self, coeffs, errors):
+        self._partial[self._num_decoded] = coeffs
+        self._num_decoded += 1
+        if errors:
+            self._confirmed_errors |= set(errors)
+            self._available_points -= set(errors)
+            self._z = [i for i in self._z if i not in errors]
+
     def _robust_update(self):
         t = self.ctx.torch
+        d = self.degree + 1
         while self._num_decoded < self.batch_size:
-            # the reference's next robust_decode, alone: while it stalls (undecodable, or too few points once its errors
-            # are dropped) nothing else can be accepted either, and an arrival costs one codeword instead of all of them
+            # the reference's next robust_decode, alone: while it stalls (undecodable, or too few points once its errors are
+            # dropped) nothing else can be accepted either, and an arrival costs one codeword instead of all of them
             ok, coeffs, errs = self._robust_batch(1)
             if not bool(ok[0].item()):
+                self._undecodable(0)
                 return
-            if len(self._available_points) - int(errs[0].sum().item()) < self._min_points_required():
+            errors = t.nonzero(errs[0]).flatten().tolist()
+            if len(self._available_points) - len(errors) < self._min_points_required():
                 return
+            if errors:
+                self._accept(coeffs[0], errors)          # this polynomial confirmed senders in error: the next one sees fewer points
+                continue
+            # no error in this polynomial over the arrival set.  If every remaining polynomial interpolates from d of the
+            # arrived columns and agrees with all the others, each of them robust-decodes to that interpolant with no
+            # errors and passes the same agreement count as this one: accept them all.
+            dec, all_agree, _ = self._interpolate_and_check(self._z[:d], self._z[d:])
+            if all_agree:
+                self._partial[self._num_decoded :] = dec[self._num_decoded :]
+                self._num_decoded = self.batch_size
+                self.plan_accepts += 1
+                break
+            # some later polynomial still has an error: batched robust decode, accepted in order up to the first such one
             ok, coeffs, errs = self._robust_batch()
             has_err = errs.any(dim=1)
-            stop = (~ok) | has_err                       # the first polynomial that is not a plain accept
+            stop = (~ok) | has_err
             first = int(t.nonzero(stop)[0].item()) if bool(stop.any().item()) else int(ok.shape[0])
-            if len(self._available_points) < self._min_points_required():
-                return                                   # even an error-free polynomial cannot be accepted yet
             if first:                                    # error-free polynomials before it: accepted as they are
                 self._partial[self._num_decoded : self._num_decoded + first] = coeffs[:first]
                 self._num_decoded += first
             if first == ok.shape[0]:
                 break
             if not bool(ok[first].item()):
+                self._undecodable(first)
                 return                                   # (None, None): more columns needed
-            errors = [i for i in t.nonzero(errs[first]).flatten().tolist()]
+            errors = t.nonzero(errs[first]).flatten().tolist()
             if len(self._available_points) - len(errors) < self._min_points_required():
                 return
-            self._partial[self._num_decoded] = coeffs[first]
-            self._num_decoded += 1
-            self._confirmed_errors |= set(errors)
-            self._available_points -= set(errors)
-            self._z = [i for i in self._z if i not in errors]
+            self._accept(coeffs[first], errors)
         if self._num_decoded == self.batch_size:
             self._result = self._partial
 
     def add(self, idx, column):
-        """column: (C, 4) limb tensor on the device, or a list of C ints."""
+        """column: (C, limbs) limb tensor on the device, or a list of C ints."""
         if self.done() or idx in self._available_points or idx in self._confirmed_errors:
             return
         if not hasattr(column, "shape"):
@@ -335,6 +407,7 @@ class DeviceIncrementalDecoder:
             column = self.ctx.upload_ints(column)
         if tuple(column.shape) != (self.batch_size, self.L):
             raise ValueError("Incorrect length of data")
+        column = self.ctx.elems(column, self.batch_size, what="column")
         self._available_points.add(idx)
         self._z.append(idx)
         self._cols[idx] = column

@@ -6,8 +6,14 @@ honeybadgermpc/ntl/hbmpc_ntl_helpers.pyx:73-455).
 Same names, positional orders, padding / truncation rules and error behaviour;
 the arithmetic runs on the MI355X through libhbmpc_hip.so (include/hbmpc_hip.h).
 Inputs are lists/tuples of non-negative Python ints, outputs lists of canonical
-ints, exactly like the reference boundary.  For bulk work without the list
-round-trip use :mod:`honeybadgermpc_amd.device` (tensors stay in HBM).
+ints, exactly like the reference boundary.
+
+Packed batches.  Marshalling Python ints costs ~60 ns each on either side of the call -- more than the arithmetic.
+Every batched argument (`polynomials`, `data_list`, `coeffs`, `ys_list`, `ys`) therefore also accepts the kernels' own
+layout, and the result comes back in the same kind:
+    numpy.ndarray  uint64, shape (rows, width, limbs)      little-endian limbs, limbs = 4 (p < 2^256) or 1 (p < 2^64)
+    torch.Tensor   int64,  shape (rows, width, limbs)      host or device; a device tensor never leaves HBM
+Values are reduced on entry like list inputs (pyx:31-32).  The points / exponents (x, zs, omega) stay small lists.
 """
 import ctypes
 
@@ -45,6 +51,48 @@ def _rows(flat, width, count):
     return [flat[i * width : (i + 1) * width] for i in range(count)]
 
 
+class _Batch:
+    """a batched argument on the device: `dev` (rows * width, limbs) tensor + how the caller handed it over"""
+
+    def __init__(self, ctx, data, pad_to=None, what="batch"):
+        t = ctx.torch
+        self.ctx = ctx
+        if isinstance(data, np.ndarray) or isinstance(data, t.Tensor):
+            if data.ndim != 3 or data.shape[2] != ctx.n_limbs:
+                raise ValueError(f"{what}: packed batches have shape (rows, width, {ctx.n_limbs})")
+            self.rows, self.width = int(data.shape[0]), int(data.shape[1])
+            if isinstance(data, np.ndarray):
+                if data.dtype != np.uint64:
+                    raise ValueError(f"{what}: numpy batches must be uint64 limbs")
+                self.kind = "numpy"
+                dev = ctx.to_device(data.reshape(self.rows * self.width, ctx.n_limbs))
+            else:
+                if data.dtype != t.int64:
+                    raise ValueError(f"{what}: torch batches must be int64 (u64 limbs viewed as int64)")
+                self.kind = "torch-device" if data.is_cuda else "torch-host"
+                dev = data.reshape(self.rows * self.width, ctx.n_limbs).contiguous().to(ctx.tdev)
+            if pad_to is not None and pad_to != self.width:
+                raise ValueError(f"{what}: packed rows must have length {pad_to}")
+            self.dev = dev
+            return
+        self.kind = "list"
+        self.rows = len(data)
+        self.width = max([len(r) for r in data]) if pad_to is None else pad_to
+        self.dev = ctx.upload_ints(_flat_padded(data, self.width)) if self.rows * self.width else ctx.empty(1)
+
+    def result(self, out, width):
+        """(rows * width, limbs) device tensor -> what the caller's kind of batch looks like"""
+        ctx = self.ctx
+        if self.kind == "list":
+            return _rows(ctx.download_ints(out), width, self.rows)
+        shaped = out.view(self.rows, width, ctx.n_limbs)
+        if self.kind == "torch-device":
+            return shaped
+        if self.kind == "torch-host":
+            return shaped.cpu()
+        return shaped.cpu().numpy().view(np.uint64)
+
+
 # ---------------------------------------------------------------------------
 # Vandermonde path
 # ---------------------------------------------------------------------------
@@ -52,35 +100,33 @@ def vandermonde_batch_evaluate(x, polynomials, modulus):
     """result[j][i] = sum_l polynomials[j][l] * x[i]^l  (pyx:199-244)."""
     _require_list(x)
     ctx = Context.get(modulus)
-    n, k = len(x), len(polynomials)
-    d = max([len(poly) for poly in polynomials])
-    din = ctx.upload_ints(_flat_padded(polynomials, d))
+    batch = _Batch(ctx, polynomials, what="polynomials")
+    n, k, d = len(x), batch.rows, batch.width
     dout = ctx.empty(k * n)
     rc = ctx.lib.hb_vandermonde_batch_evaluate(
-        ctx.h, np_ptr(ctx.host_elems(x)), n, ctx.ptr(din), k, d, ctx.ptr(dout), ctx.stream()
+        ctx.h, np_ptr(ctx.host_elems(x)), n, ctx.ptr(batch.dev), k, d, ctx.ptr(dout), ctx.stream()
     )
     ctx.check(rc, "vandermonde_batch_evaluate")
-    return _rows(ctx.download_ints(dout), n, k)
+    return batch.result(dout, n)
 
 
 def vandermonde_batch_interpolate(x, data_list, modulus):
     """polynomials[j] = coefficients (untrimmed, len(x) of them) of the P_j with
     P_j(x[i]) = data_list[j][i]; InterpolationError when V(x) is singular (pyx:139-197)."""
     ctx = Context.get(modulus)
-    k = max([len(d) for d in data_list])
-    n_chunks = len(data_list)
+    batch = _Batch(ctx, data_list, what="data_list")
+    k, n_chunks = batch.width, batch.rows
     if k != len(x):
         # NTL would abort on the dimension mismatch (unpinned in the reference); be explicit
         raise ValueError("vandermonde_batch_interpolate: len(x) must equal the row length")
-    din = ctx.upload_ints(_flat_padded(data_list, k))
     dout = ctx.empty(n_chunks * k)
     rc = ctx.lib.hb_vandermonde_batch_interpolate(
-        ctx.h, np_ptr(ctx.host_elems(x)), k, ctx.ptr(din), n_chunks, ctx.ptr(dout), ctx.stream()
+        ctx.h, np_ptr(ctx.host_elems(x)), k, ctx.ptr(batch.dev), n_chunks, ctx.ptr(dout), ctx.stream()
     )
     if rc == HB_ERR_SINGULAR:
         raise InterpolationError("Interpolation failed")
     ctx.check(rc, "vandermonde_batch_interpolate")
-    return _rows(ctx.download_ints(dout), k, n_chunks)
+    return batch.result(dout, k)
 
 
 def vandermonde_inverse(x, modulus):
@@ -131,22 +177,23 @@ def evaluate(polynomial, x, modulus):
 def fft_batch_evaluate(coeffs, omega, modulus, n, k):
     """Row-wise first k of the n-point transform a[i] = sum_j c[j] omega^(ij) (pyx:286-316)."""
     ctx = Context.get(modulus)
-    batch_size = len(coeffs)
-    d = len(coeffs[0])
-    for row in coeffs:
-        if len(row) != d:
-            # the reference sizes every row from row 0 (pyx:295): ragged input is UB there
-            raise ValueError("fft_batch_evaluate: all rows must have the same length")
+    if isinstance(coeffs, (list, tuple)):
+        d0 = len(coeffs[0])
+        for row in coeffs:
+            if len(row) != d0:
+                # the reference sizes every row from row 0 (pyx:295): ragged input is UB there
+                raise ValueError("fft_batch_evaluate: all rows must have the same length")
     n, k = int(n), int(k)
     if k > n or n <= 0 or n & (n - 1):
         raise ValueError("fft_batch_evaluate: n must be a power of two and k <= n")
-    din = ctx.upload_ints([c for row in coeffs for c in row]) if d else ctx.empty(1)
+    batch = _Batch(ctx, coeffs, what="coeffs")
+    batch_size, d = batch.rows, batch.width
     dout = ctx.empty(batch_size * k)
     rc = ctx.lib.hb_fft_batch_evaluate(
-        ctx.h, np_ptr(ctx.host_elems([omega])), n, ctx.ptr(din), batch_size, d, k, ctx.ptr(dout), ctx.stream()
+        ctx.h, np_ptr(ctx.host_elems([omega])), n, ctx.ptr(batch.dev), batch_size, d, k, ctx.ptr(dout), ctx.stream()
     )
     ctx.check(rc, "fft_batch_evaluate")
-    return _rows(ctx.download_ints(dout), k, batch_size)
+    return batch.result(dout, k)
 
 
 def fft(coeffs, omega, modulus, n):
@@ -162,19 +209,21 @@ def fft_batch_interpolate(zs, ys_list, omega, modulus, n):
     """Row-wise P (k = len(zs) untrimmed coefficients) with P(omega^zs[i]) = ys[i] (pyx:342-381)."""
     ctx = Context.get(modulus)
     k = len(zs)
-    n_chunks = len(ys_list)
     za = np.array([int(z) for z in zs], dtype=np.int32)
     if k and (za.min() < 0 or za.max() >= int(n)):
         raise ValueError("fft_batch_interpolate: zs must lie in [0, n)")
-    din = ctx.upload_ints([y for row in ys_list for y in row[:k]]) if k else ctx.empty(1)
+    if isinstance(ys_list, (list, tuple)):
+        ys_list = [list(row[:k]) for row in ys_list]
+    batch = _Batch(ctx, ys_list, pad_to=k, what="ys_list")
+    n_chunks = batch.rows
     dout = ctx.empty(n_chunks * k)
     rc = ctx.lib.hb_fft_batch_interpolate(
-        ctx.h, np_ptr(ctx.host_elems([omega])), int(n), np_ptr(za), k, ctx.ptr(din), n_chunks, ctx.ptr(dout), ctx.stream()
+        ctx.h, np_ptr(ctx.host_elems([omega])), int(n), np_ptr(za), k, ctx.ptr(batch.dev), n_chunks, ctx.ptr(dout), ctx.stream()
     )
     if rc == HB_ERR_SINGULAR:
         raise ValueError("fft_batch_interpolate: zs must be distinct")
     ctx.check(rc, "fft_batch_interpolate")
-    return _rows(ctx.download_ints(dout), k, n_chunks)
+    return batch.result(dout, k)
 
 
 def fft_interpolate(zs, ys, omega, modulus, n):
@@ -188,8 +237,9 @@ def gao_interpolate_batch(x, ys, k, modulus):
     """C codewords sharing the points x (no erasures) decoded in one launch.
     Returns a list of (coeffs, error_poly) | (None, None).  (Batched form of pyx:389-439.)"""
     ctx = Context.get(modulus)
-    n, c = len(x), len(ys)
-    dys = ctx.upload_ints([v for row in ys for v in row])
+    batch = _Batch(ctx, ys, pad_to=len(x), what="ys")
+    n, c = len(x), batch.rows
+    dys = batch.dev
     dco = ctx.empty(c * k)
     derr = ctx.empty(c * (n + 1))
     t = ctx.torch
@@ -200,6 +250,15 @@ def gao_interpolate_batch(x, ys, k, modulus):
         ctx.ptr(dco), ctx.ptr(derr), ctx.ptr(dlen), ctx.ptr(dok), ctx.stream(),
     )
     ctx.check(rc, "gao_interpolate")
+    if batch.kind != "list":
+        # packed: (coeffs (C, k, limbs), error polynomials (C, n + 1, limbs) zero beyond their lengths, lengths (C,), ok (C,))
+        keep = t.arange(n + 1, device=ctx.tdev).unsqueeze(0) < dlen.unsqueeze(1)
+        derr = derr.view(c, n + 1, ctx.n_limbs) * keep.unsqueeze(2)
+        if batch.kind == "torch-device":
+            return dco.view(c, k, ctx.n_limbs), derr, dlen, dok.bool()
+        if batch.kind == "torch-host":
+            return dco.view(c, k, ctx.n_limbs).cpu(), derr.cpu(), dlen.cpu(), dok.bool().cpu()
+        return (dco.view(c, k, ctx.n_limbs).cpu().numpy().view(np.uint64), derr.cpu().numpy().view(np.uint64), dlen.cpu().numpy(), dok.bool().cpu().numpy())
     ok, lens = dok.cpu().tolist(), dlen.cpu().tolist()
     co, er = ctx.download_ints(dco), ctx.download_ints(derr)
     out = []

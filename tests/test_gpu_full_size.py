@@ -1,0 +1,334 @@
+"""
+GPU tests at BASELINE.json's full sizes for the configurations round 1 only covered at reduced size:
+config 4 (robust decoders, n=100 t=33), config 5's shard (n=256 t=85, 2^19 shares), a bounded randomised differential run
+of the two kernel families, every entry point on the narrow (p < 2^64, 1-limb) instantiation, and the bounded table caches.
+Bit-exact: generating polynomials / secrets must come back, and oracle subsets are compared value by value.
+"""
+import ctypes
+import random
+import time
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import BLS
+
+pytestmark = pytest.mark.gpu
+
+P = BLS
+
+
+def _rand(torch, count, gen):
+    t = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device="cuda", generator=gen)
+    t[:, 3] &= (1 << 61) - 1
+    return t
+
+
+# ---------------------------------------------------------------------------------------------- config 4
+@pytest.mark.parametrize("decoder,count", [("gao", 1 << 18), ("wb", 1 << 14)])
+def test_robust_decoders_full_batch_cfg4(decoder, count):
+    """n=100, t=33: `count` codewords of random degree-33 polynomials, exactly 33 positions of each replaced by random field
+    elements (the decoding radius), no erasures -> every generating polynomial recovered bit for bit; a 64-codeword subset
+    against the oracle's decoders; a batch with codewords beyond the radius keeps the reference's outcomes."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context, np_ptr
+
+    n, t = 100, 33
+    k = t + 1
+    ctx = Context.get(P)
+    lib = ctx.lib
+    xh = ctx.host_elems(list(range(1, n + 1)))
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(44)
+    msg = _rand(torch, count * k, gen)
+    code = ctx.empty(count * n)
+    ctx.check(lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(xh), n, ctx.ptr(msg), count, k, ctx.ptr(code), ctx.stream()), "enc")
+    pos = torch.rand((count, n), device="cuda", generator=gen).argsort(dim=1)[:, :t]
+    idx = (torch.arange(count, device="cuda").unsqueeze(1) * n + pos).reshape(-1)
+    bad = code.clone()
+    bad[idx] = _rand(torch, count * t, gen)
+    out = ctx.empty(count * k)
+    if decoder == "gao":
+        err = ctx.empty(count * (n + 1))
+        elen = torch.zeros(count, dtype=torch.int32, device="cuda")
+        ok = torch.zeros(count, dtype=torch.uint8, device="cuda")
+        ctx.check(lib.hb_gao_decode(ctx.h, np_ptr(xh), n, k, ctx.ptr(bad), count, ctx.ptr(out), ctx.ptr(err), ctx.ptr(elen), ctx.ptr(ok), ctx.stream()), "gao")
+        assert bool(ok.all().item()) and bool((elen == t + 1).all().item())
+        # the error locator's roots are exactly the corrupted positions (first 16 codewords, exact integers)
+        ev = ctx.empty(16 * n)
+        ctx.check(lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(xh), n, ctx.ptr(err), 16, n + 1, ctx.ptr(ev), ctx.stream()), "ev")
+        roots = (ev.view(16, n, 4) == 0).all(dim=2)
+        want = torch.zeros((16, n), dtype=torch.bool, device="cuda")
+        want.scatter_(1, pos[:16], True)
+        changed = (bad.view(count, n, 4)[:16] != code.view(count, n, 4)[:16]).any(dim=2)
+        assert torch.equal(roots, want & changed)
+    else:
+        present = torch.ones(count * n, dtype=torch.uint8, device="cuda")
+        olen = torch.zeros(count, dtype=torch.int32, device="cuda")
+        st = torch.zeros(count, dtype=torch.int32, device="cuda")
+        ctx.check(lib.hb_wb_decode(ctx.h, np_ptr(xh), n, k, ctx.ptr(bad), ctx.ptr(present), count, ctx.ptr(out), ctx.ptr(olen), ctx.ptr(st), ctx.stream()), "wb")
+        assert bool((st == 0).all().item())
+        top_nonzero = (msg.view(count, k, 4)[:, k - 1] != 0).any(dim=1)
+        assert bool((olen[top_nonzero] == k).all().item())
+    assert torch.equal(out, msg), "decoded coefficients differ from the generating polynomials"
+    # oracle subset
+    sub = 8 if decoder == "wb" else 64
+    words = ctx.download_ints(bad[: sub * n])
+    rows = [words[i * n : (i + 1) * n] for i in range(sub)]
+    got = ctx.download_ints(out[: sub * k])
+    if decoder == "gao":
+        ref = oracle.gao_interpolate_batch(list(range(1, n + 1)), rows, k, P)
+        assert [got[i * k : (i + 1) * k] for i in range(sub)] == [r[0] for r in ref]
+    else:
+        ref = oracle.wb_decode_batch(list(range(1, n + 1)), k, rows, P)
+        for i in range(sub):
+            coeffs = ref[i][0]
+            assert coeffs is not None and got[i * k : i * k + len(coeffs)] == coeffs
+    if decoder == "wb":
+        # beyond the radius (34 errors): the row reduction decides, exactly as the oracle's restatement of the reference does
+        m = 6
+        gen2 = random.Random(6)
+        words = ctx.download_ints(code[: m * n])
+        rows = []
+        for i in range(m):
+            row = words[i * n : (i + 1) * n]
+            for j in gen2.sample(range(n), t + 1 + (i % 2)):
+                row[j] = gen2.randrange(P)
+            rows.append(row)
+        from honeybadgermpc_amd.device import wb_decode_batch
+
+        assert wb_decode_batch(list(range(1, n + 1)), k, rows, P) == oracle.wb_decode_batch(list(range(1, n + 1)), k, rows, P)
+
+
+# ---------------------------------------------------------------------------------------------- config 5 (one shard)
+def test_full_size_open_cfg5_shard():
+    """One GPU's 1/8 shard of BASELINE config 5 (n=256, t=85, omega points, 2^19 shares): consistent inputs, both kernel
+    families agree, the secrets come back, a corrupted validated column is caught, and the first 1 024 chunks of the R1
+    encode and of the result equal the oracle's."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+
+    import bench
+
+    n, t, b = 256, 85, (1 << 22) // 8
+    d = t + 1
+    c = (b + d - 1) // d
+    ctx = Context.get(P)
+    shares0, r1_cols, r2_cols, secrets, x = bench.make_inputs_light(torch, ctx, n, t, b, True, seed=55)
+    order = np.random.Generator(np.random.PCG64(5)).permutation(n).tolist()
+    z, zc = order[:d], order[d : d + t]
+    op = BatchOpen(P, n, t, z=z, zc=zc, use_omega_powers=True, max_shares=b)
+    assert op.uses_matrix_cores()
+    outs = {}
+    for on in (True, False):
+        op.set_matrix_cores(on)
+        r1 = op.r1_encode(shares0)
+        msg = op.r1_decode(r1_cols, b)
+        res = op.r2_decode(r2_cols, b)
+        assert op.ok()
+        assert torch.equal(res, secrets) and torch.equal(msg, r2_cols[:c])
+        outs[on] = (r1.clone(), msg.clone(), res.clone())
+    assert all(torch.equal(a, bb) for a, bb in zip(outs[True], outs[False])), "matrix-core and integer-VALU decodes differ"
+    bad = r2_cols.clone()
+    bad[zc[3] * c + c // 2, 1] ^= 1 << 17
+    op.set_matrix_cores(True)
+    op.r2_decode(bad, b)
+    assert not op.ok()
+    # oracle subset: the first 1 024 chunks
+    sub = 1024
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+
+    point = EvalPoint(GF(P), n, use_omega_powers=True)
+    sh = ctx.download_ints(shares0[: sub * d])
+    want = oracle.fft_batch_evaluate([sh[i * d : (i + 1) * d] for i in range(sub)], point.omega.value, P, point.order, n)
+    got = ctx.download_ints(outs[True][0].view(n, c, 4)[:, :sub].contiguous().view(n * sub, 4))
+    assert [[got[j * sub + i] for j in range(n)] for i in range(sub)] == want
+    cols = ctx.download_ints(r2_cols.view(n, c, 4)[:, :sub].contiguous().view(n * sub, 4))
+    ys = [[cols[j * sub + i] for j in z] for i in range(sub)]
+    coef = oracle.fft_batch_interpolate(z, ys, point.omega.value, P, point.order)
+    assert ctx.download_ints(outs[True][2][: sub * d]) == [v for row in coef for v in row]
+
+
+# ---------------------------------------------------------------------------------------------- bounded stress
+def test_randomised_differential_open_paths():
+    """~20 s, seeded: random shapes / arrival orders / edge-heavy inputs through the matrix-core and the integer-VALU
+    kernels (scratch/stress_open_paths.py ran 248 k such opens in round 1; this is its bounded twin inside the suite),
+    now including shapes that take the full-size matrix-core kernel (omega points, large powers)."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+
+    edge = [0, 1, 2, P - 1, P - 2, (P - 1) // 2, int("80" * 32, 16) % P, int("7f" * 32, 16) % P, int("ff00" * 16, 16) % P, 1 << 254, (1 << 254) - 1]
+    rnd = random.Random(20260928)
+    ctx = Context.get(P)
+    as_np = lambda tns: tns.cpu().numpy().view(np.uint64)  # noqa: E731
+    t_end = time.time() + 20.0
+    trials = wide = 0
+    while time.time() < t_end or trials < 40:
+        n = rnd.choice([4, 5, 7, 8, 13, 16, 17, 22, 31, 32, 33, 40, 47, 48, 49, 63, 64, 100, 128])
+        t = rnd.randrange(0, min(n, 32))
+        use_omega = rnd.random() < 0.25
+        d = t + 1
+        b = rnd.choice([1, d, d + 1, 16 * d, 16 * d + 1, 33 * d - 1, rnd.randrange(1, 3000)])
+        c = (b + d - 1) // d
+        order = list(range(n))
+        rnd.shuffle(order)
+        z, zc = order[:d], order[d : d + min(t, n - d)]
+        op = BatchOpen(P, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=b)
+        if not op.uses_matrix_cores():
+            continue
+        wide += use_omega or n ** t >= 127 * 256 ** 15
+        shares = [rnd.choice(edge) if rnd.random() < rnd.choice([0.0, 0.1, 0.9]) else rnd.randrange(P) for _ in range(b)]
+        sh = ctx.upload_ints(shares)
+        enc_m = op.r1_encode(sh)
+        op.set_matrix_cores(False)
+        enc_v = op.r1_encode(sh)
+        assert np.array_equal(as_np(enc_m), as_np(enc_v)), ("encode", n, t, b, use_omega)
+        bad = None
+        if zc and rnd.random() < 0.5:
+            bad = enc_m.clone()
+            bad[rnd.choice(zc) * c + rnd.randrange(c), rnd.randrange(4)] ^= 1 << rnd.randrange(60)
+        outs = []
+        for on in (True, False):
+            op.set_matrix_cores(on)
+            msg = op.r1_decode(enc_m, b)
+            res = op.r2_decode(enc_m, b)
+            assert op.ok(), ("validate", n, t, b, on, use_omega)
+            assert ctx.download_ints(res) == shares, ("decode", n, t, b, on, use_omega)
+            outs.append((as_np(msg).copy(), as_np(res).copy()))
+            if bad is not None:
+                op.r2_decode(bad, b)
+                assert not op.ok(), ("corruption missed", n, t, b, on, use_omega)
+        assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+        trials += 1
+        del op
+    torch.cuda.synchronize()
+    assert trials >= 40 and wide >= 5
+
+
+# ---------------------------------------------------------------------------------------------- narrow contexts
+@pytest.mark.parametrize("p", [(1 << 64) - 59, 0xFFFFFFFF00000001, (1 << 61) - 1])
+def test_narrow_context_every_entry_point(p):
+    """north star "64/256-bit prime": a modulus below 2^64 gets the 1-limb context (8-byte elements, 3 x 29-bit digits)
+    from Context.get, and every entry point of the drop-in on it equals the oracle."""
+    from honeybadgermpc_amd import ntl
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen, DeviceIncrementalDecoder, wb_decode_batch
+
+    ctx = Context.get(p)
+    assert ctx.n_limbs == 1 and ctx.nbytes == 8 and ctx.empty(3).shape == (3, 1)
+    rnd = random.Random(p % 9973)
+    n, d, c = 32, 11, 300
+    x = [rnd.randrange(1, p) for _ in range(n)]
+    polys = [[rnd.randrange(p) for _ in range(d)] for _ in range(c)]
+    ev = oracle.vandermonde_batch_evaluate(x, polys, p)
+    assert ntl.vandermonde_batch_evaluate(x, polys, p) == ev
+    zsel = rnd.sample(range(n), d)
+    assert ntl.vandermonde_batch_interpolate([x[j] for j in zsel], [[row[j] for j in zsel] for row in ev], p) == polys
+    # NTT (2-adicity: 2^64 - 59 has p - 1 = 2 * odd: order-2 transforms only; the other two primes take order 32)
+    order = 32 if (p - 1) % 32 == 0 else 2
+    g = next(a for a in range(2, 1000) if pow(a, (p - 1) // 2, p) != 1)
+    omega = pow(g, (p - 1) // order, p)
+    dd = min(d, order)
+    co = [row[:dd] for row in polys]
+    fev = oracle.fft_batch_evaluate(co, omega, p, order, order)
+    assert ntl.fft_batch_evaluate(co, omega, p, order, order) == fev
+    zs = rnd.sample(range(order), dd)
+    assert ntl.fft_batch_interpolate(zs, [[row[j] for j in zs] for row in fev], omega, p, order) == co
+    # Gao and Welch-Berlekamp with errors
+    words = []
+    for row in ev[:40]:
+        row = list(row)
+        for j in rnd.sample(range(n), rnd.randrange(0, (n - d) // 2 + 1)):
+            row[j] = rnd.randrange(p)
+        words.append(row)
+    assert ntl.gao_interpolate_batch(x, words, d, p) == oracle.gao_interpolate_batch(x, words, d, p)
+    xs = list(range(1, 17))
+    wpolys = [[rnd.randrange(p) for _ in range(5)] for _ in range(12)]
+    wrows = []
+    for row in oracle.vandermonde_batch_evaluate(xs, wpolys, p):
+        row = list(row)
+        for j in rnd.sample(range(16), rnd.randrange(0, 7)):
+            row[j] = rnd.randrange(p) if rnd.random() < 0.8 else None
+        wrows.append(row)
+    assert wb_decode_batch(xs, 5, wrows, p) == oracle.wb_decode_batch(xs, 5, wrows, p)
+    assert ntl.sqrt_mod(pow(12345, 2, p), p) in (12345 % p, p - 12345 % p)
+    # the open and the device decoder
+    nn, t, b = 16, 5, 200
+    dq = t + 1
+    cq = (b + dq - 1) // dq
+    xq = list(range(1, nn + 1))
+    shares = [rnd.randrange(p) for _ in range(b)]
+    p1 = [[rnd.randrange(p) for _ in range(dq)] for _ in range(cq)]
+    p2 = [[rnd.randrange(p) for _ in range(dq)] for _ in range(cq)]
+    e1, e2 = oracle.vandermonde_batch_evaluate(xq, p1, p), oracle.vandermonde_batch_evaluate(xq, p2, p)
+    r1c = [[e1[k][j] for k in range(cq)] for j in range(nn)]
+    r2c = [[e2[k][j] for k in range(cq)] for j in range(nn)]
+    order_ = list(range(nn))
+    rnd.shuffle(order_)
+    z, zc = order_[:dq], order_[dq : dq + t]
+    lim = lambda rows: oracle._limbs([v for r in rows for v in r], p)  # noqa: E731
+    rc, o_r1, o_msg, o_res = oracle.batch_open_limbs(p, nn, dq, xq, oracle._limbs(shares, p), lim(r1c), lim(r2c), z, zc)
+    assert rc == 0
+    op = BatchOpen(p, nn, t, z=z, zc=zc, max_shares=b)
+    assert not op.uses_matrix_cores()
+    assert ctx.download_ints(op.r1_encode(ctx.upload_ints(shares))) == oracle._ints(o_r1)
+    assert ctx.download_ints(op.r1_decode(ctx.upload_ints([v for col in r1c for v in col]), b)) == oracle._ints(o_msg)
+    assert ctx.download_ints(op.r2_decode(ctx.upload_ints([v for col in r2c for v in col]), b)) == oracle._ints(o_res)
+    assert op.ok()
+    dec = DeviceIncrementalDecoder(p, nn, t, batch_size=cq)
+    liar = order_[1]
+    for idx in order_:
+        col = list(r2c[idx])
+        if idx == liar:
+            col[3] = (col[3] + 1) % p
+        dec.add(idx, col)
+        if dec.done():
+            break
+    res, errs = dec.get_results()
+    assert errs == {liar} and ctx.download_ints(res.reshape(-1, 1)) == [v for row in p2 for v in row]
+
+
+# ---------------------------------------------------------------------------------------------- bounded caches
+def test_table_caches_are_bounded(monkeypatch):
+    """the per-context caches are keyed by the arrival set of every asynchronous open.  With a cap of 16 entries,
+    hundreds of different arrival sets leave at most the cap (+ the entries of the call in flight) resident, results stay
+    right, the sorted-set key makes re-orderings of one set hit the same table, and cache_clear drops everything."""
+    from honeybadgermpc_amd import ntl
+    from honeybadgermpc_amd._capi import Context
+
+    p = (1 << 255) - 19                      # a modulus no other test holds a context for: the cap is read at context creation
+    monkeypatch.setenv("HB_CACHE_CAP", "16")
+    Context._cache.pop((p, 0, 4), None)
+    ctx = Context.get(p, 0)
+    rnd = random.Random(8)
+    n, d = 24, 6
+    x = list(range(1, n + 1))
+    polys = [[rnd.randrange(p) for _ in range(d)] for _ in range(4)]
+    ev = oracle.vandermonde_batch_evaluate(x, polys, p)
+    high = 0
+    for _ in range(150):
+        z = rnd.sample(range(n), d)
+        assert ntl.vandermonde_batch_interpolate([x[j] for j in z], [[row[j] for j in z] for row in ev], p) == polys
+        words = [list(row) for row in ev]
+        sub = sorted(rnd.sample(range(n), 16))
+        assert ntl.gao_interpolate_batch([x[j] for j in sub], [[row[j] for j in sub] for row in words], d, p)[0][0] == polys[0]
+        high = max(high, ctx.cache_entries())
+    assert high <= 16 + 8, high
+    # one set, many orders: one table
+    ctx.cache_clear()
+    assert ctx.cache_entries() == 0
+    zset = rnd.sample(range(n), d)
+    for _ in range(20):
+        rnd.shuffle(zset)
+        assert ntl.vandermonde_batch_interpolate([x[j] for j in zset], [[row[j] for j in zset] for row in ev], p) == polys
+    assert ctx.cache_entries() <= 1 + 20     # the table + at most one cached permutation per order
+    tables = ctx.cache_entries()
+    ctx.cache_clear()
+    assert ctx.cache_entries() == 0 and tables >= 1
