@@ -24,6 +24,7 @@
 // identical because every output is a canonical residue.
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "hb_common.hpp"
 
@@ -69,6 +70,66 @@ __device__ __forceinline__ void butterfly(uint32_t *a0, uint32_t *a1, const uint
     for (int q = 0; q < NL; q++) { a0[q] = s0[q]; a1[q] = s1[q]; }
 }
 
+// ---- value-lazy butterflies -------------------------------------------------------------------------------------------
+// Between the input and the output of a transform nothing has to be canonical.  Elements are kept as normalised digits of a
+// value below 2^(29 NL) (the top digit takes the excess):
+//     t  = REDC(w v)          < 2p for ANY v < R = 2^(29 NL)  (w < p):  no conditional subtraction
+//     u' = u + t,  v' = u - t + 2p                                      one carry pass each, no comparison with p
+// so a stage adds at most 2p to the bound: inputs below 2^(32 NW) and log2(n) <= 12 stages stay below 2^(32 NW) + 24 p < R.
+// One canonicalisation per OUTPUT replaces three conditional subtractions per butterfly (a quarter of its instructions).
+// multiples of p for the trivial butterflies of the first pass: m[u] >= bound of an element after u stages, B_0 = 2^(32 NW),
+// B_{u+1} = B_u + m[u]
+template <int NL> struct LazyConsts { uint32_t m[3][NL]; uint32_t p2[NL]; /* 2p */ };
+
+template <int NL> __device__ __forceinline__ void mont_mul_lazy(uint32_t (&r)[NL], const uint32_t (&a)[NL], const uint32_t (&b)[NL], const FpParams<NL> &P) {
+    uint64_t c[2 * NL];
+    col_zero(c);
+    mac<NL>(c, a, b);
+    carry(c);
+    redc(r, c, P);
+}
+template <int NL> __device__ __forceinline__ void add_lazy(uint32_t (&r)[NL], const uint32_t (&a)[NL], const uint32_t (&b)[NL]) {
+    uint32_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t v = a[i] + b[i] + cy;
+        if (i < NL - 1) { cy = v >> LB; r[i] = v & DMASK; } else r[i] = v;
+    }
+}
+// r = a - b + p2 with p2 = 2p >= b: non-negative, one signed carry pass
+template <int NL> __device__ __forceinline__ void sub_lazy(uint32_t (&r)[NL], const uint32_t (&a)[NL], const uint32_t (&b)[NL], const uint32_t (&p2)[NL]) {
+    int32_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const int32_t v = (int32_t)a[i] - (int32_t)b[i] + (int32_t)p2[i] + cy;      // |v| < 2^31: digits < 2^29 (top: < 2^30 by the bound above)
+        if (i < NL - 1) { cy = v >> LB; r[i] = (uint32_t)v & DMASK; } else r[i] = (uint32_t)v;
+    }
+}
+// x < R  ->  the same residue below 2p.  Wide contexts with 2^254 <= p < 2^256 (psc != nullptr): a one-digit Barrett quotient from
+// the top digit, qhat = floor(x[8] mu / 2^58) with mu = floor(2^290 / p), which is floor(x / p) or one less (the digits below
+// the top one and the truncation of mu cost less than 1 + 2^-21), then x - qhat p as x + qhat (2^261 - p) mod 2^261: ~30
+// instructions.  Any other modulus: x = REDC(x (R mod p)).
+template <int NL, bool PSC> __device__ __forceinline__ void reduce2p(uint32_t (&r)[NL], const uint32_t (&x)[NL], const FpParams<NL> &P, const PrescaleParams &psc) {
+    if constexpr (NL == 9 && PSC) {
+        {
+            const uint64_t mid = (uint64_t)x[8] * psc.m1 + (((uint64_t)x[8] * psc.m0) >> LB);
+            const uint32_t q0 = (uint32_t)(mid >> LB);          // < 2^7
+            uint64_t dc[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) dc[k] = x[k] + (uint64_t)q0 * psc.pbar[k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { r[k] = (uint32_t)dc[k] & DMASK; if (k < 8) dc[k + 1] += dc[k] >> LB; }
+            return;
+        }
+    }
+    mont_mul_lazy(r, x, P.one, P);
+}
+// canonical residue of a lazy value x < R
+template <int NL, bool PSC> __device__ __forceinline__ void canon_lazy(uint32_t (&r)[NL], const uint32_t (&x)[NL], const FpParams<NL> &P, const PrescaleParams &psc) {
+    reduce2p<NL, PSC>(r, x, P, psc);
+    cond_sub_p(r, P);
+}
+
 // One radix-2^R pass (R stages s .. s+R-1 of the decimation-in-time transform) of one unit: the 2^R elements at
 // positions hi 2^(s+R) + q 2^s + lo, q < 2^R, are read once, transformed in registers and written back.
 // Stage s+u pairs the elements whose q differ in bit u; the twiddle of the pair is omega^(j n / 2^(s+u+1)) with
@@ -76,9 +137,10 @@ __device__ __forceinline__ void butterfly(uint32_t *a0, uint32_t *a1, const uint
 // Input pruning: after S stages the block at positions [m 2^S, (m+1) 2^S) holds the sub-transform of the coefficients
 // j = r (mod n / 2^S), r = bitrev(m); with dd < n coefficients present it is identically zero when r >= dd.  A butterfly
 // whose lower operand lies in such a block is a copy (u, u); the upper operand's class is smaller, so it is the only case.
-template <int NL, int R>
+template <int NL, int R, bool FIRST, bool PSC>
 __device__ __forceinline__ void ntt_unit(uint32_t *__restrict__ base /* polynomial in LDS */, const uint32_t *__restrict__ twl, int n, int logn,
-                                         int s, int hi, int lo, int dd, bool first, const FpParams<NL> &P) {
+                                         int s, int hi, int lo, int dd, const FpParams<NL> &P,
+                                         const PrescaleParams &psc, const LazyConsts<NL> &lc) {
     constexpr int M = 1 << R;
     uint32_t e[M][NL];
     const int p0 = (hi << (s + R)) + lo;
@@ -86,7 +148,7 @@ __device__ __forceinline__ void ntt_unit(uint32_t *__restrict__ base /* polynomi
     for (int q = 0; q < M; q++) {
         const int pos = p0 + (q << s);
         // the first pass reads positions that the loader never wrote (classes >= dd) as zero instead of clearing LDS
-        const bool present = !first || (int)(__brev((uint32_t)pos) >> (32 - logn)) < dd;
+        const bool present = !FIRST || (int)(__brev((uint32_t)pos) >> (32 - logn)) < dd;
 #pragma unroll
         for (int w = 0; w < NL; w++) e[q][w] = present ? base[(size_t)pos * NL + w] : 0u;
     }
@@ -107,18 +169,33 @@ __device__ __forceinline__ void ntt_unit(uint32_t *__restrict__ base /* polynomi
             }
             const int j = ((q & ((1 << u) - 1)) << s) + lo;
             uint32_t t[NL];
-            if (j == 0) {
-                fp_set(t, e[qb]);
+            // Trivial twiddles (j = 0): no product.  In the first pass (s = 0, lo = 0) j is a compile-time function of (q, u) --
+            // 7/8 of all trivial butterflies live there -- and the subtraction adds a precomputed multiple of p that covers
+            // the bound of its operand (values may double per stage there: 8 x 2^(32 NW) after three stages, still below R / 4);
+            // later passes multiply by tw[0] = R mod p like any other twiddle (a lane-dependent branch here sends the element
+            // file to scratch).
+            if (FIRST && (q & ((1 << u) - 1)) == 0) {
+                // (u, v) -> (u + v, u - v + M_u), M_u a multiple of p above the bound of v at stage u of the first pass
+                uint32_t s0[NL], s1[NL], mu_[NL];
+#pragma unroll
+                for (int w = 0; w < NL; w++) mu_[w] = lc.m[u][w];
+                add_lazy(s0, e[q], e[qb]);
+                sub_lazy(s1, e[q], e[qb], mu_);
+                fp_set(e[q], s0);
+                fp_set(e[qb], s1);
+                continue;
             } else {
                 const uint32_t *wp = twl + (size_t)(j * (n >> (S + 1))) * NL;
                 uint32_t wd[NL];
 #pragma unroll
                 for (int w = 0; w < NL; w++) wd[w] = wp[w];
-                mont_mul(t, wd, e[qb], P);
+                mont_mul_lazy(t, wd, e[qb], P);
             }
-            uint32_t s0[NL], s1[NL];
-            fp_add(s0, e[q], t, P);
-            fp_sub(s1, e[q], t, P);
+            uint32_t s0[NL], s1[NL], p2l[NL];
+#pragma unroll
+            for (int w = 0; w < NL; w++) p2l[w] = lc.p2[w];
+            add_lazy(s0, e[q], t);
+            sub_lazy(s1, e[q], t, p2l);
             fp_set(e[q], s0);
             fp_set(e[qb], s1);
         }
@@ -140,13 +217,13 @@ __device__ __forceinline__ void ntt_unit(uint32_t *__restrict__ base /* polynomi
 // (the validating re-encode of IncrementalDecoder, reed_solomon.py:313-326).
 // The log2(n) stages run as radix-8 passes in registers (a remainder of one or two stages first): 3 LDS round trips and
 // barriers for n = 256 instead of 8, twiddles (Montgomery form) staged in LDS once per block.
-template <int NL, int NW, bool CHECK>
+template <int NL, int NW, bool CHECK, bool PSC>
 __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uint32_t *__restrict__ tw,
                                                  const uint32_t *__restrict__ in, int64_t in_sc, int64_t in_sl, int64_t in_count, int d,
                                                  int n, int logn, int k,
                                                  uint32_t *__restrict__ out, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
-                                                 int64_t C, int PB, int in_poly_fast, int out_poly_fast) {
+                                                 int64_t C, int PB, int in_poly_fast, int out_poly_fast, PrescaleParams psc, LazyConsts<NL> lc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int64_t c0 = (int64_t)blockIdx.x * PB;
     const int npoly = (int)min((int64_t)PB, C - c0);
@@ -185,7 +262,8 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
             const int lo = u & ((1 << lo_bits) - 1);
             const int hr = u >> lo_bits;
             const int hi = hi_bits > 0 ? (int)(__brev((uint32_t)hr) >> (32 - hi_bits)) : 0;
-            ntt_unit<NL, R>(data + (size_t)pl * n * NL, twl, n, logn, s, hi, lo, dd, first, P);
+            if (first) ntt_unit<NL, R, true, PSC>(data + (size_t)pl * n * NL, twl, n, logn, 0, hi, 0, dd, P, psc, lc);
+            else ntt_unit<NL, R, false, PSC>(data + (size_t)pl * n * NL, twl, n, logn, s, hi, lo, dd, P, psc, lc);
         }
         __syncthreads();
         s += R;
@@ -199,10 +277,11 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
         const int pl = out_poly_fast ? idx % npoly : idx / k;
         const int i = out_poly_fast ? idx / npoly : idx % k;
         const int64_t e = (c0 + pl) * out_sc + (int64_t)i * out_sl;
-        uint32_t dg[NL];
+        uint32_t dg[NL], lz[NL];
         const bool present = logn > 0 || dd > 0;         // order 1 with no coefficient: zero
 #pragma unroll
-        for (int q = 0; q < NL; q++) dg[q] = present ? data[((size_t)pl * n + i) * NL + q] : 0u;
+        for (int q = 0; q < NL; q++) lz[q] = present ? data[((size_t)pl * n + i) * NL + q] : 0u;
+        canon_lazy<NL, PSC>(dg, lz, P, psc);
         if constexpr (CHECK) {
             if (check_mask[i]) {
                 uint32_t w[NW], ex[NW];
@@ -281,6 +360,50 @@ int get_twiddles(hb_ctx *ctx, const uint64_t *omega_host, int n, uint32_t **tw, 
     return HB_OK;
 }
 
+// m[u] = p * ceil(B_u / p), B_0 = 2^(32 NW), B_{u+1} = B_u + m[u]  (radix-2^29 digits; plain long arithmetic, once per launch)
+template <int NL> static LazyConsts<NL> lazy_consts(hb_ctx *ctx) {
+    constexpr int W = 12;                                   // 32-bit words: values stay below 2^261
+    typedef std::vector<uint32_t> Big;
+    Big p(W, 0);
+    for (int i = 0; i < ctx->n_limbs; i++) { p[2 * i] = (uint32_t)ctx->p_limbs[i]; p[2 * i + 1] = (uint32_t)(ctx->p_limbs[i] >> 32); }
+    auto ge = [](const Big &a, const Big &b) { for (int i = W - 1; i >= 0; i--) if (a[i] != b[i]) return a[i] > b[i]; return true; };
+    auto sub = [](Big &a, const Big &b) { int64_t br = 0; for (int i = 0; i < W; i++) { int64_t t = (int64_t)a[i] - b[i] + br; a[i] = (uint32_t)t; br = t >> 32; } };
+    auto add = [](Big &a, const Big &b) { uint64_t cy = 0; for (int i = 0; i < W; i++) { uint64_t t = (uint64_t)a[i] + b[i] + cy; a[i] = (uint32_t)t; cy = t >> 32; } };
+    auto mod = [&](const Big &x) {                          // x mod p, binary long division
+        Big r(W, 0);
+        for (int bit = W * 32 - 1; bit >= 0; bit--) {
+            for (int i = W - 1; i > 0; i--) r[i] = (r[i] << 1) | (r[i - 1] >> 31);
+            r[0] = (r[0] << 1) | ((x[bit >> 5] >> (bit & 31)) & 1u);
+            if (ge(r, p)) sub(r, p);
+        }
+        return r;
+    };
+    LazyConsts<NL> lc;
+    Big b(W, 0);
+    b[(ctx->n_limbs * 64) >> 5] = 1u;                       // B_0 = 2^(64 limbs)
+    for (int u = 0; u < 3; u++) {
+        Big m(b), r = mod(b);
+        bool zero = true; for (int i = 0; i < W; i++) if (r[i]) zero = false;
+        if (!zero) { sub(m, r); add(m, p); }                // round up to a multiple of p
+        for (int k = 0; k < NL; k++) {
+            const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
+            const uint64_t v = m[j] | ((uint64_t)(j + 1 < W ? m[j + 1] : 0) << 32);
+            lc.m[u][k] = (uint32_t)(v >> sft) & (k < NL - 1 ? DMASK : 0xffffffffu);
+        }
+        add(b, m);
+    }
+    {
+        Big two(p);
+        add(two, p);
+        for (int k = 0; k < NL; k++) {
+            const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
+            const uint64_t v = two[j] | ((uint64_t)(j + 1 < W ? two[j + 1] : 0) << 32);
+            lc.p2[k] = (uint32_t)(v >> sft) & (k < NL - 1 ? DMASK : 0xffffffffu);
+        }
+    }
+    return lc;
+}
+
 // LDS NTT launcher with views; returns HB_ERR_UNSUPPORTED when the order does not fit LDS
 int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, hb_view iv, int64_t in_count, int d, int k,
                    uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
@@ -299,14 +422,18 @@ int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, h
     if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "fft: batch too large");
     const int ipf = iv.stride_c == 1 ? 1 : 0, opf = ov.stride_c == 1 ? 1 : 0;
     const bool check = check_mask_dev != nullptr;
+    const int psc_ok = (ctx->n_limbs == 4 && prescale_params(ctx)) ? 1 : 0;      // 2^254 <= p < 2^256: the cheap lazy -> canonical step
 #define HB_NTT(NL_, NW_, CHK_, PP_)                                                                                                       \
+    do { if (psc_ok) HB_NTT_(NL_, NW_, CHK_, true, PP_); else HB_NTT_(NL_, NW_, CHK_, false, PP_); } while (0)
+#define HB_NTT_(NL_, NW_, CHK_, PSC_, PP_)                                                                                                \
     do {                                                                                                                                  \
-        HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds<NL_, NW_, CHK_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024))); \
-        k_ntt_lds<NL_, NW_, CHK_><<<(unsigned)blocks, 256, lds, s>>>(PP_, tw, in, iv.stride_c, iv.stride_l, in_count, d, n, logn, k, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev, C, PB, ipf, opf); \
+        HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds<NL_, NW_, CHK_, PSC_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024))); \
+        k_ntt_lds<NL_, NW_, CHK_, PSC_><<<(unsigned)blocks, 256, lds, s>>>(PP_, tw, in, iv.stride_c, iv.stride_l, in_count, d, n, logn, k, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev, C, PB, ipf, opf, ctx->psc, lazy_consts<NL_>(ctx)); \
     } while (0)
     if (ctx->n_limbs == 4) { if (check) HB_NTT(9, 8, true, ctx->pw); else HB_NTT(9, 8, false, ctx->pw); }
     else { if (check) HB_NTT(3, 2, true, ctx->pn); else HB_NTT(3, 2, false, ctx->pn); }
 #undef HB_NTT
+#undef HB_NTT_
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;
 }
