@@ -30,7 +30,7 @@ def main(dirs):
                 meta[row["Dispatch_Id"]] = (short(row["Kernel_Name"]), int(row["Grid_Size"]))
             for (disp, ctr), v in per_dispatch.items():
                 acc[meta[disp]][ctr].append(v)
-    keep = [k for k in acc if any(s in k[0] for s in ("k_mm8", "k_prescale", "k_matvec3", "k_decode_check"))]
+    keep = [k for k in acc if any(s in k[0] for s in ("k_mm8", "k_prescale", "k_matvec3", "k_decode_check", "k_ntt", "k_gao", "k_wb", "k_matvec2"))]
     ctrs = sorted({c for k in keep for c in acc[k]})
     print(f"{'kernel':<44} {'grid':>9} {'launches':>8} " + " ".join(f"{c:>24}" for c in ctrs) + f" {'HBM bytes/launch':>18}")
     for k in sorted(keep, key=lambda k: -sum(acc[k].get("WRITE_SIZE", [0]))):
