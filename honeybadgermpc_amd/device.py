@@ -240,7 +240,9 @@ class DeviceIncrementalDecoder:
         self._partial = ctx.empty(self.batch_size * (self.degree + 1)).view(self.batch_size, self.degree + 1, self.L)
         self._result = None
         self._last_status = None
+        self._probe_memo = None         # (polynomial index, arrival list, coefficient ints, error set) of the last successful probe
         self.probes = 0                 # single-codeword robust decodes so far (diagnostic)
+        self.probes_replayed = 0        # probes answered from the previous one (diagnostic)
         self.launches = 0               # batched robust-decode launches so far (diagnostic)
         self.plan_accepts = 0           # batches accepted by one interpolate-and-check plan (diagnostic)
 
@@ -352,21 +354,54 @@ class DeviceIncrementalDecoder:
             self._available_points -= set(errors)
             self._z = [i for i in self._z if i not in errors]
 
+    def _probe(self):
+        """The reference's next robust_decode (one polynomial over the current arrival set): -> (coeffs (d, limbs) | None, errors).
+        Gao's answer is determined by its inputs: the unique polynomial of degree < d within floor((|z| - d) / 2) errors of the
+        points, and the senders where it disagrees.  When the previous probe of the SAME polynomial succeeded over a prefix of
+        the current arrival list, that polynomial evaluated at the new points says whether each of them agrees; as long as the
+        disagreeing senders stay within the new radius, the decode over the longer list is the same polynomial with the
+        enlarged error set -- no launch needed.  (Welch-Berlekamp beyond the radius may answer differently: it is always run.)"""
+        t = self.ctx.torch
+        d, lo = self.degree + 1, self._num_decoded
+        memo = self._probe_memo
+        if self.robust == "gao" and memo is not None and memo[0] == lo and self._z[: len(memo[1])] == memo[1] and len(self._z) > len(memo[1]):
+            _, z_old, ints, errors, coeffs = memo
+            errors = set(errors)
+            p = self.ctx.modulus
+            for idx in self._z[len(z_old):]:
+                want = 0
+                for c in reversed(ints):
+                    want = (want * self.x[idx] + c) % p
+                got = self.ctx.download_ints(self._cols[idx, lo : lo + 1])[0]
+                if got != want:
+                    errors.add(idx)
+            if len(errors) <= (len(self._z) - d) // 2:
+                self._probe_memo = (lo, list(self._z), ints, set(errors), coeffs)
+                self.probes_replayed += 1
+                return coeffs, sorted(errors)
+        ok, coeffs, errs = self._robust_batch(1)
+        if not bool(ok[0].item()):
+            self._undecodable(0)
+            self._probe_memo = None
+            return None, None
+        errors = t.nonzero(errs[0]).flatten().tolist()
+        if self.robust == "gao":
+            self._probe_memo = (lo, list(self._z), self.ctx.download_ints(coeffs[0]), set(errors), coeffs[0].clone())
+        return coeffs[0], errors
+
     def _robust_update(self):
         t = self.ctx.torch
         d = self.degree + 1
         while self._num_decoded < self.batch_size:
             # the reference's next robust_decode, alone: while it stalls (undecodable, or too few points once its errors are
             # dropped) nothing else can be accepted either, and an arrival costs one codeword instead of all of them
-            ok, coeffs, errs = self._robust_batch(1)
-            if not bool(ok[0].item()):
-                self._undecodable(0)
+            coeffs0, errors = self._probe()
+            if coeffs0 is None:
                 return
-            errors = t.nonzero(errs[0]).flatten().tolist()
             if len(self._available_points) - len(errors) < self._min_points_required():
                 return
             if errors:
-                self._accept(coeffs[0], errors)          # this polynomial confirmed senders in error: the next one sees fewer points
+                self._accept(coeffs0, errors)            # this polynomial confirmed senders in error: the next one sees fewer points
                 continue
             # no error in this polynomial over the arrival set.  If every remaining polynomial interpolates from d of the
             # arrived columns and agrees with all the others, each of them robust-decodes to that interpolant with no
