@@ -105,25 +105,41 @@ class BatchOpen:
     def chunks(self, b):
         return (b + self.d - 1) // self.d
 
+    def _check_batch(self, b):
+        if b > self.max_shares:
+            raise ValueError(f"{b} shares exceed this plan's max_shares = {self.max_shares}")
+
     def r1_encode(self, shares, out=None):
+        shares = self.ctx.elems(shares, what="shares")
         b = shares.shape[0]
+        self._check_batch(b)
         c = self.chunks(b)
         if out is None:
             out = self.ctx.empty(self.n * c)
+        else:
+            out = self.ctx.elems(out, self.n * c, what="out")
         rc = self.ctx.lib.hb_open_r1_encode(self.h, self.ctx.ptr(shares), b, self.ctx.ptr(out), self.ctx.stream())
         self.ctx.check(rc, "hb_open_r1_encode")
         return out
 
     def r1_decode(self, r1_cols, b, out=None):
+        self._check_batch(b)
+        r1_cols = self.ctx.elems(r1_cols, self.n * self.chunks(b), what="r1_cols")
         if out is None:
             out = self.ctx.empty(self.chunks(b))
+        else:
+            out = self.ctx.elems(out, self.chunks(b), what="out")
         rc = self.ctx.lib.hb_open_r1_decode(self.h, self.ctx.ptr(r1_cols), b, self.ctx.ptr(out), self.ctx.stream())
         self.ctx.check(rc, "hb_open_r1_decode")
         return out
 
     def r2_decode(self, r2_cols, b, out=None):
+        self._check_batch(b)
+        r2_cols = self.ctx.elems(r2_cols, self.n * self.chunks(b), what="r2_cols")
         if out is None:
             out = self.ctx.empty(b)
+        else:
+            out = self.ctx.elems(out, b, what="out")
         rc = self.ctx.lib.hb_open_r2_decode(self.h, self.ctx.ptr(r2_cols), b, self.ctx.ptr(out), self.ctx.stream())
         self.ctx.check(rc, "hb_open_r2_decode")
         return out

@@ -23,6 +23,20 @@ from .device import BatchOpen, DeviceIncrementalDecoder
 from .utils.misc import subscribe_recv
 
 
+_ENCODERS = {}
+
+
+def _encoder(p, n, t, degree, use_omega_powers, device, b):
+    """the R1 encode needs a plan (tables, int8 images, scratch): kept per (field, shape, device) and regrown when a larger
+    batch comes, instead of being rebuilt and torn down by every open"""
+    key = (p, n, t, degree, bool(use_omega_powers), device)
+    op = _ENCODERS.get(key)
+    if op is None or op.max_shares < b:
+        op = BatchOpen(p, n, t, use_omega_powers=use_omega_powers, degree=degree, max_shares=max(b, 1024, 2 * (op.max_shares if op else 0)), device=device)
+        _ENCODERS[key] = op
+    return op
+
+
 async def _incremental_decode_device(receivers, make_decoder, device):
     """reference :43-61 with packed payloads; a payload that is not a well-formed column of the right length is that
     sender's problem: it is dropped (the reference's `_validate` raises on a wrong length; here the sender is simply
@@ -69,7 +83,7 @@ async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_
         for task in background:
             task.cancel()
 
-    op = BatchOpen(p, n, t, use_omega_powers=use_omega_powers, degree=degree, max_shares=max(b, 1), device=ctx.device)
+    op = _encoder(p, n, t, degree, use_omega_powers, ctx.device, max(b, 1))
     c = op.chunks(b)
 
     def make_decoder():

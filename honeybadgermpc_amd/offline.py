@@ -101,7 +101,10 @@ class HyperInvertible:
         self._v = m
 
     def refine(self, received, out=None):
+        received = self.ctx.elems(received, what="received")
         n, k = self.n, received.shape[0] // self.n
+        if received.shape[0] != n * k:
+            raise ValueError("received: expected n rows of k elements")
         if out is None:
             out = self.ctx.empty(n * k)
         view = HbView(1, k)                   # element (column j, row l) at l * k + j, for the input and the output
@@ -110,6 +113,7 @@ class HyperInvertible:
         return out
 
     def check(self, shares, degree):
+        shares = self.ctx.elems(shares, what="shares")
         t = self.ctx.torch
         n, k = self.n, shares.shape[0] // self.n
         rows = shares.view(n, k, self.ctx.n_limbs).transpose(0, 1).contiguous().view(k * n, self.ctx.n_limbs)     # [k][n]: one polynomial's points per row
