@@ -68,16 +68,18 @@ def main():
     pn = np.frombuffer(b"".join(v.to_bytes(32, "little") for row in polys for v in row), dtype=np.uint64).reshape(c, d, 4).copy()
     for kind, give in (("numpy (pageable host)", lambda a: a), ("torch device tensor", lambda a: torch.from_numpy(a.view(np.int64)).cuda())):
         arr = give(pn)
-        ntl.vandermonde_batch_evaluate(xs, arr, P)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        enc_p = ntl.vandermonde_batch_evaluate(xs, arr, P)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        rows_p = enc_p[:, :d].copy() if isinstance(enc_p, np.ndarray) else enc_p[:, :d].contiguous()
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        dec_p = ntl.vandermonde_batch_interpolate(xs[:d], rows_p, P)
-        torch.cuda.synchronize(); t3 = time.perf_counter()
+        ev = it = None
+        for _ in range(4):                               # the first calls build the tables; steady state = the fastest
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            enc_p = ntl.vandermonde_batch_evaluate(xs, arr, P)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            rows_p = enc_p[:, :d].copy() if isinstance(enc_p, np.ndarray) else enc_p[:, :d].contiguous()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            dec_p = ntl.vandermonde_batch_interpolate(xs[:d], rows_p, P)
+            torch.cuda.synchronize(); t3 = time.perf_counter()
+            ev = t1 - t0 if ev is None else min(ev, t1 - t0)
+            it = t3 - t2 if it is None else min(it, t3 - t2)
         same = np.array_equal(dec_p if isinstance(dec_p, np.ndarray) else dec_p.cpu().numpy().view(np.uint64), pn)
-        ev, it = t1 - t0, t3 - t2
         total = 3 * ev + 2 * it
         print(f"(c) packed batches, {kind}: evaluate {ev * 1e3:.2f} ms, interpolate {it * 1e3:.2f} ms per call -> 3 + 2 calls = {total * 1e3:.2f} ms per open = {b / total / 1e6:.0f} M shares/s, round trip exact: {same}")
 
