@@ -127,11 +127,15 @@ template <int NL> HB_HD void finish(uint32_t (&r)[NL], uint64_t (&c)[2 * NL], co
 }
 
 // ---------------------------------------------------------------- field ops on digits (values < p)
+// One product needs no carry pass before REDC: a column holds at most NL products of two 29-bit digits plus, during REDC, NL more
+// and the carry of its neighbour -- 2 NL 2^58 + 2^35 < 2^63 -- and REDC propagates carries itself as it goes (the pass in
+// finish() is for lazy dot products of several terms).  51 of ~300 instructions saved per multiplication.
 template <int NL> HB_HD void mont_mul(uint32_t (&r)[NL], const uint32_t (&a)[NL], const uint32_t (&b)[NL], const FpParams<NL>& P) {
     uint64_t c[2 * NL];
     col_zero(c);
     mac<NL>(c, a, b);
-    finish(r, c, P, 1);
+    redc(r, c, P);
+    cond_sub_p(r, P);
 }
 template <int NL> HB_HD void fp_add(uint32_t (&r)[NL], const uint32_t (&a)[NL], const uint32_t (&b)[NL], const FpParams<NL>& P) {
     uint32_t carry_ = 0;
