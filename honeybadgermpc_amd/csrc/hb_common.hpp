@@ -139,7 +139,7 @@ int launch_copy_view(hb_ctx *ctx, const uint32_t *src, hb_view sv, uint32_t *dst
 int get_twiddles(hb_ctx *ctx, const uint64_t *omega_host, int n, uint32_t **tw, hipStream_t s);
 int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, hb_view iv, int64_t in_count, int d, int k,
                    uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                   int64_t C, hipStream_t s);
+                   int64_t C, hipStream_t s, uint32_t *copy_dst = nullptr, hb_view cpv = hb_view{0, 0}, int64_t copy_count = 0, int copy_rows = 0);
 
 // ---- second-generation (raw small-entry matrix) path, hb_fast.hip ----------------------
 struct FastMatrix {

@@ -102,15 +102,20 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
     const int lane = threadIdx.x;
     const int64_t c = blockIdx.x;
     const int len = npts + 1;
-    uint32_t *R0 = smem, *R1 = R0 + (size_t)len * NL, *T0 = R1 + (size_t)len * NL, *T1 = T0 + (size_t)len * NL;
+    // deg t_{i+1} + deg r_i = npts throughout the Euclid loop and it runs while deg r >= D: the cofactors never exceed degree
+    // npts - D, so their arrays are short -- 10 KB of LDS per codeword instead of 14.5 at n = 100: 16 resident waves per CU, not 11
+    const int lenT = npts - (npts + k) / 2 + 3;
+    uint32_t *R0 = smem, *R1 = R0 + (size_t)len * NL, *T0 = R1 + (size_t)len * NL, *T1 = T0 + (size_t)lenT * NL;
 
     for (int idx = lane; idx < len; idx += 64) {
         uint32_t a[NL], z[NL], m[NL];
 #pragma unroll
         for (int q = 0; q < NL; q++) { a[q] = g0[(size_t)idx * NL + q]; z[q] = 0; }
         lds_put<NL>(R0 + (size_t)idx * NL, a);
-        lds_put<NL>(T0 + (size_t)idx * NL, z);
-        if (idx == 0) lds_put<NL>(T1, P.one); else lds_put<NL>(T1 + (size_t)idx * NL, z);
+        if (idx < lenT) {
+            lds_put<NL>(T0 + (size_t)idx * NL, z);
+            if (idx == 0) lds_put<NL>(T1, P.one); else lds_put<NL>(T1 + (size_t)idx * NL, z);
+        }
         if (idx < npts) {
             uint32_t yd[NL];
             load_digits<NL, NW>(yd, g1buf + ((size_t)idx * C + c) * NW);
@@ -193,7 +198,7 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
         mont_mul(inv_c, winv, lcv, P);             // 1 / cs
         mont_mul(inv_lc, winv, cs, P);             // 1 / lc(V)
     }
-    uint32_t *F = (vp == T0) ? T1 : T0;            // free array: quotient scratch
+    uint32_t *F = (rp == R0) ? R1 : R0;            // the remainder array not in use: quotient scratch (up to D coefficients)
     int df = -1;
     if (ok) {
         // error locator (true cofactor v) out, then make V monic in place
@@ -300,7 +305,7 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     hb_view iv{npts, 1}, ov{1, C};
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (rc) { (void)hipFree(g1); return rc; }
-    size_t lds = (size_t)4 * (npts + 1) * NLr * 4;
+    size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3)) * NLr * 4;
     if (ctx->n_limbs == 4) {
         HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev);

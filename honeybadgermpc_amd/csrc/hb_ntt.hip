@@ -222,7 +222,8 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
                                                  int n, int logn, int k,
                                                  uint32_t *__restrict__ out, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
-                                                 int64_t C, int PB, int in_poly_fast, int out_poly_fast, PrescaleParams psc, LazyConsts<NL> lc) {
+                                                 int64_t C, int PB, int in_poly_fast, int out_poly_fast, PrescaleParams psc, LazyConsts<NL> lc,
+                                                 uint32_t *__restrict__ copy_dst, int64_t copy_sc, int64_t copy_sl, int64_t copy_count, int copy_rows) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     const int64_t c0 = (int64_t)blockIdx.x * PB;
     const int npoly = (int)min((int64_t)PB, C - c0);
@@ -236,11 +237,18 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
         const int pl = in_poly_fast ? idx % npoly : idx / dd;
         const int j = in_poly_fast ? idx / npoly : idx % dd;
         const int64_t e = (c0 + pl) * in_sc + (int64_t)j * in_sl;
-        uint32_t dg[NL];
-        if (e < in_count) load_digits<NL, NW>(dg, in + e * NW);
-        else {
+        uint32_t dg[NL], wd_[NW];
 #pragma unroll
-            for (int q = 0; q < NL; q++) dg[q] = 0;
+        for (int q = 0; q < NW; q++) wd_[q] = 0;
+        if (e < in_count) load_words<NW>(wd_, in + e * NW);
+        unpack<NL, NW>(dg, wd_);
+        if constexpr (CHECK) {
+            // hand the caller its rows of the input (the decoded coefficients) in its own layout while they pass through
+            // (row 0 -> the R2 message, all rows chunk-major -> the result): replaces a copy kernel
+            if (copy_dst && j < copy_rows) {
+                const int64_t ci = (c0 + pl) * copy_sc + (int64_t)j * copy_sl;
+                if (ci < copy_count) store_words<NW>(copy_dst + ci * NW, wd_);
+            }
         }
         uint32_t *dst = data + ((size_t)pl * n + bitrev((uint32_t)j, logn)) * NL;
 #pragma unroll
@@ -406,7 +414,7 @@ template <int NL> static LazyConsts<NL> lazy_consts(hb_ctx *ctx) {
 // LDS NTT launcher with views; returns HB_ERR_UNSUPPORTED when the order does not fit LDS
 int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, hb_view iv, int64_t in_count, int d, int k,
                    uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                   int64_t C, hipStream_t s) {
+                   int64_t C, hipStream_t s, uint32_t *copy_dst, hb_view cpv, int64_t copy_count, int copy_rows) {
     if (C <= 0 || k <= 0) return HB_OK;
     int logn = 0; while ((1 << logn) < n) logn++;
     const size_t elem_lds = (size_t)ctx->nl() * 4;
@@ -427,7 +435,7 @@ int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, h
 #define HB_NTT_(NL_, NW_, CHK_, PSC_, PP_)                                                                                                \
     do {                                                                                                                                  \
         HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_ntt_lds<NL_, NW_, CHK_, PSC_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024))); \
-        k_ntt_lds<NL_, NW_, CHK_, PSC_><<<(unsigned)blocks, 256, lds, s>>>(PP_, tw, in, iv.stride_c, iv.stride_l, in_count, d, n, logn, k, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev, C, PB, ipf, opf, ctx->psc, lazy_consts<NL_>(ctx)); \
+        k_ntt_lds<NL_, NW_, CHK_, PSC_><<<(unsigned)blocks, 256, lds, s>>>(PP_, tw, in, iv.stride_c, iv.stride_l, in_count, d, n, logn, k, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev, C, PB, ipf, opf, ctx->psc, lazy_consts<NL_>(ctx), copy_dst, cpv.stride_c, cpv.stride_l, copy_count, copy_rows); \
     } while (0)
     if (ctx->n_limbs == 4) { if (check) HB_NTT(9, 8, true, ctx->pw); else HB_NTT(9, 8, false, ctx->pw); }
     else { if (check) HB_NTT(3, 2, true, ctx->pn); else HB_NTT(3, 2, false, ctx->pn); }

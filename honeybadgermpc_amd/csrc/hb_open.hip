@@ -172,10 +172,10 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
                      : launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
                                       pl->coef_pk, pm, INT64_MAX, pl->d, 1, nullptr, nullptr, nullptr, C, s);
         if (rc) return rc;
-        rc = launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, pl->coef_pk, pm, INT64_MAX, pl->d, pl->n,
-                            (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s);
-        if (rc) return rc;
-        return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
+        // the NTT in CHECK mode hands the caller its rows of the coefficients as they pass through
+        return launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, pl->coef_pk, pm, INT64_MAX, pl->d, pl->n,
+                              (uint32_t *)const_cast<uint64_t *>(cols_dev), pm, INT64_MAX, pl->mask_dev, pl->mismatch_dev, C, s,
+                              pk_dst, pv, pk_count, pk_rows);
     }
     if (pl->V8 && pl->use_v8) {
         // decode to canonical coefficients (VALU path, d outputs), validate on the matrix cores: the
