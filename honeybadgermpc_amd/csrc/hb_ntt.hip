@@ -230,7 +230,10 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
     const int dd = min(d, n);
     const int half = n >> 1;
     uint32_t *twl = lds;                                  // [max(n/2, 1)][NL]
-    uint32_t *data = lds + (size_t)(half > 0 ? half : 1) * NL;   // [PB][n][NL]
+    uint32_t *data = lds + (size_t)(half > 0 ? half : 1) * NL;   // [PB][n][NL], polynomials one dword further apart than n NL:
+    // with party-major / coefficient-major buffers consecutive lanes hold consecutive polynomials, and n NL = 576 or 2304
+    // dwords would put them all on one LDS bank (measured: order 64, party-major output 138 us against 118 chunk-major)
+    const int pstride = n * NL + 1;
     for (int idx = threadIdx.x; idx < half * NL; idx += blockDim.x) twl[idx] = tw[idx];
     // load the dd coefficients of every polynomial into bit-reversed positions
     for (int idx = threadIdx.x; idx < npoly * dd; idx += blockDim.x) {
@@ -250,7 +253,7 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
                 if (ci < copy_count) store_words<NW>(copy_dst + ci * NW, wd_);
             }
         }
-        uint32_t *dst = data + ((size_t)pl * n + bitrev((uint32_t)j, logn)) * NL;
+        uint32_t *dst = data + (size_t)pl * pstride + (size_t)bitrev((uint32_t)j, logn) * NL;
 #pragma unroll
         for (int q = 0; q < NL; q++) dst[q] = dg[q];
     }
@@ -269,8 +272,8 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
             const int lo = u & ((1 << lo_bits) - 1);
             const int hr = u >> lo_bits;
             const int hi = hi_bits > 0 ? (int)(__brev((uint32_t)hr) >> (32 - hi_bits)) : 0;
-            if (first) ntt_unit<NL, R, true, PSC>(data + (size_t)pl * n * NL, twl, n, logn, 0, hi, 0, dd, P, psc, lc);
-            else ntt_unit<NL, R, false, PSC>(data + (size_t)pl * n * NL, twl, n, logn, s, hi, lo, dd, P, psc, lc);
+            if (first) ntt_unit<NL, R, true, PSC>(data + (size_t)pl * pstride, twl, n, logn, 0, hi, 0, dd, P, psc, lc);
+            else ntt_unit<NL, R, false, PSC>(data + (size_t)pl * pstride, twl, n, logn, s, hi, lo, dd, P, psc, lc);
         }
         __syncthreads();
         s += R;
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
         uint32_t dg[NL], lz[NL];
         const bool present = logn > 0 || dd > 0;         // order 1 with no coefficient: zero
 #pragma unroll
-        for (int q = 0; q < NL; q++) lz[q] = present ? data[((size_t)pl * n + i) * NL + q] : 0u;
+        for (int q = 0; q < NL; q++) lz[q] = present ? data[(size_t)pl * pstride + (size_t)i * NL + q] : 0u;
         canon_lazy<NL, PSC>(dg, lz, P, psc);
         if constexpr (CHECK) {
             if (check_mask[i]) {
@@ -423,7 +426,7 @@ int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, h
     int PB = n <= 2048 ? 2048 / n : 1; if (PB > 256) PB = 256;
     if (const char *e = getenv("HB_NTT_PB")) { int v = atoi(e); if (v >= 1 && (size_t)v * n * elem_lds <= 150 * 1024) PB = v; }   // experiment hook
     if ((int64_t)PB > C) PB = (int)C;
-    const size_t lds = ((size_t)PB * n + (size_t)(n > 1 ? n / 2 : 1)) * elem_lds;
+    const size_t lds = ((size_t)PB * n + (size_t)(n > 1 ? n / 2 : 1)) * elem_lds + (size_t)PB * 4;
     if (lds > 160 * 1024) return fail(ctx, HB_ERR_UNSUPPORTED, "ntt: order does not fit LDS");
     const int64_t blocks = (C + PB - 1) / PB;
     if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "fft: batch too large");
