@@ -267,7 +267,9 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
         const int units = n >> R;                         // per polynomial
         const int lo_bits = s, hi_bits = logn - s - R;
         for (int uidx = threadIdx.x; uidx < npoly * units; uidx += blockDim.x) {
-            const int pl = uidx / units, u = uidx - pl * units;
+            // first pass (units = 8 contiguous elements = 72 dwords apart: 8 banks): consecutive lanes take consecutive
+            // POLYNOMIALS (odd stride: all banks); later passes: consecutive units of one polynomial (consecutive elements)
+            const int pl = first ? uidx % npoly : uidx / units, u = first ? uidx / npoly : uidx - pl * units;
             // hi in bit-reversed order: units whose lower operands are pruned end up next to each other
             const int lo = u & ((1 << lo_bits) - 1);
             const int hr = u >> lo_bits;
