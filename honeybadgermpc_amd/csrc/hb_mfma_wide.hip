@@ -142,110 +142,137 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             // and ahead of the epilogue, which hides their latency
             if (nbuf == 2 && !dma_issued) { if (next < n_units) issue_loads(next, buf ^ 1); dma_issued = true; }
             MM8W_T(2);   // DMA issue
-            // T_k for the four reductions of this pass: LDS broadcast reads into registers once (the asm phase has released its
-            // 66 reserved registers; 90 scalars would not fit the SGPR file beside the rest)
-            uint4 tk[30];
+            // the reduction constants come by scalar loads once per pass: kept across the MFMA phase they would spill
+            uint64_t wqa = (uint64_t)(uintptr_t)wpp;
+            asm volatile("" : "+s"(wqa));
+            const __attribute__((address_space(4))) WideParams *wq = (const __attribute__((address_space(4))) WideParams *)wqa;
+            // Two outputs at a time, STAGE by stage: one wave per SIMD has nothing but its own independent work to cover the
+            // 8-cycle dependent-issue latency of the carry / MAD chains, and an inline-asm statement per output (as in the
+            // first version) is a scheduling boundary that serialised the four reductions.
 #pragma unroll
-            for (int q = 0; q < 30; q++) tk[q] = tlds[q];
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                if (16 * rt + 4 * reg >= n_out) break;               // whole outputs of padding rows (wave-uniform)
-                const int i = 16 * rt + 4 * reg + g;
-                // the reduction constants come by scalar loads per output: kept across the MFMA phase they would spill
-                uint64_t wqa = (uint64_t)(uintptr_t)wpp;
-                asm volatile("" : "+s"(wqa));
-                const __attribute__((address_space(4))) WideParams *wq = (const __attribute__((address_space(4))) WideParams *)wqa;
-                uint32_t ew[8];
-                bool cmp = false;
-                if constexpr (CHECK) {
-                    const int erow = maskl[16 * rt + 4 * reg + g];
-                    cmp = (chunk < n_chunks) && erow;
-                    if (cmp) load_words<8>(ew, out_pk + (chunk * out_sc + (int64_t)(erow - 1) * out_sl) * 8);
-                }
-                (void)ew; (void)cmp;
+            for (int rp = 0; rp < 4; rp += 2) {
+                if (16 * rt + 4 * rp >= n_out) break;                // whole outputs of padding rows (wave-uniform)
+                uint32_t ew[2][8];
+                bool cmp[2] = {false, false};
                 // S = sum_c (col_c + bias) 2^(8c): four SIGNED columns per 32-bit step go into one 64-bit accumulator that starts
                 // from bias (1 + 2^8 + 2^16 + 2^24) -- four v_mad_i64_i32, no per-column bias add -- then one add-with-carry per word
-                uint32_t w[MM8W_WORDS + 1];
+                uint32_t w[2][MM8W_WORDS + 1];
                 {
-                    uint32_t hi_prev = 0;
-                    unsigned cy = 0;
+                    uint32_t hi_prev[2] = {0, 0};
+                    unsigned cy[2] = {0, 0};
 #pragma unroll
                     for (int j = 0; j < 16; j++) {
-                        int64_t a64 = (int64_t)acc[4 * j][reg] * k1 + (4 * j + 3 < MM8W_NC ? bias4 : bias3);
-                        a64 += (int64_t)acc[4 * j + 1][reg] * k256;
-                        a64 += (int64_t)acc[4 * j + 2][reg] * k64k;
-                        if (4 * j + 3 < MM8W_NC) a64 += (int64_t)acc[4 * j + 3][reg] * k16m;
-                        if (j == 0) w[0] = (uint32_t)a64;
-                        else w[j] = __builtin_addc((uint32_t)a64, hi_prev, cy, &cy);
-                        hi_prev = (uint32_t)((uint64_t)a64 >> 32);
+#pragma unroll
+                        for (int o = 0; o < 2; o++) {
+                            const int reg = rp + o;
+                            int64_t a64 = (int64_t)acc[4 * j][reg] * k1 + (4 * j + 3 < MM8W_NC ? bias4 : bias3);
+                            a64 += (int64_t)acc[4 * j + 1][reg] * k256;
+                            a64 += (int64_t)acc[4 * j + 2][reg] * k64k;
+                            if (4 * j + 3 < MM8W_NC) a64 += (int64_t)acc[4 * j + 3][reg] * k16m;
+                            if (j == 0) w[o][0] = (uint32_t)a64;
+                            else w[o][j] = __builtin_addc((uint32_t)a64, hi_prev[o], cy[o], &cy[o]);
+                            hi_prev[o] = (uint32_t)((uint64_t)a64 >> 32);
+                        }
                     }
-                    w[16] = hi_prev + cy;
-                    w[17] = 0;
+#pragma unroll
+                    for (int o = 0; o < 2; o++) { w[o][16] = hi_prev[o] + cy[o]; w[o][17] = 0; }
                 }
-                uint32_t sd[MM8W_SD];
+                uint32_t sd[2][MM8W_SD];
 #pragma unroll
                 for (int k = 0; k < MM8W_SD; k++) {
                     const int bit = LB * k, j = bit >> 5, sft = bit & 31;
-                    sd[k] = (sft == 0 ? w[j] : __builtin_amdgcn_alignbit(w[j + 1], w[j], (uint32_t)sft)) & DMASK;
+#pragma unroll
+                    for (int o = 0; o < 2; o++)
+                        sd[o][k] = (sft == 0 ? w[o][j] : __builtin_amdgcn_alignbit(w[o][j + 1], w[o][j], (uint32_t)sft)) & DMASK;
                 }
                 // V = S_lo + sum_{k >= 9} s_k T_k + row constant  <  2^261 + (9 2^29 + 2^7) p + p  <  2^290
-                uint64_t col[10];
-                {
+                uint64_t col[2][10];
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    const int i = 16 * rt + 4 * (rp + o) + g;
                     const uint4 *cr = reinterpret_cast<const uint4 *>(crl + (size_t)i * 16);
                     const uint4 c0v = cr[0], c1v = cr[1], c2v = cr[2];
-                    col[0] = (uint64_t)sd[0] + c0v.x; col[1] = (uint64_t)sd[1] + c0v.y; col[2] = (uint64_t)sd[2] + c0v.z; col[3] = (uint64_t)sd[3] + c0v.w;
-                    col[4] = (uint64_t)sd[4] + c1v.x; col[5] = (uint64_t)sd[5] + c1v.y; col[6] = (uint64_t)sd[6] + c1v.z; col[7] = (uint64_t)sd[7] + c1v.w;
-                    col[8] = (uint64_t)sd[8] + c2v.x; col[9] = 0;
+                    col[o][0] = (uint64_t)sd[o][0] + c0v.x; col[o][1] = (uint64_t)sd[o][1] + c0v.y; col[o][2] = (uint64_t)sd[o][2] + c0v.z; col[o][3] = (uint64_t)sd[o][3] + c0v.w;
+                    col[o][4] = (uint64_t)sd[o][4] + c1v.x; col[o][5] = (uint64_t)sd[o][5] + c1v.y; col[o][6] = (uint64_t)sd[o][6] + c1v.z; col[o][7] = (uint64_t)sd[o][7] + c1v.w;
+                    col[o][8] = (uint64_t)sd[o][8] + c2v.x; col[o][9] = 0;
                 }
 #pragma unroll
                 for (int k = 0; k < 10; k++) {
-                    const uint4 t0 = tk[3 * k], t1 = tk[3 * k + 1], t2 = tk[3 * k + 2];
-                    const uint32_t sk = sd[9 + k];
-                    col[0] += (uint64_t)sk * t0.x; col[1] += (uint64_t)sk * t0.y; col[2] += (uint64_t)sk * t0.z; col[3] += (uint64_t)sk * t0.w;
-                    col[4] += (uint64_t)sk * t1.x; col[5] += (uint64_t)sk * t1.y; col[6] += (uint64_t)sk * t1.z; col[7] += (uint64_t)sk * t1.w;
-                    col[8] += (uint64_t)sk * t2.x;
-                }
-                uint32_t v[10];
+                    const uint4 t0 = tlds[3 * k], t1 = tlds[3 * k + 1], t2 = tlds[3 * k + 2];
 #pragma unroll
-                for (int k = 0; k < 9; k++) { v[k] = (uint32_t)col[k] & DMASK; col[k + 1] += col[k] >> LB; }
-                v[9] = (uint32_t)col[9];                                  // < 2^29
-                // qhat = floor(floor(V / 2^232) mu / 2^58) is floor(V / p) or one less (V / 2^290 + 2^232 / p < 1)
-                const uint64_t mid = (uint64_t)v[9] * wq->m0 + (uint64_t)v[8] * wq->m1 + (((uint64_t)v[8] * wq->m0) >> LB);
-                const uint64_t qh = (uint64_t)v[9] * wq->m1 + (mid >> LB);
-                const uint32_t q0 = (uint32_t)qh & DMASK, q1 = (uint32_t)(qh >> LB);
-                uint64_t dc[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    dc[k] = v[k] + (uint64_t)q0 * wq->pbar[k];
-                    if (k > 0) dc[k] += (uint64_t)q1 * wq->pbar[k - 1];
+                    for (int o = 0; o < 2; o++) {
+                        const uint32_t sk = sd[o][9 + k];
+                        col[o][0] += (uint64_t)sk * t0.x; col[o][1] += (uint64_t)sk * t0.y; col[o][2] += (uint64_t)sk * t0.z; col[o][3] += (uint64_t)sk * t0.w;
+                        col[o][4] += (uint64_t)sk * t1.x; col[o][5] += (uint64_t)sk * t1.y; col[o][6] += (uint64_t)sk * t1.z; col[o][7] += (uint64_t)sk * t1.w;
+                        col[o][8] += (uint64_t)sk * t2.x;
+                    }
                 }
-                uint32_t r[9];
+                uint32_t v[2][10];
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    r[k] = (uint32_t)dc[k] & DMASK;
-                    if (k < 8) dc[k + 1] += dc[k] >> LB;
+                for (int k = 0; k < 9; k++)
+#pragma unroll
+                    for (int o = 0; o < 2; o++) { v[o][k] = (uint32_t)col[o][k] & DMASK; col[o][k + 1] += col[o][k] >> LB; }
+                // the rows to compare with: requested once the fold has released its registers, used after the Barrett step
+                if constexpr (CHECK) {
+#pragma unroll
+                    for (int o = 0; o < 2; o++) {
+                        const int erow = maskl[16 * rt + 4 * (rp + o) + g];
+                        cmp[o] = (chunk < n_chunks) && erow;
+                        if (cmp[o]) load_words<8>(ew[o], out_pk + (chunk * out_sc + (int64_t)(erow - 1) * out_sl) * 8);
+                    }
                 }
-                uint32_t ow[8];
-                pack<9, 8>(ow, r);
-                {
+                (void)ew; (void)cmp;
+                uint64_t dc[2][9];
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    v[o][9] = (uint32_t)col[o][9];                        // < 2^29
+                    // qhat = floor(floor(V / 2^232) mu / 2^58) is floor(V / p) or one less (V / 2^290 + 2^232 / p < 1)
+                    const uint64_t mid = (uint64_t)v[o][9] * wq->m0 + (uint64_t)v[o][8] * wq->m1 + (((uint64_t)v[o][8] * wq->m0) >> LB);
+                    const uint64_t qh = (uint64_t)v[o][9] * wq->m1 + (mid >> LB);
+                    const uint32_t q0 = (uint32_t)qh & DMASK, q1 = (uint32_t)(qh >> LB);
+#pragma unroll
+                    for (int k = 0; k < 9; k++) {
+                        dc[o][k] = v[o][k] + (uint64_t)q0 * wq->pbar[k];
+                        if (k > 0) dc[o][k] += (uint64_t)q1 * wq->pbar[k - 1];
+                    }
+                }
+                uint32_t r[2][9];
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+#pragma unroll
+                    for (int o = 0; o < 2; o++) {
+                        r[o][k] = (uint32_t)dc[o][k] & DMASK;
+                        if (k < 8) dc[o][k + 1] += dc[o][k] >> LB;
+                    }
+                uint32_t ow[2][8];
+#pragma unroll
+                for (int o = 0; o < 2; o++) {
+                    pack<9, 8>(ow[o], r[o]);
                     uint32_t u[8];
                     unsigned cy2 = 0;
 #pragma unroll
-                    for (int k = 0; k < 8; k++) u[k] = __builtin_addc(ow[k], wq->pneg[k], cy2, &cy2);
+                    for (int k = 0; k < 8; k++) u[k] = __builtin_addc(ow[o][k], wq->pneg[k], cy2, &cy2);
 #pragma unroll
-                    for (int k = 0; k < 8; k++) ow[k] = cy2 ? u[k] : ow[k];
+                    for (int k = 0; k < 8; k++) ow[o][k] = cy2 ? u[k] : ow[o][k];
                 }
                 if constexpr (CHECK) {
-                    if (cmp) {
-                        uint32_t diff = 0;
 #pragma unroll
-                        for (int k = 0; k < 8; k++) diff |= ew[k] ^ ow[k];
-                        if (diff) atomicOr(mismatch, 1);
-                    }
+                    for (int o = 0; o < 2; o++)
+                        if (cmp[o]) {
+                            uint32_t diff = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++) diff |= ew[o][k] ^ ow[o][k];
+                            if (diff) atomicOr(mismatch, 1);
+                        }
                 } else {
-                    const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
-                    asm volatile("" ::"v"(ow[0]), "v"(ow[1]), "v"(ow[2]), "v"(ow[3]), "v"(ow[4]), "v"(ow[5]), "v"(ow[6]), "v"(ow[7]));
-                    if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow);
+                    asm volatile("" ::"v"(ow[0][0]), "v"(ow[0][1]), "v"(ow[0][2]), "v"(ow[0][3]), "v"(ow[0][4]), "v"(ow[0][5]), "v"(ow[0][6]), "v"(ow[0][7]),
+                                 "v"(ow[1][0]), "v"(ow[1][1]), "v"(ow[1][2]), "v"(ow[1][3]), "v"(ow[1][4]), "v"(ow[1][5]), "v"(ow[1][6]), "v"(ow[1][7]));
+#pragma unroll
+                    for (int o = 0; o < 2; o++) {
+                        const int i = 16 * rt + 4 * (rp + o) + g;
+                        const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
+                        if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow[o]);
+                    }
                 }
             }
             MM8W_T(3);   // epilogue
