@@ -188,7 +188,7 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
 void mm8w_free(Mm8wMatrix *m);
 int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                 uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                int64_t C, hipStream_t s);
+                int64_t C, hipStream_t s, const uint32_t *cmp = nullptr, hb_view cv = hb_view{0, 0}, int n_store = 0);
 // the wide image of a generic matrix, built on first use (nullptr when the path does not apply)
 const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *m, hipStream_t s);
 

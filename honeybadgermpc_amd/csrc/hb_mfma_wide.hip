@@ -66,6 +66,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                                                  const int32_t *__restrict__ in_rows, int64_t in_count, int d,
                                                  uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
+                                                 const uint32_t *__restrict__ cmp_pk, int64_t cmp_sc, int64_t cmp_sl, int mask_is_map, int n_store,
                                                  int n_out, int n_rt, int nkb, int tpw, int nbuf, int64_t n_chunks, int64_t n_units,
                                                  uint32_t bias, const WideParams *__restrict__ wpp) {
     extern __shared__ uint4 mm8w_lds[];
@@ -87,7 +88,8 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     }
     for (int i = threadIdx.x; i < n_rt * 16 * 16; i += 256) crl[i] = crowd[i];
     if constexpr (CHECK) {
-        for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = (i < n_out && check_mask[i]) ? i + 1 : 0;
+        // a flag per row (compare with the same row), or a map: 1 + the row of the compare view, 0 = a row to store
+        for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = i < n_out ? (mask_is_map ? check_mask[i] : (check_mask[i] ? i + 1 : 0)) : 0;
     }
     __syncthreads();
     const int n_slots = tpw * nkb * 2;
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                     for (int o = 0; o < 2; o++) {
                         const int erow = maskl[16 * rt + 4 * (rp + o) + g];
                         cmp[o] = (chunk < n_chunks) && erow;
-                        if (cmp[o]) load_words<8>(ew[o], out_pk + (chunk * out_sc + (int64_t)(erow - 1) * out_sl) * 8);
+                        if (cmp[o]) load_words<8>(ew[o], cmp_pk + (chunk * cmp_sc + (int64_t)(erow - 1) * cmp_sl) * 8);
                     }
                 }
                 (void)ew; (void)cmp;
@@ -264,6 +266,15 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                             for (int k = 0; k < 8; k++) diff |= ew[o][k] ^ ow[o][k];
                             if (diff) atomicOr(mismatch, 1);
                         }
+                    // the rows of a fused decode + validate that are results, not predictions
+                    if (n_store > 0) {
+#pragma unroll
+                        for (int o = 0; o < 2; o++) {
+                            const int i = 16 * rt + 4 * (rp + o) + g;
+                            const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
+                            if (chunk < n_chunks && i < n_store && !maskl[i] && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow[o]);
+                        }
+                    }
                 } else {
                     asm volatile("" ::"v"(ow[0][0]), "v"(ow[0][1]), "v"(ow[0][2]), "v"(ow[0][3]), "v"(ow[0][4]), "v"(ow[0][5]), "v"(ow[0][6]), "v"(ow[0][7]),
                                  "v"(ow[1][0]), "v"(ow[1][1]), "v"(ow[1][2]), "v"(ow[1][3]), "v"(ow[1][4]), "v"(ow[1][5]), "v"(ow[1][6]), "v"(ow[1][7]));
@@ -480,10 +491,12 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     return HB_OK;
 }
 
-// out(c, i) = sum_l M[i][l] in(c, rows[l]) mod p, canonical; CHECK mode when check_mask_dev != nullptr (out = expected values)
+// out(c, i) = sum_l M[i][l] in(c, rows[l]) mod p, canonical; CHECK mode when check_mask_dev != nullptr: a flag per row and
+// out = the expected values, or -- with a compare view cmp -- a map (1 + row of cmp to compare row i with; 0: row i is a
+// result, stored to out when i < n_store): the fused decode + validate of hb_open.hip
 int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                 uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                int64_t C, hipStream_t s) {
+                int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store) {
     if (C <= 0) return HB_OK;
     int tpw = 1, nbuf = 1;
     const int64_t n_tiles = (C + 15) / 16;
@@ -502,6 +515,7 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
         }                                                                                                                             \
         hipLaunchKernelGGL((k_mm8w<CHK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
+                           cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
                            m->n_out, m->n_rt, m->nkb, tpw, nbuf, C, n_units, m->bias, m->wp);                                        \
     } while (0)
     if (check) MM8W_LAUNCH(true); else MM8W_LAUNCH(false);

@@ -52,7 +52,59 @@ struct hb_open_plan {
     const Mm8wMatrix *Winv8;     // its int8 image, owned by Winv; nullptr: integer-VALU decode
     hb_matrix *Vw;               // full n x d Vandermonde table (only when the encodes are not NTTs)
     const Mm8wMatrix *Vw8;       // its int8 image; nullptr: integer-VALU encodes
+    // Fused decode + validate on that kernel: the prediction of a later arrival is a LINEAR function of the arrival set,
+    // V[zc] (Winv y) = (V[zc] Winv) y, so one launch over the rows [Winv rows the caller wants ; V[zc] Winv] decodes and
+    // compares (same canonical values as interpolating first and evaluating after: exact arithmetic mod p).
+    Mm8wMatrix *F1, *F2;         // [Winv row 0 ; V[zc] Winv] for the R1 message, [Winv ; V[zc] Winv] for the R2 result (owned)
+    int32_t *fmap1, *fmap2;      // per row: 0 = a result row, else 1 + the received row to compare the prediction with
 };
+
+// [rows of Winv ; V[zc] Winv] as int8 images.  V[zc] Winv is computed on the device (the plain mat-vec over the columns of
+// Winv) and read back once; UNSUPPORTED shapes leave F1 / F2 null and the plan on its two-launch path.
+static int build_fused(hb_open_plan *pl, const uint64_t *x_host, hipStream_t s) {
+    hb_ctx *ctx = pl->ctx;
+    const int d = pl->d, nc = pl->n_check, L = ctx->n_limbs;
+    std::vector<uint64_t> W((size_t)d * d * L), P((size_t)nc * d * L);
+    int rc = hb_matrix_to_host(ctx, pl->Winv, W.data(), s);
+    if (rc) return rc;
+    if (nc > 0) {
+        std::vector<uint64_t> xzc((size_t)nc * L);
+        for (int j = 0; j < nc; j++) memcpy(&xzc[(size_t)j * L], x_host + (size_t)pl->zc[j] * L, (size_t)L * 8);
+        hb_matrix *Vzc = nullptr;
+        uint32_t *Wd = nullptr, *Pd = nullptr;
+        rc = hb_vand_matrix_create(ctx, xzc.data(), nc, d, &Vzc, s);
+        if (!rc) rc = upload_elems(ctx, W.data(), (size_t)d * d, &Wd, s);
+        if (!rc && hipMalloc(&Pd, P.size() * 8) != hipSuccess) rc = fail(ctx, HB_ERR_HIP, "fused validate: hipMalloc");
+        // in(c, l) = Winv[l][c], out(c, i) = (V[zc] Winv)[i][c]: both row-major d-wide
+        if (!rc) rc = hb_matvec(ctx, Vzc, (const uint64_t *)Wd, hb_view{1, d}, nullptr, (uint64_t *)Pd, hb_view{1, d}, d, s);
+        if (!rc && hipMemcpyAsync(P.data(), Pd, P.size() * 8, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(ctx, HB_ERR_HIP, "fused validate: copy");
+        if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(ctx, HB_ERR_HIP, "fused validate: sync");
+        if (Vzc) matrix_unref(Vzc);
+        if (Wd) (void)hipFree(Wd);
+        if (Pd) (void)hipFree(Pd);
+        if (rc) return rc;
+    }
+    std::vector<uint64_t> m2((size_t)(d + nc) * d * L), m1((size_t)(1 + nc) * d * L);
+    memcpy(m2.data(), W.data(), W.size() * 8);
+    memcpy(m1.data(), W.data(), (size_t)d * L * 8);
+    if (nc > 0) {
+        memcpy(&m2[(size_t)d * d * L], P.data(), P.size() * 8);
+        memcpy(&m1[(size_t)d * L], P.data(), P.size() * 8);
+    }
+    std::vector<int32_t> map2((size_t)d + nc + 1, 0), map1((size_t)1 + nc + 1, 0);
+    for (int j = 0; j < nc; j++) { map2[(size_t)d + j] = pl->zc[j] + 1; map1[(size_t)1 + j] = pl->zc[j] + 1; }
+    rc = mm8w_from_host(ctx, m2.data(), d + nc, d, &pl->F2, s);
+    if (!rc) rc = mm8w_from_host(ctx, m1.data(), 1 + nc, d, &pl->F1, s);
+    if (!rc) rc = own_int_array(ctx, map2.data(), (int)map2.size(), &pl->fmap2, s);
+    if (!rc) rc = own_int_array(ctx, map1.data(), (int)map1.size(), &pl->fmap1, s);
+    if (rc) {
+        mm8w_free(pl->F1); mm8w_free(pl->F2); pl->F1 = pl->F2 = nullptr;
+        if (pl->fmap1) { (void)hipFree(pl->fmap1); pl->fmap1 = nullptr; }
+        if (pl->fmap2) { (void)hipFree(pl->fmap2); pl->fmap2 = nullptr; }
+        return rc == HB_ERR_UNSUPPORTED ? HB_OK : rc;
+    }
+    return HB_OK;
+}
 
 extern "C" {
 
@@ -129,6 +181,9 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
             pl->Vw8 = matrix_wide(ctx, pl->Vw, s);
         }
         if ((pl->Winv8 || pl->Vw8) && !pl->coef_pk) PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
+        if (pl->Winv8 && !getenv("HB_NO_FUSED_VALIDATE")) {
+            rc = build_fused(pl, x_host, s); if (rc) goto done;
+        }
     }
     PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
@@ -164,6 +219,12 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
 static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64_t C, uint32_t *pk_dst, hb_view pv, int64_t pk_count,
                                int pk_rows, hipStream_t s) {
     hb_view pm{1, C};
+    if (pl->F1 && pl->F2 && pl->use_v8 && (pk_rows == 1 || pk_rows == pl->d)) {
+        // full-size entries: ONE launch decodes the rows the caller wants and compares the predictions of the later arrivals
+        const bool r1 = pk_rows == 1 && pl->d > 1;
+        return launch_mm8w(pl->ctx, r1 ? pl->F1 : pl->F2, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pk_dst, pv, pk_count,
+                           r1 ? pl->fmap1 : pl->fmap2, pl->mismatch_dev, C, s, (const uint32_t *)cols_dev, pm, pk_rows);
+    }
     if (pl->ntt_order) {
         // decode to canonical coefficient-major coefficients, validate with an NTT in CHECK mode,
         // then hand the caller the rows it asked for
@@ -294,6 +355,9 @@ void hb_open_plan_destroy(hb_open_plan *pl) {
     if (pl->ones_dev) (void)hipFree(pl->ones_dev);
     fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8); mm8_free(pl->Vinv8); mm8_free(pl->Vzc8);
     if (pl->scaled_pk) (void)hipFree(pl->scaled_pk);
+    mm8w_free(pl->F1); mm8w_free(pl->F2);
+    if (pl->fmap1) (void)hipFree(pl->fmap1);
+    if (pl->fmap2) (void)hipFree(pl->fmap2);
     if (pl->Winv) matrix_unref(pl->Winv);
     if (pl->Vw) matrix_unref(pl->Vw);
     delete pl;

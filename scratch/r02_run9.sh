@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r02v
+O=gpurun_out/r02z
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python scratch/test_mm8w.py > $O/mm8w.txt 2>&1
