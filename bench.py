@@ -564,6 +564,26 @@ def main():
     op.set_validate_arrived_only(False)
     assert ok4 and torch.equal(result, secrets)
 
+    # ---- secondary (untimed for `value`): the fused decode + validate switched off ------------------
+    # Plans with full-size matrix entries validate inside the decode launch (HB_OPEN_OPT_FUSED_VALIDATE); this is the
+    # same open as decode, full re-encode of all n points, compare -- the reference's three full encodes.
+    dt_unfused = None
+    if op.uses_fused_validate():
+        op.set_fused_validate(False)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        ok5 = op.ok()
+        torch.cuda.synchronize()
+        dt_unfused = time.perf_counter() - t1
+        op.set_fused_validate(True)
+        assert ok5 and torch.equal(result, secrets)
+        step()
+        assert op.ok()
+
     # ---- secondary (untimed for `value`): two independent opens in flight ------------------------
     # A party opens many share arrays concurrently (Mpc.open_share_array under asyncio); with a second plan
     # on a second stream consecutive opens overlap (kernel tails, the elementwise pass, and co-resident
@@ -658,6 +678,11 @@ def main():
                 "shares_per_s_per_gpu_validate_arrived_only": B * args.steps / dt_arrived,
                 "validate_arrived_only_note": "opt-in plan option: the guess is re-evaluated at the t compared points only (same accept/reject); "
                                               "NOT the headline, which re-encodes all n rows like the reference",
+                "fused_decode_validate": dt_unfused is not None,
+                "shares_per_s_per_gpu_three_full_encodes": (B * args.steps / dt_unfused) if dt_unfused else None,
+                "fused_decode_validate_note": "full-size matrix entries (omega-power points): each decode launch also produces the guess's values at the "
+                                              "compared points as (V[zc] Vinv) y and compares them (HB_OPEN_OPT_FUSED_VALIDATE, default on where it applies; "
+                                              "same results, same accept/reject); three_full_encodes = the option off: decode, re-encode all n points, compare",
                 "shares_per_s_per_gpu_two_opens_in_flight": (B * args.steps / dt_two) if dt_two else None,
                 "two_opens_in_flight_note": "same opens issued alternately on two streams with two plans (independent batches overlap); "
                                             "`value` is one open at a time on one stream",

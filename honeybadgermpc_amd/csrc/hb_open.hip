@@ -35,6 +35,7 @@ struct hb_open_plan {
     Mm8Matrix *Vinv8;    // same for the numerators N of the factored inverse (decode on the matrix cores); may be nullptr
     uint32_t *scaled_pk; // [d][max_C] received columns / den_j, the matrix-core decode's input
     int use_v8;          // option HB_OPEN_OPT_MATRIX_CORES (default 1)
+    int use_fused;       // option HB_OPEN_OPT_FUSED_VALIDATE (default 1)
     int32_t *z_dev;      // d row indices
     int32_t *mask_dev;   // n+1 ints: rows to validate
     uint32_t *in_dg;     // [d][NL][max_C] pre-scaled inputs (digit planes)
@@ -121,6 +122,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
     pl->use_v8 = 1;
+    pl->use_fused = 1;
     const int L = ctx->n_limbs;
     uint32_t *xd = nullptr, *xzd = nullptr;
     int rc = HB_OK;
@@ -219,7 +221,7 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
 static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64_t C, uint32_t *pk_dst, hb_view pv, int64_t pk_count,
                                int pk_rows, hipStream_t s) {
     hb_view pm{1, C};
-    if (pl->F1 && pl->F2 && pl->use_v8 && (pk_rows == 1 || pk_rows == pl->d)) {
+    if (pl->F1 && pl->F2 && pl->use_v8 && pl->use_fused && (pk_rows == 1 || pk_rows == pl->d)) {
         // full-size entries: ONE launch decodes the rows the caller wants and compares the predictions of the later arrivals
         const bool r1 = pk_rows == 1 && pl->d > 1;
         return launch_mm8w(pl->ctx, r1 ? pl->F1 : pl->F2, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pk_dst, pv, pk_count,
@@ -333,6 +335,7 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
         return HB_OK;
     }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { pl->use_v8 = value ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { pl->use_fused = value ? 1 : 0; return HB_OK; }
     return HB_ERR_BAD_ARG;
 }
 
@@ -340,6 +343,7 @@ int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) {
     if (!pl || !value) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { *value = pl->validate_arrived_only; return HB_OK; }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = ((pl->V8 || pl->Winv8 || pl->Vw8) && pl->use_v8) ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (pl->F1 && pl->F2 && pl->use_v8 && pl->use_fused) ? 1 : 0; return HB_OK; }
     return HB_ERR_BAD_ARG;
 }
 

@@ -96,6 +96,18 @@ class BatchOpen:
         re-encode; results are bit-identical either way."""
         self.ctx.check(self.ctx.lib.hb_open_plan_set_option(self.h, self.MATRIX_CORES, 1 if on else 0), "set_option")
 
+    FUSED_VALIDATE = 3
+
+    def set_fused_validate(self, on):
+        """Allow (default) or forbid the one-launch decode + validate of plans with full-size matrix entries
+        (include/hbmpc_hip.h, HB_OPEN_OPT_FUSED_VALIDATE); off = decode, re-encode all n points, compare."""
+        self.ctx.check(self.ctx.lib.hb_open_plan_set_option(self.h, self.FUSED_VALIDATE, 1 if on else 0), "set_option")
+
+    def uses_fused_validate(self):
+        v = ctypes.c_int(0)
+        self.ctx.check(self.ctx.lib.hb_open_plan_get_option(self.h, self.FUSED_VALIDATE, ctypes.byref(v)), "get_option")
+        return bool(v.value)
+
     def uses_matrix_cores(self):
         """True when this plan's encode / validation run on the matrix cores (shapes qualify and not disabled)."""
         v = ctypes.c_int(0)

@@ -165,9 +165,16 @@ int hb_open_status(hb_open_plan *plan, void *stream);
  * 2^254 <= p < 2^256 (the reference's BLS12-381 scalar field with the default points 1..n), the R1 encode
  * and the validating re-encode run as an exact int8 GEMM on the matrix cores (csrc/hb_mfma.hip); 0 forces
  * the integer-VALU kernels.  Results are bit-identical either way.  get_option reports whether the
- * matrix-core path is in use for this plan (0 when the plan's shapes do not qualify). */
+ * matrix-core path is in use for this plan (0 when the plan's shapes do not qualify).
+ * HB_OPEN_OPT_FUSED_VALIDATE (default 1): plans whose matrix entries are full-size residues (omega-power points, powers
+ * beyond 2^127) decode AND validate in one launch of the full-size matrix-core kernel: the value the guess takes at a later
+ * arrival's point is a linear function of the arrival set, V[zc] (Vinv y) = (V[zc] Vinv) y, so the rows [Vinv rows wanted ;
+ * V[zc] Vinv] applied to the received columns give the coefficients and the predictions to compare (reference:
+ * decoder.decode_batch + encoder.encode_batch + compare, reed_solomon.py:300-323; same canonical values, same accept /
+ * reject).  0: decode, then re-encode all n points (NTT or mat-vec) and compare.  get_option: in use for this plan. */
 #define HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY 1
 #define HB_OPEN_OPT_MATRIX_CORES 2
+#define HB_OPEN_OPT_FUSED_VALIDATE 3
 int hb_open_plan_set_option(hb_open_plan *plan, int option, int value);
 int hb_open_plan_get_option(hb_open_plan *plan, int option, int *value);
 void hb_open_plan_destroy(hb_open_plan *plan);

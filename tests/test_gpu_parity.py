@@ -269,6 +269,27 @@ def test_batch_open_vs_oracle(n, t, b, use_omega, matrix_cores):
         bad[rest[0]][0] = (bad[rest[0]][0] + 1) % P
         op.r2_decode(ctx.upload_ints([v for col in bad for v in col]), b)
         assert op.ok()
+    # full-size entries decode and validate in one launch (include/hbmpc_hip.h, HB_OPEN_OPT_FUSED_VALIDATE); switched off
+    # the plan decodes, re-encodes all n points and compares: same values, same decisions
+    assert op.uses_fused_validate() == (matrix_cores and eligible_wide)
+    if op.uses_fused_validate():
+        op.set_fused_validate(False)
+        assert not op.uses_fused_validate()
+        msg3 = op.r1_decode(ctx.upload_ints([v for col in r1_cols for v in col]), b)
+        res3 = op.r2_decode(ctx.upload_ints([v for col in r2_cols for v in col]), b)
+        assert op.ok() and np.array_equal(as_np(msg3), o_r2msg) and np.array_equal(as_np(res3), o_res)
+        for fused in (False, True):
+            op.set_fused_validate(fused)
+            for which in ("r1", "r2"):
+                for row in (zc[0], zc[-1]) if zc else ():
+                    bad = [list(col) for col in (r1_cols if which == "r1" else r2_cols)]
+                    k = rnd.randrange(c)
+                    bad[row][k] = (bad[row][k] ^ (1 << rnd.randrange(255))) % P
+                    if bad[row][k] == (r1_cols if which == "r1" else r2_cols)[row][k]:
+                        continue
+                    cols = ctx.upload_ints([v for col in bad for v in col])
+                    (op.r1_decode if which == "r1" else op.r2_decode)(cols, b)
+                    assert not op.ok(), (fused, which, row, k)
 
 
 def test_full_size_properties_cfg3():
