@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Emits hb_mm8w_body.inc: the MFMA phase of k_mm8w (hb_mfma_wide.hip) as one inline-asm block.
+"""Emits hb_mm8w_body.inc: the passes of k_mm8w (hb_mfma_wide.hip) as inline-asm statements.
 
 k_mm8w is the matrix-core mat-vec for FULL-SIZE matrix entries (any residue mod p: inverse Vandermonde
-matrices at omega-power points, Vandermonde matrices whose powers outgrow 2^127, arbitrary hb_matrix
-operands).  Entries are cut into 32 base-256 digits M_b, inputs into their 32 bytes X_a:
+matrices at omega-power points, Vandermonde matrices whose powers outgrow 2^127, the fused decode + validate
+matrices of hb_open.hip, arbitrary hb_matrix operands).  Entries are cut into 32 base-256 digits M_b, inputs
+into their 32 bytes X_a:
 
     S = sum_l M[l] x[l] = sum_c 2^(8c) col_c,   col_c = sum_l sum_b M_b[l] X_{c-b}[l],   c < 63.
 
@@ -11,33 +12,81 @@ One v_mfma_i32_16x16x64_i8 contracts 4 terms x 16 digits, so a column needs two 
 [16G, 16G + 16)) per term block: with s = c - 15 - 16G the B operand is bytes [s, s + 15] of the element,
 i.e. dwords q .. q+3 of the element shifted right by rho bytes (s = 4q + rho).  Every window s in
 [-15, 31] therefore feeds TWO MFMAs (group 0 -> column s + 15, group 1 -> column s + 31): 94 per term
-block, against 18 preparation ops per (term block, rho) -- the phase is matrix-pipe bound, which is the
-point: the int8 pipe does the 1024 byte products of a 256 x 256-bit multiplication in 16 cycles per 16 x 16
-outputs, the VALU needs 81 half-rate v_mad_u64_u32 per lane.
+block, against 18 preparation ops per (term block, rho): the int8 pipe does the 1024 byte products of a
+256 x 256-bit multiplication in 16 cycles per 16 x 16 outputs, the VALU needs 81 half-rate v_mad_u64_u32 per lane.
 
-Register files and the schedule are those of gen_mm8.py (two EA sets for even q, EB one register apart for
-odd q, the next group's shifts built while the current group's MFMAs issue), with four shifts rho = 0..3 per
-term block instead of two per half, all 63 accumulators live (AGPR operands of the asm statement: the kernel
-runs one wave per SIMD with the 512-register budget), the matrix digits streamed from L2 (two dwordx4 per lane
-per term block, one block ahead) and a LOOP over pairs of term blocks, so that the code does not grow with
-the inner dimension.  The first pair is peeled: its first touch of every column starts from the inline
-constant 0.
+A pass = one asm statement, SOFTWARE-PIPELINED over passes: the kernel runs one wave per SIMD (all 63 accumulators of
+16 x 16 outputs live in AGPRs a0..a251), so nothing else could hide the reduction of S mod p (~310 VALU instructions per
+output) -- it would simply follow the MFMA phase, which leaves the VALU three quarters idle.  Instead a pass ends by
+moving its sums out of the AGPRs as 17 words per output (68 VGPRs), and the NEXT pass reduces, compares and stores them
+between its own MFMAs: outputs 0, 1 inside the first pair of term blocks, outputs 2, 3 inside the last pair (both peeled;
+the pairs between them are a loop, so the code does not grow with the inner dimension).  After its last pass a wave
+runs the reduction alone (mm8w_reduce).
 
-Operands: %0..%62 accumulators; %63 LDS byte address of the lane's element slot (advanced here), %64 per-lane
-byte offset into the digit image (advanced here), %65 loop count = nkb / 2 - 1 (consumed), %66 digit image
-base of this row tile (SGPR pair).
+Register files (VGPRs the statement owns: v124 .. v255): v190.. the MFMA operand files of the first version (two EA sets
+for even q, EB one register apart for odd q, the next group's shifts built while the current group's MFMAs issue, element
+prefetch XB, digit buffers ABUF); v124 .. v189 the reduction (ten 64-bit columns, two buffers for the T_k rows, the packed
+result, the row to compare with).  SGPRs s68 .. s89: the Barrett constants (scalar loads from WideParams), a saved exec.
+
+Reduction of one output (the arithmetic of k_prescale_tab / the first version's C++ epilogue, same bounds):
+  19 radix-2^29 digits of the 17 words; V = low nine digits + per-row constant + sum_{k >= 9} s_k T_k (T_k = 2^(29k) mod p from
+  LDS, 90 MADs) < 2^290; carry; two-digit Barrett quotient against mu = floor(2^290 / p); V + q (2^261 - p) in nine digits;
+  pack to eight words; conditional subtraction of p; then the lane's mode word says store (1), compare (2) or neither (0).
 """
 import os
 
 NC = 63
+NWORDS = 17
+RB = 124                       # first register the statement owns
+# ---- MFMA operand files ----
 XB = 190                       # 8 dwords: LDS prefetch of the next term block's element
 ABUF = [[198, 202], [206, 210]]  # [term block parity][digit group]: 4 dwords each
 EA_SETS = [214, 228]           # 14 registers each, k = -4 .. 9
 EA_KMIN = -4
 EB0, EB_KMIN = 242, -3         # 14 registers, k = -3 .. 10
-CLOBBER_LO, CLOBBER_HI = 190, 255
 RHOS = (0, 1, 2, 3)
-OP_XA, OP_VA, OP_CNT, OP_SB = "%63", "%64", "%65", "%66"
+# ---- reduction file ----
+C0 = 124                       # ten 64-bit columns: C0 + 2j (low), + 1 (high)
+TB = [144, 156, 176]           # three buffers for the T_k rows / the row constant (9 digits; the first two padded to 12)
+OW = 168                       # packed result, 8 words
+EX = 176                       # row to compare with, 8 words: the third T buffer once the fold is done with it
+SK, T1, T2, ZERO = 189, 185, 186, 188   # T2 is a pair
+QP, Q0, Q1 = 144, 146, 147     # Barrett quotient (the T buffers are free by then)
+UB = 124                       # ow + (2^256 - p): the columns are free by then
+DIFF = 144
+# ---- tail (word assembly) ----
+TL_TMP = [[124, 125, 126, 127], [128, 129, 130, 131]]
+TL_T = [[132, 134, 136, 138], [140, 142, 144, 146]]
+# ---- SGPRs ----
+S_PBAR, S_PNEG, S_M0, S_M1 = 68, 77, 85, 86    # WideParams: pbar[9] pneg[8] m0 m1 pad, loaded to s68 .. s87
+S_SAVE = 88                    # saved exec, pair
+MASK = "0x1fffffff"
+LB = 29
+
+
+class Ops:
+    """operand numbering of the asm statement"""
+
+    def __init__(self, check):
+        self.outs, self.ins = [], []
+        for r in range(4):
+            for j in range(NWORDS):
+                self.outs.append((f"W{r}_{j}", '"+v"', f"w[{r}][{j}]"))
+        self.outs += [("XA", '"+v"', "xa"), ("VA", '"+v"', "va"), ("CNT", '"+s"', "cnt")]
+        if check:
+            self.outs.append(("FLAG", '"+s"', "flag"))
+        self.ins += [("ABASE", '"s"', "abase"), ("K256", '"s"', "k256"), ("K64K", '"s"', "k64k"), ("K16M", '"s"', "k16m"),
+                     ("B4", '"v"', "bias4"), ("B3", '"v"', "bias3"), ("WPP", '"s"', "wpa")]
+        for r in range(4):
+            self.ins.append((f"CRL{r}", '"v"', f"crl_addr[{r}]"))
+        for r in range(4):
+            self.ins.append((f"ADDR{r}", '"v"', f"addr[{r}]"))
+        for r in range(4):
+            self.ins.append((f"MODE{r}", '"v"', f"mode[{r}]"))
+        self.idx = {name: i for i, (name, _, _) in enumerate(self.outs + self.ins)}
+
+    def __call__(self, name):
+        return f"%{self.idx[name]}"
 
 
 def ea(s, k):
@@ -54,16 +103,20 @@ def windows(rho):
     return [q for q in range(-4, 8) if -15 <= 4 * q + rho <= 31]
 
 
-def loads(par):
+def acc(c):
+    return f"a[{4 * c}:{4 * c + 3}]"
+
+
+def loads(par, o):
     """element and digits of the NEXT term block -> XB, ABUF[par]; both cursors move on by one block"""
     a0, a1 = ABUF[par]
     return [
-        f"ds_read_b128 v[{XB}:{XB + 3}], {OP_XA}",
-        f"ds_read_b128 v[{XB + 4}:{XB + 7}], {OP_XA} offset:1024",
-        f"v_add_u32 {OP_XA}, 0x800, {OP_XA}",
-        f"global_load_dwordx4 v[{a0}:{a0 + 3}], {OP_VA}, {OP_SB}",
-        f"global_load_dwordx4 v[{a1}:{a1 + 3}], {OP_VA}, {OP_SB} offset:1024",
-        f"v_add_u32 {OP_VA}, 0x800, {OP_VA}",
+        f"ds_read_b128 v[{XB}:{XB + 3}], {o('XA')}",
+        f"ds_read_b128 v[{XB + 4}:{XB + 7}], {o('XA')} offset:1024",
+        f"v_add_u32 {o('XA')}, 0x800, {o('XA')}",
+        f"global_load_dwordx4 v[{a0}:{a0 + 3}], {o('VA')}, {o('ABASE')}",
+        f"global_load_dwordx4 v[{a1}:{a1 + 3}], {o('VA')}, {o('ABASE')} offset:1024",
+        f"v_add_u32 {o('VA')}, 0x800, {o('VA')}",
     ]
 
 
@@ -122,75 +175,311 @@ def mfmas(gi, parity, par, seen):
             c = 4 * q + rho + 15 + 16 * grp
             assert 0 <= c < NC
             ab = ABUF[par][grp]
-            cin = f"%{c}"
+            cin = acc(c)
             if seen is not None and c not in seen:
                 cin = "0"
                 seen.add(c)
-            out.append(f"v_mfma_i32_16x16x64_i8 %{c}, v[{ab}:{ab + 3}], v[{r}:{r + 3}], {cin}")
+            out.append(f"v_mfma_i32_16x16x64_i8 {acc(c)}, v[{ab}:{ab + 3}], v[{r}:{r + 3}], {cin}")
     return out
 
 
-def pair(first):
+def pair(kind, o):
     """two term blocks (8 groups): digits of the even one in ABUF[0], of the odd one in ABUF[1].  On entry the first
     group's EA / EB files are ready, XB has been consumed and the even block's digits are in flight.
     The odd block of the LAST pair must not prefetch: nothing waits for a load issued there, and one that lands after the
     asm statement would overwrite registers the compiler has taken back (it did, once per ~10^4 launches, when L2 was cold)."""
     L = []
-    seen = set() if first else None
-    tag = "p" if first else "l"
+    seen = set() if kind == "first" else None
     for gi in range(8):
         par = gi // 4
         if gi % 4 == 0:
             # the digits of this block were requested one block ago; every MFMA reading the other buffer has been issued
             L.append("s_waitcnt vmcnt(0)")
-            if gi == 4:
-                # remaining pairs after this one: the counter itself in the peeled pair, counter - 1 in the loop body
-                L += [f"s_cmp_eq_u32 {OP_CNT}, {0 if first else 1}", f"s_cbranch_scc1 .Lmm8w_nopf_{tag}_%="]
-            L += loads(1 - par)
-            if gi == 4:
-                L.append(f".Lmm8w_nopf_{tag}_%=:")
+            if not (gi == 4 and kind == "last"):
+                L += loads(1 - par, o)
         L += interleave(mfmas(gi, 1, par, seen), prep_a(gi + 1))
         L += interleave(mfmas(gi, 0, par, seen), prep_b(gi + 1))
         L.append("s_nop 0")
-    if first:
+    if kind == "first":
         assert seen == set(range(NC))
     return L
 
 
-def asm_lines():
+# ------------------------------------------------------------------------------------------------ reduction
+def masked(o, r, mode_value, body):
+    """body under exec & (mode == mode_value): one unit, never interleaved with the MFMA stream"""
+    return [[f"s_mov_b64 s[{S_SAVE}:{S_SAVE + 1}], exec",
+             f"v_cmp_eq_u32_e32 vcc, {mode_value}, {o(f'MODE{r}')}",
+             "s_and_b64 exec, exec, vcc"] + body + [f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]"]]
+
+
+def digit(o, r, k, dst):
+    """dst = digit k (29 bits) of the 17 words of output r"""
+    bit = LB * k
+    j, sft = bit >> 5, bit & 31
+    w = lambda i: o(f"W{r}_{i}")  # noqa: E731
+    if sft == 0:
+        return [f"v_and_b32 v{dst}, {MASK}, {w(j)}"]
+    if j + 1 >= NWORDS:
+        return [f"v_lshrrev_b32 v{dst}, {sft}, {w(j)}", f"v_and_b32 v{dst}, {MASK}, v{dst}"]
+    return [f"v_alignbit_b32 v{dst}, {w(j + 1)}, {w(j)}, {sft}", f"v_and_b32 v{dst}, {MASK}, v{dst}"]
+
+
+def row_reads(addr, off, buf):
+    """nine digits of a 48-byte LDS row -> TB[buf] (two 16-byte reads and one dword: the third buffer has nine registers)"""
+    b = TB[buf]
+    return [f"ds_read_b128 v[{b}:{b + 3}], {addr} offset:{off}",
+            f"ds_read_b128 v[{b + 4}:{b + 7}], {addr} offset:{off + 16}",
+            f"ds_read_b32 v{b + 8}, {addr} offset:{off + 32}"]
+
+
+def t_reads(k):
+    return row_reads(f"v{ZERO}", 48 * k, k % 3)
+
+
+def cpair(j):
+    return f"v[{C0 + 2 * j}:{C0 + 2 * j + 1}]"
+
+
+def carry(upto):
+    """columns 0 .. upto-1 keep 29 bits, the rest moves up"""
     L = []
+    for j in range(upto):
+        L += [f"v_lshrrev_b64 v[{T2}:{T2 + 1}], {LB}, {cpair(j)}",
+              f"v_and_b32 v{C0 + 2 * j}, {MASK}, v{C0 + 2 * j}",
+              f"v_lshl_add_u64 {cpair(j + 1)}, v[{T2}:{T2 + 1}], 0, {cpair(j + 1)}"]
+    return L
+
+
+def reduce_output(o, r, check):
+    """units (lists of lines) reducing output r's 17 words and storing / comparing the canonical element"""
+    U = []
+    one = lambda ln: U.append([ln])  # noqa: E731
+    # per-row constant -> TB[2], T_9 -> TB[0], T_10 -> TB[1]; the rows are requested THREE steps ahead of their use: one wave
+    # per SIMD has only its own instructions (and the MFMAs between them) to cover the LDS latency
+    for ln in row_reads(o(f"CRL{r}"), 0, 2) + t_reads(0) + t_reads(1):
+        one(ln)
+    one("s_waitcnt lgkmcnt(6)")
+    for j in range(9):
+        for ln in digit(o, r, j, T1):
+            one(ln)
+        one(f"v_add_u32 v{C0 + 2 * j}, v{T1}, v{TB[2] + j}")
+        one(f"v_mov_b32 v{C0 + 2 * j + 1}, 0")
+    one(f"v_mov_b32 v{C0 + 18}, 0")
+    one(f"v_mov_b32 v{C0 + 19}, 0")
+    for ln in t_reads(2):
+        one(ln)
+    # V += s_(9+k) T_k
+    for k in range(10):
+        for ln in digit(o, r, 9 + k, SK):
+            one(ln)
+        one(f"s_waitcnt lgkmcnt({3 * min(2, 9 - k)})")
+        b = TB[k % 3]
+        for j in range(9):
+            one(f"v_mad_u64_u32 {cpair(j)}, vcc, v{SK}, v{b + j}, {cpair(j)}")
+        if k + 3 < 10:
+            for ln in t_reads(k + 3):
+                one(ln)
+        if check and k == 8:
+            # the row to compare with lands in the third T buffer, which the fold has just left
+            U += masked(o, r, 2, [f"global_load_dwordx4 v[{EX}:{EX + 3}], {o(f'ADDR{r}')}, off",
+                                  f"global_load_dwordx4 v[{EX + 4}:{EX + 7}], {o(f'ADDR{r}')}, off offset:16"])
+    for ln in carry(9):
+        one(ln)
+    v8, v9 = C0 + 16, C0 + 18
+    # qhat = floor(floor(V / 2^232) mu / 2^58): floor(V / p) or one less
+    for ln in [f"v_mad_u64_u32 v[{QP}:{QP + 1}], vcc, v{v8}, s{S_M0}, 0",
+               f"v_lshrrev_b64 v[{QP}:{QP + 1}], {LB}, v[{QP}:{QP + 1}]",
+               f"v_mad_u64_u32 v[{QP}:{QP + 1}], vcc, v{v8}, s{S_M1}, v[{QP}:{QP + 1}]",
+               f"v_mad_u64_u32 v[{QP}:{QP + 1}], vcc, v{v9}, s{S_M0}, v[{QP}:{QP + 1}]",
+               f"v_lshrrev_b64 v[{QP}:{QP + 1}], {LB}, v[{QP}:{QP + 1}]",
+               f"v_mad_u64_u32 v[{QP}:{QP + 1}], vcc, v{v9}, s{S_M1}, v[{QP}:{QP + 1}]",
+               f"v_and_b32 v{Q0}, {MASK}, v{QP}",
+               f"v_alignbit_b32 v{Q1}, v{QP + 1}, v{QP}, {LB}"]:
+        one(ln)
+    # V + q (2^261 - p), nine digits (what leaves digit 8 is the 2^261 q that was added)
+    for j in range(9):
+        one(f"v_mov_b32 v{C0 + 2 * j + 1}, 0")
+        one(f"v_mad_u64_u32 {cpair(j)}, vcc, v{Q0}, s{S_PBAR + j}, {cpair(j)}")
+        if j > 0:
+            one(f"v_mad_u64_u32 {cpair(j)}, vcc, v{Q1}, s{S_PBAR + j - 1}, {cpair(j)}")
+    for ln in carry(8):
+        one(ln)
+    one(f"v_and_b32 v{C0 + 16}, {MASK}, v{C0 + 16}")
+    # nine digits -> eight words
+    one(f"v_lshl_or_b32 v{OW}, v{C0 + 2}, {LB}, v{C0}")
+    for j in range(1, 8):
+        one(f"v_lshrrev_b32 v{T1}, {3 * j}, v{C0 + 2 * j}")
+        one(f"v_lshl_or_b32 v{OW + j}, v{C0 + 2 * j + 2}, {LB - 3 * j}, v{T1}")
+    # conditional subtraction: the carry out of ow + (2^256 - p) says ow >= p.  One unit: the carry chain lives in vcc
+    # (an SGPR operand beside the carry in vcc would be two constant-bus reads: 2^256 - p goes through the free T buffer)
+    for j in range(8):
+        one(f"v_mov_b32 v{TB[1] + j}, s{S_PNEG + j}")
+    cs = [f"v_add_co_u32_e32 v{UB}, vcc, v{TB[1]}, v{OW}"]
+    for j in range(1, 8):
+        cs.append(f"v_addc_co_u32_e32 v{UB + j}, vcc, v{TB[1] + j}, v{OW + j}, vcc")
+    for j in range(8):
+        cs.append(f"v_cndmask_b32_e32 v{OW + j}, v{OW + j}, v{UB + j}, vcc")
+    U.append(cs)
+    if check:
+        cmp = ["s_waitcnt vmcnt(0)"]
+        for j in range(8):
+            cmp.append(f"v_xor_b32 v{DIFF + j}, v{EX + j}, v{OW + j}")
+        cmp += [f"v_or3_b32 v{DIFF}, v{DIFF}, v{DIFF + 1}, v{DIFF + 2}",
+                f"v_or3_b32 v{DIFF + 3}, v{DIFF + 3}, v{DIFF + 4}, v{DIFF + 5}",
+                f"v_or3_b32 v{DIFF}, v{DIFF}, v{DIFF + 6}, v{DIFF + 7}",
+                f"v_or_b32 v{DIFF}, v{DIFF}, v{DIFF + 3}"]
+        U.append(cmp)
+        U += masked(o, r, 2, [f"v_cmp_ne_u32_e32 vcc, 0, v{DIFF}", f"s_or_b64 {o('FLAG')}, {o('FLAG')}, vcc"])
+    U += masked(o, r, 1, [f"global_store_dwordx4 {o(f'ADDR{r}')}, v[{OW}:{OW + 3}], off",
+                          f"global_store_dwordx4 {o(f'ADDR{r}')}, v[{OW + 4}:{OW + 7}], off offset:16"])
+    return U
+
+
+ABLATE = os.environ.get("HB_GEN_MM8W_ABLATE", "").split(",")    # timing experiments only (wrong results): nored, notail, nofold, nommfa
+
+
+def merge(stream, units):
+    """spread the reduction units evenly behind the MFMAs of `stream`"""
+    if "nored" in ABLATE:
+        units = []
+    if "nomfma" in ABLATE:
+        stream = [ln for ln in stream if not ln.startswith("v_mfma")] + ["v_mfma_i32_16x16x64_i8 a[0:3], v[198:201], v[214:217], a[0:3]"]
+    n_mfma = sum(1 for ln in stream if ln.startswith("v_mfma"))
+    out, done, seen = [], 0, 0
+    for ln in stream:
+        out.append(ln)
+        if ln.startswith("v_mfma"):
+            seen += 1
+            want = (len(units) * seen + n_mfma - 1) // n_mfma
+            while done < want:
+                out += units[done]
+                done += 1
+    assert done == len(units)
+    return out
+
+
+def consts(o):
+    return [f"s_load_dwordx16 s[{S_PBAR}:{S_PBAR + 15}], {o('WPP')}, 0x0",
+            f"s_load_dwordx4 s[{S_PBAR + 16}:{S_PBAR + 19}], {o('WPP')}, 0x40",
+            f"v_mov_b32 v{ZERO}, 0"]
+
+
+# ------------------------------------------------------------------------------------------------ tail
+def tail(o):
+    """The accumulators leave as 32-bit words of S = sum_c (col_c + bias) 2^(8c): per word four signed columns go into one
+    64-bit sum by v_mad_i64_i32 (x 1, 2^8, 2^16, 2^24; the first one adds the bias of all four), the previous word's high half
+    comes in by one more MAD (x 1) -- every term is non-negative, so there is no carry flag anywhere -- and the four outputs
+    of the lane run side by side."""
+    K = {1: o("K256"), 2: o("K64K"), 3: o("K16M")}
+    L = []
+    n_words = (NC + 3) // 4
+    for j in range(n_words):
+        ts = TL_T[j & 1]
+        cols = [c for c in range(4 * j, 4 * j + 4) if c < NC]
+        bias = o("B4") if len(cols) == 4 else o("B3")
+        assert len(cols) in (3, 4)
+        reads = [[f"v_accvgpr_read_b32 v{TL_TMP[i & 1][r]}, a{4 * c + r}" for r in range(4)] for i, c in enumerate(cols)]
+        L += reads[0]
+        for i, c in enumerate(cols):
+            if i + 1 < len(cols):
+                L += reads[i + 1]
+            mul = "1" if i == 0 else K[i]
+            for r in range(4):
+                add = bias if i == 0 else f"v[{ts[r]}:{ts[r] + 1}]"
+                L.append(f"v_mad_i64_i32 v[{ts[r]}:{ts[r] + 1}], vcc, v{TL_TMP[i & 1][r]}, {mul}, {add}")
+        if j > 0:
+            for r in range(4):
+                L.append(f"v_mad_u64_u32 v[{ts[r]}:{ts[r] + 1}], vcc, v{TL_T[1 - (j & 1)][r] + 1}, 1, v[{ts[r]}:{ts[r] + 1}]")
+        for r in range(4):
+            L.append(f"v_mov_b32 {o(f'W{r}_{j}')}, v{ts[r]}")
+    assert n_words == NWORDS - 1
+    for r in range(4):
+        L.append(f"v_mov_b32 {o(f'W{r}_{NWORDS - 1}')}, v{TL_T[(n_words - 1) & 1][r] + 1}")
+    return L
+
+
+def split(units, parts):
+    n = len(units)
+    return [units[n * i // parts:n * (i + 1) // parts] for i in range(parts)]
+
+
+def pass_lines(check, peel):
+    """`peel` pairs of term blocks are straight-line code carrying the reduction of the pass before, in equal shares (one wave
+    per SIMD issues a VALU instruction every ~7 cycles at best -- profiles/r01_mad_issue_rate_vs_occupancy.txt -- so a pair
+    hides about one output's reduction behind its 188 MFMAs); the other nkb/2 - peel pairs run as a loop in the middle."""
+    o = Ops(check)
+    L = consts(o)
     # positions that are read but never written stay zero: k <= -2 and k >= 8
     for s in range(2):
         for k in (-4, -3, -2, 8, 9):
             L.append(f"v_mov_b32 v{ea(s, k)}, 0")
     for k in (-3, -2, 8, 9, 10):
         L.append(f"v_mov_b32 v{eb(k)}, 0")
-    L += loads(0)                                   # term block 0
-    L += prep_a(0) + prep_b(0) + ["s_nop 1"]
-    L += pair(True)
-    L += [f"s_cmp_eq_u32 {OP_CNT}, 0", "s_cbranch_scc1 .Lmm8w_end_%="]
-    L.append(".Lmm8w_loop_%=:")
-    L += pair(False)
-    L += [f"s_sub_u32 {OP_CNT}, {OP_CNT}, 1", f"s_cmp_lg_u32 {OP_CNT}, 0", "s_cbranch_scc1 .Lmm8w_loop_%="]
-    L.append(".Lmm8w_end_%=:")
+    L += loads(0, o)                                # term block 0
+    L += prep_a(0) + prep_b(0) + ["s_nop 1"]        # (its lgkmcnt(0) also covers the scalar loads)
+    units = []
+    for r in range(4):
+        units += reduce_output(o, r, check)
+    shares = split(units, peel)
+    head = (peel + 1) // 2
+    for i in range(peel):
+        if i == head:
+            L += [f"s_cmp_eq_u32 {o('CNT')}, 0", "s_cbranch_scc1 .Lmm8w_rest_%="]
+            L.append(".Lmm8w_loop_%=:")
+            L += pair("mid", o)
+            L += [f"s_sub_u32 {o('CNT')}, {o('CNT')}, 1", f"s_cmp_lg_u32 {o('CNT')}, 0", "s_cbranch_scc1 .Lmm8w_loop_%="]
+            L.append(".Lmm8w_rest_%=:")
+        kind = "first" if i == 0 else ("last" if i == peel - 1 else "mid")
+        L += merge(pair(kind, o), shares[i])
     L += ["s_nop 7", "s_nop 7"]
-    return L
+    if "notail" not in ABLATE:
+        L += tail(o)
+    return o, L
+
+
+def reduce_lines(check):
+    o = Ops(check)
+    L = consts(o) + ["s_waitcnt lgkmcnt(0)"]
+    for r in range(4):
+        for u in reduce_output(o, r, check):
+            L += u
+    return o, L
+
+
+def emit_fn(name, o, lines, check):
+    out = []
+    sig = ("uint32_t (&w)[4][17], uint32_t &xa, uint32_t &va, uint32_t &cnt, uint64_t &flag, uint64_t abase, int32_t k256, int32_t k64k, "
+           "int32_t k16m, int64_t bias4, int64_t bias3, uint64_t wpa, const uint32_t (&crl_addr)[4], const uint64_t (&addr)[4], "
+           "const uint32_t (&mode)[4]")
+    out.append(f"static __device__ __forceinline__ void {name}({sig}) {{")
+    if not check:
+        out.append("    (void)flag;")
+    out.append("    asm volatile(")
+    for ln in lines:
+        out.append(f'        "{ln}\\n\\t"')
+    out.append("        : " + ", ".join(f"{c}({e})" for _, c, e in o.outs))
+    out.append("        : " + ", ".join(f"{c}({e})" for _, c, e in o.ins))
+    clob = [f'"v{r}"' for r in range(RB, 256)] + [f'"a{r}"' for r in range(4 * NC)] + [f'"s{r}"' for r in range(S_PBAR, S_SAVE + 2)]
+    out.append("        : " + ", ".join(clob) + ', "vcc", "scc", "memory");')
+    out.append("}")
+    out.append("")
+    return out
+
+
+PEELS = (2, 3, 4)
 
 
 def emit():
     out = ["// GENERATED by gen_mm8w.py -- do not edit", ""]
-    clob = ", ".join(f'"v{r}"' for r in range(CLOBBER_LO, CLOBBER_HI + 1))
-    lines = asm_lines()
-    out.append("static __device__ __forceinline__ void mm8w_phase(v4i (&acc)[63], uint32_t &xa, uint32_t &va, uint32_t &cnt, uint64_t abase) {")
-    out.append("    asm volatile(")
-    for ln in lines:
-        out.append(f'        "{ln}\\n\\t"')
-    outs = ", ".join(f'"=&a"(acc[{i}])' for i in range(NC))
-    out.append(f"        : {outs}, \"+v\"(xa), \"+v\"(va), \"+s\"(cnt)")
-    out.append('        : "s"(abase)')
-    out.append(f'        : {clob}, "scc", "memory");')
-    out.append("}")
-    return "\n".join(out) + "\n"
+    for check in (False, True):
+        sfx = "_check" if check else ""
+        for peel in PEELS:
+            o, lines = pass_lines(check, peel)
+            out += emit_fn(f"mm8w_pass{sfx}_p{peel}", o, lines, check)
+        o, lines = reduce_lines(check)
+        out += emit_fn(f"mm8w_reduce{sfx}", o, lines, check)
+    return "\n".join(out)
 
 
 if __name__ == "__main__":

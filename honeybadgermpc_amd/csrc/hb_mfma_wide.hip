@@ -21,6 +21,7 @@
 // Inputs are biased by XOR 0x80 (int8 operands are signed); the per-row constant takes that and the accumulator
 // bias back out, mod p.  No Montgomery form anywhere.
 #include <algorithm>
+#include <cstddef>
 
 #include "hb_common.hpp"
 
@@ -32,12 +33,14 @@ constexpr int MM8W_NC = 63;     // int32 columns per output
 constexpr int MM8W_WORDS = 17;  // 32-bit words of the biased sum
 constexpr int MM8W_SD = 19;     // its radix-2^29 digits
 
-struct WideParams {
-    uint32_t T[10][9];   // 2^(29 (9 + k)) mod p, digits
+struct WideParams {     // the asm passes fetch the first 20 dwords by scalar loads (gen_mm8w.py: s68 .. s87)
     uint32_t pbar[9];    // 2^261 - p, digits
     uint32_t pneg[8];    // 2^256 - p, words
     uint32_t m0, m1;     // floor(2^290 / p), digits
+    uint32_t pad;
+    uint32_t T[10][9];   // 2^(29 (9 + k)) mod p, digits
 };
+static_assert(offsetof(WideParams, T) == 80, "gen_mm8w.py loads pbar, pneg, m0, m1 from offsets 0 .. 75");
 
 struct Mm8wMatrix {
     int n_out, d, nkb, n_rt;
@@ -59,7 +62,7 @@ __device__ unsigned long long g_mm8w_t[1024 * 8];
 #define MM8W_T(k) do { } while (0)
 #endif
 
-template <bool CHECK>
+template <bool CHECK, int PEEL>
 __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
                                                  const uint32_t *__restrict__ zero_src,
                                                  const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
@@ -72,9 +75,9 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     extern __shared__ uint4 mm8w_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
-    uint32_t *crl = reinterpret_cast<uint32_t *>(mm8w_lds);                 // [n_rt * 16][16]
-    uint4 *tlds = mm8w_lds + n_rt * 64;                                     // [10][3] uint4: T_k, 9 digits + 3 pad (32 uint4 reserved)
-    uint4 *xbuf = tlds + 32;                                                // nbuf x [tpw][nkb][2][64] uint4, then 2 KB of slack
+    uint4 *tlds = mm8w_lds;                                                 // LDS offset 0 (the asm reads it by immediate offsets): [10][3] uint4: T_k, 9 digits + 3 pad
+    uint32_t *crl = reinterpret_cast<uint32_t *>(mm8w_lds + 32);            // [n_rt * 16][16]
+    uint4 *xbuf = mm8w_lds + 32 + n_rt * 64;                                // nbuf x [tpw][nkb][2][64] uint4, then 2 KB of slack
     const int bufsz = tpw * nkb * 2 * 64;
     int32_t *rowl = reinterpret_cast<int32_t *>(xbuf + (size_t)nbuf * bufsz + 128);   // [4 nkb] term -> input row
     int32_t *maskl = rowl + 4 * nkb;                                        // [16 n_rt] CHECK: 1 + row to compare with, or 0
@@ -110,9 +113,21 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         }
     };
     const int n_pairs = tpw * n_rt;
-    int32_t k1 = 1, k256 = 256, k64k = 1 << 16, k16m = 1 << 24;  // opaque, so that the word assembly stays one v_mad_i64_i32 per column
-    asm volatile("" : "+s"(k1), "+s"(k256), "+s"(k64k), "+s"(k16m));
+    const int32_t k256 = 256, k64k = 1 << 16, k16m = 1 << 24;
     const int64_t bias4 = (int64_t)bias * 0x01010101ll, bias3 = (int64_t)bias * 0x00010101ll;   // the accumulator bias of 4 (3) columns
+    const uint64_t wpa = (uint64_t)(uintptr_t)wpp;
+    // The sums of the pass before (17 words per output) and where they go: reduced, compared and stored INSIDE the next
+    // pass's MFMA phase (gen_mm8w.py).  mode: 0 nothing, 1 store to addr, 2 compare with the row at addr.
+    uint32_t w[4][17];
+    uint32_t crl_addr[4], mode[4];
+    uint64_t addr[4], flag = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int j = 0; j < 17; j++) w[r][j] = 0;
+        crl_addr[r] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)crl;
+        mode[r] = 0; addr[r] = 0;
+    }
     int buf = 0;
     int64_t unit = blockIdx.x;
 #ifdef HB_MM8_TIMING
@@ -128,165 +143,56 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         for (int pidx = wave; pidx < n_pairs; pidx += 4) {
             const int tl = pidx / n_rt, rt = pidx - tl * n_rt;
             const int64_t chunk = (unit * tpw + tl) * 16 + n;
-            v4i acc[MM8W_NC];
             {
                 uint32_t xa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(xbuf + (size_t)buf * bufsz + (size_t)tl * nkb * 2 * 64 + lane);
                 uint32_t va = (uint32_t)lane * 16u;
-                uint32_t cnt = (uint32_t)(nkb / 2 - 1);
+                uint32_t cnt = (uint32_t)(nkb / 2 - PEEL);       // pairs of term blocks that run as a loop between the peeled ones
                 const uint64_t abase = (uint64_t)(uintptr_t)(a8 + (size_t)rt * nkb * 2 * 64);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                mm8w_phase(acc, xa, va, cnt, abase);
+#define MM8W_ARGS w, xa, va, cnt, flag, abase, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
+                if constexpr (CHECK) {
+                    if constexpr (PEEL == 2) mm8w_pass_check_p2(MM8W_ARGS);
+                    else if constexpr (PEEL == 3) mm8w_pass_check_p3(MM8W_ARGS);
+                    else mm8w_pass_check_p4(MM8W_ARGS);
+                } else {
+                    if constexpr (PEEL == 2) mm8w_pass_p2(MM8W_ARGS);
+                    else if constexpr (PEEL == 3) mm8w_pass_p3(MM8W_ARGS);
+                    else mm8w_pass_p4(MM8W_ARGS);
+                }
+#undef MM8W_ARGS
                 __builtin_amdgcn_sched_barrier(0);
             }
-            MM8W_T(1);   // MFMA phase
-            // the next unit's tiles: requested here, behind the MFMA phase (whose waits on its digit loads are vmcnt(0))
-            // and ahead of the epilogue, which hides their latency
-            if (nbuf == 2 && !dma_issued) { if (next < n_units) issue_loads(next, buf ^ 1); dma_issued = true; }
-            MM8W_T(2);   // DMA issue
-            // the reduction constants come by scalar loads once per pass: kept across the MFMA phase they would spill
-            uint64_t wqa = (uint64_t)(uintptr_t)wpp;
-            asm volatile("" : "+s"(wqa));
-            const __attribute__((address_space(4))) WideParams *wq = (const __attribute__((address_space(4))) WideParams *)wqa;
-            // Two outputs at a time, STAGE by stage: one wave per SIMD has nothing but its own independent work to cover the
-            // 8-cycle dependent-issue latency of the carry / MAD chains, and an inline-asm statement per output (as in the
-            // first version) is a scheduling boundary that serialised the four reductions.
+            MM8W_T(1);   // MFMA phase + the reduction of the pass before + word assembly
+            // where this pass's outputs go (used by the next pass, or by the drain below)
 #pragma unroll
-            for (int rp = 0; rp < 4; rp += 2) {
-                if (16 * rt + 4 * rp >= n_out) break;                // whole outputs of padding rows (wave-uniform)
-                uint32_t ew[2][8];
-                bool cmp[2] = {false, false};
-                // S = sum_c (col_c + bias) 2^(8c): four SIGNED columns per 32-bit step go into one 64-bit accumulator that starts
-                // from bias (1 + 2^8 + 2^16 + 2^24) -- four v_mad_i64_i32, no per-column bias add -- then one add-with-carry per word
-                uint32_t w[2][MM8W_WORDS + 1];
-                {
-                    uint32_t hi_prev[2] = {0, 0};
-                    unsigned cy[2] = {0, 0};
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-#pragma unroll
-                        for (int o = 0; o < 2; o++) {
-                            const int reg = rp + o;
-                            int64_t a64 = (int64_t)acc[4 * j][reg] * k1 + (4 * j + 3 < MM8W_NC ? bias4 : bias3);
-                            a64 += (int64_t)acc[4 * j + 1][reg] * k256;
-                            a64 += (int64_t)acc[4 * j + 2][reg] * k64k;
-                            if (4 * j + 3 < MM8W_NC) a64 += (int64_t)acc[4 * j + 3][reg] * k16m;
-                            if (j == 0) w[o][0] = (uint32_t)a64;
-                            else w[o][j] = __builtin_addc((uint32_t)a64, hi_prev[o], cy[o], &cy[o]);
-                            hi_prev[o] = (uint32_t)((uint64_t)a64 >> 32);
-                        }
-                    }
-#pragma unroll
-                    for (int o = 0; o < 2; o++) { w[o][16] = hi_prev[o] + cy[o]; w[o][17] = 0; }
-                }
-                uint32_t sd[2][MM8W_SD];
-#pragma unroll
-                for (int k = 0; k < MM8W_SD; k++) {
-                    const int bit = LB * k, j = bit >> 5, sft = bit & 31;
-#pragma unroll
-                    for (int o = 0; o < 2; o++)
-                        sd[o][k] = (sft == 0 ? w[o][j] : __builtin_amdgcn_alignbit(w[o][j + 1], w[o][j], (uint32_t)sft)) & DMASK;
-                }
-                // V = S_lo + sum_{k >= 9} s_k T_k + row constant  <  2^261 + (9 2^29 + 2^7) p + p  <  2^290
-                uint64_t col[2][10];
-#pragma unroll
-                for (int o = 0; o < 2; o++) {
-                    const int i = 16 * rt + 4 * (rp + o) + g;
-                    const uint4 *cr = reinterpret_cast<const uint4 *>(crl + (size_t)i * 16);
-                    const uint4 c0v = cr[0], c1v = cr[1], c2v = cr[2];
-                    col[o][0] = (uint64_t)sd[o][0] + c0v.x; col[o][1] = (uint64_t)sd[o][1] + c0v.y; col[o][2] = (uint64_t)sd[o][2] + c0v.z; col[o][3] = (uint64_t)sd[o][3] + c0v.w;
-                    col[o][4] = (uint64_t)sd[o][4] + c1v.x; col[o][5] = (uint64_t)sd[o][5] + c1v.y; col[o][6] = (uint64_t)sd[o][6] + c1v.z; col[o][7] = (uint64_t)sd[o][7] + c1v.w;
-                    col[o][8] = (uint64_t)sd[o][8] + c2v.x; col[o][9] = 0;
-                }
-#pragma unroll
-                for (int k = 0; k < 10; k++) {
-                    const uint4 t0 = tlds[3 * k], t1 = tlds[3 * k + 1], t2 = tlds[3 * k + 2];
-#pragma unroll
-                    for (int o = 0; o < 2; o++) {
-                        const uint32_t sk = sd[o][9 + k];
-                        col[o][0] += (uint64_t)sk * t0.x; col[o][1] += (uint64_t)sk * t0.y; col[o][2] += (uint64_t)sk * t0.z; col[o][3] += (uint64_t)sk * t0.w;
-                        col[o][4] += (uint64_t)sk * t1.x; col[o][5] += (uint64_t)sk * t1.y; col[o][6] += (uint64_t)sk * t1.z; col[o][7] += (uint64_t)sk * t1.w;
-                        col[o][8] += (uint64_t)sk * t2.x;
-                    }
-                }
-                uint32_t v[2][10];
-#pragma unroll
-                for (int k = 0; k < 9; k++)
-#pragma unroll
-                    for (int o = 0; o < 2; o++) { v[o][k] = (uint32_t)col[o][k] & DMASK; col[o][k + 1] += col[o][k] >> LB; }
-                // the rows to compare with: requested once the fold has released its registers, used after the Barrett step
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * rt + 4 * r + g;
+                crl_addr[r] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(crl + (size_t)i * 16);
+                const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
                 if constexpr (CHECK) {
-#pragma unroll
-                    for (int o = 0; o < 2; o++) {
-                        const int erow = maskl[16 * rt + 4 * (rp + o) + g];
-                        cmp[o] = (chunk < n_chunks) && erow;
-                        if (cmp[o]) load_words<8>(ew[o], cmp_pk + (chunk * cmp_sc + (int64_t)(erow - 1) * cmp_sl) * 8);
-                    }
-                }
-                (void)ew; (void)cmp;
-                uint64_t dc[2][9];
-#pragma unroll
-                for (int o = 0; o < 2; o++) {
-                    v[o][9] = (uint32_t)col[o][9];                        // < 2^29
-                    // qhat = floor(floor(V / 2^232) mu / 2^58) is floor(V / p) or one less (V / 2^290 + 2^232 / p < 1)
-                    const uint64_t mid = (uint64_t)v[o][9] * wq->m0 + (uint64_t)v[o][8] * wq->m1 + (((uint64_t)v[o][8] * wq->m0) >> LB);
-                    const uint64_t qh = (uint64_t)v[o][9] * wq->m1 + (mid >> LB);
-                    const uint32_t q0 = (uint32_t)qh & DMASK, q1 = (uint32_t)(qh >> LB);
-#pragma unroll
-                    for (int k = 0; k < 9; k++) {
-                        dc[o][k] = v[o][k] + (uint64_t)q0 * wq->pbar[k];
-                        if (k > 0) dc[o][k] += (uint64_t)q1 * wq->pbar[k - 1];
-                    }
-                }
-                uint32_t r[2][9];
-#pragma unroll
-                for (int k = 0; k < 9; k++)
-#pragma unroll
-                    for (int o = 0; o < 2; o++) {
-                        r[o][k] = (uint32_t)dc[o][k] & DMASK;
-                        if (k < 8) dc[o][k + 1] += dc[o][k] >> LB;
-                    }
-                uint32_t ow[2][8];
-#pragma unroll
-                for (int o = 0; o < 2; o++) {
-                    pack<9, 8>(ow[o], r[o]);
-                    uint32_t u[8];
-                    unsigned cy2 = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; k++) u[k] = __builtin_addc(ow[o][k], wq->pneg[k], cy2, &cy2);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) ow[o][k] = cy2 ? u[k] : ow[o][k];
-                }
-                if constexpr (CHECK) {
-#pragma unroll
-                    for (int o = 0; o < 2; o++)
-                        if (cmp[o]) {
-                            uint32_t diff = 0;
-#pragma unroll
-                            for (int k = 0; k < 8; k++) diff |= ew[o][k] ^ ow[o][k];
-                            if (diff) atomicOr(mismatch, 1);
-                        }
-                    // the rows of a fused decode + validate that are results, not predictions
-                    if (n_store > 0) {
-#pragma unroll
-                        for (int o = 0; o < 2; o++) {
-                            const int i = 16 * rt + 4 * (rp + o) + g;
-                            const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
-                            if (chunk < n_chunks && i < n_store && !maskl[i] && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow[o]);
-                        }
+                    const int erow = maskl[i];
+                    const bool live = chunk < n_chunks && i < n_out;
+                    if (live && erow) {
+                        mode[r] = 2;
+                        addr[r] = (uint64_t)(uintptr_t)(cmp_pk + (chunk * cmp_sc + (int64_t)(erow - 1) * cmp_sl) * 8);
+                    } else if (live && i < n_store && oidx < out_count) {
+                        mode[r] = 1;
+                        addr[r] = (uint64_t)(uintptr_t)(out_pk + oidx * 8);
+                    } else {
+                        mode[r] = 0;
+                        addr[r] = 0;
                     }
                 } else {
-                    asm volatile("" ::"v"(ow[0][0]), "v"(ow[0][1]), "v"(ow[0][2]), "v"(ow[0][3]), "v"(ow[0][4]), "v"(ow[0][5]), "v"(ow[0][6]), "v"(ow[0][7]),
-                                 "v"(ow[1][0]), "v"(ow[1][1]), "v"(ow[1][2]), "v"(ow[1][3]), "v"(ow[1][4]), "v"(ow[1][5]), "v"(ow[1][6]), "v"(ow[1][7]));
-#pragma unroll
-                    for (int o = 0; o < 2; o++) {
-                        const int i = 16 * rt + 4 * (rp + o) + g;
-                        const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
-                        if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow[o]);
-                    }
+                    const bool st = chunk < n_chunks && i < n_out && oidx < out_count;
+                    mode[r] = st ? 1 : 0;
+                    addr[r] = st ? (uint64_t)(uintptr_t)(out_pk + oidx * 8) : 0;
                 }
             }
-            MM8W_T(3);   // epilogue
+            MM8W_T(3);   // bookkeeping
+            // the next unit's tiles: requested here, behind the MFMA phase (whose waits on its digit loads are vmcnt(0))
+            if (nbuf == 2 && !dma_issued) { if (next < n_units) issue_loads(next, buf ^ 1); dma_issued = true; }
+            MM8W_T(2);   // DMA issue
         }
         if (nbuf == 2 && !dma_issued && next < n_units) issue_loads(next, buf ^ 1);   // a wave without a pair still owns DMA slots
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -301,6 +207,17 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             buf ^= 1;
         }
         MM8W_T(6);   // single-buffer reload
+    }
+    // drain: the last pass's sums
+    {
+        uint32_t xa = 0, va = 0, cnt = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (CHECK) mm8w_reduce_check(w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode);
+        else mm8w_reduce(w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (CHECK) {
+        if (flag != 0 && lane == 0) atomicOr(mismatch, 1);
     }
 #ifdef HB_MM8_TIMING
     if (lane == 0 && blockIdx.x < 256) for (int k = 0; k < 8; k++) g_mm8w_t[(blockIdx.x * 4 + wave) * 8 + k] = tacc[k];
@@ -416,7 +333,7 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE")) return HB_ERR_UNSUPPORTED;
     if (ctx->n_limbs != 4 || n_out < 1 || n_in < 1) return HB_ERR_UNSUPPORTED;
     if (!prescale_params(ctx)) return HB_ERR_UNSUPPORTED;              // 2^254 <= p < 2^256
-    const int d = n_in, nkb = 2 * ((d + 7) / 8), n_rt = (n_out + 15) / 16;
+    const int d = n_in, nkb = std::max(4, 2 * ((d + 7) / 8)), n_rt = (n_out + 15) / 16;   // two peeled pairs of term blocks at least
     int tpw = 0, nbuf = 0;
     if (!mm8w_shape(n_rt, nkb, 1, 1, &tpw, &nbuf)) return HB_ERR_UNSUPPORTED;
     const Big p = big_from_limbs(ctx->p_limbs, 4);
@@ -468,6 +385,7 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     Mm8wMatrix *m = new Mm8wMatrix();
     m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr; m->bias = bias; m->wp = nullptr;
     WideParams wph;
+    memset(&wph, 0, sizeof wph);
     for (int k = 0; k < 10; k++) to_digits(big_mod(big_pow2(29 * (9 + k), 18), p), wph.T[k], 9);
     memcpy(wph.pbar, ctx->psc.pbar, sizeof wph.pbar);
     memcpy(wph.pneg, ctx->psc.pneg, sizeof wph.pneg);
@@ -506,19 +424,22 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
     if (blocks > n_units) blocks = n_units;
     const size_t lds = mm8w_lds_bytes(m->n_rt, m->nkb, tpw, nbuf);
     const bool check = check_mask_dev != nullptr;
-#define MM8W_LAUNCH(CHK)                                                                                                              \
+#define MM8W_LAUNCH(CHK, PL)                                                                                                          \
     do {                                                                                                                              \
         static bool attr_done = false;                                                                                                \
         if (!attr_done) {                                                                                                             \
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_done = true;                                                                                                         \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_mm8w<CHK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
+        hipLaunchKernelGGL((k_mm8w<CHK, PL>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
                            m->n_out, m->n_rt, m->nkb, tpw, nbuf, C, n_units, m->bias, m->wp);                                        \
     } while (0)
-    if (check) MM8W_LAUNCH(true); else MM8W_LAUNCH(false);
+    // pairs of term blocks written out with a share of the reduction each (gen_mm8w.py): all of them up to four
+    const int peel = std::min(m->nkb / 2, 4);
+    if (check) { if (peel == 2) MM8W_LAUNCH(true, 2); else if (peel == 3) MM8W_LAUNCH(true, 3); else MM8W_LAUNCH(true, 4); }
+    else { if (peel == 2) MM8W_LAUNCH(false, 2); else if (peel == 3) MM8W_LAUNCH(false, 3); else MM8W_LAUNCH(false, 4); }
 #undef MM8W_LAUNCH
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;

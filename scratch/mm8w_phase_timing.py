@@ -5,7 +5,7 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 from honeybadgermpc_amd._capi import Context, HbView, np_ptr
 P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
-NAMES = ["prologue", "MFMA phase", "DMA issue", "epilogues", "vmcnt wait", "barrier", "reload", "-"]
+NAMES = ["prologue", "asm pass", "DMA issue", "bookkeeping", "vmcnt wait", "barrier", "reload", "-"]
 ctx = Context.get(P); lib = ctx.lib
 rnd = random.Random(3)
 g = torch.Generator(device='cuda'); g.manual_seed(1)
