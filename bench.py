@@ -584,6 +584,27 @@ def main():
         step()
         assert op.ok()
 
+    # ---- secondary (untimed for `value`): the fused decode + validate asked for on a small-entry plan -----
+    # The headline validates like the reference (re-encode all n points on its own kernels); on request the plan also
+    # builds [Vinv rows ; V[zc] Vinv] for the full-size kernel and decodes + compares in one launch.
+    dt_fused_optin = None
+    if dt_unfused is None and mfma:
+        op.set_fused_validate(True)
+        if op.uses_fused_validate():
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            ok6 = op.ok()
+            torch.cuda.synchronize()
+            dt_fused_optin = time.perf_counter() - t1
+            assert ok6 and torch.equal(result, secrets)
+        op.set_fused_validate(False)
+        step()
+        assert op.ok()
+
     # ---- secondary (untimed for `value`): two independent opens in flight ------------------------
     # A party opens many share arrays concurrently (Mpc.open_share_array under asyncio); with a second plan
     # on a second stream consecutive opens overlap (kernel tails, the elementwise pass, and co-resident
@@ -683,6 +704,7 @@ def main():
                 "fused_decode_validate_note": "full-size matrix entries (omega-power points): each decode launch also produces the guess's values at the "
                                               "compared points as (V[zc] Vinv) y and compares them (HB_OPEN_OPT_FUSED_VALIDATE, default on where it applies; "
                                               "same results, same accept/reject); three_full_encodes = the option off: decode, re-encode all n points, compare",
+                "shares_per_s_per_gpu_fused_validate_on_request": (B * args.steps / dt_fused_optin) if dt_fused_optin else None,
                 "shares_per_s_per_gpu_two_opens_in_flight": (B * args.steps / dt_two) if dt_two else None,
                 "two_opens_in_flight_note": "same opens issued alternately on two streams with two plans (independent batches overlap); "
                                             "`value` is one open at a time on one stream",

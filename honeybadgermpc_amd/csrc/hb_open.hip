@@ -32,6 +32,8 @@ struct hb_open_plan {
     Mm8Matrix *Vzc8;     // rows zc of V only: the validating re-encode under HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY (built on demand)
     int32_t *zc_dev, *ones_dev;   // its expected-row map and compare mask
     std::vector<int32_t> zc;
+    std::vector<int32_t> z;            // the arrival set and the points: kept for tables built on request (set_option)
+    std::vector<uint64_t> x;
     Mm8Matrix *Vinv8;    // same for the numerators N of the factored inverse (decode on the matrix cores); may be nullptr
     uint32_t *scaled_pk; // [d][max_C] received columns / den_j, the matrix-core decode's input
     int use_v8;          // option HB_OPEN_OPT_MATRIX_CORES (default 1)
@@ -139,6 +141,8 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         if (rc) goto done;
     }
     rc = own_int_array(ctx, z_host, d, &pl->z_dev, s); if (rc) goto done;
+    pl->z.assign(z_host, z_host + d);
+    pl->x.assign(x_host, x_host + (size_t)n * L);
     {
         std::vector<int32_t> mask((size_t)n + 1, 0);
         mask[n] = -1;
@@ -335,7 +339,24 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
         return HB_OK;
     }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { pl->use_v8 = value ? 1 : 0; return HB_OK; }
-    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { pl->use_fused = value ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_FUSED_VALIDATE) {
+        pl->use_fused = value ? 1 : 0;
+        if (value && !pl->F1 && pl->d >= 4 && pl->n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
+            // a plan whose entries are small integers validates with its own kernels by default; asked to, it builds the
+            // full inverse and the fused matrices too (UNSUPPORTED shapes stay as they are)
+            hb_ctx *ctx = pl->ctx;
+            const int L = ctx->n_limbs;
+            if (!pl->Winv) {
+                std::vector<uint64_t> xz((size_t)pl->d * L);
+                for (int i = 0; i < pl->d; i++) memcpy(&xz[(size_t)i * L], &pl->x[(size_t)pl->z[i] * L], (size_t)L * 8);
+                int rc = hb_vand_inverse_create(ctx, xz.data(), pl->d, &pl->Winv, nullptr);
+                if (rc) return rc;
+                pl->Winv8 = matrix_wide(ctx, pl->Winv, 0);
+            }
+            if (pl->Winv8) { int rc = build_fused(pl, pl->x.data(), 0); if (rc) return rc; }
+        }
+        return HB_OK;
+    }
     return HB_ERR_BAD_ARG;
 }
 
