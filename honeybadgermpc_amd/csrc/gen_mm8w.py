@@ -23,9 +23,9 @@ between its own MFMAs: outputs 0, 1 inside the first pair of term blocks, output
 the pairs between them are a loop, so the code does not grow with the inner dimension).  After its last pass a wave
 runs the reduction alone (mm8w_reduce).
 
-Register files (VGPRs the statement owns: v124 .. v255): v190.. the MFMA operand files of the first version (two EA sets
+Register files (VGPRs the statement owns: v122 .. v255): v190.. the MFMA operand files of the first version (two EA sets
 for even q, EB one register apart for odd q, the next group's shifts built while the current group's MFMAs issue, element
-prefetch XB, digit buffers ABUF); v124 .. v189 the reduction (ten 64-bit columns, two buffers for the T_k rows, the packed
+prefetch XB, digit buffers ABUF); v122 .. v189 the reduction (ten 64-bit columns, two buffers for the T_k rows, the packed
 result, the row to compare with).  SGPRs s68 .. s89: the Barrett constants (scalar loads from WideParams), a saved exec.
 
 Reduction of one output (the arithmetic of k_prescale_tab / the first version's C++ epilogue, same bounds):
@@ -37,7 +37,7 @@ import os
 
 NC = 63
 NWORDS = 17
-RB = 124                       # first register the statement owns
+RB = 122                       # first register the statement owns
 # ---- MFMA operand files ----
 XB = 190                       # 8 dwords: LDS prefetch of the next term block's element
 ABUF = [[198, 202], [206, 210]]  # [term block parity][digit group]: 4 dwords each
@@ -45,18 +45,19 @@ EA_SETS = [214, 228]           # 14 registers each, k = -4 .. 9
 EA_KMIN = -4
 EB0, EB_KMIN = 242, -3         # 14 registers, k = -3 .. 10
 RHOS = (0, 1, 2, 3)
-# ---- reduction file ----
-C0 = 124                       # ten 64-bit columns: C0 + 2j (low), + 1 (high)
-TB = [144, 156, 176]           # three buffers for the T_k rows / the row constant (9 digits; the first two padded to 12)
-OW = 168                       # packed result, 8 words
-EX = 176                       # row to compare with, 8 words: the third T buffer once the fold is done with it
-SK, T1, T2, ZERO = 189, 185, 186, 188   # T2 is a pair
-QP, Q0, Q1 = 144, 146, 147     # Barrett quotient (the T buffers are free by then)
-UB = 124                       # ow + (2^256 - p): the columns are free by then
-DIFF = 144
+# ---- reduction file (v122 .. v189) ----
+C0 = 122                       # ten 64-bit columns: C0 + 2j (low), + 1 (high)
+TB = [142, 152, 162]           # three buffers of nine for the T_k rows / the row constant (even bases: 128-bit LDS reads)
+T1, SK, ZERO = 151, 161, 171
+OW = 172                       # packed result, 8 words
+EX = 180                       # row to compare with, 8 words (requested when the output's reduction starts)
+T2 = 188                       # pair
+QP, Q0, Q1 = 142, 144, 145     # Barrett quotient (the T buffers are free by then)
+UB = 122                       # ow + (2^256 - p): the columns are free by then
+DIFF = 142
 # ---- tail (word assembly) ----
-TL_TMP = [[124, 125, 126, 127], [128, 129, 130, 131]]
-TL_T = [[132, 134, 136, 138], [140, 142, 144, 146]]
+TL_TMP = [[122, 123, 124, 125], [126, 127, 128, 129]]
+TL_T = [[130, 132, 134, 136], [138, 140, 142, 144]]
 # ---- SGPRs ----
 S_PBAR, S_PNEG, S_M0, S_M1 = 68, 77, 85, 86    # WideParams: pbar[9] pneg[8] m0 m1 pad, loaded to s68 .. s87
 S_SAVE = 88                    # saved exec, pair
@@ -189,18 +190,18 @@ def pair(kind, o):
     The odd block of the LAST pair must not prefetch: nothing waits for a load issued there, and one that lands after the
     asm statement would overwrite registers the compiler has taken back (it did, once per ~10^4 launches, when L2 was cold)."""
     L = []
-    seen = set() if kind == "first" else None
+    seen = set() if kind in ("first", "only") else None
     for gi in range(8):
         par = gi // 4
         if gi % 4 == 0:
             # the digits of this block were requested one block ago; every MFMA reading the other buffer has been issued
             L.append("s_waitcnt vmcnt(0)")
-            if not (gi == 4 and kind == "last"):
+            if not (gi == 4 and kind in ("last", "only")):
                 L += loads(1 - par, o)
         L += interleave(mfmas(gi, 1, par, seen), prep_a(gi + 1))
         L += interleave(mfmas(gi, 0, par, seen), prep_b(gi + 1))
         L.append("s_nop 0")
-    if kind == "first":
+    if seen is not None:
         assert seen == set(range(NC))
     return L
 
@@ -255,6 +256,10 @@ def reduce_output(o, r, check):
     """units (lists of lines) reducing output r's 17 words and storing / comparing the canonical element"""
     U = []
     one = lambda ln: U.append([ln])  # noqa: E731
+    if check:
+        # the received row: from HBM, a microsecond away -- requested first, compared last
+        U += masked(o, r, 2, ["@ELOAD", f"global_load_dwordx4 v[{EX}:{EX + 3}], {o(f'ADDR{r}')}, off",
+                              f"global_load_dwordx4 v[{EX + 4}:{EX + 7}], {o(f'ADDR{r}')}, off offset:16"])
     # per-row constant -> TB[2], T_9 -> TB[0], T_10 -> TB[1]; the rows are requested THREE steps ahead of their use: one wave
     # per SIMD has only its own instructions (and the MFMAs between them) to cover the LDS latency
     for ln in row_reads(o(f"CRL{r}"), 0, 2) + t_reads(0) + t_reads(1):
@@ -280,10 +285,6 @@ def reduce_output(o, r, check):
         if k + 3 < 10:
             for ln in t_reads(k + 3):
                 one(ln)
-        if check and k == 8:
-            # the row to compare with lands in the third T buffer, which the fold has just left
-            U += masked(o, r, 2, [f"global_load_dwordx4 v[{EX}:{EX + 3}], {o(f'ADDR{r}')}, off",
-                                  f"global_load_dwordx4 v[{EX + 4}:{EX + 7}], {o(f'ADDR{r}')}, off offset:16"])
     for ln in carry(9):
         one(ln)
     v8, v9 = C0 + 16, C0 + 18
@@ -322,7 +323,7 @@ def reduce_output(o, r, check):
         cs.append(f"v_cndmask_b32_e32 v{OW + j}, v{OW + j}, v{UB + j}, vcc")
     U.append(cs)
     if check:
-        cmp = ["s_waitcnt vmcnt(0)"]
+        cmp = ["@EWAIT"]
         for j in range(8):
             cmp.append(f"v_xor_b32 v{DIFF + j}, v{EX + j}, v{OW + j}")
         cmp += [f"v_or3_b32 v{DIFF}, v{DIFF}, v{DIFF + 1}, v{DIFF + 2}",
@@ -356,6 +357,33 @@ def merge(stream, units):
                 out += units[done]
                 done += 1
     assert done == len(units)
+    return out
+
+
+def resolve_waits(lines):
+    """@ELOAD marks the two loads of the row to compare with, @EWAIT the point where they must have landed.  Vector memory
+    operations return in order, so the wait is vmcnt(number issued since) -- a plain vmcnt(0) would also wait for the next term
+    block's digits, requested a few instructions earlier (that cost 10 % of a CHECK pass).  Anything the walk cannot count
+    (a label or a branch in between) falls back to vmcnt(0)."""
+    out = []
+    since = None            # VMEM operations issued after the marked loads; None = unknown
+    for ln in lines:
+        if ln == "@ELOAD":
+            since = -2       # the two loads themselves follow
+            continue
+        if ln == "@EWAIT":
+            out.append(f"s_waitcnt vmcnt({since})" if since is not None and 0 <= since <= 15 else "s_waitcnt vmcnt(0)")
+            since = None
+            continue
+        out.append(ln)
+        if ln.startswith(".L") or ln.startswith("s_cbranch"):
+            since = None
+        elif ln.startswith("global_load") or ln.startswith("global_store"):
+            if since is not None:
+                since += 1
+        elif ln.startswith("s_waitcnt vmcnt(0)"):
+            if since is not None and since >= 0:
+                since = 0    # everything landed; later operations are counted from here (the wait then allows all of them)
     return out
 
 
@@ -430,12 +458,12 @@ def pass_lines(check, peel):
             L += pair("mid", o)
             L += [f"s_sub_u32 {o('CNT')}, {o('CNT')}, 1", f"s_cmp_lg_u32 {o('CNT')}, 0", "s_cbranch_scc1 .Lmm8w_loop_%="]
             L.append(".Lmm8w_rest_%=:")
-        kind = "first" if i == 0 else ("last" if i == peel - 1 else "mid")
+        kind = "only" if peel == 1 else ("first" if i == 0 else ("last" if i == peel - 1 else "mid"))
         L += merge(pair(kind, o), shares[i])
     L += ["s_nop 7", "s_nop 7"]
     if "notail" not in ABLATE:
         L += tail(o)
-    return o, L
+    return o, resolve_waits(L)
 
 
 def reduce_lines(check):
@@ -444,7 +472,7 @@ def reduce_lines(check):
     for r in range(4):
         for u in reduce_output(o, r, check):
             L += u
-    return o, L
+    return o, resolve_waits(L)
 
 
 def emit_fn(name, o, lines, check):
@@ -467,7 +495,7 @@ def emit_fn(name, o, lines, check):
     return out
 
 
-PEELS = (2, 3, 4)
+PEELS = (1, 2, 3, 4)
 
 
 def emit():

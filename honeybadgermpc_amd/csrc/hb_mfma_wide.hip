@@ -9,15 +9,18 @@
 //   * Vandermonde matrices at the points 1..n whose powers outgrow 2^127 (n = 100, t = 33: 100^33 > 2^219);
 //   * arbitrary hb_matrix operands (hb_matvec), the interpolant of gao_interpolate (rsdecode_impl.h:281-405).
 // hb_mfma.hip covers the small-entry case (16 digits, 47 columns, VALU-bound by its reduction); here the
-// entries have 32 base-256 digits, the sum has 63 int32 columns, and the kernel is matrix-pipe bound:
-// 94 v_mfma_i32_16x16x64_i8 per block of 4 terms and 16 x 16 outputs (gen_mm8w.py emits that phase).
+// entries have 32 base-256 digits and the sum has 63 int32 columns: 94 v_mfma_i32_16x16x64_i8 per block of 4 terms
+// and 16 x 16 outputs.
 //
-// One wave per SIMD (512-register budget): all 63 accumulators of a 16-chunk x 16-row pass live in AGPRs.
+// One wave per SIMD (512-register budget): all 63 accumulators of a 16-chunk x 16-row pass live in AGPRs a0..a251.
 // A workgroup owns a unit of `tpw` tiles of 16 chunks, DMA'd into LDS in MFMA-operand order; its 4 waves take the
-// (tile, row tile) pairs.  The digits stream from L2 inside the MFMA phase.  Epilogue per output (VALU):
-// 63 columns + bias -> 16 base-2^32 groups (3 v_mad_u64_u32 each) -> 17 words -> 19 radix-2^29 digits ->
-// fold the ten high digits through T_k = 2^(29k) mod p (90 MADs) + per-row constant -> two-digit Barrett quotient
-// (as k_prescale_tab, hb_fast.hip) -> conditional subtraction -> packed canonical element.
+// (tile, row tile) pairs.  The digits stream from L2 inside the MFMA phase.
+// A pass is ONE asm statement (gen_mm8w.py), software-pipelined over passes: it ends by moving its sums out of the
+// AGPRs as 17 words per output, and the NEXT pass reduces them mod p between its own MFMAs -- 19 radix-2^29 digits,
+// fold of the ten high digits through T_k = 2^(29k) mod p (90 MADs) + per-row constant, two-digit Barrett quotient (as
+// k_prescale_tab, hb_fast.hip), conditional subtraction -- and stores the canonical element or compares it with a
+// received one (the fused decode + validate of hb_open.hip).  A wave alone on its SIMD issues one instruction every
+// ~5.5 cycles whatever its kind, so every instruction taken out of the serial part of a pass counts.
 // Inputs are biased by XOR 0x80 (int8 operands are signed); the per-row constant takes that and the accumulator
 // bias back out, mod p.  No Montgomery form anywhere.
 #include <algorithm>
@@ -79,15 +82,15 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     uint32_t *crl = reinterpret_cast<uint32_t *>(mm8w_lds + 32);            // [n_rt * 16][16]
     uint4 *xbuf = mm8w_lds + 32 + n_rt * 64;                                // nbuf x [tpw][nkb][2][64] uint4, then 2 KB of slack
     const int bufsz = tpw * nkb * 2 * 64;
-    int32_t *rowl = reinterpret_cast<int32_t *>(xbuf + (size_t)nbuf * bufsz + 128);   // [4 nkb] term -> input row
-    int32_t *maskl = rowl + 4 * nkb;                                        // [16 n_rt] CHECK: 1 + row to compare with, or 0
+    int64_t *rowoff = reinterpret_cast<int64_t *>(xbuf + (size_t)nbuf * bufsz + 128);   // [4 nkb] term -> element offset of its input row
+    int32_t *maskl = reinterpret_cast<int32_t *>(rowoff + 4 * nkb);         // [16 n_rt] CHECK: 1 + row to compare with, or 0
     if (threadIdx.x < 120) {
         const int k = threadIdx.x / 12, j = threadIdx.x % 12;
         reinterpret_cast<uint32_t *>(tlds)[threadIdx.x] = j < 9 ? wpp->T[k][j] : 0u;
     }
     for (int l = threadIdx.x; l < 4 * nkb; l += 256) {
         const int lc = l < d ? l : d - 1;
-        rowl[l] = in_rows ? in_rows[lc] : lc;
+        rowoff[l] = (int64_t)(in_rows ? in_rows[lc] : lc) * in_sl;
     }
     for (int i = threadIdx.x; i < n_rt * 16 * 16; i += 256) crl[i] = crowd[i];
     if constexpr (CHECK) {
@@ -95,21 +98,28 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = i < n_out ? (mask_is_map ? check_mask[i] : (check_mask[i] ? i + 1 : 0)) : 0;
     }
     __syncthreads();
-    const int n_slots = tpw * nkb * 2;
-    // slot s = (t * nkb + kb) * 2 + h holds half h of element (chunk n, term 4 kb + g) of tile t for lane (n, g)
+    // slot s = (t * nkb + kb) * 2 + h holds half h of element (chunk n, term 4 kb + g) of tile t for lane (n, g).  2 nkb is a
+    // multiple of 4, so a wave always moves the same half (h = wave & 1) of every second term block: per slot a 64-bit LDS read
+    // (the row's offset), an add, a bound and the DMA -- this loop is ~10 % of a short pass otherwise (one wave per SIMD pays
+    // ~5.5 cycles for every instruction)
     auto issue_loads = [&](int64_t unit, int buf) {
-        for (int s = wave; s < n_slots; s += 4) {
-            const int h = s & 1, q = s >> 1, t = q / nkb, kb = q - t * nkb;
+        const int h = wave & 1;
+        const uint4 *base = reinterpret_cast<const uint4 *>(in_pk) + h;
+        const uint4 *zsrc = reinterpret_cast<const uint4 *>(zero_src) + h;
+        for (int t = 0; t < tpw; t++) {
             int64_t chunk = (unit * tpw + t) * 16 + n;
             if (chunk >= n_chunks) chunk = n_chunks - 1;
-            const int64_t idx = chunk * in_sc + (int64_t)rowl[4 * kb + g] * in_sl;
-            const uint4 *src = (idx < in_count) ? reinterpret_cast<const uint4 *>(in_pk) + idx * 2 + h
-                                                : reinterpret_cast<const uint4 *>(zero_src) + h;
-            const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
-                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(xbuf + (size_t)buf * bufsz + s * 64));
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+            const int64_t cbase = chunk * in_sc;
+            for (int kb = wave >> 1; kb < nkb; kb += 2) {
+                const int64_t idx = cbase + rowoff[4 * kb + g];
+                const uint4 *src = (idx < in_count) ? base + idx * 2 : zsrc;
+                const int s = (t * nkb + kb) * 2 + h;
+                const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(xbuf + (size_t)buf * bufsz + s * 64));
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+            }
         }
     };
     const int n_pairs = tpw * n_rt;
@@ -152,11 +162,13 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                 __builtin_amdgcn_sched_barrier(0);
 #define MM8W_ARGS w, xa, va, cnt, flag, abase, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
                 if constexpr (CHECK) {
-                    if constexpr (PEEL == 2) mm8w_pass_check_p2(MM8W_ARGS);
+                    if constexpr (PEEL == 1) mm8w_pass_check_p1(MM8W_ARGS);
+                    else if constexpr (PEEL == 2) mm8w_pass_check_p2(MM8W_ARGS);
                     else if constexpr (PEEL == 3) mm8w_pass_check_p3(MM8W_ARGS);
                     else mm8w_pass_check_p4(MM8W_ARGS);
                 } else {
-                    if constexpr (PEEL == 2) mm8w_pass_p2(MM8W_ARGS);
+                    if constexpr (PEEL == 1) mm8w_pass_p1(MM8W_ARGS);
+                    else if constexpr (PEEL == 2) mm8w_pass_p2(MM8W_ARGS);
                     else if constexpr (PEEL == 3) mm8w_pass_p3(MM8W_ARGS);
                     else mm8w_pass_p4(MM8W_ARGS);
                 }
@@ -280,7 +292,7 @@ void to_digits(const Big &v, uint32_t *dg, int nd) {
 }
 
 size_t mm8w_lds_bytes(int n_rt, int nkb, int tpw, int nbuf) {
-    return ((size_t)n_rt * 64 + (size_t)nbuf * tpw * nkb * 2 * 64 + 128 + 32) * 16 + (size_t)(4 * nkb + 16 * n_rt) * 4;
+    return ((size_t)n_rt * 64 + (size_t)nbuf * tpw * nkb * 2 * 64 + 128 + 32) * 16 + (size_t)(8 * nkb + 16 * n_rt) * 4;
 }
 constexpr size_t MM8W_LDS_LIMIT = 156 * 1024;
 
@@ -333,7 +345,7 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE")) return HB_ERR_UNSUPPORTED;
     if (ctx->n_limbs != 4 || n_out < 1 || n_in < 1) return HB_ERR_UNSUPPORTED;
     if (!prescale_params(ctx)) return HB_ERR_UNSUPPORTED;              // 2^254 <= p < 2^256
-    const int d = n_in, nkb = std::max(4, 2 * ((d + 7) / 8)), n_rt = (n_out + 15) / 16;   // two peeled pairs of term blocks at least
+    const int d = n_in, nkb = 2 * ((d + 7) / 8), n_rt = (n_out + 15) / 16;
     int tpw = 0, nbuf = 0;
     if (!mm8w_shape(n_rt, nkb, 1, 1, &tpw, &nbuf)) return HB_ERR_UNSUPPORTED;
     const Big p = big_from_limbs(ctx->p_limbs, 4);
@@ -438,8 +450,8 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
     } while (0)
     // pairs of term blocks written out with a share of the reduction each (gen_mm8w.py): all of them up to four
     const int peel = std::min(m->nkb / 2, 4);
-    if (check) { if (peel == 2) MM8W_LAUNCH(true, 2); else if (peel == 3) MM8W_LAUNCH(true, 3); else MM8W_LAUNCH(true, 4); }
-    else { if (peel == 2) MM8W_LAUNCH(false, 2); else if (peel == 3) MM8W_LAUNCH(false, 3); else MM8W_LAUNCH(false, 4); }
+    if (check) { if (peel == 1) MM8W_LAUNCH(true, 1); else if (peel == 2) MM8W_LAUNCH(true, 2); else if (peel == 3) MM8W_LAUNCH(true, 3); else MM8W_LAUNCH(true, 4); }
+    else { if (peel == 1) MM8W_LAUNCH(false, 1); else if (peel == 2) MM8W_LAUNCH(false, 2); else if (peel == 3) MM8W_LAUNCH(false, 3); else MM8W_LAUNCH(false, 4); }
 #undef MM8W_LAUNCH
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;

@@ -29,6 +29,11 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/c5_pmc_$name" -o p -- python bench.py --workload cfg5-shard --steps 3 --warmup 1 --cpu-sample 0 --no-two-streams-extra > "$OUT/c5_pmc_$name.log" 2>&1
 done
 python profiles/summarize_pmc.py "$OUT"/c5_pmc_* > "$OUT/pmc_summary_cfg5-shard.txt" 2>&1
+for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
+  name=$(echo "$pass" | cut -d' ' -f1)
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/c3o_pmc_$name" -o p -- python bench.py --workload cfg3-omega --steps 3 --warmup 1 --cpu-sample 0 --no-two-streams-extra > "$OUT/c3o_pmc_$name.log" 2>&1
+done
+python profiles/summarize_pmc.py "$OUT"/c3o_pmc_* > "$OUT/pmc_summary_cfg3-omega.txt" 2>&1
 python scratch/bench_robust.py 262144 > "$OUT/robust_cfg4.txt" 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/c4_pmc_$pass" -o p -- python scratch/bench_robust.py 16384 > "$OUT/c4_pmc_$pass.log" 2>&1
@@ -36,4 +41,6 @@ done
 python profiles/summarize_pmc.py "$OUT"/c4_pmc_* > "$OUT/pmc_summary_cfg4.txt" 2>&1
 python scratch/bench_device_decoder.py > "$OUT/device_decoder.txt" 2>&1
 python scratch/bench_coalescer.py > "$OUT/coalescer.txt" 2>&1
+python scratch/boundary_rates.py > "$OUT/boundary_rates.txt" 2>&1
+if [ -f honeybadgermpc_amd/lib/libhbmpc_hip_timing.so ]; then HBMPC_HIP_LIB=honeybadgermpc_amd/lib/libhbmpc_hip_timing.so python scratch/mm8w_phase_timing.py > "$OUT/mm8w_phase_timing.txt" 2>&1; fi
 tail -1 "$OUT/bench_default.json" | cut -c1-300

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel averages of rocprofv3 --pmc passes (csv output).  Usage:
     python profiles/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
-Kernels are keyed by short name + grid; every counter found in the given directories is averaged over the
-launches of that kernel.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB units; gfx950 FETCH_SIZE
+Kernels are keyed by short name + grid, and launches of one kernel whose written bytes / instruction counts differ (two
+significant digits) are separate rows (the fused R1 / R2 decodes of an open, the input generator): launch i of one pass is
+matched with launch i of the others.  Every counter found in the given directories is averaged over the launches of a row.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB units; gfx950 FETCH_SIZE
 reports half of a wide coalesced read: MI355X_MICROARCH.md, HBM section)."""
 import csv
 import glob
@@ -18,22 +19,54 @@ def short(name):
     return name if len(name) < 60 else name[:57] + "..."
 
 
+def sig2(v):
+    """two significant digits: launches of one kernel with different shapes differ by more than that"""
+    if v == 0:
+        return 0
+    import math
+    e = int(math.floor(math.log10(abs(v)))) - 1
+    return int(round(v / 10 ** e)) * 10 ** e
+
+
 def main(dirs):
-    acc = defaultdict(lambda: defaultdict(list))
+    # per (kernel, grid): one list of launches per pass, in dispatch order -- the benchmark is deterministic, so launch i of
+    # one pass is launch i of another
+    passes = defaultdict(list)
     for d in dirs:
         for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-            per_dispatch = defaultdict(float)
+            per_dispatch = defaultdict(lambda: defaultdict(float))
             meta = {}
             for row in csv.DictReader(open(path)):
-                key = (row["Dispatch_Id"], row["Counter_Name"])
-                per_dispatch[key] += float(row["Counter_Value"])
-                meta[row["Dispatch_Id"]] = (short(row["Kernel_Name"]), int(row["Grid_Size"]))
-            for (disp, ctr), v in per_dispatch.items():
-                acc[meta[disp]][ctr].append(v)
+                disp = int(row["Dispatch_Id"])
+                per_dispatch[disp][row["Counter_Name"]] += float(row["Counter_Value"])
+                meta[disp] = (short(row["Kernel_Name"]), int(row["Grid_Size"]))
+            by_kernel = defaultdict(list)
+            for disp in sorted(per_dispatch):
+                by_kernel[meta[disp]].append(dict(per_dispatch[disp]))
+            for k, launches in by_kernel.items():
+                passes[k].append(launches)
+    acc = defaultdict(lambda: defaultdict(list))
+    for k, plist in passes.items():
+        n = len(plist[0])
+        if all(len(p) == n for p in plist):
+            merged = [dict() for _ in range(n)]
+            for p in plist:
+                for i, l in enumerate(p):
+                    merged[i].update(l)
+            for l in merged:
+                # same kernel, different shapes (the fused R1 / R2 decodes of an open, the input generator): separate rows
+                shape = tuple(sig2(l[c]) for c in ("WRITE_SIZE", "SQ_INSTS_VALU") if c in l)
+                for c, v in l.items():
+                    acc[k + (shape,)][c].append(v)
+        else:
+            for p in plist:
+                for l in p:
+                    for c, v in l.items():
+                        acc[k + ((),)][c].append(v)
     keep = [k for k in acc if any(s in k[0] for s in ("k_mm8", "k_prescale", "k_matvec3", "k_decode_check", "k_ntt", "k_gao", "k_wb", "k_matvec2"))]
     ctrs = sorted({c for k in keep for c in acc[k]})
     print(f"{'kernel':<44} {'grid':>9} {'launches':>8} " + " ".join(f"{c:>24}" for c in ctrs) + f" {'HBM bytes/launch':>18}")
-    for k in sorted(keep, key=lambda k: -sum(acc[k].get("WRITE_SIZE", [0]))):
+    for k in sorted(keep, key=lambda k: (k[0], k[1], -sum(acc[k].get("WRITE_SIZE", [0])) / max(1, len(acc[k].get("WRITE_SIZE", [0]))))):
         vals = {c: sum(v) / len(v) for c, v in acc[k].items()}
         n = max(len(v) for v in acc[k].values())
         hbm = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals else None
