@@ -195,8 +195,12 @@ def valu_roofline(workload, launch_ms):
     return {"bound": "valu-issue", "achieved": achieved, "peak": peak, "unit": "G wave-instr/s", "frac": achieved / peak,
             "wave_instr_per_launch": n_instr, "mfma_per_launch": pc.get("mfma_per_launch"),
             "pmc_valu_busy_frac_of_kernel_cycles": pc.get("valu_busy_frac"), "pmc_matrix_pipe_busy_frac": pc.get("mfma_busy_frac"),
-            "note": "frac is against the nominal 2.4 GHz; under this kernel the shader clock averages ~2.06 GHz (busy cycles / duration in the PMC pass), "
-                    "where the same instruction stream is the pmc_valu_busy fraction of the kernel's cycles"}
+            "pmc_kernel_cycles": pc.get("kernel_cycles"),
+            "note": "frac is against the nominal 2.4 GHz and one wave-instruction per 4 cycles per SIMD; the PMC pass counts the kernel's busy cycles "
+                    "(pmc_kernel_cycles; / duration = the clock it sustained, ~2.1 GHz), of which the same instruction stream is the "
+                    "pmc_valu_busy fraction.  A kernel that runs ONE wave per SIMD (k_mm8w) issues an instruction every ~5.5 cycles at best, "
+                    "whatever its kind (profiles/r01_mad_issue_rate_vs_occupancy.txt, profiles/r02_mm8w_phase_timing.txt): for it "
+                    "0.5 on this scale is the ceiling"}
 
 
 def ntl_baseline(n, t, sample_b, threads):
@@ -500,14 +504,21 @@ def main():
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev3 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
     def step(i=None):
         if i is not None:
             ev0[i].record()
-        op.r1_encode(shares0, out=r1_out)            # dominant kernel: k_matvec (n x d encode)
+        op.r1_encode(shares0, out=r1_out)            # dominant kernel of small-entry plans: the n x d encode
         if i is not None:
             ev1[i].record()
         op.r1_decode(r1_cols, B, out=r2_msg)
-        op.r2_decode(r2_cols, B, out=result)
+        if i is not None:
+            ev2[i].record()
+        op.r2_decode(r2_cols, B, out=result)         # dominant kernel of fused plans: decode + validate in one launch
+        if i is not None:
+            ev3[i].record()
 
     for _ in range(args.warmup):
         step()
@@ -551,6 +562,9 @@ def main():
         assert op.ok()
 
     # ---- secondary (untimed for `value`): validation restricted to the compared points -----------
+    fused_now = op.uses_fused_validate()
+    if fused_now:
+        op.set_fused_validate(False)         # the option below acts on the decode + re-encode + compare pipeline
     op.set_validate_arrived_only(True)
     for _ in range(2):
         step()
@@ -562,6 +576,8 @@ def main():
     torch.cuda.synchronize()
     dt_arrived = time.perf_counter() - t1
     op.set_validate_arrived_only(False)
+    if fused_now:
+        op.set_fused_validate(True)
     assert ok4 and torch.equal(result, secrets)
 
     # ---- secondary (untimed for `value`): the fused decode + validate switched off ------------------
@@ -648,10 +664,16 @@ def main():
     assert torch.equal(r2_msg, r2_cols[:C]), "R2 message != what party 0 would broadcast"
 
     enc_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    r2_ms = sum(a.elapsed_time(b) for a, b in zip(ev2, ev3)) / args.steps
+    fused_default = dt_unfused is not None         # the plan decodes + validates in one k_mm8w launch by default
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * args.steps / dt
     alg_bytes_open = 32 * C * (3 * n + 7 * d)
     alg_bytes_enc = 32 * C * (d + n)
+    if fused_default:
+        # the roofline kernel of these workloads: the R2 launch reads the d arrival columns and the compared columns, writes d rows
+        alg_bytes_enc = 32 * C * (2 * d + len(zc))
+        enc_ms = r2_ms
     achieved = alg_bytes_enc / (enc_ms * 1e-3) / 1e9
     mulmods_open = C * (3 * n * d + 2 * d * d)
 
@@ -677,13 +699,19 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic_from_profiles(args.workload if mfma else args.workload + "_valu"),
-                "kernel": ("k_mm8<NKB,false> (R1 encode: n x d small-entry Vandermonde mat-vec as a byte-split int8 GEMM + Barrett; "
+                "kernel": (profile_counters(args.workload).get("kernel") or
+                           "k_mm8w<true,PEEL> (R2: fused decode + validate, (d + n_check) x d full-size entries as a byte-split int8 GEMM; "
+                           "the next pass reduces, stores and compares the sums of the pass before)") if fused_default else
+                          ("k_mm8<NKB,false> (R1 encode: n x d small-entry Vandermonde mat-vec as a byte-split int8 GEMM + Barrett; "
                            "the validating re-encodes are the same kernel in CHECK mode, the decodes the same kernel over the factored inverse's numerators)" if mfma else
                            "k_matvec3<9,8,false> (R1 encode: fused pre-scale + n x d small-entry Vandermonde mat-vec)"),
                 "algorithmic_bytes_per_launch": alg_bytes_enc, "avg_launch_ms": enc_ms,
                 "copy_GBps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
                 "second": valu_roofline(args.workload if mfma else args.workload + "_valu", enc_ms),
-                "note": ("neither HBM nor the matrix pipe binds: per 16x16 tile 47 int32 columns x (d/4) MFMAs are followed by a 390-bit "
+                "note": ("instruction-issue bound: one wave per SIMD (all 63 int32 columns of a 16 x 16 pass live in AGPRs) issues an instruction every "
+                         "~5.5 cycles, ~3000 per pass at d = 22 of which 564 are MFMAs (9.0 k of 16.2 k cycles of matrix-pipe time); "
+                         "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md section 4c") if fused_default else
+                        ("neither HBM nor the matrix pipe binds: per 16x16 tile 47 int32 columns x (d/4) MFMAs are followed by a 390-bit "
                          "reduction + Barrett per output on the VALU (~1550 VALU ops per wave pass, VALU ~67% busy, matrix pipe ~41% busy by PMC); "
                          if mfma else
                          "integer-ALU bound by construction (~840 VALU instructions per 32-byte output, VALU ~76% busy by PMC); ") +
@@ -697,13 +725,14 @@ def main():
                 "bit_exact_vs_secrets": True,
                 "matrix_core_path": bool(mfma),
                 "shares_per_s_per_gpu_validate_arrived_only": B * args.steps / dt_arrived,
-                "validate_arrived_only_note": "opt-in plan option: the guess is re-evaluated at the t compared points only (same accept/reject); "
-                                              "NOT the headline, which re-encodes all n rows like the reference",
+                "validate_arrived_only_note": "plan option on the unfused pipeline (decode, re-encode, compare): the guess is re-evaluated at the t compared "
+                                              "points only (same accept/reject)",
                 "fused_decode_validate": dt_unfused is not None,
                 "shares_per_s_per_gpu_three_full_encodes": (B * args.steps / dt_unfused) if dt_unfused else None,
-                "fused_decode_validate_note": "full-size matrix entries (omega-power points): each decode launch also produces the guess's values at the "
-                                              "compared points as (V[zc] Vinv) y and compares them (HB_OPEN_OPT_FUSED_VALIDATE, default on where it applies; "
-                                              "same results, same accept/reject); three_full_encodes = the option off: decode, re-encode all n points, compare",
+                "fused_decode_validate_note": "each decode launch also produces the guess's values at the compared points as (V[zc] Vinv) y and compares them "
+                                              "(HB_OPEN_OPT_FUSED_VALIDATE: default on for full-size matrix entries and from 8 coefficients up; same results, "
+                                              "same accept/reject as the reference's decode + encode_batch + compare); three_full_encodes = the option off: "
+                                              "decode, re-encode ALL n points on the plan's own kernels, compare -- the round-1 definition of `value`",
                 "shares_per_s_per_gpu_fused_validate_on_request": (B * args.steps / dt_fused_optin) if dt_fused_optin else None,
                 "shares_per_s_per_gpu_two_opens_in_flight": (B * args.steps / dt_two) if dt_two else None,
                 "two_opens_in_flight_note": "same opens issued alternately on two streams with two plans (independent batches overlap); "

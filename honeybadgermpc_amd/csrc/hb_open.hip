@@ -176,13 +176,16 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
             if (pl->Vinv8) PLAN_HIP(hipMalloc(&pl->scaled_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
         }
     }
-    if (!pl->V8 && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
-        // not small integers: full tables on the full-size matrix-core kernel (decode always, encodes unless they are NTTs)
+    // Full tables on the full-size matrix-core kernel: the decode (fused with the validation) of every plan whose entries are
+    // not small integers, and of small-entry plans from 8 coefficients up, where one k_mm8w launch over [V^-1 rows ; V[zc] V^-1]
+    // beats pre-scale + decode + validating re-encode on k_mm8 (n = 64, t = 21: 0.15 against 0.20 ms for the two decodes;
+    // below 8 coefficients the three small launches win: scratch/fused_vs_default.py); the encodes unless they are NTTs or k_mm8.
+    if ((!pl->V8 || d >= 8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
         std::vector<uint64_t> xz((size_t)d * L);
         for (int i = 0; i < d; i++) memcpy(&xz[(size_t)i * L], x_host + (size_t)z_host[i] * L, (size_t)L * 8);
         rc = hb_vand_inverse_create(ctx, xz.data(), d, &pl->Winv, stream); if (rc) goto done;
         pl->Winv8 = matrix_wide(ctx, pl->Winv, s);
-        if (!pl->ntt_order) {
+        if (!pl->ntt_order && !pl->V8) {
             rc = hb_vand_matrix_create(ctx, x_host, n, d, &pl->Vw, stream); if (rc) goto done;
             pl->Vw8 = matrix_wide(ctx, pl->Vw, s);
         }

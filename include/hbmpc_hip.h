@@ -167,7 +167,8 @@ int hb_open_status(hb_open_plan *plan, void *stream);
  * the integer-VALU kernels.  Results are bit-identical either way.  get_option reports whether the
  * matrix-core path is in use for this plan (0 when the plan's shapes do not qualify).
  * HB_OPEN_OPT_FUSED_VALIDATE (default 1): plans whose matrix entries are full-size residues (omega-power points, powers
- * beyond 2^127) decode AND validate in one launch of the full-size matrix-core kernel: the value the guess takes at a later
+ * beyond 2^127), and small-entry plans from 8 coefficients up (below that on request: set the option to 1), decode AND
+ * validate in one launch of the full-size matrix-core kernel: the value the guess takes at a later
  * arrival's point is a linear function of the arrival set, V[zc] (Vinv y) = (V[zc] Vinv) y, so the rows [Vinv rows wanted ;
  * V[zc] Vinv] applied to the received columns give the coefficients and the predictions to compare (reference:
  * decoder.decode_batch + encoder.encode_batch + compare, reed_solomon.py:300-323; same canonical values, same accept /

@@ -17,6 +17,7 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/pmc_$name" -o p -- python bench.py --steps 3 --warmup 1 --cpu-sample 0 --no-two-streams-extra > "$OUT/pmc_$name.log" 2>&1
 done
 python profiles/summarize_pmc.py "$OUT"/pmc_* > "$OUT/pmc_summary_cfg3.txt" 2>&1
+python profiles/make_traffic.py "$OUT/pmc_summary_cfg3.txt" cfg3 "profiles/r02_pmc_cfg3.txt (rocprofv3 --pmc, separate passes: FETCH_SIZE | WRITE_SIZE | SQ counters; FETCH x2 gfx950 correction)" > "$OUT/traffic_cfg3.json"
 for w in cfg5-shard cfg3-omega cfg2 cfg5; do
   python bench.py --workload $w --steps 30 --warmup 5 --cpu-sample 0 --no-two-streams-extra > "$OUT/bench_$w.json" 2> "$OUT/bench_$w.err"
 done
@@ -29,11 +30,13 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VAL
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/c5_pmc_$name" -o p -- python bench.py --workload cfg5-shard --steps 3 --warmup 1 --cpu-sample 0 --no-two-streams-extra > "$OUT/c5_pmc_$name.log" 2>&1
 done
 python profiles/summarize_pmc.py "$OUT"/c5_pmc_* > "$OUT/pmc_summary_cfg5-shard.txt" 2>&1
+python profiles/make_traffic.py "$OUT/pmc_summary_cfg5-shard.txt" cfg5-shard "profiles/r02_pmc_cfg5-shard.txt (same passes and correction)" > "$OUT/traffic_cfg5-shard.json"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY"; do
   name=$(echo "$pass" | cut -d' ' -f1)
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/c3o_pmc_$name" -o p -- python bench.py --workload cfg3-omega --steps 3 --warmup 1 --cpu-sample 0 --no-two-streams-extra > "$OUT/c3o_pmc_$name.log" 2>&1
 done
 python profiles/summarize_pmc.py "$OUT"/c3o_pmc_* > "$OUT/pmc_summary_cfg3-omega.txt" 2>&1
+python profiles/make_traffic.py "$OUT/pmc_summary_cfg3-omega.txt" cfg3-omega "profiles/r02_pmc_cfg3-omega.txt (same passes and correction)" > "$OUT/traffic_cfg3-omega.json"
 python scratch/bench_robust.py 262144 > "$OUT/robust_cfg4.txt" 2>&1
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d "$OUT/c4_pmc_$pass" -o p -- python scratch/bench_robust.py 16384 > "$OUT/c4_pmc_$pass.log" 2>&1

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""profiles/traffic_<workload>.json from a PMC summary (profiles/summarize_pmc.py output): the counters of the roofline kernel of
+a workload, which bench.py copies into roofline.traffic / roofline.second.  For plans that decode and validate in one launch
+the roofline kernel is the R2 launch of k_mm8w<true, PEEL> (the row of that kernel that writes the most).
+usage: python profiles/make_traffic.py <pmc_summary.txt> <workload> <source note>"""
+import json
+import sys
+
+
+def main(path, workload, source):
+    lines = open(path).read().splitlines()
+    hdr = lines[0].split()
+    cols = hdr[3:-2]                       # counters between 'launches' and 'HBM bytes/launch'
+    rows = []
+    for ln in lines[1:]:
+        if not ln.startswith("hb::k_mm8w<true"):
+            continue
+        name = ln[:44].strip()
+        f = ln[44:].split()
+        vals = dict(zip(cols, map(float, f[2:2 + len(cols)])))
+        vals["hbm_mb"] = float(f[2 + len(cols)]) if len(f) > 2 + len(cols) else None
+        rows.append((name, vals))
+    if not rows:
+        raise SystemExit("no k_mm8w<true,...> row in " + path)
+    name, v = max(rows, key=lambda r: r[1].get("WRITE_SIZE", 0.0))
+    simds, ses = 1024, 32                  # SQ_BUSY_CYCLES sums 32 shader-engine instances, instruction counters all 1024 SIMDs
+    cycles = v["SQ_BUSY_CYCLES"] / ses
+    out = {
+        "workload": workload,
+        "kernel": f"{name} (R2: fused decode + validate; the sums of a pass are reduced, stored and compared inside the next pass)",
+        "hbm_bytes_per_launch": v["hbm_mb"] * 1e6 if v["hbm_mb"] is not None else None,
+        "valu_wave_instr_per_launch": int(v["SQ_INSTS_VALU"]),
+        "mfma_per_launch": int(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 16),
+        "valu_busy_frac": round(4 * v["SQ_INSTS_VALU"] / simds / cycles, 4),
+        "mfma_busy_frac": round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / cycles, 4),
+        "kernel_cycles": round(cycles),
+        "source": source,
+    }
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])
