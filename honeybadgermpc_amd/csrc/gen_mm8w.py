@@ -37,27 +37,27 @@ import os
 
 NC = 63
 NWORDS = 17
-RB = 122                       # first register the statement owns
-# ---- MFMA operand files ----
-XB = 190                       # 8 dwords: LDS prefetch of the next term block's element
-ABUF = [[198, 202], [206, 210]]  # [term block parity][digit group]: 4 dwords each
-EA_SETS = [214, 228]           # 14 registers each, k = -4 .. 9
-EA_KMIN = -4
-EB0, EB_KMIN = 242, -3         # 14 registers, k = -3 .. 10
+RB = 96                        # first register the statement owns
+# ---- MFMA operand files (the layout of gen_mm8.py: 8 terms x 8 digits per K-block) ----
+XB = 164                       # 16 dwords: LDS prefetch of the next K-block's two elements, element e dword k at XB + 8 e + k
+ABUF = [[180, 184, 188, 192], [196, 200, 204, 208]]   # [K-block parity][digit group]: 4 dwords each
+F_SETS = [212, 234]            # 22 registers each: dword k = -2 .. 8 of element e at base + 2 (k + 2) + e
+F_KMIN = -2
 RHOS = (0, 1, 2, 3)
-# ---- reduction file (v122 .. v189) ----
-C0 = 122                       # ten 64-bit columns: C0 + 2j (low), + 1 (high)
-TB = [142, 152, 162]           # three buffers of nine for the T_k rows / the row constant (even bases: 128-bit LDS reads)
-T1, SK, ZERO = 151, 161, 171
-OW = 172                       # packed result, 8 words
-EX = 180                       # row to compare with, 8 words (requested when the output's reduction starts)
-T2 = 188                       # pair
-QP, Q0, Q1 = 142, 144, 145     # Barrett quotient (the T buffers are free by then)
-UB = 122                       # ow + (2^256 - p): the columns are free by then
-DIFF = 142
+NG = 4                         # digit groups of 8
+# ---- reduction file (v96 .. v163) ----
+C0 = 96                        # ten 64-bit columns: C0 + 2j (low), + 1 (high)
+TB = [116, 126, 136]           # three buffers of nine for the T_k rows / the row constant (even bases: 128-bit LDS reads)
+T1, SK, ZERO = 125, 135, 145
+OW = 146                       # packed result, 8 words
+EX = 154                       # row to compare with, 8 words (requested when the output's reduction starts)
+T2 = 162                       # pair
+QP, Q0, Q1 = 116, 118, 119     # Barrett quotient (the T buffers are free by then)
+UB = 96                        # ow + (2^256 - p): the columns are free by then
+DIFF = 116
 # ---- tail (word assembly) ----
-TL_TMP = [[122, 123, 124, 125], [126, 127, 128, 129]]
-TL_T = [[130, 132, 134, 136], [138, 140, 142, 144]]
+TL_TMP = [[96, 97, 98, 99], [100, 101, 102, 103]]
+TL_T = [[104, 106, 108, 110], [112, 114, 116, 118]]
 # ---- SGPRs ----
 S_PBAR, S_PNEG, S_M0, S_M1 = 68, 77, 85, 86    # WideParams: pbar[9] pneg[8] m0 m1 pad, loaded to s68 .. s87
 S_SAVE = 88                    # saved exec, pair
@@ -77,9 +77,7 @@ class Ops:
         if check:
             self.outs.append(("FLAG", '"+s"', "flag"))
         self.ins += [("ABASE", '"s"', "abase"), ("K256", '"s"', "k256"), ("K64K", '"s"', "k64k"), ("K16M", '"s"', "k16m"),
-                     ("B4", '"v"', "bias4"), ("B3", '"v"', "bias3"), ("WPP", '"s"', "wpa")]
-        for r in range(4):
-            self.ins.append((f"CRL{r}", '"v"', f"crl_addr[{r}]"))
+                     ("B4", '"s"', "bias4"), ("B3", '"s"', "bias3"), ("WPP", '"s"', "wpa"), ("CRL", '"v"', "crl_addr")]
         for r in range(4):
             self.ins.append((f"ADDR{r}", '"v"', f"addr[{r}]"))
         for r in range(4):
@@ -90,18 +88,14 @@ class Ops:
         return f"%{self.idx[name]}"
 
 
-def ea(s, k):
-    assert -4 <= k <= 9
-    return EA_SETS[s] + k - EA_KMIN
-
-
-def eb(k):
-    assert -3 <= k <= 10
-    return EB0 + k - EB_KMIN
+def f(s, k, e):
+    assert -2 <= k <= 8 and e in (0, 1)
+    return F_SETS[s] + 2 * (k - F_KMIN) + e
 
 
 def windows(rho):
-    return [q for q in range(-4, 8) if -15 <= 4 * q + rho <= 31]
+    """dword offsets q of the windows s = 4 q + rho in [-7, 31]"""
+    return [q for q in range(-2, 8) if -7 <= 4 * q + rho <= 31]
 
 
 def acc(c):
@@ -109,16 +103,18 @@ def acc(c):
 
 
 def loads(par, o):
-    """element and digits of the NEXT term block -> XB, ABUF[par]; both cursors move on by one block"""
-    a0, a1 = ABUF[par]
-    return [
-        f"ds_read_b128 v[{XB}:{XB + 3}], {o('XA')}",
-        f"ds_read_b128 v[{XB + 4}:{XB + 7}], {o('XA')} offset:1024",
-        f"v_add_u32 {o('XA')}, 0x800, {o('XA')}",
-        f"global_load_dwordx4 v[{a0}:{a0 + 3}], {o('VA')}, {o('ABASE')}",
-        f"global_load_dwordx4 v[{a1}:{a1 + 3}], {o('VA')}, {o('ABASE')} offset:1024",
-        f"v_add_u32 {o('VA')}, 0x800, {o('VA')}",
-    ]
+    """both elements of the lane and the four digit groups of the NEXT K-block -> XB, ABUF[par]; the cursors move on by a block"""
+    L = []
+    for e in (0, 1):
+        for h in (0, 1):
+            off = (e * 2 + h) * 1024
+            L.append(f"ds_read_b128 v[{XB + 8 * e + 4 * h}:{XB + 8 * e + 4 * h + 3}], {o('XA')}" + (f" offset:{off}" if off else ""))
+    L.append(f"v_add_u32 {o('XA')}, 0x1000, {o('XA')}")
+    for g in range(NG):
+        a0 = ABUF[par][g]
+        L.append(f"global_load_dwordx4 v[{a0}:{a0 + 3}], {o('VA')}, {o('ABASE')}" + (f" offset:{g * 1024}" if g else ""))
+    L.append(f"v_add_u32 {o('VA')}, 0x1000, {o('VA')}")
+    return L
 
 
 def interleave(mfmas, ops):
@@ -140,40 +136,34 @@ def interleave(mfmas, ops):
     return out
 
 
-def prep_a(gi):
-    """fill EA set gi & 1 for group gi = (term block, rho): from XB for rho = 0, else one more byte of shift"""
+def prep(gi):
+    """fill file set gi & 1 for group gi = (K-block, rho): from XB for rho = 0, else one more byte of shift of the other set"""
     rho = RHOS[gi % 4]
     s = gi & 1
     ops = []
     if rho == 0:
         ops.append("s_waitcnt lgkmcnt(0)")
-        for k in range(8):
-            ops.append(f"v_xor_b32 v{ea(s, k)}, 0x80808080, v{XB + k}")
-        ops.append(f"v_mov_b32 v{ea(s, -1)}, 0")
+        for e in (0, 1):
+            for k in range(8):
+                ops.append(f"v_xor_b32 v{f(s, k, e)}, 0x80808080, v{XB + 8 * e + k}")
+            ops.append(f"v_mov_b32 v{f(s, -1, e)}, 0")
     else:
-        for k in range(-1, 8):
-            ops.append(f"v_alignbyte_b32 v{ea(s, k)}, v{ea(1 - s, k + 1)}, v{ea(1 - s, k)}, 1")
+        for e in (0, 1):
+            for k in range(-1, 8):
+                ops.append(f"v_alignbyte_b32 v{f(s, k, e)}, v{f(1 - s, k + 1, e)}, v{f(1 - s, k, e)}, 1")
     return ops
 
 
-def prep_b(gi):
-    s = gi & 1
-    return [f"v_mov_b32 v{eb(k)}, v{ea(s, k)}" for k in range(-1, 8)]
-
-
-def mfmas(gi, parity, par, seen):
-    """MFMAs of group gi whose window starts on an even (parity 0: EA) / odd (1: EB) dword; `seen` = columns already
-    started (None: accumulate always)"""
+def mfmas(gi, par, seen):
+    """MFMAs of group gi; `seen` = columns already started (None: accumulate always)"""
     rho = RHOS[gi % 4]
     s = gi & 1
     out = []
     for q in windows(rho):
-        if q % 2 != parity:
-            continue
-        r = ea(s, q) if parity == 0 else eb(q)
+        r = f(s, q, 0)
         assert r % 2 == 0
-        for grp in (0, 1):
-            c = 4 * q + rho + 15 + 16 * grp
+        for grp in range(NG):
+            c = 4 * q + rho + 7 + 8 * grp
             assert 0 <= c < NC
             ab = ABUF[par][grp]
             cin = acc(c)
@@ -184,22 +174,19 @@ def mfmas(gi, parity, par, seen):
     return out
 
 
-def pair(kind, o):
-    """two term blocks (8 groups): digits of the even one in ABUF[0], of the odd one in ABUF[1].  On entry the first
-    group's EA / EB files are ready, XB has been consumed and the even block's digits are in flight.
-    The odd block of the LAST pair must not prefetch: nothing waits for a load issued there, and one that lands after the
-    asm statement would overwrite registers the compiler has taken back (it did, once per ~10^4 launches, when L2 was cold)."""
+def kblock(par, first, last, o):
+    """one K-block of 8 terms (4 groups, 156 MFMAs): its digits in ABUF[par].  On entry the first group's file set is ready, XB has
+    been consumed and this block's digits are in flight.  The LAST block must not prefetch: nothing waits for a load issued there,
+    and one that lands after the asm statement would overwrite registers the compiler has taken back (it did, once per ~10^4
+    launches, when L2 was cold)."""
     L = []
-    seen = set() if kind in ("first", "only") else None
-    for gi in range(8):
-        par = gi // 4
-        if gi % 4 == 0:
-            # the digits of this block were requested one block ago; every MFMA reading the other buffer has been issued
-            L.append("s_waitcnt vmcnt(0)")
-            if not (gi == 4 and kind in ("last", "only")):
-                L += loads(1 - par, o)
-        L += interleave(mfmas(gi, 1, par, seen), prep_a(gi + 1))
-        L += interleave(mfmas(gi, 0, par, seen), prep_b(gi + 1))
+    seen = set() if first else None
+    # the digits of this block were requested one block ago; every MFMA reading the other buffers has been issued
+    L.append("s_waitcnt vmcnt(0)")
+    if not last:
+        L += loads(1 - par, o)
+    for gi in range(4):
+        L += interleave(mfmas(gi, par, seen), prep(gi + 1) if not (last and gi == 3) else [])
         L.append("s_nop 0")
     if seen is not None:
         assert seen == set(range(NC))
@@ -262,7 +249,7 @@ def reduce_output(o, r, check):
                               f"global_load_dwordx4 v[{EX + 4}:{EX + 7}], {o(f'ADDR{r}')}, off offset:16"])
     # per-row constant -> TB[2], T_9 -> TB[0], T_10 -> TB[1]; the rows are requested THREE steps ahead of their use: one wave
     # per SIMD has only its own instructions (and the MFMAs between them) to cover the LDS latency
-    for ln in row_reads(o(f"CRL{r}"), 0, 2) + t_reads(0) + t_reads(1):
+    for ln in row_reads(o("CRL"), 256 * r, 2) + t_reads(0) + t_reads(1):          # output r's row is 4 r rows (64 B each) further on
         one(ln)
     one("s_waitcnt lgkmcnt(6)")
     for j in range(9):
@@ -433,19 +420,19 @@ def split(units, parts):
 
 
 def pass_lines(check, peel):
-    """`peel` pairs of term blocks are straight-line code carrying the reduction of the pass before, in equal shares (one wave
-    per SIMD issues a VALU instruction every ~7 cycles at best -- profiles/r01_mad_issue_rate_vs_occupancy.txt -- so a pair
-    hides about one output's reduction behind its 188 MFMAs); the other nkb/2 - peel pairs run as a loop in the middle."""
+    """`peel` K-blocks are straight-line code carrying the reduction of the pass before, in equal shares (one wave per SIMD
+    issues an instruction every ~5.5 cycles at best -- profiles/r01_mad_issue_rate_vs_occupancy.txt, r02_mm8w_phase_timing.txt --
+    so everything a pass executes counts); the other nkb - peel K-blocks run as a loop of two-block bodies in the middle (the digit
+    buffers alternate by block parity, so the launcher picks peel = nkb for nkb <= 2, else 3 for odd and 4 for even nkb)."""
     o = Ops(check)
     L = consts(o)
-    # positions that are read but never written stay zero: k <= -2 and k >= 8
+    # positions that are read but never written stay zero: k = -2 and k = 8
     for s in range(2):
-        for k in (-4, -3, -2, 8, 9):
-            L.append(f"v_mov_b32 v{ea(s, k)}, 0")
-    for k in (-3, -2, 8, 9, 10):
-        L.append(f"v_mov_b32 v{eb(k)}, 0")
-    L += loads(0, o)                                # term block 0
-    L += prep_a(0) + prep_b(0) + ["s_nop 1"]        # (its lgkmcnt(0) also covers the scalar loads)
+        for k in (-2, 8):
+            for e in (0, 1):
+                L.append(f"v_mov_b32 v{f(s, k, e)}, 0")
+    L += loads(0, o)                                # K-block 0
+    L += prep(0) + ["s_nop 1"]                      # (its lgkmcnt(0) also covers the scalar loads)
     units = []
     for r in range(4):
         units += reduce_output(o, r, check)
@@ -455,11 +442,10 @@ def pass_lines(check, peel):
         if i == head:
             L += [f"s_cmp_eq_u32 {o('CNT')}, 0", "s_cbranch_scc1 .Lmm8w_rest_%="]
             L.append(".Lmm8w_loop_%=:")
-            L += pair("mid", o)
+            L += kblock(head & 1, False, False, o) + kblock(1 - (head & 1), False, False, o)
             L += [f"s_sub_u32 {o('CNT')}, {o('CNT')}, 1", f"s_cmp_lg_u32 {o('CNT')}, 0", "s_cbranch_scc1 .Lmm8w_loop_%="]
             L.append(".Lmm8w_rest_%=:")
-        kind = "only" if peel == 1 else ("first" if i == 0 else ("last" if i == peel - 1 else "mid"))
-        L += merge(pair(kind, o), shares[i])
+        L += merge(kblock(i & 1, i == 0, i == peel - 1, o), shares[i])
     L += ["s_nop 7", "s_nop 7"]
     if "notail" not in ABLATE:
         L += tail(o)
@@ -478,7 +464,7 @@ def reduce_lines(check):
 def emit_fn(name, o, lines, check):
     out = []
     sig = ("uint32_t (&w)[4][17], uint32_t &xa, uint32_t &va, uint32_t &cnt, uint64_t &flag, uint64_t abase, int32_t k256, int32_t k64k, "
-           "int32_t k16m, int64_t bias4, int64_t bias3, uint64_t wpa, const uint32_t (&crl_addr)[4], const uint64_t (&addr)[4], "
+           "int32_t k16m, int64_t bias4, int64_t bias3, uint64_t wpa, uint32_t crl_addr, const uint64_t (&addr)[4], "
            "const uint32_t (&mode)[4]")
     out.append(f"static __device__ __forceinline__ void {name}({sig}) {{")
     if not check:

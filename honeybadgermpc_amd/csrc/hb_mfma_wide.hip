@@ -47,8 +47,8 @@ static_assert(offsetof(WideParams, T) == 80, "gen_mm8w.py loads pbar, pneg, m0, 
 
 struct Mm8wMatrix {
     int n_out, d, nkb, n_rt;
-    int4 *a8;          // [n_rt][nkb][2 digit groups][64 lanes] 16 digits each (+ one block of padding): lane (r, g) = row
-                       // 16 rt + 4 (r % 4) + r / 4, term 4 kb + g, digit 16 G + 15 - j
+    int4 *a8;          // [n_rt][nkb][4 digit groups][64 lanes] 16 bytes each (+ one block of padding): lane (r, g) = row
+                       // 16 rt + 4 (r % 4) + r / 4, terms 8 kb + 2 g and + 1, eight digits of group G each
     uint32_t *crow;    // [n_rt * 16][16]: 9 radix-2^29 digits of the per-row constant
     uint32_t *zero;    // 32 zero bytes: DMA source for inputs beyond in_count
     uint32_t bias;     // >= every |column| of every row
@@ -80,15 +80,15 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     const int n = lane & 15, g = lane >> 4;
     uint4 *tlds = mm8w_lds;                                                 // LDS offset 0 (the asm reads it by immediate offsets): [10][3] uint4: T_k, 9 digits + 3 pad
     uint32_t *crl = reinterpret_cast<uint32_t *>(mm8w_lds + 32);            // [n_rt * 16][16]
-    uint4 *xbuf = mm8w_lds + 32 + n_rt * 64;                                // nbuf x [tpw][nkb][2][64] uint4, then 2 KB of slack
-    const int bufsz = tpw * nkb * 2 * 64;
-    int64_t *rowoff = reinterpret_cast<int64_t *>(xbuf + (size_t)nbuf * bufsz + 128);   // [4 nkb] term -> element offset of its input row
-    int32_t *maskl = reinterpret_cast<int32_t *>(rowoff + 4 * nkb);         // [16 n_rt] CHECK: 1 + row to compare with, or 0
+    uint4 *xbuf = mm8w_lds + 32 + n_rt * 64;                                // nbuf x [tpw][nkb][2 elements][2 halves][64] uint4, then 2 KB of slack
+    const int bufsz = tpw * nkb * 4 * 64;
+    int64_t *rowoff = reinterpret_cast<int64_t *>(xbuf + (size_t)nbuf * bufsz + 128);   // [8 nkb] term -> element offset of its input row
+    int32_t *maskl = reinterpret_cast<int32_t *>(rowoff + 8 * nkb);         // [16 n_rt] CHECK: 1 + row to compare with, or 0
     if (threadIdx.x < 120) {
         const int k = threadIdx.x / 12, j = threadIdx.x % 12;
         reinterpret_cast<uint32_t *>(tlds)[threadIdx.x] = j < 9 ? wpp->T[k][j] : 0u;
     }
-    for (int l = threadIdx.x; l < 4 * nkb; l += 256) {
+    for (int l = threadIdx.x; l < 8 * nkb; l += 256) {
         const int lc = l < d ? l : d - 1;
         rowoff[l] = (int64_t)(in_rows ? in_rows[lc] : lc) * in_sl;
     }
@@ -98,22 +98,23 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = i < n_out ? (mask_is_map ? check_mask[i] : (check_mask[i] ? i + 1 : 0)) : 0;
     }
     __syncthreads();
-    // slot s = (t * nkb + kb) * 2 + h holds half h of element (chunk n, term 4 kb + g) of tile t for lane (n, g).  2 nkb is a
-    // multiple of 4, so a wave always moves the same half (h = wave & 1) of every second term block: per slot a 64-bit LDS read
-    // (the row's offset), an add, a bound and the DMA -- this loop is ~10 % of a short pass otherwise (one wave per SIMD pays
-    // ~5.5 cycles for every instruction)
+    // slot s = ((t * nkb + kb) * 2 + e) * 2 + h holds half h of element (chunk n, term 8 kb + 2 g + e) of tile t for lane (n, g): a
+    // wave always moves the same (e, h) of every K-block -- per slot a 64-bit LDS read (the row's offset), an add, a bound and the
+    // DMA; the general address arithmetic per slot was ~10 % of a short pass (one wave per SIMD pays ~5.5 cycles per instruction)
     auto issue_loads = [&](int64_t unit, int buf) {
-        const int h = wave & 1;
+        const int e = (wave >> 1) & 1, h = wave & 1;
         const uint4 *base = reinterpret_cast<const uint4 *>(in_pk) + h;
         const uint4 *zsrc = reinterpret_cast<const uint4 *>(zero_src) + h;
         for (int t = 0; t < tpw; t++) {
             int64_t chunk = (unit * tpw + t) * 16 + n;
             if (chunk >= n_chunks) chunk = n_chunks - 1;
             const int64_t cbase = chunk * in_sc;
-            for (int kb = wave >> 1; kb < nkb; kb += 2) {
-                const int64_t idx = cbase + rowoff[4 * kb + g];
+            int64_t ro = rowoff[2 * g + e];
+            for (int kb = 0; kb < nkb; kb++) {
+                const int64_t idx = cbase + ro;
+                ro = rowoff[8 * (kb + 1 < nkb ? kb + 1 : kb) + 2 * g + e];      // the next slot's row offset: its LDS latency under this slot's work
                 const uint4 *src = (idx < in_count) ? base + idx * 2 : zsrc;
-                const int s = (t * nkb + kb) * 2 + h;
+                const int s = ((t * nkb + kb) * 2 + e) * 2 + h;
                 const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
                     (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(xbuf + (size_t)buf * bufsz + s * 64));
                 uint32_t keep;
@@ -129,13 +130,13 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     // The sums of the pass before (17 words per output) and where they go: reduced, compared and stored INSIDE the next
     // pass's MFMA phase (gen_mm8w.py).  mode: 0 nothing, 1 store to addr, 2 compare with the row at addr.
     uint32_t w[4][17];
-    uint32_t crl_addr[4], mode[4];
+    uint32_t crl_addr, mode[4];
     uint64_t addr[4], flag = 0;
+    crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)crl;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
         for (int j = 0; j < 17; j++) w[r][j] = 0;
-        crl_addr[r] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)crl;
         mode[r] = 0; addr[r] = 0;
     }
     int buf = 0;
@@ -154,10 +155,10 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             const int tl = pidx / n_rt, rt = pidx - tl * n_rt;
             const int64_t chunk = (unit * tpw + tl) * 16 + n;
             {
-                uint32_t xa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(xbuf + (size_t)buf * bufsz + (size_t)tl * nkb * 2 * 64 + lane);
+                uint32_t xa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(xbuf + (size_t)buf * bufsz + (size_t)tl * nkb * 4 * 64 + lane);
                 uint32_t va = (uint32_t)lane * 16u;
-                uint32_t cnt = (uint32_t)(nkb / 2 - PEEL);       // pairs of term blocks that run as a loop between the peeled ones
-                const uint64_t abase = (uint64_t)(uintptr_t)(a8 + (size_t)rt * nkb * 2 * 64);
+                uint32_t cnt = (uint32_t)((nkb - PEEL) / 2);     // two-K-block loop bodies between the peeled K-blocks
+                const uint64_t abase = (uint64_t)(uintptr_t)(a8 + (size_t)rt * nkb * 4 * 64);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #define MM8W_ARGS w, xa, va, cnt, flag, abase, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
@@ -176,11 +177,11 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                 __builtin_amdgcn_sched_barrier(0);
             }
             MM8W_T(1);   // MFMA phase + the reduction of the pass before + word assembly
-            // where this pass's outputs go (used by the next pass, or by the drain below)
+            // where this pass's outputs go (used by the next pass, or by the drain below); output r's row constant is 4 r rows on
+            crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(crl + (size_t)(16 * rt + g) * 16);
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int i = 16 * rt + 4 * r + g;
-                crl_addr[r] = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(crl + (size_t)i * 16);
                 const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
                 if constexpr (CHECK) {
                     const int erow = maskl[i];
@@ -292,7 +293,7 @@ void to_digits(const Big &v, uint32_t *dg, int nd) {
 }
 
 size_t mm8w_lds_bytes(int n_rt, int nkb, int tpw, int nbuf) {
-    return ((size_t)n_rt * 64 + (size_t)nbuf * tpw * nkb * 2 * 64 + 128 + 32) * 16 + (size_t)(8 * nkb + 16 * n_rt) * 4;
+    return ((size_t)n_rt * 64 + (size_t)nbuf * tpw * nkb * 4 * 64 + 128 + 32) * 16 + (size_t)(16 * nkb + 16 * n_rt) * 4;
 }
 constexpr size_t MM8W_LDS_LIMIT = 156 * 1024;
 
@@ -345,12 +346,12 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE")) return HB_ERR_UNSUPPORTED;
     if (ctx->n_limbs != 4 || n_out < 1 || n_in < 1) return HB_ERR_UNSUPPORTED;
     if (!prescale_params(ctx)) return HB_ERR_UNSUPPORTED;              // 2^254 <= p < 2^256
-    const int d = n_in, nkb = 2 * ((d + 7) / 8), n_rt = (n_out + 15) / 16;
+    const int d = n_in, nkb = (d + 7) / 8, n_rt = (n_out + 15) / 16;       // K-blocks of 8 terms
     int tpw = 0, nbuf = 0;
     if (!mm8w_shape(n_rt, nkb, 1, 1, &tpw, &nbuf)) return HB_ERR_UNSUPPORTED;
     const Big p = big_from_limbs(ctx->p_limbs, 4);
     // balanced base-256 digits (an int8 operand is signed), row sums and the column bound
-    std::vector<uint8_t> a(((size_t)n_rt * nkb + 1) * 2 * 64 * 16, 0);      // one block of padding: the phase prefetches past the end
+    std::vector<uint8_t> a(((size_t)n_rt * nkb + 1) * 4 * 64 * 16, 0);      // one block of padding
     std::vector<Big> rowsum((size_t)n_out, Big(10, 0));
     uint64_t maxdig = 0;
     for (int i = 0; i < n_out; i++) {
@@ -360,13 +361,16 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
             const Big ev = big_from_limbs(e, 4);
             if (big_ge(ev, p)) return fail(ctx, HB_ERR_BAD_ARG, "mm8w: matrix entry is not a canonical residue");
             big_add(rowsum[i], ev);
-            const int rt = i / 16, j16 = i % 16, r = 4 * (j16 % 4) + j16 / 4, kb = l / 4, g = l % 4;
+            // lane (r, g) of K-block kb = l / 8 holds terms 8 kb + 2 g and 8 kb + 2 g + 1: g = (l % 8) / 2, element el = l % 2
+            const int rt = i / 16, j16 = i % 16, r = 4 * (j16 % 4) + j16 / 4, kb = l / 8, g = (l % 8) / 2, el = l & 1;
             int carry = 0;
             for (int b = 0; b < 32; b++) {
                 int t = (int)((e[b >> 3] >> (8 * (b & 7))) & 0xffu) + carry;
                 if (t > 127) { t -= 256; carry = 1; } else carry = 0;
-                const int grp = b >> 4, j = 15 - (b & 15);
-                a[((((size_t)rt * nkb + kb) * 2 + grp) * 64 + (size_t)(r + 16 * g)) * 16 + j] = (uint8_t)(int8_t)t;
+                // digit b = 8 G + 7 - 4 hi - bi sits at byte 4 (2 hi + el) + bi of the lane's 16 bytes of group G (gen_mm8w.py: the
+                // operand of window q is [q of e0, q of e1, q + 1 of e0, q + 1 of e1])
+                const int grp = b >> 3, r7 = 7 - (b & 7), hi = r7 >> 2, bi = r7 & 3;
+                a[((((size_t)rt * nkb + kb) * 4 + grp) * 64 + (size_t)(r + 16 * g)) * 16 + 4 * (2 * hi + el) + bi] = (uint8_t)(int8_t)t;
                 dsum += (uint64_t)(t < 0 ? -t : t);
             }
             if (carry) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: entry needs a 33rd digit");   // not for p < 2^255 + 2^254
@@ -448,8 +452,8 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
                            m->n_out, m->n_rt, m->nkb, tpw, nbuf, C, n_units, m->bias, m->wp);                                        \
     } while (0)
-    // pairs of term blocks written out with a share of the reduction each (gen_mm8w.py): all of them up to four
-    const int peel = std::min(m->nkb / 2, 4);
+    // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
+    const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);
     if (check) { if (peel == 1) MM8W_LAUNCH(true, 1); else if (peel == 2) MM8W_LAUNCH(true, 2); else if (peel == 3) MM8W_LAUNCH(true, 3); else MM8W_LAUNCH(true, 4); }
     else { if (peel == 1) MM8W_LAUNCH(false, 1); else if (peel == 2) MM8W_LAUNCH(false, 2); else if (peel == 3) MM8W_LAUNCH(false, 3); else MM8W_LAUNCH(false, 4); }
 #undef MM8W_LAUNCH
