@@ -8,24 +8,27 @@ into their 32 bytes X_a:
 
     S = sum_l M[l] x[l] = sum_c 2^(8c) col_c,   col_c = sum_l sum_b M_b[l] X_{c-b}[l],   c < 63.
 
-One v_mfma_i32_16x16x64_i8 contracts 4 terms x 16 digits, so a column needs two digit groups G (b in
-[16G, 16G + 16)) per term block: with s = c - 15 - 16G the B operand is bytes [s, s + 15] of the element,
-i.e. dwords q .. q+3 of the element shifted right by rho bytes (s = 4q + rho).  Every window s in
-[-15, 31] therefore feeds TWO MFMAs (group 0 -> column s + 15, group 1 -> column s + 31): 94 per term
-block, against 18 preparation ops per (term block, rho): the int8 pipe does the 1024 byte products of a
-256 x 256-bit multiplication in 16 cycles per 16 x 16 outputs, the VALU needs 81 half-rate v_mad_u64_u32 per lane.
+One v_mfma_i32_16x16x64_i8 contracts 64 products per (row, chunk); a lane's 16 operand bytes are cut as in gen_mm8.py:
+8 TERMS x 8 DIGITS per K-block -- lane (n, g) feeds terms 8 kb + 2 g and + 1 of chunk n, the 32 digits of an entry are four
+groups G (b in [8 G, 8 G + 8)), and with s = c - 7 - 8 G = 4 q + rho the B operand is the 8-byte windows [s, s + 7] of both
+elements: dwords q, q + 1 of each shifted right by rho bytes.  Every window s in [-7, 31] feeds FOUR MFMAs (group G -> column
+s + 7 + 8 G): 156 per K-block = 78 per 4 terms (the first version cut 4 terms x 16 digits: 94), and with the register file laid
+out [dword k][element e] the operand of window q is registers 2 q .. 2 q + 3, always even-aligned: one file, 18 preparation ops
+per (K-block, rho) for eight terms (the first version: 18 per four, half of them copies into a second file one register apart).
+The int8 pipe does the 1024 byte products of a 256 x 256-bit multiplication in 16 cycles per 16 x 16 outputs, the VALU needs 81
+half-rate v_mad_u64_u32 per lane.
 
 A pass = one asm statement, SOFTWARE-PIPELINED over passes: the kernel runs one wave per SIMD (all 63 accumulators of
 16 x 16 outputs live in AGPRs a0..a251), so nothing else could hide the reduction of S mod p (~310 VALU instructions per
 output) -- it would simply follow the MFMA phase, which leaves the VALU three quarters idle.  Instead a pass ends by
 moving its sums out of the AGPRs as 17 words per output (68 VGPRs), and the NEXT pass reduces, compares and stores them
-between its own MFMAs: outputs 0, 1 inside the first pair of term blocks, outputs 2, 3 inside the last pair (both peeled;
-the pairs between them are a loop, so the code does not grow with the inner dimension).  After its last pass a wave
+between its own MFMAs: up to four K-blocks are written out, each carrying an equal share of that reduction; the K-blocks between
+them are a loop of two-block bodies, so the code does not grow with the inner dimension.  After its last pass a wave
 runs the reduction alone (mm8w_reduce).
 
-Register files (VGPRs the statement owns: v122 .. v255): v190.. the MFMA operand files of the first version (two EA sets
-for even q, EB one register apart for odd q, the next group's shifts built while the current group's MFMAs issue, element
-prefetch XB, digit buffers ABUF); v122 .. v189 the reduction (ten 64-bit columns, two buffers for the T_k rows, the packed
+Register files (VGPRs the statement owns: v96 .. v255): v164.. the MFMA operand files (two file sets, the next group's
+shifts built from the other set while the current group's MFMAs issue; element prefetch XB, digit buffers ABUF of two
+K-block parities); v96 .. v163 the reduction (ten 64-bit columns, two buffers for the T_k rows, the packed
 result, the row to compare with).  SGPRs s68 .. s89: the Barrett constants (scalar loads from WideParams), a saved exec.
 
 Reduction of one output (the arithmetic of k_prescale_tab / the first version's C++ epilogue, same bounds):
@@ -332,7 +335,7 @@ def merge(stream, units):
     if "nored" in ABLATE:
         units = []
     if "nomfma" in ABLATE:
-        stream = [ln for ln in stream if not ln.startswith("v_mfma")] + ["v_mfma_i32_16x16x64_i8 a[0:3], v[198:201], v[214:217], a[0:3]"]
+        stream = [ln for ln in stream if not ln.startswith("v_mfma")] + [f"v_mfma_i32_16x16x64_i8 a[0:3], v[{ABUF[0][0]}:{ABUF[0][0] + 3}], v[{F_SETS[0]}:{F_SETS[0] + 3}], a[0:3]"]
     n_mfma = sum(1 for ln in stream if ln.startswith("v_mfma"))
     out, done, seen = [], 0, 0
     for ln in stream:

@@ -9,8 +9,8 @@
 //   * Vandermonde matrices at the points 1..n whose powers outgrow 2^127 (n = 100, t = 33: 100^33 > 2^219);
 //   * arbitrary hb_matrix operands (hb_matvec), the interpolant of gao_interpolate (rsdecode_impl.h:281-405).
 // hb_mfma.hip covers the small-entry case (16 digits, 47 columns, VALU-bound by its reduction); here the
-// entries have 32 base-256 digits and the sum has 63 int32 columns: 94 v_mfma_i32_16x16x64_i8 per block of 4 terms
-// and 16 x 16 outputs.
+// entries have 32 base-256 digits and the sum has 63 int32 columns: 156 v_mfma_i32_16x16x64_i8 per K-block of 8 terms
+// and 16 x 16 outputs (8 terms x 8 digits per MFMA, as hb_mfma.hip).
 //
 // One wave per SIMD (512-register budget): all 63 accumulators of a 16-chunk x 16-row pass live in AGPRs a0..a251.
 // A workgroup owns a unit of `tpw` tiles of 16 chunks, DMA'd into LDS in MFMA-operand order; its 4 waves take the
