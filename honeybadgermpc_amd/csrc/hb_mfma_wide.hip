@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     uint4 *xbuf = mm8w_lds + 32 + n_rt * 64;                                // nbuf x [tpw][nkb][2 elements][2 halves][64] uint4, then 2 KB of slack
     const int bufsz = tpw * nkb * 4 * 64;
     int64_t *rowoff = reinterpret_cast<int64_t *>(xbuf + (size_t)nbuf * bufsz + 128);   // [8 nkb] term -> element offset of its input row
-    int32_t *maskl = reinterpret_cast<int32_t *>(rowoff + 8 * nkb);         // [16 n_rt] CHECK: 1 + row to compare with, or 0
+    uint64_t *rowdst = reinterpret_cast<uint64_t *>(rowoff + 8 * nkb);      // [16 n_rt] where row i's elements go: address of its chunk 0 | mode (1 store, 2 compare), 0 = nowhere
     if (threadIdx.x < 120) {
         const int k = threadIdx.x / 12, j = threadIdx.x % 12;
         reinterpret_cast<uint32_t *>(tlds)[threadIdx.x] = j < 9 ? wpp->T[k][j] : 0u;
@@ -93,9 +93,16 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         rowoff[l] = (int64_t)(in_rows ? in_rows[lc] : lc) * in_sl;
     }
     for (int i = threadIdx.x; i < n_rt * 16 * 16; i += 256) crl[i] = crowd[i];
-    if constexpr (CHECK) {
-        // a flag per row (compare with the same row), or a map: 1 + the row of the compare view, 0 = a row to store
-        for (int i = threadIdx.x; i < n_rt * 16; i += 256) maskl[i] = i < n_out ? (mask_is_map ? check_mask[i] : (check_mask[i] ? i + 1 : 0)) : 0;
+    for (int i = threadIdx.x; i < n_rt * 16; i += 256) {
+        uint64_t e = 0;
+        if (i < n_out) {
+            int erow = 0;
+            // CHECK: a flag per row (compare with the same row), or a map: 1 + the row of the compare view, 0 = a row to store
+            if constexpr (CHECK) erow = mask_is_map ? check_mask[i] : (check_mask[i] ? i + 1 : 0);
+            if (erow) e = (uint64_t)(uintptr_t)(cmp_pk + (int64_t)(erow - 1) * cmp_sl * 8) | 2u;
+            else if (!CHECK || i < n_store) e = (uint64_t)(uintptr_t)(out_pk + (int64_t)i * out_sl * 8) | 1u;
+        }
+        rowdst[i] = e;
     }
     __syncthreads();
     // slot s = ((t * nkb + kb) * 2 + e) * 2 + h holds half h of element (chunk n, term 8 kb + 2 g + e) of tile t for lane (n, g): a
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     const int32_t k256 = 256, k64k = 1 << 16, k16m = 1 << 24;
     const int64_t bias4 = (int64_t)bias * 0x01010101ll, bias3 = (int64_t)bias * 0x00010101ll;   // the accumulator bias of 4 (3) columns
     const uint64_t wpa = (uint64_t)(uintptr_t)wpp;
+    const uint64_t out_lim = out_count >= (int64_t)1 << 56 ? ~(uint64_t)0 : (uint64_t)(uintptr_t)(out_pk + out_count * 8);
     // The sums of the pass before (17 words per output) and where they go: reduced, compared and stored INSIDE the next
     // pass's MFMA phase (gen_mm8w.py).  mode: 0 nothing, 1 store to addr, 2 compare with the row at addr.
     uint32_t w[4][17];
@@ -179,27 +187,17 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             MM8W_T(1);   // MFMA phase + the reduction of the pass before + word assembly
             // where this pass's outputs go (used by the next pass, or by the drain below); output r's row constant is 4 r rows on
             crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(crl + (size_t)(16 * rt + g) * 16);
+            {
+                const bool in_batch = chunk < n_chunks;
+                const uint64_t c_out = (uint64_t)(chunk * out_sc) * 32u, c_cmp = (uint64_t)(chunk * cmp_sc) * 32u;
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int i = 16 * rt + 4 * r + g;
-                const int64_t oidx = chunk * out_sc + (int64_t)i * out_sl;
-                if constexpr (CHECK) {
-                    const int erow = maskl[i];
-                    const bool live = chunk < n_chunks && i < n_out;
-                    if (live && erow) {
-                        mode[r] = 2;
-                        addr[r] = (uint64_t)(uintptr_t)(cmp_pk + (chunk * cmp_sc + (int64_t)(erow - 1) * cmp_sl) * 8);
-                    } else if (live && i < n_store && oidx < out_count) {
-                        mode[r] = 1;
-                        addr[r] = (uint64_t)(uintptr_t)(out_pk + oidx * 8);
-                    } else {
-                        mode[r] = 0;
-                        addr[r] = 0;
-                    }
-                } else {
-                    const bool st = chunk < n_chunks && i < n_out && oidx < out_count;
-                    mode[r] = st ? 1 : 0;
-                    addr[r] = st ? (uint64_t)(uintptr_t)(out_pk + oidx * 8) : 0;
+                for (int r = 0; r < 4; r++) {
+                    const uint64_t e = rowdst[16 * rt + 4 * r + g];
+                    const uint32_t m = (uint32_t)e & 3u;
+                    const uint64_t a = (e & ~(uint64_t)3) + (m == 2 ? c_cmp : c_out);
+                    const bool ok = in_batch && m != 0 && (m == 2 || a < out_lim);       // out_lim: the view's end (truncated results)
+                    mode[r] = ok ? m : 0;
+                    addr[r] = ok ? a : 0;
                 }
             }
             MM8W_T(3);   // bookkeeping
@@ -293,7 +291,7 @@ void to_digits(const Big &v, uint32_t *dg, int nd) {
 }
 
 size_t mm8w_lds_bytes(int n_rt, int nkb, int tpw, int nbuf) {
-    return ((size_t)n_rt * 64 + (size_t)nbuf * tpw * nkb * 4 * 64 + 128 + 32) * 16 + (size_t)(16 * nkb + 16 * n_rt) * 4;
+    return ((size_t)n_rt * 64 + (size_t)nbuf * tpw * nkb * 4 * 64 + 128 + 32) * 16 + (size_t)(16 * nkb + 32 * n_rt) * 4;
 }
 constexpr size_t MM8W_LDS_LIMIT = 156 * 1024;
 
