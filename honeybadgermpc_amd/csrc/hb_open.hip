@@ -38,6 +38,8 @@ struct hb_open_plan {
     uint32_t *scaled_pk; // [d][max_C] received columns / den_j, the matrix-core decode's input
     int use_v8;          // option HB_OPEN_OPT_MATRIX_CORES (default 1)
     int use_fused;       // option HB_OPEN_OPT_FUSED_VALIDATE (default 1)
+    int fused_pending;   // the fused matrices apply to this plan but are not built yet: a plan pays for them (1-2.5 ms) once it
+    int decode_calls;    // has decoded twice -- arrival sets that are seen once (a decoder probing its way past liars) never do
     int32_t *z_dev;      // d row indices
     int32_t *mask_dev;   // n+1 ints: rows to validate
     uint32_t *in_dg;     // [d][NL][max_C] pre-scaled inputs (digit planes)
@@ -107,6 +109,23 @@ static int build_fused(hb_open_plan *pl, const uint64_t *x_host, hipStream_t s) 
         return rc == HB_ERR_UNSUPPORTED ? HB_OK : rc;
     }
     return HB_OK;
+}
+
+// builds the full inverse (small-entry plans have only the factored one) and the fused matrices; shapes the full-size kernel
+// does not take leave the plan as it is
+static int ensure_fused(hb_open_plan *pl, hipStream_t s) {
+    pl->fused_pending = 0;
+    if (pl->F1 || pl->d < 4 || pl->n < 4 || getenv("HB_NO_MFMA_DECODE")) return HB_OK;
+    hb_ctx *ctx = pl->ctx;
+    const int L = ctx->n_limbs;
+    if (!pl->Winv) {
+        std::vector<uint64_t> xz((size_t)pl->d * L);
+        for (int i = 0; i < pl->d; i++) memcpy(&xz[(size_t)i * L], &pl->x[(size_t)pl->z[i] * L], (size_t)L * 8);
+        int rc = hb_vand_inverse_create(ctx, xz.data(), pl->d, &pl->Winv, (void *)s);
+        if (rc) return rc;
+        pl->Winv8 = matrix_wide(ctx, pl->Winv, s);
+    }
+    return pl->Winv8 ? build_fused(pl, pl->x.data(), s) : HB_OK;
 }
 
 extern "C" {
@@ -180,20 +199,20 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     // not small integers, and of small-entry plans from 8 coefficients up, where one k_mm8w launch over [V^-1 rows ; V[zc] V^-1]
     // beats pre-scale + decode + validating re-encode on k_mm8 (n = 64, t = 21: 0.15 against 0.20 ms for the two decodes;
     // below 8 coefficients the three small launches win: scratch/fused_vs_default.py); the encodes unless they are NTTs or k_mm8.
-    if ((!pl->V8 || d >= 8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
+    if (!pl->V8 && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
         std::vector<uint64_t> xz((size_t)d * L);
         for (int i = 0; i < d; i++) memcpy(&xz[(size_t)i * L], x_host + (size_t)z_host[i] * L, (size_t)L * 8);
         rc = hb_vand_inverse_create(ctx, xz.data(), d, &pl->Winv, stream); if (rc) goto done;
         pl->Winv8 = matrix_wide(ctx, pl->Winv, s);
-        if (!pl->ntt_order && !pl->V8) {
+        if (!pl->ntt_order) {
             rc = hb_vand_matrix_create(ctx, x_host, n, d, &pl->Vw, stream); if (rc) goto done;
             pl->Vw8 = matrix_wide(ctx, pl->Vw, s);
         }
         if ((pl->Winv8 || pl->Vw8) && !pl->coef_pk) PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
-        if (pl->Winv8 && !getenv("HB_NO_FUSED_VALIDATE")) {
-            rc = build_fused(pl, x_host, s); if (rc) goto done;
-        }
     }
+    // the fused matrices are built when the plan decodes for the third time (ensure_fused), or at once on request (set_option)
+    pl->fused_pending = ((pl->V8 ? d >= 8 : pl->Winv8 != nullptr) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") &&
+                         !getenv("HB_NO_FUSED_VALIDATE")) ? 1 : 0;
     PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
 #undef PLAN_HIP
@@ -228,6 +247,10 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
 static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64_t C, uint32_t *pk_dst, hb_view pv, int64_t pk_count,
                                int pk_rows, hipStream_t s) {
     hb_view pm{1, C};
+    if (pl->fused_pending && pl->use_v8 && pl->use_fused && ++pl->decode_calls > 2) {
+        int rc = ensure_fused(pl, s);
+        if (rc) return rc;
+    }
     if (pl->F1 && pl->F2 && pl->use_v8 && pl->use_fused && (pk_rows == 1 || pk_rows == pl->d)) {
         // full-size entries: ONE launch decodes the rows the caller wants and compares the predictions of the later arrivals
         const bool r1 = pk_rows == 1 && pl->d > 1;
@@ -344,19 +367,10 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
     if (option == HB_OPEN_OPT_MATRIX_CORES) { pl->use_v8 = value ? 1 : 0; return HB_OK; }
     if (option == HB_OPEN_OPT_FUSED_VALIDATE) {
         pl->use_fused = value ? 1 : 0;
-        if (value && !pl->F1 && pl->d >= 4 && pl->n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
-            // a plan whose entries are small integers validates with its own kernels by default; asked to, it builds the
-            // full inverse and the fused matrices too (UNSUPPORTED shapes stay as they are)
-            hb_ctx *ctx = pl->ctx;
-            const int L = ctx->n_limbs;
-            if (!pl->Winv) {
-                std::vector<uint64_t> xz((size_t)pl->d * L);
-                for (int i = 0; i < pl->d; i++) memcpy(&xz[(size_t)i * L], &pl->x[(size_t)pl->z[i] * L], (size_t)L * 8);
-                int rc = hb_vand_inverse_create(ctx, xz.data(), pl->d, &pl->Winv, nullptr);
-                if (rc) return rc;
-                pl->Winv8 = matrix_wide(ctx, pl->Winv, 0);
-            }
-            if (pl->Winv8) { int rc = build_fused(pl, pl->x.data(), 0); if (rc) return rc; }
+        if (value && !pl->F1) {
+            // asked for explicitly: built now (also for small-entry plans below 8 coefficients, which do not get it by default)
+            int rc = ensure_fused(pl, 0);
+            if (rc) return rc;
         }
         return HB_OK;
     }
@@ -367,7 +381,7 @@ int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) {
     if (!pl || !value) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { *value = pl->validate_arrived_only; return HB_OK; }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = ((pl->V8 || pl->Winv8 || pl->Vw8) && pl->use_v8) ? 1 : 0; return HB_OK; }
-    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (pl->F1 && pl->F2 && pl->use_v8 && pl->use_fused) ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (((pl->F1 && pl->F2) || pl->fused_pending) && pl->use_v8 && pl->use_fused) ? 1 : 0; return HB_OK; }
     return HB_ERR_BAD_ARG;
 }
 
