@@ -71,9 +71,11 @@ LB = 29
 class Ops:
     """operand numbering of the asm statement"""
 
-    def __init__(self, check):
+    def __init__(self, check, nout=4):
         self.outs, self.ins = [], []
-        for r in range(4):
+        self.nout = nout           # outputs per lane that are kept: 4 (16-row tiles) or 3 (12-row tiles: the fourth row of every group of
+                                   # the MFMA tile is padding -- a matrix of 22 rows is two tiles either way, and a pass reduces 3 sums, not 4)
+        for r in range(nout):
             for j in range(NWORDS):
                 self.outs.append((f"W{r}_{j}", '"+v"', f"w[{r}][{j}]"))
         self.outs += [("XA", '"+v"', "xa"), ("VA", '"+v"', "va"), ("CNT", '"+s"', "cnt")]
@@ -81,9 +83,9 @@ class Ops:
             self.outs.append(("FLAG", '"+s"', "flag"))
         self.ins += [("ABASE", '"s"', "abase"), ("K256", '"s"', "k256"), ("K64K", '"s"', "k64k"), ("K16M", '"s"', "k16m"),
                      ("B4", '"s"', "bias4"), ("B3", '"s"', "bias3"), ("WPP", '"s"', "wpa"), ("CRL", '"v"', "crl_addr")]
-        for r in range(4):
+        for r in range(nout):
             self.ins.append((f"ADDR{r}", '"v"', f"addr[{r}]"))
-        for r in range(4):
+        for r in range(nout):
             self.ins.append((f"MODE{r}", '"v"', f"mode[{r}]"))
         self.idx = {name: i for i, (name, _, _) in enumerate(self.outs + self.ins)}
 
@@ -397,22 +399,22 @@ def tail(o):
         cols = [c for c in range(4 * j, 4 * j + 4) if c < NC]
         bias = o("B4") if len(cols) == 4 else o("B3")
         assert len(cols) in (3, 4)
-        reads = [[f"v_accvgpr_read_b32 v{TL_TMP[i & 1][r]}, a{4 * c + r}" for r in range(4)] for i, c in enumerate(cols)]
+        reads = [[f"v_accvgpr_read_b32 v{TL_TMP[i & 1][r]}, a{4 * c + r}" for r in range(o.nout)] for i, c in enumerate(cols)]
         L += reads[0]
         for i, c in enumerate(cols):
             if i + 1 < len(cols):
                 L += reads[i + 1]
             mul = "1" if i == 0 else K[i]
-            for r in range(4):
+            for r in range(o.nout):
                 add = bias if i == 0 else f"v[{ts[r]}:{ts[r] + 1}]"
                 L.append(f"v_mad_i64_i32 v[{ts[r]}:{ts[r] + 1}], vcc, v{TL_TMP[i & 1][r]}, {mul}, {add}")
         if j > 0:
-            for r in range(4):
+            for r in range(o.nout):
                 L.append(f"v_mad_u64_u32 v[{ts[r]}:{ts[r] + 1}], vcc, v{TL_T[1 - (j & 1)][r] + 1}, 1, v[{ts[r]}:{ts[r] + 1}]")
-        for r in range(4):
+        for r in range(o.nout):
             L.append(f"v_mov_b32 {o(f'W{r}_{j}')}, v{ts[r]}")
     assert n_words == NWORDS - 1
-    for r in range(4):
+    for r in range(o.nout):
         L.append(f"v_mov_b32 {o(f'W{r}_{NWORDS - 1}')}, v{TL_T[(n_words - 1) & 1][r] + 1}")
     return L
 
@@ -422,12 +424,12 @@ def split(units, parts):
     return [units[n * i // parts:n * (i + 1) // parts] for i in range(parts)]
 
 
-def pass_lines(check, peel):
+def pass_lines(check, peel, nout=4):
     """`peel` K-blocks are straight-line code carrying the reduction of the pass before, in equal shares (one wave per SIMD
     issues an instruction every ~5.5 cycles at best -- profiles/r01_mad_issue_rate_vs_occupancy.txt, r02_mm8w_phase_timing.txt --
     so everything a pass executes counts); the other nkb - peel K-blocks run as a loop of two-block bodies in the middle (the digit
     buffers alternate by block parity, so the launcher picks peel = nkb for nkb <= 2, else 3 for odd and 4 for even nkb)."""
-    o = Ops(check)
+    o = Ops(check, nout)
     L = consts(o)
     # positions that are read but never written stay zero: k = -2 and k = 8
     for s in range(2):
@@ -437,7 +439,7 @@ def pass_lines(check, peel):
     L += loads(0, o)                                # K-block 0
     L += prep(0) + ["s_nop 1"]                      # (its lgkmcnt(0) also covers the scalar loads)
     units = []
-    for r in range(4):
+    for r in range(nout):
         units += reduce_output(o, r, check)
     shares = split(units, peel)
     head = (peel + 1) // 2
@@ -455,10 +457,10 @@ def pass_lines(check, peel):
     return o, resolve_waits(L)
 
 
-def reduce_lines(check):
-    o = Ops(check)
+def reduce_lines(check, nout=4):
+    o = Ops(check, nout)
     L = consts(o) + ["s_waitcnt lgkmcnt(0)"]
-    for r in range(4):
+    for r in range(nout):
         for u in reduce_output(o, r, check):
             L += u
     return o, resolve_waits(L)
@@ -466,9 +468,10 @@ def reduce_lines(check):
 
 def emit_fn(name, o, lines, check):
     out = []
-    sig = ("uint32_t (&w)[4][17], uint32_t &xa, uint32_t &va, uint32_t &cnt, uint64_t &flag, uint64_t abase, int32_t k256, int32_t k64k, "
-           "int32_t k16m, int64_t bias4, int64_t bias3, uint64_t wpa, uint32_t crl_addr, const uint64_t (&addr)[4], "
-           "const uint32_t (&mode)[4]")
+    n = o.nout
+    sig = (f"uint32_t (&w)[{n}][17], uint32_t &xa, uint32_t &va, uint32_t &cnt, uint64_t &flag, uint64_t abase, int32_t k256, int32_t k64k, "
+           f"int32_t k16m, int64_t bias4, int64_t bias3, uint64_t wpa, uint32_t crl_addr, const uint64_t (&addr)[{n}], "
+           f"const uint32_t (&mode)[{n}]")
     out.append(f"static __device__ __forceinline__ void {name}({sig}) {{")
     if not check:
         out.append("    (void)flag;")
@@ -491,11 +494,12 @@ def emit():
     out = ["// GENERATED by gen_mm8w.py -- do not edit", ""]
     for check in (False, True):
         sfx = "_check" if check else ""
-        for peel in PEELS:
-            o, lines = pass_lines(check, peel)
-            out += emit_fn(f"mm8w_pass{sfx}_p{peel}", o, lines, check)
-        o, lines = reduce_lines(check)
-        out += emit_fn(f"mm8w_reduce{sfx}", o, lines, check)
+        for nout in (4, 3):
+            for peel in PEELS:
+                o, lines = pass_lines(check, peel, nout)
+                out += emit_fn(f"mm8w_pass{sfx}_p{peel}_k{nout}", o, lines, check)
+            o, lines = reduce_lines(check, nout)
+            out += emit_fn(f"mm8w_reduce{sfx}_k{nout}", o, lines, check)
     return "\n".join(out)
 
 

@@ -47,6 +47,7 @@ static_assert(offsetof(WideParams, T) == 80, "gen_mm8w.py loads pbar, pneg, m0, 
 
 struct Mm8wMatrix {
     int n_out, d, nkb, n_rt;
+    int tile_rows;     // 16, or 12 when that makes fewer or cheaper passes (three sums per lane instead of four)
     int4 *a8;          // [n_rt][nkb][4 digit groups][64 lanes] 16 bytes each (+ one block of padding): lane (r, g) = row
                        // 16 rt + 4 (r % 4) + r / 4, terms 8 kb + 2 g and + 1, eight digits of group G each
     uint32_t *crow;    // [n_rt * 16][16]: 9 radix-2^29 digits of the per-row constant
@@ -65,7 +66,8 @@ __device__ unsigned long long g_mm8w_t[1024 * 8];
 #define MM8W_T(k) do { } while (0)
 #endif
 
-template <bool CHECK, int PEEL>
+// K = outputs kept per lane: 4 (row tiles of 16 rows) or 3 (row tiles of 12: the fourth row of every group of the MFMA tile is padding)
+template <bool CHECK, int PEEL, int K>
 __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
                                                  const uint32_t *__restrict__ zero_src,
                                                  const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
@@ -95,12 +97,13 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     for (int i = threadIdx.x; i < n_rt * 16 * 16; i += 256) crl[i] = crowd[i];
     for (int i = threadIdx.x; i < n_rt * 16; i += 256) {
         uint64_t e = 0;
-        if (i < n_out) {
+        const int row = (i >> 4) * (4 * K) + (i & 15);          // slot i = 16 rt + 4 r + g holds row 4 K rt + 4 r + g when r < K
+        if ((i & 15) < 4 * K && row < n_out) {
             int erow = 0;
             // CHECK: a flag per row (compare with the same row), or a map: 1 + the row of the compare view, 0 = a row to store
-            if constexpr (CHECK) erow = mask_is_map ? check_mask[i] : (check_mask[i] ? i + 1 : 0);
+            if constexpr (CHECK) erow = mask_is_map ? check_mask[row] : (check_mask[row] ? row + 1 : 0);
             if (erow) e = (uint64_t)(uintptr_t)(cmp_pk + (int64_t)(erow - 1) * cmp_sl * 8) | 2u;
-            else if (!CHECK || i < n_store) e = (uint64_t)(uintptr_t)(out_pk + (int64_t)i * out_sl * 8) | 1u;
+            else if (!CHECK || row < n_store) e = (uint64_t)(uintptr_t)(out_pk + (int64_t)row * out_sl * 8) | 1u;
         }
         rowdst[i] = e;
     }
@@ -137,12 +140,12 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     const uint64_t out_lim = out_count >= (int64_t)1 << 56 ? ~(uint64_t)0 : (uint64_t)(uintptr_t)(out_pk + out_count * 8);
     // The sums of the pass before (17 words per output) and where they go: reduced, compared and stored INSIDE the next
     // pass's MFMA phase (gen_mm8w.py).  mode: 0 nothing, 1 store to addr, 2 compare with the row at addr.
-    uint32_t w[4][17];
-    uint32_t crl_addr, mode[4];
-    uint64_t addr[4], flag = 0;
+    uint32_t w[K][17];
+    uint32_t crl_addr, mode[K];
+    uint64_t addr[K], flag = 0;
     crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)crl;
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
+    for (int r = 0; r < K; r++) {
 #pragma unroll
         for (int j = 0; j < 17; j++) w[r][j] = 0;
         mode[r] = 0; addr[r] = 0;
@@ -170,17 +173,22 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #define MM8W_ARGS w, xa, va, cnt, flag, abase, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
-                if constexpr (CHECK) {
-                    if constexpr (PEEL == 1) mm8w_pass_check_p1(MM8W_ARGS);
-                    else if constexpr (PEEL == 2) mm8w_pass_check_p2(MM8W_ARGS);
-                    else if constexpr (PEEL == 3) mm8w_pass_check_p3(MM8W_ARGS);
-                    else mm8w_pass_check_p4(MM8W_ARGS);
-                } else {
-                    if constexpr (PEEL == 1) mm8w_pass_p1(MM8W_ARGS);
-                    else if constexpr (PEEL == 2) mm8w_pass_p2(MM8W_ARGS);
-                    else if constexpr (PEEL == 3) mm8w_pass_p3(MM8W_ARGS);
-                    else mm8w_pass_p4(MM8W_ARGS);
-                }
+#define MM8W_PASS(SFX)                                                                     \
+    do {                                                                                   \
+        if constexpr (K == 4) {                                                            \
+            if constexpr (PEEL == 1) mm8w_pass##SFX##_p1_k4(MM8W_ARGS);                    \
+            else if constexpr (PEEL == 2) mm8w_pass##SFX##_p2_k4(MM8W_ARGS);               \
+            else if constexpr (PEEL == 3) mm8w_pass##SFX##_p3_k4(MM8W_ARGS);               \
+            else mm8w_pass##SFX##_p4_k4(MM8W_ARGS);                                        \
+        } else {                                                                           \
+            if constexpr (PEEL == 1) mm8w_pass##SFX##_p1_k3(MM8W_ARGS);                    \
+            else if constexpr (PEEL == 2) mm8w_pass##SFX##_p2_k3(MM8W_ARGS);               \
+            else if constexpr (PEEL == 3) mm8w_pass##SFX##_p3_k3(MM8W_ARGS);               \
+            else mm8w_pass##SFX##_p4_k3(MM8W_ARGS);                                        \
+        }                                                                                  \
+    } while (0)
+                if constexpr (CHECK) MM8W_PASS(_check); else MM8W_PASS();
+#undef MM8W_PASS
 #undef MM8W_ARGS
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -191,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                 const bool in_batch = chunk < n_chunks;
                 const uint64_t c_out = (uint64_t)(chunk * out_sc) * 32u, c_cmp = (uint64_t)(chunk * cmp_sc) * 32u;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
+                for (int r = 0; r < K; r++) {
                     const uint64_t e = rowdst[16 * rt + 4 * r + g];
                     const uint32_t m = (uint32_t)e & 3u;
                     const uint64_t a = (e & ~(uint64_t)3) + (m == 2 ? c_cmp : c_out);
@@ -223,8 +231,10 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     {
         uint32_t xa = 0, va = 0, cnt = 0;
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (CHECK) mm8w_reduce_check(w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode);
-        else mm8w_reduce(w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode);
+#define MM8W_ARGS w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
+        if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_k4(MM8W_ARGS); else mm8w_reduce_check_k3(MM8W_ARGS); }
+        else { if constexpr (K == 4) mm8w_reduce_k4(MM8W_ARGS); else mm8w_reduce_k3(MM8W_ARGS); }
+#undef MM8W_ARGS
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (CHECK) {
@@ -344,7 +354,13 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE")) return HB_ERR_UNSUPPORTED;
     if (ctx->n_limbs != 4 || n_out < 1 || n_in < 1) return HB_ERR_UNSUPPORTED;
     if (!prescale_params(ctx)) return HB_ERR_UNSUPPORTED;              // 2^254 <= p < 2^256
-    const int d = n_in, nkb = (d + 7) / 8, n_rt = (n_out + 15) / 16;       // K-blocks of 8 terms
+    const int d = n_in, nkb = (d + 7) / 8;                                 // K-blocks of 8 terms
+    // Row tiles of 16 rows, or of 12 (the fourth row of every group of the MFMA tile left empty): a pass costs its MFMA phase plus
+    // ~490 instructions per output a lane keeps (reduction + word assembly), all at the same ~5.5 cycles each -- 22 rows are two
+    // passes either way, and two passes of three outputs beat two of four.
+    const double per_pass16 = 228.0 * nkb + 160 + 4 * 490, per_pass12 = 228.0 * nkb + 160 + 3 * 490;
+    const int tile_rows = (!getenv("HB_MM8W_TILE16") && ((n_out + 11) / 12) * per_pass12 < ((n_out + 15) / 16) * per_pass16) ? 12 : 16;
+    const int n_rt = (n_out + tile_rows - 1) / tile_rows;
     int tpw = 0, nbuf = 0;
     if (!mm8w_shape(n_rt, nkb, 1, 1, &tpw, &nbuf)) return HB_ERR_UNSUPPORTED;
     const Big p = big_from_limbs(ctx->p_limbs, 4);
@@ -360,7 +376,7 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
             if (big_ge(ev, p)) return fail(ctx, HB_ERR_BAD_ARG, "mm8w: matrix entry is not a canonical residue");
             big_add(rowsum[i], ev);
             // lane (r, g) of K-block kb = l / 8 holds terms 8 kb + 2 g and 8 kb + 2 g + 1: g = (l % 8) / 2, element el = l % 2
-            const int rt = i / 16, j16 = i % 16, r = 4 * (j16 % 4) + j16 / 4, kb = l / 8, g = (l % 8) / 2, el = l & 1;
+            const int rt = i / tile_rows, j16 = i % tile_rows, r = 4 * (j16 % 4) + j16 / 4, kb = l / 8, g = (l % 8) / 2, el = l & 1;
             int carry = 0;
             for (int b = 0; b < 32; b++) {
                 int t = (int)((e[b >> 3] >> (8 * (b & 7))) & 0xffu) + carry;
@@ -394,10 +410,10 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
         Big corr = big_mod(big_mul(c80, rowsum[i]), p);
         if (!big_ge(corr, biasmod)) big_add(corr, p);
         big_sub(corr, biasmod);                                 // in [0, p)
-        to_digits(corr, &cr[(size_t)i * 16], 9);
+        to_digits(corr, &cr[((size_t)(i / tile_rows) * 16 + i % tile_rows) * 16], 9);      // slot 16 rt + 4 r + g
     }
     Mm8wMatrix *m = new Mm8wMatrix();
-    m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr; m->bias = bias; m->wp = nullptr;
+    m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->tile_rows = tile_rows; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr; m->bias = bias; m->wp = nullptr;
     WideParams wph;
     memset(&wph, 0, sizeof wph);
     for (int k = 0; k < 10; k++) to_digits(big_mod(big_pow2(29 * (9 + k), 18), p), wph.T[k], 9);
@@ -438,22 +454,24 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
     if (blocks > n_units) blocks = n_units;
     const size_t lds = mm8w_lds_bytes(m->n_rt, m->nkb, tpw, nbuf);
     const bool check = check_mask_dev != nullptr;
-#define MM8W_LAUNCH(CHK, PL)                                                                                                          \
+#define MM8W_LAUNCH_K(CHK, PL, KK)                                                                                                         \
     do {                                                                                                                              \
         static bool attr_done = false;                                                                                                \
         if (!attr_done) {                                                                                                             \
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK, PL>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK, PL, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_done = true;                                                                                                         \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_mm8w<CHK, PL>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
+        hipLaunchKernelGGL((k_mm8w<CHK, PL, KK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
                            m->n_out, m->n_rt, m->nkb, tpw, nbuf, C, n_units, m->bias, m->wp);                                        \
     } while (0)
     // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
     const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);
+#define MM8W_LAUNCH(CHK, PL) do { if (m->tile_rows == 12) MM8W_LAUNCH_K(CHK, PL, 3); else MM8W_LAUNCH_K(CHK, PL, 4); } while (0)
     if (check) { if (peel == 1) MM8W_LAUNCH(true, 1); else if (peel == 2) MM8W_LAUNCH(true, 2); else if (peel == 3) MM8W_LAUNCH(true, 3); else MM8W_LAUNCH(true, 4); }
     else { if (peel == 1) MM8W_LAUNCH(false, 1); else if (peel == 2) MM8W_LAUNCH(false, 2); else if (peel == 3) MM8W_LAUNCH(false, 3); else MM8W_LAUNCH(false, 4); }
+#undef MM8W_LAUNCH_K
 #undef MM8W_LAUNCH
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;

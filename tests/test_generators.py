@@ -34,10 +34,14 @@ def test_resolve_waits_counts_vector_memory_operations(gen):
     assert gen.resolve_waits(["@ELOAD", ld, ld, "global_store_dwordx4 v[4:5], v[0:3], off", "@EWAIT"])[-1] == "s_waitcnt vmcnt(1)"
 
 
+@pytest.mark.parametrize("nout", [4, 3])
 @pytest.mark.parametrize("check", [False, True])
 @pytest.mark.parametrize("peel", [1, 2, 3, 4])
-def test_pass_structure(gen, check, peel):
-    o, lines = gen.pass_lines(check, peel)
+def test_pass_structure(gen, check, peel, nout):
+    o, lines = gen.pass_lines(check, peel, nout)
+    # a lane keeps nout of its four sums (row tiles of 4 nout rows): that many reductions, stores, word columns
+    assert sum(ln.startswith("global_store_dwordx4") for ln in lines) == 2 * nout
+    assert sum(ln.startswith("v_accvgpr_read_b32") for ln in lines) == gen.NC * nout
     text = "\n".join(lines)
     assert "@E" not in text
     mf = [ln for ln in lines if ln.startswith("v_mfma")]
@@ -79,11 +83,12 @@ def test_pass_structure(gen, check, peel):
     assert last_block
 
 
-def test_reduction_units_cover_every_output(gen):
+@pytest.mark.parametrize("nout", [4, 3])
+def test_reduction_units_cover_every_output(gen, nout):
     for check in (False, True):
-        o, lines = gen.reduce_lines(check)
+        o, lines = gen.reduce_lines(check, nout)
         stores = [ln for ln in lines if ln.startswith("global_store_dwordx4")]
-        assert len(stores) == 8                      # two 16-byte stores per output
+        assert len(stores) == 2 * nout               # two 16-byte stores per output
         if check:
-            assert sum(ln.startswith("global_load_dwordx4") for ln in lines) == 8
-            assert sum(ln.startswith("v_cmp_ne_u32") for ln in lines) == 4
+            assert sum(ln.startswith("global_load_dwordx4") for ln in lines) == 2 * nout
+            assert sum(ln.startswith("v_cmp_ne_u32") for ln in lines) == nout
