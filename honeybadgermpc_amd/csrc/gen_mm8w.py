@@ -26,6 +26,9 @@ between its own MFMAs: up to four K-blocks are written out, each carrying an equ
 them are a loop of two-block bodies, so the code does not grow with the inner dimension.  After its last pass a wave
 runs the reduction alone (mm8w_reduce).
 
+Every pass exists for lanes that keep 4 sums (row tiles of 16 rows) and 3 sums (12 rows: the fourth row of every group of the
+MFMA tile is empty, its reduction and word assembly are not emitted); hb_mfma_wide.hip picks per matrix.
+
 Register files (VGPRs the statement owns: v96 .. v255): v164.. the MFMA operand files (two file sets, the next group's
 shifts built from the other set while the current group's MFMAs issue; element prefetch XB, digit buffers ABUF of two
 K-block parities); v96 .. v163 the reduction (ten 64-bit columns, two buffers for the T_k rows, the packed

@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r02ao
+O=gpurun_out/r02av
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 400 python scratch/stress_wide.py 300 41 > $O/stress_wide.txt 2>&1
