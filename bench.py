@@ -730,7 +730,7 @@ def main():
                 "fused_decode_validate": dt_unfused is not None,
                 "shares_per_s_per_gpu_three_full_encodes": (B * args.steps / dt_unfused) if dt_unfused else None,
                 "fused_decode_validate_note": "each decode launch also produces the guess's values at the compared points as (V[zc] Vinv) y and compares them "
-                                              "(HB_OPEN_OPT_FUSED_VALIDATE: default on for full-size matrix entries and from 8 coefficients up; same results, "
+                                              "(HB_OPEN_OPT_FUSED_VALIDATE, default on; same results, "
                                               "same accept/reject as the reference's decode + encode_batch + compare); three_full_encodes = the option off: "
                                               "decode, re-encode ALL n points on the plan's own kernels, compare -- the round-1 definition of `value`",
                 "shares_per_s_per_gpu_fused_validate_on_request": (B * args.steps / dt_fused_optin) if dt_fused_optin else None,

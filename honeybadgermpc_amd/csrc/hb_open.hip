@@ -195,10 +195,11 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
             if (pl->Vinv8) PLAN_HIP(hipMalloc(&pl->scaled_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
         }
     }
-    // Full tables on the full-size matrix-core kernel: the decode (fused with the validation) of every plan whose entries are
-    // not small integers, and of small-entry plans from 8 coefficients up, where one k_mm8w launch over [V^-1 rows ; V[zc] V^-1]
-    // beats pre-scale + decode + validating re-encode on k_mm8 (n = 64, t = 21: 0.15 against 0.20 ms for the two decodes;
-    // below 8 coefficients the three small launches win: scratch/fused_vs_default.py); the encodes unless they are NTTs or k_mm8.
+    // Full tables on the full-size matrix-core kernel for plans whose entries are not small integers: the decode, and the encodes
+    // unless they are NTTs.  (Every plan from 4 coefficients up also decodes + validates there in ONE launch over
+    // [V^-1 rows ; V[zc] V^-1] once it has decoded twice -- ensure_fused; it beats pre-scale + decode + validating re-encode on
+    // k_mm8 at every size: n = 64, t = 21: 0.127 against 0.200 ms for the two decodes, n = 8, t = 3: 0.170 against 0.180;
+    // scratch/fused_vs_default.py.)
     if (!pl->V8 && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
         std::vector<uint64_t> xz((size_t)d * L);
         for (int i = 0; i < d; i++) memcpy(&xz[(size_t)i * L], x_host + (size_t)z_host[i] * L, (size_t)L * 8);
@@ -211,8 +212,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         if ((pl->Winv8 || pl->Vw8) && !pl->coef_pk) PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
     }
     // the fused matrices are built when the plan decodes for the third time (ensure_fused), or at once on request (set_option)
-    pl->fused_pending = ((pl->V8 ? d >= 8 : pl->Winv8 != nullptr) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") &&
-                         !getenv("HB_NO_FUSED_VALIDATE")) ? 1 : 0;
+    pl->fused_pending = ((pl->V8 || pl->Winv8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") && !getenv("HB_NO_FUSED_VALIDATE")) ? 1 : 0;
     PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
 #undef PLAN_HIP
@@ -368,7 +368,7 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
     if (option == HB_OPEN_OPT_FUSED_VALIDATE) {
         pl->use_fused = value ? 1 : 0;
         if (value && !pl->F1) {
-            // asked for explicitly: built now (also for small-entry plans below 8 coefficients, which do not get it by default)
+            // asked for explicitly: built now instead of at the third decode
             int rc = ensure_fused(pl, 0);
             if (rc) return rc;
         }

@@ -166,8 +166,7 @@ int hb_open_status(hb_open_plan *plan, void *stream);
  * and the validating re-encode run as an exact int8 GEMM on the matrix cores (csrc/hb_mfma.hip); 0 forces
  * the integer-VALU kernels.  Results are bit-identical either way.  get_option reports whether the
  * matrix-core path is in use for this plan (0 when the plan's shapes do not qualify).
- * HB_OPEN_OPT_FUSED_VALIDATE (default 1): plans whose matrix entries are full-size residues (omega-power points, powers
- * beyond 2^127), and small-entry plans from 8 coefficients up (below that on request: set the option to 1), decode AND
+ * HB_OPEN_OPT_FUSED_VALIDATE (default 1): plans on the matrix cores with at least 4 coefficients and 4 points decode AND
  * validate in one launch of the full-size matrix-core kernel: the value the guess takes at a later
  * arrival's point is a linear function of the arrival set, V[zc] (Vinv y) = (V[zc] Vinv) y, so the rows [Vinv rows wanted ;
  * V[zc] Vinv] applied to the received columns give the coefficients and the predictions to compare (reference:
