@@ -6,6 +6,9 @@ Element layout: int64 tensor of shape (count, 4) holding little-endian 4 x uint6
 limbs of canonical residues -- the layout of the C ABI (include/hbmpc_hip.h).
 """
 import ctypes
+import os
+import threading
+from collections import OrderedDict
 
 import numpy as np
 
@@ -221,6 +224,35 @@ class BatchOpenPipeline:
         return res
 
 
+class _PlanCache(threading.local):
+    """Open plans of this thread, most recently used last.  A plan costs ~2 ms to create (tables, images, a handful of
+    synchronisations) -- as much as decoding 2^20 shares -- and consecutive opens of an MPC program see the same few arrival
+    patterns; a plan is immutable apart from its mismatch flag, which its user reads right after the launch it belongs to (no
+    await in between), so plans are shared between the decoders of one thread and never across threads."""
+
+    def __init__(self):
+        self.plans = OrderedDict()
+
+
+_plan_cache = _PlanCache()
+
+
+def cached_batch_open(modulus, n, t, z, zc, use_omega_powers=False, degree=None, max_shares=1 << 20, device=None):
+    """BatchOpen(...) through the per-thread LRU of plans (HB_PLAN_CACHE entries, default 16; 0 = no caching)."""
+    cap = int(os.environ.get("HB_PLAN_CACHE", "16"))
+    if cap <= 0:
+        return BatchOpen(modulus, n, t, z=z, zc=zc, use_omega_powers=use_omega_powers, degree=degree, max_shares=max_shares, device=device)
+    key = (int(modulus), n, t, tuple(z), tuple(zc), bool(use_omega_powers), degree, int(max_shares), device)
+    plans = _plan_cache.plans
+    plan = plans.pop(key, None)
+    if plan is None:
+        plan = BatchOpen(modulus, n, t, z=z, zc=zc, use_omega_powers=use_omega_powers, degree=degree, max_shares=max_shares, device=device)
+    plans[key] = plan
+    while len(plans) > cap:
+        plans.popitem(last=False)
+    return plan
+
+
 class DeviceIncrementalDecoder:
     """IncrementalDecoder (reference reed_solomon.py:232-403) on device tensors: columns arrive as (C, limbs) tensors
     and stay in one party-major buffer in HBM; the guess, its validation and the robust fallback are launches over all
@@ -276,8 +308,8 @@ class DeviceIncrementalDecoder:
 
     # -- kernels ---------------------------------------------------------------------------------
     def _plan(self, z, zc):
-        return BatchOpen(self.ctx.modulus, self.n, self.max_errors, z=z, zc=zc, use_omega_powers=self.use_omega_powers,
-                         degree=self.degree, max_shares=self.batch_size * (self.degree + 1), device=self.ctx.device)
+        return cached_batch_open(self.ctx.modulus, self.n, self.max_errors, z, zc, use_omega_powers=self.use_omega_powers,
+                                 degree=self.degree, max_shares=self.batch_size * (self.degree + 1), device=self.ctx.device)
 
     def _interpolate_and_check(self, z, zc):
         """coefficients of every polynomial from the arrived rows z of the party-major buffer, validated against rows zc:

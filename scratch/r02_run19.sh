@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r02as
+O=gpurun_out/r02ay
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1
