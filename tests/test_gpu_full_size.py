@@ -332,3 +332,56 @@ def test_table_caches_are_bounded(monkeypatch):
     tables = ctx.cache_entries()
     ctx.cache_clear()
     assert ctx.cache_entries() == 0 and tables >= 1
+
+
+def test_open_plans_are_cached_per_thread(monkeypatch):
+    """A plan costs ~2 ms to build; the device decoder takes its plans from a per-thread LRU keyed by everything that
+    determines them, bounded by HB_PLAN_CACHE, and switched off by 0.  Two decoders fed the same arrival pattern share
+    plans and still decide independently (the mismatch flag is read right after the launch it belongs to)."""
+    import threading
+
+    import torch
+
+    from honeybadgermpc_amd import device
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import DeviceIncrementalDecoder, cached_batch_open
+
+    ctx = Context.get(P)
+    n, t, c = 16, 5, 40
+    d = t + 1
+    rnd = random.Random(4)
+    polys = [[rnd.randrange(P) for _ in range(d)] for _ in range(c)]
+    x = list(range(1, n + 1))
+    ev = oracle.vandermonde_batch_evaluate(x, polys, P)
+    cols = [ctx.upload_ints([ev[k][j] for k in range(c)]) for j in range(n)]
+    device._plan_cache.plans.clear()
+    a = cached_batch_open(P, n, t, list(range(d)), list(range(d, d + t)), max_shares=c * d)
+    assert cached_batch_open(P, n, t, list(range(d)), list(range(d, d + t)), max_shares=c * d) is a
+    assert cached_batch_open(P, n, t, list(range(1, d + 1)), [0], max_shares=c * d) is not a
+    seen = {}
+    th = threading.Thread(target=lambda: seen.setdefault("other", cached_batch_open(P, n, t, list(range(d)), list(range(d, d + t)), max_shares=c * d)))
+    th.start(); th.join()
+    assert seen["other"] is not a                   # never across threads
+    monkeypatch.setenv("HB_PLAN_CACHE", "2")
+    for s in range(5):
+        cached_batch_open(P, n, t, list(range(s, s + d)), [], max_shares=c * d)
+    assert len(device._plan_cache.plans) <= 2
+    monkeypatch.setenv("HB_PLAN_CACHE", "0")
+    assert cached_batch_open(P, n, t, list(range(d)), [], max_shares=c * d) is not cached_batch_open(P, n, t, list(range(d)), [], max_shares=c * d)
+    monkeypatch.delenv("HB_PLAN_CACHE")
+    # same arrival pattern twice, the second time with a liar: the shared plans must not leak the first run's verdict
+    device._plan_cache.plans.clear()
+    for liar in (None, 2):
+        dec = DeviceIncrementalDecoder(P, n, t, batch_size=c)
+        for j in range(n):
+            col = cols[j]
+            if liar == j:
+                col = col.clone(); col[:, 0] ^= 1
+            dec.add(j, col)
+            if dec.done():
+                break
+        coeffs, errs = dec.get_results()
+        assert ctx.download_ints(coeffs.reshape(c * d, -1)) == [v for row in polys for v in row]
+        assert errs == (set() if liar is None else {liar})
+    assert len(device._plan_cache.plans) >= 1
+    torch.cuda.synchronize()
