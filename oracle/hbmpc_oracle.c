@@ -803,8 +803,12 @@ static int wb_decode_one(const field_t *F, const fe *xs, int n, int k, const fe 
         fe *sol = (fe *)malloc((size_t)(cols - 1) * sizeof(fe));
         if (wb_some_solution(F, M, rows, cols, sol)) { free(M); free(sol); status = 2; break; }
         poly E, Q, Pq, R; poly_init(&E, env + 1); poly_init(&Q, qnv + 1); poly_init(&Pq, qnv + 1); poly_init(&R, qnv + 1);
-        for (int j = 0; j < env; j++) E.c[j] = sol[j]; E.deg = env - 1; poly_norm(&E);
-        for (int j = 0; j < qnv; j++) Q.c[j] = sol[env + j]; Q.deg = qnv - 1; poly_norm(&Q);
+        for (int j = 0; j < env; j++) E.c[j] = sol[j];
+        E.deg = env - 1;
+        poly_norm(&E);
+        for (int j = 0; j < qnv; j++) Q.c[j] = sol[env + j];
+        Q.deg = qnv - 1;
+        poly_norm(&Q);
         int exact = 0;
         if (E.deg >= 0) { poly_divrem(F, &Pq, &R, &Q, &E); exact = (R.deg < 0); }
         if (exact) { *out_len = Pq.deg + 1; for (int i = 0; i <= Pq.deg; i++) out[i] = Pq.c[i]; status = 0; }

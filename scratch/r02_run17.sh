@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r02al
+O=gpurun_out/r02ba
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1
