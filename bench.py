@@ -334,6 +334,8 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
     order = np.random.Generator(np.random.PCG64(2024)).permutation(n).tolist()     # one arrival order: it is one party's open
     z, zc = order[:d], order[d : d + t]
     so = ShardedOpen(BLS, n, t, B, gather_mode=args.gather, z=z, zc=zc, use_omega_powers=use_omega, device=local_rank)
+    if hasattr(so.op, "uses_fused_validate") and so.op.uses_fused_validate():
+        so.op.set_fused_validate(True)       # built now, not at the third decode (see main())
     b_loc, c_loc = so.local_shares, so.chunks
     shares0, r1_cols, r2_cols, secrets, _ = make_inputs_light(torch, ctx, n, t, b_loc, use_omega, seed=1000 + rank)
     r1_out, r2_msg, result = ctx.empty(n * c_loc), ctx.empty(c_loc), ctx.empty(b_loc)
@@ -495,6 +497,10 @@ def main():
     z = order[:d]
     zc = order[d : d + t]
     op = BatchOpen(BLS, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=B, device=local_rank)
+    if op.uses_fused_validate():
+        # a plan builds its fused decode + validate matrices when it decodes for the third time (1-2.5 ms, with a stream
+        # synchronise); a benchmark that may be run with --warmup 0 asks for them now instead of inside its timed region
+        op.set_fused_validate(True)
     if args.no_matrix_cores:
         op.set_matrix_cores(False)
     r1_out = ctx.empty(n * C)
