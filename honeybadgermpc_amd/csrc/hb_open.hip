@@ -64,6 +64,16 @@ struct hb_open_plan {
     int32_t *fmap1, *fmap2;      // per row: 0 = a result row, else 1 + the received row to compare the prediction with
 };
 
+// the digit planes of the integer-VALU kernels (2 x 36 B per share): plans on the matrix cores never touch them
+static int valu_planes(hb_open_plan *pl) {
+    if (pl->in_dg && pl->coef_dg) return HB_OK;
+    hb_ctx *ctx = pl->ctx;
+    const size_t bytes = (size_t)pl->max_C * pl->d * ctx->nl() * 4;
+    if (!pl->in_dg && hipMalloc(&pl->in_dg, bytes) != hipSuccess) return fail(ctx, HB_ERR_HIP, "open plan: hipMalloc(in_dg)");
+    if (!pl->coef_dg && hipMalloc(&pl->coef_dg, bytes) != hipSuccess) return fail(ctx, HB_ERR_HIP, "open plan: hipMalloc(coef_dg)");
+    return HB_OK;
+}
+
 // [rows of Winv ; V[zc] Winv] as int8 images.  V[zc] Winv is computed on the device (the plain mat-vec over the columns of
 // Winv) and read back once; UNSUPPORTED shapes leave F1 / F2 null and the plan on its two-launch path.
 static int build_fused(hb_open_plan *pl, const uint64_t *x_host, hipStream_t s) {
@@ -168,8 +178,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         for (int j = 0; j < n_check; j++) { mask[zc_host[j]] = 1; pl->zc.push_back(zc_host[j]); }
         rc = own_int_array(ctx, mask.data(), n + 1, &pl->mask_dev, s); if (rc) goto done;
     }
-    PLAN_HIP(hipMalloc(&pl->in_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
-    PLAN_HIP(hipMalloc(&pl->coef_dg, (size_t)pl->max_C * d * ctx->nl() * 4));
+    // (in_dg / coef_dg, the digit planes of the integer-VALU kernels, are allocated by the first launch that needs them: valu_planes)
     if (use_omega_powers && omega_host && order >= n && order > 0 && (order & (order - 1)) == 0) {
         // MADs per chunk: full-digit mat-vec n*d*NL^2 vs butterflies (order/2)*log2(order)*(2 NL^2 + 4 NL)
         int logn = 0; while ((1 << logn) < order) logn++;
@@ -239,6 +248,7 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
     if (pl->Vw8 && pl->use_v8)
         return launch_mm8w(pl->ctx, pl->Vw8, (const uint32_t *)shares_dev, iv, nullptr, B, (uint32_t *)r1_out_dev, ov, INT64_MAX,
                            nullptr, nullptr, C, s);
+    if (int rc = valu_planes(pl)) return rc;
     return launch_matvec2(pl->ctx, pl->V, nullptr, (const uint32_t *)shares_dev, iv, nullptr, B, pl->in_dg,
                           (uint32_t *)r1_out_dev, ov, INT64_MAX, pl->n, 0, nullptr, nullptr, nullptr, C, s);
 }
@@ -260,7 +270,9 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
     if (pl->ntt_order) {
         // decode to canonical coefficient-major coefficients, validate with an NTT in CHECK mode,
         // then hand the caller the rows it asked for
-        int rc = pl->Winv8 && pl->use_v8
+        int rc = (pl->Winv8 && pl->use_v8) ? HB_OK : valu_planes(pl);
+        if (rc) return rc;
+        rc = pl->Winv8 && pl->use_v8
                      ? launch_mm8w(pl->ctx, pl->Winv8, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->coef_pk, pm, INT64_MAX, nullptr, nullptr, C, s)
                      : launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
                                       pl->coef_pk, pm, INT64_MAX, pl->d, 1, nullptr, nullptr, nullptr, C, s);
@@ -281,6 +293,8 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
             if (rc) return rc;
             rc = launch_mm8(pl->ctx, pl->Vinv8, pl->scaled_pk, pm, nullptr, INT64_MAX, pl->coef_pk, pm, INT64_MAX, nullptr, nullptr, C, s);
         } else {
+            rc = valu_planes(pl);
+            if (rc) return rc;
             rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,
                                 pl->coef_pk, pm, INT64_MAX, pl->d, 0, nullptr, nullptr, nullptr, C, s, 0, pl->Vinv->K2);
         }
@@ -302,7 +316,9 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
         return launch_copy_view(pl->ctx, pl->coef_pk, pm, pk_dst, pv, C, pk_rows, pk_count, s);
     }
     // one launch when the shapes allow it (decode + validating re-encode of the same 64-chunk group)
-    int rc = launch_decode_check(pl->ctx, pl->Vinv, pl->V, (const uint32_t *)cols_dev, pm, pl->z_dev, pk_dst, pv, pk_count, pk_rows,
+    int rc = valu_planes(pl);
+    if (rc) return rc;
+    rc = launch_decode_check(pl->ctx, pl->Vinv, pl->V, (const uint32_t *)cols_dev, pm, pl->z_dev, pk_dst, pv, pk_count, pk_rows,
                                  pl->coef_dg, pl->mask_dev, pl->mismatch_dev, C, s, pl->validate_arrived_only);
     if (rc != HB_ERR_UNSUPPORTED) return rc;
     rc = launch_matvec2(pl->ctx, pl->Vinv, nullptr, (const uint32_t *)cols_dev, pm, pl->z_dev, INT64_MAX, pl->in_dg,

@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r02ay
+O=gpurun_out/r02bd
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python -m pytest tests -m gpu -q > $O/pytest.txt 2>&1
