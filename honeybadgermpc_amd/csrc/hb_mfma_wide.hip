@@ -86,26 +86,9 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     const int bufsz = tpw * nkb * 4 * 64;
     int64_t *rowoff = reinterpret_cast<int64_t *>(xbuf + (size_t)nbuf * bufsz + 128);   // [8 nkb] term -> element offset of its input row
     uint64_t *rowdst = reinterpret_cast<uint64_t *>(rowoff + 8 * nkb);      // [16 n_rt] where row i's elements go: address of its chunk 0 | mode (1 store, 2 compare), 0 = nowhere
-    if (threadIdx.x < 120) {
-        const int k = threadIdx.x / 12, j = threadIdx.x % 12;
-        reinterpret_cast<uint32_t *>(tlds)[threadIdx.x] = j < 9 ? wpp->T[k][j] : 0u;
-    }
     for (int l = threadIdx.x; l < 8 * nkb; l += 256) {
         const int lc = l < d ? l : d - 1;
         rowoff[l] = (int64_t)(in_rows ? in_rows[lc] : lc) * in_sl;
-    }
-    for (int i = threadIdx.x; i < n_rt * 16 * 16; i += 256) crl[i] = crowd[i];
-    for (int i = threadIdx.x; i < n_rt * 16; i += 256) {
-        uint64_t e = 0;
-        const int row = (i >> 4) * (4 * K) + (i & 15);          // slot i = 16 rt + 4 r + g holds row 4 K rt + 4 r + g when r < K
-        if ((i & 15) < 4 * K && row < n_out) {
-            int erow = 0;
-            // CHECK: a flag per row (compare with the same row), or a map: 1 + the row of the compare view, 0 = a row to store
-            if constexpr (CHECK) erow = mask_is_map ? check_mask[row] : (check_mask[row] ? row + 1 : 0);
-            if (erow) e = (uint64_t)(uintptr_t)(cmp_pk + (int64_t)(erow - 1) * cmp_sl * 8) | 2u;
-            else if (!CHECK || row < n_store) e = (uint64_t)(uintptr_t)(out_pk + (int64_t)row * out_sl * 8) | 1u;
-        }
-        rowdst[i] = e;
     }
     __syncthreads();
     // slot s = ((t * nkb + kb) * 2 + e) * 2 + h holds half h of element (chunk n, term 8 kb + 2 g + e) of tile t for lane (n, g): a
@@ -156,6 +139,24 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
     if (unit < n_units) issue_loads(unit, 0);
+    // the other tables are filled while the first unit's tiles are in flight (the DMA only needs the row offsets)
+    if (threadIdx.x < 120) {
+        const int k = threadIdx.x / 12, j = threadIdx.x % 12;
+        reinterpret_cast<uint32_t *>(tlds)[threadIdx.x] = j < 9 ? wpp->T[k][j] : 0u;
+    }
+    for (int i = threadIdx.x; i < n_rt * 16 * 16; i += 256) crl[i] = crowd[i];
+    for (int i = threadIdx.x; i < n_rt * 16; i += 256) {
+        uint64_t e = 0;
+        const int row = (i >> 4) * (4 * K) + (i & 15);          // slot i = 16 rt + 4 r + g holds row 4 K rt + 4 r + g when r < K
+        if ((i & 15) < 4 * K && row < n_out) {
+            int erow = 0;
+            // CHECK: a flag per row (compare with the same row), or a map: 1 + the row of the compare view, 0 = a row to store
+            if constexpr (CHECK) erow = mask_is_map ? check_mask[row] : (check_mask[row] ? row + 1 : 0);
+            if (erow) e = (uint64_t)(uintptr_t)(cmp_pk + (int64_t)(erow - 1) * cmp_sl * 8) | 2u;
+            else if (!CHECK || row < n_store) e = (uint64_t)(uintptr_t)(out_pk + (int64_t)row * out_sl * 8) | 1u;
+        }
+        rowdst[i] = e;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     MM8W_T(0);   // prologue
