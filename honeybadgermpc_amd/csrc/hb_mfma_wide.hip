@@ -48,6 +48,8 @@ static_assert(offsetof(WideParams, T) == 80, "gen_mm8w.py loads pbar, pneg, m0, 
 struct Mm8wMatrix {
     int n_out, d, nkb, n_rt;
     int tile_rows;     // 16, or 12 when that makes fewer or cheaper passes (three sums per lane instead of four)
+    mutable int64_t shape_tiles;                 // the launch geometry chosen for the last batch size (mm8w_shape simulates: not per launch)
+    mutable int shape_tpw, shape_nbuf, shape_rq;
     int4 *a8;          // [n_rt][nkb][4 digit groups][64 lanes] 16 bytes each (+ one block of padding): lane (r, g) = row
                        // 16 rt + 4 (r % 4) + r / 4, terms 8 kb + 2 g and + 1, eight digits of group G each
     uint32_t *crow;    // [n_rt * 16][16]: 9 radix-2^29 digits of the per-row constant
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                                                  uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
                                                  const uint32_t *__restrict__ cmp_pk, int64_t cmp_sc, int64_t cmp_sl, int mask_is_map, int n_store,
-                                                 int n_out, int n_rt, int nkb, int tpw, int nbuf, int64_t n_chunks, int64_t n_units,
+                                                 int n_out, int n_rt, int nkb, int tpw, int nbuf, int rq, int64_t n_chunks, int64_t n_units,
                                                  uint32_t bias, const WideParams *__restrict__ wpp) {
     extern __shared__ uint4 mm8w_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -94,12 +96,16 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     // slot s = ((t * nkb + kb) * 2 + e) * 2 + h holds half h of element (chunk n, term 8 kb + 2 g + e) of tile t for lane (n, g): a
     // wave always moves the same (e, h) of every K-block -- per slot a 64-bit LDS read (the row's offset), an add, a bound and the
     // DMA; the general address arithmetic per slot was ~10 % of a short pass (one wave per SIMD pays ~5.5 cycles per instruction)
+    // A unit = `tpw` tiles of 16 chunks x `rq` row tiles (unit u: tiles of u / n_quads, row tiles from rq (u % n_quads)): matrices
+    // of many row tiles and few chunk tiles (86 x 86 over 381 tiles) are cut by rows too, or a workgroup's two units of 6 passes
+    // each would take 4 pass-times where 2.2 are the average.
+    const int n_quads = (n_rt + rq - 1) / rq;
     auto issue_loads = [&](int64_t unit, int buf) {
         const int e = (wave >> 1) & 1, h = wave & 1;
         const uint4 *base = reinterpret_cast<const uint4 *>(in_pk) + h;
         const uint4 *zsrc = reinterpret_cast<const uint4 *>(zero_src) + h;
         for (int t = 0; t < tpw; t++) {
-            int64_t chunk = (unit * tpw + t) * 16 + n;
+            int64_t chunk = ((unit / n_quads) * tpw + t) * 16 + n;
             if (chunk >= n_chunks) chunk = n_chunks - 1;
             const int64_t cbase = chunk * in_sc;
             int64_t ro = rowoff[2 * g + e];
@@ -116,7 +122,6 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             }
         }
     };
-    const int n_pairs = tpw * n_rt;
     const int32_t k256 = 256, k64k = 1 << 16, k16m = 1 << 24;
     const int64_t bias4 = (int64_t)bias * 0x01010101ll, bias3 = (int64_t)bias * 0x00010101ll;   // the accumulator bias of 4 (3) columns
     const uint64_t wpa = (uint64_t)(uintptr_t)wpp;
@@ -163,9 +168,11 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     for (; unit < n_units; unit += gridDim.x) {
         const int64_t next = unit + gridDim.x;
         bool dma_issued = false;
+        const int rt_lo = (int)(unit % n_quads) * rq, rt_cnt = n_rt - rt_lo < rq ? n_rt - rt_lo : rq;
+        const int n_pairs = tpw * rt_cnt;
         for (int pidx = wave; pidx < n_pairs; pidx += 4) {
-            const int tl = pidx / n_rt, rt = pidx - tl * n_rt;
-            const int64_t chunk = (unit * tpw + tl) * 16 + n;
+            const int tl = pidx / rt_cnt, rt = rt_lo + pidx - tl * rt_cnt;
+            const int64_t chunk = ((unit / n_quads) * tpw + tl) * 16 + n;
             {
                 uint32_t xa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(xbuf + (size_t)buf * bufsz + (size_t)tl * nkb * 4 * 64 + lane);
                 uint32_t va = (uint32_t)lane * 16u;
@@ -306,21 +313,39 @@ size_t mm8w_lds_bytes(int n_rt, int nkb, int tpw, int nbuf) {
 }
 constexpr size_t MM8W_LDS_LIMIT = 156 * 1024;
 
-// tiles per unit and buffers: the (tile, row tile) pairs of a unit should fill the 4 waves' rounds, units should outnumber
-// the CUs when the batch allows, and the element buffer is doubled when LDS allows
-bool mm8w_shape(int n_rt, int nkb, int64_t n_tiles, int n_cus, int *tpw, int *nbuf) {
-    int best = 0;
-    double best_eff = 0.0;
+// Tiles per unit, row tiles per unit and buffers.  A workgroup's four waves take the (tile, row tile) passes of a unit in rounds,
+// units go round-robin over the workgroups: the candidates are simulated (pass-times of the slowest workgroup) and the fastest
+// wins; ties go to the larger row group (a tile is loaded once per row group), then to double buffering.
+bool mm8w_shape(int n_rt, int nkb, int64_t n_tiles, int n_cus, int *tpw, int *nbuf, int *rq) {
+    double best_cost = 0.0;
+    int best_t = 0, best_rq = 0, best_nbuf = 0;
+    const int rqs[3] = {n_rt, 8, 4};
     for (int t = 1; t <= 4; t++) {
         if (mm8w_lds_bytes(n_rt, nkb, t, 1) > MM8W_LDS_LIMIT) break;
-        if (t > 1 && n_tiles / t < (int64_t)n_cus) break;              // keep every CU busy first
-        const int pairs = t * n_rt;
-        const double eff = (double)pairs / (4.0 * ((pairs + 3) / 4));
-        if (eff > best_eff + 1e-9) { best_eff = eff; best = t; }
+        const int nb = mm8w_lds_bytes(n_rt, nkb, t, 2) <= MM8W_LDS_LIMIT ? 2 : 1;
+        for (int ri = 0; ri < 3; ri++) {
+            const int r = rqs[ri];
+            if (r > n_rt || (ri > 0 && r >= n_rt)) continue;
+            const int nq = (n_rt + r - 1) / r;
+            const int64_t units = ((n_tiles + t - 1) / t) * nq;
+            const int64_t G = units < n_cus ? units : n_cus;
+            // rounds of unit u = ceil(t * rows(u % nq) / 4); workgroup b takes u = b, b + G, ...
+            int64_t worst = 0;
+            for (int64_t b = 0; b < G && b < 4096; b++) {
+                int64_t sum = 0;
+                for (int64_t u = b; u < units; u += G) {
+                    const int q = (int)(u % nq), cnt = n_rt - q * r < r ? n_rt - q * r : r;
+                    sum += (t * cnt + 3) / 4;
+                }
+                if (sum > worst) worst = sum;
+            }
+            // a pass-time each, plus what a unit costs beyond its passes (barrier, DMA wait: ~6 % of a pass, twice that unbuffered)
+            const double cost = (double)worst + 0.06 * (nb == 2 ? 1 : 2) * (double)((units + G - 1) / G);
+            if (!best_t || cost < best_cost - 1e-9) { best_cost = cost; best_t = t; best_rq = r; best_nbuf = nb; }
+        }
     }
-    if (!best) return false;
-    *tpw = best;
-    *nbuf = mm8w_lds_bytes(n_rt, nkb, best, 2) <= MM8W_LDS_LIMIT ? 2 : 1;
+    if (!best_t) return false;
+    *tpw = best_t; *rq = best_rq; *nbuf = best_nbuf;
     return true;
 }
 
@@ -362,8 +387,8 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     const double per_pass16 = 228.0 * nkb + 160 + 4 * 490, per_pass12 = 228.0 * nkb + 160 + 3 * 490;
     const int tile_rows = (!getenv("HB_MM8W_TILE16") && ((n_out + 11) / 12) * per_pass12 < ((n_out + 15) / 16) * per_pass16) ? 12 : 16;
     const int n_rt = (n_out + tile_rows - 1) / tile_rows;
-    int tpw = 0, nbuf = 0;
-    if (!mm8w_shape(n_rt, nkb, 1, 1, &tpw, &nbuf)) return HB_ERR_UNSUPPORTED;
+    int tpw = 0, nbuf = 0, rq = 0;
+    if (!mm8w_shape(n_rt, nkb, 1, 1, &tpw, &nbuf, &rq)) return HB_ERR_UNSUPPORTED;
     const Big p = big_from_limbs(ctx->p_limbs, 4);
     // balanced base-256 digits (an int8 operand is signed), row sums and the column bound
     std::vector<uint8_t> a(((size_t)n_rt * nkb + 1) * 4 * 64 * 16, 0);      // one block of padding
@@ -414,7 +439,7 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
         to_digits(corr, &cr[((size_t)(i / tile_rows) * 16 + i % tile_rows) * 16], 9);      // slot 16 rt + 4 r + g
     }
     Mm8wMatrix *m = new Mm8wMatrix();
-    m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->tile_rows = tile_rows; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr; m->bias = bias; m->wp = nullptr;
+    m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->tile_rows = tile_rows; m->shape_tiles = -1; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr; m->bias = bias; m->wp = nullptr;
     WideParams wph;
     memset(&wph, 0, sizeof wph);
     for (int k = 0; k < 10; k++) to_digits(big_mod(big_pow2(29 * (9 + k), 18), p), wph.T[k], 9);
@@ -447,10 +472,14 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
                 uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                 int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store) {
     if (C <= 0) return HB_OK;
-    int tpw = 1, nbuf = 1;
+    int tpw = 1, nbuf = 1, rq = m->n_rt;
     const int64_t n_tiles = (C + 15) / 16;
-    if (!mm8w_shape(m->n_rt, m->nkb, n_tiles, mm8w_num_cus(), &tpw, &nbuf)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: shape");
-    const int64_t n_units = (n_tiles + tpw - 1) / tpw;
+    if (m->shape_tiles == n_tiles) { tpw = m->shape_tpw; nbuf = m->shape_nbuf; rq = m->shape_rq; }
+    else {
+        if (!mm8w_shape(m->n_rt, m->nkb, n_tiles, mm8w_num_cus(), &tpw, &nbuf, &rq)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: shape");
+        m->shape_tiles = n_tiles; m->shape_tpw = tpw; m->shape_nbuf = nbuf; m->shape_rq = rq;
+    }
+    const int64_t n_units = ((n_tiles + tpw - 1) / tpw) * ((m->n_rt + rq - 1) / rq);
     int64_t blocks = mm8w_num_cus();
     if (blocks > n_units) blocks = n_units;
     const size_t lds = mm8w_lds_bytes(m->n_rt, m->nkb, tpw, nbuf);
@@ -465,7 +494,7 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
         hipLaunchKernelGGL((k_mm8w<CHK, PL, KK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
-                           m->n_out, m->n_rt, m->nkb, tpw, nbuf, C, n_units, m->bias, m->wp);                                        \
+                           m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp);                                        \
     } while (0)
     // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
     const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);

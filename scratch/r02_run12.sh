@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r02be
+O=gpurun_out/r02bf
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python scratch/test_mm8w.py > $O/mm8w.txt 2>&1; python -m pytest tests/test_gpu_parity.py tests/test_gpu_full_size.py tests/test_gpu_offline.py -m gpu -q -x > $O/pytest.txt 2>&1
