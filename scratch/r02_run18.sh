@@ -1,5 +1,5 @@
 #!/bin/bash
-O=gpurun_out/r02final9
+O=gpurun_out/r02final11
 mkdir -p $O
 cd $GRAFT_REPO_ROOT
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
