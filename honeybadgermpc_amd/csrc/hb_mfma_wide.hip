@@ -331,7 +331,13 @@ bool mm8w_shape(int n_rt, int nkb, int64_t n_tiles, int n_cus, int *tpw, int *nb
             const int64_t G = units < n_cus ? units : n_cus;
             // rounds of unit u = ceil(t * rows(u % nq) / 4); workgroup b takes u = b, b + G, ...
             int64_t worst = 0;
-            for (int64_t b = 0; b < G && b < 4096; b++) {
+            if (units > 64 * G) {
+                // many units per workgroup: every workgroup sees every kind of unit equally often
+                int64_t per_period = 0;
+                for (int q = 0; q < nq; q++) { const int cnt = n_rt - q * r < r ? n_rt - q * r : r; per_period += (t * cnt + 3) / 4; }
+                worst = (per_period * ((units + G - 1) / G) + nq - 1) / nq;
+            } else
+            for (int64_t b = 0; b < G; b++) {
                 int64_t sum = 0;
                 for (int64_t u = b; u < units; u += G) {
                     const int q = (int)(u % nq), cnt = n_rt - q * r < r ? n_rt - q * r : r;
