@@ -221,7 +221,8 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         if ((pl->Winv8 || pl->Vw8) && !pl->coef_pk) PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
     }
     // the fused matrices are built when the plan decodes for the third time (ensure_fused), or at once on request (set_option)
-    pl->fused_pending = ((pl->V8 || pl->Winv8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") && !getenv("HB_NO_FUSED_VALIDATE")) ? 1 : 0;
+    pl->fused_pending = ((pl->V8 || pl->Winv8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") && !getenv("HB_NO_FUSED_VALIDATE") &&
+                         !getenv("HB_NO_MFMA_WIDE") && ctx->n_limbs == 4 && prescale_params(ctx)) ? 1 : 0;
     PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
 #undef PLAN_HIP

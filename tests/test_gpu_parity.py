@@ -271,8 +271,9 @@ def test_batch_open_vs_oracle(n, t, b, use_omega, matrix_cores):
         assert op.ok()
     # full-size entries decode and validate in one launch (include/hbmpc_hip.h, HB_OPEN_OPT_FUSED_VALIDATE); switched off
     # the plan decodes, re-encodes all n points and compares: same values, same decisions
-    assert op.uses_fused_validate() == (matrix_cores and (eligible_wide or (eligible and d >= 4 and n >= 4)))
-    if matrix_cores and eligible and d >= 4:
+    fused_off = bool(os.environ.get("HB_NO_FUSED_VALIDATE") or os.environ.get("HB_NO_MFMA_WIDE") or os.environ.get("HB_NO_MFMA_DECODE"))   # A/B hooks
+    assert op.uses_fused_validate() == (matrix_cores and not fused_off and (eligible_wide or (eligible and d >= 4 and n >= 4)))
+    if matrix_cores and eligible and d >= 4 and not fused_off:
         op.set_fused_validate(True)     # small-entry plans build the fused matrices on request
         assert op.uses_fused_validate()
     if op.uses_fused_validate():
