@@ -26,8 +26,8 @@ between its own MFMAs: up to four K-blocks are written out, each carrying an equ
 them are a loop of two-block bodies, so the code does not grow with the inner dimension.  After its last pass a wave
 runs the reduction alone (mm8w_reduce).
 
-Every pass exists for lanes that keep 4 sums (row tiles of 16 rows) and 3 sums (12 rows: the fourth row of every group of the
-MFMA tile is empty, its reduction and word assembly are not emitted); hb_mfma_wide.hip picks per matrix.
+Every pass exists for lanes that keep 4 sums (row tiles of 16 rows), 3 sums (12 rows: the fourth row of every group of the
+MFMA tile is empty, its reduction and word assembly are not emitted) and 2 sums (8 rows); hb_mfma_wide.hip picks per matrix.
 
 Register files (VGPRs the statement owns: v96 .. v255): v164.. the MFMA operand files (two file sets, the next group's
 shifts built from the other set while the current group's MFMAs issue; element prefetch XB, digit buffers ABUF of two
@@ -497,7 +497,7 @@ def emit():
     out = ["// GENERATED by gen_mm8w.py -- do not edit", ""]
     for check in (False, True):
         sfx = "_check" if check else ""
-        for nout in (4, 3):
+        for nout in (4, 3, 2):
             for peel in PEELS:
                 o, lines = pass_lines(check, peel, nout)
                 out += emit_fn(f"mm8w_pass{sfx}_p{peel}_k{nout}", o, lines, check)

@@ -47,7 +47,7 @@ static_assert(offsetof(WideParams, T) == 80, "gen_mm8w.py loads pbar, pneg, m0, 
 
 struct Mm8wMatrix {
     int n_out, d, nkb, n_rt;
-    int tile_rows;     // 16, or 12 when that makes fewer or cheaper passes (three sums per lane instead of four)
+    int tile_rows;     // 16, or 12 / 8 when that makes fewer or cheaper passes (three / two sums per lane instead of four)
     mutable int64_t shape_tiles;                 // the launch geometry chosen for the last batch size (mm8w_shape simulates: not per launch)
     mutable int shape_tpw, shape_nbuf, shape_rq;
     int4 *a8;          // [n_rt][nkb][4 digit groups][64 lanes] 16 bytes each (+ one block of padding): lane (r, g) = row
@@ -68,7 +68,7 @@ __device__ unsigned long long g_mm8w_t[1024 * 8];
 #define MM8W_T(k) do { } while (0)
 #endif
 
-// K = outputs kept per lane: 4 (row tiles of 16 rows) or 3 (row tiles of 12: the fourth row of every group of the MFMA tile is padding)
+// K = outputs kept per lane: 4 (row tiles of 16 rows), 3 (row tiles of 12: the fourth row of every group of the MFMA tile is padding) or 2 (8)
 template <bool CHECK, int PEEL, int K>
 __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
                                                  const uint32_t *__restrict__ zero_src,
@@ -188,11 +188,16 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             else if constexpr (PEEL == 2) mm8w_pass##SFX##_p2_k4(MM8W_ARGS);               \
             else if constexpr (PEEL == 3) mm8w_pass##SFX##_p3_k4(MM8W_ARGS);               \
             else mm8w_pass##SFX##_p4_k4(MM8W_ARGS);                                        \
-        } else {                                                                           \
+        } else if constexpr (K == 3) {                                                     \
             if constexpr (PEEL == 1) mm8w_pass##SFX##_p1_k3(MM8W_ARGS);                    \
             else if constexpr (PEEL == 2) mm8w_pass##SFX##_p2_k3(MM8W_ARGS);               \
             else if constexpr (PEEL == 3) mm8w_pass##SFX##_p3_k3(MM8W_ARGS);               \
             else mm8w_pass##SFX##_p4_k3(MM8W_ARGS);                                        \
+        } else {                                                                           \
+            if constexpr (PEEL == 1) mm8w_pass##SFX##_p1_k2(MM8W_ARGS);                    \
+            else if constexpr (PEEL == 2) mm8w_pass##SFX##_p2_k2(MM8W_ARGS);               \
+            else if constexpr (PEEL == 3) mm8w_pass##SFX##_p3_k2(MM8W_ARGS);               \
+            else mm8w_pass##SFX##_p4_k2(MM8W_ARGS);                                        \
         }                                                                                  \
     } while (0)
                 if constexpr (CHECK) MM8W_PASS(_check); else MM8W_PASS();
@@ -240,8 +245,8 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         uint32_t xa = 0, va = 0, cnt = 0;
         __builtin_amdgcn_sched_barrier(0);
 #define MM8W_ARGS w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
-        if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_k4(MM8W_ARGS); else mm8w_reduce_check_k3(MM8W_ARGS); }
-        else { if constexpr (K == 4) mm8w_reduce_k4(MM8W_ARGS); else mm8w_reduce_k3(MM8W_ARGS); }
+        if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_check_k3(MM8W_ARGS); else mm8w_reduce_check_k2(MM8W_ARGS); }
+        else { if constexpr (K == 4) mm8w_reduce_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_k3(MM8W_ARGS); else mm8w_reduce_k2(MM8W_ARGS); }
 #undef MM8W_ARGS
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -387,11 +392,17 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     if (ctx->n_limbs != 4 || n_out < 1 || n_in < 1) return HB_ERR_UNSUPPORTED;
     if (!prescale_params(ctx)) return HB_ERR_UNSUPPORTED;              // 2^254 <= p < 2^256
     const int d = n_in, nkb = (d + 7) / 8;                                 // K-blocks of 8 terms
-    // Row tiles of 16 rows, or of 12 (the fourth row of every group of the MFMA tile left empty): a pass costs its MFMA phase plus
+    // Row tiles of 16 rows, or of 12 / 8 (the last rows of every group of the MFMA tile left empty): a pass costs its MFMA phase plus
     // ~490 instructions per output a lane keeps (reduction + word assembly), all at the same ~5.5 cycles each -- 22 rows are two
     // passes either way, and two passes of three outputs beat two of four.
-    const double per_pass16 = 228.0 * nkb + 160 + 4 * 490, per_pass12 = 228.0 * nkb + 160 + 3 * 490;
-    const int tile_rows = (!getenv("HB_MM8W_TILE16") && ((n_out + 11) / 12) * per_pass12 < ((n_out + 15) / 16) * per_pass16) ? 12 : 16;
+    int tile_rows = 16;
+    if (!getenv("HB_MM8W_TILE16")) {
+        double best = 0.0;
+        for (int tr = 16; tr >= 8; tr -= 4) {
+            const double cost = (double)((n_out + tr - 1) / tr) * (228.0 * nkb + 160 + (tr / 4) * 490);
+            if (tr == 16 || cost < best - 1e-9) { best = cost; tile_rows = tr; }
+        }
+    }
     const int n_rt = (n_out + tile_rows - 1) / tile_rows;
     int tpw = 0, nbuf = 0, rq = 0;
     if (!mm8w_shape(n_rt, nkb, 1, 1, &tpw, &nbuf, &rq)) return HB_ERR_UNSUPPORTED;
@@ -504,7 +515,7 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
     } while (0)
     // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
     const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);
-#define MM8W_LAUNCH(CHK, PL) do { if (m->tile_rows == 12) MM8W_LAUNCH_K(CHK, PL, 3); else MM8W_LAUNCH_K(CHK, PL, 4); } while (0)
+#define MM8W_LAUNCH(CHK, PL) do { if (m->tile_rows == 12) MM8W_LAUNCH_K(CHK, PL, 3); else if (m->tile_rows == 8) MM8W_LAUNCH_K(CHK, PL, 2); else MM8W_LAUNCH_K(CHK, PL, 4); } while (0)
     if (check) { if (peel == 1) MM8W_LAUNCH(true, 1); else if (peel == 2) MM8W_LAUNCH(true, 2); else if (peel == 3) MM8W_LAUNCH(true, 3); else MM8W_LAUNCH(true, 4); }
     else { if (peel == 1) MM8W_LAUNCH(false, 1); else if (peel == 2) MM8W_LAUNCH(false, 2); else if (peel == 3) MM8W_LAUNCH(false, 3); else MM8W_LAUNCH(false, 4); }
 #undef MM8W_LAUNCH_K

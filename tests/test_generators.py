@@ -34,7 +34,7 @@ def test_resolve_waits_counts_vector_memory_operations(gen):
     assert gen.resolve_waits(["@ELOAD", ld, ld, "global_store_dwordx4 v[4:5], v[0:3], off", "@EWAIT"])[-1] == "s_waitcnt vmcnt(1)"
 
 
-@pytest.mark.parametrize("nout", [4, 3])
+@pytest.mark.parametrize("nout", [4, 3, 2])
 @pytest.mark.parametrize("check", [False, True])
 @pytest.mark.parametrize("peel", [1, 2, 3, 4])
 def test_pass_structure(gen, check, peel, nout):
@@ -83,7 +83,7 @@ def test_pass_structure(gen, check, peel, nout):
     assert last_block
 
 
-@pytest.mark.parametrize("nout", [4, 3])
+@pytest.mark.parametrize("nout", [4, 3, 2])
 def test_reduction_units_cover_every_output(gen, nout):
     for check in (False, True):
         o, lines = gen.reduce_lines(check, nout)
