@@ -14,7 +14,7 @@ pids=""
 for src in "$HERE"/*.hip; do
   obj="$HERE/.obj/$(basename "${src%.hip}").o"
   objs="$objs $obj"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find "$HERE" "$HERE/../../include" -maxdepth 1 \( -name '*.cuh' -o -name '*.hpp' -o -name '*.h' -o -name '*.inc' \) -newer "$obj" 2>/dev/null)" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ -n "$(find "$HERE" "$HERE/../../include" -maxdepth 1 \( -name '*.hpp' -o -name '*.h' -o -name '*.inc' \) -newer "$obj" 2>/dev/null)" ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids="$pids $!"
   fi

@@ -1,4 +1,4 @@
-// fp29.cuh -- GF(p) arithmetic for gfx950 in a carry-free radix-2^29 representation.
+// fp29.hpp -- GF(p) arithmetic for gfx950 in a carry-free radix-2^29 representation.
 //
 // Why radix 2^29 and not 32-bit limbs: measured on MI355X (scratch/ubench.hip,
 // gpurun_out/ubench2.txt) v_mad_u64_u32 issues at the same half rate (~4.4 cycles per

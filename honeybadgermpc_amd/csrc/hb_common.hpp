@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/hbmpc_hip.h"
-#include "fp29.cuh"
+#include "fp29.hpp"
 
 namespace hb {
 struct FastMatrix;

@@ -85,7 +85,7 @@ template <int NL> __device__ __forceinline__ void mont_mul_lazy(uint32_t (&r)[NL
     uint64_t c[2 * NL];
     col_zero(c);
     mac<NL>(c, a, b);
-    redc(r, c, P);                                        // no carry pass needed for a single product (fp29.cuh: mont_mul)
+    redc(r, c, P);                                        // no carry pass needed for a single product (fp29.hpp: mont_mul)
 }
 template <int NL> __device__ __forceinline__ void add_lazy(uint32_t (&r)[NL], const uint32_t (&a)[NL], const uint32_t (&b)[NL]) {
     uint32_t cy = 0;

@@ -48,10 +48,12 @@ def all_gather_opened(local, num_shares, d, group=None, mode="collective", out=N
             if peer == rank:
                 continue
             plo, phi = sizes[peer]
+            # P2POp addresses peers by GLOBAL rank; `peer` counts within `group`
+            gpeer = peer if group is None else dist.get_global_rank(group, peer)
             if hi > lo:
-                ops.append(dist.P2POp(dist.isend, local, peer, group))
+                ops.append(dist.P2POp(dist.isend, local, gpeer, group))
             if phi > plo:
-                ops.append(dist.P2POp(dist.irecv, out[plo:phi], peer, group))
+                ops.append(dist.P2POp(dist.irecv, out[plo:phi], gpeer, group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()

@@ -2,7 +2,7 @@
 import sys
 
 sys.path.insert(0, "scratch")
-import test_mm8 as T  # noqa: E402
+import check_mm8 as T  # noqa: E402
 
 ctx = T.Context.get(T.P)
 T.timing(ctx, int(sys.argv[1]) if len(sys.argv) > 1 else 64, int(sys.argv[2]) if len(sys.argv) > 2 else 22,

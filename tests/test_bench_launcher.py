@@ -1,0 +1,56 @@
+"""bench.py as its own launcher: `python bench.py --gpus N` with no torchrun environment must start N ranks
+under torch.distributed.run.  HB_BENCH_RENDEZVOUS_ONLY=1 stops every rank after the rendezvous (gloo), so this runs without a GPU;
+the GPU twins (real opens on 2 ranks) are in tests/test_gpu_multirank.py."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import REPO
+
+_TORCHRUN_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GROUP_RANK", "LOCAL_WORLD_SIZE")
+
+
+def _plain_env():
+    env = {k: v for k, v in os.environ.items() if k not in _TORCHRUN_VARS}
+    env["HB_BENCH_RENDEZVOUS_ONLY"] = "1"
+    return env
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_plain_python_invocation_launches_its_ranks():
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "3", "--workload", "tiny"], cwd=REPO, env=_plain_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _json_line(res.stdout)
+    assert out == {"rendezvous_only": True, "world_size_env": 3, "ranks_seen": 3, "gpus_requested": 3, "self_launched": True}
+    assert "launching 3 ranks" in res.stderr
+
+
+def test_single_gpu_invocation_stays_one_process():
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--workload", "tiny"], cwd=REPO, env=_plain_env(),
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _json_line(res.stdout)
+    assert out["ranks_seen"] == 1 and not out["self_launched"]
+
+
+def test_under_torchrun_no_second_launch():
+    """the driver's own launch line: the script must NOT re-launch when torchrun already set RANK / WORLD_SIZE"""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--workload", "tiny"]
+    res = subprocess.run(cmd, cwd=REPO, env=_plain_env(), capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = _json_line(res.stdout)
+    assert out["ranks_seen"] == 2 and out["world_size_env"] == 2 and not out["self_launched"]

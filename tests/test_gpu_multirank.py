@@ -29,6 +29,50 @@ def _run(extra, timeout=900):
     return json.loads(lines[0])
 
 
+def _run_plain(extra, timeout=900):
+    """`python bench.py --gpus 2 ...` with NO torchrun on the command line and no RANK / WORLD_SIZE in the environment: the script
+    must launch its own ranks (this is how the driver invokes --gpus 1, and the r2 script died on an assert)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+    env["HB_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-sample", "0"] + extra
+    res = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_self_launch_weak():
+    out = _run_plain(["--workload", "tiny", "--no-two-streams-extra"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["distributed"]["world_size"] == 2 and "self-launch" in out["distributed"]["launcher"]
+
+
+def test_self_launch_sharded_auto_gather():
+    out = _run_plain(["--workload", "cfg5-mini"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
+    dd = out["distributed"]
+    assert dd["world_size"] == 2 and dd["gather"]["requested"] == "auto" and dd["gather_mode"] in ("direct", "collective")
+    assert set(dd["gather"]["probe_ms"]) == {"direct", "collective"}
+    assert out["detail"]["bit_exact_vs_secrets"]
+
+
+def test_wrong_world_size_is_reported_not_fatal():
+    """torchrun with 2 ranks but --gpus 4: the launcher's world is what runs"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HB_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--workload", "tiny",
+           "--no-two-streams-extra"]
+    res = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["distributed"]["gpus_requested"] == 4
+
+
 def test_two_ranks_weak_scaling_path():
     out = _run(["--workload", "tiny", "--no-two-streams-extra"])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["detail"]["bit_exact_vs_secrets"]
@@ -42,4 +86,5 @@ def test_two_ranks_sharded_open_with_gather(mode):
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0
     assert out["config"]["shares_total"] == 1 << 16 and out["config"]["shares_this_rank"] <= (1 << 15) + 86
     assert out["detail"]["gather_mode"] == mode and out["detail"]["allgather_ms_per_step_max_over_ranks"] >= 0
+    assert out["distributed"]["backend"] == "gloo" and out["distributed"]["world_size"] == 2
     assert out["detail"]["bit_exact_vs_secrets"] and out["detail"]["matrix_core_path"]

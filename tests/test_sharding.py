@@ -202,3 +202,43 @@ def test_sharded_open_class_on_gloo(mode, world, b):
         p.join(180)
         assert p.exitcode == 0
     assert all(ret[r] for r in range(world))
+
+
+def _worker_subgroup(rank, world, port, b, d, mode, ret):
+    """all_gather_opened inside a NON-default group (ranks 1..world-1): P2POp peers are global ranks, slices are indexed by
+    the rank within the group"""
+    from honeybadgermpc_amd.sharding import all_gather_opened
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    members = list(range(1, world))
+    group = dist.new_group(ranks=members)
+    good = True
+    if rank in members:
+        gr = dist.get_rank(group)
+        gw = len(members)
+        lo, hi = shard_bounds(b, d, gw, gr)
+        whole = torch.arange(b * 4, dtype=torch.int64).reshape(b, 4) * 7 + 3
+        full = all_gather_opened(whole[lo:hi].clone(), b, d, group=group, mode=mode)
+        good = torch.equal(full, whole)
+    ret[rank] = bool(good)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["direct", "collective"])
+def test_gather_inside_a_subgroup(mode):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_subgroup, args=(r, 3, port, 31, 3, mode, ret)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret[r] for r in range(3))
