@@ -100,6 +100,8 @@ def make_inputs(torch, ctx, n, t, B, use_omega, seed):
     r2_cols = ctx.empty(n * C)
     ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(sec_pad), HbView(d, 1), None, ctx.ptr(r2_cols), HbView(1, C), C, ctx.stream()), "r2cols")
     torch.cuda.synchronize()
+    lib.hb_matrix_destroy(V)
+    lib.hb_matrix_destroy(V0)
     del shares_all, coef
     return shares0, r1_cols, r2_cols, secrets, x
 

@@ -60,6 +60,7 @@ SYMBOLS = {
     "hb_matrix_from_host": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
     "hb_matrix_to_host": (_i, [_vp, _vp, _vp, _vp]),
     "hb_matrix_destroy": (None, [_vp]),
+    "hb_reduce": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "hb_matvec": (_i, [_vp, _vp, _vp, HbView, _vp, _vp, HbView, _i64, _vp]),
     "hb_matvec_check": (_i, [_vp, _vp, _vp, HbView, _vp, _vp, HbView, _vp, _i, _vp, _i64, _vp]),
     "hb_vandermonde_batch_evaluate": (_i, [_vp, _vp, _i, _vp, _i64, _i, _vp, _vp]),
@@ -268,6 +269,14 @@ class Context:
         if count is not None and tensor.numel() != int(count) * self.n_limbs:
             raise ValueError(f"{what}: expected {int(count)} elements, got {tensor.numel() // self.n_limbs}")
         return tensor if tensor.is_contiguous() else tensor.contiguous()
+
+    def reduce_(self, tensor):
+        """in place: every element of a (count, limbs) device tensor -> its canonical residue (hb_reduce; the reference reduces
+        whatever enters its boundary, pyx:31-32).  For buffers filled from outside: wire payloads, files."""
+        tensor = self.elems(tensor, what="tensor")
+        count = tensor.numel() // self.n_limbs
+        self.check(self.lib.hb_reduce(self.h, self.ptr(tensor), self.ptr(tensor), count, None, self.stream()), "hb_reduce")
+        return tensor
 
     def cache_clear(self):
         """drop every cached table of this context (hb_ctx_cache_clear)"""

@@ -311,9 +311,13 @@ def reduce_output(o, r, check):
     # (an SGPR operand beside the carry in vcc would be two constant-bus reads: 2^256 - p goes through the free T buffer)
     for j in range(8):
         one(f"v_mov_b32 v{TB[1] + j}, s{S_PNEG + j}")
-    cs = [f"v_add_co_u32_e32 v{UB}, vcc, v{TB[1]}, v{OW}"]
+    # r < 2p < 2^257: bit 256 of r (bit 24 of the top digit; the eight words drop it) also means r >= p, and r - p is the
+    # same sum mod 2^256.  It joins the carry chain as a ninth word: hi + 0xffffffff + carry carries out iff hi or carry.
+    cs = [f"v_lshrrev_b32 v{T1}, 24, v{C0 + 16}",
+          f"v_add_co_u32_e32 v{UB}, vcc, v{TB[1]}, v{OW}"]
     for j in range(1, 8):
         cs.append(f"v_addc_co_u32_e32 v{UB + j}, vcc, v{TB[1] + j}, v{OW + j}, vcc")
+    cs.append(f"v_addc_co_u32_e32 v{T1}, vcc, -1, v{T1}, vcc")
     for j in range(8):
         cs.append(f"v_cndmask_b32_e32 v{OW + j}, v{OW + j}, v{UB + j}, vcc")
     U.append(cs)

@@ -8,6 +8,7 @@
 
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,15 @@ struct hb_matrix {
 };
 
 namespace hb {
+// ctx->err: assignment and c_str() act on the CALLING thread's message (hb_last_error is asked for by the thread whose call failed)
+struct TlsError {
+    static std::string &slot() { static thread_local std::string s; return s; }
+    TlsError &operator=(const std::string &m) { slot() = m; return *this; }
+    TlsError &operator=(const char *m) { slot() = m ? m : ""; return *this; }
+    const char *c_str() const { return slot().c_str(); }
+    void clear() { slot().clear(); }
+    bool empty() const { return slot().empty(); }
+};
 // constants of the table pre-scale (k_prescale_tab): 2^261 - p in digits, 2^256 - p in words, floor(2^290 / p) in digits
 struct PrescaleParams {
     uint32_t pbar[9];
@@ -61,7 +71,14 @@ struct hb_ctx {
     hb::FpParams<9> pw; // valid when n_limbs == 4
     hb::FpParams<3> pn; // valid when n_limbs == 1
     uint64_t p_limbs[4];
-    std::string err;
+    // One context may be shared by several host threads (device.py keeps a per-thread plan cache over one Context per
+    // modulus, and ctypes releases the GIL during calls): every API entry point that takes a context, a plan or a matrix
+    // handle holds `mu` from its table lookups to the enqueue of its last launch (HB_API_GUARD), so the registry, the cache
+    // maps, reference counts, lazily built images and cache_trim never run concurrently.  Recursive: entry points call
+    // each other.  The last error is kept per calling thread.
+    std::recursive_mutex mu;
+    int api_depth = 0;                                // entry points on the stack of the thread that holds `mu`
+    hb::TlsError err;
     std::map<std::string, hb_matrix *> mcache;        // tables keyed by (kind, n, d, point bytes)
     std::map<std::vector<int32_t>, int32_t *> icache; // small int arrays resident on device
     std::map<std::string, void *> dcache;             // other device tables (twiddles, ...), hipFree'd with the ctx
@@ -82,6 +99,18 @@ struct hb_ctx {
     int elem_words() const { return n_limbs == 4 ? 8 : 2; }
     int nl() const { return n_limbs == 4 ? 9 : 3; }
 };
+
+// entry-point guard: holds the context's mutex and counts the nesting of entry points (one calls another: hb_wb_decode ->
+// hb_gao_decode -> hb_vand_inverse_create).  cache_trim only acts in the OUTERMOST call: an inner call must not free tables
+// the outer one looked up and is about to launch with.
+struct hb_api_guard {
+    hb_ctx *c;
+    explicit hb_api_guard(hb_ctx *ctx) : c(ctx) { if (c) { c->mu.lock(); c->api_depth++; } }
+    ~hb_api_guard() { if (c) { c->api_depth--; c->mu.unlock(); } }
+    hb_api_guard(const hb_api_guard &) = delete;
+    hb_api_guard &operator=(const hb_api_guard &) = delete;
+};
+#define HB_API_GUARD(ctxexpr) hb_api_guard hb_api_guard__(ctxexpr)
 
 #define HB_HIP(ctx, call)                                                                         \
     do {                                                                                          \

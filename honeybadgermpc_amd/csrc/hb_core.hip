@@ -325,6 +325,30 @@ __global__ void k_copy_view(const uint32_t *__restrict__ src, int64_t s_sc, int6
     store_words<NW>(dst + di * NW, w);
 }
 
+// canonical residues of arbitrary packed words (to_ZZ_p, hbmpc_ntl_helpers.pyx:31-32, for packed batches): x < 2^(32 NW) < R,
+// so x R mod p by one Montgomery product with R^2 and back by one REDC; *changed counts the elements that were not canonical
+template <int NL, int NW>
+__global__ void k_reduce(const FpParams<NL> P, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst, int64_t count,
+                         int32_t *__restrict__ changed) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    uint32_t w[NW], d[NL], m[NL], o[NW];
+    load_words<NW>(w, src + i * NW);
+    unpack<NL, NW>(d, w);
+    to_mont<NL>(m, d, P);
+    from_mont<NL>(d, m, P);
+    pack<NL, NW>(o, d);
+    bool diff = false;
+#pragma unroll
+    for (int q = 0; q < NW; q++) diff |= o[q] != w[q];
+    if (diff) {
+        store_words<NW>(dst + i * NW, o);
+        if (changed) atomicAdd(changed, 1);
+    } else if (dst != src) {
+        store_words<NW>(dst + i * NW, w);
+    }
+}
+
 // =====================================================================================
 // host side
 // =====================================================================================
@@ -353,6 +377,7 @@ static void cache_drop_down_to(hb_ctx *ctx, size_t keep) {
     }
 }
 void cache_trim(hb_ctx *ctx) {
+    if (ctx->api_depth > 1) return;                     // only the outermost entry point trims (hb_common.hpp: hb_api_guard)
     size_t unpinned = 0;
     for (auto &kv : ctx->lru) if (!kv.second.pinned) unpinned++;
     if (unpinned > ctx->cache_cap) cache_drop_down_to(ctx, ctx->cache_cap / 2);
@@ -410,6 +435,16 @@ __global__ void k_upload_copy(const uint4 *__restrict__ src, uint4 *__restrict__
 }
 int upload_table(hb_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes, hipStream_t s) {
     if (bytes == 0) return HB_OK;
+    // HB_UPLOAD_MODE=memcpy: the round-2 defect's upload path (copy engine straight into the table, stream synchronise), kept
+    // ONLY so that the stale-read experiment can be repeated (tests/test_gpu_full_size.py::test_table_recycling_first_launch,
+    // DESIGN section 9); never set in production
+    static const int legacy = [] { const char *e = getenv("HB_UPLOAD_MODE"); return e && !strcmp(e, "memcpy") ? 1 : 0; }();
+    if (legacy) {
+        hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { ctx->err = std::string("table upload: ") + hipGetErrorString(e); return HB_ERR_HIP; }
+        return HB_OK;
+    }
     const size_t n16 = (bytes + 15) / 16;
     void *stage = nullptr;
     HB_HIP(ctx, hipMalloc(&stage, n16 * 16));
@@ -469,7 +504,7 @@ int hb_ctx_create(hb_ctx **out, const uint64_t *p_limbs, int n_limbs, int device
     memset(ctx->p_limbs, 0, sizeof ctx->p_limbs);
     memcpy(ctx->p_limbs, p_limbs, (size_t)n_limbs * 8);
     if (n_limbs == 4) make_params<9>(ctx->pw, p_limbs, 4); else make_params<3>(ctx->pn, p_limbs, 1);
-    if (const char *e = getenv("HB_CACHE_CAP")) { long v = atol(e); if (v >= 8) ctx->cache_cap = (size_t)v; }
+    if (const char *e = getenv("HB_CACHE_CAP")) { long v = atol(e); if (v >= 1) ctx->cache_cap = (size_t)v; }
     ctx->flag_dev = nullptr;
     if (hipMalloc(&ctx->flag_dev, 64 * sizeof(int32_t)) != hipSuccess) { delete ctx; return HB_ERR_HIP; }
     (void)hipMemset(ctx->flag_dev, 0, 64 * sizeof(int32_t));
@@ -493,16 +528,16 @@ void hb_ctx_destroy(hb_ctx *ctx) {
 const char *hb_last_error(const hb_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 int hb_elem_bytes(const hb_ctx *ctx) { return ctx ? ctx->n_limbs * 8 : 0; }
 
-int hb_malloc(hb_ctx *ctx, void **dptr, size_t bytes) { HB_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 4)); return HB_OK; }
-int hb_free(hb_ctx *ctx, void *dptr) { HB_HIP(ctx, hipFree(dptr)); return HB_OK; }
-int hb_memcpy_h2d(hb_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+int hb_malloc(hb_ctx *ctx, void **dptr, size_t bytes) { HB_API_GUARD(ctx); HB_HIP(ctx, hipMalloc(dptr, bytes ? bytes : 4)); return HB_OK; }
+int hb_free(hb_ctx *ctx, void *dptr) { HB_API_GUARD(ctx); HB_HIP(ctx, hipFree(dptr)); return HB_OK; }
+int hb_memcpy_h2d(hb_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) { HB_API_GUARD(ctx);
     HB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); return HB_OK;
 }
-int hb_memcpy_d2h(hb_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) {
+int hb_memcpy_d2h(hb_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream) { HB_API_GUARD(ctx);
     HB_HIP(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
     HB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream)); return HB_OK;
 }
-int hb_stream_sync(hb_ctx *ctx, void *stream) { HB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream)); return HB_OK; }
+int hb_stream_sync(hb_ctx *ctx, void *stream) { HB_API_GUARD(ctx); HB_HIP(ctx, hipStreamSynchronize((hipStream_t)stream)); return HB_OK; }
 
 // ---- tables -------------------------------------------------------------------------
 }  // extern "C"
@@ -585,7 +620,7 @@ int vinv_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_dev, in
 
 extern "C" {
 
-int hb_vand_matrix_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, hb_matrix **out, void *stream) {
+int hb_vand_matrix_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, hb_matrix **out, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !out || n < 0 || d < 0) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     cache_trim(ctx);
@@ -601,7 +636,7 @@ int hb_vand_matrix_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, hb_
     return rc;
 }
 
-int hb_vand_inverse_create(hb_ctx *ctx, const uint64_t *x_host, int k, hb_matrix **out, void *stream) {
+int hb_vand_inverse_create(hb_ctx *ctx, const uint64_t *x_host, int k, hb_matrix **out, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !out || k < 0) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     cache_trim(ctx);
@@ -617,7 +652,7 @@ int hb_vand_inverse_create(hb_ctx *ctx, const uint64_t *x_host, int k, hb_matrix
     return rc;
 }
 
-int hb_matrix_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, hb_matrix **out, void *stream) {
+int hb_matrix_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, hb_matrix **out, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !out || n_out < 0 || n_in < 0) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     hb_matrix *m = nullptr;
@@ -638,7 +673,7 @@ int hb_matrix_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in
     return HB_OK;
 }
 
-int hb_matrix_to_host(hb_ctx *ctx, const hb_matrix *m, uint64_t *m_host, void *stream) {
+int hb_matrix_to_host(hb_ctx *ctx, const hb_matrix *m, uint64_t *m_host, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !m || !m_host) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int tot = m->n_out * m->n_in;
@@ -656,7 +691,7 @@ int hb_matrix_to_host(hb_ctx *ctx, const hb_matrix *m, uint64_t *m_host, void *s
     return HB_OK;
 }
 
-void hb_matrix_destroy(hb_matrix *m) { matrix_unref(m); }   // cached tables live on until the cache lets go of them too
+void hb_matrix_destroy(hb_matrix *m) { HB_API_GUARD((m ? m->ctx : nullptr)); matrix_unref(m); }   // cached tables live on until the cache lets go of them too
 
 }  // extern "C"
 
@@ -719,8 +754,20 @@ int launch_copy_view(hb_ctx *ctx, const uint32_t *src, hb_view sv, uint32_t *dst
 
 extern "C" {
 
+int hb_reduce(hb_ctx *ctx, const uint64_t *in_dev, uint64_t *out_dev, int64_t count, int32_t *changed_dev, void *stream) { HB_API_GUARD(ctx);
+    if (!ctx || count < 0 || (count > 0 && (!in_dev || !out_dev))) return HB_ERR_BAD_ARG;
+    if (count == 0) return HB_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((count + 255) / 256);
+    HB_DISPATCH(ctx,
+        (k_reduce<9, 8><<<blocks, 256, 0, s>>>(ctx->pw, (const uint32_t *)in_dev, (uint32_t *)out_dev, count, changed_dev)),
+        (k_reduce<3, 2><<<blocks, 256, 0, s>>>(ctx->pn, (const uint32_t *)in_dev, (uint32_t *)out_dev, count, changed_dev)));
+    HB_LAUNCH_CHECK(ctx);
+    return HB_OK;
+}
+
 int hb_matvec(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_view in, const int32_t *in_rows,
-              uint64_t *out_dev, hb_view out, int64_t C, void *stream) {
+              uint64_t *out_dev, hb_view out, int64_t C, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !m || (C > 0 && (!in_dev || !out_dev))) return HB_ERR_BAD_ARG;
     cache_trim(ctx);
     hipStream_t s = (hipStream_t)stream;
@@ -731,7 +778,7 @@ int hb_matvec(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_view i
 
 int hb_matvec_check(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_view in, const int32_t *in_rows,
                     const uint64_t *expect_dev, hb_view expect, const int32_t *check_rows, int n_check,
-                    int32_t *mismatch_dev, int64_t C, void *stream) {
+                    int32_t *mismatch_dev, int64_t C, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !m || !mismatch_dev || (C > 0 && (!in_dev || !expect_dev))) return HB_ERR_BAD_ARG;
     if (n_check < 0 || (n_check > 0 && !check_rows)) return HB_ERR_BAD_ARG;
     cache_trim(ctx);
@@ -790,7 +837,7 @@ static int fast_scratch(hb_ctx *ctx, int n_in, int64_t C, uint32_t **scratch) {
 }
 
 int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_t *polys_dev,
-                                  int64_t C, int d, uint64_t *out_dev, void *stream) {
+                                  int64_t C, int d, uint64_t *out_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || n < 0 || d < 0 || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0 || n == 0) return HB_OK;
     cache_trim(ctx);
@@ -820,7 +867,7 @@ int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, co
 }
 
 int hb_vandermonde_batch_interpolate(hb_ctx *ctx, const uint64_t *x_host, int k, const uint64_t *data_dev,
-                                     int64_t C, uint64_t *out_dev, void *stream) {
+                                     int64_t C, uint64_t *out_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || k < 0 || C < 0 || (k > 0 && !x_host)) return HB_ERR_BAD_ARG;
     cache_trim(ctx);
     hipStream_t s = (hipStream_t)stream;
@@ -881,7 +928,7 @@ int hb_vandermonde_batch_interpolate(hb_ctx *ctx, const uint64_t *x_host, int k,
 // Drop every cached table of the context (synchronises the device).  Handles returned by hb_vand_*_create stay valid
 // until hb_matrix_destroy.  The caches also bound themselves (least recently used entries go once more than
 // `cache_cap` are resident), so calling this is never required.
-int hb_ctx_cache_clear(hb_ctx *ctx) {
+int hb_ctx_cache_clear(hb_ctx *ctx) { HB_API_GUARD(ctx);
     if (!ctx) return HB_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
     cache_drop_down_to(ctx, 0);

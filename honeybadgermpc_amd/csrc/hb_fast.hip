@@ -141,8 +141,9 @@ __global__ void __launch_bounds__(256) k_prescale_tab(const PrescaleParams PP, c
         unsigned cy = 0;
 #pragma unroll
         for (int k = 0; k < NW; k++) u[k] = __builtin_addc(w[k], PP.pneg[k], cy, &cy);
+        const bool take = cy || (r[NL - 1] >> 24);     // r < 2p < 2^257: bit 256 (dropped by pack) also means r >= p
 #pragma unroll
-        for (int k = 0; k < NW; k++) w[k] = ok ? (cy ? u[k] : w[k]) : 0u;
+        for (int k = 0; k < NW; k++) w[k] = ok ? (take ? u[k] : w[k]) : 0u;
     }
     if (c < C) store_words<NW>(out_pk + ((size_t)l * (size_t)C + (size_t)c) * NW, w);
 }

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
 }  // namespace
 
 extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const uint64_t *ys_dev, int64_t C,
-                             uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream) {
+                             uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !x_host || npts < 1 || k < 0 || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0) return HB_OK;
     if (!ys_dev || !coeffs_dev || !errloc_dev || !errloc_len_dev || !ok_dev) return HB_ERR_BAD_ARG;

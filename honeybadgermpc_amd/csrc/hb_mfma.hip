@@ -340,14 +340,16 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         }
                         uint32_t ow[8];
                         pack<9, 8>(ow, r);
-                        // r < 2p < 2^256;  r >= p  <=>  r + (2^256 - p) carries out of word 7
+                        // r < 2p < 2^257;  r >= p  <=>  bit 256 of r is set (bit 24 of digit 8: possible once p > 2^255, and
+                        // pack() drops it) or r mod 2^256 + (2^256 - p) carries out of word 7; either way r - p is that sum mod 2^256
                         {
                             uint32_t u[8];
                             unsigned cy2 = 0;
 #pragma unroll
                             for (int k = 0; k < 8; k++) u[k] = __builtin_addc(ow[k], bp.pneg[k], cy2, &cy2);
+                            const bool take = cy2 || (r[8] >> 24);
 #pragma unroll
-                            for (int k = 0; k < 8; k++) ow[k] = cy2 ? u[k] : ow[k];
+                            for (int k = 0; k < 8; k++) ow[k] = take ? u[k] : ow[k];
                         }
                         const int64_t oidx = obase + reg * ostep;
                         if constexpr (CHECK) {
@@ -650,7 +652,7 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
 }  // namespace hb
 
 // ---- diagnostic entry points (scratch/test_mm8.py): the matrix-core mat-vec on its own ----------
-extern "C" int hb_debug_mm8_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, void **out) {
+extern "C" int hb_debug_mm8_create(hb_ctx *ctx, const uint64_t *x_host, int n, int d, void **out) { HB_API_GUARD(ctx);
     uint32_t *xd = nullptr;
     int rc = upload_elems(ctx, x_host, (size_t)n, &xd, 0);
     if (rc) return rc;
@@ -666,7 +668,7 @@ extern "C" int hb_debug_mm8_create(hb_ctx *ctx, const uint64_t *x_host, int n, i
 }
 extern "C" int hb_debug_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, int64_t in_sc, int64_t in_sl, int64_t in_count,
                                   void *out_dev, int64_t out_sc, int64_t out_sl, int64_t out_count, int64_t n_chunks,
-                                  const int32_t *check_mask_dev, int32_t *mismatch_dev) {
+                                  const int32_t *check_mask_dev, int32_t *mismatch_dev) { HB_API_GUARD(ctx);
     hb_view iv{in_sc, in_sl}, ov{out_sc, out_sl};
     return launch_mm8(ctx, (const Mm8Matrix *)mat, (const uint32_t *)in_dev, iv, nullptr, in_count, (uint32_t *)out_dev, ov, out_count,
                       check_mask_dev, mismatch_dev, n_chunks, 0, nullptr, hb_view{0, 0}, 0, 0, nullptr);

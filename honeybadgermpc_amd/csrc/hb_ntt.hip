@@ -458,7 +458,7 @@ namespace {
 extern "C" {
 
 int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, const uint64_t *coeffs_dev,
-                          int64_t C, int d, int k, uint64_t *out_dev, void *stream) {
+                          int64_t C, int d, int k, uint64_t *out_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !omega_host || order <= 0 || (order & (order - 1)) || k < 0 || k > order || d < 0 || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0 || k == 0) return HB_OK;
     if (!coeffs_dev || !out_dev) return HB_ERR_BAD_ARG;
@@ -517,7 +517,7 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, co
 }
 
 int hb_fft_batch_interpolate(hb_ctx *ctx, const uint64_t *omega_host, int order, const int32_t *zs_host, int k,
-                             const uint64_t *ys_dev, int64_t C, uint64_t *out_dev, void *stream) {
+                             const uint64_t *ys_dev, int64_t C, uint64_t *out_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !omega_host || order <= 0 || (order & (order - 1)) || k < 0 || C < 0 || (k > 0 && !zs_host)) return HB_ERR_BAD_ARG;
     if (k == 0 || C == 0) return HB_OK;
     if (!ys_dev || !out_dev) return HB_ERR_BAD_ARG;

@@ -142,13 +142,14 @@ extern "C" {
 
 int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const uint64_t *x_host,
                         const uint64_t *omega_host, int order, const int32_t *z_host, const int32_t *zc_host,
-                        int n_check, int64_t max_B, hb_open_plan **out, void *stream) {
+                        int n_check, int64_t max_B, hb_open_plan **out, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !out || n <= 0 || d <= 0 || d > n || !x_host || !z_host || max_B < 0) return HB_ERR_BAD_ARG;
     if (n_check < 0 || n_check > n || (n_check > 0 && !zc_host)) return HB_ERR_BAD_ARG;
     for (int i = 0; i < d; i++) if (z_host[i] < 0 || z_host[i] >= n) return HB_ERR_BAD_ARG;
     for (int j = 0; j < n_check; j++) if (zc_host[j] < 0 || zc_host[j] >= n) return HB_ERR_BAD_ARG;
     *out = nullptr;
     hipStream_t s = (hipStream_t)stream;
+    cache_trim(ctx);                            // plan creation is the busiest user of the table caches: bound them here too
     hb_open_plan *pl = new hb_open_plan();      // value-initialised: every pointer null, so destroy is safe at any point
     pl->ctx = ctx; pl->n = n; pl->d = d; pl->n_check = n_check; pl->max_B = max_B;
     pl->max_C = (max_B + d - 1) / d; if (pl->max_C < 1) pl->max_C = 1;
@@ -235,7 +236,7 @@ done:
 }
 
 // R1: shares [B] (chunk c = shares[c*d .. c*d+d), zero padded) -> r1_out [n][C]
-int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, uint64_t *r1_out_dev, void *stream) {
+int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, uint64_t *r1_out_dev, void *stream) { HB_API_GUARD((pl ? pl->ctx : nullptr));
     if (!pl || B < 0 || B > pl->max_B) return HB_ERR_BAD_ARG;
     const int64_t C = (B + pl->d - 1) / pl->d;
     hb_view iv{pl->d, 1}, ov{1, C};
@@ -259,8 +260,10 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
                                int pk_rows, hipStream_t s) {
     hb_view pm{1, C};
     if (pl->fused_pending && pl->use_v8 && pl->use_fused && ++pl->decode_calls > 2) {
-        int rc = ensure_fused(pl, s);
-        if (rc) return rc;
+        // Building the fused matrices is an optimisation of a plan that already decodes correctly on the two-launch path: if
+        // it fails for any reason (out of memory while building F1 / F2, ...) the decode goes on unfused and the error is dropped.
+        // ensure_fused clears fused_pending first, so a failure is not retried on every call.
+        if (ensure_fused(pl, s) != HB_OK) pl->ctx->err.clear();
     }
     if (pl->F1 && pl->F2 && pl->use_v8 && pl->use_fused && (pk_rows == 1 || pk_rows == pl->d)) {
         // full-size entries: ONE launch decodes the rows the caller wants and compares the predictions of the later arrivals
@@ -332,7 +335,7 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
                           pl->mask_dev, pl->mismatch_dev, C, s, pl->validate_arrived_only);
 }
 
-int hb_open_r1_decode(hb_open_plan *pl, const uint64_t *r1_cols_dev, int64_t B, uint64_t *r2_msg_dev, void *stream) {
+int hb_open_r1_decode(hb_open_plan *pl, const uint64_t *r1_cols_dev, int64_t B, uint64_t *r2_msg_dev, void *stream) { HB_API_GUARD((pl ? pl->ctx : nullptr));
     if (!pl || B < 0 || B > pl->max_B) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t C = (B + pl->d - 1) / pl->d;
@@ -342,7 +345,7 @@ int hb_open_r1_decode(hb_open_plan *pl, const uint64_t *r1_cols_dev, int64_t B, 
     return decode_and_validate(pl, r1_cols_dev, C, (uint32_t *)r2_msg_dev, pv, INT64_MAX, 1, s);
 }
 
-int hb_open_r2_decode(hb_open_plan *pl, const uint64_t *r2_cols_dev, int64_t B, uint64_t *result_dev, void *stream) {
+int hb_open_r2_decode(hb_open_plan *pl, const uint64_t *r2_cols_dev, int64_t B, uint64_t *result_dev, void *stream) { HB_API_GUARD((pl ? pl->ctx : nullptr));
     if (!pl || B < 0 || B > pl->max_B) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     const int64_t C = (B + pl->d - 1) / pl->d;
@@ -351,7 +354,7 @@ int hb_open_r2_decode(hb_open_plan *pl, const uint64_t *r2_cols_dev, int64_t B, 
     return decode_and_validate(pl, r2_cols_dev, C, (uint32_t *)result_dev, dv, B, pl->d, s);
 }
 
-int hb_open_status(hb_open_plan *pl, void *stream) {
+int hb_open_status(hb_open_plan *pl, void *stream) { HB_API_GUARD((pl ? pl->ctx : nullptr));
     if (!pl) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     int32_t flag = 0;
@@ -364,7 +367,7 @@ int hb_open_status(hb_open_plan *pl, void *stream) {
     return HB_OK;
 }
 
-int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
+int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) { HB_API_GUARD((pl ? pl->ctx : nullptr));
     if (!pl) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) {
         pl->validate_arrived_only = value ? 1 : 0;
@@ -394,7 +397,7 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) {
     return HB_ERR_BAD_ARG;
 }
 
-int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) {
+int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) { HB_API_GUARD((pl ? pl->ctx : nullptr));
     if (!pl || !value) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { *value = pl->validate_arrived_only; return HB_OK; }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = ((pl->V8 || pl->Winv8 || pl->Vw8) && pl->use_v8) ? 1 : 0; return HB_OK; }
@@ -402,7 +405,7 @@ int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) {
     return HB_ERR_BAD_ARG;
 }
 
-void hb_open_plan_destroy(hb_open_plan *pl) {
+void hb_open_plan_destroy(hb_open_plan *pl) { HB_API_GUARD((pl ? pl->ctx : nullptr));
     if (!pl) return;
     if (pl->in_dg) (void)hipFree(pl->in_dg);
     if (pl->coef_dg) (void)hipFree(pl->coef_dg);

@@ -131,7 +131,7 @@ void make_exps(SqrtExps &E, const uint64_t *p_limbs, int n_limbs, int nl) {
 
 }  // namespace
 
-extern "C" int hb_sqrt_mod(hb_ctx *ctx, const uint64_t *a_dev, int64_t C, uint64_t *out_dev, uint8_t *ok_dev, void *stream) {
+extern "C" int hb_sqrt_mod(hb_ctx *ctx, const uint64_t *a_dev, int64_t C, uint64_t *out_dev, uint8_t *ok_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0) return HB_OK;
     if (!a_dev || !out_dev || !ok_dev) return HB_ERR_BAD_ARG;

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(WB_THREADS) k_wb(const FpParams<NL> P, const u
                                                    const uint32_t *__restrict__ ys, const uint8_t *__restrict__ present,
                                                    int n, int k, int64_t C, uint32_t *__restrict__ scratch, size_t slab_words,
                                                    uint32_t *__restrict__ coeffs, int32_t *__restrict__ coeff_len, int32_t *__restrict__ status,
-                                                   const uint8_t *__restrict__ done /* codewords already decoded (Gao inside the radius) */) {
+                                                   const int32_t *__restrict__ todo /* nullptr: all C codewords; else the C indices Gao left undecided */) {
     __shared__ uint32_t s_mult[WB_MAXROWS * NL];     // column-j multipliers of every row
     __shared__ uint32_t s_prow[WB_MAXCOLS * NL];     // pivot row / later: solution vector
     __shared__ uint32_t s_dinv[WB_MAXROWS * NL];     // inverse pivots
@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(WB_THREADS) k_wb(const FpParams<NL> P, const u
     const int tid = threadIdx.x;
     uint32_t *M = scratch + (size_t)blockIdx.x * slab_words;
 
-    for (int64_t cw = blockIdx.x; cw < C; cw += gridDim.x) {
-        if (done && done[cw]) continue;              // block-uniform
+    for (int64_t it = blockIdx.x; it < C; it += gridDim.x) {
+        const int64_t cw = todo ? (int64_t)todo[it] : it;    // block-uniform
         const uint32_t *y = ys + (size_t)cw * n * NW;
         const uint8_t *pr = present + (size_t)cw * n;
         __syncthreads();
@@ -358,9 +358,11 @@ __global__ void k_wb_any_erasure(const uint8_t *__restrict__ present, int64_t to
 // stripping trailing zeros (polynomial.py:14-20); the others are left to k_wb
 template <int NW>
 __global__ void k_wb_take_gao(const uint8_t *__restrict__ ok, const uint32_t *__restrict__ coeffs, int k, int64_t C,
-                              int32_t *__restrict__ coeff_len, int32_t *__restrict__ status) {
+                              int32_t *__restrict__ coeff_len, int32_t *__restrict__ status, int32_t *__restrict__ rejected,
+                              int32_t *__restrict__ todo) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C || !ok[c]) return;
+    if (c >= C) return;
+    if (!ok[c]) { todo[atomicAdd(rejected, 1)] = (int32_t)c; return; }   // the row reduction's work list (any order: codewords are independent)
     int len = k;
     while (len > 0) {
         const uint32_t *e = coeffs + ((size_t)c * k + (len - 1)) * NW;
@@ -375,16 +377,28 @@ __global__ void k_wb_take_gao(const uint8_t *__restrict__ ok, const uint32_t *__
 
 extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, const uint64_t *ys_dev,
                             const uint8_t *present_dev, int64_t C, uint64_t *coeffs_dev, int32_t *coeff_len_dev,
-                            int32_t *status_dev, void *stream) {
+                            int32_t *status_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !x_host || n < 1 || k < 1 || k > n || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0) return HB_OK;
     if (!ys_dev || !present_dev || !coeffs_dev || !coeff_len_dev || !status_dev) return HB_ERR_BAD_ARG;
     if (n + 1 > WB_MAXROWS || n + 4 > WB_MAXCOLS) return fail(ctx, HB_ERR_UNSUPPORTED, "welch-berlekamp: n > 255");
     hipStream_t s = (hipStream_t)stream;
     const int NLr = ctx->nl();
+    // every temporary of this call is released on every way out (the HB_HIP / launch checks return early);
+    // hipFree waits for the device, so nothing in flight loses its buffers
+    struct Temps {
+        std::vector<void *> bufs;
+        ~Temps() { for (void *q : bufs) if (q) (void)hipFree(q); }
+        int alloc(hb_ctx *c, void **out, size_t bytes) {
+            HB_HIP(c, hipMalloc(out, bytes ? bytes : 4));
+            bufs.push_back(*out);
+            return HB_OK;
+        }
+    } tmp;
     uint32_t *xd = nullptr, *xm = nullptr;
     int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
-    HB_HIP(ctx, hipMalloc(&xm, (size_t)n * NLr * 4));
+    tmp.bufs.push_back(xd);
+    rc = tmp.alloc(ctx, (void **)&xm, (size_t)n * NLr * 4); if (rc) return rc;
     HB_DISPATCH(ctx,
         (k_points_to_mont<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, xd, n, xm)),
         (k_points_to_mont<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, xd, n, xm)));
@@ -398,9 +412,11 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
     // reference's particular solution, its descending-e' loop and its two failure messages matter -- goes through the
     // row reduction below.  Batches with erasures (per-codeword point sets) take the row reduction throughout.
     uint8_t *gao_ok = nullptr;
+    int32_t *todo = nullptr;
+    int64_t rejected = C;                            // codewords the row reduction still has to look at
     if (!getenv("HB_WB_NO_GAO") && n - k >= 1 && 2 * (k - 1) + 1 <= n) {
         int32_t erased = 0;
-        HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, sizeof(int32_t), s));
+        HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, 2 * sizeof(int32_t), s));
         const int64_t tot = C * n;
         k_wb_any_erasure<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(present_dev, tot, ctx->flag_dev);
         HB_LAUNCH_CHECK(ctx);
@@ -409,30 +425,33 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
         if (!erased) {
             uint32_t *errloc = nullptr;
             int32_t *errlen = nullptr;
-            HB_HIP(ctx, hipMalloc(&gao_ok, (size_t)C));
-            HB_HIP(ctx, hipMalloc(&errloc, (size_t)C * (n + 1) * ctx->elem_words() * 4));
-            HB_HIP(ctx, hipMalloc(&errlen, (size_t)C * sizeof(int32_t)));
+            rc = tmp.alloc(ctx, (void **)&gao_ok, (size_t)C); if (rc) return rc;
+            rc = tmp.alloc(ctx, (void **)&errloc, (size_t)C * (n + 1) * ctx->elem_words() * 4); if (rc) return rc;
+            rc = tmp.alloc(ctx, (void **)&errlen, (size_t)C * sizeof(int32_t)); if (rc) return rc;
+            rc = tmp.alloc(ctx, (void **)&todo, (size_t)C * sizeof(int32_t)); if (rc) return rc;
             rc = hb_gao_decode(ctx, x_host, n, k, ys_dev, C, coeffs_dev, (uint64_t *)errloc, errlen, gao_ok, stream);
-            (void)hipFree(errloc); (void)hipFree(errlen);
-            if (rc) { (void)hipFree(gao_ok); (void)hipFree(xd); (void)hipFree(xm); return rc; }
-            if (ctx->n_limbs == 4) k_wb_take_gao<8><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev);
-            else k_wb_take_gao<2><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev);
+            if (rc) return rc;
+            if (ctx->n_limbs == 4) k_wb_take_gao<8><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
+            else k_wb_take_gao<2><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
             HB_LAUNCH_CHECK(ctx);
+            int32_t rej = 0;
+            HB_HIP(ctx, hipMemcpyAsync(&rej, ctx->flag_dev + 1, sizeof rej, hipMemcpyDeviceToHost, s));
+            HB_HIP(ctx, hipStreamSynchronize(s));
+            rejected = rej;
         }
     }
-    int64_t blocks = C < 1024 ? C : 1024;
-    uint32_t *scratch = nullptr;
-    HB_HIP(ctx, hipMalloc(&scratch, slab_words * 4 * (size_t)blocks));
-    HB_DISPATCH(ctx,
-        (k_wb<9, 8><<<(unsigned)blocks, WB_THREADS, 0, s>>>(ctx->pw, xm, (const uint32_t *)ys_dev, present_dev, n, k, C, scratch, slab_words,
-                                                          (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, gao_ok)),
-        (k_wb<3, 2><<<(unsigned)blocks, WB_THREADS, 0, s>>>(ctx->pn, xm, (const uint32_t *)ys_dev, present_dev, n, k, C, scratch, slab_words,
-                                                          (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, gao_ok)));
-    HB_LAUNCH_CHECK(ctx);
+    if (rejected > 0) {
+        // the slab-resident row reduction: one block per codeword in turn; no more blocks (and slabs) than codewords left for it
+        int64_t blocks = rejected < 1024 ? rejected : 1024;
+        uint32_t *scratch = nullptr;
+        rc = tmp.alloc(ctx, (void **)&scratch, slab_words * 4 * (size_t)blocks); if (rc) return rc;
+        HB_DISPATCH(ctx,
+            (k_wb<9, 8><<<(unsigned)blocks, WB_THREADS, 0, s>>>(ctx->pw, xm, (const uint32_t *)ys_dev, present_dev, n, k, rejected, scratch, slab_words,
+                                                              (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, todo)),
+            (k_wb<3, 2><<<(unsigned)blocks, WB_THREADS, 0, s>>>(ctx->pn, xm, (const uint32_t *)ys_dev, present_dev, n, k, rejected, scratch, slab_words,
+                                                              (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, todo)));
+        HB_LAUNCH_CHECK(ctx);
+    }
     HB_HIP(ctx, hipStreamSynchronize(s));
-    if (gao_ok) HB_HIP(ctx, hipFree(gao_ok));
-    HB_HIP(ctx, hipFree(scratch));
-    HB_HIP(ctx, hipFree(xd));
-    HB_HIP(ctx, hipFree(xm));
     return HB_OK;
 }

@@ -50,7 +50,10 @@ async def _incremental_decode_device(receivers, make_decoder, device):
                     raise ValueError("column of non-integers")
                 inc.add(idx, list(blob))
             else:
-                inc.add(idx, wire.wire_to_tensor(blob, device))
+                col = wire.wire_to_tensor(blob, device)
+                if col.dim() == 2 and col.shape[1] == inc.ctx.n_limbs and col.shape[0]:
+                    inc.ctx.reduce_(col)     # a sender's words at or above p mean their residues, as at the reference's boundary
+                inc.add(idx, col)
         except (ValueError, TypeError, OverflowError, struct.error):
             # one Byzantine sender must not abort an honest party's open: whatever it sent, it is not a column
             logging.error("[BatchReconstructDevice] malformed column from %d dropped", idx)

@@ -13,7 +13,7 @@ Every batched argument (`polynomials`, `data_list`, `coeffs`, `ys_list`, `ys`) t
 layout, and the result comes back in the same kind:
     numpy.ndarray  uint64, shape (rows, width, limbs)      little-endian limbs, limbs = 4 (p < 2^256) or 1 (p < 2^64)
     torch.Tensor   int64,  shape (rows, width, limbs)      host or device; a device tensor never leaves HBM
-Values are reduced on entry like list inputs (pyx:31-32).  The points / exponents (x, zs, omega) stay small lists.
+Values are reduced on entry like list inputs (pyx:31-32; one elementwise launch, `hb_reduce`): words at or above p are fine.  The points / exponents (x, zs, omega) stay small lists.
 """
 import ctypes
 
@@ -73,7 +73,11 @@ class _Batch:
                 dev = data.reshape(self.rows * self.width, ctx.n_limbs).contiguous().to(ctx.tdev)
             if pad_to is not None and pad_to != self.width:
                 raise ValueError(f"{what}: packed rows must have length {pad_to}")
-            self.dev = dev
+            # to_ZZ_p (pyx:31-32): whatever words the caller packed, the kernels see canonical residues.  A caller's own
+            # device tensor is never written: it is reduced into a fresh buffer; host batches were copied already.
+            red = ctx.empty(dev.shape[0]) if self.kind == "torch-device" else dev
+            ctx.check(ctx.lib.hb_reduce(ctx.h, ctx.ptr(dev), ctx.ptr(red), dev.shape[0], None, ctx.stream()), "reduce")
+            self.dev = red
             return
         self.kind = "list"
         self.rows = len(data)
@@ -141,7 +145,10 @@ def vandermonde_inverse(x, modulus):
         return "[]"
     ctx.check(rc, "vandermonde_inverse")
     out = np.zeros((k * k, ctx.n_limbs), dtype=np.uint64)
-    ctx.check(ctx.lib.hb_matrix_to_host(ctx.h, m, np_ptr(out), ctx.stream()), "matrix_to_host")
+    try:
+        ctx.check(ctx.lib.hb_matrix_to_host(ctx.h, m, np_ptr(out), ctx.stream()), "matrix_to_host")
+    finally:
+        ctx.lib.hb_matrix_destroy(m)          # this call's handle; the context's cache keeps (and bounds) its own reference
     from .._capi import limbs_to_ints
 
     vals = limbs_to_ints(out, ctx.nbytes)

@@ -107,6 +107,13 @@ int hb_matvec_check(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_
                     const uint64_t *expect_dev, hb_view expect, const int32_t *check_rows, int n_check,
                     int32_t *mismatch_dev, int64_t C, void *stream);
 
+/* to_ZZ_p for packed batches (hbmpc_ntl_helpers.pyx:31-32: every value entering the reference's boundary is reduced
+ * mod p): out[i] = in[i] mod p for `count` packed elements of any word content (in == out allowed).  *changed_dev, when
+ * given, is incremented once per element that was not already canonical.  The kernels behind every other entry point
+ * expect canonical residues; list-of-int inputs are reduced by the Python glue, packed numpy / torch batches pass through
+ * this call.  Asynchronous. */
+int hb_reduce(hb_ctx *ctx, const uint64_t *in_dev, uint64_t *out_dev, int64_t count, int32_t *changed_dev, void *stream);
+
 /* ---- reference-shaped entry points (chunk-major buffers, tables cached in ctx) -------- */
 /* vandermonde_batch_evaluate (pyx:199-244): polys_dev [C][d] -> out_dev [C][n] */
 int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_t *polys_dev,

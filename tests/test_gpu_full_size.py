@@ -27,7 +27,7 @@ def _rand(torch, count, gen):
 
 
 # ---------------------------------------------------------------------------------------------- config 4
-@pytest.mark.parametrize("decoder,count", [("gao", 1 << 18), ("wb", 1 << 14)])
+@pytest.mark.parametrize("decoder,count", [("gao", 1 << 18), ("wb", 1 << 14), ("wb", 1 << 18)])
 def test_robust_decoders_full_batch_cfg4(decoder, count):
     """n=100, t=33: `count` codewords of random degree-33 polynomials, exactly 33 positions of each replaced by random field
     elements (the decoding radius), no erasures -> every generating polynomial recovered bit for bit; a 64-codeword subset
@@ -157,7 +157,7 @@ def test_full_size_open_cfg5_shard():
 
 # ---------------------------------------------------------------------------------------------- bounded stress
 def test_randomised_differential_open_paths():
-    """~20 s, seeded: random shapes / arrival orders / edge-heavy inputs through the matrix-core and the integer-VALU
+    """~60 s (HB_STRESS_SECONDS), seeded: random shapes / arrival orders / edge-heavy inputs through the matrix-core and the integer-VALU
     kernels (scratch/stress_open_paths.py ran 248 k such opens in round 1; this is its bounded twin inside the suite),
     now including shapes that take the full-size matrix-core kernel (omega points, large powers)."""
     import torch
@@ -169,7 +169,7 @@ def test_randomised_differential_open_paths():
     rnd = random.Random(20260928)
     ctx = Context.get(P)
     as_np = lambda tns: tns.cpu().numpy().view(np.uint64)  # noqa: E731
-    t_end = time.time() + 20.0
+    t_end = time.time() + float(os.environ.get("HB_STRESS_SECONDS", "60"))
     trials = wide = 0
     while time.time() < t_end or trials < 40:
         n = rnd.choice([4, 5, 7, 8, 13, 16, 17, 22, 31, 32, 33, 40, 47, 48, 49, 63, 64, 100, 128])
@@ -211,6 +211,82 @@ def test_randomised_differential_open_paths():
         del op
     torch.cuda.synchronize()
     assert trials >= 40 and wide >= 5
+
+
+def _table_recycling_trials(seconds, seed):
+    """Plans created and destroyed in a tight loop on a context whose table cache holds ONE entry: every plan's tables are
+    built at addresses freed a moment ago, and the FIRST launch over each fresh table is what is compared (round 2's stale-table
+    defect only ever showed there: DESIGN section 9).  Returns (trials, failures) -- run in a subprocess so that HB_UPLOAD_MODE
+    and the cap are read by a fresh library."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+
+    rnd = random.Random(seed)
+    ctx = Context.get(P)
+    as_np = lambda tns: tns.cpu().numpy().view(np.uint64)  # noqa: E731
+    t_end = time.time() + seconds
+    trials, failures = 0, []
+    while time.time() < t_end:
+        n = rnd.choice([16, 22, 31, 32, 48, 64, 64, 64, 100])
+        t = rnd.randrange(3, min(n // 3 + 1, 32))
+        use_omega = rnd.random() < 0.5
+        d = t + 1
+        b = rnd.choice([16 * d, 33 * d - 1, 300 * d, rnd.randrange(1, 6000)])
+        c = (b + d - 1) // d
+        order = list(range(n))
+        rnd.shuffle(order)
+        z, zc = order[:d], order[d : d + min(t, n - d)]
+        op = BatchOpen(P, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=b)
+        if not op.uses_matrix_cores():
+            continue
+        if op.uses_fused_validate():
+            op.set_fused_validate(True)                      # the fused matrices too: built now, first launch below
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(rnd.randrange(1 << 30))
+        sh = _rand(torch, b, gen)
+        enc_first = as_np(op.r1_encode(sh)).copy()           # first launch over the freshly built encode table
+        res_first = as_np(op.r2_decode(torch.from_numpy(enc_first.view(np.int64)).cuda(), b)).copy()
+        ok_first = op.ok()
+        enc_again = as_np(op.r1_encode(sh))
+        res_again = as_np(op.r2_decode(torch.from_numpy(enc_first.view(np.int64)).cuda(), b))
+        ok_again = op.ok()
+        want = as_np(sh)
+        if not (np.array_equal(enc_first, enc_again) and np.array_equal(res_first, want) and np.array_equal(res_again, want) and ok_first and ok_again):
+            failures.append((n, t, b, use_omega, bool(np.array_equal(enc_first, enc_again)), bool(np.array_equal(res_first, want)), ok_first, ok_again))
+        trials += 1
+        del op
+    torch.cuda.synchronize()
+    return trials, failures
+
+
+def _run_recycling_subprocess(seconds, seed, upload_mode=None):
+    import json
+    import subprocess
+    import sys
+
+    from conftest import REPO
+
+    env = dict(os.environ, HB_CACHE_CAP="1", HB_PLAN_CACHE="0")
+    env.pop("HB_UPLOAD_MODE", None)
+    if upload_mode:
+        env["HB_UPLOAD_MODE"] = upload_mode
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_full_size as T; "
+            "tr, fl = T._table_recycling_trials(%r, %r); print('RESULT ' + json.dumps({'trials': tr, 'failures': fl}))"
+            % (REPO, os.path.join(REPO, "tests"), seconds, seed))
+    res = subprocess.run([sys.executable, "-c", code], cwd=REPO, env=env, capture_output=True, text=True, timeout=seconds + 600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT ")][-1]
+    return json.loads(line[len("RESULT "):])
+
+
+def test_table_recycling_first_launch():
+    """create / destroy plans in a loop with HB_CACHE_CAP=1 and compare every first launch (~25 s).  The
+    production upload path (table images written by a copy KERNEL on the stream) must show no stale table."""
+    out = _run_recycling_subprocess(25.0, 20260928)
+    assert out["trials"] >= 200, out["trials"]
+    assert not out["failures"], out["failures"][:5]
 
 
 # ---------------------------------------------------------------------------------------------- narrow contexts
@@ -335,6 +411,70 @@ def test_table_caches_are_bounded(monkeypatch):
     assert ctx.cache_entries() == 0 and tables >= 1
 
 
+def test_one_context_shared_by_concurrent_threads(monkeypatch):
+    """ctypes releases the GIL, so threads that share one Context (= one hb_ctx) really are inside the library at
+    the same time.  Four threads create plans for different arrival sets, interpolate, Gao-decode and open concurrently with a
+    table cap of 8 entries (cache_trim runs on almost every call and frees tables other threads looked up a moment ago);
+    every result must equal the single-threaded answer.  The library serialises its table / cache / refcount sections
+    per context (hb_common.hpp: HB_API_GUARD)."""
+    import threading
+
+    import torch
+
+    from honeybadgermpc_amd import ntl
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+
+    p = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141   # secp256k1's group order: a prime no other test holds a context for
+    monkeypatch.setenv("HB_CACHE_CAP", "8")
+    Context._cache.pop((p, 0, 4), None)
+    ctx = Context.get(p, 0)
+    n, t = 24, 5
+    d = t + 1
+    x = list(range(1, n + 1))
+    rnd = random.Random(77)
+    polys = [[rnd.randrange(p) for _ in range(d)] for _ in range(6)]
+    ev = oracle.vandermonde_batch_evaluate(x, polys, p)                      # [6][n]
+    c = 700
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(5)
+    coef = _rand(torch, c * d, gen)                                            # < 2^253 < p: canonical
+    V = BatchOpen(p, n, t, max_shares=c * d)
+    cols = V.r1_encode(coef).clone()                                           # [n][c]: values of c polynomials at all points
+    torch.cuda.synchronize()
+    errors, rounds = [], 40
+
+    def worker(seed):
+        try:
+            r = random.Random(seed)
+            for _ in range(rounds):
+                z = r.sample(range(n), d)
+                zc = [j for j in r.sample(range(n), n) if j not in z][:t]
+                got = ntl.vandermonde_batch_interpolate([x[j] for j in z], [[row[j] for j in z] for row in ev], p)
+                if got != polys:
+                    errors.append(("interpolate", seed, z))
+                sub = sorted(r.sample(range(n), 16))
+                g = ntl.gao_interpolate_batch([x[j] for j in sub], [[row[j] for j in sub] for row in ev], d, p)
+                if [a for a, _ in g] != polys:
+                    errors.append(("gao", seed, sub))
+                op = BatchOpen(p, n, t, z=z, zc=zc, max_shares=c * d)
+                res = op.r2_decode(cols, c * d)
+                fine = op.ok()
+                if not fine or not torch.equal(res, coef):
+                    errors.append(("open", seed, z, fine))
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append(("exception", seed, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+        assert not th.is_alive()
+    assert not errors, errors[:5]
+    ctx.cache_clear()
+
+
 def test_open_plans_are_cached_per_thread(monkeypatch):
     """A plan costs ~2 ms to build; the device decoder takes its plans from a per-thread LRU keyed by everything that
     determines them, bounded by HB_PLAN_CACHE, and switched off by 0.  Two decoders fed the same arrival pattern share
@@ -386,3 +526,50 @@ def test_open_plans_are_cached_per_thread(monkeypatch):
         assert errs == (set() if liar is None else {liar})
     assert len(device._plan_cache.plans) >= 1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("p", [0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141, (1 << 256) - 189,
+                               (1 << 256) - (1 << 32) - 977, (1 << 255) + 95, P])
+def test_moduli_above_2_255_on_the_matrix_cores(p):
+    """Round-3 finding: for p > 2^255 a Barrett remainder r < 2p can reach 2^256, and the matrix-core epilogues (k_mm8, k_mm8w,
+    k_prescale_tab) decided r >= p from the eight packed words alone -- about one output in 10^4 came back as r - 2^256 + ... wrong
+    (secp256k1's group order: 1 of 16 800 encode outputs).  Large seeded batches through both kernel families, encode / fused
+    and unfused decode, plus an oracle subset."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+
+    if pow(2, p - 1, p) != 1:
+        pytest.skip("not a prime")
+    ctx = Context.get(p, 0)
+    n, t = 24, 5
+    d = t + 1
+    c = 6000
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(p % 1000003)
+    coef = torch.randint(-(1 << 63), (1 << 63) - 1, (c * d, 4), dtype=torch.int64, device="cuda", generator=gen)
+    coef[:, 3] &= (1 << (p.bit_length() - 193)) - 1          # below 2^(bits-1) <= p: canonical
+    rnd = random.Random(9)
+    as_np = lambda tns: tns.cpu().numpy().view(np.uint64)  # noqa: E731
+    z = rnd.sample(range(n), d)
+    zc = [j for j in range(n) if j not in z][:t]
+    op = BatchOpen(p, n, t, z=z, zc=zc, max_shares=c * d)
+    assert op.uses_matrix_cores()
+    enc_m = op.r1_encode(coef)
+    op.set_matrix_cores(False)
+    enc_v = op.r1_encode(coef)
+    assert np.array_equal(as_np(enc_m), as_np(enc_v)), "k_mm8 encode differs from the integer-VALU encode"
+    x = list(range(1, n + 1))
+    ints = ctx.download_ints(coef[: 40 * d])
+    want = oracle.vandermonde_batch_evaluate(x, [ints[i * d : (i + 1) * d] for i in range(40)], p)
+    got = ctx.download_ints(enc_v.view(n, c, 4)[:, :40, :].contiguous().view(-1, 4))
+    assert got == [want[k][j] for j in range(n) for k in range(40)]
+    for mc, fused in ((True, True), (True, False), (False, False)):
+        op.set_matrix_cores(mc)
+        op.set_fused_validate(fused)
+        res = op.r2_decode(enc_v, c * d)
+        msg = op.r1_decode(enc_v, c * d)
+        assert op.ok(), (mc, fused)
+        assert torch.equal(res, coef), (mc, fused)
+        assert torch.equal(msg, coef.view(c, d, 4)[:, 0, :]), (mc, fused)

@@ -401,6 +401,8 @@ def test_open_coalescer_many_small_opens(n, t, liars):
         second = [co.open_share_array(shares[k][i]) for k in range(66, 72)]
         got += [await h for h in reversed(second)][::-1]
         counters[i] = (co.opens, co.batches)
+        assert co.pending_batches() == 0, "a finished batch is still held after its last open was delivered"
+        assert (await first[3] is got[3])                  # a second await of a delivered open still answers
         return got
 
     async def main():
@@ -416,6 +418,90 @@ def test_open_coalescer_many_small_opens(n, t, liars):
             continue
         for k in range(72):
             assert ctx.download_ints(results[i][k]) == secrets[k], (i, k)
+
+
+def test_open_coalescer_cut_points_with_concurrent_coroutines():
+    """with several coroutines per party the point where "the first await" falls depends on the scheduler, so
+    (a) a batch cut by an await may only hold opens of ONE coroutine -- otherwise RuntimeError instead of parties exchanging
+    batches of different composition; (b) flush() cuts at a point of the program order: two coroutines queue, a third one
+    flushes, every party sees the same single batch whatever order its coroutines ran in; (c) nothing is kept once every
+    open of a batch was delivered, also when some opens are never awaited."""
+    import gc
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.open_coalescer import OpenCoalescer
+
+    n, t = 4, 1
+    rnd = random.Random(12)
+    ctx = Context.get(P)
+    xs = list(range(1, n + 1))
+    secrets = [[rnd.randrange(P) for _ in range(5)] for _ in range(6)]
+
+    def share_all(vals):
+        polys = [[s] + [rnd.randrange(P) for _ in range(t)] for s in vals]
+        return [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+
+    shares = [share_all(v) for v in secrets]
+
+    async def party(i, net, order):
+        co = OpenCoalescer(P, n, t, i, net.get_send_recv(i), cut_on_await=False)
+        handles = {}
+        queued = asyncio.Event()
+
+        turn = [0]
+
+        async def producer(ks, delay):
+            # the ORDER of open_share_array calls is the program order every party shares (the reference numbers share ids by
+            # it); what differs from party to party is how the coroutines interleave around those calls
+            for k in ks:
+                while turn[0] != k:
+                    await asyncio.sleep(0)
+                for _ in range(delay):
+                    await asyncio.sleep(0)
+                handles[k] = co.open_share_array(shares[k][i])
+                turn[0] += 1
+
+        async def consumer(k):
+            await queued.wait()
+            return ctx.download_ints(await handles[k])
+
+        prods = [asyncio.ensure_future(producer([0, 2, 4], order)), asyncio.ensure_future(producer([1, 3], 3 - order))]
+        await asyncio.gather(*prods)
+        with pytest.raises(RuntimeError, match="flush"):
+            await handles[0]                              # cut_on_await=False: not cut yet -> loud
+        co.flush()                                        # the deterministic cut: all five opens, one batch, on every party
+        queued.set()
+        got = await asyncio.gather(*[consumer(k) for k in (0, 1, 2, 3)])       # open 4 is never awaited
+        assert co.batches == 1
+        del handles
+        gc.collect()
+        assert co.pending_batches() == 0
+        return got
+
+    async def mixed(i, net):
+        """cut_on_await=True and a batch holding opens of two coroutines: refused"""
+        co = OpenCoalescer(P, n, t, i, net.get_send_recv(i))
+        h = {}
+
+        async def q(k):
+            h[k] = co.open_share_array(shares[k][i])
+
+        await asyncio.gather(q(0), q(1))
+        with pytest.raises(RuntimeError, match="more than one coroutine"):
+            await h[0]
+        co.flush()
+        return ctx.download_ints(await h[1])
+
+    async def main():
+        net = _TaggedNet(n)
+        a = await asyncio.gather(*[party(i, net, i % 3) for i in range(n)])
+        net2 = _TaggedNet(n)
+        b = await asyncio.gather(*[mixed(i, net2) for i in range(n)])
+        return a, b
+
+    a, b = asyncio.run(main())
+    for i in range(n):
+        assert a[i] == secrets[:4] and b[i] == secrets[1]
 
 
 def test_batch_reconstruct_device_survives_non_bytes_payloads():
@@ -442,6 +528,12 @@ def test_batch_reconstruct_device_survives_non_bytes_payloads():
                 return (tag, junk[i] if tag == "R1" else ["x", 1.5] if i == 0 else "R2?")
             if i == 2:                                   # honest, but speaks the reference's format: a list of Python ints
                 return (tag, wire.unpack_ints(blob))
+            if i == 3:                                   # honest values as non-canonical words (x + p < 2^256): residues count, as at
+                import numpy as np                       # the reference's boundary (to_ZZ_p, pyx:31-32)
+
+                vals = [v + P if v + P < (1 << 256) else v for v in wire.unpack_ints(blob)]
+                raw = np.array([[(v >> (64 * q)) & ((1 << 64) - 1) for q in range(4)] for v in vals], dtype=np.uint64)
+                return (tag, wire.pack_limbs(raw))
             return msg
 
         return tamper
