@@ -96,6 +96,15 @@ struct hb_ctx {
     int32_t *flag_dev;                                // 64 status words
     hb::PrescaleParams psc;                           // valid when psc_state == 1
     int psc_state = 0;                                // 0 not computed yet, 1 valid, -1 modulus outside [2^254, 2^256)
+    // the plan-free robust path (hb_quick.hip): per point set a table of x, x^i and 1 / (x_a - x_b); a ring of scratch slots for the
+    // matrices built on the device; pooled probe states; per inner dimension the constants every device-built image shares
+    std::map<std::string, void *> ptcache;            // hb::PointTable *
+    struct QuickSlot { void *buf = nullptr; size_t cap = 0; void *ev = nullptr; };
+    std::vector<QuickSlot> qslots;
+    unsigned qnext = 0;
+    std::vector<void *> probe_pool, probe_host_pool;
+    std::map<int, void *> wide_shared;                // d -> hb::Mm8wShared *
+    std::map<std::string, std::vector<int>> wide_shapes;   // launch geometry per (row tiles, K-blocks, chunk tiles)
     int elem_words() const { return n_limbs == 4 ? 8 : 2; }
     int nl() const { return n_limbs == 4 ? 9 : 3; }
 };
@@ -218,6 +227,17 @@ void mm8w_free(Mm8wMatrix *m);
 int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                 uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                 int64_t C, hipStream_t s, const uint32_t *cmp = nullptr, hb_view cv = hb_view{0, 0}, int n_store = 0);
+// device-built images (hb_quick.hip): geometry of an n_out x d image, the per-(context, d) constants, and the launch over
+// borrowed buffers; first_bad_dev (CHECK mode, optional): atomicMin of the first chunk whose compare failed
+struct Mm8wShared { uint32_t bias; uint32_t c80r[9], biasmod[9]; void *wp; uint32_t *zero; };
+int mm8w_geometry(int n_out, int d, int *tile_rows, int *n_rt, int *nkb, size_t *a8_bytes, size_t *crow_words);
+int mm8w_shared(hb_ctx *ctx, int d, const Mm8wShared **out, hipStream_t s);
+void mm8w_shared_free(hb_ctx *ctx);
+int launch_mm8w_raw(hb_ctx *ctx, int n_out, int d, int tile_rows, const void *a8, const uint32_t *crow, const Mm8wShared *sh,
+                    const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *out, hb_view ov, int64_t out_count,
+                    const int32_t *check_mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store,
+                    int32_t *first_bad_dev);
+void point_tables_free(hb_ctx *ctx);
 // the wide image of a generic matrix, built on first use (nullptr when the path does not apply)
 const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *m, hipStream_t s);
 

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
                                                  const uint32_t *__restrict__ cmp_pk, int64_t cmp_sc, int64_t cmp_sl, int mask_is_map, int n_store,
                                                  int n_out, int n_rt, int nkb, int tpw, int nbuf, int rq, int64_t n_chunks, int64_t n_units,
-                                                 uint32_t bias, const WideParams *__restrict__ wpp) {
+                                                 uint32_t bias, const WideParams *__restrict__ wpp, int32_t *__restrict__ first_bad) {
     extern __shared__ uint4 mm8w_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -140,6 +140,9 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     }
     int buf = 0;
     int64_t unit = blockIdx.x;
+    // CHECK mode with first_bad: the first chunk whose compare failed.  A pass's compares run inside the NEXT pass, and a wave's
+    // passes walk the chunk tiles in increasing order: the first time its flag becomes non-zero names its smallest such chunk.
+    int64_t cmp_chunk0 = 0, bad_chunk = -1;
 #ifdef HB_MM8_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -205,6 +208,13 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
 #undef MM8W_ARGS
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (CHECK) {
+                if (flag != 0 && bad_chunk < 0) {
+                    const uint32_t m16 = (uint32_t)((flag | (flag >> 16) | (flag >> 32) | (flag >> 48)) & 0xffffu);    // lane = chunk + 16 g
+                    bad_chunk = cmp_chunk0 + (__builtin_ctz(m16));
+                }
+                cmp_chunk0 = chunk - n;          // the tile whose sums this pass leaves for the next one to compare
+            }
             MM8W_T(1);   // MFMA phase + the reduction of the pass before + word assembly
             // where this pass's outputs go (used by the next pass, or by the drain below); output r's row constant is 4 r rows on
             crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(crl + (size_t)(16 * rt + g) * 16);
@@ -251,7 +261,14 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (CHECK) {
-        if (flag != 0 && lane == 0) atomicOr(mismatch, 1);
+        if (flag != 0 && bad_chunk < 0) {
+            const uint32_t m16 = (uint32_t)((flag | (flag >> 16) | (flag >> 32) | (flag >> 48)) & 0xffffu);
+            bad_chunk = cmp_chunk0 + (__builtin_ctz(m16));
+        }
+        if (flag != 0 && lane == 0) {
+            atomicOr(mismatch, 1);
+            if (first_bad) atomicMin(first_bad, (int32_t)(bad_chunk > 0x7fffffff ? 0x7fffffff : bad_chunk));
+        }
     }
 #ifdef HB_MM8_TIMING
     if (lane == 0 && blockIdx.x < 256) for (int k = 0; k < 8; k++) g_mm8w_t[(blockIdx.x * 4 + wave) * 8 + k] = tacc[k];
@@ -383,6 +400,8 @@ void mm8w_free(Mm8wMatrix *m) {
     delete m;
 }
 
+int mm8w_tile_rows(int n_out, int nkb);
+
 // Image of an n_out x n_in matrix given as canonical residues, row-major, 4 x u64 limbs each.
 // HB_ERR_UNSUPPORTED when the path does not apply (narrow context, modulus outside [2^254, 2^256), inner
 // dimension beyond the LDS budget, HB_NO_MFMA / HB_NO_MFMA_WIDE set).
@@ -395,14 +414,7 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     // Row tiles of 16 rows, or of 12 / 8 (the last rows of every group of the MFMA tile left empty): a pass costs its MFMA phase plus
     // ~490 instructions per output a lane keeps (reduction + word assembly), all at the same ~5.5 cycles each -- 22 rows are two
     // passes either way, and two passes of three outputs beat two of four.
-    int tile_rows = 16;
-    if (!getenv("HB_MM8W_TILE16")) {
-        double best = 0.0;
-        for (int tr = 16; tr >= 8; tr -= 4) {
-            const double cost = (double)((n_out + tr - 1) / tr) * (228.0 * nkb + 160 + (tr / 4) * 490);
-            if (tr == 16 || cost < best - 1e-9) { best = cost; tile_rows = tr; }
-        }
-    }
+    const int tile_rows = mm8w_tile_rows(n_out, nkb);
     const int n_rt = (n_out + tile_rows - 1) / tile_rows;
     int tpw = 0, nbuf = 0, rq = 0;
     if (!mm8w_shape(n_rt, nkb, 1, 1, &tpw, &nbuf, &rq)) return HB_ERR_UNSUPPORTED;
@@ -485,15 +497,33 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
 // out(c, i) = sum_l M[i][l] in(c, rows[l]) mod p, canonical; CHECK mode when check_mask_dev != nullptr: a flag per row and
 // out = the expected values, or -- with a compare view cmp -- a map (1 + row of cmp to compare row i with; 0: row i is a
 // result, stored to out when i < n_store): the fused decode + validate of hb_open.hip
+static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
+                            uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev);
+
 int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                 uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                 int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store) {
+    return launch_mm8w_impl(ctx, m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, nullptr);
+}
+
+static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
+                            uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
+                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev) {
     if (C <= 0) return HB_OK;
     int tpw = 1, nbuf = 1, rq = m->n_rt;
     const int64_t n_tiles = (C + 15) / 16;
     if (m->shape_tiles == n_tiles) { tpw = m->shape_tpw; nbuf = m->shape_nbuf; rq = m->shape_rq; }
     else {
-        if (!mm8w_shape(m->n_rt, m->nkb, n_tiles, mm8w_num_cus(), &tpw, &nbuf, &rq)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: shape");
+        // the simulation costs tens of microseconds: remembered per matrix, and per context for images that live for one launch
+        const std::string sk = std::to_string(m->n_rt) + ":" + std::to_string(m->nkb) + ":" + std::to_string((long long)n_tiles);
+        auto hit = ctx->wide_shapes.find(sk);
+        if (hit != ctx->wide_shapes.end()) { tpw = hit->second[0]; nbuf = hit->second[1]; rq = hit->second[2]; }
+        else {
+            if (!mm8w_shape(m->n_rt, m->nkb, n_tiles, mm8w_num_cus(), &tpw, &nbuf, &rq)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: shape");
+            if (ctx->wide_shapes.size() > 4096) ctx->wide_shapes.clear();
+            ctx->wide_shapes[sk] = std::vector<int>{tpw, nbuf, rq};
+        }
         m->shape_tiles = n_tiles; m->shape_tpw = tpw; m->shape_nbuf = nbuf; m->shape_rq = rq;
     }
     const int64_t n_units = ((n_tiles + tpw - 1) / tpw) * ((m->n_rt + rq - 1) / rq);
@@ -511,7 +541,7 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
         hipLaunchKernelGGL((k_mm8w<CHK, PL, KK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
-                           m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp);                                        \
+                           m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp, first_bad_dev);                         \
     } while (0)
     // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
     const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);
@@ -522,6 +552,100 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
 #undef MM8W_LAUNCH
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;
+}
+
+int mm8w_tile_rows(int n_out, int nkb) {
+    int tile_rows = 16;
+    if (!getenv("HB_MM8W_TILE16")) {
+        double best = 0.0;
+        for (int tr = 16; tr >= 8; tr -= 4) {
+            const double cost = (double)((n_out + tr - 1) / tr) * (228.0 * nkb + 160 + (tr / 4) * 490);
+            if (tr == 16 || cost < best - 1e-9) { best = cost; tile_rows = tr; }
+        }
+    }
+    return tile_rows;
+}
+
+// geometry of the int8 image of an n_out x d matrix (the same choices as mm8w_from_host)
+int mm8w_geometry(int n_out, int d, int *tile_rows, int *n_rt, int *nkb, size_t *a8_bytes, size_t *crow_words) {
+    if (n_out < 1 || d < 1) return HB_ERR_UNSUPPORTED;
+    *nkb = (d + 7) / 8;
+    *tile_rows = mm8w_tile_rows(n_out, *nkb);
+    *n_rt = (n_out + *tile_rows - 1) / *tile_rows;
+    int tpw = 0, nbuf = 0, rq = 0;
+    if (!mm8w_shape(*n_rt, *nkb, 1, 1, &tpw, &nbuf, &rq)) return HB_ERR_UNSUPPORTED;
+    *a8_bytes = ((size_t)*n_rt * *nkb + 1) * 4 * 64 * 16;          // one block of padding
+    *crow_words = (size_t)*n_rt * 16 * 16;
+    return HB_OK;
+}
+
+// What every device-built image of inner dimension d shares: the reduction constants (one device copy per context), the zero
+// block, and a bias that bounds the columns of ANY matrix of that width (|digit| <= 128, 32 digits, d terms) together with the
+// two constants of the per-row correction, (0x80..80 R) mod p and (bias sum_c 2^(8c)) mod p.
+int mm8w_shared(hb_ctx *ctx, int d, const Mm8wShared **out, hipStream_t s) {
+    auto it = ctx->wide_shared.find(d);
+    if (it != ctx->wide_shared.end()) { *out = static_cast<const Mm8wShared *>(it->second); return HB_OK; }
+    if (ctx->n_limbs != 4 || !prescale_params(ctx)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: modulus");
+    const uint64_t bias64 = 128ull * ((uint64_t)d * 32 * 128) + 1;
+    if (bias64 >= (1ull << 30)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: column bound too large");
+    Mm8wShared *sh = new Mm8wShared();
+    sh->bias = (uint32_t)bias64; sh->wp = nullptr; sh->zero = nullptr;
+    const Big p = big_from_limbs(ctx->p_limbs, 4);
+    Big biasall(17, 0);
+    for (int c = 0; c < MM8W_NC; c++) {
+        const int bit = 8 * c, j = bit >> 5, sft = bit & 31;
+        Big t(17, 0);
+        const uint64_t v = (uint64_t)sh->bias << sft;
+        t[j] = (uint32_t)v; t[j + 1] = (uint32_t)(v >> 32);
+        big_add(biasall, t);
+    }
+    to_digits(big_mod(biasall, p), sh->biasmod, 9);
+    Big c80(8, 0x80808080u);
+    to_digits(big_mod(big_mul(c80, big_pow2(261, 10)), p), sh->c80r, 9);
+    // the context-wide device copies (shared by every d)
+    void *wp = nullptr;
+    uint32_t *zero = nullptr;
+    for (auto &kv : ctx->wide_shared) { wp = static_cast<Mm8wShared *>(kv.second)->wp; zero = static_cast<Mm8wShared *>(kv.second)->zero; break; }
+    if (!wp) {
+        WideParams wph;
+        memset(&wph, 0, sizeof wph);
+        for (int k = 0; k < 10; k++) to_digits(big_mod(big_pow2(29 * (9 + k), 18), p), wph.T[k], 9);
+        memcpy(wph.pbar, ctx->psc.pbar, sizeof wph.pbar);
+        memcpy(wph.pneg, ctx->psc.pneg, sizeof wph.pneg);
+        wph.m0 = ctx->psc.m0; wph.m1 = ctx->psc.m1;
+        std::vector<uint8_t> zero64(64, 0), wpb((sizeof(WideParams) + 15) / 16 * 16, 0);
+        memcpy(wpb.data(), &wph, sizeof wph);
+        hipError_t e = hipMalloc(&wp, wpb.size());
+        if (e == hipSuccess) e = hipMalloc(&zero, 64);
+        int rc = e == hipSuccess ? upload_table(ctx, wp, wpb.data(), wpb.size(), s) : HB_ERR_HIP;
+        if (!rc) rc = upload_table(ctx, zero, zero64.data(), 64, s);
+        if (rc) { if (wp) (void)hipFree(wp); if (zero) (void)hipFree(zero); delete sh; return rc == HB_ERR_HIP ? fail(ctx, rc, "mm8w: shared tables") : rc; }
+    }
+    sh->wp = wp; sh->zero = zero;
+    ctx->wide_shared[d] = sh;
+    *out = sh;
+    return HB_OK;
+}
+
+void mm8w_shared_free(hb_ctx *ctx) {
+    bool first = true;
+    for (auto &kv : ctx->wide_shared) {
+        Mm8wShared *sh = static_cast<Mm8wShared *>(kv.second);
+        if (first) { (void)hipFree(sh->wp); (void)hipFree(sh->zero); first = false; }
+        delete sh;
+    }
+    ctx->wide_shared.clear();
+}
+
+int launch_mm8w_raw(hb_ctx *ctx, int n_out, int d, int tile_rows, const void *a8, const uint32_t *crow, const Mm8wShared *sh,
+                    const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *out, hb_view ov, int64_t out_count,
+                    const int32_t *check_mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store,
+                    int32_t *first_bad_dev) {
+    Mm8wMatrix m;
+    m.n_out = n_out; m.d = d; m.nkb = (d + 7) / 8; m.tile_rows = tile_rows; m.n_rt = (n_out + tile_rows - 1) / tile_rows;
+    m.shape_tiles = -1; m.shape_tpw = m.shape_nbuf = m.shape_rq = 0;
+    m.a8 = (int4 *)const_cast<void *>(a8); m.crow = const_cast<uint32_t *>(crow); m.zero = sh->zero; m.bias = sh->bias; m.wp = (WideParams *)sh->wp;
+    return launch_mm8w_impl(ctx, &m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, first_bad_dev);
 }
 
 }  // namespace hb

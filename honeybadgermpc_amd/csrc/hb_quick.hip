@@ -1,0 +1,763 @@
+// hb_quick.hip -- the robust path of the device decoder without plans, tables built on the host, or synchronisation.
+//
+// Reference: IncrementalDecoder (honeybadgermpc/reed_solomon.py:232-403).  Every arrival set is new to a decoder that is
+// probing its way past liars, so whatever it needs per arrival set must cost microseconds, not the ~2 ms of an open plan
+// (hb_open.hip) or the ~0.7 ms of an n' x n' inverse:
+//
+//   * hb_quick_interp_check: decoder.decode_batch over the first d arrivals + encoder.encode_batch + the compare loop
+//     (reed_solomon.py:305-326) for ANY (z, zc) as ONE launch of the full-size matrix-core kernel (hb_mfma_wide.hip) over
+//     [V^-1(z) ; V[zc] V^-1(z)].  The matrix is built ON THE DEVICE from a per-point-set table of 1 / (x_a - x_b)
+//     (Lagrange: row m of V^-1 is the m-th coefficient of L_j(X) = prod_{q != j} (X - x_q) / (x_j - x_q); the prediction at
+//     a later arrival is L_j(x_i)), turned into the kernel's int8 digit image by a second small kernel, and launched --
+//     three small launches and the big one, all enqueued, none waited for.
+//
+//   * hb_probe_*: gao_interpolate for ONE codeword (rsdecode_impl.h:325-363, what robust_decode runs per polynomial,
+//     reed_solomon.py:334-365), incremental in the points: Koetter / Welch-Berlekamp rational interpolation keeps two
+//     polynomial pairs Q_j = (A_j, B_j) with A_j(x_i) + y_i B_j(x_i) = 0 on every point fed so far, a reduced basis of that
+//     module for the (1, k-1)-weighted degree; a new point costs O(n') multiplications done by one workgroup in parallel.
+//     The decision is the reference's exactly (scratch/koetter_check.py, tests/test_probe_rule.py: 12 073 prefix decisions
+//     against the oracle, 118 of them beyond the unique-decoding radius): with Q_0 the pair whose leading term is in A and
+//     T = (n' + k) / 2 (integer division, as partial_gcd's stopping rule, rsdecode_impl.h:281-323)
+//         Gao decodes  <=>  deg A_0 >= T  and  B_1 | A_1   (Q_1 first reduced against Q_0 to deg A_1 < T),
+//     and its error locator is B_1 up to a scalar: the erroneous senders are the roots of B_1 among the party points
+//     (reed_solomon.py:174-184).  No division of field elements anywhere: updates and the divisibility test are fraction-free.
+#include <algorithm>
+
+#include "hb_common.hpp"
+
+using namespace hb;
+
+namespace hb {
+
+constexpr int QUICK_MAX = 128;       // d and the number of compared rows
+constexpr int PROBE_MAXN = 256;      // party points of a probe
+
+struct QuickIdx { uint16_t z[QUICK_MAX], zc[QUICK_MAX]; };
+struct ProbeIdx { uint16_t idx[PROBE_MAXN]; };
+
+template <int NL> __device__ __forceinline__ void ldg(uint32_t (&r)[NL], const uint32_t *p) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) r[i] = p[i];
+}
+template <int NL> __device__ __forceinline__ void stg(uint32_t *p, const uint32_t (&r)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) p[i] = r[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per point set: x (Montgomery), the powers x_a^i (the probe evaluates its polynomials with them) and 1 / (x_a - x_b)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NL, int NW>
+__global__ void k_pt_mont(const FpParams<NL> P, const uint32_t *__restrict__ x_pk, int n, uint32_t *__restrict__ xm, uint32_t *__restrict__ pw, int S) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    uint32_t xd[NL], x[NL], acc[NL];
+    load_digits<NL, NW>(xd, x_pk + (size_t)a * NW);
+    to_mont(x, xd, P);
+    stg<NL>(xm + (size_t)a * NL, x);
+    fp_set(acc, P.one);
+    for (int i = 0; i < S; i++) {
+        stg<NL>(pw + ((size_t)a * S + i) * NL, acc);
+        mont_mul(acc, acc, x, P);
+    }
+}
+// row a of the table by one inversion: prefix products forward, the inverse of the whole product walked back
+template <int NL>
+__global__ void k_pt_inv(const FpParams<NL> P, const uint32_t *__restrict__ xm, int n, uint32_t *__restrict__ inv, int32_t *__restrict__ bad) {
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= n) return;
+    uint32_t xa[NL], pref[NL], df[NL], xb[NL];
+    ldg<NL>(xa, xm + (size_t)a * NL);
+    fp_set(pref, P.one);
+    uint32_t *row = inv + (size_t)a * n * NL;
+    for (int b = 0; b < n; b++) {
+        if (b == a) continue;
+        ldg<NL>(xb, xm + (size_t)b * NL);
+        fp_sub(df, xa, xb, P);
+        if (fp_is_zero(df)) { atomicOr(bad, 1); fp_set(df, P.one); }       // a repeated point: the table is unusable, say so
+        stg<NL>(row + (size_t)b * NL, pref);
+        mont_mul(pref, pref, df, P);
+    }
+    uint32_t ip[NL];
+    fp_inv(ip, pref, P);
+    for (int b = n - 1; b >= 0; b--) {
+        if (b == a) continue;
+        ldg<NL>(xb, xm + (size_t)b * NL);
+        fp_sub(df, xa, xb, P);
+        if (fp_is_zero(df)) fp_set(df, P.one);
+        uint32_t t[NL], v[NL];
+        ldg<NL>(t, row + (size_t)b * NL);
+        mont_mul(v, ip, t, P);
+        stg<NL>(row + (size_t)b * NL, v);
+        mont_mul(ip, ip, df, P);
+    }
+    uint32_t z[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) z[i] = 0;
+    stg<NL>(row + (size_t)a * NL, z);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// [V^-1(z) rows ; V[zc] V^-1(z)] on the device
+// ---------------------------------------------------------------------------------------------------------------------
+// logical task t of a phase -> thread: consecutive tasks go to different waves, so the few dozen chains of dependent
+// multiplications of a phase issue from all 16 waves of the workgroup instead of from the first one
+__device__ __forceinline__ int quick_task(int tid) { return (tid & 63) * 16 + (tid >> 6); }
+
+// one workgroup of 1024: A(X) = prod_q (X - x_zq) in LDS; per arrival j: w_j = prod_{q != j} 1 / (x_zj - x_zq) and the
+// coefficients of N_j = A / (X - x_zj) (synthetic division); per compared row i: full_i = prod_q (x_zci - x_zq);
+// the row index arrays of the big launch
+template <int NL>
+__global__ void __launch_bounds__(1024) k_quick_matrix(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ inv, int n,
+                                                       const QuickIdx ix, int d, int nc, int n_coef, uint32_t *__restrict__ wj, uint32_t *__restrict__ full,
+                                                       uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap) {
+    extern __shared__ uint32_t q_lds[];
+    uint32_t *Ac = q_lds;                               // [(d + 1)][NL]
+    const int t = quick_task(threadIdx.x);
+    if (threadIdx.x < d) z_dev[threadIdx.x] = ix.z[threadIdx.x];
+    if (threadIdx.x <= n_coef + nc) fmap[threadIdx.x] = (threadIdx.x >= n_coef && threadIdx.x < n_coef + nc) ? (int32_t)ix.zc[threadIdx.x - n_coef] + 1 : 0;
+    if (t <= d) {
+        uint32_t v[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++) v[i] = (t == 0) ? P.one[i] : 0u;
+        stg<NL>(Ac + (size_t)t * NL, v);
+    }
+    __syncthreads();
+    for (int q = 0; q < d; q++) {
+        uint32_t nv[NL];
+        const bool act = t <= q + 1;
+        if (act) {
+            uint32_t xq[NL], cur[NL], prev[NL], m[NL];
+            ldg<NL>(xq, xm + (size_t)ix.z[q] * NL);
+            ldg<NL>(cur, Ac + (size_t)t * NL);
+            mont_mul(m, xq, cur, P);
+            if (t > 0) ldg<NL>(prev, Ac + (size_t)(t - 1) * NL);
+            else {
+#pragma unroll
+                for (int i = 0; i < NL; i++) prev[i] = 0;
+            }
+            fp_sub(nv, prev, m, P);
+        }
+        __syncthreads();
+        if (act) stg<NL>(Ac + (size_t)t * NL, nv);
+        __syncthreads();
+    }
+    if (t < d) {
+        const int j = t;
+        uint32_t w[NL], xj[NL];
+        fp_set(w, P.one);
+        const uint32_t *row = inv + (size_t)ix.z[j] * n * NL;
+        for (int q = 0; q < d; q++) {
+            if (q == j) continue;
+            uint32_t f[NL];
+            ldg<NL>(f, row + (size_t)ix.z[q] * NL);
+            mont_mul(w, w, f, P);
+        }
+        stg<NL>(wj + (size_t)j * NL, w);
+        // N_j[d-1] = A[d] = 1, N_j[m-1] = A[m] + x_j N_j[m]
+        ldg<NL>(xj, xm + (size_t)ix.z[j] * NL);
+        uint32_t cur[NL];
+        fp_set(cur, P.one);
+        for (int m = d - 1; m >= 0; m--) {
+            if (m < n_coef) stg<NL>(nraw + ((size_t)m * d + j) * NL, cur);
+            if (m > 0) {
+                uint32_t a[NL], pr[NL];
+                ldg<NL>(a, Ac + (size_t)m * NL);
+                mont_mul(pr, xj, cur, P);
+                fp_add(cur, a, pr, P);
+            }
+        }
+    } else if (t < d + nc) {
+        const int i = t - d;
+        uint32_t xi[NL], f[NL];
+        ldg<NL>(xi, xm + (size_t)ix.zc[i] * NL);
+        fp_set(f, P.one);
+        for (int q = 0; q < d; q++) {
+            uint32_t xq[NL], df[NL];
+            ldg<NL>(xq, xm + (size_t)ix.z[q] * NL);
+            fp_sub(df, xi, xq, P);
+            mont_mul(f, f, df, P);
+        }
+        stg<NL>(full + (size_t)i * NL, f);
+    }
+}
+
+// one thread per matrix entry: its canonical value and its 32 balanced base-256 digits at their place in the int8 image
+// (the layout of mm8w_from_host, hb_mfma_wide.hip)
+__global__ void k_quick_image(const FpParams<9> P, const uint32_t *__restrict__ inv, int n, const QuickIdx ix, int d, int nc, int n_coef,
+                              const uint32_t *__restrict__ wj, const uint32_t *__restrict__ full, const uint32_t *__restrict__ nraw,
+                              uint32_t *__restrict__ mcan, uint8_t *__restrict__ a8, int tile_rows, int nkb) {
+    constexpr int NL = 9, NW = 8;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n_out = n_coef + nc;
+    if (e >= n_out * d) return;
+    const int i = e / d, l = e - i * d;
+    uint32_t w[NL], v[NL];
+    ldg<NL>(w, wj + (size_t)l * NL);
+    if (i < n_coef) {
+        uint32_t c[NL];
+        ldg<NL>(c, nraw + ((size_t)i * d + l) * NL);
+        mont_mul(v, c, w, P);
+    } else {
+        const int r = i - n_coef;
+        uint32_t f[NL], g[NL], t[NL];
+        ldg<NL>(f, full + (size_t)r * NL);
+        ldg<NL>(g, inv + ((size_t)ix.zc[r] * n + ix.z[l]) * NL);
+        mont_mul(t, f, g, P);
+        mont_mul(v, t, w, P);
+    }
+    uint32_t cd[NL], cw[NW];
+    from_mont(cd, v, P);
+    pack<NL, NW>(cw, cd);
+    store_words<NW>(mcan + (size_t)e * NW, cw);
+    const int rt = i / tile_rows, j16 = i % tile_rows, r = 4 * (j16 % 4) + j16 / 4, kb = l / 8, g = (l % 8) / 2, el = l & 1;
+    int carry = 0;
+#pragma unroll
+    for (int b = 0; b < 32; b++) {
+        int tt = (int)((cw[b >> 2] >> (8 * (b & 3))) & 0xffu) + carry;
+        if (tt > 127) { tt -= 256; carry = 1; } else carry = 0;
+        const int grp = b >> 3, r7 = 7 - (b & 7), hi = r7 >> 2, bi = r7 & 3;
+        a8[((((size_t)rt * nkb + kb) * 4 + grp) * 64 + (size_t)(r + 16 * g)) * 16 + 4 * (2 * hi + el) + bi] = (uint8_t)(int8_t)tt;
+    }
+}
+
+// per row: the constant that takes the XOR-0x80 input bias and the accumulator bias back out,
+// (0x80..80 * sum_l M[i][l] - bias * sum_c 2^(8c)) mod p, as 9 digits in the kernel's row-constant slot
+struct QuickRowConst { uint32_t c80r[9], biasmod[9]; };
+__global__ void k_quick_rows(const FpParams<9> P, const uint32_t *__restrict__ mcan, int n_out, int d, const QuickRowConst rc,
+                             uint32_t *__restrict__ crow, int tile_rows) {
+    constexpr int NL = 9, NW = 8;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    uint32_t sum[NL];
+#pragma unroll
+    for (int q = 0; q < NL; q++) sum[q] = 0;
+    for (int l = 0; l < d; l++) {
+        uint32_t e[NL];
+        load_digits<NL, NW>(e, mcan + ((size_t)i * d + l) * NW);
+        fp_add(sum, sum, e, P);
+    }
+    uint32_t k[NL], b[NL], prod[NL], corr[NL];
+#pragma unroll
+    for (int q = 0; q < NL; q++) { k[q] = rc.c80r[q]; b[q] = rc.biasmod[q]; }
+    mont_mul(prod, sum, k, P);                  // sum * (0x80..80 R) / R
+    fp_sub(corr, prod, b, P);
+    uint32_t *dst = crow + ((size_t)(i / tile_rows) * 16 + i % tile_rows) * 16;
+#pragma unroll
+    for (int q = 0; q < NL; q++) dst[q] = corr[q];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the probe: one workgroup, the four polynomials A_0, B_0, A_1, B_1 in LDS
+// ---------------------------------------------------------------------------------------------------------------------
+struct ProbeResult { int32_t ok, n_err, npts, pad; uint8_t err[PROBE_MAXN]; };
+
+template <int NL> __device__ __forceinline__ bool lds_nonzero(const uint32_t *p) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) o |= p[i];
+    return o != 0;
+}
+
+template <int NL, int NW>
+__global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ pw, int n, int S,
+                                                    uint32_t *__restrict__ state, const ProbeIdx ix, int count, int reset,
+                                                    const uint32_t *__restrict__ cols, int64_t C, int64_t poly, int k, int decide,
+                                                    ProbeResult *__restrict__ result) {
+    extern __shared__ uint32_t p_lds[];
+    // coef[q][i][NL], q: 0 = A_0, 1 = B_0, 2 = A_1, 3 = B_1; two scratch polynomials for the decision; the reduction buffer
+    uint32_t *coef = p_lds;
+    uint32_t *scr = coef + (size_t)4 * S * NL;               // [2][S][NL]: R (the dividend) and the divisor
+    uint32_t *red = scr + (size_t)2 * S * NL;                // [256][NL]
+    __shared__ int deg[4], ctl[8], sdeg[2];
+    __shared__ uint32_t dl[2][NL], yv[NL], lead[2][NL];
+    const int tid = threadIdx.x;
+    const size_t words = (size_t)4 * S * NL;
+    int32_t *st_i = reinterpret_cast<int32_t *>(state + words);   // [0..3] degrees, [4] points fed
+    if (reset) {
+        for (size_t i = tid; i < words; i += 256) coef[i] = 0;
+        __syncthreads();
+        if (tid < NL) { coef[(size_t)0 * S * NL + tid] = P.one[tid]; coef[(size_t)3 * S * NL + tid] = P.one[tid]; }   // Q_0 = 1, Q_1 = Y
+        if (tid == 0) { deg[0] = 0; deg[1] = -1; deg[2] = -1; deg[3] = 0; ctl[6] = 0; }
+    } else {
+        for (size_t i = tid; i < words; i += 256) coef[i] = state[i];
+        if (tid < 4) deg[tid] = st_i[tid];
+        if (tid == 0) ctl[6] = st_i[4];
+    }
+    __syncthreads();
+    const int q = tid >> 6, lane = tid & 63;
+    for (int pt = 0; pt < count; pt++) {
+        const int a = ix.idx[pt];
+        const uint32_t *pwr = pw + (size_t)a * S * NL;
+        // partial sums of the four evaluations at x_a
+        {
+            uint32_t acc[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) acc[i] = 0;
+            const int dq = deg[q];
+            for (int i = lane; i <= dq; i += 64) {
+                uint32_t c[NL], xp[NL], m[NL];
+                ldg<NL>(c, coef + ((size_t)q * S + i) * NL);
+                ldg<NL>(xp, pwr + (size_t)i * NL);
+                mont_mul(m, c, xp, P);
+                fp_add(acc, acc, m, P);
+            }
+            stg<NL>(red + (size_t)tid * NL, acc);
+        }
+        if (tid == 0) {
+            uint32_t yd[NL], ym[NL];
+            load_digits<NL, NW>(yd, cols + ((size_t)a * (size_t)C + (size_t)poly) * NW);
+            // whatever words the sender packed: their residue (the reference reduces at its boundary)
+            to_mont(ym, yd, P);
+            stg<NL>(yv, ym);
+        }
+        __syncthreads();
+        for (int s = 32; s >= 1; s >>= 1) {
+            if (lane < s) {
+                uint32_t u[NL], v[NL];
+                ldg<NL>(u, red + (size_t)tid * NL);
+                ldg<NL>(v, red + (size_t)(tid + s) * NL);
+                fp_add(u, u, v, P);
+                stg<NL>(red + (size_t)tid * NL, u);
+            }
+            __syncthreads();
+        }
+        if (tid < 2) {
+            // discrepancy of Q_tid at the new point
+            uint32_t sa[NL], sb[NL], y[NL], m[NL], dd[NL];
+            ldg<NL>(sa, red + (size_t)(2 * tid) * 64 * NL);
+            ldg<NL>(sb, red + (size_t)(2 * tid + 1) * 64 * NL);
+            ldg<NL>(y, yv);
+            mont_mul(m, y, sb, P);
+            fp_add(dd, sa, m, P);
+            stg<NL>(dl[tid], dd);
+            ctl[tid] = fp_is_zero(dd) ? 0 : 1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            // the pair of smaller leading monomial among those with a discrepancy; (1, k-1)-weighted degree, ties: Y terms larger
+            int js = -1, best_w = 0, best_y = 0;
+            for (int j = 0; j < 2; j++) {
+                if (!ctl[j]) continue;
+                const int wa = deg[2 * j], wb = deg[2 * j + 1] >= 0 ? deg[2 * j + 1] + k - 1 : -1;
+                const int w = wa > wb ? wa : wb, yy = wb >= wa ? 1 : 0;
+                if (js < 0 || w < best_w || (w == best_w && yy < best_y)) { js = j; best_w = w; best_y = yy; }
+            }
+            ctl[2] = js;
+            ctl[6] += 1;
+        }
+        __syncthreads();
+        const int js = ctl[2];
+        if (js >= 0) {
+            const int jo = 1 - js;
+            const int top = max(max(deg[0], deg[1]), max(deg[2], deg[3])) + 1;      // highest index any polynomial reaches after this step
+            if (ctl[jo]) {
+                // Q_jo <- dl[js] Q_jo - dl[jo] Q_js
+                uint32_t ds[NL], dj[NL];
+                ldg<NL>(ds, dl[js]);
+                ldg<NL>(dj, dl[jo]);
+                for (int e = tid; e < 2 * (top + 1); e += 256) {
+                    const int part = e / (top + 1), i = e - part * (top + 1);
+                    uint32_t u[NL], v[NL], m1[NL], m2[NL], r[NL];
+                    uint32_t *po = coef + ((size_t)(2 * jo + part) * S + i) * NL;
+                    ldg<NL>(u, po);
+                    ldg<NL>(v, coef + ((size_t)(2 * js + part) * S + i) * NL);
+                    mont_mul(m1, ds, u, P);
+                    mont_mul(m2, dj, v, P);
+                    fp_sub(r, m1, m2, P);
+                    stg<NL>(po, r);
+                }
+            }
+            __syncthreads();
+            // Q_js <- (X - x_a) Q_js: values first, the barrier, then the stores
+            {
+                uint32_t xa[NL];
+                ldg<NL>(xa, xm + (size_t)a * NL);
+                uint32_t keep[3][NL];     // 2 (n + 3) values over 256 threads: at most three each
+                int cnt = 0;
+                for (int e = tid; e < 2 * (top + 1); e += 256, cnt++) {
+                    const int part = e / (top + 1), i = e - part * (top + 1);
+                    const uint32_t *ps = coef + ((size_t)(2 * js + part) * S) * NL;
+                    uint32_t cur[NL], prev[NL], m[NL];
+                    ldg<NL>(cur, ps + (size_t)i * NL);
+                    if (i > 0) ldg<NL>(prev, ps + (size_t)(i - 1) * NL);
+                    else {
+#pragma unroll
+                        for (int w = 0; w < NL; w++) prev[w] = 0;
+                    }
+                    mont_mul(m, xa, cur, P);
+                    if (cnt < 3) fp_sub(keep[cnt], prev, m, P);
+                }
+                __syncthreads();
+                cnt = 0;
+                for (int e = tid; e < 2 * (top + 1); e += 256, cnt++) {
+                    const int part = e / (top + 1), i = e - part * (top + 1);
+                    if (cnt < 3) stg<NL>(coef + ((size_t)(2 * js + part) * S + i) * NL, keep[cnt]);
+                }
+            }
+            __syncthreads();
+            if (tid < 4) deg[tid] = -1;
+            __syncthreads();
+            for (int e = tid; e < 4 * (top + 1); e += 256) {
+                const int part = e / (top + 1), i = e - part * (top + 1);
+                if (lds_nonzero<NL>(coef + ((size_t)part * S + i) * NL)) atomicMax(&deg[part], i);
+            }
+            __syncthreads();
+        }
+    }
+    // persistent state back (the decision below works on copies)
+    for (size_t i = tid; i < words; i += 256) state[i] = coef[i];
+    if (tid < 4) st_i[tid] = deg[tid];
+    if (tid == 0) st_i[4] = ctl[6];
+    if (!decide) return;
+    __syncthreads();
+    // ---- the reference's outcome for the points fed so far -----------------------------------------------------------
+    const int npts = ctl[6];
+    if (tid == 0) {
+        // Q_0: the pair whose leading monomial is in A
+        int cls[2];
+        for (int j = 0; j < 2; j++) {
+            const int wa = deg[2 * j], wb = deg[2 * j + 1] >= 0 ? deg[2 * j + 1] + k - 1 : -1;
+            cls[j] = wb >= wa ? 1 : 0;
+        }
+        const int j0 = cls[0] == 0 ? 0 : 1, j1 = 1 - j0;
+        const int T = (npts + k) / 2;
+        ctl[3] = j0; ctl[4] = j1;
+        ctl[5] = (cls[j0] == 0 && cls[j1] == 1 && deg[2 * j0] >= T) ? 1 : 0;       // 0: Gao's row has deg f >= k -> not decodable
+        ctl[7] = (deg[2 * j0] == T && deg[2 * j1] >= T) ? 1 : 0;                    // the tie: reduce Q_1 against Q_0
+    }
+    __syncthreads();
+    bool fine = ctl[5] != 0;
+    const int j0 = ctl[3], j1 = ctl[4];
+    uint32_t *R = scr, *Bd = scr + (size_t)S * NL;
+    if (fine) {
+        const int T = (npts + k) / 2;
+        if (ctl[7]) {
+            uint32_t c0[NL], c1[NL];
+            ldg<NL>(c0, coef + ((size_t)(2 * j0) * S + T) * NL);
+            ldg<NL>(c1, coef + ((size_t)(2 * j1) * S + T) * NL);
+            for (int e = tid; e < 2 * S; e += 256) {
+                const int part = e / S, i = e - part * S;
+                uint32_t u[NL], v[NL], m1[NL], m2[NL], r[NL];
+                ldg<NL>(u, coef + ((size_t)(2 * j1 + part) * S + i) * NL);
+                ldg<NL>(v, coef + ((size_t)(2 * j0 + part) * S + i) * NL);
+                mont_mul(m1, c0, u, P);
+                mont_mul(m2, c1, v, P);
+                fp_sub(r, m1, m2, P);
+                stg<NL>((part ? Bd : R) + (size_t)i * NL, r);
+            }
+        } else {
+            for (int e = tid; e < 2 * S; e += 256) {
+                const int part = e / S, i = e - part * S;
+                uint32_t u[NL];
+                ldg<NL>(u, coef + ((size_t)(2 * j1 + part) * S + i) * NL);
+                stg<NL>((part ? Bd : R) + (size_t)i * NL, u);
+            }
+        }
+        if (tid < 2) sdeg[tid] = -1;
+        __syncthreads();
+        for (int e = tid; e < 2 * S; e += 256) {
+            const int part = e / S, i = e - part * S;
+            if (lds_nonzero<NL>((part ? Bd : R) + (size_t)i * NL)) atomicMax(&sdeg[part], i);
+        }
+        __syncthreads();
+        const int db = sdeg[1];
+        // fraction-free division: does the divisor divide R?
+        while (fine) {
+            const int dr = sdeg[0];
+            if (dr < db || db < 0) break;
+            if (tid < NL) { lead[0][tid] = R[(size_t)dr * NL + tid]; lead[1][tid] = Bd[(size_t)db * NL + tid]; }
+            __syncthreads();
+            uint32_t lr[NL], lb[NL];
+            ldg<NL>(lr, lead[0]);
+            ldg<NL>(lb, lead[1]);
+            const int sft = dr - db;
+            for (int i = tid; i <= dr; i += 256) {
+                uint32_t u[NL], m1[NL], r[NL];
+                ldg<NL>(u, R + (size_t)i * NL);
+                mont_mul(m1, lb, u, P);
+                if (i >= sft && i - sft <= db) {
+                    uint32_t v[NL], m2[NL];
+                    ldg<NL>(v, Bd + (size_t)(i - sft) * NL);
+                    mont_mul(m2, lr, v, P);
+                    fp_sub(r, m1, m2, P);
+                } else fp_set(r, m1);
+                stg<NL>(R + (size_t)i * NL, r);
+            }
+            if (tid == 0) sdeg[0] = -1;
+            __syncthreads();
+            for (int i = tid; i <= dr; i += 256)
+                if (lds_nonzero<NL>(R + (size_t)i * NL)) atomicMax(&sdeg[0], i);
+            __syncthreads();
+        }
+        if (db < 0 || sdeg[0] >= 0) fine = false;
+    }
+    // the senders in error: the roots of the locator among ALL party points
+    if (tid == 0) { result->ok = fine ? 1 : 0; result->npts = npts; ctl[0] = 0; }
+    __syncthreads();
+    if (fine) {
+        const int db = sdeg[1];
+        for (int a = tid; a < n; a += 256) {
+            const uint32_t *pwr = pw + (size_t)a * S * NL;
+            uint32_t acc[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) acc[i] = 0;
+            for (int i = 0; i <= db; i++) {
+                uint32_t c[NL], xp[NL], m[NL];
+                ldg<NL>(c, Bd + (size_t)i * NL);
+                ldg<NL>(xp, pwr + (size_t)i * NL);
+                mont_mul(m, c, xp, P);
+                fp_add(acc, acc, m, P);
+            }
+            const bool root = fp_is_zero(acc) && db >= 1;     // a constant locator names nobody
+            result->err[a] = root ? 1 : 0;
+            if (root) atomicAdd(&ctl[0], 1);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) { result->n_err = fine ? ctl[0] : 0; __threadfence_system(); }
+}
+
+struct PointTable {
+    int n, S;
+    uint32_t *xm, *inv, *pw;
+    bool usable;
+};
+
+// per (context, point set); pinned in the context (a handful per modulus)
+static int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hipStream_t s) {
+    std::string key = table_key("PT", ctx, x_host, n, 0);
+    auto it = ctx->ptcache.find(key);
+    if (it != ctx->ptcache.end()) { *out = static_cast<PointTable *>(it->second); return HB_OK; }
+    PointTable *pt = new PointTable();
+    pt->n = n; pt->S = n + 2; pt->xm = pt->inv = pt->pw = nullptr; pt->usable = false;
+    const int NLr = ctx->nl();
+    uint32_t *xd = nullptr;
+    int32_t *bad = nullptr;
+    int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMalloc(&pt->xm, (size_t)n * NLr * 4);
+        if (e == hipSuccess) e = hipMalloc(&pt->inv, (size_t)n * n * NLr * 4);
+        if (e == hipSuccess) e = hipMalloc(&pt->pw, (size_t)n * pt->S * NLr * 4);
+        if (e == hipSuccess) e = hipMalloc(&bad, sizeof(int32_t));
+        if (e == hipSuccess) e = hipMemsetAsync(bad, 0, sizeof(int32_t), s);
+    }
+    int32_t badh = 0;
+    if (!rc && e == hipSuccess) {
+        const unsigned blocks = (unsigned)((n + 63) / 64);
+        if (ctx->n_limbs == 4) {
+            k_pt_mont<9, 8><<<blocks, 64, 0, s>>>(ctx->pw, xd, n, pt->xm, pt->pw, pt->S);
+            k_pt_inv<9><<<blocks, 64, 0, s>>>(ctx->pw, pt->xm, n, pt->inv, bad);
+        } else {
+            k_pt_mont<3, 2><<<blocks, 64, 0, s>>>(ctx->pn, xd, n, pt->xm, pt->pw, pt->S);
+            k_pt_inv<3><<<blocks, 64, 0, s>>>(ctx->pn, pt->xm, n, pt->inv, bad);
+        }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&badh, bad, sizeof badh, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (xd) (void)hipFree(xd);
+    if (bad) (void)hipFree(bad);
+    if (rc || e != hipSuccess) {
+        if (pt->xm) (void)hipFree(pt->xm);
+        if (pt->inv) (void)hipFree(pt->inv);
+        if (pt->pw) (void)hipFree(pt->pw);
+        delete pt;
+        if (!rc) { ctx->err = std::string("point table: ") + hipGetErrorString(e); rc = HB_ERR_HIP; }
+        return rc;
+    }
+    pt->usable = badh == 0;                       // repeated points: interpolation over them is singular (callers fall back and report it)
+    ctx->ptcache[key] = pt;
+    *out = pt;
+    return HB_OK;
+}
+
+void point_tables_free(hb_ctx *ctx) {
+    for (auto &kv : ctx->ptcache) {
+        PointTable *pt = static_cast<PointTable *>(kv.second);
+        (void)hipFree(pt->xm); (void)hipFree(pt->inv); (void)hipFree(pt->pw);
+        delete pt;
+    }
+    ctx->ptcache.clear();
+    for (auto &sl : ctx->qslots) {
+        if (sl.buf) (void)hipFree(sl.buf);
+        if (sl.ev) (void)hipEventDestroy((hipEvent_t)sl.ev);
+    }
+    ctx->qslots.clear();
+    for (void *p : ctx->probe_pool) (void)hipFree(p);
+    ctx->probe_pool.clear();
+    for (void *p : ctx->probe_host_pool) (void)hipHostFree(p);
+    ctx->probe_host_pool.clear();
+}
+
+}  // namespace hb
+
+struct hb_probe {
+    hb_ctx *ctx;
+    int n, k;
+    PointTable *pt;
+    uint32_t *state;              // 4 polynomials of n + 2 coefficients + 8 ints
+    size_t state_bytes;
+    ProbeResult *res_host;        // pinned, device-visible: the kernel writes the verdict where the host reads it
+    ProbeResult *res_dev;
+    std::vector<int32_t> fed;
+    int64_t poly;
+};
+
+extern "C" {
+
+int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
+                          const uint64_t *cols_dev, int64_t C, uint64_t *coeffs_dev, int32_t *status_dev, void *stream) { HB_API_GUARD(ctx);
+    if (!ctx || !x_host || !z || n < 1 || d < 1 || d > n || nc < 0 || (nc > 0 && !zc) || C < 0) return HB_ERR_BAD_ARG;
+    if (C == 0) return HB_OK;
+    if (!cols_dev || (nc > 0 && !status_dev)) return HB_ERR_BAD_ARG;
+    if (ctx->n_limbs != 4 || d < 4 || d > QUICK_MAX || nc > QUICK_MAX || n > 65535) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: shape");
+    if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE") || getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: disabled");
+    // entries below p must fit 32 balanced base-256 digits: top byte of p at most 0x7e
+    if (!prescale_params(ctx) || (ctx->p_limbs[3] >> 56) > 0x7e) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: modulus");
+    std::vector<uint8_t> seen((size_t)n, 0);
+    for (int i = 0; i < d; i++) { if (z[i] < 0 || z[i] >= n || seen[z[i]]) return HB_ERR_BAD_ARG; seen[z[i]] = 1; }
+    for (int j = 0; j < nc; j++) { if (zc[j] < 0 || zc[j] >= n || seen[zc[j]]) return HB_ERR_BAD_ARG; seen[zc[j]] = 1; }
+    hipStream_t s = (hipStream_t)stream;
+    PointTable *pt = nullptr;
+    int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
+    if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: repeated points");
+    const int n_coef = coeffs_dev ? d : 1;            // nothing to store: one coefficient row keeps the kernel's shapes simple
+    const int n_out = n_coef + nc;
+    int tile_rows = 0, n_rt = 0, nkb = 0;
+    size_t a8_bytes = 0, crow_words = 0;
+    rc = mm8w_geometry(n_out, d, &tile_rows, &n_rt, &nkb, &a8_bytes, &crow_words); if (rc) return fail(ctx, rc, "quick: geometry");
+    const Mm8wShared *sh = nullptr;
+    rc = mm8w_shared(ctx, d, &sh, s); if (rc) return rc;
+    // one slot of the context's ring: image, row constants, scratch, index arrays
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_a8 = 0, o_crow = o_a8 + al(a8_bytes), o_wj = o_crow + al(crow_words * 4), o_full = o_wj + al((size_t)d * 36),
+                 o_nraw = o_full + al((size_t)(nc ? nc : 1) * 36), o_mcan = o_nraw + al((size_t)n_coef * d * 36),
+                 o_z = o_mcan + al((size_t)n_out * d * 32), o_map = o_z + al((size_t)d * 4), need = o_map + al((size_t)(n_out + 2) * 4);
+    if (ctx->qslots.empty()) ctx->qslots.resize(4);
+    hb_ctx::QuickSlot &sl = ctx->qslots[ctx->qnext++ % ctx->qslots.size()];
+    if (sl.ev) HB_HIP(ctx, hipEventSynchronize((hipEvent_t)sl.ev));      // the launch that last used this slot is over
+    else { hipEvent_t ev; HB_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); sl.ev = ev; }
+    if (sl.cap < need) {
+        if (sl.buf) HB_HIP(ctx, hipFree(sl.buf));
+        sl.buf = nullptr; sl.cap = 0;
+        HB_HIP(ctx, hipMalloc(&sl.buf, need));
+        sl.cap = need;
+    }
+    uint8_t *base = static_cast<uint8_t *>(sl.buf);
+    HB_HIP(ctx, hipMemsetAsync(base, 0, o_wj, s));                      // image and row constants: padding rows / terms are zero
+    QuickIdx ix;
+    memset(&ix, 0, sizeof ix);
+    for (int i = 0; i < d; i++) ix.z[i] = (uint16_t)z[i];
+    for (int j = 0; j < nc; j++) ix.zc[j] = (uint16_t)zc[j];
+    uint32_t *wj = (uint32_t *)(base + o_wj), *full = (uint32_t *)(base + o_full), *nraw = (uint32_t *)(base + o_nraw), *mcan = (uint32_t *)(base + o_mcan);
+    int32_t *z_dev = (int32_t *)(base + o_z), *fmap = (int32_t *)(base + o_map);
+    k_quick_matrix<9><<<1, 1024, (size_t)(d + 1) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, n_coef, wj, full, nraw, z_dev, fmap);
+    HB_LAUNCH_CHECK(ctx);
+    k_quick_image<<<(unsigned)((n_out * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, n_coef, wj, full, nraw, mcan, base + o_a8, tile_rows, nkb);
+    HB_LAUNCH_CHECK(ctx);
+    QuickRowConst rcs;
+    memcpy(rcs.c80r, sh->c80r, sizeof rcs.c80r);
+    memcpy(rcs.biasmod, sh->biasmod, sizeof rcs.biasmod);
+    k_quick_rows<<<(unsigned)((n_out + 63) / 64), 64, 0, s>>>(ctx->pw, mcan, n_out, d, rcs, (uint32_t *)(base + o_crow), tile_rows);
+    HB_LAUNCH_CHECK(ctx);
+    hb_view pm{1, C}, dv{d, 1};
+    uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev : mcan;       // n_store = 0 below when there is nothing to store
+    rc = launch_mm8w_raw(ctx, n_out, d, tile_rows, (const void *)(base + o_a8), (const uint32_t *)(base + o_crow), sh,
+                         (const uint32_t *)cols_dev, pm, z_dev, INT64_MAX, out, dv, coeffs_dev ? C * (int64_t)d : 0,
+                         nc > 0 ? fmap : nullptr, status_dev, C, s, (const uint32_t *)cols_dev, pm, coeffs_dev ? d : 0,
+                         nc > 0 ? status_dev + 1 : nullptr);
+    if (rc) return rc;
+    HB_HIP(ctx, hipEventRecord((hipEvent_t)sl.ev, s));
+    return HB_OK;
+}
+
+int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe **out, void *stream) { HB_API_GUARD(ctx);
+    if (!ctx || !x_host || !out || n < 1 || k < 1 || k > n) return HB_ERR_BAD_ARG;
+    *out = nullptr;
+    if (n > PROBE_MAXN) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: more than 256 points");
+    if (getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: disabled");
+    hipStream_t s = (hipStream_t)stream;
+    PointTable *pt = nullptr;
+    int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
+    if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: repeated points");
+    hb_probe *pr = new hb_probe();
+    pr->ctx = ctx; pr->n = n; pr->k = k; pr->pt = pt; pr->poly = -1;
+    pr->state_bytes = ((size_t)4 * pt->S * ctx->nl() + 8) * 4;
+    const size_t pool_bytes = ((size_t)4 * (PROBE_MAXN + 2) * 9 + 8) * 4;     // pooled states are all of the largest size
+    pr->state = nullptr; pr->res_host = nullptr; pr->res_dev = nullptr;
+    if (!ctx->probe_pool.empty()) { pr->state = (uint32_t *)ctx->probe_pool.back(); ctx->probe_pool.pop_back(); }
+    else if (hipMalloc(&pr->state, pool_bytes) != hipSuccess) { delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipMalloc"); }
+    if (!ctx->probe_host_pool.empty()) { pr->res_host = (ProbeResult *)ctx->probe_host_pool.back(); ctx->probe_host_pool.pop_back(); }
+    else if (hipHostMalloc((void **)&pr->res_host, sizeof(ProbeResult), hipHostMallocMapped) != hipSuccess) {
+        ctx->probe_pool.push_back(pr->state); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipHostMalloc");
+    }
+    if (hipHostGetDevicePointer((void **)&pr->res_dev, pr->res_host, 0) != hipSuccess) {
+        ctx->probe_pool.push_back(pr->state); ctx->probe_host_pool.push_back(pr->res_host); delete pr; return fail(ctx, HB_ERR_HIP, "probe: device pointer");
+    }
+    *out = pr;
+    return HB_OK;
+}
+
+// Feed the values polynomial `poly` takes at the parties idx[0..count) -- element `poly` of their columns in the party-major
+// buffer cols [n][C] -- and, with decide != 0, wait for the reference's outcome over everything fed: *ok and err_mask[0..n)
+// (1 = that party is a root of the error locator).  The points of one polynomial are fed in arrival order, each once;
+// hb_probe_reset starts another polynomial (or another arrival list).
+int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *cols_dev, int64_t C, int64_t poly, int decide,
+                  int32_t *ok, uint8_t *err_mask, void *stream) { HB_API_GUARD((pr ? pr->ctx : nullptr));
+    if (!pr || count < 0 || (count > 0 && (!idx || !cols_dev)) || poly < 0 || poly >= C) return HB_ERR_BAD_ARG;
+    if (decide && (!ok || !err_mask)) return HB_ERR_BAD_ARG;
+    hb_ctx *ctx = pr->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    const bool reset = pr->fed.empty();
+    if (!reset && poly != pr->poly) return fail(ctx, HB_ERR_BAD_ARG, "probe: another polynomial without a reset");
+    if ((int)pr->fed.size() + count > pr->n) return fail(ctx, HB_ERR_BAD_ARG, "probe: more points than parties");
+    ProbeIdx ix;
+    memset(&ix, 0, sizeof ix);
+    for (int i = 0; i < count; i++) {
+        if (idx[i] < 0 || idx[i] >= pr->n || std::find(pr->fed.begin(), pr->fed.end(), idx[i]) != pr->fed.end()) return fail(ctx, HB_ERR_BAD_ARG, "probe: point fed twice or out of range");
+        ix.idx[i] = (uint16_t)idx[i];
+        pr->fed.push_back(idx[i]);
+    }
+    pr->poly = poly;
+    if (count == 0 && reset) return fail(ctx, HB_ERR_BAD_ARG, "probe: nothing fed yet");
+    const int S = pr->pt->S, NLr = ctx->nl();
+    const size_t lds = ((size_t)6 * S * NLr + (size_t)256 * NLr) * 4;
+#define PROBE_LAUNCH(NLV, NWV, PARAMS)                                                                                                     \
+    do {                                                                                                                                   \
+        static bool attr_done = false;                                                                                                     \
+        if (!attr_done) { HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_feed<NLV, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_done = true; } \
+        k_probe_feed<NLV, NWV><<<1, 256, lds, s>>>(PARAMS, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,        \
+                                                   (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev);            \
+    } while (0)
+    if (ctx->n_limbs == 4) PROBE_LAUNCH(9, 8, ctx->pw); else PROBE_LAUNCH(3, 2, ctx->pn);
+#undef PROBE_LAUNCH
+    HB_LAUNCH_CHECK(ctx);
+    if (!decide) return HB_OK;
+    HB_HIP(ctx, hipStreamSynchronize(s));
+    *ok = pr->res_host->ok;
+    memcpy(err_mask, pr->res_host->err, (size_t)pr->n);
+    if (!*ok) memset(err_mask, 0, (size_t)pr->n);
+    return HB_OK;
+}
+
+int hb_probe_reset(hb_probe *pr) { HB_API_GUARD((pr ? pr->ctx : nullptr));
+    if (!pr) return HB_ERR_BAD_ARG;
+    pr->fed.clear();
+    pr->poly = -1;
+    return HB_OK;
+}
+
+int hb_probe_points_fed(hb_probe *pr) { return pr ? (int)pr->fed.size() : 0; }
+
+void hb_probe_destroy(hb_probe *pr) { HB_API_GUARD((pr ? pr->ctx : nullptr));
+    if (!pr) return;
+    // a kernel of this probe may still be running: the buffers go back to the pool only once the device is done with them
+    (void)hipDeviceSynchronize();
+    pr->ctx->probe_pool.push_back(pr->state);
+    pr->ctx->probe_host_pool.push_back(pr->res_host);
+    delete pr;
+}
+
+}  // extern "C"

@@ -114,6 +114,34 @@ int hb_matvec_check(hb_ctx *ctx, const hb_matrix *m, const uint64_t *in_dev, hb_
  * this call.  Asynchronous. */
 int hb_reduce(hb_ctx *ctx, const uint64_t *in_dev, uint64_t *out_dev, int64_t count, int32_t *changed_dev, void *stream);
 
+/* ---- the robust path of IncrementalDecoder without plans (hb_quick.hip) -------------------------------------------
+ * A decoder that is working its way past faulty senders sees every arrival set once: these entry points build what they
+ * need on the device and enqueue it; none of them creates tables on the host. */
+/* decoder.decode_batch over the arrivals z[0..d) + encoder.encode_batch + the compare loop with the later arrivals zc[0..nc)
+ * (reed_solomon.py:305-326) as one launch: cols_dev is the party-major buffer [n][C] (row j = what party j sent), x_host the n
+ * party points; coefficients go chunk-major to coeffs_dev ((C, d) elements; NULL: validate only).  On a disagreement
+ * status_dev[0] |= 1 and status_dev[1] = min(status_dev[1], first disagreeing chunk); the caller initialises both (0, INT32_MAX)
+ * and reads them after synchronising.  z and zc are disjoint party indices.  Asynchronous.  HB_ERR_UNSUPPORTED outside the
+ * full-size matrix-core kernel's range (narrow contexts, p outside [2^254, 0x7f 2^248), d < 4 or > 128, repeated points):
+ * callers use an open plan then. */
+int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
+                          const uint64_t *cols_dev, int64_t C, uint64_t *coeffs_dev, int32_t *status_dev, void *stream);
+
+/* gao_interpolate for ONE codeword, incremental in its points (rsdecode_impl.h:325-363 as GaoRobustDecoder.robust_decode
+ * runs it per polynomial, reed_solomon.py:151-186, 334-365): the probe keeps a reduced basis of the interpolation module of
+ * the points fed so far (Koetter / Welch-Berlekamp; one workgroup, O(n') multiplications per new point) and decides exactly
+ * as the reference's Gao does, beyond the unique-decoding radius included. */
+typedef struct hb_probe hb_probe;
+int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe **out, void *stream);
+/* feed element `poly` of the columns of parties idx[0..count) of the party-major buffer cols_dev [n][C] (arrival order, each party
+ * once); with decide != 0 synchronise and report: *ok = the codeword decodes over everything fed, err_mask[0..n) = 1 at the
+ * parties that are roots of the error locator (reed_solomon.py:174-184). */
+int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *cols_dev, int64_t C, int64_t poly, int decide,
+                  int32_t *ok, uint8_t *err_mask, void *stream);
+int hb_probe_reset(hb_probe *pr);          /* start over: another polynomial, or another arrival list */
+int hb_probe_points_fed(hb_probe *pr);
+void hb_probe_destroy(hb_probe *pr);
+
 /* ---- reference-shaped entry points (chunk-major buffers, tables cached in ctx) -------- */
 /* vandermonde_batch_evaluate (pyx:199-244): polys_dev [C][d] -> out_dev [C][n] */
 int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_t *polys_dev,

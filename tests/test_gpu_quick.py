@@ -1,0 +1,205 @@
+"""The plan-free robust path (hb_quick.hip) through the C ABI: hb_quick_interp_check against the oracle's interpolate / evaluate
+and hb_probe_* against the oracle's Gao (reference rsdecode_impl.h:281-363, reed_solomon.py:151-186) -- bit-exact outcomes."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import BLS as P
+
+pytestmark = pytest.mark.gpu
+
+INT_MAX = (1 << 31) - 1
+
+
+def _quick(ctx, x, z, zc, cols, c, store=True):
+    import torch
+
+    from honeybadgermpc_amd._capi import np_ptr
+
+    d = len(z)
+    out = ctx.empty(c * d) if store else None
+    status = torch.tensor([0, INT_MAX], dtype=torch.int32, device="cuda")
+    za, zca = np.array(z, dtype=np.int32), np.array(zc if zc else [0], dtype=np.int32)
+    rc = ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), len(x), np_ptr(za), d, np_ptr(zca), len(zc), ctx.ptr(cols), c,
+                                       ctx.ptr(out) if store else None, ctx.ptr(status), ctx.stream())
+    ctx.check(rc, "hb_quick_interp_check")
+    st = status.cpu().tolist()
+    return out, st[0], st[1]
+
+
+@pytest.mark.parametrize("n,t,c,omega", [(16, 5, 300, False), (64, 21, 2000, False), (64, 21, 777, True), (100, 33, 500, False), (256, 85, 260, True), (7, 3, 40, False)])
+def test_quick_interp_check_vs_oracle(n, t, c, omega):
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+
+    ctx = Context.get(P)
+    rnd = random.Random(n * 1000 + t)
+    d = t + 1
+    point = EvalPoint(GF(P), n, use_omega_powers=omega)
+    x = [point(i).value for i in range(n)]
+    polys = [[rnd.randrange(P) for _ in range(d)] for _ in range(c)]
+    enc = oracle.vandermonde_batch_evaluate(x, polys, P)                       # [c][n]
+    flat = [enc[k][j] for j in range(n) for k in range(c)]
+    cols = ctx.upload_ints(flat)
+    for trial in range(4):
+        order = list(range(n))
+        rnd.shuffle(order)
+        z = order[:d]
+        zc = order[d : d + rnd.choice([0, 1, t, min(n - d, t + 3)])]
+        out, flag, first = _quick(ctx, x, z, zc, cols, c)
+        got = ctx.download_ints(out)
+        assert got == [v for row in polys for v in row], (trial, z, zc)
+        assert flag == 0 and first == INT_MAX
+        if zc:
+            # validate only (no coefficient store) and a corrupted compared column: the flag and the FIRST disagreeing chunk
+            _, flag, _ = _quick(ctx, x, z, zc, cols, c, store=False)
+            assert flag == 0
+            bad_chunks = sorted(rnd.sample(range(c), 3))
+            bad = list(flat)
+            for m in bad_chunks:
+                j = rnd.choice(zc)
+                bad[j * c + m] = (bad[j * c + m] + 1 + rnd.randrange(P - 1)) % P
+            out, flag, first = _quick(ctx, x, z, zc, ctx.upload_ints(bad), c)
+            assert flag == 1 and first == bad_chunks[0], (first, bad_chunks)
+            assert ctx.download_ints(out) == [v for row in polys for v in row]       # the decode itself only reads the rows z
+        # a corrupted DECODED column changes coefficients and must disagree with every compared row of those chunks
+        if zc:
+            bad = list(flat)
+            m = rnd.randrange(c)
+            bad[z[0] * c + m] = (bad[z[0] * c + m] + 5) % P
+            _, flag, first = _quick(ctx, x, z, zc, ctx.upload_ints(bad), c)
+            assert flag == 1 and first == m
+
+
+def test_quick_rejects_what_it_cannot_take():
+    from honeybadgermpc_amd._capi import HB_OK, Context, np_ptr
+
+    ctx = Context.get(P)
+    x = list(range(1, 9))
+    cols = ctx.upload_ints([1] * 8 * 4)
+    z = np.array([0, 1, 1, 2], dtype=np.int32)                                   # repeated index
+    zc = np.array([5], dtype=np.int32)
+    import torch
+
+    st = torch.tensor([0, INT_MAX], dtype=torch.int32, device="cuda")
+    assert ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, ctx.ptr(cols), 4, None, ctx.ptr(st), ctx.stream()) != HB_OK
+    z = np.array([0, 1, 2, 5], dtype=np.int32)                                   # zc overlaps z
+    assert ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, ctx.ptr(cols), 4, None, ctx.ptr(st), ctx.stream()) != HB_OK
+    narrow = Context.get((1 << 61) - 1)
+    z = np.array([0, 1, 2, 3], dtype=np.int32)
+    colsn = narrow.upload_ints([1] * 32)
+    rc = narrow.lib.hb_quick_interp_check(narrow.h, np_ptr(narrow.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, narrow.ptr(colsn), 4, None, narrow.ptr(st), narrow.stream())
+    assert rc != HB_OK                                                            # UNSUPPORTED: callers fall back to an open plan
+
+
+class _Probe:
+    def __init__(self, ctx, x, k):
+        from honeybadgermpc_amd._capi import np_ptr
+
+        self.ctx, self.n = ctx, len(x)
+        self.h = ctypes.c_void_p()
+        ctx.check(ctx.lib.hb_probe_create(ctx.h, np_ptr(ctx.host_elems(x)), len(x), k, ctypes.byref(self.h), ctx.stream()), "probe_create")
+
+    def feed(self, idx, cols, c, poly, decide=True):
+        from honeybadgermpc_amd._capi import np_ptr
+
+        ia = np.array(idx if idx else [0], dtype=np.int32)
+        ok = ctypes.c_int32(0)
+        mask = np.zeros(self.n, dtype=np.uint8)
+        rc = self.ctx.lib.hb_probe_feed(self.h, np_ptr(ia), len(idx), self.ctx.ptr(cols), c, poly, 1 if decide else 0, ctypes.byref(ok), np_ptr(mask), self.ctx.stream())
+        self.ctx.check(rc, "probe_feed")
+        return (sorted(np.nonzero(mask)[0].tolist()) if ok.value else None) if decide else None
+
+    def reset(self):
+        self.ctx.check(self.ctx.lib.hb_probe_reset(self.h), "probe_reset")
+
+    def close(self):
+        self.ctx.lib.hb_probe_destroy(self.h)
+
+
+def _ev(a, x, p):
+    r = 0
+    for cc in reversed(a):
+        r = (r * x + cc) % p
+    return r
+
+
+@pytest.mark.parametrize("p", [P, (1 << 61) - 1, 257, 53, 13])
+def test_probe_equals_gao_on_every_prefix(p):
+    """random codewords, random arrival orders, errors inside / at / beyond the radius: after every arrival the probe's verdict
+    and its error set equal the oracle's Gao over the same prefix (error set = roots of Gao's locator among all party points)"""
+    from honeybadgermpc_amd._capi import Context
+
+    ctx = Context.get(p)
+    rnd = random.Random(p % 1009)
+    trials = decoded = beyond = 0
+    for case in range(60 if p > 100 else 150):
+        n = rnd.randrange(4, min(40, p))
+        k = rnd.randrange(1, n + 1)
+        x = rnd.sample(range(1, min(p, 10 ** 6)), n)
+        c = rnd.randrange(1, 6)
+        poly = rnd.randrange(c)
+        arrive = list(range(n))
+        rnd.shuffle(arrive)
+        arrive = arrive[: rnd.randrange(max(k, 1), n + 1)]
+        n1 = len(arrive)
+        f = [rnd.randrange(p) for _ in range(k)]
+        e = max((n1 - k) // 2, 0)
+        nerr = min(rnd.choice([0, 1, e, e, e + 1, e + 1, e + 2, rnd.randrange(0, n1 + 1)]), n1)
+        bad = set(rnd.sample(arrive, nerr))
+        # the buffer holds c codewords; only `poly` matters, and its values at non-arrived parties are never read meaningfully
+        vals = [[rnd.randrange(p) for _ in range(c)] for _ in range(n)]
+        for i in range(n):
+            vals[i][poly] = rnd.randrange(p) if i in bad else _ev(f, x[i], p)
+        cols = ctx.upload_ints([v for row in vals for v in row])
+        pr = _Probe(ctx, x, k)
+        # first k - 1 points in one batch without a decision, then one at a time
+        head = arrive[: max(k - 1, 0)]
+        if head:
+            pr.feed(head, cols, c, poly, decide=False)
+        for m in range(len(head) + 1, n1 + 1):
+            got = pr.feed([arrive[m - 1]], cols, c, poly)
+            xs = [x[i] for i in arrive[:m]]
+            ys = [vals[i][poly] for i in arrive[:m]]
+            co, el = oracle.gao_interpolate(xs, ys, k, p)
+            want = None
+            if co is not None:
+                want = sorted(i for i in range(n) if _ev(el, x[i], p) == 0) if len(el) > 1 else []
+                beyond += sum(1 for j in range(m) if _ev(co, xs[j], p) != ys[j]) > (m - k) // 2
+            assert got == want, (case, n, k, m, got, want)
+            trials += 1
+            decoded += want is not None
+        # reset: the same object decodes another polynomial from scratch, all points at once
+        pr.reset()
+        got = pr.feed(arrive, cols, c, poly)
+        co, el = oracle.gao_interpolate([x[i] for i in arrive], [vals[i][poly] for i in arrive], k, p)
+        assert (got is None) == (co is None)
+        pr.close()
+    assert trials > 300 and decoded > 100 and (beyond >= 1 or p > 100), (trials, decoded, beyond)   # beyond-radius decodes only happen in small fields
+
+
+def test_probe_at_config3_shape_with_21_liars():
+    """n = 64, t = 21: 21 garbage columns first -- every prefix from 43 to 63 points fails, 64 decodes and names the 21 liars"""
+    from honeybadgermpc_amd._capi import Context
+
+    ctx = Context.get(P)
+    rnd = random.Random(64)
+    n, t, c = 64, 21, 3
+    d = t + 1
+    x = list(range(1, n + 1))
+    f = [rnd.randrange(P) for _ in range(d)]
+    vals = [[rnd.randrange(P) for _ in range(c)] for _ in range(n)]
+    for i in range(n):
+        vals[i][1] = rnd.randrange(P) if i < t else _ev(f, x[i], P)
+    cols = ctx.upload_ints([v for row in vals for v in row])
+    pr = _Probe(ctx, x, d)
+    order = list(range(n))
+    assert pr.feed(order[:43], cols, c, 1) is None
+    for m in range(44, 64):
+        assert pr.feed([order[m - 1]], cols, c, 1) is None, m
+    assert pr.feed([order[63]], cols, c, 1) == list(range(t))
+    pr.close()
