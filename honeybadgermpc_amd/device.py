@@ -12,7 +12,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from ._capi import HB_ERR_MISMATCH, HB_OK, Context, np_ptr
+from ._capi import HB_ERR_MISMATCH, HB_ERR_UNSUPPORTED, HB_OK, Context, np_ptr
 
 
 def wb_decode_batch(x, k, rows, modulus):
@@ -253,6 +253,65 @@ def cached_batch_open(modulus, n, t, z, zc, use_omega_powers=False, degree=None,
     return plan
 
 
+INT32_MAX = (1 << 31) - 1
+
+
+class _Probe:
+    """hb_probe_*: the reference's per-polynomial Gao decode (reed_solomon.py:151-186) for ONE codeword of the party-major
+    buffer, incremental in the arrivals (include/hbmpc_hip.h)."""
+
+    def __init__(self, ctx, xh_all, n, k):
+        self.ctx, self.n, self.k = ctx, n, k
+        self.h = ctypes.c_void_p()
+        rc = ctx.lib.hb_probe_create(ctx.h, np_ptr(xh_all), n, k, ctypes.byref(self.h), ctx.stream())
+        if rc != HB_OK:
+            self.h = None
+            raise _Unsupported()
+        self.fed, self.poly = [], -1
+        self._ok = ctypes.c_int32(0)
+        self._mask = np.zeros(n, dtype=np.uint8)
+
+    def decide(self, z, cols, c, poly):
+        """the verdict over the arrival list z for polynomial `poly`: None, or the sorted list of senders in error"""
+        if poly != self.poly or z[: len(self.fed)] != self.fed:
+            self.ctx.check(self.ctx.lib.hb_probe_reset(self.h), "hb_probe_reset")
+            self.fed, self.poly = [], poly
+        new = z[len(self.fed):]
+        ia = np.array(new if new else [0], dtype=np.int32)
+        rc = self.ctx.lib.hb_probe_feed(self.h, np_ptr(ia), len(new), self.ctx.ptr(cols), c, poly, 1, ctypes.byref(self._ok), np_ptr(self._mask), self.ctx.stream())
+        self.ctx.check(rc, "hb_probe_feed")
+        self.fed = list(z)
+        if not self._ok.value:
+            return None
+        return np.nonzero(self._mask)[0].tolist()
+
+    def close(self):
+        if self.h is not None:
+            self.ctx.lib.hb_probe_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+class _Unsupported(Exception):
+    """the plan-free path does not take this context / shape: the caller uses open plans"""
+
+
+class _ProbePool(threading.local):
+    """idle probes of this thread by (modulus, device, points, k): a decoder borrows one when it first needs it (only in robust
+    mode) and hands it back when it is finished"""
+
+    def __init__(self):
+        self.idle = {}
+
+
+_probe_pool = _ProbePool()
+
+
 class DeviceIncrementalDecoder:
     """IncrementalDecoder (reference reed_solomon.py:232-403) on device tensors: columns arrive as (C, limbs) tensors
     and stay in one party-major buffer in HBM; the guess, its validation and the robust fallback are launches over all
@@ -271,6 +330,19 @@ class DeviceIncrementalDecoder:
 
     robust: "gao" (what batch_reconstruct uses, batch_reconstruction.py:85-90) or "wb".
     get_results() -> ((C, degree+1, limbs) coefficient tensor, set of confirmed erroneous senders) or (None, None).
+
+    Plan-free fast path (wide contexts the full-size matrix-core kernel takes; `HB_NO_QUICK=1` or an unsupported shape selects
+    the plan-based path above, same decisions):
+      * optimistic phase: nothing is computed until enough columns are in to finish (degree+1+max_errors-|confirmed|): the guess
+        from the first degree+1 arrivals and its comparison with every later arrival are ONE launch then
+        (`hb_quick_interp_check`, matrix built on the device).  Before that point the reference's state -- guess, "still
+        optimistic" -- has no observable effect: a disagreement only matters once the robust decoder may run, which needs the
+        same number of columns.
+      * robust phase: the next polynomial's Gao verdict comes from an incremental single-codeword probe (`hb_probe_*`: one small
+        kernel per arrival, no n' x n' inverse); once it decodes, its errors are dropped and ONE launch interpolates ALL remaining
+        polynomials from degree+1 of the remaining columns and checks them against the rest, reporting the first chunk that
+        still disagrees: everything before it is accepted (each would robust-decode to exactly that with no errors), and the
+        probe moves on to that chunk.
     """
 
     def __init__(self, modulus, n, t, degree=None, batch_size=1, use_omega_powers=False, confirmed_errors=None, device=None, robust="gao"):
@@ -301,10 +373,14 @@ class DeviceIncrementalDecoder:
         self._result = None
         self._last_status = None
         self._probe_memo = None         # (polynomial index, arrival list, coefficient ints, error set) of the last successful probe
+        self._fast = ctx.n_limbs == 4 and (self.degree + 1) >= 4 and not os.environ.get("HB_NO_QUICK")   # cleared at the first UNSUPPORTED
+        self._status = None             # (2,) int32 on the device: disagreement flag, first disagreeing chunk
+        self._probe_obj = None
         self.probes = 0                 # single-codeword robust decodes so far (diagnostic)
         self.probes_replayed = 0        # probes answered from the previous one (diagnostic)
         self.launches = 0               # batched robust-decode launches so far (diagnostic)
-        self.plan_accepts = 0           # batches accepted by one interpolate-and-check plan (diagnostic)
+        self.plan_accepts = 0           # batches accepted by one interpolate-and-check launch (diagnostic)
+        self.quick_launches = 0         # plan-free interpolate-and-check launches (diagnostic)
 
     # -- kernels ---------------------------------------------------------------------------------
     def _plan(self, z, zc):
@@ -388,6 +464,106 @@ class DeviceIncrementalDecoder:
                 raise Exception("No solution")           # reed_solomon_wb.py:245
             if st == 3:
                 raise AssertionError("2 * t + 1 + c <= n")   # reed_solomon_wb.py:132
+
+    # -- plan-free kernels (hb_quick.hip) ----------------------------------------------------------------
+    def _quick(self, z, zc, store=True, lo=0):
+        """interpolate every polynomial from chunk `lo` on from the arrived rows z, compare with the arrived rows zc, in one launch:
+        -> ((C, d, limbs) | None, all agreed?, first disagreeing chunk); raises _Unsupported when the kernel does not take it"""
+        ctx, t = self.ctx, self.ctx.torch
+        d = self.degree + 1
+        if self._status is None:
+            self._status = self._status_init().clone()
+        out = ctx.empty(self.batch_size * d) if store else None
+        za = np.array(z, dtype=np.int32)
+        zca = np.array(zc if zc else [0], dtype=np.int32)
+        rc = ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(self._xh_all), self.n, np_ptr(za), d, np_ptr(zca), len(zc),
+                                           ctx.ptr(self._cols), self.batch_size, lo, ctx.ptr(out) if store else None, ctx.ptr(self._status), ctx.stream())
+        if rc == HB_ERR_UNSUPPORTED:
+            raise _Unsupported()
+        ctx.check(rc, "hb_quick_interp_check")
+        self.quick_launches += 1
+        dec = out.view(self.batch_size, d, self.L) if store else None
+        if not zc:
+            return dec, True, INT32_MAX
+        flag, first = self._status.tolist()          # synchronises
+        if flag:
+            self._status.copy_(self._status_init())
+        return dec, not flag, (first + lo if flag else INT32_MAX)
+
+    def _status_init(self):
+        init = getattr(self.ctx, "_quick_status_init", None)
+        if init is None:
+            init = self.ctx._quick_status_init = self.ctx.torch.tensor([0, INT32_MAX], dtype=self.ctx.torch.int32, device=self.ctx.tdev)
+        return init
+
+    def _borrow_probe(self):
+        if self._probe_obj is None:
+            key = (self.ctx.modulus, self.ctx.device, self.n, self.degree + 1, self.use_omega_powers)
+            idle = _probe_pool.idle.setdefault(key, [])
+            self._probe_obj = idle.pop() if idle else _Probe(self.ctx, self._xh_all, self.n, self.degree + 1)
+            self._probe_key = key
+        return self._probe_obj
+
+    def _return_probe(self):
+        pr, self._probe_obj = self._probe_obj, None
+        if pr is not None and pr.h is not None:
+            idle = _probe_pool.idle.setdefault(self._probe_key, [])
+            if len(idle) < 8:
+                idle.append(pr)
+            else:
+                pr.close()
+
+    def __del__(self):
+        try:
+            self._return_probe()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+    def _fast_optimistic(self):
+        """enough columns to finish: the guess from the first degree+1 arrivals against every later one.  True = done."""
+        d = self.degree + 1
+        dec, agree, _ = self._quick(self._z[:d], self._z[d:])
+        if agree:
+            self._result = dec
+            return True
+        self._optimistic = False
+        return False
+
+    def _fast_robust_update(self):
+        """reference :334-365 with the Gao decoder, plan-free (see the class docstring)"""
+        d = self.degree + 1
+        pr = self._borrow_probe()
+        while self._num_decoded < self.batch_size:
+            lo = self._num_decoded
+            self.probes += 1
+            errors = pr.decide(self._z, self._cols, self.batch_size, lo)
+            if errors is None:
+                return                                   # (None, None): more columns needed
+            if len(self._available_points) - len(errors) < self._min_points_required():
+                return
+            if errors:
+                es = set(errors)
+                self._confirmed_errors |= es
+                self._available_points -= es
+                self._z = [i for i in self._z if i not in es]
+            # polynomial lo decodes over the remaining columns with no error; so does every later one up to the first chunk
+            # in which some remaining column still disagrees with the interpolant of the others
+            dec, agree, first = self._quick(self._z[:d], self._z[d:], lo=lo)
+            if agree:
+                if lo == 0:
+                    self._partial = dec              # nothing accepted before: the launch's output is the result
+                else:
+                    self._partial[lo:] = dec[lo:]
+                self._num_decoded = self.batch_size
+                self.plan_accepts += 1
+                break
+            if first <= lo:                              # cannot happen: lo was just verified over these very columns
+                raise RuntimeError("device decoder: the probe and the batched check disagree on a decoded polynomial")
+            self._partial[lo:first] = dec[lo:first]
+            self._num_decoded = first
+        if self._num_decoded == self.batch_size:
+            self._result = self._partial
+            self._return_probe()
 
     # -- the state machine (reference :288-372) ------------------------------------------------------
     def _min_points_required(self):
@@ -508,10 +684,48 @@ class DeviceIncrementalDecoder:
         self._cols[idx] = column
         if len(self._available_points) <= self.degree:
             return
+        if self._fast:
+            try:
+                return self._fast_add()
+            except _Unsupported:
+                self._fast = False                       # this context / shape: open plans from here on (same decisions)
+                if self._optimistic and self._guess_decoded is None and len(self._available_points) > self.degree + 1:
+                    self._catch_up_optimistic()
+                    if self.done() or self._optimistic:
+                        return
+                    if len(self._available_points) >= self._min_points_required():
+                        self._robust_update()
+                    return
         if self._optimistic and self._optimistic_update(idx):
             return
         if len(self._available_points) >= self._min_points_required():
             self._robust_update()
+
+    def _fast_add(self):
+        enough = len(self._available_points) >= self._min_points_required()
+        if self._optimistic:
+            if not enough or self._fast_optimistic():
+                return
+        if enough:
+            if self.robust == "gao":
+                self._fast_robust_update()
+            else:
+                self._robust_update()
+
+    def _catch_up_optimistic(self):
+        """the plan-based optimistic path for a decoder that skipped it while the plan-free path looked available: guess from the
+        first degree+1 arrivals, then every later arrival in order (reference :305-330)"""
+        d = self.degree + 1
+        later = self._z[d:]
+        saved_z, saved_av = self._z, self._available_points
+        self._z, self._available_points = saved_z[:d], set(saved_z[:d])
+        self._decode_and_encode()
+        for idx in later:
+            self._z.append(idx)
+            self._available_points.add(idx)
+            if not self._optimistic_update(idx) or self.done():
+                break
+        self._z, self._available_points = saved_z, saved_av
 
     def done(self):
         return self._result is not None

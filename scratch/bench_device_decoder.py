@@ -1,4 +1,5 @@
-"""Faulty-party open at config-3 shape on the device decoder: `liars` parties send garbage in every chunk and arrive first."""
+"""Faulty-party open at config-3 shape on the device decoder: `liars` parties send garbage in every chunk and arrive first;
+"late" = the same liars corrupt ONE late chunk only (polynomial 0 decodes clean: what defeats a decode-polynomial-0-alone shortcut)."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -21,11 +22,14 @@ cols = ctx.empty(n * C)
 ctx.check(lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(xh), n, ctx.ptr(coef), C, d, ctx.ptr(cols), ctx.stream()), "enc")
 cols = cols.view(C, n, 4).transpose(0, 1).contiguous()      # [n][C]
 for robust in ("gao", "wb"):
-    for liars in (0, 5, 21):
+    for liars, late in ((0, False), (5, False), (21, False), (5, True), (21, True)):
         bad = list(range(liars))
         data = cols.clone()
         for i in bad:
-            data[i] = rand(C)
+            if late:
+                data[i, C // 2 + 3 * i] = rand(1)[0]       # each liar corrupts one chunk of its own, none touches chunk 0
+            else:
+                data[i] = rand(C)
         order = bad + [i for i in range(n) if i not in bad]
         times = []
         for rep in range(3):              # warm-up (one-time initialisation), plans built (cache cleared), plans cached
@@ -45,7 +49,7 @@ for robust in ("gao", "wb"):
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             times.append(dt)
         if failed:
-            print(f"{robust}: {liars} liars: raised {failed} after {used} columns, as the reference's decoder does beyond the radius", flush=True)
+            print(f"{robust}: {liars} liars{' (late chunks only)' if late else ''}: raised {failed} after {used} columns, as the reference's decoder does beyond the radius", flush=True)
             continue
         ok = torch.equal(res.reshape(-1, 4), coef)
-        print(f"{robust}: {liars} liars: {dt*1e3:.1f} ms for 2^20 shares = {B/dt/1e6:.1f} M shares/s (arrival pattern seen before: its plans come from the per-thread cache; building them: {times[1]*1e3:.1f} ms = {B/times[1]/1e6:.1f} M shares/s), {used} columns used, errors {sorted(errs)}, launches {dec.launches}, plan accepts {dec.plan_accepts}, exact {ok}", flush=True)
+        print(f"{robust}: {liars} liars{' (late chunks only)' if late else ''}: {dt*1e3:.1f} ms for 2^20 shares = {B/dt/1e6:.1f} M shares/s (arrival pattern seen before: its plans come from the per-thread cache; building them: {times[1]*1e3:.1f} ms = {B/times[1]/1e6:.1f} M shares/s), {used} columns used, errors {sorted(errs)}, launches {dec.launches}, plan accepts {dec.plan_accepts}, probes {dec.probes}, quick launches {dec.quick_launches}, exact {ok}", flush=True)

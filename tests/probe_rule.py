@@ -71,14 +71,8 @@ class Probe:
         assert deg(A1) < T
         db = deg(B1)
         assert db >= 0
-        # fraction-free pseudo-division: B1 | A1 ?
-        R = list(A1)
-        lb = B1[db]
-        while deg(R) >= db:
-            dr = deg(R)
-            lr = R[dr]
-            s = dr - db
-            R = [(lb * R[i] - (lr * B1[i - s] if 0 <= i - s <= db else 0)) % p for i in range(len(R))]
-        if deg(R) >= 0:
+        # B1 | A1  <=>  B1 has deg B1 distinct roots among the points fed (A1 + y B1 vanishes on every point; conversely the
+        # locator of a decodable word is the product over its errors): no polynomial division
+        if sum(1 for x, _ in self.pts if ev(B1, x, p) == 0) != db:
             return None
         return [i for i, x in enumerate(party_points) if ev(B1, x, p) == 0]

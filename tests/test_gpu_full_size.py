@@ -511,6 +511,8 @@ def test_open_plans_are_cached_per_thread(monkeypatch):
     assert cached_batch_open(P, n, t, list(range(d)), [], max_shares=c * d) is not cached_batch_open(P, n, t, list(range(d)), [], max_shares=c * d)
     monkeypatch.delenv("HB_PLAN_CACHE")
     # same arrival pattern twice, the second time with a liar: the shared plans must not leak the first run's verdict
+    # (the plan-based decoder path: contexts / shapes the plan-free kernels do not take, or HB_NO_QUICK=1)
+    monkeypatch.setenv("HB_NO_QUICK", "1")
     device._plan_cache.plans.clear()
     for liar in (None, 2):
         dec = DeviceIncrementalDecoder(P, n, t, batch_size=c)
@@ -525,6 +527,22 @@ def test_open_plans_are_cached_per_thread(monkeypatch):
         assert ctx.download_ints(coeffs.reshape(c * d, -1)) == [v for row in polys for v in row]
         assert errs == (set() if liar is None else {liar})
     assert len(device._plan_cache.plans) >= 1
+    # the default, plan-free path builds no plan at all for the same two runs
+    monkeypatch.delenv("HB_NO_QUICK")
+    device._plan_cache.plans.clear()
+    for liar in (None, 2):
+        dec = DeviceIncrementalDecoder(P, n, t, batch_size=c)
+        for j in range(n):
+            col = cols[j]
+            if liar == j:
+                col = col.clone(); col[:, 0] ^= 1
+            dec.add(j, col)
+            if dec.done():
+                break
+        coeffs, errs = dec.get_results()
+        assert ctx.download_ints(coeffs.reshape(c * d, -1)) == [v for row in polys for v in row]
+        assert errs == (set() if liar is None else {liar}) and dec.quick_launches >= 1
+    assert len(device._plan_cache.plans) == 0
     torch.cuda.synchronize()
 
 

@@ -243,6 +243,59 @@ def test_device_incremental_decoder_trajectory(n, t, c, seed, robust, use_omega)
     assert robust_launches > 0          # the seeds above all reach the robust path at least once
 
 
+@pytest.mark.parametrize("n, t, c, pattern", [(31, 10, 120, "late-distinct"), (31, 10, 120, "late-same"), (64, 21, 96, "late-distinct"), (64, 21, 64, "everywhere"),
+                                              (16, 5, 300, "late-distinct")])
+def test_device_decoder_worst_case_adversaries(n, t, c, pattern):
+    """t liars that arrive FIRST.  "everywhere": garbage in every chunk (every probe up to the last column
+    fails).  "late-*": each liar corrupts one chunk k > 0 only -- polynomial 0 decodes clean, so nothing that looks at polynomial
+    0 alone can vouch for the batch; "late-distinct" gives every liar a chunk of its own (one round of probe + batched check per
+    liar), "late-same" puts them all in one chunk.  The device decoder (plan-free path: hb_quick_interp_check + hb_probe_*) must
+    walk the host mirror's trajectory -- done / confirmed errors / arrival list / polynomials decoded -- after EVERY column."""
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+    from honeybadgermpc_amd.reed_solomon import Algorithm, DecoderFactory, EncoderFactory, IncrementalDecoder, RobustDecoderFactory
+
+    rnd = random.Random(n * 100 + t + len(pattern))
+    ctx = Context.get(P)
+    point = EvalPoint(GF(P), n)
+    xs = [point(i).value for i in range(n)]
+    polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+    cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+    liars = rnd.sample(range(n), t)
+    for r, i in enumerate(liars):
+        if pattern == "everywhere":
+            hit = range(c)
+        elif pattern == "late-same":
+            hit = [c // 2]
+        else:
+            hit = [1 + (r * 7) % (c - 1)]
+        for j in hit:
+            cols[i][j] = (cols[i][j] + 1 + rnd.randrange(P - 1)) % P
+    honest = [i for i in range(n) if i not in liars]
+    rnd.shuffle(honest)
+    order = liars + honest
+    host = IncrementalDecoder(EncoderFactory.get(point, Algorithm.VANDERMONDE), DecoderFactory.get(point, Algorithm.VANDERMONDE),
+                              RobustDecoderFactory.get(t, point, algorithm=Algorithm.GAO), degree=t, batch_size=c, max_errors=t)
+    dev = DeviceIncrementalDecoder(P, n, t, batch_size=c)
+    for step, idx in enumerate(order):
+        host.add(idx, cols[idx])
+        dev.add(idx, ctx.upload_ints(cols[idx]))
+        assert dev.done() == host.done(), step
+        assert dev._confirmed_errors == host._confirmed_errors and dev._z == host._z and dev._num_decoded == host._num_decoded, step
+        if host.done():
+            break
+    assert host.done() and dev.done()
+    hres, herr = host.get_results()
+    dres, derr = dev.get_results()
+    assert derr == herr == set(liars)
+    assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in hres for v in row] == [v for row in polys for v in row]
+    assert dev.quick_launches > 0 and dev.launches == 0          # the plan-free path did it: no batched Gao launch, no plan
+    if pattern != "late-same":
+        assert dev.probes >= (t if pattern == "everywhere" else len({1 + (r * 7) % (c - 1) for r in range(t)}))
+
+
 def test_device_incremental_decoder_reference_transcripts(golden):
     """The transcripts tests/golden/incremental_decoder.json recorded from the reference's own IncrementalDecoder
     (done / result / confirmed errors after every add), replayed on the device decoder with the transcript's robust
