@@ -271,6 +271,32 @@ def gen_wb():
     dump("welch_berlekamp.json", S({"cases": cases}))
 
 
+def gen_wb_cfg4():
+    """BASELINE config 4's shape from the reference itself: n = 100, k = 34, the reference's own
+    make_wb_encoder_decoder at the full radius (33 errors), beyond it (34), and with erasures + errors.  ~2.3 s per row
+    reduction in the reference's pure Python, and a word beyond the radius walks the whole descending-e' loop: a few minutes."""
+    rnd = random.Random(4100)
+    p, n, k = BLS, 100, 34
+    enc, dec, _ = make_wb_encoder_decoder(n, k, p)
+    x = list(range(1, n + 1))
+    cases = []
+    fpw = GF(p)
+    for ne, nn in [(33, 0), (33, 0), (33, 0), (32, 1), (28, 10), (28, 10), (23, 20), (34, 0)]:
+        msg = [rnd.randrange(p) for _ in range(k)]
+        if (ne, nn) == (32, 1):
+            msg = msg[: k - 2] + [0, 0]                     # stripped output shorter than k
+        encoded = [v.value for v in enc(msg)]
+        word, errpos = corrupt(rnd, encoded, ne, nn, p)
+        try:
+            out = dec([None if w is None else fpw(w) for w in word], debug=False)
+            res = {"coeffs": [c.value for c in out], "error": None}
+        except Exception as e:  # noqa: BLE001 - the reference raises bare Exceptions
+            res = {"coeffs": None, "error": str(e)}
+        cases.append({"p": p, "n": n, "k": k, "x": x, "msg": msg, "word": word, "errpos": errpos,
+                      "beyond_radius": 2 * ne + nn > n - k, **res})
+    dump("welch_berlekamp_cfg4.json", S({"cases": cases}))
+
+
 # --------------------------------------------------------------------------- F
 def gen_misc():
     out = {
@@ -387,6 +413,7 @@ if __name__ == "__main__":
     gen_fft()
     gen_fft_interpolate()
     gen_wb()
+    gen_wb_cfg4()
     gen_misc()
     gen_incremental()
     gen_batch_reconstruct()

@@ -718,6 +718,26 @@ def test_wb_golden_hip(golden):
     assert seen == {None, "No solution", "found no divisors!"}
 
 
+def test_wb_golden_cfg4_shape_hip(golden):
+    """the reference's own Welch-Berlekamp outcomes at config 4's shape (n = 100, k = 34: 33 errors, erasures + errors, a
+    stripped result, one word beyond the radius) through hb_wb_decode, and the error-free-erasure cases through hb_gao_decode"""
+    from honeybadgermpc_amd import ntl
+    from honeybadgermpc_amd.device import wb_decode_batch
+
+    cases = golden("welch_berlekamp_cfg4.json")["cases"]
+    res = wb_decode_batch(cases[0]["x"], 34, [c["word"] for c in cases], cases[0]["p"])
+    for case, (coeffs, status) in zip(cases, res):
+        if case["error"] is None:
+            assert status == 0 and coeffs == case["coeffs"]
+        else:
+            assert coeffs is None and oracle.WB_MESSAGES[status] == case["error"]
+    full = [c for c in cases if c["error"] is None and not any(w is None for w in c["word"])]
+    got = ntl.gao_interpolate_batch(full[0]["x"], [c["word"] for c in full], 34, full[0]["p"])
+    for case, (co, err) in zip(full, got):
+        assert co == case["coeffs"] + [0] * (34 - len(case["coeffs"]))
+        assert len(err) - 1 == len(case["errpos"])
+
+
 @pytest.mark.parametrize("p,n,k,reps", [(P, 100, 34, 6), (P, 64, 22, 8), (53, 22, 8, 40), (13, 10, 3, 40), (P, 7, 1, 6)])
 def test_wb_batch_vs_oracle(p, n, k, reps):
     from honeybadgermpc_amd.device import wb_decode_batch

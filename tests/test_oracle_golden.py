@@ -192,6 +192,31 @@ def test_golden_welch_berlekamp(golden):
     assert n_fail > 0  # the beyond-radius cases exercise the failure paths
 
 
+def test_golden_welch_berlekamp_cfg4_shape(golden):
+    """BASELINE config 4's shape pinned by the reference itself: n = 100, k = 34, make_wb_encoder_decoder at
+    the full radius (33 errors), with erasures + errors, a stripped-zero result and one word beyond the radius ("No solution")"""
+    cases = golden("welch_berlekamp_cfg4.json")["cases"]
+    assert len(cases) >= 8 and {c["n"] for c in cases} == {100} and {c["k"] for c in cases} == {34}
+    outcomes = set()
+    for case in cases:
+        res, status = oracle.wb_decode_batch(case["x"], case["k"], [case["word"]], case["p"])[0]
+        if case["error"] is None:
+            assert status == 0 and res == case["coeffs"]
+            # inside the radius the result is the message with its trailing zeros stripped (polynomial.py:14-20)
+            msg = list(case["msg"])
+            while msg and msg[-1] == 0:
+                msg.pop()
+            assert res == msg
+            if not any(w is None for w in case["word"]):
+                co, err = oracle.gao_interpolate(case["x"], case["word"], case["k"], case["p"])
+                assert co == case["coeffs"] + [0] * (case["k"] - len(case["coeffs"]))
+                assert [i for i in range(100) if peval(err, case["x"][i], case["p"]) == 0] == case["errpos"]
+        else:
+            assert res is None and oracle.WB_MESSAGES[status] == case["error"]
+        outcomes.add(case["error"])
+    assert outcomes == {None, "No solution"}
+
+
 def test_golden_wb_vs_gao(golden):
     """Inside the decoding radius Gao must return what the reference's WB returns, and the
     roots of its error locator must be exactly the corrupted positions."""
