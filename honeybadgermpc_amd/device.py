@@ -376,6 +376,9 @@ class DeviceIncrementalDecoder:
         self._fast = ctx.n_limbs == 4 and (self.degree + 1) >= 4 and not os.environ.get("HB_NO_QUICK")   # cleared at the first UNSUPPORTED
         self._status = None             # (2,) int32 on the device: disagreement flag, first disagreeing chunk
         self._probe_obj = None
+        self._stalled = None            # polynomial the last robust update could not decode (the probe is on it)
+        self._checked = None            # (arrival list, first chunk, coefficients, first disagreeing chunk) of a launch the robust phase may reuse
+        self.radius_verdicts = 0        # polynomials settled by the batched launch's own candidate (diagnostic)
         self.probes = 0                 # single-codeword robust decodes so far (diagnostic)
         self.probes_replayed = 0        # probes answered from the previous one (diagnostic)
         self.launches = 0               # batched robust-decode launches so far (diagnostic)
@@ -522,33 +525,58 @@ class DeviceIncrementalDecoder:
     def _fast_optimistic(self):
         """enough columns to finish: the guess from the first degree+1 arrivals against every later one.  True = done."""
         d = self.degree + 1
-        dec, agree, _ = self._quick(self._z[:d], self._z[d:])
+        dec, agree, first = self._quick(self._z[:d], self._z[d:])
         if agree:
             self._result = dec
             return True
         self._optimistic = False
+        self._checked = (list(self._z), 0, dec, first)      # the robust phase starts from this very launch
         return False
 
-    def _fast_robust_update(self):
-        """reference :334-365 with the Gao decoder, plan-free (see the class docstring)"""
+    def _disagreeing(self, coeffs):
+        """the arrived senders whose symbol of ONE polynomial differs from `coeffs` ((d, limbs)) evaluated at their point"""
+        ctx, t = self.ctx, self.ctx.torch
         d = self.degree + 1
-        pr = self._borrow_probe()
+        ev = ctx.empty(self.n)
+        ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), self.n, ctx.ptr(coeffs.contiguous()), 1, d, ctx.ptr(ev), ctx.stream()), "evaluate")
+        return ev
+
+    def _expel(self, errors):
+        es = set(errors)
+        self._confirmed_errors |= es
+        self._available_points -= es
+        self._z = [i for i in self._z if i not in es]
+
+    def _fast_robust_update(self):
+        """reference :334-365 with the Gao decoder, plan-free (see the class docstring).
+
+        One launch interpolates every open polynomial from degree+1 of the arrived columns and compares with the rest.  Everything
+        before the first disagreeing chunk m is accepted (each of those polynomials robust-decodes to exactly that, with no error).
+        For polynomial m the launch has also produced a candidate: if the senders that disagree with it number at most
+        floor((|z| - degree - 1) / 2), the candidate is within the unique-decoding radius of the received word, hence IS what Gao
+        returns, and those senders are its errors -- no decode needed.  Otherwise the interpolation set itself was contaminated
+        and the incremental probe (hb_probe_*) gives Gao's verdict; while it says "undecodable", later arrivals only cost its
+        update."""
+        t = self.ctx.torch
+        d = self.degree + 1
         while self._num_decoded < self.batch_size:
             lo = self._num_decoded
-            self.probes += 1
-            errors = pr.decide(self._z, self._cols, self.batch_size, lo)
-            if errors is None:
-                return                                   # (None, None): more columns needed
-            if len(self._available_points) - len(errors) < self._min_points_required():
-                return
-            if errors:
-                es = set(errors)
-                self._confirmed_errors |= es
-                self._available_points -= es
-                self._z = [i for i in self._z if i not in es]
-            # polynomial lo decodes over the remaining columns with no error; so does every later one up to the first chunk
-            # in which some remaining column still disagrees with the interpolant of the others
-            dec, agree, first = self._quick(self._z[:d], self._z[d:], lo=lo)
+            if self._stalled == lo:
+                pr = self._borrow_probe()
+                self.probes += 1
+                errors = pr.decide(self._z, self._cols, self.batch_size, lo)
+                if errors is None:
+                    return                                   # (None, None): more columns needed
+                if len(self._available_points) - len(errors) < self._min_points_required():
+                    return
+                self._stalled = None
+                self._expel(errors)
+            chk, self._checked = self._checked, None
+            if chk is not None and chk[0] == self._z and chk[1] == lo:
+                dec, first = chk[2], chk[3]
+                agree = False
+            else:
+                dec, agree, first = self._quick(self._z[:d], self._z[d:], lo=lo)
             if agree:
                 if lo == 0:
                     self._partial = dec              # nothing accepted before: the launch's output is the result
@@ -557,10 +585,21 @@ class DeviceIncrementalDecoder:
                 self._num_decoded = self.batch_size
                 self.plan_accepts += 1
                 break
-            if first <= lo:                              # cannot happen: lo was just verified over these very columns
-                raise RuntimeError("device decoder: the probe and the batched check disagree on a decoded polynomial")
-            self._partial[lo:first] = dec[lo:first]
-            self._num_decoded = first
+            if first > lo:
+                self._partial[lo:first] = dec[lo:first]
+                self._num_decoded = first
+            # polynomial `first`: is the candidate the launch produced within the radius?
+            ev = self._disagreeing(dec[first])
+            zt = t.tensor(self._z, dtype=t.int64, device=self.ctx.tdev)
+            differs = (ev.index_select(0, zt) != self._cols[:, first, :].index_select(0, zt)).any(dim=1)
+            errors = [self._z[i] for i in t.nonzero(differs).flatten().tolist()]
+            if len(errors) <= (len(self._z) - d) // 2:
+                if len(self._available_points) - len(errors) < self._min_points_required():
+                    return
+                self.radius_verdicts += 1
+                self._expel(errors)
+                continue
+            self._stalled = first                        # only the probe can say when it becomes decodable
         if self._num_decoded == self.batch_size:
             self._result = self._partial
             self._return_probe()

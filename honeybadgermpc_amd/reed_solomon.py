@@ -144,25 +144,9 @@ class GaoRobustDecoder(RobustDecoder):
         self.use_omega_powers = point.use_omega_powers
 
     def robust_decode(self, z, encoded):
-        x = [self.point(zi).value for zi in z]
-        args = [x, encoded, self.d + 1, self.modulus]
-        if self.use_omega_powers:
-            args += [z, self.point.omega.value, self.point.order]
-        decoded, error_poly = gao_interpolate(*args, use_omega_powers=self.use_omega_powers)
-        if decoded is None:
-            return None, None
-
-        errors = []
-        if len(error_poly) > 1:
-            # roots of the error locator among the party points are the faulty parties (:174-184)
-            if self.use_omega_powers:
-                err_eval = fft(error_poly, self.point.omega.value, self.modulus, self.point.order)[: self.point.n]
-            else:
-                xs = [self.point(i).value for i in range(self.point.n)]
-                err_eval = vandermonde_batch_evaluate(xs, [error_poly], self.modulus)[0]
-            errors = [i for i in range(self.point.n) if err_eval[i] == 0]
-        return decoded, errors
-
+        """(coefficients, senders in error) or (None, None): the batch of one (reference :158-186 -- Gao's decode, then the
+        roots of its error locator among all party points)"""
+        return self.robust_decode_batch(z, [encoded])[0]
 
     def robust_decode_batch(self, z, rows):
         """All rows (codewords over the same arrival set z, no erasures) in one launch
@@ -198,29 +182,15 @@ class WelchBerlekampRobustDecoder(RobustDecoder):
         self.d = d
         self.modulus = point.field.modulus
         self.point = point
-        _, self._dec, _ = make_wb_encoder_decoder(self.n, self.d + 1, self.modulus, self.point)
 
     def robust_decode(self, z, encoded):
-        where = {zi: i for i, zi in enumerate(z)}
-        enc_extended = [self.point.field(encoded[where[i]]) if i in where else None for i in range(self.n)]
-        try:
-            coeffs = self._dec(enc_extended)
-        except Exception as e:
-            # the reference swallows exactly these two messages and re-raises the rest (:205-212)
-            if str(e) not in ("Wrong degree", "found no divisors!"):
-                raise e
-            coeffs = None
-        if coeffs is None:
-            return None, None
-        coeffs = [c.value for c in coeffs]
-        xs = [self.point(i).value for i in range(self.point.n)]
-        poly_eval = vandermonde_batch_evaluate(xs, [coeffs], self.modulus)[0]
-        errors = [
-            i for i in range(self.point.n)
-            if enc_extended[i] is not None and enc_extended[i].value != poly_eval[i]
-        ]
-        return coeffs, errors
-
+        """reference :197-225: the word is extended to all n positions (erasures where nobody has sent), decoded, and the senders
+        whose symbols differ from the re-encoded result are the errors.  "Wrong degree" / "found no divisors!" mean (None, None);
+        what else the reference's solver raises ("No solution", the 2t + 1 + c <= n assertion) propagates."""
+        answer = self.robust_decode_batch(z, [encoded])[0]
+        if isinstance(answer, BaseException):
+            raise answer
+        return answer
 
     def robust_decode_batch(self, z, rows):
         """Batched robust_decode.  An entry is (coeffs, errors), (None, None), or an Exception
@@ -258,144 +228,135 @@ class DecodeValidationError(HoneyBadgerMPCError):
 
 
 # ---------------------------------------------------------------------------
-# IncrementalDecoder (reference :232-403)
+# IncrementalDecoder (behaviour of reference :232-403; own organisation)
 # ---------------------------------------------------------------------------
+class _ArrivalLog:
+    """Who has been heard from, in what order, and who has been caught lying: the part of an incremental decode that is
+    independent of where the data lives (this host class keeps columns as Python lists, `device.DeviceIncrementalDecoder`
+    keeps them in HBM; both walk the same phases)."""
+
+    def __init__(self, caught=None):
+        self.order = []                                  # senders whose columns count, oldest first
+        self.present = set()
+        self.caught = set() if caught is None else caught   # shared with the caller on purpose (batch_reconstruct reuses it)
+
+    def admits(self, sender):
+        return sender not in self.present and sender not in self.caught
+
+    def record(self, sender):
+        self.order.append(sender)
+        self.present.add(sender)
+
+    def expel(self, senders):
+        """senders proven wrong by a robust decode: they stop counting, now and for every later column"""
+        gone = set(senders)
+        self.caught |= gone
+        self.present -= gone
+        self.order[:] = [s for s in self.order if s not in gone]
+        return bool(gone)
+
+
 class IncrementalDecoder(object):
     """Feed columns (one per party, in arrival order); be fast when nobody lies.
 
-    After degree+1 columns: optimistic decode + re-encode ("the guess").  Every later
-    column is compared with the guess; when degree+1+max_errors-|confirmed errors|
-    columns agree on every polynomial of the batch we are done.  A single mismatch
-    switches permanently to robust mode, which decodes polynomial by polynomial,
-    confirms erroneous senders and drops their columns.
+    Phases.  *collecting*: fewer than degree + 1 columns.  *optimistic*: the first degree + 1 columns are interpolated
+    and re-encoded ("the guess"); every later column either agrees with the guess at its point -- and once
+    degree + 1 + max_errors - |caught| columns are in, the guess is the answer -- or ends optimism for good.  *robust*:
+    polynomial by polynomial, in order, the robust decoder names the senders in error; they are expelled and the
+    remaining polynomials are decoded over what is left.  Outcomes, step by step, are the reference's (its transcripts are
+    replayed in tests/test_host_logic.py); columns are kept per sender, not per polynomial, so expelling a sender is O(1).
     """
 
     def __init__(self, encoder, decoder, robust_decoder, degree, batch_size, max_errors,
                  confirmed_errors=None, validator=None):
-        self.encoder = encoder
-        self.decoder = decoder
-        self.robust_decoder = robust_decoder
-        self.degree = degree
-        self.batch_size = batch_size
-        self.max_errors = max_errors
+        self.encoder, self.decoder, self.robust_decoder = encoder, decoder, robust_decoder
+        self.degree, self.batch_size, self.max_errors = degree, batch_size, max_errors
         self.validator = validator
-
-        self._confirmed_errors = set() if confirmed_errors is None else confirmed_errors
-        self._available_points = set()
-        self._z = []
-        self._available_data = [[] for _ in range(batch_size)]
-
+        self._log = _ArrivalLog(confirmed_errors)
+        self._columns = {}                  # sender -> its column
         self._optimistic = True
-        self._guess_decoded = None
-        self._guess_encoded = None
-
-        self._num_decoded = 0
-        self._partial_result = []
+        self._guess = None                  # (coefficients per polynomial, evaluations per polynomial)
+        self._settled = []                  # robust phase: polynomials decoded so far, in order
         self._result = None
 
-    def _validate(self, data):
+    # views the tests and batch_reconstruct look at (names as in the reference)
+    _z = property(lambda self: self._log.order)
+    _available_points = property(lambda self: self._log.present)
+    _confirmed_errors = property(lambda self: self._log.caught)
+    _num_decoded = property(lambda self: len(self._settled))
+
+    def _threshold(self):
+        """columns needed before anything can be final: degree + 1 to interpolate, one more per error still possible"""
+        return self.degree + 1 + self.max_errors - len(self._log.caught)
+
+    _min_points_required = _threshold
+
+    def _check_column(self, data):
         if len(data) != self.batch_size:
             raise DecodeValidationError("Incorrect length of data")
-        if data is None:  # unreachable after len(); kept for parity with reference :294-295
-            return False
         if self.validator is not None:
-            for d in data:
-                self.validator(d)
+            for value in data:
+                self.validator(value)
+
+    def _rows(self, first):
+        """polynomials first.. as codewords over the current arrival list (what the codecs take)"""
+        cols = [self._columns[s] for s in self._log.order]
+        return [[col[i] for col in cols] for i in range(first, self.batch_size)]
+
+    def _optimistic_step(self, sender, data):
+        """-> still optimistic?"""
+        if self._guess is None:
+            coeffs = self.decoder.decode_batch(self._log.order, self._rows(0))
+            self._guess = (coeffs, self.encoder.encode_batch(coeffs))
+        elif any(data[i] != row[sender] for i, row in enumerate(self._guess[1])):
+            logging.critical("Optimistic decoding failed")
+            self._guess, self._optimistic = None, False
+            return False
+        if len(self._log.present) >= self._threshold():
+            self._result = self._guess[0]
         return True
 
-    def _min_points_required(self):
-        return self.degree + 1 + self.max_errors - len(self._confirmed_errors)
-
-    def _optimistic_update(self, idx, data):
-        agree = True
-        if len(self._available_points) == self.degree + 1:
-            self._guess_decoded = self.decoder.decode_batch(self._z, self._available_data)
-            self._guess_encoded = self.encoder.encode_batch(self._guess_decoded)
-        else:
-            guess = self._guess_encoded
-            for i in range(self.batch_size):
-                if data[i] != guess[i][idx]:
-                    agree = False
-                    break
-            if not agree:
-                logging.critical("Optimistic decoding failed")
-                self._guess_decoded = None
-                self._guess_encoded = None
-                self._optimistic = False
-        if agree and len(self._available_points) >= self._min_points_required():
-            self._result = self._guess_decoded
-        return agree
-
-    def _accept(self, decoded, errors):
-        """Bookkeeping for one robustly decoded polynomial (reference :344-361).  Returns True
-        when the arrival set changed (confirmed errors were dropped)."""
-        self._num_decoded += 1
-        self._available_data = self._available_data[1:]
-        self._partial_result.append(decoded)
-        self._confirmed_errors |= set(errors)
-        self._available_points -= set(errors)
-        for e in errors:
-            pos = self._z.index(e)
-            del self._z[pos]
-            for row in self._available_data:
-                del row[pos]
-        return len(errors) > 0
-
-    def _robust_update(self):
-        batch = getattr(self.robust_decoder, "robust_decode_batch", None)
-        stalled = False
-        while self._num_decoded < self.batch_size and not stalled:
-            if batch is None:
-                # the reference's loop: one robust_decode per polynomial (:335-361)
-                results = [self.robust_decoder.robust_decode(self._z, self._available_data[0])]
-            else:
-                # every remaining polynomial over the current arrival set in ONE launch; the
-                # results stay valid until an accepted polynomial confirms new errors (which
-                # changes the arrival set), at which point the rest is decoded again.
-                results = batch(self._z, self._available_data)
-            for res in results:
-                if isinstance(res, BaseException):
-                    raise res
-                decoded, errors = res
-                if decoded is None:
-                    stalled = True          # need more columns
-                    break
-                if len(self._available_points) - len(errors) < self._min_points_required():
-                    stalled = True
-                    break
-                if self._accept(decoded, errors):
-                    break                   # arrival set changed: re-decode what is left
-        if self._num_decoded == self.batch_size:
-            self._result = self._partial_result
+    def _robust_steps(self):
+        whole_batch = getattr(self.robust_decoder, "robust_decode_batch", None)
+        while len(self._settled) < self.batch_size:
+            pending = self._rows(len(self._settled))
+            # one launch over everything still open when the decoder offers it; its answers hold until a sender is expelled
+            answers = whole_batch(self._log.order, pending) if whole_batch else [self.robust_decoder.robust_decode(self._log.order, pending[0])]
+            progressed = False
+            for answer in answers:
+                if isinstance(answer, BaseException):
+                    raise answer
+                coeffs, liars = answer
+                if coeffs is None or len(self._log.present) - len(liars) < self._threshold():
+                    return                                   # this polynomial needs more columns; so does everything after it
+                self._settled.append(coeffs)
+                progressed = True
+                if self._log.expel(liars):
+                    break                                    # fewer columns now: decode the rest again
+            if not progressed:
+                return
+        self._result = self._settled
 
     def add(self, idx, data):
-        if self.done():
+        if self._result is not None or not self._log.admits(idx):
             return
-        if idx in self._available_points or idx in self._confirmed_errors:
+        self._check_column(data)
+        self._columns[idx] = data
+        self._log.record(idx)
+        if len(self._log.present) <= self.degree:
             return
-        if not self._validate(data):
-            logging.error("Validation failed for data from %d: %s", idx, str(data))
-            raise DecodeValidationError("Custom validation failed for %s" % str(data))
-
-        self._available_points.add(idx)
-        self._z.append(idx)
-        for i in range(self._num_decoded, self.batch_size):
-            self._available_data[i - self._num_decoded].append(data[i])
-
-        if len(self._available_points) <= self.degree:
+        if self._optimistic and self._optimistic_step(idx, data):
             return
-        if self._optimistic and self._optimistic_update(idx, data):
-            return
-        if len(self._available_points) >= self._min_points_required():
-            self._robust_update()
+        if len(self._log.present) >= self._threshold():
+            self._robust_steps()
 
     def done(self):
         return self._result is not None
 
     def get_results(self):
-        if self._result is not None:
-            return self._result, self._confirmed_errors
-        return None, None
+        if self._result is None:
+            return None, None
+        return self._result, self._log.caught
 
 
 # ---------------------------------------------------------------------------

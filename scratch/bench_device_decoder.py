@@ -52,4 +52,4 @@ for robust in ("gao", "wb"):
             print(f"{robust}: {liars} liars{' (late chunks only)' if late else ''}: raised {failed} after {used} columns, as the reference's decoder does beyond the radius", flush=True)
             continue
         ok = torch.equal(res.reshape(-1, 4), coef)
-        print(f"{robust}: {liars} liars{' (late chunks only)' if late else ''}: {dt*1e3:.1f} ms for 2^20 shares = {B/dt/1e6:.1f} M shares/s (arrival pattern seen before: its plans come from the per-thread cache; building them: {times[1]*1e3:.1f} ms = {B/times[1]/1e6:.1f} M shares/s), {used} columns used, errors {sorted(errs)}, launches {dec.launches}, plan accepts {dec.plan_accepts}, probes {dec.probes}, quick launches {dec.quick_launches}, exact {ok}", flush=True)
+        print(f"{robust}: {liars} liars{' (late chunks only)' if late else ''}: {dt*1e3:.1f} ms for 2^20 shares = {B/dt/1e6:.1f} M shares/s (arrival pattern seen before: its plans come from the per-thread cache; building them: {times[1]*1e3:.1f} ms = {B/times[1]/1e6:.1f} M shares/s), {used} columns used, errors {sorted(errs)}, launches {dec.launches}, plan accepts {dec.plan_accepts}, probes {dec.probes}, quick launches {dec.quick_launches}, settled inside the radius {dec.radius_verdicts}, exact {ok}", flush=True)
