@@ -376,6 +376,8 @@ class DeviceIncrementalDecoder:
         self._fast = ctx.n_limbs == 4 and (self.degree + 1) >= 4 and not os.environ.get("HB_NO_QUICK")   # cleared at the first UNSUPPORTED
         self._status = None             # (2,) int32 on the device: disagreement flag, first disagreeing chunk
         self._probe_obj = None
+        self._memo = None               # (polynomial, arrival list, candidate) settled inside the radius while short of columns
+        self._prefer_tail = False       # robust phase: interpolate from the newest arrivals (True) or the oldest
         self._stalled = None            # polynomial the last robust update could not decode (the probe is on it)
         self._checked = None            # (arrival list, first chunk, coefficients, first disagreeing chunk) of a launch the robust phase may reuse
         self.radius_verdicts = 0        # polynomials settled by the batched launch's own candidate (diagnostic)
@@ -541,6 +543,18 @@ class DeviceIncrementalDecoder:
         ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), self.n, ctx.ptr(coeffs.contiguous()), 1, d, ctx.ptr(ev), ctx.stream()), "evaluate")
         return ev
 
+    def _split(self, tail):
+        """degree+1 arrived columns to interpolate from and the rest to compare with: the oldest or the newest arrivals"""
+        d = self.degree + 1
+        return (self._z[-d:], self._z[:-d]) if tail else (self._z[:d], self._z[d:])
+
+    def _candidate_errors(self, coeffs, chunk):
+        t = self.ctx.torch
+        ev = self._disagreeing(coeffs)
+        zt = t.tensor(self._z, dtype=t.int64, device=self.ctx.tdev)
+        differs = (ev.index_select(0, zt) != self._cols[:, chunk, :].index_select(0, zt)).any(dim=1)
+        return [self._z[i] for i in t.nonzero(differs).flatten().tolist()]
+
     def _expel(self, errors):
         es = set(errors)
         self._confirmed_errors |= es
@@ -571,12 +585,24 @@ class DeviceIncrementalDecoder:
                     return
                 self._stalled = None
                 self._expel(errors)
+            memo, self._memo = self._memo, None
+            if memo is not None and memo[0] == lo and self._z[: len(memo[1])] == memo[1]:
+                # the previous call settled this polynomial inside the radius but was short of columns: the same candidate, with
+                # whatever the newer arrivals add to its disagreements, stays Gao's answer while they fit the (larger) radius
+                errors = self._candidate_errors(memo[2], lo)
+                if len(errors) <= (len(self._z) - d) // 2:
+                    if len(self._available_points) - len(errors) < self._min_points_required():
+                        self._memo = (lo, list(self._z), memo[2])
+                        return
+                    self.radius_verdicts += 1
+                    self._expel(errors)
             chk, self._checked = self._checked, None
+            tail_split = self._prefer_tail
             if chk is not None and chk[0] == self._z and chk[1] == lo:
                 dec, first = chk[2], chk[3]
-                agree = False
+                agree, tail_split = False, False
             else:
-                dec, agree, first = self._quick(self._z[:d], self._z[d:], lo=lo)
+                dec, agree, first = self._quick(*self._split(tail_split), lo=lo)
             if agree:
                 if lo == 0:
                     self._partial = dec              # nothing accepted before: the launch's output is the result
@@ -588,13 +614,22 @@ class DeviceIncrementalDecoder:
             if first > lo:
                 self._partial[lo:first] = dec[lo:first]
                 self._num_decoded = first
-            # polynomial `first`: is the candidate the launch produced within the radius?
-            ev = self._disagreeing(dec[first])
-            zt = t.tensor(self._z, dtype=t.int64, device=self.ctx.tdev)
-            differs = (ev.index_select(0, zt) != self._cols[:, first, :].index_select(0, zt)).any(dim=1)
-            errors = [self._z[i] for i in t.nonzero(differs).flatten().tolist()]
-            if len(errors) <= (len(self._z) - d) // 2:
+            # polynomial `first`: is the candidate the launch produced within the radius?  Any degree+1 of the arrived columns
+            # interpolate a candidate; a sender that lies in this chunk may sit among them, so the other end of the arrival
+            # list gets one try too (whichever end worked is tried first from then on).
+            radius = (len(self._z) - d) // 2
+            first_split, dec2 = tail_split, None
+            errors = self._candidate_errors(dec[first], first)
+            if len(errors) > radius and len(self._z) > d:
+                tail_split = not tail_split
+                dec2, _, first2 = self._quick(*self._split(tail_split), lo=first)
+                if first2 == first:
+                    errors = self._candidate_errors(dec2[first], first)
+                # (first2 > first cannot be: some column disagrees with every interpolant of this chunk or the first split would have agreed)
+            if len(errors) <= radius:
+                self._prefer_tail = tail_split
                 if len(self._available_points) - len(errors) < self._min_points_required():
+                    self._memo = (first, list(self._z), (dec2 if tail_split != first_split else dec)[first].clone())
                     return
                 self.radius_verdicts += 1
                 self._expel(errors)
