@@ -25,6 +25,11 @@ import os
 import sys
 import time
 
+# The affinity mask this process was started with, read before anything can load an OpenMP runtime: with OMP_PROC_BIND set,
+# libgomp / libomp pin the initial thread to its place when they are loaded (torch and the oracle both bring one), and from
+# then on sched_getaffinity -- here and in every child process -- reports that one place (round 2 printed "2 CPUs").
+_START_AFFINITY = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else []
+
 # the CPU baseline's OpenMP threads: pinned, one per core (must be set before the OpenMP runtime starts)
 os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
@@ -231,9 +236,8 @@ def ntl_baseline(n, t, sample_b, threads):
 
 
 def host_cpu_facts():
-    """What the host gives this process, read in a FRESH subprocess with no OpenMP variables set -- once an OpenMP runtime has
-    started with OMP_PROC_BIND, the calling thread is pinned to its place and sched_getaffinity only reports that place (round 2
-    printed "2 CPUs" on a 128-core box for this reason)."""
+    """What the host gives this process: the affinity mask it was started with (_START_AFFINITY, read at the top of this file)
+    and, from a child process, the cgroup limits and the NUMA layout."""
     import subprocess
 
     code = ("import os, json\n"
@@ -251,9 +255,13 @@ def host_cpu_facts():
     env = {k: v for k, v in os.environ.items() if not k.startswith(("OMP_", "GOMP_", "KMP_"))}
     try:
         res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=60)
-        return json.loads(res.stdout.strip().splitlines()[-1])
+        facts = json.loads(res.stdout.strip().splitlines()[-1])
     except Exception as e:  # noqa: BLE001 - informational
-        return {"error": f"{type(e).__name__}: {e}"}
+        facts = {"error": f"{type(e).__name__}: {e}"}
+    facts["affinity_cpus_after_openmp_pinning"] = facts.get("affinity_cpus")     # what a child of the pinned thread inherits
+    facts["affinity_cpus"] = len(_START_AFFINITY)
+    facts["affinity_first_last"] = [_START_AFFINITY[0], _START_AFFINITY[-1]] if _START_AFFINITY else None
+    return facts
 
 
 def cpu_baseline(n, t, use_omega, sample_b, seed=7):
@@ -330,7 +338,7 @@ def cpu_baseline(n, t, use_omega, sample_b, seed=7):
                f"cgroup cpu.max = {facts.get('cgroup_cpu_max')!r} (a CPU-time quota below the core count throttles the larger teams), "
                f"cpuset = {facts.get('cgroup_cpuset')!r}, {facts.get('numa_nodes')} NUMA node(s) with every buffer first touched by the calling thread")
     scaling_txt = ("whole-open rate by thread count, threads -> k shares/s: " + ", ".join(f"{k} -> {rates[k] / 1e3:.0f}" for k in sorted(rates)) +
-                   f"; affinity mask of a fresh process = {facts.get('affinity_cpus')} CPUs, {phys} physical cores, "
+                   f"; affinity mask at process start = {facts.get('affinity_cpus')} CPUs, {phys} physical cores, "
                    f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')}" + why)
     ntl = ntl_baseline(n, t, table[cores]["sample_shares"], phys) if not use_omega else "NTL driver covers the Vandermonde open only"
     out = {

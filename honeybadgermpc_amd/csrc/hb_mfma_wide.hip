@@ -100,12 +100,29 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     // of many row tiles and few chunk tiles (86 x 86 over 381 tiles) are cut by rows too, or a workgroup's two units of 6 passes
     // each would take 4 pass-times where 2.2 are the average.
     const int n_quads = (n_rt + rq - 1) / rq;
+    // unit -> (tile group, row group).  The row groups of one tile group read the same tile; block b runs on XCD b % 8 (observed,
+    // a speed assumption only) and units go to blocks round-robin with a stride that is a multiple of 8, so the row groups of a
+    // tile group are given unit numbers that agree mod 8: they run on ONE XCD at about the same time and the tile comes from HBM
+    // once, the other row groups find it in that XCD's L2 (cfg5's shard, 11 row tiles in groups of 4: 103.6 -> 62.7 MB measured
+    // without row groups; profiles/r03_pmc_cfg5-shard_row_groups.txt).  Whole blocks of 8 n_quads units are remapped, the tail keeps
+    // the plain order: a bijection either way.
+    const int64_t n_tg = n_units / n_quads, xg = 8 * (int64_t)n_quads, x_full = (n_tg / 8) * xg;
+    auto unit_tg = [&](int64_t u) -> int64_t {
+        if (n_quads == 1) return u;
+        if (u < x_full) return (u / xg) * 8 + (u % 8);
+        return (n_tg / 8) * 8 + (u - x_full) / n_quads;
+    };
+    auto unit_q = [&](int64_t u) -> int {
+        if (n_quads == 1) return 0;
+        if (u < x_full) return (int)((u % xg) / 8);
+        return (int)((u - x_full) % n_quads);
+    };
     auto issue_loads = [&](int64_t unit, int buf) {
         const int e = (wave >> 1) & 1, h = wave & 1;
         const uint4 *base = reinterpret_cast<const uint4 *>(in_pk) + h;
         const uint4 *zsrc = reinterpret_cast<const uint4 *>(zero_src) + h;
         for (int t = 0; t < tpw; t++) {
-            int64_t chunk = ((unit / n_quads) * tpw + t) * 16 + n;
+            int64_t chunk = (unit_tg(unit) * tpw + t) * 16 + n;
             if (chunk >= n_chunks) chunk = n_chunks - 1;
             const int64_t cbase = chunk * in_sc;
             int64_t ro = rowoff[2 * g + e];
@@ -171,11 +188,12 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     for (; unit < n_units; unit += gridDim.x) {
         const int64_t next = unit + gridDim.x;
         bool dma_issued = false;
-        const int rt_lo = (int)(unit % n_quads) * rq, rt_cnt = n_rt - rt_lo < rq ? n_rt - rt_lo : rq;
+        const int rt_lo = unit_q(unit) * rq, rt_cnt = n_rt - rt_lo < rq ? n_rt - rt_lo : rq;
+        const int64_t tg = unit_tg(unit);
         const int n_pairs = tpw * rt_cnt;
         for (int pidx = wave; pidx < n_pairs; pidx += 4) {
             const int tl = pidx / rt_cnt, rt = rt_lo + pidx - tl * rt_cnt;
-            const int64_t chunk = ((unit / n_quads) * tpw + tl) * 16 + n;
+            const int64_t chunk = (tg * tpw + tl) * 16 + n;
             {
                 uint32_t xa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(xbuf + (size_t)buf * bufsz + (size_t)tl * nkb * 4 * 64 + lane);
                 uint32_t va = (uint32_t)lane * 16u;
@@ -341,7 +359,11 @@ constexpr size_t MM8W_LDS_LIMIT = 156 * 1024;
 bool mm8w_shape(int n_rt, int nkb, int64_t n_tiles, int n_cus, int *tpw, int *nbuf, int *rq) {
     double best_cost = 0.0;
     int best_t = 0, best_rq = 0, best_nbuf = 0;
-    const int rqs[3] = {n_rt, 8, 4};
+    int rqs[3] = {n_rt, 8, 4};
+    // HB_MM8W_RQ=all: no row groups (every unit takes all row tiles of its chunk tiles) -- the traffic experiment of
+    // profiles/r03_pmc_cfg5-shard_row_groups.txt; never set in production
+    static const bool rq_all = [] { const char *e = getenv("HB_MM8W_RQ"); return e && !strcmp(e, "all"); }();
+    if (rq_all) rqs[1] = rqs[2] = n_rt;
     for (int t = 1; t <= 4; t++) {
         if (mm8w_lds_bytes(n_rt, nkb, t, 1) > MM8W_LDS_LIMIT) break;
         const int nb = mm8w_lds_bytes(n_rt, nkb, t, 2) <= MM8W_LDS_LIMIT ? 2 : 1;
