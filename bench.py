@@ -670,17 +670,21 @@ def main():
     ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev3 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
+    # HIP events bracket the roofline kernel only (every record is a packet the GPU processes between two dependent launches):
+    # the R2 launch for plans that decode + validate in one launch, the R1 encode otherwise
+    time_r2 = bool(op.uses_fused_validate()) and not args.no_matrix_cores
+
     def step(i=None):
-        if i is not None:
+        if i is not None and not time_r2:
             ev0[i].record()
         op.r1_encode(shares0, out=r1_out)            # dominant kernel of small-entry plans: the n x d encode
-        if i is not None:
+        if i is not None and not time_r2:
             ev1[i].record()
         op.r1_decode(r1_cols, B, out=r2_msg)
-        if i is not None:
+        if i is not None and time_r2:
             ev2[i].record()
         op.r2_decode(r2_cols, B, out=result)         # dominant kernel of fused plans: decode + validate in one launch
-        if i is not None:
+        if i is not None and time_r2:
             ev3[i].record()
 
     for _ in range(args.warmup):
@@ -826,9 +830,10 @@ def main():
     sec_pad = secrets
     assert torch.equal(r2_msg, r2_cols[:C]), "R2 message != what party 0 would broadcast"
 
-    enc_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
-    r2_ms = sum(a.elapsed_time(b) for a, b in zip(ev2, ev3)) / args.steps
     fused_default = dt_unfused is not None         # the plan decodes + validates in one k_mm8w launch by default
+    assert fused_default == time_r2 or args.no_matrix_cores, "the events bracketed the wrong launch"
+    enc_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps if not time_r2 else None
+    r2_ms = sum(a.elapsed_time(b) for a, b in zip(ev2, ev3)) / args.steps if time_r2 else None
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * args.steps / dt
     alg_bytes_open = 32 * C * (3 * n + 7 * d)
