@@ -617,7 +617,9 @@ def main():
             print(json.dumps({"rendezvous_only": True, "world_size_env": world, "ranks_seen": ranks_seen, "gpus_requested": args.gpus,
                               "self_launched": os.environ.get("HB_BENCH_SELF_LAUNCHED") == "1"}), flush=True)
         return
-    if world > 1:
+    # under a launcher (RANK set) the process group is created even for ONE rank: the N = 1 point of a scaling run then goes through
+    # the same RCCL init / barrier / reduction as N = 2, 4, 8 (plain `python bench.py` stays free of torch.distributed)
+    if world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ):
         import torch.distributed as dist_mod
 
         dist = dist_mod
