@@ -643,9 +643,9 @@ struct hb_probe {
 extern "C" {
 
 int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
-                          const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, uint64_t *coeffs_dev, int32_t *status_dev, void *stream) { HB_API_GUARD(ctx);
-    if (!ctx || !x_host || !z || n < 1 || d < 1 || d > n || nc < 0 || (nc > 0 && !zc) || C < 0 || chunk_lo < 0 || chunk_lo > C) return HB_ERR_BAD_ARG;
-    if (C == chunk_lo) return HB_OK;
+                          const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev, void *stream) { HB_API_GUARD(ctx);
+    if (!ctx || !x_host || !z || n < 1 || d < 1 || d > n || nc < 0 || (nc > 0 && !zc) || C < 0 || chunk_lo < 0 || chunk_hi > C || chunk_lo > chunk_hi) return HB_ERR_BAD_ARG;
+    if (chunk_hi == chunk_lo) return HB_OK;
     if (!cols_dev || (nc > 0 && !status_dev)) return HB_ERR_BAD_ARG;
     if (ctx->n_limbs != 4 || d < 4 || d > QUICK_MAX || nc > QUICK_MAXC || n > 65535) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: shape");
     if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE") || getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: disabled");
@@ -697,9 +697,9 @@ int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int3
     memcpy(rcs.biasmod, sh->biasmod, sizeof rcs.biasmod);
     k_quick_rows<<<(unsigned)((n_out + 63) / 64), 64, 0, s>>>(ctx->pw, mcan, n_out, d, rcs, (uint32_t *)(base + o_crow), tile_rows);
     HB_LAUNCH_CHECK(ctx);
-    // chunks [chunk_lo, C): the views keep the buffer's row stride C, the bases move to chunk_lo
+    // chunks [chunk_lo, chunk_hi): the views keep the buffer's row stride C, the bases move to chunk_lo
     hb_view pm{1, C}, dv{d, 1};
-    const int64_t cnt = C - chunk_lo;
+    const int64_t cnt = chunk_hi - chunk_lo;
     const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
     uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * d * 8 : mcan;       // n_store = 0 below when there is nothing to store
     rc = launch_mm8w_raw(ctx, n_out, d, tile_rows, (const void *)(base + o_a8), (const uint32_t *)(base + o_crow), sh,

@@ -471,7 +471,7 @@ class DeviceIncrementalDecoder:
                 raise AssertionError("2 * t + 1 + c <= n")   # reed_solomon_wb.py:132
 
     # -- plan-free kernels (hb_quick.hip) ----------------------------------------------------------------
-    def _quick(self, z, zc, store=True, lo=0):
+    def _quick(self, z, zc, store=True, lo=0, hi=None):
         """interpolate every polynomial from chunk `lo` on from the arrived rows z, compare with the arrived rows zc, in one launch:
         -> ((C, d, limbs) | None, all agreed?, first disagreeing chunk); raises _Unsupported when the kernel does not take it"""
         ctx, t = self.ctx, self.ctx.torch
@@ -482,7 +482,8 @@ class DeviceIncrementalDecoder:
         za = np.array(z, dtype=np.int32)
         zca = np.array(zc if zc else [0], dtype=np.int32)
         rc = ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(self._xh_all), self.n, np_ptr(za), d, np_ptr(zca), len(zc),
-                                           ctx.ptr(self._cols), self.batch_size, lo, ctx.ptr(out) if store else None, ctx.ptr(self._status), ctx.stream())
+                                           ctx.ptr(self._cols), self.batch_size, lo, self.batch_size if hi is None else hi,
+                                           ctx.ptr(out) if store else None, ctx.ptr(self._status), ctx.stream())
         if rc == HB_ERR_UNSUPPORTED:
             raise _Unsupported()
         ctx.check(rc, "hb_quick_interp_check")
@@ -622,10 +623,8 @@ class DeviceIncrementalDecoder:
             errors = self._candidate_errors(dec[first], first)
             if len(errors) > radius and len(self._z) > d:
                 tail_split = not tail_split
-                dec2, _, first2 = self._quick(*self._split(tail_split), lo=first)
-                if first2 == first:
-                    errors = self._candidate_errors(dec2[first], first)
-                # (first2 > first cannot be: some column disagrees with every interpolant of this chunk or the first split would have agreed)
+                dec2, _, _ = self._quick(*self._split(tail_split), lo=first, hi=first + 1)      # this one polynomial only
+                errors = self._candidate_errors(dec2[first], first)
             if len(errors) <= radius:
                 self._prefer_tail = tail_split
                 if len(self._available_points) - len(errors) < self._min_points_required():

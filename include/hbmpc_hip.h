@@ -121,12 +121,13 @@ int hb_reduce(hb_ctx *ctx, const uint64_t *in_dev, uint64_t *out_dev, int64_t co
  * (reed_solomon.py:305-326) as one launch: cols_dev is the party-major buffer [n][C] (row j = what party j sent), x_host the n
  * party points; coefficients go chunk-major to coeffs_dev ((C, d) elements; NULL: validate only).  On a disagreement
  * status_dev[0] |= 1 and status_dev[1] = min(status_dev[1], first disagreeing chunk - chunk_lo); the caller initialises both (0, INT32_MAX)
- * and reads them after synchronising.  Only the chunks [chunk_lo, C) are read, written and compared (a decoder that has accepted
+ * and reads them after synchronising.  Only the chunks [chunk_lo, chunk_hi) are read, written and compared (a decoder that has accepted
  * its first polynomials goes on from there).  z and zc are disjoint party indices.  Asynchronous.  HB_ERR_UNSUPPORTED outside the
  * full-size matrix-core kernel's range (narrow contexts, p outside [2^254, 0x7f 2^248), d < 4 or > 128, repeated points):
  * callers use an open plan then. */
 int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
-                          const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, uint64_t *coeffs_dev, int32_t *status_dev, void *stream);
+                          const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev,
+                          void *stream);
 
 /* gao_interpolate for ONE codeword, incremental in its points (rsdecode_impl.h:325-363 as GaoRobustDecoder.robust_decode
  * runs it per polynomial, reed_solomon.py:151-186, 334-365): the probe keeps a reduced basis of the interpolation module of

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 INT_MAX = (1 << 31) - 1
 
 
-def _quick(ctx, x, z, zc, cols, c, store=True, lo=0):
+def _quick(ctx, x, z, zc, cols, c, store=True, lo=0, hi=None):
     import torch
 
     from honeybadgermpc_amd._capi import np_ptr
@@ -23,7 +23,7 @@ def _quick(ctx, x, z, zc, cols, c, store=True, lo=0):
     out = ctx.empty(c * d) if store else None
     status = torch.tensor([0, INT_MAX], dtype=torch.int32, device="cuda")
     za, zca = np.array(z, dtype=np.int32), np.array(zc if zc else [0], dtype=np.int32)
-    rc = ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), len(x), np_ptr(za), d, np_ptr(zca), len(zc), ctx.ptr(cols), c, lo,
+    rc = ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), len(x), np_ptr(za), d, np_ptr(zca), len(zc), ctx.ptr(cols), c, lo, c if hi is None else hi,
                                        ctx.ptr(out) if store else None, ctx.ptr(status), ctx.stream())
     ctx.check(rc, "hb_quick_interp_check")
     st = status.cpu().tolist()
@@ -75,6 +75,11 @@ def test_quick_interp_check_vs_oracle(n, t, c, omega):
             out, flag, first = _quick(ctx, x, z, zc, ctx.upload_ints(bad), c, lo=lo)
             assert flag == 1 and first == 7
             assert ctx.download_ints(out[lo * d :]) == [v for row in polys[lo:] for v in row]
+            # a single chunk: [lo + 7, lo + 8) holds the corrupted symbol, [lo + 8, lo + 9) does not; nothing else is written
+            out1, flag, first = _quick(ctx, x, z, zc, ctx.upload_ints(bad), c, lo=lo + 7, hi=lo + 8)
+            assert flag == 1 and first == 0 and ctx.download_ints(out1[(lo + 7) * d : (lo + 8) * d]) == polys[lo + 7]
+            _, flag, _ = _quick(ctx, x, z, zc, ctx.upload_ints(bad), c, lo=lo + 8, hi=lo + 9)
+            assert flag == 0
         # a corrupted DECODED column changes coefficients and must disagree with every compared row of those chunks
         if zc:
             bad = list(flat)
@@ -95,13 +100,13 @@ def test_quick_rejects_what_it_cannot_take():
     import torch
 
     st = torch.tensor([0, INT_MAX], dtype=torch.int32, device="cuda")
-    assert ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, ctx.ptr(cols), 4, 0, None, ctx.ptr(st), ctx.stream()) != HB_OK
+    assert ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, ctx.ptr(cols), 4, 0, 4, None, ctx.ptr(st), ctx.stream()) != HB_OK
     z = np.array([0, 1, 2, 5], dtype=np.int32)                                   # zc overlaps z
-    assert ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, ctx.ptr(cols), 4, 0, None, ctx.ptr(st), ctx.stream()) != HB_OK
+    assert ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(ctx.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, ctx.ptr(cols), 4, 0, 4, None, ctx.ptr(st), ctx.stream()) != HB_OK
     narrow = Context.get((1 << 61) - 1)
     z = np.array([0, 1, 2, 3], dtype=np.int32)
     colsn = narrow.upload_ints([1] * 32)
-    rc = narrow.lib.hb_quick_interp_check(narrow.h, np_ptr(narrow.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, narrow.ptr(colsn), 4, 0, None, narrow.ptr(st), narrow.stream())
+    rc = narrow.lib.hb_quick_interp_check(narrow.h, np_ptr(narrow.host_elems(x)), 8, np_ptr(z), 4, np_ptr(zc), 1, narrow.ptr(colsn), 4, 0, 4, None, narrow.ptr(st), narrow.stream())
     assert rc != HB_OK                                                            # UNSUPPORTED: callers fall back to an open plan
 
 
