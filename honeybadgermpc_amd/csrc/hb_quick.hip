@@ -23,6 +23,8 @@
 //     conversely the locator of a decodable word is exactly the product over its errors), and those roots are the erroneous
 //     senders (reed_solomon.py:174-184).  No division anywhere, of field elements or of polynomials: the updates are fraction-free.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 
 #include "hb_common.hpp"
 
@@ -292,7 +294,7 @@ __global__ void k_quick_rows(const FpParams<9> P, const uint32_t *__restrict__ m
 // ---------------------------------------------------------------------------------------------------------------------
 // the probe: one workgroup, the four polynomials A_0, B_0, A_1, B_1 in LDS
 // ---------------------------------------------------------------------------------------------------------------------
-struct ProbeResult { int32_t ok, n_err, npts, pad; uint8_t err[PROBE_MAXN]; };
+struct ProbeResult { int32_t ok, n_err, npts, seq; uint8_t err[PROBE_MAXN]; };    // seq: written last, the host polls it
 
 template <int NL> __device__ __forceinline__ bool lds_nonzero(const uint32_t *p) {
     uint32_t o = 0;
@@ -305,7 +307,7 @@ template <int NL, int NW>
 __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ pw, int n, int S,
                                                     uint32_t *__restrict__ state, const ProbeIdx ix, int count, int reset,
                                                     const uint32_t *__restrict__ cols, int64_t C, int64_t poly, int k, int decide,
-                                                    ProbeResult *__restrict__ result) {
+                                                    ProbeResult *__restrict__ result, int seq) {
     extern __shared__ uint32_t p_lds[];
     // coef[q][i][NL], q: 0 = A_0, 1 = B_0, 2 = A_1, 3 = B_1; two scratch polynomials for the decision; the reduction buffer
     uint32_t *coef = p_lds;
@@ -313,6 +315,7 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
     uint32_t *red = scr + (size_t)S * NL;                    // [256][NL]
     __shared__ int deg[4], ctl[8], sdeg[2];
     __shared__ uint16_t fedl[PROBE_MAXN];                     // the parties fed so far, in order (persisted with the state)
+    __shared__ uint32_t serr[PROBE_MAXN / 4];                 // the verdict's error bytes, gathered before they cross to the host
     __shared__ uint32_t dl[2][NL], yv[NL];
     const int tid = threadIdx.x;
     const size_t words = (size_t)4 * S * NL;
@@ -509,7 +512,8 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
     // vanishes on every point -- and conversely a decodable word's locator is exactly the product over its errors; checked
     // against the oracle on 15 000 prefixes, 299 beyond the unique-decoding radius: tests/test_probe_rule.py).  Four threads
     // per point, each a quarter of the coefficients; the senders in error are those roots (reed_solomon.py:174-184).
-    for (int a = tid; a < n; a += 256) result->err[a] = 0;
+    if (tid < PROBE_MAXN / 4) serr[tid] = 0;
+    __syncthreads();
     const int db = fine ? sdeg[1] : -1;
     if (fine) {
         for (int base = 0; base < npts; base += 64) {
@@ -540,7 +544,7 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
                     fp_add(u, u, v, P);
                 }
                 if (fp_is_zero(u) && db >= 1) {            // a constant locator names nobody
-                    result->err[a] = 1;
+                    atomicOr(&serr[a >> 2], 1u << (8 * (a & 3)));
                     atomicAdd(&ctl[0], 1);
                 }
             }
@@ -548,9 +552,14 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
         }
         if (db < 0 || ctl[0] != (db >= 1 ? db : 0)) fine = false;
     }
-    if (tid == 0) { result->ok = fine ? 1 : 0; result->npts = npts; }
     __syncthreads();
-    if (tid == 0) { result->n_err = fine ? ctl[0] : 0; __threadfence_system(); }
+    // one wave hands the verdict over: its stores, a system-scope fence, then the sequence number the host is polling
+    if (tid < 64) {
+        reinterpret_cast<uint32_t *>(result->err)[tid] = fine ? serr[tid] : 0u;
+        if (tid == 0) { result->ok = fine ? 1 : 0; result->npts = npts; result->n_err = fine ? ctl[0] : 0; }
+        __threadfence_system();
+        if (tid == 0) *reinterpret_cast<volatile int32_t *>(&result->seq) = seq;
+    }
 }
 
 struct PointTable {
@@ -638,6 +647,7 @@ struct hb_probe {
     ProbeResult *res_dev;
     std::vector<int32_t> fed;
     int64_t poly;
+    int seq;                      // launches so far: the kernel echoes it into res_host->seq when its verdict is complete
 };
 
 extern "C" {
@@ -721,7 +731,7 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
     if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: repeated points");
     hb_probe *pr = new hb_probe();
-    pr->ctx = ctx; pr->n = n; pr->k = k; pr->pt = pt; pr->poly = -1;
+    pr->ctx = ctx; pr->n = n; pr->k = k; pr->pt = pt; pr->poly = -1; pr->seq = 0;
     pr->state_bytes = ((size_t)4 * pt->S * ctx->nl() + 8 + PROBE_MAXN) * 4;
     const size_t pool_bytes = ((size_t)4 * (PROBE_MAXN + 2) * 9 + 8 + PROBE_MAXN) * 4;     // pooled states are all of the largest size
     pr->state = nullptr; pr->res_host = nullptr; pr->res_dev = nullptr;
@@ -734,6 +744,7 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     if (hipHostGetDevicePointer((void **)&pr->res_dev, pr->res_host, 0) != hipSuccess) {
         ctx->probe_pool.push_back(pr->state); ctx->probe_host_pool.push_back(pr->res_host); delete pr; return fail(ctx, HB_ERR_HIP, "probe: device pointer");
     }
+    pr->res_host->seq = 0;                 // a pooled buffer keeps its last owner's number
     *out = pr;
     return HB_OK;
 }
@@ -761,19 +772,34 @@ int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *c
     pr->poly = poly;
     if (count == 0 && reset) return fail(ctx, HB_ERR_BAD_ARG, "probe: nothing fed yet");
     const int S = pr->pt->S, NLr = ctx->nl();
+    const int seq = ++pr->seq;
     const size_t lds = ((size_t)5 * S * NLr + (size_t)256 * NLr) * 4;
 #define PROBE_LAUNCH(NLV, NWV, PARAMS)                                                                                                     \
     do {                                                                                                                                   \
         static bool attr_done = false;                                                                                                     \
         if (!attr_done) { HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_feed<NLV, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_done = true; } \
         k_probe_feed<NLV, NWV><<<1, 256, lds, s>>>(PARAMS, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,        \
-                                                   (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev);            \
+                                                   (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq);       \
     } while (0)
     if (ctx->n_limbs == 4) PROBE_LAUNCH(9, 8, ctx->pw); else PROBE_LAUNCH(3, 2, ctx->pn);
 #undef PROBE_LAUNCH
     HB_LAUNCH_CHECK(ctx);
     if (!decide) return HB_OK;
-    HB_HIP(ctx, hipStreamSynchronize(s));
+    {
+        // the kernel writes its verdict into pinned host memory and the sequence number last: polling that word sees it a few
+        // microseconds after the last store instead of a stream synchronisation's wake-up later; past 2 ms, synchronise
+        volatile int32_t *flag = &pr->res_host->seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        int spins = 0;
+        while (*flag != seq) {
+            if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                HB_HIP(ctx, hipStreamSynchronize(s));
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*flag != seq) return fail(ctx, HB_ERR_HIP, "probe: the kernel finished without a verdict");
+    }
     *ok = pr->res_host->ok;
     memcpy(err_mask, pr->res_host->err, (size_t)pr->n);
     if (!*ok) memset(err_mask, 0, (size_t)pr->n);
