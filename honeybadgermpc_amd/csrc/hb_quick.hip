@@ -333,10 +333,26 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
     }
     __syncthreads();
     const int q = tid >> 6, lane = tid & 63;
+    // the operands of a point that come from HBM / L2 (its power row, its x, the received symbol) are requested one point ahead:
+    // a microsecond or two of latency per point would otherwise sit in front of every evaluation
+    uint32_t xp_pre[NL], xa_pre[NL], y_pre[NW];
+    auto prefetch = [&](int pt) {
+        const int a = ix.idx[pt];
+        ldg<NL>(xp_pre, pw + ((size_t)a * S + (lane < S ? lane : S - 1)) * NL);      // inside the row also for short rows
+        ldg<NL>(xa_pre, xm + (size_t)a * NL);
+        if (tid == 0) load_words<NW>(y_pre, cols + ((size_t)a * (size_t)C + (size_t)poly) * NW);
+    };
+    if (count > 0) prefetch(0);
     for (int pt = 0; pt < count; pt++) {
         const int a = ix.idx[pt];
         const uint32_t *pwr = pw + (size_t)a * S * NL;
-        // partial sums of the four evaluations at x_a
+        uint32_t xp0[NL], xa[NL], yw[NW];
+        fp_set(xp0, xp_pre);
+        fp_set(xa, xa_pre);
+#pragma unroll
+        for (int i = 0; i < NW; i++) yw[i] = y_pre[i];
+        if (pt + 1 < count) prefetch(pt + 1);
+        // partial sums of the four evaluations at x_a: wave q owns polynomial q, a lane its coefficients lane, lane + 64, ...
         {
             uint32_t acc[NL];
 #pragma unroll
@@ -345,7 +361,7 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
             for (int i = lane; i <= dq; i += 64) {
                 uint32_t c[NL], xp[NL], m[NL];
                 ldg<NL>(c, coef + ((size_t)q * S + i) * NL);
-                ldg<NL>(xp, pwr + (size_t)i * NL);
+                if (i == lane) fp_set(xp, xp0); else ldg<NL>(xp, pwr + (size_t)i * NL);
                 mont_mul(m, c, xp, P);
                 fp_add(acc, acc, m, P);
             }
@@ -353,13 +369,15 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
         }
         if (tid == 0) {
             uint32_t yd[NL], ym[NL];
-            load_digits<NL, NW>(yd, cols + ((size_t)a * (size_t)C + (size_t)poly) * NW);
+            unpack<NL, NW>(yd, yw);
             // whatever words the sender packed: their residue (the reference reduces at its boundary)
             to_mont(ym, yd, P);
             stg<NL>(yv, ym);
         }
-        __syncthreads();
+        // the 64 partial sums of a polynomial live in ONE wave: reduced with wave-level synchronisation only
         for (int s = 32; s >= 1; s >>= 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             if (lane < s) {
                 uint32_t u[NL], v[NL];
                 ldg<NL>(u, red + (size_t)tid * NL);
@@ -367,8 +385,8 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
                 fp_add(u, u, v, P);
                 stg<NL>(red + (size_t)tid * NL, u);
             }
-            __syncthreads();
         }
+        __syncthreads();
         if (tid < 2) {
             // discrepancy of Q_tid at the new point
             uint32_t sa[NL], sb[NL], y[NL], m[NL], dd[NL];
@@ -419,8 +437,6 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
             __syncthreads();
             // Q_js <- (X - x_a) Q_js: values first, the barrier, then the stores
             {
-                uint32_t xa[NL];
-                ldg<NL>(xa, xm + (size_t)a * NL);
                 uint32_t keep[3][NL];     // 2 (n + 3) values over 256 threads: at most three each
                 int cnt = 0;
                 for (int e = tid; e < 2 * (top + 1); e += 256, cnt++) {
@@ -444,13 +460,31 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
                 }
             }
             __syncthreads();
-            if (tid < 4) deg[tid] = -1;
-            __syncthreads();
-            for (int e = tid; e < 4 * (top + 1); e += 256) {
-                const int part = e / (top + 1), i = e - part * (top + 1);
-                if (lds_nonzero<NL>(coef + ((size_t)part * S + i) * NL)) atomicMax(&deg[part], i);
+            // new degrees: the pivot's parts grow by one, the other pair's parts become the larger of the two; a scan only when a
+            // leading coefficient cancelled (an event of probability ~1/p for random data, but exactness does not gamble)
+            if (tid == 0) {
+                int nd[4], rescan = 0;
+                for (int part = 0; part < 2; part++) {
+                    const int djs = deg[2 * js + part], djo = deg[2 * jo + part];
+                    nd[2 * js + part] = djs >= 0 ? djs + 1 : -1;
+                    nd[2 * jo + part] = ctl[jo] ? (djs > djo ? djs : djo) : djo;
+                }
+                for (int x = 0; x < 4; x++) {
+                    if (nd[x] >= 0 && !lds_nonzero<NL>(coef + ((size_t)x * S + nd[x]) * NL)) rescan = 1;
+                    deg[x] = nd[x];
+                }
+                ctl[3] = rescan;
             }
             __syncthreads();
+            if (ctl[3]) {
+                if (tid < 4) deg[tid] = -1;
+                __syncthreads();
+                for (int e = tid; e < 4 * (top + 1); e += 256) {
+                    const int part = e / (top + 1), i = e - part * (top + 1);
+                    if (lds_nonzero<NL>(coef + ((size_t)part * S + i) * NL)) atomicMax(&deg[part], i);
+                }
+                __syncthreads();
+            }
         }
     }
     // persistent state back (the decision below works on copies)
