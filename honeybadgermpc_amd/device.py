@@ -376,6 +376,7 @@ class DeviceIncrementalDecoder:
         self._fast = ctx.n_limbs == 4 and (self.degree + 1) >= 4 and not os.environ.get("HB_NO_QUICK")   # cleared at the first UNSUPPORTED
         self._status = None             # (2,) int32 on the device: disagreement flag, first disagreeing chunk
         self._probe_obj = None
+        self._settled = None            # polynomial whose verdict is in (its errors expelled) but which is not accepted yet
         self._memo = None               # (polynomial, arrival list, candidate) settled inside the radius while short of columns
         self._prefer_tail = False       # robust phase: interpolate from the newest arrivals (True) or the oldest
         self._stalled = None            # polynomial the last robust update could not decode (the probe is on it)
@@ -563,7 +564,7 @@ class DeviceIncrementalDecoder:
         self._z = [i for i in self._z if i not in es]
 
     def _fast_robust_update(self):
-        """reference :334-365 with the Gao decoder, plan-free (see the class docstring).
+        """reference :334-365, plan-free (see the class docstring); robust decoder Gao or Welch-Berlekamp.
 
         One launch interpolates every open polynomial from degree+1 of the arrived columns and compares with the rest.  Everything
         before the first disagreeing chunk m is accepted (each of those polynomials robust-decodes to exactly that, with no error).
@@ -576,16 +577,32 @@ class DeviceIncrementalDecoder:
         d = self.degree + 1
         while self._num_decoded < self.batch_size:
             lo = self._num_decoded
+            # The reference's Welch-Berlekamp decoder refuses before it looks at the data when fewer than 2 degree + 1 columns are
+            # left (reed_solomon_wb.py:132).  Polynomial lo may already have its verdict (errors expelled, not accepted yet): it
+            # was decoded over the longer list; every polynomial after it meets the refusal.
+            wb_short = self.robust == "wb" and len(self._z) < 2 * self.degree + 1
+            settled = self._settled == lo
+            if wb_short and (not settled or lo + 1 < self.batch_size):
+                raise AssertionError("2 * t + 1 + c <= n")
             if self._stalled == lo:
-                pr = self._borrow_probe()
-                self.probes += 1
-                errors = pr.decide(self._z, self._cols, self.batch_size, lo)
-                if errors is None:
-                    return                                   # (None, None): more columns needed
+                if self.robust == "gao":
+                    pr = self._borrow_probe()
+                    self.probes += 1
+                    errors = pr.decide(self._z, self._cols, self.batch_size, lo)
+                    if errors is None:
+                        return                               # (None, None): more columns needed
+                else:
+                    # Welch-Berlekamp beyond the unique-decoding radius answers in its own way (or raises): always the real decode
+                    ok, _, errs = self._robust_batch(1)
+                    if not bool(ok[0].item()):
+                        self._undecodable(0)                 # raises what the reference re-raises
+                        return
+                    errors = t.nonzero(errs[0]).flatten().tolist()
                 if len(self._available_points) - len(errors) < self._min_points_required():
                     return
                 self._stalled = None
                 self._expel(errors)
+                self._settled = lo
             memo, self._memo = self._memo, None
             if memo is not None and memo[0] == lo and self._z[: len(memo[1])] == memo[1]:
                 # the previous call settled this polynomial inside the radius but was short of columns: the same candidate, with
@@ -597,6 +614,7 @@ class DeviceIncrementalDecoder:
                         return
                     self.radius_verdicts += 1
                     self._expel(errors)
+                    self._settled = lo
             chk, self._checked = self._checked, None
             tail_split = self._prefer_tail
             if chk is not None and chk[0] == self._z and chk[1] == lo:
@@ -632,6 +650,7 @@ class DeviceIncrementalDecoder:
                     return
                 self.radius_verdicts += 1
                 self._expel(errors)
+                self._settled = first
                 continue
             self._stalled = first                        # only the probe can say when it becomes decodable
         if self._num_decoded == self.batch_size:
@@ -780,10 +799,7 @@ class DeviceIncrementalDecoder:
             if not enough or self._fast_optimistic():
                 return
         if enough:
-            if self.robust == "gao":
-                self._fast_robust_update()
-            else:
-                self._robust_update()
+            self._fast_robust_update()
 
     def _catch_up_optimistic(self):
         """the plan-based optimistic path for a decoder that skipped it while the plan-free path looked available: guess from the

@@ -243,6 +243,54 @@ def test_device_incremental_decoder_trajectory(n, t, c, seed, robust, use_omega)
     assert robust_launches > 0          # the seeds above all reach the robust path at least once
 
 
+@pytest.mark.parametrize("robust, liar_count", [("wb", 1), ("wb", 2), ("wb", 5)])
+@pytest.mark.parametrize("pattern", ["late-distinct", "everywhere"])
+def test_device_decoder_adversaries_welch_berlekamp(robust, liar_count, pattern):
+    """the same adversaries with the Welch-Berlekamp robust decoder (n = 16, t = 5): the plan-free path settles what lies inside the
+    unique-decoding radius from its batched candidates and hands everything else to hb_wb_decode; the reference's refusals
+    ("No solution", the 2t + 1 + c <= n assertion once expelled senders shrank the list) must come at the same column"""
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+    from honeybadgermpc_amd.reed_solomon import Algorithm, DecoderFactory, EncoderFactory, IncrementalDecoder, RobustDecoderFactory
+
+    n, t, c = 16, 5, 30
+    rnd = random.Random(liar_count * 17 + len(pattern))
+    ctx = Context.get(P)
+    point = EvalPoint(GF(P), n)
+    xs = [point(i).value for i in range(n)]
+    polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+    cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+    liars = rnd.sample(range(n), liar_count)
+    for r, i in enumerate(liars):
+        for j in (range(c) if pattern == "everywhere" else [1 + (r * 7) % (c - 1)]):
+            cols[i][j] = (cols[i][j] + 1 + rnd.randrange(P - 1)) % P
+    honest = [i for i in range(n) if i not in liars]
+    rnd.shuffle(honest)
+    order = liars + honest
+    host = IncrementalDecoder(EncoderFactory.get(point, Algorithm.VANDERMONDE), DecoderFactory.get(point, Algorithm.VANDERMONDE),
+                              RobustDecoderFactory.get(t, point, algorithm=Algorithm.WELCH_BERLEKAMP), degree=t, batch_size=c, max_errors=t)
+    dev = DeviceIncrementalDecoder(P, n, t, batch_size=c, robust=robust)
+    for step, idx in enumerate(order):
+        try:
+            host.add(idx, cols[idx])
+        except (AssertionError, Exception) as exc:  # noqa: B014 - the reference re-raises bare Exceptions
+            with pytest.raises(type(exc)):
+                dev.add(idx, ctx.upload_ints(cols[idx]))
+            return
+        dev.add(idx, ctx.upload_ints(cols[idx]))
+        assert dev.done() == host.done(), step
+        assert dev._confirmed_errors == host._confirmed_errors and dev._z == host._z and dev._num_decoded == host._num_decoded, step
+        if host.done():
+            break
+    assert host.done() and dev.done()
+    hres, herr = host.get_results()
+    dres, derr = dev.get_results()
+    assert derr == herr and ctx.download_ints(dres.reshape(-1, 4)) == [v for row in hres for v in row] == [v for row in polys for v in row]
+    assert dev.quick_launches > 0
+
+
 @pytest.mark.parametrize("n, t, c, pattern", [(31, 10, 120, "late-distinct"), (31, 10, 120, "late-same"), (64, 21, 96, "late-distinct"), (64, 21, 64, "everywhere"),
                                               (16, 5, 300, "late-distinct")])
 def test_device_decoder_worst_case_adversaries(n, t, c, pattern):
