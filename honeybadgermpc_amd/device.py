@@ -557,6 +557,12 @@ class DeviceIncrementalDecoder:
         differs = (ev.index_select(0, zt) != self._cols[:, chunk, :].index_select(0, zt)).any(dim=1)
         return [self._z[i] for i in t.nonzero(differs).flatten().tolist()]
 
+    def _wb_refusal(self, lo):
+        """Welch-Berlekamp only: raise what the reference's decoder raises when it is asked to decode over fewer than
+        2 degree + 1 columns.  Polynomial lo is exempt while its verdict is in (`_settled`): it was decoded over the longer list."""
+        if self.robust == "wb" and len(self._z) < 2 * self.degree + 1 and (self._settled != lo or lo + 1 < self.batch_size):
+            raise AssertionError("2 * t + 1 + c <= n")
+
     def _expel(self, errors):
         es = set(errors)
         self._confirmed_errors |= es
@@ -580,10 +586,7 @@ class DeviceIncrementalDecoder:
             # The reference's Welch-Berlekamp decoder refuses before it looks at the data when fewer than 2 degree + 1 columns are
             # left (reed_solomon_wb.py:132).  Polynomial lo may already have its verdict (errors expelled, not accepted yet): it
             # was decoded over the longer list; every polynomial after it meets the refusal.
-            wb_short = self.robust == "wb" and len(self._z) < 2 * self.degree + 1
-            settled = self._settled == lo
-            if wb_short and (not settled or lo + 1 < self.batch_size):
-                raise AssertionError("2 * t + 1 + c <= n")
+            self._wb_refusal(lo)
             if self._stalled == lo:
                 if self.robust == "gao":
                     pr = self._borrow_probe()
@@ -615,6 +618,7 @@ class DeviceIncrementalDecoder:
                     self.radius_verdicts += 1
                     self._expel(errors)
                     self._settled = lo
+            self._wb_refusal(lo)                             # the list may just have shrunk (expulsions above)
             chk, self._checked = self._checked, None
             tail_split = self._prefer_tail
             if chk is not None and chk[0] == self._z and chk[1] == lo:

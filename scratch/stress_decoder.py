@@ -1,0 +1,74 @@
+"""Randomised differential run of the device decoder's plan-free robust path against the host mirror of the reference's IncrementalDecoder:
+random shapes, liar counts, corruption patterns (everywhere / one chunk / a few chunks / last chunk), arrival orders; after EVERY column the
+two must agree on done / confirmed errors / arrival list / polynomials decoded, raise the same exception at the same column (Welch-Berlekamp),
+and return the shared polynomials.   usage: python scratch/stress_decoder.py [seconds] [seed]"""
+import random, sys, time
+sys.path.insert(0, '.')
+from honeybadgermpc_amd._capi import Context
+from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+from honeybadgermpc_amd.field import GF
+from honeybadgermpc_amd.polynomial import EvalPoint
+from honeybadgermpc_amd.reed_solomon import Algorithm, DecoderFactory, EncoderFactory, IncrementalDecoder, RobustDecoderFactory
+P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rnd = random.Random(seed)
+ctx = Context.get(P)
+t_end = time.time() + budget
+runs = fails = raised = robust_runs = 0
+while time.time() < t_end:
+    n = rnd.choice([7, 10, 13, 16, 22, 31])
+    t = rnd.randrange(3, (n - 1) // 3 + 1) if (n - 1) // 3 >= 3 else (n - 1) // 3
+    if t < 3:
+        continue
+    c = rnd.choice([1, 2, 5, 17, 40])
+    use_omega = rnd.random() < 0.3
+    robust = rnd.choice(["gao", "gao", "wb"])
+    point = EvalPoint(GF(P), n, use_omega_powers=use_omega)
+    xs = [point(i).value for i in range(n)]
+    polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+    cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+    liars = rnd.sample(range(n), rnd.randrange(0, t + 2))          # sometimes one liar too many
+    for i in liars:
+        kind = rnd.randrange(4)
+        hit = {0: range(c), 1: [c - 1], 2: [rnd.randrange(c)], 3: rnd.sample(range(c), max(1, c // 3))}[kind]
+        for j in hit:
+            cols[i][j] = (cols[i][j] + 1 + rnd.randrange(P - 1)) % P
+    order = list(range(n))
+    rnd.shuffle(order)
+    if rnd.random() < 0.5:
+        order = liars + [i for i in order if i not in liars]
+    codec = Algorithm.FFT if use_omega else Algorithm.VANDERMONDE
+    host = IncrementalDecoder(EncoderFactory.get(point, codec), DecoderFactory.get(point, codec),
+                              RobustDecoderFactory.get(t, point, algorithm=Algorithm.GAO if robust == "gao" else Algorithm.WELCH_BERLEKAMP),
+                              degree=t, batch_size=c, max_errors=t)
+    dev = DeviceIncrementalDecoder(P, n, t, batch_size=c, robust=robust, use_omega_powers=use_omega)
+    bad = None
+    for step, idx in enumerate(order):
+        hexc = dexc = None
+        try:
+            host.add(idx, cols[idx])
+        except BaseException as e:  # noqa: BLE001
+            hexc = e
+        try:
+            dev.add(idx, ctx.upload_ints(cols[idx]))
+        except BaseException as e:  # noqa: BLE001
+            dexc = e
+        if (hexc is None) != (dexc is None) or (hexc is not None and type(hexc) is not type(dexc)):
+            bad = ("exception", step, repr(hexc), repr(dexc)); break
+        if hexc is not None:
+            raised += 1; break
+        if dev.done() != host.done() or dev._confirmed_errors != host._confirmed_errors or dev._z != host._z or dev._num_decoded != host._num_decoded:
+            bad = ("state", step, host.done(), dev.done(), sorted(host._confirmed_errors), sorted(dev._confirmed_errors), host._num_decoded, dev._num_decoded); break
+        if host.done():
+            hres, _ = host.get_results()
+            dres, _ = dev.get_results()
+            if ctx.download_ints(dres.reshape(-1, 4)) != [v for row in hres for v in row]:
+                bad = ("result", step)
+            break
+    robust_runs += dev.probes + dev.radius_verdicts + dev.launches > 0
+    if bad:
+        fails += 1
+        print("FAIL", n, t, c, use_omega, robust, "liars", liars, "order", order, bad, flush=True)
+    runs += 1
+print(f"stress_decoder: {runs} decodes ({robust_runs} reached the robust phase, {raised} ended in the reference's own exception), {fails} failures (seed {seed}, {budget:.0f} s)")

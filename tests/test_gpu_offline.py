@@ -345,6 +345,72 @@ def test_device_decoder_worst_case_adversaries(n, t, c, pattern):
         assert dev.probes + dev.radius_verdicts >= (t if pattern == "everywhere" else len({1 + (r * 7) % (c - 1) for r in range(t)}))
 
 
+def test_device_decoder_randomised_vs_host_mirror():
+    """~20 s, seeded: the bounded twin of scratch/stress_decoder.py (which found a missed Welch-Berlekamp refusal in the first
+    version of the plan-free path: 94 divergences in 36 444 decodes, all of that one kind; 0 in 22 898 after the fix).  Random
+    shapes / liar counts (up to one too many) / corruption patterns / arrival orders, both robust decoders, both point
+    policies; after every column: same done / confirmed errors / arrival list / polynomials decoded, same exception type."""
+    import time
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+    from honeybadgermpc_amd.reed_solomon import Algorithm, DecoderFactory, EncoderFactory, IncrementalDecoder, RobustDecoderFactory
+
+    rnd = random.Random(20260929)
+    ctx = Context.get(P)
+    t_end = time.time() + 20.0
+    runs = robust_runs = raised = 0
+    while time.time() < t_end or runs < 200:
+        n = rnd.choice([10, 13, 16, 22, 31])
+        t = rnd.randrange(3, (n - 1) // 3 + 1)
+        c = rnd.choice([1, 2, 5, 17, 40])
+        use_omega = rnd.random() < 0.3
+        robust = rnd.choice(["gao", "gao", "wb"])
+        point = EvalPoint(GF(P), n, use_omega_powers=use_omega)
+        xs = [point(i).value for i in range(n)]
+        polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+        cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
+        liars = rnd.sample(range(n), rnd.randrange(0, t + 2))
+        for i in liars:
+            hit = {0: range(c), 1: [c - 1], 2: [rnd.randrange(c)], 3: rnd.sample(range(c), max(1, c // 3))}[rnd.randrange(4)]
+            for j in hit:
+                cols[i][j] = (cols[i][j] + 1 + rnd.randrange(P - 1)) % P
+        order = list(range(n))
+        rnd.shuffle(order)
+        if rnd.random() < 0.5:
+            order = liars + [i for i in order if i not in liars]
+        codec = Algorithm.FFT if use_omega else Algorithm.VANDERMONDE
+        host = IncrementalDecoder(EncoderFactory.get(point, codec), DecoderFactory.get(point, codec),
+                                  RobustDecoderFactory.get(t, point, algorithm=Algorithm.GAO if robust == "gao" else Algorithm.WELCH_BERLEKAMP),
+                                  degree=t, batch_size=c, max_errors=t)
+        dev = DeviceIncrementalDecoder(P, n, t, batch_size=c, robust=robust, use_omega_powers=use_omega)
+        what = (n, t, c, use_omega, robust, liars, order)
+        for step, idx in enumerate(order):
+            hexc = dexc = None
+            try:
+                host.add(idx, cols[idx])
+            except BaseException as e:  # noqa: BLE001 - the reference re-raises bare Exceptions and assertion failures
+                hexc = e
+            try:
+                dev.add(idx, ctx.upload_ints(cols[idx]))
+            except BaseException as e:  # noqa: BLE001
+                dexc = e
+            assert type(hexc) is type(dexc), (what, step, repr(hexc), repr(dexc))
+            if hexc is not None:
+                raised += 1
+                break
+            assert dev.done() == host.done() and dev._confirmed_errors == host._confirmed_errors, (what, step)
+            assert dev._z == host._z and dev._num_decoded == host._num_decoded, (what, step)
+            if host.done():
+                assert ctx.download_ints(dev.get_results()[0].reshape(-1, 4)) == [v for row in host.get_results()[0] for v in row], what
+                break
+        robust_runs += dev.probes + dev.radius_verdicts + dev.launches > 0
+        runs += 1
+    assert runs >= 200 and robust_runs >= 50 and raised >= 5, (runs, robust_runs, raised)
+
+
 def test_device_incremental_decoder_reference_transcripts(golden):
     """The transcripts tests/golden/incremental_decoder.json recorded from the reference's own IncrementalDecoder
     (done / result / confirmed errors after every add), replayed on the device decoder with the transcript's robust
