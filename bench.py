@@ -887,7 +887,7 @@ def main():
                 "copy_GBps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
                 "second": valu_roofline(args.workload if mfma else args.workload + "_valu", enc_ms),
                 "note": ("instruction-issue bound: one wave per SIMD (all 63 int32 columns of a 16 x 16 pass live in AGPRs) issues an instruction every "
-                         "~5.5 cycles, ~3000 per pass at d = 22 of which 564 are MFMAs (9.0 k of 16.2 k cycles of matrix-pipe time); "
+                         "~5.3 cycles, ~2800 per pass at d = 22 of which 468 are MFMAs (7.5 k of 14.8 k cycles of matrix-pipe time; DESIGN.md section 11 prices what is left in it); "
                          "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md section 4c") if fused_default else
                         ("neither HBM nor the matrix pipe binds: per 16x16 tile 47 int32 columns x (d/4) MFMAs are followed by a 390-bit "
                          "reduction + Barrett per output on the VALU (~1550 VALU ops per wave pass, VALU ~67% busy, matrix pipe ~41% busy by PMC); "
