@@ -39,7 +39,7 @@ def main(src):
         ntt = avg(t, "k_ntt_lds<9, 8, false, true>", None)
         fused = sorted(r[3] for r in t if r[0].startswith("hb::k_mm8w<true"))
         put(f"r03_bench_{w}_kernel_stats.txt", [
-            f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload {w} --steps 20 --warmup 3 --cpu-sample 0 --no-two-streams-extra  (MI355X, round 3; collected BEFORE the XCD-aware unit numbering of k_mm8w,",
+            f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload {w} --steps 20 --warmup 3 --cpu-sample 0 --no-two-streams-extra  (MI355X, round 3, final state: with the XCD-aware unit numbering of k_mm8w,",
             "# which took cfg5-shard's R2 launch from 114.4 to 110.4 us: r03_pmc_cfg5-shard_row_groups.txt)",
             f"# {shape}: k_ntt_lds<..,false,..> R1 encode ({ntt:.1f} us) + two hb::k_mm8w<true,..> launches (R1 / R2 decode + validate fused: {fused[0]:.1f} / {fused[-1]:.1f} us)"
             f" = {ntt + fused[0] + fused[-1]:.0f} us of kernels in a {jw['ms_per_step'] * 1e3:.0f} us step ({jw['value'] / 1e9:.2f} G shares/s; fusion off {jw['detail']['shares_per_s_per_gpu_three_full_encodes'] / 1e9:.2f} G)."],
@@ -55,7 +55,7 @@ def main(src):
         f"{tr['valu_wave_instr_per_launch'] / 1e6:.2f} M wave-instructions, {tr['mfma_per_launch'] / 1e6:.2f} M MFMAs, matrix pipe busy {tr['mfma_busy_frac']:.2f}, VALU busy {tr['valu_busy_frac']:.2f} of the kernel's cycles."],
         open(os.path.join(src, "pmc_summary_cfg3.txt")).read())
     put("r03_pmc_cfg3-omega.txt", ["# same passes for --workload cfg3-omega (round 3)."], open(os.path.join(src, "pmc_summary_cfg3-omega.txt")).read())
-    put("r03_pmc_cfg5-shard.txt", ["# same passes for --workload cfg5-shard (round 3, BEFORE the XCD-aware unit numbering: the R2 launch's 103.5 MB are explained and fixed in r03_pmc_cfg5-shard_row_groups.txt -> 62.4 MB)."],
+    put("r03_pmc_cfg5-shard.txt", ["# same passes for --workload cfg5-shard (round 3, final state: the R2 launch (65536 threads) moves 62 MB = 1.24 x algorithmic; before the XCD-aware unit numbering 103.5 MB, r03_pmc_cfg5-shard_row_groups.txt)."],
         open(os.path.join(src, "pmc_summary_cfg5-shard.txt")).read())
     put("r03_config4_robust_decoders.txt", [
         "# scratch/bench_robust.py 262144 (config 4: n=100, t=33, 33 errors per codeword) and FETCH/WRITE passes at 16384 codewords (round 3: kernels unchanged; hb_wb_decode now hands the row reduction",
