@@ -600,15 +600,24 @@ struct PointTable {
     int n, S;
     uint32_t *xm, *inv, *pw;
     bool usable;
+    int refs;             // the cache's reference + one per probe that works on this table
 };
 
-// per (context, point set); pinned in the context (a handful per modulus)
+static void point_table_unref(PointTable *pt) {
+    if (!pt || --pt->refs > 0) return;
+    (void)hipFree(pt->xm); (void)hipFree(pt->inv); (void)hipFree(pt->pw);
+    delete pt;
+}
+
+// per (context, point set): an entry of the context's LRU like every other table (n^2 elements: 2.4 MB at n = 256), so a caller that
+// keeps inventing point sets cannot grow it without bound; a probe holds its own reference (cache_trim synchronises the device
+// before it drops anything, and only the outermost entry point trims)
 static int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hipStream_t s) {
     std::string key = table_key("PT", ctx, x_host, n, 0);
     auto it = ctx->ptcache.find(key);
-    if (it != ctx->ptcache.end()) { *out = static_cast<PointTable *>(it->second); return HB_OK; }
+    if (it != ctx->ptcache.end()) { cache_touch(ctx, "pt|" + key); *out = static_cast<PointTable *>(it->second); return HB_OK; }
     PointTable *pt = new PointTable();
-    pt->n = n; pt->S = n + 2; pt->xm = pt->inv = pt->pw = nullptr; pt->usable = false;
+    pt->n = n; pt->S = n + 2; pt->xm = pt->inv = pt->pw = nullptr; pt->usable = false; pt->refs = 1;
     const int NLr = ctx->nl();
     uint32_t *xd = nullptr;
     int32_t *bad = nullptr;
@@ -647,16 +656,16 @@ static int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **
     }
     pt->usable = badh == 0;                       // repeated points: interpolation over them is singular (callers fall back and report it)
     ctx->ptcache[key] = pt;
+    cache_note(ctx, "pt|" + key, [ctx, key]() {
+        auto f = ctx->ptcache.find(key);
+        if (f != ctx->ptcache.end()) { PointTable *q = static_cast<PointTable *>(f->second); ctx->ptcache.erase(f); point_table_unref(q); }
+    });
     *out = pt;
     return HB_OK;
 }
 
 void point_tables_free(hb_ctx *ctx) {
-    for (auto &kv : ctx->ptcache) {
-        PointTable *pt = static_cast<PointTable *>(kv.second);
-        (void)hipFree(pt->xm); (void)hipFree(pt->inv); (void)hipFree(pt->pw);
-        delete pt;
-    }
+    for (auto &kv : ctx->ptcache) point_table_unref(static_cast<PointTable *>(kv.second));
     ctx->ptcache.clear();
     for (auto &sl : ctx->qslots) {
         if (sl.buf) (void)hipFree(sl.buf);
@@ -699,6 +708,7 @@ int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int3
     for (int i = 0; i < d; i++) { if (z[i] < 0 || z[i] >= n || seen[z[i]]) return HB_ERR_BAD_ARG; seen[z[i]] = 1; }
     for (int j = 0; j < nc; j++) { if (zc[j] < 0 || zc[j] >= n || seen[zc[j]]) return HB_ERR_BAD_ARG; seen[zc[j]] = 1; }
     hipStream_t s = (hipStream_t)stream;
+    cache_trim(ctx);
     PointTable *pt = nullptr;
     int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
     if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: repeated points");
@@ -761,22 +771,24 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     if (n > PROBE_MAXN) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: more than 256 points");
     if (getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: disabled");
     hipStream_t s = (hipStream_t)stream;
+    cache_trim(ctx);
     PointTable *pt = nullptr;
     int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
     if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: repeated points");
+    pt->refs++;                                // this probe's reference: the table outlives its cache entry while the probe lives
     hb_probe *pr = new hb_probe();
     pr->ctx = ctx; pr->n = n; pr->k = k; pr->pt = pt; pr->poly = -1; pr->seq = 0;
     pr->state_bytes = ((size_t)4 * pt->S * ctx->nl() + 8 + PROBE_MAXN) * 4;
     const size_t pool_bytes = ((size_t)4 * (PROBE_MAXN + 2) * 9 + 8 + PROBE_MAXN) * 4;     // pooled states are all of the largest size
     pr->state = nullptr; pr->res_host = nullptr; pr->res_dev = nullptr;
     if (!ctx->probe_pool.empty()) { pr->state = (uint32_t *)ctx->probe_pool.back(); ctx->probe_pool.pop_back(); }
-    else if (hipMalloc(&pr->state, pool_bytes) != hipSuccess) { delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipMalloc"); }
+    else if (hipMalloc(&pr->state, pool_bytes) != hipSuccess) { point_table_unref(pt); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipMalloc"); }
     if (!ctx->probe_host_pool.empty()) { pr->res_host = (ProbeResult *)ctx->probe_host_pool.back(); ctx->probe_host_pool.pop_back(); }
     else if (hipHostMalloc((void **)&pr->res_host, sizeof(ProbeResult), hipHostMallocMapped) != hipSuccess) {
-        ctx->probe_pool.push_back(pr->state); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipHostMalloc");
+        ctx->probe_pool.push_back(pr->state); point_table_unref(pt); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipHostMalloc");
     }
     if (hipHostGetDevicePointer((void **)&pr->res_dev, pr->res_host, 0) != hipSuccess) {
-        ctx->probe_pool.push_back(pr->state); ctx->probe_host_pool.push_back(pr->res_host); delete pr; return fail(ctx, HB_ERR_HIP, "probe: device pointer");
+        ctx->probe_pool.push_back(pr->state); ctx->probe_host_pool.push_back(pr->res_host); point_table_unref(pt); delete pr; return fail(ctx, HB_ERR_HIP, "probe: device pointer");
     }
     pr->res_host->seq = 0;                 // a pooled buffer keeps its last owner's number
     *out = pr;
@@ -855,6 +867,7 @@ void hb_probe_destroy(hb_probe *pr) { HB_API_GUARD((pr ? pr->ctx : nullptr));
     (void)hipDeviceSynchronize();
     pr->ctx->probe_pool.push_back(pr->state);
     pr->ctx->probe_host_pool.push_back(pr->res_host);
+    point_table_unref(pr->pt);
     delete pr;
 }
 

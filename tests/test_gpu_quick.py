@@ -217,3 +217,32 @@ def test_probe_at_config3_shape_with_21_liars():
         assert pr.feed([order[m - 1]], cols, c, 1) is None, m
     assert pr.feed([order[63]], cols, c, 1) == list(range(t))
     pr.close()
+
+
+def test_point_tables_are_cache_entries():
+    """the per-point-set tables (n^2 inverse differences) are entries of the context's bounded table cache: hundreds of point sets
+    leave at most the cap resident, a probe keeps its own table alive across a clear, and results stay right"""
+    from honeybadgermpc_amd._capi import Context
+
+    ctx = Context.get(P)
+    rnd = random.Random(99)
+    n, k = 12, 4
+    ctx.cache_clear()
+    keep = None
+    for i in range(260):
+        x = rnd.sample(range(1, 10 ** 6), n)
+        pr = _Probe(ctx, x, k)
+        if i == 0:
+            keep = (pr, x)
+        else:
+            pr.close()
+    assert ctx.cache_entries() <= 192 + 8, ctx.cache_entries()
+    ctx.cache_clear()
+    assert ctx.cache_entries() == 0
+    pr, x = keep                                     # its table left the cache; the probe still works on it
+    f = [rnd.randrange(P) for _ in range(k)]
+    vals = [[_ev(f, x[i], P)] for i in range(n)]
+    vals[5][0] = (vals[5][0] + 1) % P
+    cols = ctx.upload_ints([v for row in vals for v in row])
+    assert pr.feed(list(range(n)), cols, 1, 0) == [5]
+    pr.close()
