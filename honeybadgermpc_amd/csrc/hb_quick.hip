@@ -799,8 +799,9 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
 // buffer cols [n][C] -- and, with decide != 0, wait for the reference's outcome over everything fed: *ok and err_mask[0..n)
 // (1 = that party is a root of the error locator).  The points of one polynomial are fed in arrival order, each once;
 // hb_probe_reset starts another polynomial (or another arrival list).
-int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *cols_dev, int64_t C, int64_t poly, int decide,
-                  int32_t *ok, uint8_t *err_mask, void *stream) { HB_API_GUARD((pr ? pr->ctx : nullptr));
+// the launch: under the context's mutex like every entry point; *seq_out = the number the kernel will echo when its verdict is complete
+static int probe_launch(hb_probe *pr, const int32_t *idx, int count, const uint64_t *cols_dev, int64_t C, int64_t poly, int decide,
+                        int32_t *ok, uint8_t *err_mask, void *stream, int *seq_out) { HB_API_GUARD((pr ? pr->ctx : nullptr));
     if (!pr || count < 0 || (count > 0 && (!idx || !cols_dev)) || poly < 0 || poly >= C) return HB_ERR_BAD_ARG;
     if (decide && (!ok || !err_mask)) return HB_ERR_BAD_ARG;
     hb_ctx *ctx = pr->ctx;
@@ -830,10 +831,21 @@ int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *c
     if (ctx->n_limbs == 4) PROBE_LAUNCH(9, 8, ctx->pw); else PROBE_LAUNCH(3, 2, ctx->pn);
 #undef PROBE_LAUNCH
     HB_LAUNCH_CHECK(ctx);
-    if (!decide) return HB_OK;
+    *seq_out = seq;
+    return HB_OK;
+}
+
+int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *cols_dev, int64_t C, int64_t poly, int decide,
+                  int32_t *ok, uint8_t *err_mask, void *stream) {
+    int seq = 0;
+    const int rc = probe_launch(pr, idx, count, cols_dev, C, poly, decide, ok, err_mask, stream, &seq);
+    if (rc || !decide) return rc;
+    hb_ctx *ctx = pr->ctx;
+    hipStream_t s = (hipStream_t)stream;
     {
-        // the kernel writes its verdict into pinned host memory and the sequence number last: polling that word sees it a few
-        // microseconds after the last store instead of a stream synchronisation's wake-up later; past 2 ms, synchronise
+        // Outside the context's mutex (other threads of the context go on while this one waits).  The kernel writes its verdict
+        // into pinned host memory and the sequence number last: polling that word sees it a few microseconds after the last
+        // store instead of a stream synchronisation's wake-up later; past 2 ms, synchronise
         volatile int32_t *flag = &pr->res_host->seq;
         const auto t0 = std::chrono::steady_clock::now();
         int spins = 0;
