@@ -67,7 +67,8 @@ def main(src):
         "# scratch/bench_device_decoder.py, scratch/bench_coalescer.py, scratch/boundary_rates.py, scratch/plan_create_cost.py (round 3: the device decoder is plan-free -- hb_quick_interp_check + hb_probe_*;",
         "# 'building them' = first sight of the arrival pattern, the figure VERDICT r2 item 2 asks for; round 2: fault-free 305 M, 5 liars 154 M, 21 liars 49 M shares/s.  'late chunks only' = every liar corrupts ONE chunk k > 0",
         "# of its own, polynomial 0 decodes clean.  The wb rows use the plan-free optimistic launch and the plan-based Welch-Berlekamp robust path.)"],
-        clean(os.path.join(src, "device_decoder.txt")) + clean(os.path.join(src, "coalescer.txt")) + clean(os.path.join(src, "boundary_rates.txt")) + clean(os.path.join(src, "plan.txt")))
+        clean(os.path.join(src, "device_decoder.txt")) + clean(os.path.join(src, "coalescer.txt")) + clean(os.path.join(src, "boundary_rates.txt")) + clean(os.path.join(src, "plan.txt"))
+        + (clean(os.path.join(src, "decoder_cfg5_shape.txt")) if os.path.exists(os.path.join(src, "decoder_cfg5_shape.txt")) else ""))
     with open(os.path.join(HERE, "r03_bench_default_run.json"), "w") as f:
         f.write(open(os.path.join(src, "bench_default.json")).read().strip().splitlines()[-1] + "\n")
     with open(os.path.join(HERE, "r03_bench_other_workloads.json"), "w") as f:

@@ -45,6 +45,7 @@ done
 timeout 900 python profiles/summarize_pmc.py "$OUT"/c4_pmc_* > "$OUT/pmc_summary_cfg4.txt" 2>&1
 timeout 900 python scratch/bench_device_decoder.py > "$OUT/device_decoder.txt" 2>&1
 timeout 900 python scratch/bench_coalescer.py > "$OUT/coalescer.txt" 2>&1
+timeout 600 python scratch/decoder_cfg5_shape.py > "$OUT/decoder_cfg5_shape.txt" 2>&1
 timeout 900 python scratch/boundary_rates.py > "$OUT/boundary_rates.txt" 2>&1
 timeout 900 python scratch/plan_create_cost.py > "$OUT/plan.txt" 2>&1
 if [ -f honeybadgermpc_amd/lib/libhbmpc_hip_timing.so ]; then HBMPC_HIP_LIB=honeybadgermpc_amd/lib/libhbmpc_hip_timing.so python scratch/mm8w_phase_timing.py > "$OUT/mm8w_phase_timing.txt" 2>&1; fi
