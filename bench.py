@@ -657,8 +657,8 @@ def main():
     zc = order[d : d + t]
     op = BatchOpen(BLS, n, t, z=z, zc=zc, use_omega_powers=use_omega, max_shares=B, device=local_rank)
     if op.uses_fused_validate():
-        # a plan builds its fused decode + validate matrices when it decodes for the third time (1-2.5 ms, with a stream
-        # synchronise); a benchmark that may be run with --warmup 0 asks for them now instead of inside its timed region
+        # plans build their fused decode + validate matrices on the device at creation; where only the host-built form applies
+        # (moduli the device builder does not take) it would come at the third decode: ask for it now, not inside the timed region
         op.set_fused_validate(True)
     if args.no_matrix_cores:
         op.set_matrix_cores(False)

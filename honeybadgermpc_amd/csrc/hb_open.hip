@@ -62,6 +62,13 @@ struct hb_open_plan {
     // compares (same canonical values as interpolating first and evaluating after: exact arithmetic mod p).
     Mm8wMatrix *F1, *F2;         // [Winv row 0 ; V[zc] Winv] for the R1 message, [Winv ; V[zc] Winv] for the R2 result (owned)
     int32_t *fmap1, *fmap2;      // per row: 0 = a result row, else 1 + the received row to compare the prediction with
+    // The same two matrices built ON THE DEVICE at plan creation (hb_quick.hip: Lagrange from the point set's table of inverse
+    // differences, image and row constants by two small kernels; nothing waited for): where that applies the plan decodes +
+    // validates in one launch from its first decode on, and F1 / F2 (host-built: 1-2.5 ms with a stream synchronise, which is why
+    // they used to wait for a plan's third decode) are never needed.
+    uint8_t *q1, *q2;            // owned buffers (QuickLayout::need bytes each)
+    QuickLayout l1, l2;
+    const Mm8wShared *qsh;
 };
 
 // the digit planes of the integer-VALU kernels (2 x 36 B per share): plans on the matrix cores never touch them
@@ -125,7 +132,7 @@ static int build_fused(hb_open_plan *pl, const uint64_t *x_host, hipStream_t s) 
 // does not take leave the plan as it is
 static int ensure_fused(hb_open_plan *pl, hipStream_t s) {
     pl->fused_pending = 0;
-    if (pl->F1 || pl->d < 4 || pl->n < 4 || getenv("HB_NO_MFMA_DECODE")) return HB_OK;
+    if (pl->q1 || pl->F1 || pl->d < 4 || pl->n < 4 || getenv("HB_NO_MFMA_DECODE")) return HB_OK;
     hb_ctx *ctx = pl->ctx;
     const int L = ctx->n_limbs;
     if (!pl->Winv) {
@@ -221,9 +228,25 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         }
         if ((pl->Winv8 || pl->Vw8) && !pl->coef_pk) PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
     }
-    // the fused matrices are built when the plan decodes for the third time (ensure_fused), or at once on request (set_option)
+    // the fused matrices: built on the device right now where hb_quick.hip takes the shape; otherwise on the host when the plan decodes
+    // for the third time (ensure_fused), or at once on request (set_option)
     pl->fused_pending = ((pl->V8 || pl->Winv8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") && !getenv("HB_NO_FUSED_VALIDATE") &&
                          !getenv("HB_NO_MFMA_WIDE") && ctx->n_limbs == 4 && prescale_params(ctx)) ? 1 : 0;
+    if (pl->fused_pending && !getenv("HB_NO_QUICK_PLAN")) {
+        QuickLayout a, b;
+        if (quick_layout(ctx, n, d, n_check, 1, &a) == HB_OK && quick_layout(ctx, n, d, n_check, d, &b) == HB_OK) {
+            uint8_t *b1 = nullptr, *b2 = nullptr;
+            const Mm8wShared *sh = nullptr;
+            int qrc = HB_OK;
+            if (hipMalloc(&b1, a.need) != hipSuccess || hipMalloc(&b2, b.need) != hipSuccess) qrc = HB_ERR_HIP;
+            const int32_t *zcp = n_check > 0 ? zc_host : z_host;      // (unused when n_check == 0)
+            if (!qrc) qrc = quick_build(ctx, x_host, z_host, zcp, a, b1, &sh, s);
+            if (!qrc) qrc = quick_build(ctx, x_host, z_host, zcp, b, b2, &sh, s);
+            if (!qrc) { pl->q1 = b1; pl->q2 = b2; pl->l1 = a; pl->l2 = b; pl->qsh = sh; pl->fused_pending = 0; }
+            else { if (b1) (void)hipFree(b1); if (b2) (void)hipFree(b2); }   // repeated points, overlapping index sets, ...: the host-built path stays
+        }
+        ctx->err.clear();                    // "unsupported" from the device builder is not this call's error
+    }
     PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
 #undef PLAN_HIP
@@ -264,6 +287,12 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
         // it fails for any reason (out of memory while building F1 / F2, ...) the decode goes on unfused and the error is dropped.
         // ensure_fused clears fused_pending first, so a failure is not retried on every call.
         if (ensure_fused(pl, s) != HB_OK) pl->ctx->err.clear();
+    }
+    if (pl->q1 && pl->q2 && pl->use_v8 && pl->use_fused && (pk_rows == 1 || pk_rows == pl->d)) {
+        // device-built images: ONE launch decodes the rows the caller wants and compares the predictions of the later arrivals
+        const bool r1 = pk_rows == 1 && pl->d > 1;
+        return quick_launch(pl->ctx, r1 ? pl->l1 : pl->l2, r1 ? pl->q1 : pl->q2, pl->qsh, (const uint32_t *)cols_dev, pm, pk_dst, pv, pk_count, pk_rows,
+                            pl->mismatch_dev, nullptr, C, s);
     }
     if (pl->F1 && pl->F2 && pl->use_v8 && pl->use_fused && (pk_rows == 1 || pk_rows == pl->d)) {
         // full-size entries: ONE launch decodes the rows the caller wants and compares the predictions of the later arrivals
@@ -387,7 +416,7 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) { HB_API_GU
     if (option == HB_OPEN_OPT_MATRIX_CORES) { pl->use_v8 = value ? 1 : 0; return HB_OK; }
     if (option == HB_OPEN_OPT_FUSED_VALIDATE) {
         pl->use_fused = value ? 1 : 0;
-        if (value && !pl->F1) {
+        if (value && !pl->F1 && !pl->q1) {
             // asked for explicitly: built now instead of at the third decode
             int rc = ensure_fused(pl, 0);
             if (rc) return rc;
@@ -401,7 +430,7 @@ int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) { HB_API_G
     if (!pl || !value) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { *value = pl->validate_arrived_only; return HB_OK; }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = ((pl->V8 || pl->Winv8 || pl->Vw8) && pl->use_v8) ? 1 : 0; return HB_OK; }
-    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (((pl->F1 && pl->F2) || pl->fused_pending) && pl->use_v8 && pl->use_fused) ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (((pl->F1 && pl->F2) || (pl->q1 && pl->q2) || pl->fused_pending) && pl->use_v8 && pl->use_fused) ? 1 : 0; return HB_OK; }
     return HB_ERR_BAD_ARG;
 }
 
@@ -418,6 +447,8 @@ void hb_open_plan_destroy(hb_open_plan *pl) { HB_API_GUARD((pl ? pl->ctx : nullp
     fast_matrix_free(pl->V); fast_matrix_free(pl->Vinv); mm8_free(pl->V8); mm8_free(pl->Vinv8); mm8_free(pl->Vzc8);
     if (pl->scaled_pk) (void)hipFree(pl->scaled_pk);
     mm8w_free(pl->F1); mm8w_free(pl->F2);
+    if (pl->q1) (void)hipFree(pl->q1);
+    if (pl->q2) (void)hipFree(pl->q2);
     if (pl->fmap1) (void)hipFree(pl->fmap1);
     if (pl->fmap2) (void)hipFree(pl->fmap2);
     if (pl->Winv) matrix_unref(pl->Winv);

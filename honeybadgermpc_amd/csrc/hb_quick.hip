@@ -695,71 +695,102 @@ struct hb_probe {
 
 extern "C" {
 
+}  // extern "C" (the builder below is shared with hb_open.hip)
+
+namespace hb {
+
+// sizes and offsets of everything a device-built image of [n_coef rows of V^-1(z) ; V[zc] V^-1(z)] needs, in one buffer:
+// image | row constants | (build scratch: w_j, prod_q (x_i - x_zq), N_j, canonical entries) | z as int32 | the row map
+int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L) {
+    if (ctx->n_limbs != 4 || d < 4 || d > QUICK_MAX || nc < 0 || nc > QUICK_MAXC || n > 65535 || n_coef < 1 || n_coef > d) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: shape");
+    if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE") || getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: disabled");
+    // entries below p must fit 32 balanced base-256 digits: top byte of p at most 0x7e
+    if (!prescale_params(ctx) || (ctx->p_limbs[3] >> 56) > 0x7e) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: modulus");
+    L->n = n; L->d = d; L->nc = nc; L->n_coef = n_coef; L->n_out = n_coef + nc;
+    int n_rt = 0;
+    size_t a8_bytes = 0, crow_words = 0;
+    const int rc = mm8w_geometry(L->n_out, d, &L->tile_rows, &n_rt, &L->nkb, &a8_bytes, &crow_words);
+    if (rc) return fail(ctx, rc, "quick: geometry");
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    L->o_a8 = 0; L->o_crow = L->o_a8 + al(a8_bytes); L->o_wj = L->o_crow + al(crow_words * 4); L->o_full = L->o_wj + al((size_t)d * 36);
+    L->o_nraw = L->o_full + al((size_t)(nc ? nc : 1) * 36); L->o_mcan = L->o_nraw + al((size_t)n_coef * d * 36);
+    L->o_z = L->o_mcan + al((size_t)L->n_out * d * 32); L->o_map = L->o_z + al((size_t)d * 4); L->need = L->o_map + al((size_t)(L->n_out + 2) * 4);
+    return HB_OK;
+}
+
+// enqueue the build of that image into `base` (L.need bytes, the caller's): a memset and three small kernels, nothing waited for
+int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s) {
+    const int n = L.n, d = L.d, nc = L.nc;
+    std::vector<uint8_t> seen((size_t)n, 0);
+    for (int i = 0; i < d; i++) { if (z[i] < 0 || z[i] >= n || seen[z[i]]) return fail(ctx, HB_ERR_BAD_ARG, "quick: arrival indices"); seen[z[i]] = 1; }
+    for (int j = 0; j < nc; j++) { if (zc[j] < 0 || zc[j] >= n || seen[zc[j]]) return fail(ctx, HB_ERR_BAD_ARG, "quick: compared indices"); seen[zc[j]] = 1; }
+    PointTable *pt = nullptr;
+    int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
+    if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: repeated points");
+    const Mm8wShared *sh = nullptr;
+    rc = mm8w_shared(ctx, d, &sh, s); if (rc) return rc;
+    *shared = sh;
+    HB_HIP(ctx, hipMemsetAsync(base, 0, L.o_wj, s));                    // image and row constants: padding rows / terms are zero
+    QuickIdx ix;
+    memset(&ix, 0, sizeof ix);
+    for (int i = 0; i < d; i++) ix.z[i] = (uint16_t)z[i];
+    for (int j = 0; j < nc; j++) ix.zc[j] = (uint16_t)zc[j];
+    uint32_t *wj = (uint32_t *)(base + L.o_wj), *full = (uint32_t *)(base + L.o_full), *nraw = (uint32_t *)(base + L.o_nraw), *mcan = (uint32_t *)(base + L.o_mcan);
+    k_quick_matrix<9><<<1, 512, (size_t)(d + 2) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map));
+    HB_LAUNCH_CHECK(ctx);
+    k_quick_image<<<(unsigned)((L.n_out * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, mcan, base + L.o_a8, L.tile_rows, L.nkb);
+    HB_LAUNCH_CHECK(ctx);
+    QuickRowConst rcs;
+    memcpy(rcs.c80r, sh->c80r, sizeof rcs.c80r);
+    memcpy(rcs.biasmod, sh->biasmod, sizeof rcs.biasmod);
+    k_quick_rows<<<(unsigned)((L.n_out + 63) / 64), 64, 0, s>>>(ctx->pw, mcan, L.n_out, d, rcs, (uint32_t *)(base + L.o_crow), L.tile_rows);
+    HB_LAUNCH_CHECK(ctx);
+    return HB_OK;
+}
+
+// the launch over a built image: n_store coefficient rows go to out (view ov, out_count elements), the compared rows (if any) are
+// checked against the rows of `cols` they belong to
+int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const Mm8wShared *sh, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov,
+                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s) {
+    const int32_t *fmap = (const int32_t *)(base + L.o_map);
+    return launch_mm8w_raw(ctx, L.n_out, L.d, L.tile_rows, (const void *)(base + L.o_a8), (const uint32_t *)(base + L.o_crow), sh,
+                           cols, cv, (const int32_t *)(base + L.o_z), INT64_MAX, out, ov, out_count,
+                           L.nc > 0 ? fmap : nullptr, mismatch_dev, C, s, cols, cv, n_store, L.nc > 0 ? first_bad_dev : nullptr);
+}
+
+}  // namespace hb
+
+extern "C" {
+
 int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
                           const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !x_host || !z || n < 1 || d < 1 || d > n || nc < 0 || (nc > 0 && !zc) || C < 0 || chunk_lo < 0 || chunk_hi > C || chunk_lo > chunk_hi) return HB_ERR_BAD_ARG;
     if (chunk_hi == chunk_lo) return HB_OK;
     if (!cols_dev || (nc > 0 && !status_dev)) return HB_ERR_BAD_ARG;
-    if (ctx->n_limbs != 4 || d < 4 || d > QUICK_MAX || nc > QUICK_MAXC || n > 65535) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: shape");
-    if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE") || getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: disabled");
-    // entries below p must fit 32 balanced base-256 digits: top byte of p at most 0x7e
-    if (!prescale_params(ctx) || (ctx->p_limbs[3] >> 56) > 0x7e) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: modulus");
-    std::vector<uint8_t> seen((size_t)n, 0);
-    for (int i = 0; i < d; i++) { if (z[i] < 0 || z[i] >= n || seen[z[i]]) return HB_ERR_BAD_ARG; seen[z[i]] = 1; }
-    for (int j = 0; j < nc; j++) { if (zc[j] < 0 || zc[j] >= n || seen[zc[j]]) return HB_ERR_BAD_ARG; seen[zc[j]] = 1; }
     hipStream_t s = (hipStream_t)stream;
     cache_trim(ctx);
-    PointTable *pt = nullptr;
-    int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
-    if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: repeated points");
-    const int n_coef = coeffs_dev ? d : 1;            // nothing to store: one coefficient row keeps the kernel's shapes simple
-    const int n_out = n_coef + nc;
-    int tile_rows = 0, n_rt = 0, nkb = 0;
-    size_t a8_bytes = 0, crow_words = 0;
-    rc = mm8w_geometry(n_out, d, &tile_rows, &n_rt, &nkb, &a8_bytes, &crow_words); if (rc) return fail(ctx, rc, "quick: geometry");
-    const Mm8wShared *sh = nullptr;
-    rc = mm8w_shared(ctx, d, &sh, s); if (rc) return rc;
+    QuickLayout L;
+    int rc = quick_layout(ctx, n, d, nc, coeffs_dev ? d : 1, &L); if (rc) return rc;     // nothing to store: one coefficient row keeps the kernel's shapes simple
     // one slot of the context's ring: image, row constants, scratch, index arrays
-    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t o_a8 = 0, o_crow = o_a8 + al(a8_bytes), o_wj = o_crow + al(crow_words * 4), o_full = o_wj + al((size_t)d * 36),
-                 o_nraw = o_full + al((size_t)(nc ? nc : 1) * 36), o_mcan = o_nraw + al((size_t)n_coef * d * 36),
-                 o_z = o_mcan + al((size_t)n_out * d * 32), o_map = o_z + al((size_t)d * 4), need = o_map + al((size_t)(n_out + 2) * 4);
     if (ctx->qslots.empty()) ctx->qslots.resize(4);
     hb_ctx::QuickSlot &sl = ctx->qslots[ctx->qnext++ % ctx->qslots.size()];
     if (sl.ev) HB_HIP(ctx, hipEventSynchronize((hipEvent_t)sl.ev));      // the launch that last used this slot is over
     else { hipEvent_t ev; HB_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); sl.ev = ev; }
-    if (sl.cap < need) {
+    if (sl.cap < L.need) {
         if (sl.buf) HB_HIP(ctx, hipFree(sl.buf));
         sl.buf = nullptr; sl.cap = 0;
-        HB_HIP(ctx, hipMalloc(&sl.buf, need));
-        sl.cap = need;
+        HB_HIP(ctx, hipMalloc(&sl.buf, L.need));
+        sl.cap = L.need;
     }
     uint8_t *base = static_cast<uint8_t *>(sl.buf);
-    HB_HIP(ctx, hipMemsetAsync(base, 0, o_wj, s));                      // image and row constants: padding rows / terms are zero
-    QuickIdx ix;
-    memset(&ix, 0, sizeof ix);
-    for (int i = 0; i < d; i++) ix.z[i] = (uint16_t)z[i];
-    for (int j = 0; j < nc; j++) ix.zc[j] = (uint16_t)zc[j];
-    uint32_t *wj = (uint32_t *)(base + o_wj), *full = (uint32_t *)(base + o_full), *nraw = (uint32_t *)(base + o_nraw), *mcan = (uint32_t *)(base + o_mcan);
-    int32_t *z_dev = (int32_t *)(base + o_z), *fmap = (int32_t *)(base + o_map);
-    k_quick_matrix<9><<<1, 512, (size_t)(d + 2) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, n_coef, wj, full, nraw, z_dev, fmap);
-    HB_LAUNCH_CHECK(ctx);
-    k_quick_image<<<(unsigned)((n_out * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, n_coef, wj, full, nraw, mcan, base + o_a8, tile_rows, nkb);
-    HB_LAUNCH_CHECK(ctx);
-    QuickRowConst rcs;
-    memcpy(rcs.c80r, sh->c80r, sizeof rcs.c80r);
-    memcpy(rcs.biasmod, sh->biasmod, sizeof rcs.biasmod);
-    k_quick_rows<<<(unsigned)((n_out + 63) / 64), 64, 0, s>>>(ctx->pw, mcan, n_out, d, rcs, (uint32_t *)(base + o_crow), tile_rows);
-    HB_LAUNCH_CHECK(ctx);
+    const Mm8wShared *sh = nullptr;
+    rc = quick_build(ctx, x_host, z, zc, L, base, &sh, s); if (rc) return rc;
     // chunks [chunk_lo, chunk_hi): the views keep the buffer's row stride C, the bases move to chunk_lo
     hb_view pm{1, C}, dv{d, 1};
     const int64_t cnt = chunk_hi - chunk_lo;
     const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
-    uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * d * 8 : mcan;       // n_store = 0 below when there is nothing to store
-    rc = launch_mm8w_raw(ctx, n_out, d, tile_rows, (const void *)(base + o_a8), (const uint32_t *)(base + o_crow), sh,
-                         in, pm, z_dev, INT64_MAX, out, dv, coeffs_dev ? cnt * (int64_t)d : 0,
-                         nc > 0 ? fmap : nullptr, status_dev, cnt, s, in, pm, coeffs_dev ? d : 0,
-                         nc > 0 ? status_dev + 1 : nullptr);
+    uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * d * 8 : (uint32_t *)(base + L.o_mcan);       // n_store = 0 when there is nothing to store
+    rc = quick_launch(ctx, L, base, sh, in, pm, out, dv, coeffs_dev ? cnt * (int64_t)d : 0, coeffs_dev ? d : 0, status_dev, status_dev ? status_dev + 1 : nullptr, cnt, s);
     if (rc) return rc;
     HB_HIP(ctx, hipEventRecord((hipEvent_t)sl.ev, s));
     return HB_OK;
