@@ -208,8 +208,9 @@ int hb_open_status(hb_open_plan *plan, void *stream);
  * arrival's point is a linear function of the arrival set, V[zc] (Vinv y) = (V[zc] Vinv) y, so the rows [Vinv rows wanted ;
  * V[zc] Vinv] applied to the received columns give the coefficients and the predictions to compare (reference:
  * decoder.decode_batch + encoder.encode_batch + compare, reed_solomon.py:300-323; same canonical values, same accept /
- * reject).  The two matrices cost 1-2.5 ms to build, so a plan builds them when it decodes for the THIRD time (arrival sets
- * that are seen once -- a decoder probing its way past liars -- never pay), or at once when the option is set to 1.
+ * reject).  The two matrices are built on the device when the plan is created (hb_quick.hip: enqueued, nothing waited for);
+ * where that builder does not apply (p >= 0x7f 2^248, repeated points) they are built through the host (1-2.5 ms) when the plan
+ * decodes for the third time, or at once when the option is set to 1.
  * 0: decode, then re-encode all n points (NTT or mat-vec) and compare.  get_option: enabled and available for this plan. */
 #define HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY 1
 #define HB_OPEN_OPT_MATRIX_CORES 2
