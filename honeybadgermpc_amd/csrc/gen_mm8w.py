@@ -247,8 +247,11 @@ def carry(upto):
     return L
 
 
-def reduce_output(o, r, check):
-    """units (lists of lines) reducing output r's 17 words and storing / comparing the canonical element"""
+def reduce_output(o, r, check, nfold=10):
+    """units (lists of lines) reducing output r's 17 words and storing / comparing the canonical element.
+    nfold = 10: all 19 digits of the biased sum; nfold = 9: the sum is known to stay below 2^(29 * 18) (the launcher checks the
+    bias against that bound: any matrix of fewer than 64 terms), digit 18 is zero and its fold is not emitted."""
+    assert nfold in (9, 10)
     U = []
     one = lambda ln: U.append([ln])  # noqa: E731
     if check:
@@ -270,14 +273,14 @@ def reduce_output(o, r, check):
     for ln in t_reads(2):
         one(ln)
     # V += s_(9+k) T_k
-    for k in range(10):
+    for k in range(nfold):
         for ln in digit(o, r, 9 + k, SK):
             one(ln)
-        one(f"s_waitcnt lgkmcnt({3 * min(2, 9 - k)})")
+        one(f"s_waitcnt lgkmcnt({3 * min(2, nfold - 1 - k)})")
         b = TB[k % 3]
         for j in range(9):
             one(f"v_mad_u64_u32 {cpair(j)}, vcc, v{SK}, v{b + j}, {cpair(j)}")
-        if k + 3 < 10:
+        if k + 3 < nfold:
             for ln in t_reads(k + 3):
                 one(ln)
     for ln in carry(9):
@@ -431,7 +434,7 @@ def split(units, parts):
     return [units[n * i // parts:n * (i + 1) // parts] for i in range(parts)]
 
 
-def pass_lines(check, peel, nout=4):
+def pass_lines(check, peel, nout=4, nfold=10):
     """`peel` K-blocks are straight-line code carrying the reduction of the pass before, in equal shares (one wave per SIMD
     issues an instruction every ~5.5 cycles at best -- profiles/r01_mad_issue_rate_vs_occupancy.txt, r02_mm8w_phase_timing.txt --
     so everything a pass executes counts); the other nkb - peel K-blocks run as a loop of two-block bodies in the middle (the digit
@@ -447,7 +450,7 @@ def pass_lines(check, peel, nout=4):
     L += prep(0) + ["s_nop 1"]                      # (its lgkmcnt(0) also covers the scalar loads)
     units = []
     for r in range(nout):
-        units += reduce_output(o, r, check)
+        units += reduce_output(o, r, check, nfold)
     shares = split(units, peel)
     head = (peel + 1) // 2
     for i in range(peel):
@@ -464,11 +467,11 @@ def pass_lines(check, peel, nout=4):
     return o, resolve_waits(L)
 
 
-def reduce_lines(check, nout=4):
+def reduce_lines(check, nout=4, nfold=10):
     o = Ops(check, nout)
     L = consts(o) + ["s_waitcnt lgkmcnt(0)"]
     for r in range(nout):
-        for u in reduce_output(o, r, check):
+        for u in reduce_output(o, r, check, nfold):
             L += u
     return o, resolve_waits(L)
 
@@ -499,14 +502,16 @@ PEELS = (1, 2, 3, 4)
 
 def emit():
     out = ["// GENERATED by gen_mm8w.py -- do not edit", ""]
-    for check in (False, True):
-        sfx = "_check" if check else ""
-        for nout in (4, 3, 2):
-            for peel in PEELS:
-                o, lines = pass_lines(check, peel, nout)
-                out += emit_fn(f"mm8w_pass{sfx}_p{peel}_k{nout}", o, lines, check)
-            o, lines = reduce_lines(check, nout)
-            out += emit_fn(f"mm8w_reduce{sfx}_k{nout}", o, lines, check)
+    for nfold in (10, 9):
+        fs = "" if nfold == 10 else "_f9"
+        for check in (False, True):
+            sfx = "_check" if check else ""
+            for nout in (4, 3, 2):
+                for peel in PEELS:
+                    o, lines = pass_lines(check, peel, nout, nfold)
+                    out += emit_fn(f"mm8w_pass{sfx}{fs}_p{peel}_k{nout}", o, lines, check)
+                o, lines = reduce_lines(check, nout, nfold)
+                out += emit_fn(f"mm8w_reduce{sfx}{fs}_k{nout}", o, lines, check)
     return "\n".join(out)
 
 

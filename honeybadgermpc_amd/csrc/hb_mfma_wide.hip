@@ -69,7 +69,8 @@ __device__ unsigned long long g_mm8w_t[1024 * 8];
 #endif
 
 // K = outputs kept per lane: 4 (row tiles of 16 rows), 3 (row tiles of 12: the fourth row of every group of the MFMA tile is padding) or 2 (8)
-template <bool CHECK, int PEEL, int K>
+// NF = digits of the sum folded through T_k: 10, or 9 when the launcher has checked the bias against 2^(29 * 18) (fewer than 64 terms)
+template <bool CHECK, int PEEL, int K, int NF>
 __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
                                                  const uint32_t *__restrict__ zero_src,
                                                  const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             else mm8w_pass##SFX##_p4_k2(MM8W_ARGS);                                        \
         }                                                                                  \
     } while (0)
-                if constexpr (CHECK) MM8W_PASS(_check); else MM8W_PASS();
+                if constexpr (NF == 9) { if constexpr (CHECK) MM8W_PASS(_check_f9); else MM8W_PASS(_f9); }
+                else { if constexpr (CHECK) MM8W_PASS(_check); else MM8W_PASS(); }
 #undef MM8W_PASS
 #undef MM8W_ARGS
                 __builtin_amdgcn_sched_barrier(0);
@@ -273,8 +275,13 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         uint32_t xa = 0, va = 0, cnt = 0;
         __builtin_amdgcn_sched_barrier(0);
 #define MM8W_ARGS w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
-        if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_check_k3(MM8W_ARGS); else mm8w_reduce_check_k2(MM8W_ARGS); }
-        else { if constexpr (K == 4) mm8w_reduce_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_k3(MM8W_ARGS); else mm8w_reduce_k2(MM8W_ARGS); }
+        if constexpr (NF == 9) {
+            if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_f9_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_check_f9_k3(MM8W_ARGS); else mm8w_reduce_check_f9_k2(MM8W_ARGS); }
+            else { if constexpr (K == 4) mm8w_reduce_f9_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_f9_k3(MM8W_ARGS); else mm8w_reduce_f9_k2(MM8W_ARGS); }
+        } else {
+            if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_check_k3(MM8W_ARGS); else mm8w_reduce_check_k2(MM8W_ARGS); }
+            else { if constexpr (K == 4) mm8w_reduce_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_k3(MM8W_ARGS); else mm8w_reduce_k2(MM8W_ARGS); }
+        }
 #undef MM8W_ARGS
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -553,23 +560,27 @@ static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in
     if (blocks > n_units) blocks = n_units;
     const size_t lds = mm8w_lds_bytes(m->n_rt, m->nkb, tpw, nbuf);
     const bool check = check_mask_dev != nullptr;
-#define MM8W_LAUNCH_K(CHK, PL, KK)                                                                                                         \
+#define MM8W_LAUNCH_KF(CHK, PL, KK, FF)                                                                                                \
     do {                                                                                                                              \
         static bool attr_done = false;                                                                                                \
         if (!attr_done) {                                                                                                             \
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK, PL, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK, PL, KK, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_done = true;                                                                                                         \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_mm8w<CHK, PL, KK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
+        hipLaunchKernelGGL((k_mm8w<CHK, PL, KK, FF>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
                            m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp, first_bad_dev);                         \
     } while (0)
+    // the biased sum is < 2 bias 2^496 (1 + 1/255): below 2^(29 * 18) its 19th digit is zero and is not folded (gen_mm8w.py, nfold = 9)
+    const bool f9 = m->bias < 33000000u && !getenv("HB_MM8W_FOLD10");
+#define MM8W_LAUNCH_K(CHK, PL, KK) do { if (f9) MM8W_LAUNCH_KF(CHK, PL, KK, 9); else MM8W_LAUNCH_KF(CHK, PL, KK, 10); } while (0)
     // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
     const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);
 #define MM8W_LAUNCH(CHK, PL) do { if (m->tile_rows == 12) MM8W_LAUNCH_K(CHK, PL, 3); else if (m->tile_rows == 8) MM8W_LAUNCH_K(CHK, PL, 2); else MM8W_LAUNCH_K(CHK, PL, 4); } while (0)
     if (check) { if (peel == 1) MM8W_LAUNCH(true, 1); else if (peel == 2) MM8W_LAUNCH(true, 2); else if (peel == 3) MM8W_LAUNCH(true, 3); else MM8W_LAUNCH(true, 4); }
     else { if (peel == 1) MM8W_LAUNCH(false, 1); else if (peel == 2) MM8W_LAUNCH(false, 2); else if (peel == 3) MM8W_LAUNCH(false, 3); else MM8W_LAUNCH(false, 4); }
+#undef MM8W_LAUNCH_KF
 #undef MM8W_LAUNCH_K
 #undef MM8W_LAUNCH
     HB_LAUNCH_CHECK(ctx);
