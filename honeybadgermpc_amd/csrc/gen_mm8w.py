@@ -19,7 +19,7 @@ The int8 pipe does the 1024 byte products of a 256 x 256-bit multiplication in 1
 half-rate v_mad_u64_u32 per lane.
 
 A pass = one asm statement, SOFTWARE-PIPELINED over passes: the kernel runs one wave per SIMD (all 63 accumulators of
-16 x 16 outputs live in AGPRs a0..a251), so nothing else could hide the reduction of S mod p (~310 VALU instructions per
+16 x 16 outputs live in AGPRs a0..a251), so nothing else could hide the reduction of S mod p (~190 instructions per
 output) -- it would simply follow the MFMA phase, which leaves the VALU three quarters idle.  Instead a pass ends by
 moving its sums out of the AGPRs as 17 words per output (68 VGPRs), and the NEXT pass reduces, compares and stores them
 between its own MFMAs: up to four K-blocks are written out, each carrying an equal share of that reduction; the K-blocks between
@@ -31,13 +31,15 @@ MFMA tile is empty, its reduction and word assembly are not emitted) and 2 sums 
 
 Register files (VGPRs the statement owns: v96 .. v255): v164.. the MFMA operand files (two file sets, the next group's
 shifts built from the other set while the current group's MFMAs issue; element prefetch XB, digit buffers ABUF of two
-K-block parities); v96 .. v163 the reduction (ten 64-bit columns, two buffers for the T_k rows, the packed
-result, the row to compare with).  SGPRs s68 .. s89: the Barrett constants (scalar loads from WideParams), a saved exec.
+K-block parities); v96 .. v163 the reduction (the row to compare with, the 32 columns of the fold, its operands, the packed
+result).  SGPRs s68 .. s89: the reduction constants (scalar loads from WideParams), a saved exec.
 
-Reduction of one output (the arithmetic of k_prescale_tab / the first version's C++ epilogue, same bounds):
-  19 radix-2^29 digits of the 17 words; V = low nine digits + per-row constant + sum_{k >= 9} s_k T_k (T_k = 2^(29k) mod p from
-  LDS, 90 MADs) < 2^290; carry; two-digit Barrett quotient against mu = floor(2^290 / p); V + q (2^261 - p) in nine digits;
-  pack to eight words; conditional subtraction of p; then the lane's mode word says store (1), compare (2) or neither (0).
+Reduction of one output (reduce_output below has the arithmetic; scratch/model_mfma_fold.py is its big-integer model):
+  the high eight words of the sum go back through the matrix cores against the table t_b = 2^(256 + 8 b) mod p (16 MFMAs whose
+  A operands come from LDS), the 32 columns of that, the low eight words, the top word times 2^512 mod p and the per-row constant
+  are gathered per 32-bit word; a one-word Barrett quotient; R - q p in words; conditional subtraction of p; then the lane's mode
+  word says store (1), compare (2) or neither (0).  ~190 instructions per output; rounds 2's fold on the VALU (19 radix-2^29
+  digits, 90 MADs, a two-digit quotient) took ~340.
 """
 import os
 
@@ -52,23 +54,27 @@ F_KMIN = -2
 RHOS = (0, 1, 2, 3)
 NG = 4                         # digit groups of 8
 # ---- reduction file (v96 .. v163) ----
-C0 = 96                        # ten 64-bit columns: C0 + 2j (low), + 1 (high)
-TB = [116, 126, 136]           # three buffers of nine for the T_k rows / the row constant (even bases: 128-bit LDS reads)
-T1, SK, ZERO = 125, 135, 145
-OW = 146                       # packed result, 8 words
-EX = 154                       # row to compare with, 8 words (requested when the output's reduction starts)
-T2 = 162                       # pair
-QP, Q0, Q1 = 116, 118, 119     # Barrett quotient (the T buffers are free by then)
-UB = 96                        # ow + (2^256 - p): the columns are free by then
-DIFF = 116
+EX = 96                        # row to compare with, 8 words (requested when the output's reduction starts)
+D0 = 104                       # the 32 columns of the fold: eight MFMA results of four
+HB = 136                       # the high half H of the sum, biased: two B operands of four
+AB = [144, 148, 152, 156]      # four buffers for the fold's A operands (LDS, three steps ahead)
+T1, Q, TP = 160, 161, 162      # bit 256, the quotient, a pair
+FOLD_ROW = 272                 # bytes per row of the fold table in LDS
+PB = 136                       # P_w, eight pairs: over HB and two A buffers once the MFMAs have been issued
+OW = 104                       # packed result, 8 words (the columns are spent by then)
+PN = 112                       # 2^256 - p in registers
+UB = 120                       # ow + (2^256 - p)
+DIFF = 128
 # ---- tail (word assembly) ----
 TL_TMP = [[96, 97, 98, 99], [100, 101, 102, 103]]
 TL_T = [[104, 106, 108, 110], [112, 114, 116, 118]]
 # ---- SGPRs ----
-S_PBAR, S_PNEG, S_M0, S_M1 = 68, 77, 85, 86    # WideParams: pbar[9] pneg[8] m0 m1 pad, loaded to s68 .. s87
+S_PNEG, S_MU, S_C512 = 68, 76, 77    # WideParams: pneg[8] mu c512[8] pad[3], loaded to s68 .. s87
 S_SAVE = 88                    # saved exec, pair
-MASK = "0x1fffffff"
-LB = 29
+
+
+ABLATE = os.environ.get("HB_GEN_MM8W_ABLATE", "").split(",")    # timing experiments only (wrong results): nored, notail, nomfma, nofload, nofwait, nofmfma
+SPREAD = float(os.environ.get("HB_GEN_MM8W_SPREAD", "1"))       # room of a fold line in the merged stream, relative to the other reduction lines
 
 
 class Ops:
@@ -85,7 +91,7 @@ class Ops:
         if check:
             self.outs.append(("FLAG", '"+s"', "flag"))
         self.ins += [("ABASE", '"s"', "abase"), ("K256", '"s"', "k256"), ("K64K", '"s"', "k64k"), ("K16M", '"s"', "k16m"),
-                     ("B4", '"s"', "bias4"), ("B3", '"s"', "bias3"), ("WPP", '"s"', "wpa"), ("CRL", '"v"', "crl_addr")]
+                     ("B4", '"s"', "bias4"), ("B3", '"s"', "bias3"), ("WPP", '"s"', "wpa"), ("CRL", '"v"', "crl_addr"), ("ATB", '"v"', "atb_addr")]
         for r in range(nout):
             self.ins.append((f"ADDR{r}", '"v"', f"addr[{r}]"))
         for r in range(nout):
@@ -202,128 +208,113 @@ def kblock(par, first, last, o):
 
 
 # ------------------------------------------------------------------------------------------------ reduction
+class Unit(list):
+    """lines that stay together in the merged stream; w = its share of room there"""
+    w = 1.0
+
+
 def masked(o, r, mode_value, body):
     """body under exec & (mode == mode_value): one unit, never interleaved with the MFMA stream"""
-    return [[f"s_mov_b64 s[{S_SAVE}:{S_SAVE + 1}], exec",
-             f"v_cmp_eq_u32_e32 vcc, {mode_value}, {o(f'MODE{r}')}",
-             "s_and_b64 exec, exec, vcc"] + body + [f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]"]]
+    return [Unit([f"s_mov_b64 s[{S_SAVE}:{S_SAVE + 1}], exec",
+                  f"v_cmp_eq_u32_e32 vcc, {mode_value}, {o(f'MODE{r}')}",
+                  "s_and_b64 exec, exec, vcc"] + body + [f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]"])]
 
 
-def digit(o, r, k, dst):
-    """dst = digit k (29 bits) of the 17 words of output r"""
-    bit = LB * k
-    j, sft = bit >> 5, bit & 31
-    w = lambda i: o(f"W{r}_{i}")  # noqa: E731
-    if sft == 0:
-        return [f"v_and_b32 v{dst}, {MASK}, {w(j)}"]
-    if j + 1 >= NWORDS:
-        return [f"v_lshrrev_b32 v{dst}, {sft}, {w(j)}", f"v_and_b32 v{dst}, {MASK}, v{dst}"]
-    return [f"v_alignbit_b32 v{dst}, {w(j + 1)}, {w(j)}, {sft}", f"v_and_b32 v{dst}, {MASK}, v{dst}"]
+def fold_loads(o, i):
+    """A operand of fold step i = (byte half ks, column block eb) -> buffer i % 4: row i of the table at LDS offset 0 (272 bytes per
+    row: sixteen lanes' 16 digits, then 16 zero bytes for the lanes outside the diagonal block -- their base points there)"""
+    b = AB[i % 4]
+    return f"ds_read_b128 v[{b}:{b + 3}], {o('ATB')} offset:{FOLD_ROW * i}"
 
 
-def row_reads(addr, off, buf):
-    """nine digits of a 48-byte LDS row -> TB[buf] (two 16-byte reads and one dword: the third buffer has nine registers)"""
-    b = TB[buf]
-    return [f"ds_read_b128 v[{b}:{b + 3}], {addr} offset:{off}",
-            f"ds_read_b128 v[{b + 4}:{b + 7}], {addr} offset:{off + 16}",
-            f"ds_read_b32 v{b + 8}, {addr} offset:{off + 32}"]
-
-
-def t_reads(k):
-    return row_reads(f"v{ZERO}", 48 * k, k % 3)
-
-
-def cpair(j):
-    return f"v[{C0 + 2 * j}:{C0 + 2 * j + 1}]"
-
-
-def carry(upto):
-    """columns 0 .. upto-1 keep 29 bits, the rest moves up"""
-    L = []
-    for j in range(upto):
-        L += [f"v_lshrrev_b64 v[{T2}:{T2 + 1}], {LB}, {cpair(j)}",
-              f"v_and_b32 v{C0 + 2 * j}, {MASK}, v{C0 + 2 * j}",
-              f"v_lshl_add_u64 {cpair(j + 1)}, v[{T2}:{T2 + 1}], 0, {cpair(j + 1)}"]
-    return L
-
-
-def reduce_output(o, r, check, nfold=10):
+def reduce_output(o, r, check):
     """units (lists of lines) reducing output r's 17 words and storing / comparing the canonical element.
-    nfold = 10: all 19 digits of the biased sum; nfold = 9: the sum is known to stay below 2^(29 * 18) (the launcher checks the
-    bias against that bound: any matrix of fewer than 64 terms), digit 18 is zero and its fold is not emitted."""
-    assert nfold in (9, 10)
+
+    S = L + 2^256 H + 2^512 W16 (L, H eight words each).  The high half goes back through the matrix cores: with H's 32 bytes h_b,
+    2^256 H = sum_b h_b 2^(256 + 8 b) = sum_b h_b t_b (mod p), t_b = 2^(256 + 8 b) mod p or that minus p, whichever has 32 balanced
+    base-256 digits s_(b, e).  A lane (n, g) holds the words of ITS output, so the product runs block-diagonally: the B operand is
+    16 bytes of H (biased by XOR 0x80 like every int8 input here), the A operand of lane (m, g') is s_(16 ks + pos, 4 eb + m % 4) when
+    g' = m / 4 and zero otherwise, and D[m][n] = column 4 eb + m % 4 of the fold of output (4 (m / 4) + j, n) lands in lane
+    (n, m / 4), register m % 4: the lane that owns that output.  16 MFMAs per output (2 byte halves x 8 column blocks) replace the
+    ten-digit fold on the VALU (90 MADs and the digit extraction).  Then, in 32-bit words w < 8,
+        P_w = [bias of the four columns + row constant word] + sum_k D_(4 w + k) 2^(8 k) + L_w + W16 (2^512 mod p)_w      (< 2^49)
+    (the row constant carries 128 sum_b t_b and the column biases, hb_mfma_wide.hip), R = sum_w P_w 2^(32 w) < 2^272, the quotient
+    qhat = floor(floor(R / 2^240) mu / 2^46), mu = floor(2^286 / p), is floor(R / p) or one less, u_w = qhat (2^256 - p)_w + P_w,
+    and the words of sum_w u_w 2^(32 w) are R - qhat p with qhat on top of bit 256; one conditional subtraction of p.
+    (scratch/model_mfma_fold.py is this arithmetic in big integers, bounds asserted.)"""
     U = []
-    one = lambda ln: U.append([ln])  # noqa: E731
+    wt = [1.0]
+    def one(ln):
+        u = Unit([ln]); u.w = wt[0]; U.append(u)
+    w = lambda i: o(f"W{r}_{i}")  # noqa: E731
     if check:
         # the received row: from HBM, a microsecond away -- requested first, compared last
         U += masked(o, r, 2, ["@ELOAD", f"global_load_dwordx4 v[{EX}:{EX + 3}], {o(f'ADDR{r}')}, off",
                               f"global_load_dwordx4 v[{EX + 4}:{EX + 7}], {o(f'ADDR{r}')}, off offset:16"])
-    # per-row constant -> TB[2], T_9 -> TB[0], T_10 -> TB[1]; the rows are requested THREE steps ahead of their use: one wave
-    # per SIMD has only its own instructions (and the MFMAs between them) to cover the LDS latency
-    for ln in row_reads(o("CRL"), 256 * r, 2) + t_reads(0) + t_reads(1):          # output r's row is 4 r rows (64 B each) further on
-        one(ln)
-    one("s_waitcnt lgkmcnt(6)")
-    for j in range(9):
-        for ln in digit(o, r, j, T1):
-            one(ln)
-        one(f"v_add_u32 v{C0 + 2 * j}, v{T1}, v{TB[2] + j}")
-        one(f"v_mov_b32 v{C0 + 2 * j + 1}, 0")
-    one(f"v_mov_b32 v{C0 + 18}, 0")
-    one(f"v_mov_b32 v{C0 + 19}, 0")
-    for ln in t_reads(2):
-        one(ln)
-    # V += s_(9+k) T_k
-    for k in range(nfold):
-        for ln in digit(o, r, 9 + k, SK):
-            one(ln)
-        one(f"s_waitcnt lgkmcnt({3 * min(2, nfold - 1 - k)})")
-        b = TB[k % 3]
-        for j in range(9):
-            one(f"v_mad_u64_u32 {cpair(j)}, vcc, v{SK}, v{b + j}, {cpair(j)}")
-        if k + 3 < nfold:
-            for ln in t_reads(k + 3):
-                one(ln)
-    for ln in carry(9):
-        one(ln)
-    v8, v9 = C0 + 16, C0 + 18
-    # qhat = floor(floor(V / 2^232) mu / 2^58): floor(V / p) or one less
-    for ln in [f"v_mad_u64_u32 v[{QP}:{QP + 1}], vcc, v{v8}, s{S_M0}, 0",
-               f"v_lshrrev_b64 v[{QP}:{QP + 1}], {LB}, v[{QP}:{QP + 1}]",
-               f"v_mad_u64_u32 v[{QP}:{QP + 1}], vcc, v{v8}, s{S_M1}, v[{QP}:{QP + 1}]",
-               f"v_mad_u64_u32 v[{QP}:{QP + 1}], vcc, v{v9}, s{S_M0}, v[{QP}:{QP + 1}]",
-               f"v_lshrrev_b64 v[{QP}:{QP + 1}], {LB}, v[{QP}:{QP + 1}]",
-               f"v_mad_u64_u32 v[{QP}:{QP + 1}], vcc, v{v9}, s{S_M1}, v[{QP}:{QP + 1}]",
-               f"v_and_b32 v{Q0}, {MASK}, v{QP}",
-               f"v_alignbit_b32 v{Q1}, v{QP + 1}, v{QP}, {LB}"]:
-        one(ln)
-    # V + q (2^261 - p), nine digits (what leaves digit 8 is the 2^261 q that was added)
-    for j in range(9):
-        one(f"v_mov_b32 v{C0 + 2 * j + 1}, 0")
-        one(f"v_mad_u64_u32 {cpair(j)}, vcc, v{Q0}, s{S_PBAR + j}, {cpair(j)}")
-        if j > 0:
-            one(f"v_mad_u64_u32 {cpair(j)}, vcc, v{Q1}, s{S_PBAR + j - 1}, {cpair(j)}")
-    for ln in carry(8):
-        one(ln)
-    one(f"v_and_b32 v{C0 + 16}, {MASK}, v{C0 + 16}")
-    # nine digits -> eight words
-    one(f"v_lshl_or_b32 v{OW}, v{C0 + 2}, {LB}, v{C0}")
-    for j in range(1, 8):
-        one(f"v_lshrrev_b32 v{T1}, {3 * j}, v{C0 + 2 * j}")
-        one(f"v_lshl_or_b32 v{OW + j}, v{C0 + 2 * j + 2}, {LB - 3 * j}, v{T1}")
-    # conditional subtraction: the carry out of ow + (2^256 - p) says ow >= p.  One unit: the carry chain lives in vcc
-    # (an SGPR operand beside the carry in vcc would be two constant-bus reads: 2^256 - p goes through the free T buffer)
+    # the fold's lines are given SPREAD times the room of the others in the merged stream: what stands between an operand's LDS
+    # read and the MFMA that takes it is three steps of three lines plus the main stream's share -- a wave alone on its SIMD has
+    # nothing else to cover the LDS latency with
+    wt[0] = SPREAD
+    for i in range(3):
+        if "nofload" not in ABLATE:
+            one(fold_loads(o, i))
+    for i in range(8):
+        one(f"v_xor_b32 v{HB + i}, 0x80808080, {w(8 + i)}")
+    for i in range(16):
+        ks, eb = divmod(i, 8)
+        d0 = D0 + 4 * eb
+        if "nofwait" not in ABLATE and "nofload" not in ABLATE:
+            one(f"s_waitcnt lgkmcnt({min(2, 15 - i)})")
+        cin = "0" if ks == 0 else f"v[{d0}:{d0 + 3}]"
+        if "nofmfma" not in ABLATE:
+            one(f"v_mfma_i32_16x16x64_i8 v[{d0}:{d0 + 3}], v[{AB[i % 4]}:{AB[i % 4] + 3}], v[{HB + 4 * ks}:{HB + 4 * ks + 3}], {cin}")
+        if i + 3 < 16 and "nofload" not in ABLATE:
+            one(fold_loads(o, i + 3))
+    wt[0] = 1.0
+    # the eight pairs [bias + row constant word] of output r's row (64 bytes; output r's row is 4 r rows further on) -> P, over the
+    # operand registers of the MFMAs just issued (they have read them; the loads land a hundred cycles later)
+    for i in range(4):
+        one(f"ds_read_b128 v[{PB + 4 * i}:{PB + 4 * i + 3}], {o('CRL')} offset:{256 * r + 16 * i}")
+    pp = lambda j: f"v[{PB + 2 * j}:{PB + 2 * j + 1}]"  # noqa: E731
     for j in range(8):
-        one(f"v_mov_b32 v{TB[1] + j}, s{S_PNEG + j}")
-    # r < 2p < 2^257: bit 256 of r (bit 24 of the top digit; the eight words drop it) also means r >= p, and r - p is the
-    # same sum mod 2^256.  It joins the carry chain as a ninth word: hi + 0xffffffff + carry carries out iff hi or carry.
-    cs = [f"v_lshrrev_b32 v{T1}, 24, v{C0 + 16}",
-          f"v_add_co_u32_e32 v{UB}, vcc, v{TB[1]}, v{OW}"]
+        if j % 2 == 0:
+            one(f"s_waitcnt lgkmcnt({3 - j // 2})")
+        one(f"v_mad_u64_u32 {pp(j)}, vcc, {w(j)}, 1, {pp(j)}")
+    for j in range(8):
+        one(f"v_mad_u64_u32 {pp(j)}, vcc, {w(16)}, s{S_C512 + j}, {pp(j)}")
+    # (an MFMA's result may be read by the VALU 18 issue slots after it at the earliest: the 21 lines above stand between)
+    K = {0: "1", 1: o("K256"), 2: o("K64K"), 3: o("K16M")}
+    for k in range(4):
+        for j in range(8):
+            one(f"v_mad_i64_i32 {pp(j)}, vcc, v{D0 + 4 * j + k}, {K[k]}, {pp(j)}")
+    for ln in [f"v_mad_u64_u32 v[{TP}:{TP + 1}], vcc, v{PB + 13}, 1, {pp(7)}",
+               f"v_alignbit_b32 v{TP}, v{TP + 1}, v{TP}, 16",
+               f"v_mad_u64_u32 v[{TP}:{TP + 1}], vcc, v{TP}, s{S_MU}, 0",
+               f"v_lshrrev_b32 v{Q}, 14, v{TP + 1}"]:
+        one(ln)
+    for j in range(8):
+        one(f"v_mad_u64_u32 {pp(j)}, vcc, v{Q}, s{S_PNEG + j}, {pp(j)}")
+    # words of sum_w u_w 2^(32 w); what stands above bit 256 is qhat plus bit 256 of the remainder.  One unit: the carry lives in vcc
+    cp = [f"v_mov_b32 v{OW}, v{PB}",
+          f"v_add_co_u32_e32 v{OW + 1}, vcc, v{PB + 2}, v{PB + 1}"]
+    for j in range(2, 8):
+        cp.append(f"v_addc_co_u32_e32 v{OW + j}, vcc, v{PB + 2 * j}, v{PB + 2 * j - 1}, vcc")
+    cp += [f"v_addc_co_u32_e32 v{T1}, vcc, 0, v{PB + 15}, vcc",
+           f"v_sub_u32_e32 v{T1}, v{T1}, v{Q}"]
+    U.append(Unit(cp))
+    # conditional subtraction: the carry out of ow + (2^256 - p) says ow >= p.  One unit: the carry chain lives in vcc
+    # (an SGPR operand beside the carry in vcc would be two constant-bus reads: 2^256 - p goes through registers)
+    for j in range(8):
+        one(f"v_mov_b32 v{PN + j}, s{S_PNEG + j}")
+    # r < 2p < 2^257: bit 256 of r (T1) also means r >= p, and r - p is the same sum mod 2^256.  It joins the carry chain as a
+    # ninth word: T1 + 0xffffffff + carry carries out iff T1 or carry.
+    cs = [f"v_add_co_u32_e32 v{UB}, vcc, v{PN}, v{OW}"]
     for j in range(1, 8):
-        cs.append(f"v_addc_co_u32_e32 v{UB + j}, vcc, v{TB[1] + j}, v{OW + j}, vcc")
+        cs.append(f"v_addc_co_u32_e32 v{UB + j}, vcc, v{PN + j}, v{OW + j}, vcc")
     cs.append(f"v_addc_co_u32_e32 v{T1}, vcc, -1, v{T1}, vcc")
     for j in range(8):
         cs.append(f"v_cndmask_b32_e32 v{OW + j}, v{OW + j}, v{UB + j}, vcc")
-    U.append(cs)
+    U.append(Unit(cs))
     if check:
         cmp = ["@EWAIT"]
         for j in range(8):
@@ -332,14 +323,13 @@ def reduce_output(o, r, check, nfold=10):
                 f"v_or3_b32 v{DIFF + 3}, v{DIFF + 3}, v{DIFF + 4}, v{DIFF + 5}",
                 f"v_or3_b32 v{DIFF}, v{DIFF}, v{DIFF + 6}, v{DIFF + 7}",
                 f"v_or_b32 v{DIFF}, v{DIFF}, v{DIFF + 3}"]
-        U.append(cmp)
+        U.append(Unit(cmp))
         U += masked(o, r, 2, [f"v_cmp_ne_u32_e32 vcc, 0, v{DIFF}", f"s_or_b64 {o('FLAG')}, {o('FLAG')}, vcc"])
     U += masked(o, r, 1, [f"global_store_dwordx4 {o(f'ADDR{r}')}, v[{OW}:{OW + 3}], off",
                           f"global_store_dwordx4 {o(f'ADDR{r}')}, v[{OW + 4}:{OW + 7}], off offset:16"])
     return U
 
 
-ABLATE = os.environ.get("HB_GEN_MM8W_ABLATE", "").split(",")    # timing experiments only (wrong results): nored, notail, nofold, nommfa
 
 
 def merge(stream, units):
@@ -349,14 +339,16 @@ def merge(stream, units):
     if "nomfma" in ABLATE:
         stream = [ln for ln in stream if not ln.startswith("v_mfma")] + [f"v_mfma_i32_16x16x64_i8 a[0:3], v[{ABUF[0][0]}:{ABUF[0][0] + 3}], v[{F_SETS[0]}:{F_SETS[0] + 3}], a[0:3]"]
     n_mfma = sum(1 for ln in stream if ln.startswith("v_mfma"))
-    out, done, seen = [], 0, 0
+    total = sum(u.w * len(u) for u in units)
+    out, done, seen, placed = [], 0, 0, 0.0
     for ln in stream:
         out.append(ln)
         if ln.startswith("v_mfma"):
             seen += 1
-            want = (len(units) * seen + n_mfma - 1) // n_mfma
-            while done < want:
+            want = total * seen / n_mfma
+            while done < len(units) and (placed < want - 1e-9 or seen == n_mfma):
                 out += units[done]
+                placed += units[done].w * len(units[done])
                 done += 1
     assert done == len(units)
     return out
@@ -390,9 +382,8 @@ def resolve_waits(lines):
 
 
 def consts(o):
-    return [f"s_load_dwordx16 s[{S_PBAR}:{S_PBAR + 15}], {o('WPP')}, 0x0",
-            f"s_load_dwordx4 s[{S_PBAR + 16}:{S_PBAR + 19}], {o('WPP')}, 0x40",
-            f"v_mov_b32 v{ZERO}, 0"]
+    return [f"s_load_dwordx16 s[{S_PNEG}:{S_PNEG + 15}], {o('WPP')}, 0x0",
+            f"s_load_dwordx4 s[{S_PNEG + 16}:{S_PNEG + 19}], {o('WPP')}, 0x40"]
 
 
 # ------------------------------------------------------------------------------------------------ tail
@@ -430,11 +421,22 @@ def tail(o):
 
 
 def split(units, parts):
-    n = len(units)
-    return [units[n * i // parts:n * (i + 1) // parts] for i in range(parts)]
+    """consecutive shares of equal room"""
+    total = sum(u.w * len(u) for u in units)
+    out, cur, acc = [], [], 0.0
+    for u in units:
+        if len(out) < parts - 1 and acc >= total * (len(out) + 1) / parts - 1e-9:
+            out.append(cur)
+            cur = []
+        cur.append(u)
+        acc += u.w * len(u)
+    out.append(cur)
+    while len(out) < parts:
+        out.append([])
+    return out
 
 
-def pass_lines(check, peel, nout=4, nfold=10):
+def pass_lines(check, peel, nout=4):
     """`peel` K-blocks are straight-line code carrying the reduction of the pass before, in equal shares (one wave per SIMD
     issues an instruction every ~5.5 cycles at best -- profiles/r01_mad_issue_rate_vs_occupancy.txt, r02_mm8w_phase_timing.txt --
     so everything a pass executes counts); the other nkb - peel K-blocks run as a loop of two-block bodies in the middle (the digit
@@ -450,7 +452,7 @@ def pass_lines(check, peel, nout=4, nfold=10):
     L += prep(0) + ["s_nop 1"]                      # (its lgkmcnt(0) also covers the scalar loads)
     units = []
     for r in range(nout):
-        units += reduce_output(o, r, check, nfold)
+        units += reduce_output(o, r, check)
     shares = split(units, peel)
     head = (peel + 1) // 2
     for i in range(peel):
@@ -467,11 +469,11 @@ def pass_lines(check, peel, nout=4, nfold=10):
     return o, resolve_waits(L)
 
 
-def reduce_lines(check, nout=4, nfold=10):
+def reduce_lines(check, nout=4):
     o = Ops(check, nout)
     L = consts(o) + ["s_waitcnt lgkmcnt(0)"]
     for r in range(nout):
-        for u in reduce_output(o, r, check, nfold):
+        for u in reduce_output(o, r, check):
             L += u
     return o, resolve_waits(L)
 
@@ -480,7 +482,7 @@ def emit_fn(name, o, lines, check):
     out = []
     n = o.nout
     sig = (f"uint32_t (&w)[{n}][17], uint32_t &xa, uint32_t &va, uint32_t &cnt, uint64_t &flag, uint64_t abase, int32_t k256, int32_t k64k, "
-           f"int32_t k16m, int64_t bias4, int64_t bias3, uint64_t wpa, uint32_t crl_addr, const uint64_t (&addr)[{n}], "
+           f"int32_t k16m, int64_t bias4, int64_t bias3, uint64_t wpa, uint32_t crl_addr, uint32_t atb_addr, const uint64_t (&addr)[{n}], "
            f"const uint32_t (&mode)[{n}]")
     out.append(f"static __device__ __forceinline__ void {name}({sig}) {{")
     if not check:
@@ -490,7 +492,7 @@ def emit_fn(name, o, lines, check):
         out.append(f'        "{ln}\\n\\t"')
     out.append("        : " + ", ".join(f"{c}({e})" for _, c, e in o.outs))
     out.append("        : " + ", ".join(f"{c}({e})" for _, c, e in o.ins))
-    clob = [f'"v{r}"' for r in range(RB, 256)] + [f'"a{r}"' for r in range(4 * NC)] + [f'"s{r}"' for r in range(S_PBAR, S_SAVE + 2)]
+    clob = [f'"v{r}"' for r in range(RB, 256)] + [f'"a{r}"' for r in range(4 * NC)] + [f'"s{r}"' for r in range(S_PNEG, S_SAVE + 2)]
     out.append("        : " + ", ".join(clob) + ', "vcc", "scc", "memory");')
     out.append("}")
     out.append("")
@@ -502,16 +504,14 @@ PEELS = (1, 2, 3, 4)
 
 def emit():
     out = ["// GENERATED by gen_mm8w.py -- do not edit", ""]
-    for nfold in (10, 9):
-        fs = "" if nfold == 10 else "_f9"
-        for check in (False, True):
-            sfx = "_check" if check else ""
-            for nout in (4, 3, 2):
-                for peel in PEELS:
-                    o, lines = pass_lines(check, peel, nout, nfold)
-                    out += emit_fn(f"mm8w_pass{sfx}{fs}_p{peel}_k{nout}", o, lines, check)
-                o, lines = reduce_lines(check, nout, nfold)
-                out += emit_fn(f"mm8w_reduce{sfx}{fs}_k{nout}", o, lines, check)
+    for check in (False, True):
+        sfx = "_check" if check else ""
+        for nout in (4, 3, 2):
+            for peel in PEELS:
+                o, lines = pass_lines(check, peel, nout)
+                out += emit_fn(f"mm8w_pass{sfx}_p{peel}_k{nout}", o, lines, check)
+            o, lines = reduce_lines(check, nout)
+            out += emit_fn(f"mm8w_reduce{sfx}_k{nout}", o, lines, check)
     return "\n".join(out)
 
 

@@ -16,11 +16,13 @@
 // A workgroup owns a unit of `tpw` tiles of 16 chunks, DMA'd into LDS in MFMA-operand order; its 4 waves take the
 // (tile, row tile) pairs.  The digits stream from L2 inside the MFMA phase.
 // A pass is ONE asm statement (gen_mm8w.py), software-pipelined over passes: it ends by moving its sums out of the
-// AGPRs as 17 words per output, and the NEXT pass reduces them mod p between its own MFMAs -- 19 radix-2^29 digits,
-// fold of the ten high digits through T_k = 2^(29k) mod p (90 MADs) + per-row constant, two-digit Barrett quotient (as
-// k_prescale_tab, hb_fast.hip), conditional subtraction -- and stores the canonical element or compares it with a
-// received one (the fused decode + validate of hb_open.hip).  A wave alone on its SIMD issues one instruction every
-// ~5.5 cycles whatever its kind, so every instruction taken out of the serial part of a pass counts.
+// AGPRs as 17 words per output, and the NEXT pass reduces them mod p between its own MFMAs -- the high eight words go
+// back through the matrix cores against t_b = 2^(256 + 8b) mod p (a block-diagonal product: 16 MFMAs per output,
+// round 3; round 2 folded ten radix-2^29 digits on the VALU, 90 MADs), the columns of that, the low words, the top
+// word and the per-row constant are gathered per 32-bit word, a one-word Barrett quotient, conditional subtraction --
+// and stores the canonical element or compares it with a received one (the fused decode + validate of hb_open.hip).
+// A wave alone on its SIMD issues one instruction every ~5.5 cycles whatever its kind, so every instruction taken out
+// of the serial part of a pass counts.
 // Inputs are biased by XOR 0x80 (int8 operands are signed); the per-row constant takes that and the accumulator
 // bias back out, mod p.  No Montgomery form anywhere.
 #include <algorithm>
@@ -34,16 +36,20 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int MM8W_NC = 63;     // int32 columns per output
 constexpr int MM8W_WORDS = 17;  // 32-bit words of the biased sum
-constexpr int MM8W_SD = 19;     // its radix-2^29 digits
+constexpr int MM8W_FOLD_ROW = 272;   // bytes per row of the fold table: sixteen lanes' 16 digits, then 16 zero bytes (gen_mm8w.py: FOLD_ROW)
+constexpr int MM8W_FOLD_Q = 16 * MM8W_FOLD_ROW / 16;   // the table in uint4
 
 struct WideParams {     // the asm passes fetch the first 20 dwords by scalar loads (gen_mm8w.py: s68 .. s87)
-    uint32_t pbar[9];    // 2^261 - p, digits
     uint32_t pneg[8];    // 2^256 - p, words
-    uint32_t m0, m1;     // floor(2^290 / p), digits
-    uint32_t pad;
-    uint32_t T[10][9];   // 2^(29 (9 + k)) mod p, digits
+    uint32_t mu;         // floor(2^286 / p)
+    uint32_t c512[8];    // 2^512 mod p, words
+    uint32_t pad[3];
+    // the A operands of the fold: row i = (byte half ks = i / 8, column block eb = i % 8), lane m < 16 of its diagonal block holds
+    // the balanced digits s_(16 ks + pos, 4 eb + m % 4), pos < 16, of t_b = 2^(256 + 8 b) mod p (or that minus p)
+    uint8_t fold[16][MM8W_FOLD_ROW];
 };
-static_assert(offsetof(WideParams, T) == 80, "gen_mm8w.py loads pbar, pneg, m0, m1 from offsets 0 .. 75");
+static_assert(offsetof(WideParams, fold) == 80, "gen_mm8w.py loads pneg, mu, c512 from offsets 0 .. 67");
+static_assert(sizeof(WideParams) == 80 + 16 * MM8W_FOLD_ROW, "the kernel copies the fold table as uint4");
 
 struct Mm8wMatrix {
     int n_out, d, nkb, n_rt;
@@ -52,7 +58,7 @@ struct Mm8wMatrix {
     mutable int shape_tpw, shape_nbuf, shape_rq;
     int4 *a8;          // [n_rt][nkb][4 digit groups][64 lanes] 16 bytes each (+ one block of padding): lane (r, g) = row
                        // 16 rt + 4 (r % 4) + r / 4, terms 8 kb + 2 g and + 1, eight digits of group G each
-    uint32_t *crow;    // [n_rt * 16][16]: 9 radix-2^29 digits of the per-row constant
+    uint32_t *crow;    // [n_rt * 16][16]: 9 radix-2^29 digits of the per-row constant (in [0, p); the kernel turns them into words + column bias)
     uint32_t *zero;    // 32 zero bytes: DMA source for inputs beyond in_count
     uint32_t bias;     // >= every |column| of every row
     WideParams *wp;    // device copy: the reduction constants are fetched by scalar loads where they are used
@@ -69,8 +75,7 @@ __device__ unsigned long long g_mm8w_t[1024 * 8];
 #endif
 
 // K = outputs kept per lane: 4 (row tiles of 16 rows), 3 (row tiles of 12: the fourth row of every group of the MFMA tile is padding) or 2 (8)
-// NF = digits of the sum folded through T_k: 10, or 9 when the launcher has checked the bias against 2^(29 * 18) (fewer than 64 terms)
-template <bool CHECK, int PEEL, int K, int NF>
+template <bool CHECK, int PEEL, int K>
 __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
                                                  const uint32_t *__restrict__ zero_src,
                                                  const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
@@ -83,9 +88,9 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     extern __shared__ uint4 mm8w_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
-    uint4 *tlds = mm8w_lds;                                                 // LDS offset 0 (the asm reads it by immediate offsets): [10][3] uint4: T_k, 9 digits + 3 pad
-    uint32_t *crl = reinterpret_cast<uint32_t *>(mm8w_lds + 32);            // [n_rt * 16][16]
-    uint4 *xbuf = mm8w_lds + 32 + n_rt * 64;                                // nbuf x [tpw][nkb][2 elements][2 halves][64] uint4, then 2 KB of slack
+    uint4 *tlds = mm8w_lds;                                                 // LDS offset 0: the fold table, 16 rows of 272 bytes (WideParams::fold)
+    uint32_t *crl = reinterpret_cast<uint32_t *>(mm8w_lds + MM8W_FOLD_Q);   // [n_rt * 16][16]: per row eight pairs [column bias + constant word]
+    uint4 *xbuf = mm8w_lds + MM8W_FOLD_Q + n_rt * 64;                       // nbuf x [tpw][nkb][2 elements][2 halves][64] uint4, then 2 KB of slack
     const int bufsz = tpw * nkb * 4 * 64;
     int64_t *rowoff = reinterpret_cast<int64_t *>(xbuf + (size_t)nbuf * bufsz + 128);   // [8 nkb] term -> element offset of its input row
     uint64_t *rowdst = reinterpret_cast<uint64_t *>(rowoff + 8 * nkb);      // [16 n_rt] where row i's elements go: address of its chunk 0 | mode (1 store, 2 compare), 0 = nowhere
@@ -148,6 +153,8 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     // pass's MFMA phase (gen_mm8w.py).  mode: 0 nothing, 1 store to addr, 2 compare with the row at addr.
     uint32_t w[K][17];
     uint32_t crl_addr, mode[K];
+    // the fold's A operand: lane (m, g') of the diagonal block g' = m / 4 reads its 16 digits, every other lane the row's 16 zero bytes
+    const uint32_t atb_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)tlds + (g == (n >> 2) ? 16u * (uint32_t)n : 256u);
     uint64_t addr[K], flag = 0;
     crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)crl;
 #pragma unroll
@@ -166,11 +173,21 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
 #endif
     if (unit < n_units) issue_loads(unit, 0);
     // the other tables are filled while the first unit's tiles are in flight (the DMA only needs the row offsets)
-    if (threadIdx.x < 120) {
-        const int k = threadIdx.x / 12, j = threadIdx.x % 12;
-        reinterpret_cast<uint32_t *>(tlds)[threadIdx.x] = j < 9 ? wpp->T[k][j] : 0u;
+    {
+        const uint4 *fsrc = reinterpret_cast<const uint4 *>(wpp->fold);
+        for (int i = threadIdx.x; i < MM8W_FOLD_Q; i += 256) tlds[i] = fsrc[i];
     }
-    for (int i = threadIdx.x; i < n_rt * 16 * 16; i += 256) crl[i] = crowd[i];
+    // per row: the constant's nine digits -> eight words, each with the bias of the fold's four columns (2^20 each) as one 64-bit addend
+    for (int i = threadIdx.x; i < n_rt * 16 * 8; i += 256) {
+        const int row = i >> 3, j = i & 7, bit = 32 * j, k = bit / 29, sft = bit - 29 * k;
+        const uint32_t *dg = crowd + row * 16;
+        uint64_t v = (uint64_t)dg[k] >> sft;
+        v |= (uint64_t)dg[k + 1] << (29 - sft);                 // k + 1 <= 8
+        if (k + 2 < 9 && 58 - sft < 32) v |= (uint64_t)dg[k + 2] << (58 - sft);
+        const uint64_t pair = (v & 0xffffffffull) + ((0x1010ull << 32) | 0x10100000ull);
+        crl[row * 16 + 2 * j] = (uint32_t)pair;
+        crl[row * 16 + 2 * j + 1] = (uint32_t)(pair >> 32);
+    }
     for (int i = threadIdx.x; i < n_rt * 16; i += 256) {
         uint64_t e = 0;
         const int row = (i >> 4) * (4 * K) + (i & 15);          // slot i = 16 rt + 4 r + g holds row 4 K rt + 4 r + g when r < K
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                 const uint64_t abase = (uint64_t)(uintptr_t)(a8 + (size_t)rt * nkb * 4 * 64);
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-#define MM8W_ARGS w, xa, va, cnt, flag, abase, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
+#define MM8W_ARGS w, xa, va, cnt, flag, abase, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, atb_addr, addr, mode
 #define MM8W_PASS(SFX)                                                                     \
     do {                                                                                   \
         if constexpr (K == 4) {                                                            \
@@ -222,8 +239,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             else mm8w_pass##SFX##_p4_k2(MM8W_ARGS);                                        \
         }                                                                                  \
     } while (0)
-                if constexpr (NF == 9) { if constexpr (CHECK) MM8W_PASS(_check_f9); else MM8W_PASS(_f9); }
-                else { if constexpr (CHECK) MM8W_PASS(_check); else MM8W_PASS(); }
+                if constexpr (CHECK) MM8W_PASS(_check); else MM8W_PASS();
 #undef MM8W_PASS
 #undef MM8W_ARGS
                 __builtin_amdgcn_sched_barrier(0);
@@ -274,14 +290,9 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     {
         uint32_t xa = 0, va = 0, cnt = 0;
         __builtin_amdgcn_sched_barrier(0);
-#define MM8W_ARGS w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, addr, mode
-        if constexpr (NF == 9) {
-            if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_f9_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_check_f9_k3(MM8W_ARGS); else mm8w_reduce_check_f9_k2(MM8W_ARGS); }
-            else { if constexpr (K == 4) mm8w_reduce_f9_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_f9_k3(MM8W_ARGS); else mm8w_reduce_f9_k2(MM8W_ARGS); }
-        } else {
-            if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_check_k3(MM8W_ARGS); else mm8w_reduce_check_k2(MM8W_ARGS); }
-            else { if constexpr (K == 4) mm8w_reduce_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_k3(MM8W_ARGS); else mm8w_reduce_k2(MM8W_ARGS); }
-        }
+#define MM8W_ARGS w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, atb_addr, addr, mode
+        if constexpr (CHECK) { if constexpr (K == 4) mm8w_reduce_check_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_check_k3(MM8W_ARGS); else mm8w_reduce_check_k2(MM8W_ARGS); }
+        else { if constexpr (K == 4) mm8w_reduce_k4(MM8W_ARGS); else if constexpr (K == 3) mm8w_reduce_k3(MM8W_ARGS); else mm8w_reduce_k2(MM8W_ARGS); }
 #undef MM8W_ARGS
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -355,8 +366,88 @@ void to_digits(const Big &v, uint32_t *dg, int nd) {
     }
 }
 
+// x <- 2 x mod p (x < p, both n words)
+void big_dbl_mod(Big &x, const Big &p) {
+    uint32_t top = 0;
+    for (size_t i = 0; i < x.size(); i++) { const uint32_t nt = x[i] >> 31; x[i] = (x[i] << 1) | top; top = nt; }
+    if (top || big_ge(x, p)) big_sub(x, p);       // 2x < 2p < 2^(32 n + 1): one subtraction, mod 2^(32 n) when the top bit left
+}
+
+// The constants of the reduction (gen_mm8w.py, reduce_output): the fold table of t_b = 2^(256 + 8 b) mod p, mu = floor(2^286 / p),
+// 2^512 mod p, 2^256 - p -- and what the fold adds to every sum, which the per-row constants take back out:
+// fold_shift = (128 sum_b t_b - sum_e 2^20 2^(8 e)) mod p (the operand bias of XOR 0x80 and the bias of the fold's columns).
+struct FoldConsts { WideParams wp; Big shift; };
+bool fold_consts(hb_ctx *ctx, FoldConsts *fc) {
+    const Big p = big_from_limbs(ctx->p_limbs, 4);
+    memset(&fc->wp, 0, sizeof fc->wp);
+    memcpy(fc->wp.pneg, ctx->psc.pneg, sizeof fc->wp.pneg);
+    Big T = big_mod(big_pow2(256, 9), p);          // t_0; then t_(b+1) = 256 t_b mod p
+    Big tsum(10, 0);
+    for (int b = 0; b < 32; b++) {
+        big_add(tsum, T);
+        // 32 balanced digits of T, or of T - p (two's complement over ten words) when T needs a 33rd
+        int8_t dg[32];
+        bool ok = false;
+        for (int rep_i = 0; rep_i < 2 && !ok; rep_i++) {
+            Big v(T); v.resize(10, 0);
+            if (rep_i) big_sub(v, p);
+            int carry = 0;
+            for (int k = 0; k < 32; k++) {
+                int t = (int)((v[k >> 2] >> (8 * (k & 3))) & 0xffu) + carry;
+                if (t > 127) { t -= 256; carry = 1; } else carry = 0;
+                dg[k] = (int8_t)t;
+            }
+            const uint64_t rest = (((uint64_t)v[9] << 32) | v[8]) + (uint64_t)carry;
+            ok = rest == 0;
+        }
+        if (!ok) return false;                      // cannot happen for p < 2^256: one of the two lies in [-0.502, 0.498] 2^256
+        const int ks = b / 16, pos = b % 16;
+        for (int e = 0; e < 32; e++) {
+            const int eb = e / 4, r = e % 4;
+            for (int G = 0; G < 4; G++) fc->wp.fold[ks * 8 + eb][16 * (4 * G + r) + pos] = (uint8_t)dg[e];   // lane m = 4 G + r of block G
+        }
+        for (int k = 0; k < 8; k++) big_dbl_mod(T, p);
+    }
+    for (int j = 0; j < 8; j++) fc->wp.c512[j] = T[j];           // t_32 = 2^512 mod p
+    // mu = floor(2^286 / p) by binary long division
+    {
+        Big r(9, 0), pp(p); pp.push_back(0);
+        uint64_t q = 0;
+        for (int bit = 286; bit >= 0; bit--) {
+            for (size_t i = r.size(); i-- > 0;) r[i] = (r[i] << 1) | (i ? r[i - 1] >> 31 : (bit == 286 ? 1u : 0u));
+            q <<= 1;
+            if (big_ge(r, pp)) { big_sub(r, pp); q |= 1; }
+        }
+        if (q >> 32) return false;                  // p > 2^254
+        fc->wp.mu = (uint32_t)q;
+    }
+    // shift = (128 tsum - btot) mod p
+    Big t128 = big_mul(tsum, Big(1, 128u));
+    Big a = big_mod(t128, p);
+    Big btot(9, 0);
+    for (int e = 0; e < 32; e++) {
+        const int bit = 8 * e + 20, j = bit >> 5, sft = bit & 31;
+        Big t(9, 0);
+        const uint64_t v = 1ull << sft;
+        t[j] = (uint32_t)v; if (j + 1 < 9) t[j + 1] = (uint32_t)(v >> 32);
+        big_add(btot, t);
+    }
+    const Big bm = big_mod(btot, p);
+    if (!big_ge(a, bm)) big_add(a, p);
+    big_sub(a, bm);
+    fc->shift = a;                                   // in [0, p), 8 words
+    return true;
+}
+// (the bias of the main columns, summed over the columns) - fold shift, mod p: what the per-row constants subtract
+Big fold_biasmod(const Big &biasall, const Big &p, const Big &shift) {
+    Big b = big_mod(biasall, p);
+    if (!big_ge(b, shift)) big_add(b, p);
+    big_sub(b, shift);
+    return b;
+}
+
 size_t mm8w_lds_bytes(int n_rt, int nkb, int tpw, int nbuf) {
-    return ((size_t)n_rt * 64 + (size_t)nbuf * tpw * nkb * 4 * 64 + 128 + 32) * 16 + (size_t)(16 * nkb + 32 * n_rt) * 4;
+    return ((size_t)n_rt * 64 + (size_t)nbuf * tpw * nkb * 4 * 64 + 128 + MM8W_FOLD_Q) * 16 + (size_t)(16 * nkb + 32 * n_rt) * 4;
 }
 constexpr size_t MM8W_LDS_LIMIT = 156 * 1024;
 
@@ -488,7 +579,9 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
         t[j] = (uint32_t)v; t[j + 1] = (uint32_t)(v >> 32);
         big_add(biasall, t);
     }
-    const Big biasmod = big_mod(biasall, p);
+    FoldConsts fc;
+    if (!fold_consts(ctx, &fc)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: fold table");
+    const Big biasmod = fold_biasmod(biasall, p, fc.shift);
     std::vector<uint32_t> cr((size_t)n_rt * 16 * 16, 0);
     for (int i = 0; i < n_out; i++) {
         Big corr = big_mod(big_mul(c80, rowsum[i]), p);
@@ -498,12 +591,7 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
     }
     Mm8wMatrix *m = new Mm8wMatrix();
     m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->tile_rows = tile_rows; m->shape_tiles = -1; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr; m->bias = bias; m->wp = nullptr;
-    WideParams wph;
-    memset(&wph, 0, sizeof wph);
-    for (int k = 0; k < 10; k++) to_digits(big_mod(big_pow2(29 * (9 + k), 18), p), wph.T[k], 9);
-    memcpy(wph.pbar, ctx->psc.pbar, sizeof wph.pbar);
-    memcpy(wph.pneg, ctx->psc.pneg, sizeof wph.pneg);
-    wph.m0 = ctx->psc.m0; wph.m1 = ctx->psc.m1;
+    const WideParams &wph = fc.wp;
     hipError_t e = hipMalloc(&m->a8, a.size());
     if (e == hipSuccess) e = hipMalloc(&m->wp, sizeof(WideParams));
     if (e == hipSuccess) e = hipMalloc(&m->crow, cr.size() * 4);
@@ -560,27 +648,23 @@ static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in
     if (blocks > n_units) blocks = n_units;
     const size_t lds = mm8w_lds_bytes(m->n_rt, m->nkb, tpw, nbuf);
     const bool check = check_mask_dev != nullptr;
-#define MM8W_LAUNCH_KF(CHK, PL, KK, FF)                                                                                                \
+#define MM8W_LAUNCH_K(CHK, PL, KK)                                                                                                    \
     do {                                                                                                                              \
         static bool attr_done = false;                                                                                                \
         if (!attr_done) {                                                                                                             \
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK, PL, KK, FF>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK, PL, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
             attr_done = true;                                                                                                         \
         }                                                                                                                             \
-        hipLaunchKernelGGL((k_mm8w<CHK, PL, KK, FF>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
+        hipLaunchKernelGGL((k_mm8w<CHK, PL, KK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
                            m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp, first_bad_dev);                         \
     } while (0)
-    // the biased sum is < 2 bias 2^496 (1 + 1/255): below 2^(29 * 18) its 19th digit is zero and is not folded (gen_mm8w.py, nfold = 9)
-    const bool f9 = m->bias < 33000000u && !getenv("HB_MM8W_FOLD10");
-#define MM8W_LAUNCH_K(CHK, PL, KK) do { if (f9) MM8W_LAUNCH_KF(CHK, PL, KK, 9); else MM8W_LAUNCH_KF(CHK, PL, KK, 10); } while (0)
     // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
     const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);
 #define MM8W_LAUNCH(CHK, PL) do { if (m->tile_rows == 12) MM8W_LAUNCH_K(CHK, PL, 3); else if (m->tile_rows == 8) MM8W_LAUNCH_K(CHK, PL, 2); else MM8W_LAUNCH_K(CHK, PL, 4); } while (0)
     if (check) { if (peel == 1) MM8W_LAUNCH(true, 1); else if (peel == 2) MM8W_LAUNCH(true, 2); else if (peel == 3) MM8W_LAUNCH(true, 3); else MM8W_LAUNCH(true, 4); }
     else { if (peel == 1) MM8W_LAUNCH(false, 1); else if (peel == 2) MM8W_LAUNCH(false, 2); else if (peel == 3) MM8W_LAUNCH(false, 3); else MM8W_LAUNCH(false, 4); }
-#undef MM8W_LAUNCH_KF
 #undef MM8W_LAUNCH_K
 #undef MM8W_LAUNCH
     HB_LAUNCH_CHECK(ctx);
@@ -632,7 +716,9 @@ int mm8w_shared(hb_ctx *ctx, int d, const Mm8wShared **out, hipStream_t s) {
         t[j] = (uint32_t)v; t[j + 1] = (uint32_t)(v >> 32);
         big_add(biasall, t);
     }
-    to_digits(big_mod(biasall, p), sh->biasmod, 9);
+    FoldConsts fc;
+    if (!fold_consts(ctx, &fc)) { delete sh; return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: fold table"); }
+    to_digits(fold_biasmod(biasall, p, fc.shift), sh->biasmod, 9);
     Big c80(8, 0x80808080u);
     to_digits(big_mod(big_mul(c80, big_pow2(261, 10)), p), sh->c80r, 9);
     // the context-wide device copies (shared by every d)
@@ -640,12 +726,7 @@ int mm8w_shared(hb_ctx *ctx, int d, const Mm8wShared **out, hipStream_t s) {
     uint32_t *zero = nullptr;
     for (auto &kv : ctx->wide_shared) { wp = static_cast<Mm8wShared *>(kv.second)->wp; zero = static_cast<Mm8wShared *>(kv.second)->zero; break; }
     if (!wp) {
-        WideParams wph;
-        memset(&wph, 0, sizeof wph);
-        for (int k = 0; k < 10; k++) to_digits(big_mod(big_pow2(29 * (9 + k), 18), p), wph.T[k], 9);
-        memcpy(wph.pbar, ctx->psc.pbar, sizeof wph.pbar);
-        memcpy(wph.pneg, ctx->psc.pneg, sizeof wph.pneg);
-        wph.m0 = ctx->psc.m0; wph.m1 = ctx->psc.m1;
+        const WideParams &wph = fc.wp;
         std::vector<uint8_t> zero64(64, 0), wpb((sizeof(WideParams) + 15) / 16 * 16, 0);
         memcpy(wpb.data(), &wph, sizeof wph);
         hipError_t e = hipMalloc(&wp, wpb.size());

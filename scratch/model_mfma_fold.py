@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Big-integer model of k_mm8w's reduction with the fold of the high half on the matrix cores (gen_mm8w.py, round 3):
+checks the arithmetic, the representatives t_b and every bound the generated code relies on.  CPU only."""
+import random
+
+def balanced_digits(t, n=32):
+    """n balanced base-256 digits of t (may be negative); None if it does not fit"""
+    out = []
+    for _ in range(n):
+        d = t & 0xff
+        if d > 127:
+            d -= 256
+        out.append(d)
+        t = (t - d) >> 8
+    return out if t == 0 else None
+
+def tables(p):
+    s = []
+    tsum = 0
+    for b in range(32):
+        T = pow(2, 256 + 8 * b, p)
+        dg = balanced_digits(T)
+        if dg is None:
+            dg = balanced_digits(T - p)
+        assert dg is not None, "no 32-digit representative"
+        s.append(dg)
+        tsum += T
+    mu = (1 << 286) // p
+    assert mu < 1 << 32
+    c512 = pow(2, 512, p)
+    btot = sum((1 << 20) << (8 * e) for e in range(32))
+    return s, mu, c512, btot, tsum
+
+def reduce_model(S, CRorig, p, tb):
+    s, mu, c512, btot, tsum = tb
+    assert S < 1 << 527
+    K2 = (128 * tsum - btot) % p
+    CR = (CRorig + K2) % p
+    W = [(S >> (32 * j)) & 0xffffffff for j in range(17)]
+    h = [((S >> (256 + 8 * b)) & 0xff) - 128 for b in range(32)]
+    D = [sum(h[b] * s[b][e] for b in range(32)) for e in range(32)]
+    assert all(abs(x) < 1 << 20 for x in D)
+    bias4 = (1 << 20) * 0x01010101
+    P = []
+    for w in range(8):
+        v = bias4 + ((CR >> (32 * w)) & 0xffffffff)
+        for k in range(4):
+            v += D[4 * w + k] << (8 * k)
+        v += W[w] + W[16] * ((c512 >> (32 * w)) & 0xffffffff)
+        assert 0 <= v < 1 << 49
+        P.append(v)
+    R = sum(P[w] << (32 * w) for w in range(8))
+    assert R % p == (S + CRorig) % p
+    t = (P[7] + (P[6] >> 32))
+    rtop = (t >> 16)
+    assert rtop < 1 << 32
+    q = (rtop * mu) >> 46
+    assert q in (R // p, R // p - 1), (q, R // p)
+    pneg = (1 << 256) - p
+    u = [q * ((pneg >> (32 * w)) & 0xffffffff) + P[w] for w in range(8)]
+    assert all(x < 1 << 64 for x in u)
+    rp = sum(u[w] << (32 * w) for w in range(8))
+    r = rp - (q << 256)
+    assert 0 <= r < 2 * p
+    top = (rp >> 256) - q
+    assert top in (0, 1) and top == r >> 256
+    if r >= p:
+        r -= p
+    assert r == (S + CRorig) % p
+    return r
+
+if __name__ == "__main__":
+    rng = random.Random(1)
+    primes = [0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+              0xfffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141,
+              0xfffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2f,
+              (1 << 255) - 19, (1 << 254) + 79 * 0 + 0x4f]   # the last is not prime: the arithmetic does not care
+    for p in primes:
+        tb = tables(p)
+        for it in range(3000):
+            bits = rng.choice([527, 526, 523, 517, 300, 256, 10])
+            S = rng.getrandbits(bits)
+            if it % 7 == 0:
+                S = (1 << 527) - 1 - rng.getrandbits(40)
+            if it % 11 == 0:
+                S = rng.getrandbits(15) << 512 | ((1 << 512) - 1)
+            reduce_model(S, rng.randrange(p), p, tb)
+    print("ok")
