@@ -229,6 +229,8 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
                 int64_t C, hipStream_t s, const uint32_t *cmp = nullptr, hb_view cv = hb_view{0, 0}, int n_store = 0);
 // device-built images (hb_quick.hip): geometry of an n_out x d image, the per-(context, d) constants, and the launch over
 // borrowed buffers; first_bad_dev (CHECK mode, optional): atomicMin of the first chunk whose compare failed
+// the fold of a sum's high bytes on the matrix cores (hb_mfma_wide.hip): table rows of 272 bytes, eight per 16 bytes of H
+bool fold_tables(hb_ctx *ctx, int n_bytes, uint8_t *fold, uint32_t *top8, uint32_t *mu, uint32_t *shift8);
 struct Mm8wShared { uint32_t bias; uint32_t c80r[9], biasmod[9]; void *wp; uint32_t *zero; };
 int mm8w_geometry(int n_out, int d, int *tile_rows, int *n_rt, int *nkb, size_t *a8_bytes, size_t *crow_words);
 int mm8w_shared(hb_ctx *ctx, int d, const Mm8wShared **out, hipStream_t s);

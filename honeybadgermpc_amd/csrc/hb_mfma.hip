@@ -23,9 +23,12 @@
 // (crow[], radix-2^29 digits).
 //
 // Epilogue per output: 47 int32 columns -> pairs E = col + col' 2^8 (< 2^32) -> 13 words by one
-// add-with-carry each -> 14 radix-2^29 digits + row constant -> Barrett (quotient from the top 6
-// digits x mu, 26 + 35 v_mad_u64_u32) -> packed 4 x u64 -> one conditional subtraction on the words.
-// No Montgomery form anywhere on this path.
+// add-with-carry each.  S = L + 2^256 H + 2^384 w12 (L eight words, H four): H goes back through the matrix
+// cores against t_b = 2^(256 + 8b) mod p, b < 16 -- a block-diagonal product, 8 MFMAs per output, the table and the
+// layout of hb_mfma_wide.hip / gen_mm8w.py (round 3; rounds 1-2 reduced 14 radix-2^29 digits by a six-digit Barrett
+// quotient: 26 + 35 v_mad_u64_u32 and the digit conversions both ways) -- its 32 columns, L, the top word times
+// 2^384 mod p and the per-row constant are gathered per 32-bit word (six MADs a word), a one-word Barrett quotient,
+// R - q p in words, one conditional subtraction.  No Montgomery form anywhere on this path.
 #include "hb_common.hpp"
 
 namespace hb {
@@ -34,19 +37,21 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr int MM8_NC = 47;       // int32 columns per output
 constexpr int MM8_CW = 13;       // 32-bit words of the per-row constant / the carried sum
-constexpr int MM8_SD = 14;       // radix-2^29 digits of the carried sum (S < 2^388)
+constexpr int MM8_FOLD_ROW = 272;   // bytes per row of the fold table (hb_mfma_wide.hip: sixteen lanes' 16 digits, then 16 zero bytes)
+constexpr int MM8_FOLD_Q = 8 * MM8_FOLD_ROW / 16;   // eight rows (one byte half), in uint4
 
 struct BarrettParams {
-    uint32_t pbar[9]; // 2^261 - p, digits
     uint32_t pneg[8]; // 2^256 - p, 32-bit words
-    uint32_t mu[6];   // floor(2^406 / p) digits
+    uint32_t c384[8]; // 2^384 mod p, words
+    uint32_t mu;      // floor(2^286 / p)
 };
 
 struct Mm8Matrix {
     int n_out, d, nkb, n_rt;
     int4 *a8;          // [n_rt][nkb][2 digit groups][64 lanes] 16 balanced digits each: lane (r, g) = row 16 rt + 4 (r % 4) + r / 4;
                        // byte j = 4 dd + bi is digit 7 + 8 G - 4 (dd >> 1) - bi of term 8 kb + 2 g + (dd & 1)
-    uint32_t *crow;    // [n_rt * 16][16] radix-2^29 digits of the per-row constant (14 used)
+    uint32_t *crow;    // [n_rt * 16][16]: per row eight pairs [bias of the fold's four columns + constant word]; then the fold table
+                       // (MM8_FOLD_Q uint4: the A operands of the eight column blocks)
     uint32_t *zero;    // 32 zero bytes: DMA source for inputs beyond in_count (zero padding of the last chunk)
     BarrettParams bp;
 };
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     extern __shared__ uint4 mm8_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
-    uint32_t *crl = reinterpret_cast<uint32_t *>(mm8_lds);     // [n_rt * 16][16] digits
+    uint32_t *crl = reinterpret_cast<uint32_t *>(mm8_lds);     // [n_rt * 16][16]: row constants as eight 64-bit addends
     int4 *abuf = reinterpret_cast<int4 *>(mm8_lds + n_rt * 64);   // [n_rt][NKB][2][64] matrix digits
     uint4 *xbuf = mm8_lds + n_rt * 64 + n_rt * NKB * 2 * 64;    // 2 x [tpw][NKB][2 elements][2 halves][64] uint4
     const int bufsz = tpw * NKB * 4 * 64;
@@ -100,6 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     // l -> input row table (arrival order for decodes), clamped to d - 1
     int32_t *rowl = reinterpret_cast<int32_t *>(xbuf + 2 * bufsz);
     uint32_t *rowoff = reinterpret_cast<uint32_t *>(rowl + 32);   // byte offset of row l from the chunk's first element (fast DMA path)
+    v4i *foldl = reinterpret_cast<v4i *>(rowl + 96 + 16 * n_rt);   // the fold table (16-byte aligned: everything before it is a multiple of 64 bytes)
     if (threadIdx.x < 32) {
         const int lc = (int)threadIdx.x < d ? (int)threadIdx.x : d - 1;
         const int row = in_rows ? in_rows[lc] : lc;
@@ -156,7 +162,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
     };
     const v4i biasv = v4i{MM8_BIAS, MM8_BIAS, MM8_BIAS, MM8_BIAS};
     uint32_t k256 = 256u, k16m = 1u << 24;      // opaque, so that the word assembly stays two v_mad_u64_u32 per word
-    asm volatile("" : "+s"(k256), "+s"(k16m));
+    int32_t s1 = 1, s256 = 256, s64k = 1 << 16, s16m = 1 << 24;   // and the gathering of the fold's columns one v_mad_i64_i32 each
+    uint32_t u1 = 1u;
+    asm volatile("" : "+s"(k256), "+s"(k16m), "+s"(s1), "+s"(s256), "+s"(s64k), "+s"(s16m), "+s"(u1));
 
     int buf = 0;
     int64_t unit = blockIdx.x;
@@ -178,7 +186,10 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                          : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
         }
     }
+    if (threadIdx.x < MM8_FOLD_Q) foldl[threadIdx.x] = reinterpret_cast<const v4i *>(crowd + (size_t)n_rt * 256)[threadIdx.x];
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the fold's A operand: lane (m, g') of the diagonal block g' = m / 4 reads its 16 digits, every other lane the row's zero bytes
+    const v4i *fold_lane = reinterpret_cast<const v4i *>(reinterpret_cast<const char *>(foldl) + (g == (n >> 2) ? 16 * n : 256));
     MM8_T(0);   // prologue
     for (; unit < n_units; unit += gridDim.x, buf ^= 1) {
         // every wave has waited for its share of this unit's DMA (below, before its epilogue) and is
@@ -210,7 +221,6 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
             const uint4 *xs = xbuf + (size_t)buf * bufsz + (size_t)tl * NKB * 4 * 64 + lane;
             const int4 *as = abuf + (size_t)rt * NKB * 2 * 64 + lane;
             uint32_t eap[4][11], c0p[4];     // half 0's column pairs, parked across the second MFMA block
-            uint32_t wd[4][MM8_CW];          // the 13 words of each biased sum
             // Output `reg` of lane (n, g) is row 16 rt + 4 reg + g (the host places matrix row 16 rt + j at tile row
             // 4 (j % 4) + j / 4), so the rows beyond n_out of a ragged last tile fill whole outputs from the top: when
             // outputs 2 and 3 are all padding (22 rows: the decode's second tile) their reduction is skipped
@@ -253,120 +263,109 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     if (reg == 2 && !pair1) break;
-                    // G_k = F_k 2^8 + E_k 2^24 < 2^56: the even and the odd G_k tile two multiword numbers without
-                    // carries; their sum is one add-with-carry per 32-bit word
-                    uint32_t glo[12], ghi[12];
+                    const int i = 16 * rt + 4 * reg + g;
+                    uint32_t ew[8];
+                    bool cmp = false;
+                    if constexpr (CHECK) {   // expected value: in flight while this output is reduced
+                        const int erow = maskl[i];
+                        cmp = (chunk < n_chunks) && erow;
+                        // unconditional (from the buffer's first element when there is nothing to compare): a load under `cmp` makes hipcc wrap
+                        // the whole reduction in that divergent branch, and the register copies at its join spill
+                        load_words<8>(ew, out_pk + (cmp ? (chunk * out_sc + (int64_t)(erow - 1) * out_sl) * 8 : 0));
+                    }
+                    (void)ew; (void)cmp;
+                    // G_k = F_k 2^8 + E_k 2^24 < 2^56 (+ col_0 for k = 0), S = sum_k G_k 2^(32 k).  The low eight go into the gathered words
+                    // P_w as they are -- P_w is a 64-bit addend of weight 2^(32 w), so no carry chain and no separate addition: the two
+                    // MADs that build G_w start from the row constant's pair [bias of the fold's four columns + constant word] -- except
+                    // that what G_7 has above bit 256 joins the high part.  H = that + G_8 .. G_11, exact words by add-with-carry.
+                    uint64_t pw[8];
+                    {
+                        const uint4 *cr = reinterpret_cast<const uint4 *>(crl + (size_t)i * 16);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint4 c = cr[k];
+                            pw[2 * k] = (uint64_t)c.x | ((uint64_t)c.y << 32);
+                            pw[2 * k + 1] = (uint64_t)c.z | ((uint64_t)c.w << 32);
+                        }
+                    }
+                    uint32_t glo[5], ghi[5];       // G_7 .. G_11
 #pragma unroll
                     for (int k = 0; k < 12; k++) {
                         const uint32_t f = (uint32_t)acc[2 * k][reg] + ((uint32_t)acc[2 * k + 1][reg] << 8);
-                        uint64_t gk = (uint64_t)f * k256 + (k == 0 ? (uint64_t)c0p[reg] : 0ull);
+                        uint64_t gk = (uint64_t)f * k256 + (k < 7 ? pw[k] : 0ull);
                         if (k < 11) gk += (uint64_t)eap[reg][k] * k16m;
-                        glo[k] = (uint32_t)gk;
-                        ghi[k] = (uint32_t)(gk >> 32);
+                        if (k < 7) pw[k] = gk;
+                        else { glo[k - 7] = (uint32_t)gk; ghi[k - 7] = (uint32_t)(gk >> 32); }
                     }
-                    unsigned cyw = 0;
-                    wd[reg][0] = glo[0];
-#pragma unroll
-                    for (int k = 1; k < 12; k++) wd[reg][k] = __builtin_addc(glo[k], ghi[k - 1], cyw, &cyw);
-                    wd[reg][12] = ghi[11] + cyw;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-#pragma unroll
-                for (int reg = 0; reg < 4; reg++) {
-                    if (reg == 2 && !pair1) break;
+                    pw[0] += (uint64_t)c0p[reg] * u1;
+                    pw[7] += (uint64_t)glo[0] * u1;
+                    uint32_t hw[5];
                     {
-                        uint32_t ew[8];
-                        bool cmp = false;
-                        if constexpr (CHECK) {   // expected value: in flight while this output is reduced
-                            const int i = 16 * rt + 4 * reg + g;
-                            const int erow = maskl[i];
-                            cmp = (chunk < n_chunks) && erow;
-                            if (cmp) load_words<8>(ew, out_pk + (chunk * out_sc + (int64_t)(erow - 1) * out_sl) * 8);
-                        }
-                        (void)ew; (void)cmp;
-                        uint32_t w[MM8_CW];
+                        unsigned cyw = 0;
 #pragma unroll
-                        for (int k = 0; k < MM8_CW; k++) w[k] = wd[reg][k];
-                        const int i = 16 * rt + 4 * reg + g;
-                        uint32_t sd[MM8_SD];
-#pragma unroll
-                        for (int k = 0; k < MM8_SD; k++) {   // digit k = bits [29k, 29k + 29) of the 13 words
-                            const int bit = LB * k, j = bit >> 5, sft = bit & 31;
-                            const uint32_t lo = w[j], hi = (j + 1 < MM8_CW) ? w[j + 1] : 0u;
-                            sd[k] = (sft == 0 ? lo : __builtin_amdgcn_alignbit(hi, lo, (uint32_t)sft)) & DMASK;
-                        }
-                        {
-                            const uint4 *cr = reinterpret_cast<const uint4 *>(crl + (size_t)i * 16);
-                            const uint4 c0v = cr[0], c1v = cr[1], c2v = cr[2], c3v = cr[3];
-                            sd[0] += c0v.x; sd[1] += c0v.y; sd[2] += c0v.z; sd[3] += c0v.w;
-                            sd[4] += c1v.x; sd[5] += c1v.y; sd[6] += c1v.z; sd[7] += c1v.w;
-                            sd[8] += c2v.x; sd[9] += c2v.y; sd[10] += c2v.z; sd[11] += c2v.w;
-                            sd[12] += c3v.x; sd[13] += c3v.y;
-                        }
-                        // Barrett.  S_hi = sum_{k>=8} digit_k 2^(29(k-8)) >= S / 2^232 - 2 (lazy low digits < 2^30),
-                        // mu > 2^406 / p - 1, and the four lowest product columns (10 terms < 2^59 2^(29 * 3): < 2^150 in all)
-                        // are dropped, so S_hi mu / 2^174 > S/p - S/2^406 - 2^233/p - 2^-24 > S/p - 2^-10: qhat is floor(S/p) or one less.
-                        uint64_t pc[11];
-#pragma unroll
-                        for (int k = 0; k < 11; k++) pc[k] = 0;
-#pragma unroll
-                        for (int aa = 0; aa < 6; aa++)
-#pragma unroll
-                            for (int bb = 0; bb < 6; bb++)
-                                if (aa + bb >= 4) pc[aa + bb] += (uint64_t)sd[8 + aa] * bp.mu[bb];
-#pragma unroll
-                        for (int k = 4; k < 10; k++) pc[k + 1] += pc[k] >> LB;
-                        uint32_t qd[5];
-#pragma unroll
-                        for (int k = 0; k < 5; k++) qd[k] = (uint32_t)pc[6 + k] & (k < 4 ? DMASK : 0xffffffffu);
-                        // r = S - qhat p = S + qhat (2^261 - p)  (mod 2^261), r < 2p: additions only, the low digits of S
-                        // are the MADs' addend
-                        uint64_t dc[9];
-#pragma unroll
-                        for (int k = 0; k < 9; k++) dc[k] = sd[k];
-#pragma unroll
-                        for (int aa = 0; aa < 5; aa++)
-#pragma unroll
-                            for (int bb = 0; bb < 9; bb++)
-                                if (aa + bb < 9) dc[aa + bb] += (uint64_t)qd[aa] * bp.pbar[bb];
-                        uint32_t r[9];
-#pragma unroll
-                        for (int k = 0; k < 9; k++) {
-                            r[k] = (uint32_t)dc[k] & DMASK;
-                            if (k < 8) dc[k + 1] += dc[k] >> LB;
-                        }
-                        uint32_t ow[8];
-                        pack<9, 8>(ow, r);
-                        // r < 2p < 2^257;  r >= p  <=>  bit 256 of r is set (bit 24 of digit 8: possible once p > 2^255, and
-                        // pack() drops it) or r mod 2^256 + (2^256 - p) carries out of word 7; either way r - p is that sum mod 2^256
-                        {
-                            uint32_t u[8];
-                            unsigned cy2 = 0;
-#pragma unroll
-                            for (int k = 0; k < 8; k++) u[k] = __builtin_addc(ow[k], bp.pneg[k], cy2, &cy2);
-                            const bool take = cy2 || (r[8] >> 24);
-#pragma unroll
-                            for (int k = 0; k < 8; k++) ow[k] = take ? u[k] : ow[k];
-                        }
-                        const int64_t oidx = obase + reg * ostep;
-                        if constexpr (CHECK) {
-                            if (cmp) {
-                                uint32_t diff = 0;
-#pragma unroll
-                                for (int k = 0; k < 8; k++) diff |= ew[k] ^ ow[k];
-                                if (diff) atomicOr(mismatch, 1);
-                            }
-                        } else {
-                            // keep the reduction outside the store's exec mask: hipcc otherwise wraps the whole output in a
-                            // divergent branch, and the register copies at its join spill
-                            asm volatile("" ::"v"(ow[0]), "v"(ow[1]), "v"(ow[2]), "v"(ow[3]), "v"(ow[4]), "v"(ow[5]), "v"(ow[6]), "v"(ow[7]));
-                            if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow);
-                        }
+                        for (int k = 0; k < 4; k++) hw[k] = __builtin_addc(glo[k + 1], ghi[k], cyw, &cyw);
+                        hw[4] = ghi[4] + cyw;
                     }
-                    if (reg & 1) __builtin_amdgcn_sched_barrier(0);   // two reductions at a time: ILP for the carry chains (measured: 1 -> 70.2, 2 -> 68.9, 4 -> 69.9+ us)
+                    // the fold of H (biased like every int8 input here; the row constant takes 128 sum_b t_b back out): eight MFMAs
+                    v4i hb;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) hb[k] = (int)(hw[k] ^ 0x80808080u);
+                    v4i dcol[8];
+#pragma unroll
+                    for (int eb = 0; eb < 8; eb++)
+                        dcol[eb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(fold_lane[eb * (MM8_FOLD_ROW / 16)], hb, v4i{0, 0, 0, 0}, 0, 0, 0);
+                    // P_w += hw4 (2^384 mod p)_w + sum_k D_(4 w + k) 2^(8 k)      (P_w < 2^58, P_7 < 2^47)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) pw[k] += (uint64_t)hw[4] * bp.c384[k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        int64_t t = (int64_t)pw[k] + (int64_t)dcol[k][0] * s1;
+                        t += (int64_t)dcol[k][1] * s256;
+                        t += (int64_t)dcol[k][2] * s64k;
+                        t += (int64_t)dcol[k][3] * s16m;
+                        pw[k] = (uint64_t)t;
+                    }
+                    // R = sum_w P_w 2^(32 w) < 2^272;  qhat = floor(floor(R / 2^240) mu / 2^46), mu = floor(2^286 / p): floor(R / p) or one
+                    // less (scratch/model_mfma_fold.py has the bounds);  u_w = qhat (2^256 - p)_w + P_w: the words of sum_w u_w 2^(32 w)
+                    // are R - qhat p, with qhat on top of bit 256
+                    const uint64_t tq = pw[7] + (pw[6] >> 32);
+                    const uint32_t qh = (uint32_t)(((uint64_t)(uint32_t)(tq >> 16) * bp.mu) >> 46);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) pw[k] += (uint64_t)qh * bp.pneg[k];
+                    uint32_t ow[8];
+                    uint32_t top;
+                    {
+                        unsigned cy = 0;
+                        ow[0] = (uint32_t)pw[0];
+#pragma unroll
+                        for (int k = 1; k < 8; k++) ow[k] = __builtin_addc((uint32_t)pw[k], (uint32_t)(pw[k - 1] >> 32), cy, &cy);
+                        top = (uint32_t)(pw[7] >> 32) + cy - qh;          // bit 256 of the remainder (r < 2p < 2^257)
+                    }
+                    // r >= p  <=>  bit 256 of r is set (possible once p > 2^255) or r mod 2^256 + (2^256 - p) carries out of word 7;
+                    // either way r - p is that sum mod 2^256
+                    {
+                        uint32_t u[8];
+                        unsigned cy2 = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) u[k] = __builtin_addc(ow[k], bp.pneg[k], cy2, &cy2);
+                        const bool take = cy2 || top;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) ow[k] = take ? u[k] : ow[k];
+                    }
+                    const int64_t oidx = obase + reg * ostep;
+                    if constexpr (CHECK) {
+                        uint32_t diff = 0;
+#pragma unroll
+                        for (int k = 0; k < 8; k++) diff |= ew[k] ^ ow[k];
+                        asm volatile("" : "+v"(diff));
+                        if (cmp && diff) atomicOr(mismatch, 1);
+                    } else {
+                        // keep the reduction outside the store's exec mask: hipcc otherwise wraps the whole output in a
+                        // divergent branch, and the register copies at its join spill
+                        asm volatile("" ::"v"(ow[0]), "v"(ow[1]), "v"(ow[2]), "v"(ow[3]), "v"(ow[4]), "v"(ow[5]), "v"(ow[6]), "v"(ow[7]));
+                        if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow);
+                    }
+                    if (reg & 1) __builtin_amdgcn_sched_barrier(0);   // two reductions at a time: ILP for the carry chains
                 }
             }
             MM8_T(7);   // word assembly + reduction + stores
@@ -385,7 +384,7 @@ using namespace hb;
 namespace {
 
 // dynamic LDS of k_mm8: row constants, matrix digits, two element buffers, then the int tables of the prologue
-// (rowl[32], rowoff[32], rowmax + padding [32], maskl[16 n_rt])
+// (rowl[32], rowoff[32], rowmax + padding [32], maskl[16 n_rt]) and the fold table
 constexpr size_t MM8_LDS_LIMIT = 78 * 1024;   // two workgroups per CU share 160 KB
 size_t mm8_lds_bytes(int n_rt, int nkb, int tpw);
 // tiles of 16 chunks per unit: enough (tile, row tile) pairs for the 4 waves.  (Two tiles per unit with four row tiles --
@@ -396,7 +395,7 @@ int mm8_tpw(int n_rt, int nkb) {
     return tpw;
 }
 size_t mm8_lds_bytes(int n_rt, int nkb, int tpw) {
-    return ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 2 * 64 + (size_t)2 * tpw * nkb * 4 * 64) * 16 + 96 * 4 + (size_t)n_rt * 16 * 4;
+    return ((size_t)n_rt * 64 + (size_t)n_rt * nkb * 2 * 64 + (size_t)2 * tpw * nkb * 4 * 64 + MM8_FOLD_Q) * 16 + 96 * 4 + (size_t)n_rt * 16 * 4;
 }
 
 int mm8_num_cus() {
@@ -522,14 +521,24 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     for (int k = 0; k < 4; k++) { p[2 * k] = (uint32_t)ctx->p_limbs[k]; p[2 * k + 1] = (uint32_t)(ctx->p_limbs[k] >> 32); }
     Big c80(8, 0x80808080u);
     c80 = big_divmod(c80, p, nullptr);                                   // 0x80..80 mod p
-    // K0 = (p << 137) - sum_c BIAS 2^(8c), c < 47: positive, below 2^394
-    Big K0 = big_shl(p, 137, 14);
-    { Big bt(14, 0); for (int c = 0; c < MM8_NC; c++) { Big t(1, (uint32_t)MM8_BIAS); big_add(bt, big_shl(t, 8 * c, 14)); } big_sub(K0, bt); }
-    Big two406(13, 0); two406[12] = 1u << 22;                            // 2^406
-    Big mu; big_divmod(two406, p, &mu);
+    // what every row's constant takes out: the accumulator bias of the 47 columns, less what the fold of H adds (hb_mfma_wide.hip)
+    Big biasmod;
+    { Big bt(14, 0); for (int c = 0; c < MM8_NC; c++) { Big t(1, (uint32_t)MM8_BIAS); big_add(bt, big_shl(t, 8 * c, 14)); } biasmod = big_divmod(bt, p, nullptr); }
+    std::vector<uint8_t> foldtab((size_t)MM8_FOLD_Q * 16, 0);
+    BarrettParams bpar;
+    {
+        uint32_t shift8[8];
+        if (!fold_tables(ctx, 16, foldtab.data(), bpar.c384, &bpar.mu, shift8)) return HB_ERR_UNSUPPORTED;
+        Big sh(shift8, shift8 + 8);
+        if (!big_ge(biasmod, sh)) big_add(biasmod, p);
+        big_sub(biasmod, sh);                                            // (bias sum - shift) mod p
+    }
 
     std::vector<int8_t> a((size_t)n_rt * nkb * 2 * 64 * 16, 0);
-    std::vector<uint32_t> cr((size_t)n_rt * 16 * 16, 0);
+    std::vector<uint32_t> cr((size_t)n_rt * 16 * 16 + (size_t)MM8_FOLD_Q * 4, 0);
+    memcpy(&cr[(size_t)n_rt * 16 * 16], foldtab.data(), foldtab.size());
+    // rows beyond n_out: the bias pairs alone (their outputs are never stored)
+    for (size_t i = 0; i < (size_t)n_rt * 16; i++) for (int k = 0; k < 8; k++) { cr[i * 16 + 2 * k] = 0x10100000u; cr[i * 16 + 2 * k + 1] = 0x1010u; }
     for (int i = 0; i < n_out; i++) {
         Big pos(5, 0), ngs(5, 0);   // sums of the positive / negated entries of the row (each < 32 * 2^127)
         int64_t colsum = 0;         // 128 * sum |digit| bounds every int32 column of this row
@@ -561,36 +570,22 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
         Big cp = big_divmod(big_mul(c80, pos), p, nullptr), cn = big_divmod(big_mul(c80, ngs), p, nullptr);
         if (!big_ge(cp, cn)) big_add(cp, p);
         big_sub(cp, cn);
-        Big tot(K0);
-        big_add(tot, cp);
-        for (int k = 0; k < MM8_SD; k++) {
-            const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
-            uint64_t v = tot[j] | ((uint64_t)(j + 1 < 14 ? tot[j + 1] : 0) << 32);
-            cr[(size_t)i * 16 + k] = (uint32_t)(v >> sft) & DMASK;
+        if (!big_ge(cp, biasmod)) big_add(cp, p);
+        big_sub(cp, biasmod);                                               // the row's constant, in [0, p)
+        for (int k = 0; k < 8; k++) {                                       // per word one 64-bit addend: the bias of the fold's four columns (2^20 each) + the word
+            const uint64_t pair = (uint64_t)cp[k] + ((0x1010ull << 32) | 0x10100000ull);
+            cr[(size_t)i * 16 + 2 * k] = (uint32_t)pair;
+            cr[(size_t)i * 16 + 2 * k + 1] = (uint32_t)(pair >> 32);
         }
     }
     Mm8Matrix *m = new Mm8Matrix();
     m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr;
-    {   // 2^261 - p, radix 2^29
-        Big pb(9, 0); pb[8] = 1u << 5;            // 2^261
-        Big pw9(p); pw9.push_back(0);
-        big_sub(pb, pw9);
-        for (int k = 0; k < 9; k++) {
-            const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
-            uint64_t v = pb[j] | ((uint64_t)(j + 1 < 9 ? pb[j + 1] : 0) << 32);
-            m->bp.pbar[k] = (uint32_t)(v >> sft) & DMASK;
-        }
-    }
+    m->bp = bpar;
     {   // 2^256 - p, 32-bit words
         Big pn(9, 0); pn[8] = 1;
         Big pw9(p); pw9.push_back(0);
         big_sub(pn, pw9);
         for (int k = 0; k < 8; k++) m->bp.pneg[k] = pn[k];
-    }
-    for (int k = 0; k < 6; k++) {
-        const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
-        uint64_t v = mu[j] | ((uint64_t)(j + 1 < (int)mu.size() ? mu[j + 1] : 0) << 32);
-        m->bp.mu[k] = (uint32_t)(v >> sft) & DMASK;
     }
     HB_HIP(ctx, hipMalloc(&m->a8, a.size()));
     HB_HIP(ctx, hipMalloc(&m->crow, cr.size() * 4));

@@ -373,17 +373,16 @@ void big_dbl_mod(Big &x, const Big &p) {
     if (top || big_ge(x, p)) big_sub(x, p);       // 2x < 2p < 2^(32 n + 1): one subtraction, mod 2^(32 n) when the top bit left
 }
 
-// The constants of the reduction (gen_mm8w.py, reduce_output): the fold table of t_b = 2^(256 + 8 b) mod p, mu = floor(2^286 / p),
-// 2^512 mod p, 2^256 - p -- and what the fold adds to every sum, which the per-row constants take back out:
-// fold_shift = (128 sum_b t_b - sum_e 2^20 2^(8 e)) mod p (the operand bias of XOR 0x80 and the bias of the fold's columns).
-struct FoldConsts { WideParams wp; Big shift; };
-bool fold_consts(hb_ctx *ctx, FoldConsts *fc) {
+// The constants of the reduction (gen_mm8w.py reduce_output; hb_mfma.hip's epilogue with n_bytes = 16): the fold table of
+// t_b = 2^(256 + 8 b) mod p for the n_bytes bytes of H, 2^(256 + 8 n_bytes) mod p for the word above H, mu = floor(2^286 / p) --
+// and what the fold adds to every sum, which the per-row constants take back out:
+// shift = (128 sum_b t_b - sum_e 2^20 2^(8 e)) mod p (the operand bias of XOR 0x80 and the bias of the fold's 32 columns).
+bool fold_tables_impl(hb_ctx *ctx, int n_bytes, uint8_t *fold, uint32_t *top8, uint32_t *mu_out, Big *shift) {
     const Big p = big_from_limbs(ctx->p_limbs, 4);
-    memset(&fc->wp, 0, sizeof fc->wp);
-    memcpy(fc->wp.pneg, ctx->psc.pneg, sizeof fc->wp.pneg);
+    memset(fold, 0, (size_t)(n_bytes / 16) * 8 * MM8W_FOLD_ROW);
     Big T = big_mod(big_pow2(256, 9), p);          // t_0; then t_(b+1) = 256 t_b mod p
     Big tsum(10, 0);
-    for (int b = 0; b < 32; b++) {
+    for (int b = 0; b < n_bytes; b++) {
         big_add(tsum, T);
         // 32 balanced digits of T, or of T - p (two's complement over ten words) when T needs a 33rd
         int8_t dg[32];
@@ -404,11 +403,11 @@ bool fold_consts(hb_ctx *ctx, FoldConsts *fc) {
         const int ks = b / 16, pos = b % 16;
         for (int e = 0; e < 32; e++) {
             const int eb = e / 4, r = e % 4;
-            for (int G = 0; G < 4; G++) fc->wp.fold[ks * 8 + eb][16 * (4 * G + r) + pos] = (uint8_t)dg[e];   // lane m = 4 G + r of block G
+            for (int G = 0; G < 4; G++) fold[(size_t)(ks * 8 + eb) * MM8W_FOLD_ROW + 16 * (4 * G + r) + pos] = (uint8_t)dg[e];   // lane m = 4 G + r of block G
         }
         for (int k = 0; k < 8; k++) big_dbl_mod(T, p);
     }
-    for (int j = 0; j < 8; j++) fc->wp.c512[j] = T[j];           // t_32 = 2^512 mod p
+    for (int j = 0; j < 8; j++) top8[j] = T[j];    // t_(n_bytes) = 2^(256 + 8 n_bytes) mod p
     // mu = floor(2^286 / p) by binary long division
     {
         Big r(9, 0), pp(p); pp.push_back(0);
@@ -419,11 +418,10 @@ bool fold_consts(hb_ctx *ctx, FoldConsts *fc) {
             if (big_ge(r, pp)) { big_sub(r, pp); q |= 1; }
         }
         if (q >> 32) return false;                  // p > 2^254
-        fc->wp.mu = (uint32_t)q;
+        *mu_out = (uint32_t)q;
     }
     // shift = (128 tsum - btot) mod p
-    Big t128 = big_mul(tsum, Big(1, 128u));
-    Big a = big_mod(t128, p);
+    Big a = big_mod(big_mul(tsum, Big(1, 128u)), p);
     Big btot(9, 0);
     for (int e = 0; e < 32; e++) {
         const int bit = 8 * e + 20, j = bit >> 5, sft = bit & 31;
@@ -435,8 +433,14 @@ bool fold_consts(hb_ctx *ctx, FoldConsts *fc) {
     const Big bm = big_mod(btot, p);
     if (!big_ge(a, bm)) big_add(a, p);
     big_sub(a, bm);
-    fc->shift = a;                                   // in [0, p), 8 words
+    *shift = a;                                      // in [0, p), 8 words
     return true;
+}
+struct FoldConsts { WideParams wp; Big shift; };
+bool fold_consts(hb_ctx *ctx, FoldConsts *fc) {
+    memset(&fc->wp, 0, sizeof fc->wp);
+    memcpy(fc->wp.pneg, ctx->psc.pneg, sizeof fc->wp.pneg);
+    return fold_tables_impl(ctx, 32, &fc->wp.fold[0][0], fc->wp.c512, &fc->wp.mu, &fc->shift);
 }
 // (the bias of the main columns, summed over the columns) - fold shift, mod p: what the per-row constants subtract
 Big fold_biasmod(const Big &biasall, const Big &p, const Big &shift) {
@@ -510,6 +514,14 @@ int mm8w_num_cus() {
 }  // namespace
 
 namespace hb {
+
+// for hb_mfma.hip (its sums have 16 bytes of H): the table's first byte half, 2^384 mod p, mu and the shift of the row constants
+bool fold_tables(hb_ctx *ctx, int n_bytes, uint8_t *fold, uint32_t *top8, uint32_t *mu, uint32_t *shift8) {
+    Big sh;
+    if (!fold_tables_impl(ctx, n_bytes, fold, top8, mu, &sh)) return false;
+    for (int j = 0; j < 8; j++) shift8[j] = sh[j];
+    return true;
+}
 
 void mm8w_free(Mm8wMatrix *m) {
     if (!m) return;
