@@ -389,14 +389,17 @@ def consts(o):
 # ------------------------------------------------------------------------------------------------ tail
 def tail(o):
     """The accumulators leave as 32-bit words of S = sum_c (col_c + bias) 2^(8c): per word four signed columns go into one
-    64-bit sum by v_mad_i64_i32 (x 1, 2^8, 2^16, 2^24; the first one adds the bias of all four), the previous word's high half
-    comes in by one more MAD (x 1) -- every term is non-negative, so there is no carry flag anywhere -- and the four outputs
-    of the lane run side by side."""
+    64-bit sum t_j by v_mad_i64_i32 (x 1, 2^8, 2^16, 2^24; the first one adds the bias of all four: every t_j is non-negative), and
+    word j = lo(t_j) + hi(t_(j-1)) + carry by one add-with-carry that writes the word where the next pass wants it.  The four outputs
+    of the lane run side by side, each with its carry in an SGPR pair of its own (the reduction constants there are dead by now;
+    the next statement reloads them), so consecutive links of a chain are a dozen instructions apart."""
     K = {1: o("K256"), 2: o("K64K"), 3: o("K16M")}
     L = []
     n_words = (NC + 3) // 4
+    cy = lambda r: f"s[{S_PNEG + 2 * r}:{S_PNEG + 2 * r + 1}]"  # noqa: E731
     for j in range(n_words):
         ts = TL_T[j & 1]
+        prev = TL_T[1 - (j & 1)]
         cols = [c for c in range(4 * j, 4 * j + 4) if c < NC]
         bias = o("B4") if len(cols) == 4 else o("B3")
         assert len(cols) in (3, 4)
@@ -409,14 +412,17 @@ def tail(o):
             for r in range(o.nout):
                 add = bias if i == 0 else f"v[{ts[r]}:{ts[r] + 1}]"
                 L.append(f"v_mad_i64_i32 v[{ts[r]}:{ts[r] + 1}], vcc, v{TL_TMP[i & 1][r]}, {mul}, {add}")
-        if j > 0:
-            for r in range(o.nout):
-                L.append(f"v_mad_u64_u32 v[{ts[r]}:{ts[r] + 1}], vcc, v{TL_T[1 - (j & 1)][r] + 1}, 1, v[{ts[r]}:{ts[r] + 1}]")
         for r in range(o.nout):
-            L.append(f"v_mov_b32 {o(f'W{r}_{j}')}, v{ts[r]}")
+            wj = o(f"W{r}_{j}")
+            if j == 0:
+                L.append(f"v_mov_b32 {wj}, v{ts[r]}")
+            elif j == 1:
+                L.append(f"v_add_co_u32_e64 {wj}, {cy(r)}, v{ts[r]}, v{prev[r] + 1}")
+            else:
+                L.append(f"v_addc_co_u32_e64 {wj}, {cy(r)}, v{ts[r]}, v{prev[r] + 1}, {cy(r)}")
     assert n_words == NWORDS - 1
     for r in range(o.nout):
-        L.append(f"v_mov_b32 {o(f'W{r}_{NWORDS - 1}')}, v{TL_T[(n_words - 1) & 1][r] + 1}")
+        L.append(f"v_addc_co_u32_e64 {o(f'W{r}_{NWORDS - 1}')}, {cy(r)}, v{TL_T[(n_words - 1) & 1][r] + 1}, 0, {cy(r)}")
     return L
 
 
