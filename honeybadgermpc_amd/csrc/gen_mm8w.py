@@ -70,6 +70,7 @@ TL_TMP = [[96, 97, 98, 99], [100, 101, 102, 103]]
 TL_T = [[104, 106, 108, 110], [112, 114, 116, 118]]
 # ---- SGPRs ----
 S_PNEG, S_MU, S_C512 = 68, 76, 77    # WideParams: pneg[8] mu c512[8] pad[3], loaded to s68 .. s87
+S_T0, S_T1 = 85, 86            # scratch: a word and a pair (the padding of WideParams lands there first)
 S_SAVE = 88                    # saved exec, pair
 
 
@@ -208,6 +209,9 @@ def kblock(par, first, last, o):
 
 
 # ------------------------------------------------------------------------------------------------ reduction
+_uid = iter(range(1 << 30))      # labels inside one statement
+
+
 class Unit(list):
     """lines that stay together in the merged stream; w = its share of room there"""
     w = 1.0
@@ -303,18 +307,34 @@ def reduce_output(o, r, check):
            f"v_sub_u32_e32 v{T1}, v{T1}, v{Q}"]
     U.append(Unit(cp))
     # conditional subtraction: the carry out of ow + (2^256 - p) says ow >= p.  One unit: the carry chain lives in vcc
-    # (an SGPR operand beside the carry in vcc would be two constant-bus reads: 2^256 - p goes through registers)
-    for j in range(8):
-        one(f"v_mov_b32 v{PN + j}, s{S_PNEG + j}")
+    # (an SGPR operand beside the carry in vcc would be two constant-bus reads: 2^256 - p goes through registers).
     # r < 2p < 2^257: bit 256 of r (T1) also means r >= p, and r - p is the same sum mod 2^256.  It joins the carry chain as a
     # ninth word: T1 + 0xffffffff + carry carries out iff T1 or carry.
-    cs = [f"v_add_co_u32_e32 v{UB}, vcc, v{PN}, v{OW}"]
+    # The whole of it sits behind a test that almost never fires: the quotient is one short once in ~10^4 outputs, and otherwise
+    # r < p shows in the top word alone -- ow_7 + (2^256 - p)_7 + 1 < 2^32 leaves no room for a carry out, whatever the lower
+    # words do.  A wave takes the 26 instructions only if one of its lanes has T1 set or ow_7 >= ~(2^256 - p)_7.
+    uid = next(_uid)
+    cs = [f"s_not_b32 s{S_T0}, s{S_PNEG + 7}",
+          f"v_cmp_le_u32_e32 vcc, s{S_T0}, v{OW + 7}",
+          f"v_cmp_ne_u32_e64 s[{S_T1}:{S_T1 + 1}], 0, v{T1}",
+          f"s_or_b64 s[{S_T1}:{S_T1 + 1}], vcc, s[{S_T1}:{S_T1 + 1}]",
+          f"s_cbranch_scc0 .Lcs_{uid}_%="]
+    if "nocsskip" in ABLATE:
+        cs = []
+    for j in range(8):
+        cs.append(f"v_mov_b32 v{PN + j}, s{S_PNEG + j}")
+    cs.append(f"v_add_co_u32_e32 v{UB}, vcc, v{PN}, v{OW}")
     for j in range(1, 8):
         cs.append(f"v_addc_co_u32_e32 v{UB + j}, vcc, v{PN + j}, v{OW + j}, vcc")
     cs.append(f"v_addc_co_u32_e32 v{T1}, vcc, -1, v{T1}, vcc")
     for j in range(8):
         cs.append(f"v_cndmask_b32_e32 v{OW + j}, v{OW + j}, v{UB + j}, vcc")
-    U.append(Unit(cs))
+    if "nocsskip" not in ABLATE:
+        cs.append(f".Lcs_{uid}_%=:")
+    u = Unit(cs)
+    if "nocsskip" not in ABLATE:
+        u.w = 6.0 / len(cs)           # what a wave executes of it, as a rule
+    U.append(u)
     if check:
         cmp = ["@EWAIT"]
         for j in range(8):
@@ -370,7 +390,9 @@ def resolve_waits(lines):
             since = None
             continue
         out.append(ln)
-        if ln.startswith(".L") or ln.startswith("s_cbranch"):
+        if ln.startswith(".Lcs_") or ln.startswith("s_cbranch_scc0 .Lcs_"):
+            pass             # a forward skip over register-only code: no vector memory operation inside, the count stands
+        elif ln.startswith(".L") or ln.startswith("s_cbranch"):
             since = None
         elif ln.startswith("global_load") or ln.startswith("global_store"):
             if since is not None:

@@ -343,7 +343,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                     }
                     // r >= p  <=>  bit 256 of r is set (possible once p > 2^255) or r mod 2^256 + (2^256 - p) carries out of word 7;
                     // either way r - p is that sum mod 2^256
-                    {
+                    // -- behind a test that almost never fires: the quotient is one short once in ~10^4 outputs, and otherwise r < p shows
+                    // in the top word alone (ow_7 + (2^256 - p)_7 + 1 < 2^32 leaves no room for a carry out, whatever the lower words do)
+                    if (__builtin_amdgcn_ballot_w64(top != 0 || ow[7] >= ~bp.pneg[7]) != 0) {
                         uint32_t u[8];
                         unsigned cy2 = 0;
 #pragma unroll

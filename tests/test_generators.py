@@ -27,11 +27,30 @@ def test_resolve_waits_counts_vector_memory_operations(gen):
     assert gen.resolve_waits(["@ELOAD", ld, ld, ld, ld, "@EWAIT"])[-1] == "s_waitcnt vmcnt(2)"
     # a full wait in between: everything landed, later operations need not
     assert gen.resolve_waits(["@ELOAD", ld, ld, ld, "s_waitcnt vmcnt(0)", ld, ld, ld, "@EWAIT"])[-1] == "s_waitcnt vmcnt(3)"
+    # a forward skip over register-only code (the conditional subtraction) does not disturb the count
+    assert gen.resolve_waits(["@ELOAD", ld, ld, ld, "s_cbranch_scc0 .Lcs_7_%=", "v_mov_b32 v0, 0", ".Lcs_7_%=:", "@EWAIT"])[-1] == "s_waitcnt vmcnt(1)"
     # a label or a branch in between: the count is not static
     assert gen.resolve_waits(["@ELOAD", ld, ld, ".Lx_%=:", ld, "@EWAIT"])[-1] == "s_waitcnt vmcnt(0)"
     assert gen.resolve_waits(["@ELOAD", ld, ld, "s_cbranch_scc1 .Lx_%=", ld, "@EWAIT"])[-1] == "s_waitcnt vmcnt(0)"
     # stores count like loads (one counter on gfx9)
     assert gen.resolve_waits(["@ELOAD", ld, ld, "global_store_dwordx4 v[4:5], v[0:3], off", "@EWAIT"])[-1] == "s_waitcnt vmcnt(1)"
+
+
+def check_skips(gen, lines, nout):
+    """the conditional subtraction sits behind a forward branch: its label follows inside the same unit, nothing but register
+    arithmetic in between, and resolve_waits keeps counting across it"""
+    br = [i for i, ln in enumerate(lines) if ln.startswith("s_cbranch_scc0 .Lcs_")]
+    assert len(br) == nout
+    for i in br:
+        label = lines[i].split()[1] + ":"
+        j = lines.index(label)
+        assert i < j <= i + 30
+        body = lines[i + 1:j]
+        assert all(ln.startswith(("v_mov_b32", "v_add_co_u32", "v_addc_co_u32", "v_cndmask_b32")) for ln in body), body
+        assert sum(ln.startswith("v_cndmask_b32") for ln in body) == 8
+        # the test in front of it: top word against ~(2^256 - p)_7, bit 256, or-ed into scc
+        assert lines[i - 1].startswith("s_or_b64") and lines[i - 2].startswith("v_cmp_ne_u32_e64") and lines[i - 3].startswith("v_cmp_le_u32_e32 vcc")
+    assert len({lines[i].split()[1] for i in br}) == nout
 
 
 def check_fold(gen, o, lines, nout):
@@ -100,6 +119,7 @@ def test_pass_structure(gen, check, peel, nout):
         assert a1 == a0 + 3 and any(a0 in bufs for bufs in gen.ABUF)
         assert b1 == b0 + 3 and b0 % 2 == 0 and any(fs <= b0 <= fs + 18 for fs in gen.F_SETS)
     check_fold(gen, o, lines, nout)
+    check_skips(gen, lines, nout)
     # nothing runs under a narrowed exec mask except the loads / stores / compare it was narrowed for
     inside = False
     for ln in lines:
@@ -132,5 +152,6 @@ def test_reduction_units_cover_every_output(gen, nout):
         assert len(stores) == 2 * nout               # two 16-byte stores per output
         if check:
             assert sum(ln.startswith("global_load_dwordx4") for ln in lines) == 2 * nout
-            assert sum(ln.startswith("v_cmp_ne_u32") for ln in lines) == nout
+            assert sum(ln.startswith("v_cmp_ne_u32_e32 vcc, 0") for ln in lines) == nout        # the compare of an output with its received row
         check_fold(gen, o, lines, nout)
+        check_skips(gen, lines, nout)
