@@ -865,7 +865,7 @@ def main():
             "metric": "shares reconstructed/sec (batch open, n=64 t=21)" if args.workload.startswith("cfg3") else f"shares reconstructed/sec (batch open, n={n} t={t})",
             "value": value, "unit": "shares/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("u256 (integer mod p): exact int8 x int8 -> int32 byte-split GEMM on the matrix cores, Barrett reduction on 29-bit digits"
+            "dtype": ("u256 (integer mod p): exact int8 x int8 -> int32 byte-split GEMM on the matrix cores; the high half of every sum folded mod p on the matrix cores too, one-word Barrett quotient"
                       if mfma else "u256 (integer mod p, 9 x 29-bit digits in u32, 64-bit accumulators)"), "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: batch_reconstruct per-party open, n={n}, t={t}, B={B} shares per GPU, "
@@ -886,11 +886,12 @@ def main():
                 "algorithmic_bytes_per_launch": alg_bytes_enc, "avg_launch_ms": enc_ms,
                 "copy_GBps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
                 "second": valu_roofline(args.workload if mfma else args.workload + "_valu", enc_ms),
-                "note": ("instruction-issue bound: one wave per SIMD (all 63 int32 columns of a 16 x 16 pass live in AGPRs) issues an instruction every "
-                         "~5.3 cycles, ~2800 per pass at d = 22 of which 468 are MFMAs (7.5 k of 14.8 k cycles of matrix-pipe time; DESIGN.md section 11 prices what is left in it); "
+                "note": ("instruction-issue bound: one wave per SIMD (all 63 int32 columns of a 16 x 16 pass live in AGPRs); a pass at d = 22 is 532 MFMAs "
+                         "(468 of the product, 64 of the fold of the sums' high halves) at ~12 cycles of issue each and ~1600 other instructions at ~4 "
+                         "(a wave64 instruction occupies its SIMD for four cycles whatever it is; DESIGN.md sections 4c and 11); "
                          "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md section 4c") if fused_default else
                         ("neither HBM nor the matrix pipe binds: per 16x16 tile 47 int32 columns x (d/4) MFMAs are followed by a 390-bit "
-                         "reduction + Barrett per output on the VALU (~1550 VALU ops per wave pass, VALU ~67% busy, matrix pipe ~41% busy by PMC); "
+                         "reduction per output (its high words folded on the matrix cores, the rest on the VALU: instruction-issue bound, DESIGN.md section 4b); "
                          if mfma else
                          "integer-ALU bound by construction (~840 VALU instructions per 32-byte output, VALU ~76% busy by PMC); ") +
                         "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md",

@@ -22,7 +22,7 @@ def main(src):
         c = [r for r in table if r[0].startswith(prefix) and "streams" not in r[0]]
         return max(c, key=lambda r: r[2])[3] if c else float("nan")
 
-    f1 = avg_prefix(t3, "hb::k_mm8w<true, 3, 3")        # <CHECK, written-out K-blocks, sums per lane[, folded digits]>
+    f1 = avg_prefix(t3, "hb::k_mm8w<true, 3, 3")        # <CHECK, written-out K-blocks, sums per lane>
     f2 = avg_prefix(t3, "hb::k_mm8w<true, 3, 4")
     three = j["detail"]["shares_per_s_per_gpu_three_full_encodes"]
     put("r03_bench_cfg3_kernel_stats.txt", [
@@ -33,8 +33,9 @@ def main(src):
         "# 21 us of a 208 us step; two opens in flight on two streams fill it (detail.shares_per_s_per_gpu_two_opens_in_flight).",
         f"# hb::k_mm8<3,false,true> ({dec:.1f} us), hb::k_mm8<3,true,false> with 53.9 KB of LDS ({chk:.1f} us) and k_prescale_tab ({pre:.1f} us) are the same open with HB_OPEN_OPT_FUSED_VALIDATE = 0 --",
         f"# the round-1 definition of the headline, detail.shares_per_s_per_gpu_three_full_encodes: {enc:.1f} + 2 x ({pre:.1f} + {dec:.1f} + {chk:.1f}) = {enc + 2 * (pre + dec + chk):.0f} us, {three / 1e9:.2f} G shares/s.",
-        "# k_decode_check / k_matvec3 are the integer-VALU family (bench's secondary figure), [2 streams] rows the two-opens-in-flight figure; the template arguments of k_mm8w are <CHECK, written-out K-blocks, sums kept per lane, high digits folded>.",
-        "# The kernels of the headline are round 2's (DESIGN section 12 says why they were left alone); round 3's kernel work is in hb_quick.hip (r03_device_decoder_*.txt) and in k_mm8w's unit numbering (r03_pmc_cfg5-shard_row_groups.txt)."],
+        "# k_decode_check / k_matvec3 are the integer-VALU family (bench's secondary figure), [2 streams] rows the two-opens-in-flight figure; the template arguments of k_mm8w are <CHECK, written-out K-blocks, sums kept per lane>.",
+        "# Round 3, second half: both headline kernels fold the high half of a sum on the matrix cores (DESIGN 4b / 4c; round 2: encode 54.8, R1 53.0, R2 85.1 us on the box of r03's first collections);",
+        "# round 3's other kernel work is in hb_quick.hip (r03_device_decoder_*.txt) and in k_mm8w's unit numbering (r03_pmc_cfg5-shard_row_groups.txt)."],
         open(os.path.join(src, "kernel_stats_cfg3.txt")).read())
     for w, shape in (("cfg3-omega", "config 3 at omega-power points (n=64, t=21, 2^20 shares)"),
                      ("cfg5-shard", "one GPU's 1/8 shard of BASELINE config 5 (n=256, t=85, 2^19 shares, omega points, 6097 chunks)")):
