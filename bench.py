@@ -207,9 +207,11 @@ def valu_roofline(workload, launch_ms):
             "pmc_kernel_cycles": pc.get("kernel_cycles"),
             "note": "frac is against the nominal 2.4 GHz and one wave-instruction per 4 cycles per SIMD; the PMC pass counts the kernel's busy cycles "
                     "(pmc_kernel_cycles; / duration = the clock it sustained, ~2.1 GHz), of which the same instruction stream is the "
-                    "pmc_valu_busy fraction.  A kernel that runs ONE wave per SIMD (k_mm8w) issues an instruction every ~5.5 cycles at best, "
-                    "whatever its kind (profiles/r01_mad_issue_rate_vs_occupancy.txt, profiles/r02_mm8w_phase_timing.txt): for it "
-                    "0.5 on this scale is the ceiling"}
+                    "pmc_valu_busy fraction.  A kernel that runs ONE wave per SIMD (k_mm8w) issues an instruction every ~5 cycles at best "
+                    "and an MFMA holds the SIMD's issue for ~12 of its 16 cycles (profiles/r01_mad_issue_rate_vs_occupancy.txt, "
+                    "profiles/r02_issue_rate_of_the_pass_mix.txt): for it ~0.5 on this scale is the ceiling.  Round 3 took 29 % of the R2 launch's "
+                    "instructions out (24.75 M -> 17.55 M) for 5 % of its cycles: this fraction FELL with a faster kernel -- it is a count of "
+                    "issue slots used, not a measure of how close the kernel is to a bound (DESIGN.md section 11)"}
 
 
 def ntl_baseline(n, t, sample_b, threads):
