@@ -92,7 +92,11 @@ def interleave(mfmas, ops):
     return out
 
 
-def asm_half(half, nkb):
+def asm_half(half, nkb, skip=False):
+    """skip: the matrix has no digit above the eighth in its first eight terms (Vandermonde matrices at small points: x^l < 2^56
+    for l < 8), so the MFMAs of digit group 1 in K-block 0 would add zeros -- they are left out (39 of 78 n_kb), and the columns only
+    group 1 reaches start from the bias in K-block 1 instead"""
+    assert not skip or nkb >= 2
     cols = half_columns(half)
     pos = {c: i for i, c in enumerate(cols)}
     ncol = len(cols)
@@ -103,7 +107,7 @@ def asm_half(half, nkb):
         for k in (-2, 8):
             for e in (0, 1):
                 L.append(f"v_mov_b32 v{f(s, k, e)}, 0")
-    L += lds_loads(0, xs_op, as_op)
+    L += lds_loads(0, xs_op, as_op)[:(5 if skip else 6)]          # (skip: group 1's digits of K-block 0 are not needed)
     groups = [(kb, rho) for kb in range(nkb) for rho in HALF_RHOS[half]]
 
     def prep(gi):
@@ -137,11 +141,13 @@ def asm_half(half, nkb):
             r = f(s, q, 0)
             assert r % 2 == 0
             for grp in (0, 1):
+                if skip and kb == 0 and grp == 1:
+                    continue
                 c = 4 * q + rho + 7 + 8 * grp
                 ab = ABUF[kb & 1][grp]
                 cin = f"%{pos[c]}"
                 if c not in started:
-                    assert kb == 0
+                    assert kb == 0 or (skip and kb == 1)
                     cin = bias
                     started.add(c)
                 out.append(f"v_mfma_i32_16x16x64_i8 %{pos[c]}, v[{ab}:{ab + 3}], v[{r}:{r + 3}], {cin}")
@@ -170,12 +176,12 @@ def emit():
         cols = half_columns(half)
         out.append(f"// half {half}: {cols}")
     assert half_columns(0) == [c for c in range(NC) if c % 4 in (0, 3)] and half_columns(1) == [c for c in range(NC) if c % 4 in (1, 2)]
-    out.append("template <int NKB, int HALF> struct Mm8Phase;")
+    out.append("template <int NKB, int HALF, bool SKIP = false> struct Mm8Phase;")
     clob = ", ".join(f'"v{r}"' for r in range(CLOBBER_LO, CLOBBER_HI + 1))
-    for nkb in range(1, MAXKB + 1):
+    for nkb, skip in [(k, False) for k in range(1, MAXKB + 1)] + [(k, True) for k in range(2, MAXKB + 1)]:
         for half in range(2):
-            lines, ncol = asm_half(half, nkb)
-            out.append(f"template <> struct Mm8Phase<{nkb}, {half}> {{")
+            lines, ncol = asm_half(half, nkb, skip)
+            out.append(f"template <> struct Mm8Phase<{nkb}, {half}, {'true' if skip else 'false'}> {{")
             out.append("    static __device__ __forceinline__ void run(v4i (&acc)[24], uint32_t xs_addr, uint32_t as_addr, v4i biasv) {")
             out.append("        asm volatile(")
             for ln in lines:

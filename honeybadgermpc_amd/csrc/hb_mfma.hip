@@ -48,6 +48,7 @@ struct BarrettParams {
 
 struct Mm8Matrix {
     int n_out, d, nkb, n_rt;
+    bool skip01;       // digit group 1 of K-block 0 is zero in every row tile (k_mm8<.., SKIP>)
     int4 *a8;          // [n_rt][nkb][2 digit groups][64 lanes] 16 balanced digits each: lane (r, g) = row 16 rt + 4 (r % 4) + r / 4;
                        // byte j = 4 dd + bi is digit 7 + 8 G - 4 (dd >> 1) - bi of term 8 kb + 2 g + (dd & 1)
     uint32_t *crow;    // [n_rt * 16][16]: per row eight pairs [bias of the fold's four columns + constant word]; then the fold table
@@ -83,7 +84,9 @@ __device__ unsigned long long g_mm8_t[2048 * 8];
 #else
 #define MM8_T(k) do { } while (0)
 #endif
-template <int NKB, bool CHECK, bool RAGGED>
+// SKIP: no entry of the matrix has a digit above the eighth in its first eight terms -- K-block 0 runs without its second digit group
+// (gen_mm8.py; checked when the image is built: Vandermonde matrices at the points 1 .. n, whose l-th powers stay below 2^56 for l < 8)
+template <int NKB, bool CHECK, bool RAGGED, bool SKIP>
 __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
                                                 const uint32_t *__restrict__ zero_src,
                                                 const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 v4i acc[24];
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                Mm8Phase<NKB, 0>::run(acc, xs_addr, as_addr, biasv);
+                Mm8Phase<NKB, 0, SKIP>::run(acc, xs_addr, as_addr, biasv);
                 __builtin_amdgcn_sched_barrier(0);
                 MM8_T(3);   // MFMA half 0
 #pragma unroll
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 MM8_T(4);   // parking of half 0
-                Mm8Phase<NKB, 1>::run(acc, xs_addr, as_addr, biasv);
+                Mm8Phase<NKB, 1, SKIP>::run(acc, xs_addr, as_addr, biasv);
                 __builtin_amdgcn_sched_barrier(0);
                 MM8_T(5);   // MFMA half 1
                 // next unit's DMA (issued a pass ago) must have landed before this wave reaches the barrier; waiting
@@ -537,6 +540,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     }
 
     std::vector<int8_t> a((size_t)n_rt * nkb * 2 * 64 * 16, 0);
+    bool skip01 = nkb >= 2 && !getenv("HB_MM8_NO_SKIP");
     std::vector<uint32_t> cr((size_t)n_rt * 16 * 16 + (size_t)MM8_FOLD_Q * 4, 0);
     memcpy(&cr[(size_t)n_rt * 16 * 16], foldtab.data(), foldtab.size());
     // rows beyond n_out: the bias pairs alone (their outputs are never stored)
@@ -561,6 +565,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
                 // digit b = 7 + 8 G - 4 hi - bi  sits at byte j = 4 (2 hi + el) + bi of the lane's 16 bytes of group G
                 const int grp = b >> 3, r7 = 7 - (b & 7), hi = r7 >> 2, bi = r7 & 3;
                 a[((((size_t)(i / 16) * nkb + l / 8) * 2 + grp) * 64 + (size_t)lane_) * 16 + 4 * (2 * hi + el) + bi] = (int8_t)t;
+                if (t != 0 && grp == 1 && l < 8) skip01 = false;
                 colsum += (t < 0) ? -t : t;
             }
             if (carry) return HB_ERR_UNSUPPORTED;                           // |entry| >= 127 * 256^15 or so
@@ -581,7 +586,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
         }
     }
     Mm8Matrix *m = new Mm8Matrix();
-    m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr;
+    m->n_out = n_out; m->d = d; m->nkb = nkb; m->n_rt = n_rt; m->skip01 = skip01; m->a8 = nullptr; m->crow = nullptr; m->zero = nullptr;
     m->bp = bpar;
     {   // 2^256 - p, 32-bit words
         Big pn(9, 0); pn[8] = 1;
@@ -620,27 +625,29 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
     const bool check = check_mask_dev != nullptr;
     // the last row tile holds at most 8 rows: its outputs 2 and 3 are padding and their reduction can be skipped
     const bool ragged = !check && (m->n_out % 16) >= 1 && (m->n_out % 16) <= 8;
-#define MM8_LAUNCH_(NKB, CHK, RG)                                                                                     \
+#define MM8_LAUNCH_(NKB, CHK, RG, SK)                                                                                 \
     do {                                                                                                          \
         static bool attr_done = false;                                                                            \
         if (!attr_done) {                                                                                         \
-            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8<NKB, CHK, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8<NKB, CHK, RG, SK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
             attr_done = true;                                                                                     \
         }                                                                                                         \
-        hipLaunchKernelGGL((k_mm8<NKB, CHK, RG>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, \
+        hipLaunchKernelGGL((k_mm8<NKB, CHK, RG, SK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, \
                            iv.stride_l, in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count,   \
                            check_mask_dev, check_rows_dev, mismatch_dev, copy_dst, cpv.stride_c, cpv.stride_l, copy_count, copy_rows,         \
                            m->n_out, m->n_rt, tpw, C, n_units, m->bp);             \
     } while (0)
-#define MM8_LAUNCH(NKB) do { if (check) MM8_LAUNCH_(NKB, true, false); else if (ragged) MM8_LAUNCH_(NKB, false, true); else MM8_LAUNCH_(NKB, false, false); } while (0)
+#define MM8_LAUNCH(NKB) do { if (check) MM8_LAUNCH_(NKB, true, false, false); else if (ragged) MM8_LAUNCH_(NKB, false, true, false); else MM8_LAUNCH_(NKB, false, false, false); } while (0)
+#define MM8_LAUNCH_SK(NKB) do { if (check) MM8_LAUNCH_(NKB, true, false, true); else if (ragged) MM8_LAUNCH_(NKB, false, true, false); else MM8_LAUNCH_(NKB, false, false, true); } while (0)
     switch (m->nkb) {
         case 1: MM8_LAUNCH(1); break;
-        case 2: MM8_LAUNCH(2); break;
-        case 3: MM8_LAUNCH(3); break;
-        case 4: MM8_LAUNCH(4); break;
+        case 2: if (m->skip01) MM8_LAUNCH_SK(2); else MM8_LAUNCH(2); break;
+        case 3: if (m->skip01) MM8_LAUNCH_SK(3); else MM8_LAUNCH(3); break;
+        case 4: if (m->skip01) MM8_LAUNCH_SK(4); else MM8_LAUNCH(4); break;
         default: return fail(ctx, HB_ERR_UNSUPPORTED, "mm8: more than 32 terms");
     }
 #undef MM8_LAUNCH
+#undef MM8_LAUNCH_SK
 #undef MM8_LAUNCH_
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;
