@@ -208,8 +208,8 @@ def valu_roofline(workload, launch_ms):
             "note": "frac is against the nominal 2.4 GHz and one wave-instruction per 4 cycles per SIMD; the PMC pass counts the kernel's busy cycles "
                     "(pmc_kernel_cycles; / duration = the clock it sustained, ~2.1 GHz), of which the same instruction stream is the "
                     "pmc_valu_busy fraction.  A kernel that runs ONE wave per SIMD (k_mm8w) issues an instruction every ~5 cycles at best "
-                    "and an MFMA holds the SIMD's issue for ~12 of its 16 cycles (profiles/r01_mad_issue_rate_vs_occupancy.txt, "
-                    "profiles/r02_issue_rate_of_the_pass_mix.txt): for it ~0.5 on this scale is the ceiling.  Round 3 took 29 % of the R2 launch's "
+                    "and an MFMA holds the SIMD for its whole 16 cycles (profiles/r01_mad_issue_rate_vs_occupancy.txt, "
+                    "profiles/r02_issue_rate_of_the_pass_mix.txt, the zero-group skip of k_mm8 in DESIGN.md section 11): for it ~0.5 on this scale is the ceiling.  Round 3 took 29 % of the R2 launch's "
                     "instructions out (24.75 M -> 17.55 M) for 5 % of its cycles: this fraction FELL with a faster kernel -- it is a count of "
                     "issue slots used, not a measure of how close the kernel is to a bound (DESIGN.md section 11)"}
 
@@ -889,8 +889,8 @@ def main():
                 "copy_GBps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
                 "second": valu_roofline(args.workload if mfma else args.workload + "_valu", enc_ms),
                 "note": ("instruction-issue bound: one wave per SIMD (all 63 int32 columns of a 16 x 16 pass live in AGPRs); a pass at d = 22 is 532 MFMAs "
-                         "(468 of the product, 64 of the fold of the sums' high halves) at ~12 cycles of issue each and ~1600 other instructions at ~4 "
-                         "(a wave64 instruction occupies its SIMD for four cycles whatever it is; DESIGN.md sections 4c and 11); "
+                         "(468 of the product, 64 of the fold of the sums' high halves) at ~17 cycles of the SIMD each -- nothing rides under an int8 MFMA -- "
+                         "and ~1600 other instructions at ~4 (DESIGN.md sections 4c and 11); "
                          "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md section 4c") if fused_default else
                         ("neither HBM nor the matrix pipe binds: per 16x16 tile 47 int32 columns x (d/4) MFMAs are followed by a 390-bit "
                          "reduction per output (its high words folded on the matrix cores, the rest on the VALU: instruction-issue bound, DESIGN.md section 4b); "
