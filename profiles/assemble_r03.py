@@ -14,20 +14,24 @@ from assemble_r02 import avg, clean, last_json, put, rows  # noqa: E402
 def main(src):
     j = last_json(os.path.join(src, "bench_default.json"))
     t3 = rows(os.path.join(src, "kernel_stats_cfg3.txt"))
-    enc = avg(t3, "hb::k_mm8<3, false, false>", None)
-    dec = avg(t3, "hb::k_mm8<3, false, true>", None)
-    chk = avg(t3, "hb::k_mm8<3, true, false>", "min")
-    pre = avg(t3, "k_prescale_tab", None)
-    def avg_prefix(table, prefix):
+    def avg_prefix(table, prefix, pick=None):
+        """the most-launched row whose kernel name starts with `prefix` (one stream; pick = 'min': of the smallest LDS size)"""
         c = [r for r in table if r[0].startswith(prefix) and "streams" not in r[0]]
+        if c and pick == "min":
+            c = [r for r in c if r[1] == min(x[1] for x in c)]
         return max(c, key=lambda r: r[2])[3] if c else float("nan")
+
+    enc = avg_prefix(t3, "hb::k_mm8<3, false, false")      # <K-blocks, CHECK, RAGGED, SKIP (K-block 0 without its second digit group)>
+    dec = avg_prefix(t3, "hb::k_mm8<3, false, true")
+    chk = avg_prefix(t3, "hb::k_mm8<3, true, false", "min")
+    pre = avg(t3, "k_prescale_tab", None)
 
     f1 = avg_prefix(t3, "hb::k_mm8w<true, 3, 3")        # <CHECK, written-out K-blocks, sums per lane>
     f2 = avg_prefix(t3, "hb::k_mm8w<true, 3, 4")
     three = j["detail"]["shares_per_s_per_gpu_three_full_encodes"]
     put("r03_bench_cfg3_kernel_stats.txt", [
         "# rocprofv3 --kernel-trace --stats -- python bench.py --cpu-sample 0   (MI355X, round 3, final state; summarised per kernel and launch geometry by profiles/summarize_rocpd.py)",
-        f"# One open = hb::k_mm8<3,false,false> (R1 encode, {enc:.1f} us) + hb::k_mm8w<true,3,3> (R1 decode + validate fused: rows [V^-1 row 0 ; V[zc] V^-1], 22 x 22, row tiles of 12, {f1:.1f} us)",
+        f"# One open = hb::k_mm8<3,false,false,true> (R1 encode, {enc:.1f} us) + hb::k_mm8w<true,3,3> (R1 decode + validate fused: rows [V^-1 row 0 ; V[zc] V^-1], 22 x 22, row tiles of 12, {f1:.1f} us)",
         f"#          + hb::k_mm8w<true,3,4> (R2 decode + validate fused: rows [V^-1 ; V[zc] V^-1], 43 x 22, {f2:.1f} us) = {enc + f1 + f2:.1f} us of kernels in a {j['ms_per_step'] * 1e3:.0f} us step ({j['value'] / 1e9:.2f} G shares/s on this box).",
         "# Between the dependent launches of one stream the GPU idles 5.7 us (encode -> R1, R1 -> R2) and 10 us between steps (start / end timestamps of the 212 timed opens in this trace):",
         "# 21 us of a 208 us step; two opens in flight on two streams fill it (detail.shares_per_s_per_gpu_two_opens_in_flight).",
