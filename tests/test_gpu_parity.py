@@ -109,6 +109,21 @@ def test_vandermonde_vs_oracle(hip, p):
         assert hip.vandermonde_batch_interpolate(xz, ys, p) == oracle.vandermonde_batch_interpolate(xz, ys, p)
 
 
+def test_vandermonde_points_with_and_without_high_digits_in_the_first_terms(hip, monkeypatch):
+    """k_mm8 leaves the second digit group of K-block 0 out when no entry x^l, l < 8, has a digit above the eighth (the points 1 .. n);
+    points around 1000 do have them (1000^7 > 2^69) while their powers still fit the small-entry kernel (1000^11 < 2^110): both
+    variants against the oracle, and the skipping one against itself with the skip switched off"""
+    rnd = random.Random(77)
+    for x, d, c in [(list(range(990, 1006)), 12, 300), ([3, 900, 1000, 17, 256, 255, 257, 1], 10, 270), (list(range(1, 65)), 22, 300), (list(range(1, 33)), 11, 260)]:
+        polys = rand_rows(rnd, P, c, d)
+        want = oracle.vandermonde_batch_evaluate(x, polys, P)
+        assert hip.vandermonde_batch_evaluate(x, polys, P) == want
+    monkeypatch.setenv("HB_MM8_NO_SKIP", "1")
+    x, d, c = list(range(2, 66)), 22, 300          # a point set no test has used: a fresh image, built with the switch set
+    polys = rand_rows(rnd, P, c, d)
+    assert hip.vandermonde_batch_evaluate(x, polys, P) == oracle.vandermonde_batch_evaluate(x, polys, P)
+
+
 def test_vandermonde_edge_cases(hip):
     # ragged rows are zero padded to the longest (pyx:217,232-233); tuples accepted; values reduced mod p
     x = [1, 2, 3]
