@@ -94,10 +94,16 @@ template <int NL> __device__ int poly_degree(const uint32_t *p, int hi, int lane
     return wave_max(best);
 }
 
+// One wave per codeword.  The kernel stops short of the ONE field inversion a codeword needs (Fermat: 255 squarings + ~128
+// multiplications, every lane computing the same thing -- it cost as much as everything else here together, 47 of 102 ms at config 4):
+// the division f = r / v runs as a PSEUDO-division by the un-normalised cofactor V (r <- l r - c_i x^i V, l = lc(V): the true quotient
+// digit is q_i = c_i / l^(dq - i + 1)), the raw c_i and V leave in Montgomery form, packed, in the output buffers, with cs and l in
+// a side record -- and k_gao_finish, one LANE per codeword, inverts w = cs l (64 different inversions per wave for the price of
+// one) and scales the outputs in place.
 template <int NL, int NW>
 __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
                                             int npts, int k, int64_t C, uint32_t *__restrict__ coeffs, uint32_t *__restrict__ errloc,
-                                            int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag) {
+                                            int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag, uint32_t *__restrict__ side) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x;
     const int64_t c = blockIdx.x;
@@ -139,20 +145,25 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
             uint32_t L[NL];
             lds_get<NL>(L, R1 + (size_t)dR1 * NL);
             for (int j = delta; j >= 0; j--) {
-                uint32_t a[NL];
+                uint32_t a[NL], an[NL];
                 lds_get<NL>(a, R0 + (size_t)(dR1 + j) * NL);
+                fp_neg(an, a, P);                 // L u - a w = L u + (p - a) w: ONE reduction for the two products (columns stay below
+                                                  // 3 NL 2^58 < 2^63; the sum is < 2 p^2 < p R / 16, so REDC leaves < 2p: one conditional subtraction)
                 __syncthreads();
                 const int top = dR1 + j;
                 for (int idx = lane; idx < top; idx += 64) {
-                    uint32_t u[NL], t1[NL], r[NL];
+                    uint32_t u[NL], r[NL];
+                    uint64_t col[2 * NL];
                     lds_get<NL>(u, R0 + (size_t)idx * NL);
-                    mont_mul(t1, L, u, P);
+                    col_zero(col);
+                    mac<NL>(col, L, u);
                     if (idx >= j) {
-                        uint32_t w[NL], t2[NL];
+                        uint32_t w[NL];
                         lds_get<NL>(w, R1 + (size_t)(idx - j) * NL);
-                        mont_mul(t2, a, w, P);
-                        fp_sub(r, t1, t2, P);
-                    } else fp_set(r, t1);
+                        mac<NL>(col, an, w);
+                    }
+                    redc(r, col, P);
+                    cond_sub_p(r, P);
                     lds_put<NL>(R0 + (size_t)idx * NL, r);
                 }
                 if (lane == 0) {
@@ -161,15 +172,18 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
                 }
                 const int ttop = max(dT0, dT1 + j);
                 for (int idx = lane; idx <= ttop; idx += 64) {
-                    uint32_t u[NL], t1[NL], r[NL];
+                    uint32_t u[NL], r[NL];
+                    uint64_t col[2 * NL];
                     lds_get<NL>(u, T0 + (size_t)idx * NL);
-                    mont_mul(t1, L, u, P);
+                    col_zero(col);
+                    mac<NL>(col, L, u);
                     if (idx >= j && idx - j <= dT1) {
-                        uint32_t w[NL], t2[NL];
+                        uint32_t w[NL];
                         lds_get<NL>(w, T1 + (size_t)(idx - j) * NL);
-                        mont_mul(t2, a, w, P);
-                        fp_sub(r, t1, t2, P);
-                    } else fp_set(r, t1);
+                        mac<NL>(col, an, w);
+                    }
+                    redc(r, col, P);
+                    cond_sub_p(r, P);
                     lds_put<NL>(T0 + (size_t)idx * NL, r);
                 }
                 dT0 = ttop;
@@ -186,53 +200,51 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
             uint32_t tc[NL]; fp_set(tc, c0); fp_set(c0, c1); fp_set(c1, tc);
         }
     }
-    // ---- f = r / v (exact, deg f < k), v = V / cs --------------------------------------
+    // ---- f = r / v (exact, deg f < k), v = V / cs: everything but the inversion ------------
     const int dv = poly_degree<NL>(vp, dvb, lane);
     bool ok = dv >= 0;
-    uint32_t inv_c[NL], inv_lc[NL];
+    uint32_t lcv[NL];
+    fp_set(lcv, P.one);
+    uint32_t *F = (rp == R0) ? R1 : R0;            // the remainder array not in use: the raw quotient digits c_i (up to D of them)
+    int df = -1, dq = -1;
     if (ok) {
-        uint32_t lcv[NL], w[NL], winv[NL];
         lds_get<NL>(lcv, vp + (size_t)dv * NL);
-        mont_mul(w, cs, lcv, P);
-        fp_inv(winv, w, P);                        // the only inversion
-        mont_mul(inv_c, winv, lcv, P);             // 1 / cs
-        mont_mul(inv_lc, winv, cs, P);             // 1 / lc(V)
-    }
-    uint32_t *F = (rp == R0) ? R1 : R0;            // the remainder array not in use: quotient scratch (up to D coefficients)
-    int df = -1;
-    if (ok) {
-        // error locator (true cofactor v) out, then make V monic in place
+        // the cofactor V as it is (Montgomery form, packed): k_gao_finish scales it by 1 / cs
         for (int idx = lane; idx <= dv; idx += 64) {
-            uint32_t u[NL], e[NL], ec[NL], m[NL];
+            uint32_t u[NL];
             lds_get<NL>(u, vp + (size_t)idx * NL);
-            mont_mul(e, u, inv_c, P);
-            from_mont(ec, e, P);
-            store_digits<NL, NW>(errloc + ((size_t)c * (npts + 1) + idx) * NW, ec);
-            mont_mul(m, u, inv_lc, P);
-            lds_put<NL>(vp + (size_t)idx * NL, m);
+            store_digits<NL, NW>(errloc + ((size_t)c * (npts + 1) + idx) * NW, u);
         }
-        __syncthreads();
         if (dr >= 0) {
             if (dr < dv) ok = false;               // non-zero remainder
             else {
-                const int dq = dr - dv;
+                dq = dr - dv;
                 for (int i = dq; i >= 0; i--) {
-                    uint32_t coef[NL];
+                    uint32_t coef[NL], cn[NL];
                     lds_get<NL>(coef, rp + (size_t)(i + dv) * NL);
+                    fp_neg(cn, coef, P);
                     __syncthreads();
                     if (lane == 0) lds_put<NL>(F + (size_t)i * NL, coef);
-                    for (int idx = lane; idx < dv; idx += 64) {
-                        uint32_t u[NL], w[NL], t2[NL], r[NL];
-                        lds_get<NL>(u, rp + (size_t)(i + idx) * NL);
-                        lds_get<NL>(w, vp + (size_t)idx * NL);
-                        mont_mul(t2, coef, w, P);
-                        fp_sub(r, u, t2, P);
-                        lds_put<NL>(rp + (size_t)(i + idx) * NL, r);
+                    // r <- l r - c_i x^i V below the leading term (which cancels): every remaining coefficient takes the factor l
+                    for (int idx = lane; idx < i + dv; idx += 64) {
+                        uint32_t u[NL], r[NL];
+                        uint64_t col[2 * NL];
+                        lds_get<NL>(u, rp + (size_t)idx * NL);
+                        col_zero(col);
+                        mac<NL>(col, lcv, u);
+                        if (idx >= i) {
+                            uint32_t w[NL];
+                            lds_get<NL>(w, vp + (size_t)(idx - i) * NL);
+                            mac<NL>(col, cn, w);
+                        }
+                        redc(r, col, P);
+                        cond_sub_p(r, P);
+                        lds_put<NL>(rp + (size_t)idx * NL, r);
                     }
                     __syncthreads();
                 }
-                if (poly_degree<NL>(rp, dv - 1, lane) >= 0) ok = false;   // remainder must vanish
-                df = poly_degree<NL>(F, dq, lane);
+                if (poly_degree<NL>(rp, dv - 1, lane) >= 0) ok = false;   // remainder must vanish (l != 0: scaled or not)
+                df = poly_degree<NL>(F, dq, lane);                        // c_i = l^(dq - i + 1) q_i: zero exactly where q_i is
                 if (df >= k) ok = false;
             }
         }
@@ -240,19 +252,64 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
     if (ok) {
         for (int i = lane; i < k; i += 64) {
             uint32_t o[NL];
-            if (i <= df) {
-                uint32_t u[NL], f[NL];
-                lds_get<NL>(u, F + (size_t)i * NL);
-                mont_mul(f, u, inv_lc, P);
-                from_mont(o, f, P);
-            } else {
+            if (i <= df) lds_get<NL>(o, F + (size_t)i * NL);
+            else {
 #pragma unroll
                 for (int q = 0; q < NL; q++) o[q] = 0;
             }
             store_digits<NL, NW>(coeffs + ((size_t)c * k + i) * NW, o);
         }
+        // side record: cs, l (Montgomery form, packed), dq
+        if (lane == 0) {
+            store_digits<NL, NW>(side + (size_t)c * (2 * NW + 4), cs);
+            store_digits<NL, NW>(side + (size_t)c * (2 * NW + 4) + NW, lcv);
+            side[(size_t)c * (2 * NW + 4) + 2 * NW] = (uint32_t)dq;
+            side[(size_t)c * (2 * NW + 4) + 2 * NW + 1] = (uint32_t)df;
+        }
     }
     if (lane == 0) { okflag[c] = ok ? 1 : 0; errlen[c] = ok ? dv + 1 : 0; }
+}
+
+// One lane per codeword: w = cs l, ONE inversion each -- 64 different ones per wave -- then 1 / cs = l / w scales the cofactor into
+// the reference's un-normalised error locator, and powers of 1 / l = cs / w turn the raw quotient digits into coefficients:
+// f_i = c_i / l^(dq - i + 1).  In place, canonical on the way out.
+template <int NL, int NW>
+__global__ void __launch_bounds__(64) k_gao_finish(const FpParams<NL> P, int npts, int k, int64_t C, uint32_t *__restrict__ coeffs,
+                                                   uint32_t *__restrict__ errloc, const int32_t *__restrict__ errlen,
+                                                   const uint8_t *__restrict__ okflag, const uint32_t *__restrict__ side) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (c >= C || !okflag[c]) return;
+    uint32_t cs[NL], l[NL], w[NL], winv[NL], inv_c[NL], linv[NL];
+    load_digits<NL, NW>(cs, side + (size_t)c * (2 * NW + 4));
+    load_digits<NL, NW>(l, side + (size_t)c * (2 * NW + 4) + NW);
+    const int dq = (int)side[(size_t)c * (2 * NW + 4) + 2 * NW], df = (int)side[(size_t)c * (2 * NW + 4) + 2 * NW + 1];
+    mont_mul(w, cs, l, P);
+    fp_inv(winv, w, P);
+    mont_mul(inv_c, winv, l, P);               // 1 / cs
+    mont_mul(linv, winv, cs, P);               // 1 / l
+    const int nloc = errlen[c];
+    for (int j = 0; j < nloc; j++) {
+        uint32_t u[NL], e[NL], ec[NL];
+        uint32_t *pj = errloc + ((size_t)c * (npts + 1) + j) * NW;
+        load_digits<NL, NW>(u, pj);
+        mont_mul(e, u, inv_c, P);
+        from_mont(ec, e, P);
+        store_digits<NL, NW>(pj, ec);
+    }
+    // i = dq .. 0: the power of 1 / l grows by one per step; only i <= df < k carry a non-zero digit
+    uint32_t pw[NL];
+    fp_set(pw, linv);
+    for (int i = dq; i >= 0; i--) {
+        if (i <= df) {
+            uint32_t u[NL], f[NL], o[NL];
+            uint32_t *pi = coeffs + ((size_t)c * k + i) * NW;
+            load_digits<NL, NW>(u, pi);
+            mont_mul(f, u, pw, P);
+            from_mont(o, f, P);
+            store_digits<NL, NW>(pi, o);
+        }
+        if (i > 0) mont_mul(pw, pw, linv, P);
+    }
 }
 
 }  // namespace
@@ -306,15 +363,24 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (rc) { (void)hipFree(g1); return rc; }
     size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3)) * NLr * 4;
+    // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one
+    uint32_t *side = nullptr;
+    const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
+    if (hipMalloc(&side, (size_t)C * side_words * 4) != hipSuccess) { (void)hipFree(g1); return fail(ctx, HB_ERR_HIP, "gao: side buffer"); }
+    const unsigned fin_blocks = (unsigned)((C + 63) / 64);
     if (ctx->n_limbs == 4) {
-        HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
+        k_gao_finish<9, 8><<<fin_blocks, 64, 0, s>>>(ctx->pw, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
     } else {
-        HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
+        k_gao_finish<3, 2><<<fin_blocks, 64, 0, s>>>(ctx->pn, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
     }
-    HB_LAUNCH_CHECK(ctx);
-    HB_HIP(ctx, hipStreamSynchronize(s));
-    HB_HIP(ctx, hipFree(g1));
+    const hipError_t le = hipGetLastError();
+    const hipError_t se = hipStreamSynchronize(s);
+    (void)hipFree(g1);
+    (void)hipFree(side);
+    if (le != hipSuccess || se != hipSuccess) { ctx->err = std::string("gao: ") + hipGetErrorString(le != hipSuccess ? le : se); return HB_ERR_HIP; }
     return HB_OK;
 }
