@@ -171,26 +171,60 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
                     for (int q = 0; q < NL; q++) R0[(size_t)top * NL + q] = 0;
                 }
                 const int ttop = max(dT0, dT1 + j);
-                for (int idx = lane; idx <= ttop; idx += 64) {
-                    uint32_t u[NL], r[NL];
-                    uint64_t col[2 * NL];
-                    lds_get<NL>(u, T0 + (size_t)idx * NL);
-                    col_zero(col);
-                    mac<NL>(col, L, u);
-                    if (idx >= j && idx - j <= dT1) {
-                        uint32_t w[NL];
-                        lds_get<NL>(w, T1 + (size_t)(idx - j) * NL);
-                        mac<NL>(col, an, w);
+                if (ttop < 63) {
+                    // the cofactor fits one round with lanes to spare: lane 63 takes c0 <- L c0 along (the same instructions, a lane
+                    // that would idle) instead of every lane multiplying it again afterwards -- a fifth of a step's arithmetic
+                    const bool cz = lane == 63;
+                    uint32_t hand[NL];
+#pragma unroll
+                    for (int q = 0; q < NL; q++) hand[q] = 0;
+                    if (lane <= ttop || cz) {
+                        uint32_t u[NL], r[NL];
+                        uint64_t col[2 * NL];
+                        if (cz) fp_set(u, c0); else lds_get<NL>(u, T0 + (size_t)lane * NL);
+                        col_zero(col);
+                        mac<NL>(col, L, u);
+                        if (!cz && lane >= j && lane - j <= dT1) {
+                            uint32_t w[NL];
+                            lds_get<NL>(w, T1 + (size_t)(lane - j) * NL);
+                            mac<NL>(col, an, w);
+                        }
+                        redc(r, col, P);
+                        cond_sub_p(r, P);
+                        if (!cz) lds_put<NL>(T0 + (size_t)lane * NL, r);
+#pragma unroll
+                        for (int q = 0; q < NL; q++) hand[q] = r[q];
                     }
-                    redc(r, col, P);
-                    cond_sub_p(r, P);
-                    lds_put<NL>(T0 + (size_t)idx * NL, r);
+#pragma unroll
+                    for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)hand[q], 63);
+                    dT0 = ttop;
+                    __syncthreads();
+                } else {
+                    for (int idx = lane; idx <= ttop; idx += 64) {
+                        uint32_t u[NL], r[NL];
+                        uint64_t col[2 * NL];
+                        lds_get<NL>(u, T0 + (size_t)idx * NL);
+                        col_zero(col);
+                        mac<NL>(col, L, u);
+                        if (idx >= j && idx - j <= dT1) {
+                            uint32_t w[NL];
+                            lds_get<NL>(w, T1 + (size_t)(idx - j) * NL);
+                            mac<NL>(col, an, w);
+                        }
+                        redc(r, col, P);
+                        cond_sub_p(r, P);
+                        lds_put<NL>(T0 + (size_t)idx * NL, r);
+                    }
+                    dT0 = ttop;
+                    __syncthreads();
+                    mont_mul(c0, c0, L, P);           // c0 <- lc(r1)^(delta+1) * c0, one factor per step
                 }
-                dT0 = ttop;
-                __syncthreads();
-                mont_mul(c0, c0, L, P);           // c0 <- lc(r1)^(delta+1) * c0, one factor per step
             }
-            dR0 = poly_degree<NL>(R0, dR1 - 1, lane);
+            {   // the degree drops by exactly one as a rule: look at that coefficient before scanning the polynomial
+                uint32_t topc[NL];
+                if (dR1 >= 1) lds_get<NL>(topc, R0 + (size_t)(dR1 - 1) * NL);
+                dR0 = (dR1 >= 1 && !fp_is_zero(topc)) ? dR1 - 1 : poly_degree<NL>(R0, dR1 - 1, lane);
+            }
             if (dR0 < D) { rp = R0; vp = T0; dr = dR0; dvb = dT0; fp_set(cs, c0); break; }
             // (r0, r1) <- (r1, r2)
             uint32_t *tp = R0; R0 = R1; R1 = tp;
