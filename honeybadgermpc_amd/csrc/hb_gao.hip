@@ -151,7 +151,14 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
                                                   // 3 NL 2^58 < 2^63; the sum is < 2 p^2 < p R / 16, so REDC leaves < 2p: one conditional subtraction)
                 __syncthreads();
                 const int top = dR1 + j;
-                for (int idx = lane; idx < top; idx += 64) {
+                const int ttop = max(dT0, dT1 + j);
+                // One update, r <- L u + (p - a) w, for every coefficient of the remainder R0 below `top` (w = R1[idx - j]) and of the cofactor
+                // T0 up to `ttop` (w = T1[idx - j]), and c0 <- L c0.  deg R0 + deg T0 stays about npts, so what the remainder leaves of its
+                // last round of 64 lanes holds the whole cofactor AND the scale factor: two rounds a step at n = 100 where three and a
+                // wave-wide multiplication were.
+                int base = 0;
+                for (; base + 64 <= top; base += 64) {
+                    const int idx = base + lane;
                     uint32_t u[NL], r[NL];
                     uint64_t col[2 * NL];
                     lds_get<NL>(u, R0 + (size_t)idx * NL);
@@ -166,40 +173,44 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
                     cond_sub_p(r, P);
                     lds_put<NL>(R0 + (size_t)idx * NL, r);
                 }
-                if (lane == 0) {
-#pragma unroll
-                    for (int q = 0; q < NL; q++) R0[(size_t)top * NL + q] = 0;
-                }
-                const int ttop = max(dT0, dT1 + j);
-                if (ttop < 63) {
-                    // the cofactor fits one round with lanes to spare: lane 63 takes c0 <- L c0 along (the same instructions, a lane
-                    // that would idle) instead of every lane multiplying it again afterwards -- a fifth of a step's arithmetic
-                    const bool cz = lane == 63;
+                const int n2 = top - base;                       // lanes the remainder still needs: 0 .. 63
+                const bool merged = n2 + ttop + 1 <= 63;         // ... and the cofactor beside them, lane 63 for c0
+                {
+                    const bool isR = lane < n2, isT = merged && lane >= n2 && lane <= n2 + ttop, cz = merged && lane == 63;
                     uint32_t hand[NL];
 #pragma unroll
                     for (int q = 0; q < NL; q++) hand[q] = 0;
-                    if (lane <= ttop || cz) {
+                    if (isR || isT || cz) {
+                        uint32_t *A = isR ? R0 : T0;
+                        const uint32_t *B = isR ? R1 : T1;
+                        const int idx = isR ? base + lane : lane - n2;
+                        const bool second = isR ? idx >= j : (isT && idx >= j && idx - j <= dT1);
                         uint32_t u[NL], r[NL];
                         uint64_t col[2 * NL];
-                        if (cz) fp_set(u, c0); else lds_get<NL>(u, T0 + (size_t)lane * NL);
+                        if (cz) fp_set(u, c0); else lds_get<NL>(u, A + (size_t)idx * NL);
                         col_zero(col);
                         mac<NL>(col, L, u);
-                        if (!cz && lane >= j && lane - j <= dT1) {
+                        if (second) {
                             uint32_t w[NL];
-                            lds_get<NL>(w, T1 + (size_t)(lane - j) * NL);
+                            lds_get<NL>(w, B + (size_t)(idx - j) * NL);
                             mac<NL>(col, an, w);
                         }
                         redc(r, col, P);
                         cond_sub_p(r, P);
-                        if (!cz) lds_put<NL>(T0 + (size_t)lane * NL, r);
+                        if (!cz) lds_put<NL>(A + (size_t)idx * NL, r);
 #pragma unroll
                         for (int q = 0; q < NL; q++) hand[q] = r[q];
                     }
+                    if (merged) {
 #pragma unroll
-                    for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)hand[q], 63);
-                    dT0 = ttop;
-                    __syncthreads();
-                } else {
+                        for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)hand[q], 63);
+                    }
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int q = 0; q < NL; q++) R0[(size_t)top * NL + q] = 0;
+                }
+                if (!merged) {
                     for (int idx = lane; idx <= ttop; idx += 64) {
                         uint32_t u[NL], r[NL];
                         uint64_t col[2 * NL];
@@ -215,10 +226,10 @@ __global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t
                         cond_sub_p(r, P);
                         lds_put<NL>(T0 + (size_t)idx * NL, r);
                     }
-                    dT0 = ttop;
-                    __syncthreads();
                     mont_mul(c0, c0, L, P);           // c0 <- lc(r1)^(delta+1) * c0, one factor per step
                 }
+                dT0 = ttop;
+                __syncthreads();
             }
             {   // the degree drops by exactly one as a rule: look at that coefficient before scanning the polynomial
                 uint32_t topc[NL];
