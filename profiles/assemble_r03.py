@@ -67,10 +67,13 @@ def main(src):
     put("r03_pmc_cfg5-shard.txt", ["# same passes for --workload cfg5-shard (round 3, final state: the R2 launch (65536 threads) moves 62 MB = 1.24 x algorithmic; before the XCD-aware unit numbering 103.5 MB, r03_pmc_cfg5-shard_row_groups.txt)."],
         open(os.path.join(src, "pmc_summary_cfg5-shard.txt")).read())
     put("r03_config4_robust_decoders.txt", [
-        "# scratch/bench_robust.py 262144 (config 4: n=100, t=33, 33 errors per codeword) and FETCH/WRITE passes at 16384 codewords (round 3: kernels unchanged; hb_wb_decode now hands the row reduction",
-        "# a work list of what Gao rejected).  k_gao: one wave per codeword, ~25 k modular multiplications each at 40-60 % lane occupancy (remainder / cofactor degrees shrink and grow): 5.6e10 mulmod/s is about a third",
-        "# of what 64 busy lanes per wave would give; its 15 KB per codeword are ys 3.2 + g1 written by k_mm8w 3.2 + g1 read back 3.2 + coefficients 1.1 + locator 1.1 KB + the caller's zero-fill of the locator buffer",
-        "# (the interpolant's round trip is the price of computing it on the matrix cores: V^-1 of 100 x 100 does not fit beside the EEA's polynomials in LDS)."],
+        "# scratch/bench_robust.py 262144 (config 4: n=100, t=33, 33 errors per codeword) and FETCH/WRITE passes at 16384 codewords.  Round 3 took k_gao from 117.4 ms / 2.23 M codewords/s to the figures",
+        "# below in four measured steps (DESIGN 4e): one reduction for the two products of a coefficient update 117.4 -> 99.1 ms; pseudo-division + the field inversion moved to k_gao_finish, one LANE per",
+        "# codeword (the Fermat power, computed by all 64 lanes of the codeword's wave, was 46 % of the kernel: 55.1 ms with the inversion stubbed out against 102.2) 99.1 -> 57.9 ms; the scale factor",
+        "# in an idle lane and a degree fast path 57.9 -> 49.1 ms; the cofactor's update in the lanes the remainder's last round leaves free (two rounds a step, not three) 49.1 -> 40.5 ms.",
+        "# HBM traffic per codeword: the interpolant g1 on k_mm8w 6.3 KB (ys in, g1 out), k_gao ~15 KB by the x2-corrected FETCH counter (g1 back in, raw quotient digits and cofactor out), k_gao_finish 4.6 KB",
+        "# (the raw outputs in and the scaled ones out, one lane per codeword: uncoalesced) against 4.3 KB algorithmic -- the interpolant's round trip is the price of computing it on the matrix cores",
+        "# (V^-1 of 100 x 100 does not fit beside the EEA's polynomials in LDS), the finishing kernel's re-read the price of 64 inversions per wave instead of one."],
         clean(os.path.join(src, "robust_cfg4.txt")) + open(os.path.join(src, "pmc_summary_cfg4.txt")).read())
     put("r03_device_decoder_and_coalescer.txt", [
         "# scratch/bench_device_decoder.py, scratch/bench_coalescer.py, scratch/boundary_rates.py, scratch/plan_create_cost.py (round 3: the device decoder is plan-free -- hb_quick_interp_check + hb_probe_*;",
