@@ -238,7 +238,7 @@ void mm8w_shared_free(hb_ctx *ctx);
 int launch_mm8w_raw(hb_ctx *ctx, int n_out, int d, int tile_rows, const void *a8, const uint32_t *crow, const Mm8wShared *sh,
                     const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *out, hb_view ov, int64_t out_count,
                     const int32_t *check_mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store,
-                    int32_t *first_bad_dev);
+                    int32_t *first_bad_dev, uint32_t *bad_map_dev = nullptr);
 void point_tables_free(hb_ctx *ctx);
 // device-built images of [rows of V^-1(z) ; V[zc] V^-1(z)] (hb_quick.hip): layout of one image's buffer, its build, its launch
 struct QuickLayout {
@@ -248,7 +248,7 @@ struct QuickLayout {
 int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L);
 int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s);
 int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const Mm8wShared *sh, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov,
-                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s);
+                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s, uint32_t *bad_map_dev = nullptr);
 // the wide image of a generic matrix, built on first use (nullptr when the path does not apply)
 const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *m, hipStream_t s);
 

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
                                                  const uint32_t *__restrict__ cmp_pk, int64_t cmp_sc, int64_t cmp_sl, int mask_is_map, int n_store,
                                                  int n_out, int n_rt, int nkb, int tpw, int nbuf, int rq, int64_t n_chunks, int64_t n_units,
-                                                 uint32_t bias, const WideParams *__restrict__ wpp, int32_t *__restrict__ first_bad) {
+                                                 uint32_t bias, const WideParams *__restrict__ wpp, int32_t *__restrict__ first_bad, uint32_t *__restrict__ bad_map) {
     extern __shared__ uint4 mm8w_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     uint32_t crl_addr, mode[K];
     // the fold's A operand: lane (m, g') of the diagonal block g' = m / 4 reads its 16 digits, every other lane the row's 16 zero bytes
     const uint32_t atb_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)tlds + (g == (n >> 2) ? 16u * (uint32_t)n : 256u);
-    uint64_t addr[K], flag = 0;
+    uint64_t addr[K];
     crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)crl;
 #pragma unroll
     for (int r = 0; r < K; r++) {
@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     // CHECK mode with first_bad: the first chunk whose compare failed.  A pass's compares run inside the NEXT pass, and a wave's
     // passes walk the chunk tiles in increasing order: the first time its flag becomes non-zero names its smallest such chunk.
     int64_t cmp_chunk0 = 0, bad_chunk = -1;
+    uint64_t any_bad = 0;
 #ifdef HB_MM8_TIMING
     unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
 #endif
@@ -212,6 +213,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         for (int pidx = wave; pidx < n_pairs; pidx += 4) {
             const int tl = pidx / rt_cnt, rt = rt_lo + pidx - tl * rt_cnt;
             const int64_t chunk = (tg * tpw + tl) * 16 + n;
+            uint64_t flag = 0;               // this pass's compares (of the sums the pass before left): a bit per lane
             {
                 uint32_t xa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(xbuf + (size_t)buf * bufsz + (size_t)tl * nkb * 4 * 64 + lane);
                 uint32_t va = (uint32_t)lane * 16u;
@@ -245,9 +247,13 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (CHECK) {
-                if (flag != 0 && bad_chunk < 0) {
+                // (the statement above was handed a fresh flag: what it holds now belongs to the tile compared inside this pass)
+                if (flag != 0) {
                     const uint32_t m16 = (uint32_t)((flag | (flag >> 16) | (flag >> 32) | (flag >> 48)) & 0xffffu);    // lane = chunk + 16 g
-                    bad_chunk = cmp_chunk0 + (__builtin_ctz(m16));
+                    if (bad_chunk < 0) bad_chunk = cmp_chunk0 + (__builtin_ctz(m16));
+                    // every disagreeing chunk, not only the first: a bit per chunk (hb_quick_interp_check_map)
+                    if (bad_map && lane == 0) atomicOr(bad_map + (cmp_chunk0 >> 5), m16 << (cmp_chunk0 & 16));
+                    any_bad = 1;
                 }
                 cmp_chunk0 = chunk - n;          // the tile whose sums this pass leaves for the next one to compare
             }
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         MM8W_T(6);   // single-buffer reload
     }
     // drain: the last pass's sums
+    uint64_t flag = 0;
     {
         uint32_t xa = 0, va = 0, cnt = 0;
         __builtin_amdgcn_sched_barrier(0);
@@ -297,11 +304,12 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
         __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (CHECK) {
-        if (flag != 0 && bad_chunk < 0) {
+        if (flag != 0) {
             const uint32_t m16 = (uint32_t)((flag | (flag >> 16) | (flag >> 32) | (flag >> 48)) & 0xffffu);
-            bad_chunk = cmp_chunk0 + (__builtin_ctz(m16));
+            if (bad_chunk < 0) bad_chunk = cmp_chunk0 + (__builtin_ctz(m16));
+            if (bad_map && lane == 0) atomicOr(bad_map + (cmp_chunk0 >> 5), m16 << (cmp_chunk0 & 16));
         }
-        if (flag != 0 && lane == 0) {
+        if ((flag | any_bad) != 0 && lane == 0) {
             atomicOr(mismatch, 1);
             if (first_bad) atomicMin(first_bad, (int32_t)(bad_chunk > 0x7fffffff ? 0x7fffffff : bad_chunk));
         }
@@ -628,17 +636,17 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
 // result, stored to out when i < n_store): the fused decode + validate of hb_open.hip
 static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                             uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev);
+                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev, uint32_t *bad_map_dev);
 
 int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                 uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                 int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store) {
-    return launch_mm8w_impl(ctx, m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, nullptr);
+    return launch_mm8w_impl(ctx, m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, nullptr, nullptr);
 }
 
 static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                             uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev) {
+                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev, uint32_t *bad_map_dev) {
     if (C <= 0) return HB_OK;
     int tpw = 1, nbuf = 1, rq = m->n_rt;
     const int64_t n_tiles = (C + 15) / 16;
@@ -670,7 +678,7 @@ static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in
         hipLaunchKernelGGL((k_mm8w<CHK, PL, KK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
-                           m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp, first_bad_dev);                         \
+                           m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp, first_bad_dev, bad_map_dev);            \
     } while (0)
     // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
     const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);
@@ -766,12 +774,12 @@ void mm8w_shared_free(hb_ctx *ctx) {
 int launch_mm8w_raw(hb_ctx *ctx, int n_out, int d, int tile_rows, const void *a8, const uint32_t *crow, const Mm8wShared *sh,
                     const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *out, hb_view ov, int64_t out_count,
                     const int32_t *check_mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store,
-                    int32_t *first_bad_dev) {
+                    int32_t *first_bad_dev, uint32_t *bad_map_dev) {
     Mm8wMatrix m;
     m.n_out = n_out; m.d = d; m.nkb = (d + 7) / 8; m.tile_rows = tile_rows; m.n_rt = (n_out + tile_rows - 1) / tile_rows;
     m.shape_tiles = -1; m.shape_tpw = m.shape_nbuf = m.shape_rq = 0;
     m.a8 = (int4 *)const_cast<void *>(a8); m.crow = const_cast<uint32_t *>(crow); m.zero = sh->zero; m.bias = sh->bias; m.wp = (WideParams *)sh->wp;
-    return launch_mm8w_impl(ctx, &m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, first_bad_dev);
+    return launch_mm8w_impl(ctx, &m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, first_bad_dev, bad_map_dev);
 }
 
 }  // namespace hb

@@ -751,11 +751,11 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
 // the launch over a built image: n_store coefficient rows go to out (view ov, out_count elements), the compared rows (if any) are
 // checked against the rows of `cols` they belong to
 int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const Mm8wShared *sh, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov,
-                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s) {
+                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s, uint32_t *bad_map_dev) {
     const int32_t *fmap = (const int32_t *)(base + L.o_map);
     return launch_mm8w_raw(ctx, L.n_out, L.d, L.tile_rows, (const void *)(base + L.o_a8), (const uint32_t *)(base + L.o_crow), sh,
                            cols, cv, (const int32_t *)(base + L.o_z), INT64_MAX, out, ov, out_count,
-                           L.nc > 0 ? fmap : nullptr, mismatch_dev, C, s, cols, cv, n_store, L.nc > 0 ? first_bad_dev : nullptr);
+                           L.nc > 0 ? fmap : nullptr, mismatch_dev, C, s, cols, cv, n_store, L.nc > 0 ? first_bad_dev : nullptr, L.nc > 0 ? bad_map_dev : nullptr);
 }
 
 }  // namespace hb
@@ -763,7 +763,13 @@ int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const M
 extern "C" {
 
 int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
-                          const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev, void *stream) { HB_API_GUARD(ctx);
+                          const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev, void *stream) {
+    return hb_quick_interp_check_map(ctx, x_host, n, z, d, zc, nc, cols_dev, C, chunk_lo, chunk_hi, coeffs_dev, status_dev, nullptr, stream);
+}
+
+int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
+                              const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev,
+                              uint32_t *bad_map_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !x_host || !z || n < 1 || d < 1 || d > n || nc < 0 || (nc > 0 && !zc) || C < 0 || chunk_lo < 0 || chunk_hi > C || chunk_lo > chunk_hi) return HB_ERR_BAD_ARG;
     if (chunk_hi == chunk_lo) return HB_OK;
     if (!cols_dev || (nc > 0 && !status_dev)) return HB_ERR_BAD_ARG;
@@ -790,7 +796,7 @@ int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int3
     const int64_t cnt = chunk_hi - chunk_lo;
     const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
     uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * d * 8 : (uint32_t *)(base + L.o_mcan);       // n_store = 0 when there is nothing to store
-    rc = quick_launch(ctx, L, base, sh, in, pm, out, dv, coeffs_dev ? cnt * (int64_t)d : 0, coeffs_dev ? d : 0, status_dev, status_dev ? status_dev + 1 : nullptr, cnt, s);
+    rc = quick_launch(ctx, L, base, sh, in, pm, out, dv, coeffs_dev ? cnt * (int64_t)d : 0, coeffs_dev ? d : 0, status_dev, status_dev ? status_dev + 1 : nullptr, cnt, s, bad_map_dev);
     if (rc) return rc;
     HB_HIP(ctx, hipEventRecord((hipEvent_t)sl.ev, s));
     return HB_OK;

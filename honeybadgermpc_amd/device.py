@@ -381,6 +381,7 @@ class DeviceIncrementalDecoder:
         self._prefer_tail = False       # robust phase: interpolate from the newest arrivals (True) or the oldest
         self._stalled = None            # polynomial the last robust update could not decode (the probe is on it)
         self._checked = None            # (arrival list, first chunk, coefficients, first disagreeing chunk) of a launch the robust phase may reuse
+        self._scan = None               # robust phase: one launch's coefficients, ALL its disagreeing chunks and who disagrees on each (_Scan)
         self.radius_verdicts = 0        # polynomials settled by the batched launch's own candidate (diagnostic)
         self.probes = 0                 # single-codeword robust decodes so far (diagnostic)
         self.probes_replayed = 0        # probes answered from the previous one (diagnostic)
@@ -472,9 +473,10 @@ class DeviceIncrementalDecoder:
                 raise AssertionError("2 * t + 1 + c <= n")   # reed_solomon_wb.py:132
 
     # -- plan-free kernels (hb_quick.hip) ----------------------------------------------------------------
-    def _quick(self, z, zc, store=True, lo=0, hi=None):
+    def _quick(self, z, zc, store=True, lo=0, hi=None, want_map=False):
         """interpolate every polynomial from chunk `lo` on from the arrived rows z, compare with the arrived rows zc, in one launch:
-        -> ((C, d, limbs) | None, all agreed?, first disagreeing chunk); raises _Unsupported when the kernel does not take it"""
+        -> ((C, d, limbs) | None, all agreed?, first disagreeing chunk); raises _Unsupported when the kernel does not take it.
+        want_map: a fourth value, the list of ALL disagreeing chunks (None when they all agreed)"""
         ctx, t = self.ctx, self.ctx.torch
         d = self.degree + 1
         if self._status is None:
@@ -482,20 +484,30 @@ class DeviceIncrementalDecoder:
         out = ctx.empty(self.batch_size * d) if store else None
         za = np.array(z, dtype=np.int32)
         zca = np.array(zc if zc else [0], dtype=np.int32)
-        rc = ctx.lib.hb_quick_interp_check(ctx.h, np_ptr(self._xh_all), self.n, np_ptr(za), d, np_ptr(zca), len(zc),
-                                           ctx.ptr(self._cols), self.batch_size, lo, self.batch_size if hi is None else hi,
-                                           ctx.ptr(out) if store else None, ctx.ptr(self._status), ctx.stream())
+        hi_ = self.batch_size if hi is None else hi
+        bad_map = t.zeros((hi_ - lo + 31) // 32 + 1, dtype=t.int32, device=ctx.tdev) if want_map and zc else None
+        rc = ctx.lib.hb_quick_interp_check_map(ctx.h, np_ptr(self._xh_all), self.n, np_ptr(za), d, np_ptr(zca), len(zc),
+                                               ctx.ptr(self._cols), self.batch_size, lo, hi_,
+                                               ctx.ptr(out) if store else None, ctx.ptr(self._status),
+                                               ctx.ptr(bad_map) if bad_map is not None else None, ctx.stream())
         if rc == HB_ERR_UNSUPPORTED:
             raise _Unsupported()
-        ctx.check(rc, "hb_quick_interp_check")
+        ctx.check(rc, "hb_quick_interp_check_map")
         self.quick_launches += 1
         dec = out.view(self.batch_size, d, self.L) if store else None
         if not zc:
-            return dec, True, INT32_MAX
+            return (dec, True, INT32_MAX, None) if want_map else (dec, True, INT32_MAX)
         flag, first = self._status.tolist()          # synchronises
         if flag:
             self._status.copy_(self._status_init())
-        return dec, not flag, (first + lo if flag else INT32_MAX)
+        res = (dec, not flag, (first + lo if flag else INT32_MAX))
+        if not want_map:
+            return res
+        bad = None
+        if flag and bad_map is not None:
+            bits = np.unpackbits(bad_map.cpu().numpy().view(np.uint8), bitorder="little")
+            bad = (np.nonzero(bits)[0] + lo).tolist()
+        return res + (bad,)
 
     def _status_init(self):
         init = getattr(self.ctx, "_quick_status_init", None)
@@ -556,6 +568,46 @@ class DeviceIncrementalDecoder:
         zt = t.tensor(self._z, dtype=t.int64, device=self.ctx.tdev)
         differs = (ev.index_select(0, zt) != self._cols[:, chunk, :].index_select(0, zt)).any(dim=1)
         return [self._z[i] for i in t.nonzero(differs).flatten().tolist()]
+
+    # One launch names EVERY chunk some compared sender disagrees on (hb_quick_interp_check_map), and the candidates of an interpolation
+    # set do not change when a compared sender is expelled: while the interpolation set stands and no new column has arrived, the
+    # next disagreeing chunk and the senders that disagree on it are read off a table instead of another launch.  Liars that corrupt
+    # one late chunk each cost a launch and a table, not a launch and an evaluation apiece.
+    _SCAN_CAP = 128              # chunks a table is built for (a sender that corrupts everything is found at its first chunk anyway)
+
+    def _scan_or_quick(self, tail_split, lo):
+        zi, zcmp = self._split(tail_split)
+        sc = self._scan
+        if sc is not None and sc["interp"] == tuple(zi) and sc["lo"] <= lo and set(zcmp) <= sc["check"]:
+            live = set(zcmp)
+            for b in sc["bad"]:
+                if b >= lo and not live.isdisjoint(sc["table"][b]):
+                    return sc["dec"], False, b
+            return sc["dec"], True, INT32_MAX
+        self._scan = None
+        dec, agree, first, bad = self._quick(zi, zcmp, lo=lo, want_map=True)
+        if not agree and bad and len(bad) <= self._SCAN_CAP:
+            self._scan = {"interp": tuple(zi), "check": set(zcmp), "lo": lo, "dec": dec, "bad": bad, "table": self._disagreement_table(dec, bad)}
+        return dec, agree, first
+
+    def _disagreement_table(self, dec, chunks):
+        """chunk -> the arrived senders whose symbol of that chunk differs from the candidate dec[chunk] evaluated at their point"""
+        ctx, t = self.ctx, self.ctx.torch
+        d = self.degree + 1
+        k = len(chunks)
+        idx = t.tensor(chunks, dtype=t.int64, device=ctx.tdev)
+        coeffs = dec.index_select(0, idx).contiguous()                       # (k, d, limbs)
+        ev = ctx.empty(self.n * k)
+        ctx.check(ctx.lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(self._xh_all), self.n, ctx.ptr(coeffs), k, d, ctx.ptr(ev), ctx.stream()), "evaluate")
+        differs = (ev.view(k, self.n, self.L).transpose(0, 1) != self._cols.index_select(1, idx)).any(dim=2).cpu().numpy()      # (n, k)
+        arrived = set(self._z)
+        return {c: {s for s in np.nonzero(differs[:, j])[0].tolist() if s in arrived} for j, c in enumerate(chunks)}
+
+    def _scan_errors(self, dec, first):
+        sc = self._scan
+        if sc is not None and dec is sc["dec"] and first in sc["table"]:
+            return [s for s in self._z if s in sc["table"][first]]
+        return self._candidate_errors(dec[first], first)
 
     def _wb_refusal(self, lo):
         """Welch-Berlekamp only: raise what the reference's decoder raises when it is asked to decode over fewer than
@@ -625,7 +677,7 @@ class DeviceIncrementalDecoder:
                 dec, first = chk[2], chk[3]
                 agree, tail_split = False, False
             else:
-                dec, agree, first = self._quick(*self._split(tail_split), lo=lo)
+                dec, agree, first = self._scan_or_quick(tail_split, lo)
             if agree:
                 if lo == 0:
                     self._partial = dec              # nothing accepted before: the launch's output is the result
@@ -642,7 +694,7 @@ class DeviceIncrementalDecoder:
             # list gets one try too (whichever end worked is tried first from then on).
             radius = (len(self._z) - d) // 2
             first_split, dec2 = tail_split, None
-            errors = self._candidate_errors(dec[first], first)
+            errors = self._scan_errors(dec, first)
             if len(errors) > radius and len(self._z) > d:
                 tail_split = not tail_split
                 dec2, _, _ = self._quick(*self._split(tail_split), lo=first, hi=first + 1)      # this one polynomial only

@@ -128,6 +128,14 @@ int hb_reduce(hb_ctx *ctx, const uint64_t *in_dev, uint64_t *out_dev, int64_t co
 int hb_quick_interp_check(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
                           const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev,
                           void *stream);
+/* The same, and every disagreeing chunk rather than only the first: bit (c - chunk_lo) of bad_map_dev (uint32 words, at least
+ * ceil((chunk_hi - chunk_lo + 31) / 32) + 1 of them, zeroed by the caller) is set for every chunk c some compared column disagrees on.
+ * A decoder whose liars corrupt one late chunk each reads the whole list off one launch (reed_solomon.py:334-365 walks the
+ * polynomials in order; the candidates of one interpolation set do not change when a COMPARED sender is expelled).
+ * bad_map_dev = NULL: hb_quick_interp_check. */
+int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const int32_t *z, int d, const int32_t *zc, int nc,
+                              const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev,
+                              uint32_t *bad_map_dev, void *stream);
 
 /* gao_interpolate for ONE codeword, incremental in its points (rsdecode_impl.h:325-363 as GaoRobustDecoder.robust_decode
  * runs it per polynomial, reed_solomon.py:151-186, 334-365): the probe keeps a reduced basis of the interpolation module of
