@@ -246,3 +246,48 @@ def test_point_tables_are_cache_entries():
     cols = ctx.upload_ints([v for row in vals for v in row])
     assert pr.feed(list(range(n)), cols, 1, 0) == [5]
     pr.close()
+
+
+@pytest.mark.parametrize("n,t,c,omega", [(64, 21, 2000, False), (16, 5, 333, True), (100, 33, 1500, False)])
+def test_quick_interp_check_map_names_every_disagreeing_chunk(n, t, c, omega):
+    """hb_quick_interp_check_map: a bit per chunk (counted from chunk_lo) on which some COMPARED column disagrees -- corrupted interpolation
+    columns change the candidates, not covered here -- for whole batches and sub-ranges; flag and first chunk as hb_quick_interp_check"""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context, np_ptr
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+
+    ctx = Context.get(P)
+    rnd = random.Random(n + 31 * c)
+    d = t + 1
+    point = EvalPoint(GF(P), n, use_omega_powers=omega)
+    x = [point(i).value for i in range(n)]
+    polys = [[rnd.randrange(P) for _ in range(d)] for _ in range(c)]
+    enc = oracle.vandermonde_batch_evaluate(x, polys, P)
+    flat = [enc[k][j] for j in range(n) for k in range(c)]
+    for trial in range(4):
+        order = list(range(n))
+        rnd.shuffle(order)
+        z, zc = order[:d], order[d : d + t]
+        bad_chunks = sorted(rnd.sample(range(c), rnd.choice([1, 2, 17, 40])))
+        bad = list(flat)
+        for m in bad_chunks:
+            for j in rnd.sample(zc, rnd.choice([1, 1, 3])):
+                bad[j * c + m] = (bad[j * c + m] + 1 + rnd.randrange(P - 1)) % P
+        cols = ctx.upload_ints(bad)
+        for lo, hi in [(0, c), (c // 3, c), (c // 5 + 3, c - c // 7), (bad_chunks[0], bad_chunks[0] + 1)]:
+            status = torch.tensor([0, INT_MAX], dtype=torch.int32, device="cuda")
+            words = torch.zeros((hi - lo + 31) // 32 + 1, dtype=torch.int32, device="cuda")
+            out = ctx.empty(c * d)
+            za, zca = np.array(z, dtype=np.int32), np.array(zc, dtype=np.int32)
+            rc = ctx.lib.hb_quick_interp_check_map(ctx.h, np_ptr(ctx.host_elems(x)), n, np_ptr(za), d, np_ptr(zca), len(zc), ctx.ptr(cols), c, lo, hi,
+                                                   ctx.ptr(out), ctx.ptr(status), ctx.ptr(words), ctx.stream())
+            ctx.check(rc, "hb_quick_interp_check_map")
+            flag, first = status.cpu().tolist()
+            bits = np.unpackbits(words.cpu().numpy().view(np.uint8), bitorder="little")
+            got = (np.nonzero(bits)[0] + lo).tolist()
+            want = [m for m in bad_chunks if lo <= m < hi]
+            assert got == want, (trial, lo, hi)
+            assert flag == (1 if want else 0) and first == (want[0] - lo if want else INT_MAX)
+            assert ctx.download_ints(out[lo * d : hi * d]) == [v for row in polys[lo:hi] for v in row]
