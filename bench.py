@@ -191,6 +191,25 @@ def traffic_from_profiles(workload):
 SIMDS, NOMINAL_HZ = 1024, 2.4e9       # 256 CUs x 4 SIMDs; nominal shader clock (MI355X_MICROARCH.md)
 
 
+def prewarm(step, sync, seconds):
+    """The same untimed steps the W warm-up steps are, until `seconds` of wall clock have passed: after the CPU baseline (or a cold start)
+    the GPU sits in a low power state and takes some tens of milliseconds of load to reach the clocks it then holds -- 20 timed steps
+    straight after 5 warm-up steps (5 ms in all) measured 4.9-5.1 G shares/s where 200 steps measure 5.5 G and 20 steps after 200 warm-up
+    steps 5.8 G (profiles/r03_bench_steps_and_warmup.txt).  Never inside the timed region; its length is reported in `detail`."""
+    if seconds <= 0:
+        return 0, 0.0
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        for _ in range(20):
+            step()
+        n += 20
+        sync()
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 5000:
+            return n, el * 1e3
+
+
 def valu_roofline(workload, launch_ms):
     """Second roofline of a kernel that HBM does not bind: VALU issue.  Instructions per launch come from the committed PMC
     pass (SQ_INSTS_VALU: VALU + MFMA wave-instructions), the duration is this run's; the ceiling is one wave-instruction per
@@ -489,6 +508,7 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
             evs[3][i].record()
         return res
 
+    pre_steps, pre_ms = prewarm(step, torch.cuda.synchronize, args.prewarm)
     for _ in range(args.warmup):
         step()
     assert so.ok(), "validation mismatch during warmup"
@@ -549,6 +569,9 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
                 "note": "integer-ALU bound (radix-2^29 Montgomery butterflies); the decodes run on the matrix cores (k_mm8w)",
             },
             "detail": {
+                "prewarm_steps": pre_steps, "prewarm_ms": pre_ms,
+                "prewarm_note": "untimed steps ahead of the `warmup` ones until --prewarm seconds have passed (default 0.2): the GPU leaves its idle power "
+                                "state; the timed region is the `steps` steps after them and nothing else",
                 "compute_ms_per_step_max_over_ranks": compute_ms, "allgather_ms_per_step_max_over_ranks": gather_ms,
                 "allgather_bytes_received_per_rank": 32 * (B - b_loc), "gather_mode": gather_used,
                 "algorithmic_bytes_per_open": alg_bytes_open, "open_algorithmic_GBps": alg_bytes_open / (dt / args.steps) / 1e9,
@@ -571,6 +594,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--prewarm", type=float, default=0.2,
+                    help="seconds of untimed steps ahead of the --warmup steps, to bring the GPU out of its idle power state (0 = none)")
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=1 << 20, help="shares in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-two-streams-extra", dest="two_streams_extra", action="store_false",
@@ -691,6 +716,7 @@ def main():
         if i is not None and time_r2:
             ev3[i].record()
 
+    pre_steps, pre_ms = prewarm(step, torch.cuda.synchronize, args.prewarm)
     for _ in range(args.warmup):
         step()
     assert op.ok(), "validation mismatch during warmup"
@@ -899,6 +925,9 @@ def main():
                         "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md",
             },
             "detail": {
+                "prewarm_steps": pre_steps, "prewarm_ms": pre_ms,
+                "prewarm_note": "untimed steps ahead of the `warmup` ones until --prewarm seconds have passed (default 0.2): the GPU leaves its idle power "
+                                "state; the timed region is the `steps` steps after them and nothing else",
                 "algorithmic_bytes_per_open": alg_bytes_open,
                 "algorithmic_bytes_note": "SURVEY 8d's 32 C (3n + 7d): three full encodes + two decodes, the reference's call sequence; the launches this "
                                           "open actually runs move bytes_of_launches_run (fused decode + validate reads the arrival and the compared columns once)",
