@@ -94,14 +94,15 @@ template <int NL> __device__ int poly_degree(const uint32_t *p, int hi, int lane
     return wave_max(best);
 }
 
-// One wave per codeword.  The kernel stops short of the ONE field inversion a codeword needs (Fermat: 255 squarings + ~128
+// One wave per codeword (at least three to a SIMD: the kernel waits on LDS round trips more than it computes -- 152 registers instead of
+// 194 took config 4 from 40.6 to 37.7 ms, 128 with spills to 38.2).  The kernel stops short of the ONE field inversion a codeword needs (Fermat: 255 squarings + ~128
 // multiplications, every lane computing the same thing -- it cost as much as everything else here together, 47 of 102 ms at config 4):
 // the division f = r / v runs as a PSEUDO-division by the un-normalised cofactor V (r <- l r - c_i x^i V, l = lc(V): the true quotient
 // digit is q_i = c_i / l^(dq - i + 1)), the raw c_i and V leave in Montgomery form, packed, in the output buffers, with cs and l in
 // a side record -- and k_gao_finish, one LANE per codeword, inverts w = cs l (64 different inversions per wave for the price of
 // one) and scales the outputs in place.
 template <int NL, int NW>
-__global__ void __launch_bounds__(64) k_gao(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_gao(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
                                             int npts, int k, int64_t C, uint32_t *__restrict__ coeffs, uint32_t *__restrict__ errloc,
                                             int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag, uint32_t *__restrict__ side) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
