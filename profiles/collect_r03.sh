@@ -49,4 +49,6 @@ timeout 600 python scratch/decoder_cfg5_shape.py > "$OUT/decoder_cfg5_shape.txt"
 timeout 900 python scratch/boundary_rates.py > "$OUT/boundary_rates.txt" 2>&1
 timeout 900 python scratch/plan_create_cost.py > "$OUT/plan.txt" 2>&1
 if [ -f honeybadgermpc_amd/lib/libhbmpc_hip_timing.so ]; then HBMPC_HIP_LIB=honeybadgermpc_amd/lib/libhbmpc_hip_timing.so python scratch/mm8w_phase_timing.py > "$OUT/mm8w_phase_timing.txt" 2>&1; fi
+# the raw traces (rocpd databases, counter CSVs) stay on the box: gpurun brings back 64 MiB at most, and the summaries above are what profiles/ keeps
+rm -rf "$OUT"/stats "$OUT"/stats_* "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_WAVES "$OUT"/c5_pmc_* "$OUT"/c3o_pmc_* "$OUT"/c4_pmc_*
 tail -1 "$OUT/bench_default.json" | cut -c1-300
