@@ -68,9 +68,9 @@ def main(src):
         open(os.path.join(src, "pmc_summary_cfg5-shard.txt")).read())
     put("r03_config4_robust_decoders.txt", [
         "# scratch/bench_robust.py 262144 (config 4: n=100, t=33, 33 errors per codeword) and FETCH/WRITE passes at 16384 codewords.  Round 3 took k_gao from 117.4 ms / 2.23 M codewords/s to the figures",
-        "# below in four measured steps (DESIGN 4e): one reduction for the two products of a coefficient update 117.4 -> 99.1 ms; pseudo-division + the field inversion moved to k_gao_finish, one LANE per",
+        "# below in five measured steps (DESIGN 4e): one reduction for the two products of a coefficient update 117.4 -> 99.1 ms; pseudo-division + the field inversion moved to k_gao_finish, one LANE per",
         "# codeword (the Fermat power, computed by all 64 lanes of the codeword's wave, was 46 % of the kernel: 55.1 ms with the inversion stubbed out against 102.2) 99.1 -> 57.9 ms; the scale factor",
-        "# in an idle lane and a degree fast path 57.9 -> 49.1 ms; the cofactor's update in the lanes the remainder's last round leaves free (two rounds a step, not three) 49.1 -> 40.5 ms.",
+        "# in an idle lane and a degree fast path 57.9 -> 49.1 ms; the cofactor's update in the lanes the remainder's last round leaves free (two rounds a step, not three) 49.1 -> 40.5 ms; three waves to a SIMD 40.5 -> 38 ms.",
         "# HBM traffic per codeword: the interpolant g1 on k_mm8w 6.3 KB (ys in, g1 out), k_gao ~15 KB by the x2-corrected FETCH counter (g1 back in, raw quotient digits and cofactor out), k_gao_finish 4.6 KB",
         "# (the raw outputs in and the scaled ones out, one lane per codeword: uncoalesced) against 4.3 KB algorithmic -- the interpolant's round trip is the price of computing it on the matrix cores",
         "# (V^-1 of 100 x 100 does not fit beside the EEA's polynomials in LDS), the finishing kernel's re-read the price of 64 inversions per wave instead of one."],
