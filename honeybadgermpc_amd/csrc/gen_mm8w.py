@@ -34,7 +34,7 @@ shifts built from the other set while the current group's MFMAs issue; element p
 K-block parities); v96 .. v163 the reduction (the row to compare with, the 32 columns of the fold, its operands, the packed
 result).  SGPRs s68 .. s89: the reduction constants (scalar loads from WideParams), a saved exec.
 
-Reduction of one output (reduce_output below has the arithmetic; scratch/model_mfma_fold.py is its big-integer model):
+Reduction of one output (reduce_output below has the arithmetic; tests/fold_model.py is its big-integer model):
   the high eight words of the sum go back through the matrix cores against the table t_b = 2^(256 + 8 b) mod p (16 MFMAs whose
   A operands come from LDS), the 32 columns of that, the low eight words, the top word times 2^512 mod p and the per-row constant
   are gathered per 32-bit word; a one-word Barrett quotient; R - q p in words; conditional subtraction of p; then the lane's mode
@@ -245,7 +245,7 @@ def reduce_output(o, r, check):
     (the row constant carries 128 sum_b t_b and the column biases, hb_mfma_wide.hip), R = sum_w P_w 2^(32 w) < 2^272, the quotient
     qhat = floor(floor(R / 2^240) mu / 2^46), mu = floor(2^286 / p), is floor(R / p) or one less, u_w = qhat (2^256 - p)_w + P_w,
     and the words of sum_w u_w 2^(32 w) are R - qhat p with qhat on top of bit 256; one conditional subtraction of p.
-    (scratch/model_mfma_fold.py is this arithmetic in big integers, bounds asserted.)"""
+    (tests/fold_model.py is this arithmetic in big integers, bounds asserted.)"""
     U = []
     wt = [1.0]
     def one(ln):

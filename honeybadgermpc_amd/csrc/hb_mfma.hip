@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         pw[k] = (uint64_t)t;
                     }
                     // R = sum_w P_w 2^(32 w) < 2^272;  qhat = floor(floor(R / 2^240) mu / 2^46), mu = floor(2^286 / p): floor(R / p) or one
-                    // less (scratch/model_mfma_fold.py has the bounds);  u_w = qhat (2^256 - p)_w + P_w: the words of sum_w u_w 2^(32 w)
+                    // less (tests/fold_model.py has the bounds);  u_w = qhat (2^256 - p)_w + P_w: the words of sum_w u_w 2^(32 w)
                     // are R - qhat p, with qhat on top of bit 256
                     const uint64_t tq = pw[7] + (pw[6] >> 32);
                     const uint32_t qh = (uint32_t)(((uint64_t)(uint32_t)(tq >> 16) * bp.mu) >> 46);

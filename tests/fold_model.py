@@ -1,6 +1,6 @@
-#!/usr/bin/env python3
-"""Big-integer model of k_mm8w's reduction with the fold of the high half on the matrix cores (gen_mm8w.py, round 3):
-checks the arithmetic, the representatives t_b and every bound the generated code relies on.  CPU only."""
+"""Big-integer model of the reductions of k_mm8w (gen_mm8w.py reduce_output) and k_mm8 (hb_mfma.hip, epilogue) with the high half of a
+sum folded on the matrix cores: the arithmetic, the representatives t_b and every bound the kernels rely on, as assertions.
+CPU only; tests/test_fold_model.py runs it, `python tests/fold_model.py` runs the long version."""
 import random
 
 def balanced_digits(t, n=32):
@@ -69,15 +69,17 @@ def reduce_model(S, CRorig, p, tb):
     assert r == (S + CRorig) % p
     return r
 
-if __name__ == "__main__":
-    rng = random.Random(1)
-    primes = [0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
-              0xfffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141,
-              0xfffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2f,
-              (1 << 255) - 19, (1 << 254) + 79 * 0 + 0x4f]   # the last is not prime: the arithmetic does not care
-    for p in primes:
+PRIMES = [0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001,
+          0xfffffffffffffffffffffffffffffffebaaedce6af48a03bbfd25e8cd0364141,
+          0xfffffffffffffffffffffffffffffffffffffffffffffffffffffffefffffc2f,
+          (1 << 255) - 19, (1 << 254) + 0x4f]   # the last is not prime: the arithmetic does not care
+
+
+def run_wide(iterations, seed=1):
+    rng = random.Random(seed)
+    for p in PRIMES:
         tb = tables(p)
-        for it in range(3000):
+        for it in range(iterations):
             bits = rng.choice([527, 526, 523, 517, 300, 256, 10])
             S = rng.getrandbits(bits)
             if it % 7 == 0:
@@ -85,7 +87,6 @@ if __name__ == "__main__":
             if it % 11 == 0:
                 S = rng.getrandbits(15) << 512 | ((1 << 512) - 1)
             reduce_model(S, rng.randrange(p), p, tb)
-    print("ok")
 
 
 def mm8_model(cols, CRorig, p, rng):
@@ -151,13 +152,19 @@ def mm8_model(cols, CRorig, p, rng):
     assert r == (S + CRorig) % p
 
 
-if __name__ == "__main__":
-    rng = random.Random(2)
-    for p in primes:
-        for it in range(2000):
+def run_mm8(iterations, seed=2):
+    rng = random.Random(seed)
+    for p in PRIMES:
+        for it in range(iterations):
             hi = 2 * 5800000
             cols = [rng.randrange(hi) if it % 3 else hi - 1 - rng.randrange(3) for _ in range(47)]
             if it % 5 == 0:
                 cols = [rng.randrange(4) for _ in range(47)]
             mm8_model(cols, rng.randrange(p), p, rng)
+
+
+if __name__ == "__main__":
+    run_wide(3000)
+    print("ok")
+    run_mm8(2000)
     print("mm8 ok")
