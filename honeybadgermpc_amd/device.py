@@ -711,6 +711,7 @@ class DeviceIncrementalDecoder:
             self._stalled = first                        # only the probe can say when it becomes decodable
         if self._num_decoded == self.batch_size:
             self._result = self._partial
+            self._scan = None                                # (its launch's coefficient buffer goes with it)
             self._return_probe()
 
     # -- the state machine (reference :288-372) ------------------------------------------------------
