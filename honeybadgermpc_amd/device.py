@@ -377,7 +377,8 @@ class DeviceIncrementalDecoder:
         self._status = None             # (2,) int32 on the device: disagreement flag, first disagreeing chunk
         self._probe_obj = None
         self._settled = None            # polynomial whose verdict is in (its errors expelled) but which is not accepted yet
-        self._memo = None               # (polynomial, arrival list, candidate) settled inside the radius while short of columns
+        self._memo = None               # (polynomial, arrival list, candidate, who disagreed) settled inside the radius while short of columns
+        self._memo_ev = None            # (candidate, its values at the n points)
         self._prefer_tail = False       # robust phase: interpolate from the newest arrivals (True) or the oldest
         self._stalled = None            # polynomial the last robust update could not decode (the probe is on it)
         self._checked = None            # (arrival list, first chunk, coefficients, first disagreeing chunk) of a launch the robust phase may reuse
@@ -562,6 +563,19 @@ class DeviceIncrementalDecoder:
         d = self.degree + 1
         return (self._z[-d:], self._z[:-d]) if tail else (self._z[:d], self._z[d:])
 
+    def _disagreeing_among(self, coeffs, chunk, senders):
+        """those of `senders` (in their order) whose symbol of `chunk` differs from the candidate `coeffs` at their point; the candidate's
+        values at all n points are kept beside it (one small launch the first time)"""
+        if not senders:
+            return []
+        t = self.ctx.torch
+        if self._memo_ev is None or self._memo_ev[0] is not coeffs:
+            self._memo_ev = (coeffs, self._disagreeing(coeffs))
+        ev = self._memo_ev[1]
+        st = t.tensor(senders, dtype=t.int64, device=self.ctx.tdev)
+        differs = (ev.index_select(0, st) != self._cols[:, chunk, :].index_select(0, st)).any(dim=1).tolist()
+        return [s_ for s_, df in zip(senders, differs) if df]
+
     def _candidate_errors(self, coeffs, chunk):
         t = self.ctx.torch
         ev = self._disagreeing(coeffs)
@@ -661,11 +675,12 @@ class DeviceIncrementalDecoder:
             memo, self._memo = self._memo, None
             if memo is not None and memo[0] == lo and self._z[: len(memo[1])] == memo[1]:
                 # the previous call settled this polynomial inside the radius but was short of columns: the same candidate, with
-                # whatever the newer arrivals add to its disagreements, stays Gao's answer while they fit the (larger) radius
-                errors = self._candidate_errors(memo[2], lo)
+                # whatever the newer arrivals add to its disagreements, stays Gao's answer while they fit the (larger) radius.
+                # Who disagreed among the columns of then is known (memo[3]); only the columns that arrived since are compared.
+                errors = memo[3] + self._disagreeing_among(memo[2], lo, self._z[len(memo[1]):])
                 if len(errors) <= (len(self._z) - d) // 2:
                     if len(self._available_points) - len(errors) < self._min_points_required():
-                        self._memo = (lo, list(self._z), memo[2])
+                        self._memo = (lo, list(self._z), memo[2], errors)
                         return
                     self.radius_verdicts += 1
                     self._expel(errors)
@@ -702,7 +717,7 @@ class DeviceIncrementalDecoder:
             if len(errors) <= radius:
                 self._prefer_tail = tail_split
                 if len(self._available_points) - len(errors) < self._min_points_required():
-                    self._memo = (first, list(self._z), (dec2 if tail_split != first_split else dec)[first].clone())
+                    self._memo = (first, list(self._z), (dec2 if tail_split != first_split else dec)[first].clone(), list(errors))
                     return
                 self.radius_verdicts += 1
                 self._expel(errors)
