@@ -105,6 +105,7 @@ struct hb_ctx {
     std::vector<void *> probe_pool, probe_host_pool;
     std::map<int, void *> wide_shared;                // d -> hb::Mm8wShared *
     std::map<std::string, std::vector<int>> wide_shapes;   // launch geometry per (row tiles, K-blocks, chunk tiles)
+    void *mm8_shared = nullptr;                       // hb::Mm8Shared *: constants of the small-entry matrix-core kernels (hb_mm8.hpp)
     int elem_words() const { return n_limbs == 4 ? 8 : 2; }
     int nl() const { return n_limbs == 4 ? 9 : 3; }
 };
@@ -240,6 +241,17 @@ int launch_mm8w_raw(hb_ctx *ctx, int n_out, int d, int tile_rows, const void *a8
                     const int32_t *check_mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store,
                     int32_t *first_bad_dev, uint32_t *bad_map_dev = nullptr);
 void point_tables_free(hb_ctx *ctx);
+void mm8_shared_free(hb_ctx *ctx);
+// per point set: x (Montgomery digits), the powers x_a^i and 1 / (x_a - x_b); for sets of small integers also their values
+struct PointTable {
+    int n, S;
+    uint32_t *xm, *inv, *pw;
+    bool usable;
+    int refs;             // the cache's reference + one per probe that works on this table
+    bool small;           // every point is an integer below 2^16 (the production points 1 .. n): xs holds them
+    std::vector<uint16_t> xs;
+};
+int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hipStream_t s);
 // device-built images of [rows of V^-1(z) ; V[zc] V^-1(z)] (hb_quick.hip): layout of one image's buffer, its build, its launch
 struct QuickLayout {
     int n, d, nc, n_coef, n_out, tile_rows, nkb;
@@ -249,6 +261,18 @@ int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L);
 int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s);
 int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const Mm8wShared *sh, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov,
                  int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s, uint32_t *bad_map_dev = nullptr);
+// decode + validate at small-integer points on the small-entry kernel with the 1 / den_j scaling inside (hb_mfma_fused.hip):
+// layout of one image's buffer (HB_ERR_UNSUPPORTED when the shape / point set / modulus does not qualify), its build in one or two
+// halves (what depends on the arrivals z alone; the rows of the compared senders zc), its launch
+struct FsLayout {
+    int n, d, nc, n_coef, n_out, n_rt, nkb;
+    size_t o_a8, o_crow, o_kt, o_mode, o_z, need;
+};
+constexpr int FS_BUILD_Z = 1, FS_BUILD_ZC = 2;
+int fs_layout(hb_ctx *ctx, const PointTable *pt, int d, int nc, int n_coef, FsLayout *L);
+int fs_build(hb_ctx *ctx, const PointTable *pt, const int32_t *z, const int32_t *zc, const FsLayout &L, uint8_t *base, int flags, int32_t *status_dev, hipStream_t s);
+int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov, int64_t out_count,
+              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s);
 // the wide image of a generic matrix, built on first use (nullptr when the path does not apply)
 const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *m, hipStream_t s);
 

@@ -524,6 +524,7 @@ void hb_ctx_destroy(hb_ctx *ctx) {
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
     point_tables_free(ctx);
     mm8w_shared_free(ctx);
+    mm8_shared_free(ctx);
     delete ctx;
 }
 

@@ -29,37 +29,11 @@
 // quotient: 26 + 35 v_mad_u64_u32 and the digit conversions both ways) -- its 32 columns, L, the top word times
 // 2^384 mod p and the per-row constant are gathered per 32-bit word (six MADs a word), a one-word Barrett quotient,
 // R - q p in words, one conditional subtraction.  No Montgomery form anywhere on this path.
-#include "hb_common.hpp"
+#include "hb_mm8.hpp"
 
 namespace hb {
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-
-constexpr int MM8_NC = 47;       // int32 columns per output
-constexpr int MM8_CW = 13;       // 32-bit words of the per-row constant / the carried sum
-constexpr int MM8_FOLD_ROW = 272;   // bytes per row of the fold table (hb_mfma_wide.hip: sixteen lanes' 16 digits, then 16 zero bytes)
-constexpr int MM8_FOLD_Q = 8 * MM8_FOLD_ROW / 16;   // eight rows (one byte half), in uint4
-
-struct BarrettParams {
-    uint32_t pneg[8]; // 2^256 - p, 32-bit words
-    uint32_t c384[8]; // 2^384 mod p, words
-    uint32_t mu;      // floor(2^286 / p)
-};
-
-struct Mm8Matrix {
-    int n_out, d, nkb, n_rt;
-    bool skip01;       // digit group 1 of K-block 0 is zero in every row tile (k_mm8<.., SKIP>)
-    int4 *a8;          // [n_rt][nkb][2 digit groups][64 lanes] 16 balanced digits each: lane (r, g) = row 16 rt + 4 (r % 4) + r / 4;
-                       // byte j = 4 dd + bi is digit 7 + 8 G - 4 (dd >> 1) - bi of term 8 kb + 2 g + (dd & 1)
-    uint32_t *crow;    // [n_rt * 16][16]: per row eight pairs [bias of the fold's four columns + constant word]; then the fold table
-                       // (MM8_FOLD_Q uint4: the A operands of the eight column blocks)
-    uint32_t *zero;    // 32 zero bytes: DMA source for inputs beyond in_count (zero padding of the last chunk)
-    BarrettParams bp;
-};
-
 #include "hb_mm8_body.inc"
-
-constexpr int MM8_BIAS = 5800000;   // >= 128 * sum |digit| >= |column| (checked per matrix when it is built), and 2 * BIAS * 257 < 2^32
 
 // Persistent workgroups of 4 waves, 2 workgroups per CU (2 waves per SIMD, <= 256 registers each,
 // so that one wave's MFMA stream overlaps its neighbour's VALU epilogue).
@@ -501,6 +475,53 @@ void mm8_free(Mm8Matrix *m) {
     if (!m) return;
     (void)hipFree(m->a8); (void)hipFree(m->crow); (void)hipFree(m->zero);
     delete m;
+}
+
+// The per-context constants of this kernel family (hb_mm8.hpp), for images that are built on the device (hb_mfma_fused.hip).
+int mm8_shared(hb_ctx *ctx, const Mm8Shared **out, hipStream_t s) {
+    if (ctx->mm8_shared) { *out = static_cast<const Mm8Shared *>(ctx->mm8_shared); return HB_OK; }
+    if (ctx->n_limbs != 4 || (ctx->p_limbs[3] >> 62) == 0 || !prescale_params(ctx)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8: modulus");
+    Mm8Shared *sh = new Mm8Shared();
+    memset(sh, 0, sizeof *sh);
+    Big p(8);
+    for (int k = 0; k < 4; k++) { p[2 * k] = (uint32_t)ctx->p_limbs[k]; p[2 * k + 1] = (uint32_t)(ctx->p_limbs[k] >> 32); }
+    uint32_t shift8[8];
+    if (!fold_tables(ctx, 16, sh->fold_host, sh->bp.c384, &sh->bp.mu, shift8)) { delete sh; return fail(ctx, HB_ERR_UNSUPPORTED, "mm8: fold table"); }
+    {   // 2^256 - p, 32-bit words
+        Big pn(9, 0); pn[8] = 1;
+        Big pw9(p); pw9.push_back(0);
+        big_sub(pn, pw9);
+        for (int k = 0; k < 8; k++) sh->bp.pneg[k] = pn[k];
+    }
+    auto digits9 = [](const Big &v, uint32_t *dg) {      // v < 2^256 as nine radix-2^29 digits
+        for (int k = 0; k < 9; k++) {
+            const int bit = 29 * k, j = bit >> 5, sft = bit & 31;
+            const uint64_t w = (uint64_t)(j < (int)v.size() ? v[j] : 0) | ((uint64_t)(j + 1 < (int)v.size() ? v[j + 1] : 0) << 32);
+            dg[k] = (uint32_t)(w >> sft) & DMASK;
+        }
+    };
+    Big biasmod;
+    { Big bt(14, 0); for (int c = 0; c < MM8_NC; c++) { Big t(1, (uint32_t)MM8_BIAS); big_add(bt, big_shl(t, 8 * c, 14)); } biasmod = big_divmod(bt, p, nullptr); }
+    { Big sft(shift8, shift8 + 8); if (!big_ge(biasmod, sft)) big_add(biasmod, p); big_sub(biasmod, sft); }
+    digits9(biasmod, sh->biasmod);
+    {   // (0x80..80 * 2^261) mod p: mont_mul(row sum, .) = 0x80..80 * row sum
+        Big c80(8, 0x80808080u);
+        Big r261(9, 0); r261[8] = 1u << 5;
+        digits9(big_divmod(big_mul(c80, r261), p, nullptr), sh->c80r);
+    }
+    if (hipMalloc(&sh->fold_dev, sizeof sh->fold_host) != hipSuccess) { delete sh; return fail(ctx, HB_ERR_HIP, "mm8: hipMalloc(fold table)"); }
+    if (int rc = upload_table(ctx, sh->fold_dev, sh->fold_host, sizeof sh->fold_host, s)) { (void)hipFree(sh->fold_dev); delete sh; return rc; }
+    ctx->mm8_shared = sh;
+    *out = sh;
+    return HB_OK;
+}
+
+void mm8_shared_free(hb_ctx *ctx) {
+    Mm8Shared *sh = static_cast<Mm8Shared *>(ctx->mm8_shared);
+    if (!sh) return;
+    (void)hipFree(sh->fold_dev);
+    delete sh;
+    ctx->mm8_shared = nullptr;
 }
 
 // Build the int8 operand image of a raw small-entry matrix (hb_fast.hip tables: canonical digits of

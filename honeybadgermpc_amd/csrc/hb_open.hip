@@ -69,7 +69,52 @@ struct hb_open_plan {
     uint8_t *q1, *q2;            // owned buffers (QuickLayout::need bytes each)
     QuickLayout l1, l2;
     const Mm8wShared *qsh;
+    // At points that are small integers the same two products factor as [N ; P] (y ./ den) with small INTEGER matrices: the small-entry
+    // kernel with the division inside (hb_mfma_fused.hip), half the matrix-core work of the full-size one.  Built on the device at plan
+    // creation; where it applies q1 / q2 are only built on request (HB_OPEN_OPT_FUSED_VALIDATE = 2).
+    uint8_t *fs1, *fs2;          // owned buffers (FsLayout::need bytes each)
+    FsLayout fl1, fl2;
 };
+
+// the device-built images of the full-size kernel (q1, q2); failures leave the plan as it is
+static void build_quick_wide(hb_open_plan *pl, hipStream_t s) {
+    hb_ctx *ctx = pl->ctx;
+    if (pl->q1 || getenv("HB_NO_QUICK_PLAN")) return;
+    QuickLayout a, b;
+    const int n = pl->n, d = pl->d, n_check = pl->n_check;
+    if (quick_layout(ctx, n, d, n_check, 1, &a) == HB_OK && quick_layout(ctx, n, d, n_check, d, &b) == HB_OK) {
+        uint8_t *b1 = nullptr, *b2 = nullptr;
+        const Mm8wShared *sh = nullptr;
+        int qrc = HB_OK;
+        if (hipMalloc(&b1, a.need) != hipSuccess || hipMalloc(&b2, b.need) != hipSuccess) qrc = HB_ERR_HIP;
+        const int32_t *zcp = n_check > 0 ? pl->zc.data() : pl->z.data();      // (unused when n_check == 0)
+        if (!qrc) qrc = quick_build(ctx, pl->x.data(), pl->z.data(), zcp, a, b1, &sh, s);
+        if (!qrc) qrc = quick_build(ctx, pl->x.data(), pl->z.data(), zcp, b, b2, &sh, s);
+        if (!qrc) { pl->q1 = b1; pl->q2 = b2; pl->l1 = a; pl->l2 = b; pl->qsh = sh; pl->fused_pending = 0; }
+        else { if (b1) (void)hipFree(b1); if (b2) (void)hipFree(b2); }   // repeated points, overlapping index sets, ...: the host-built path stays
+    }
+    ctx->err.clear();                    // "unsupported" from the device builder is not this call's error
+}
+
+// the device-built images of the small-entry kernel (fs1, fs2); failures leave the plan as it is
+static void build_fused_small(hb_open_plan *pl, hipStream_t s) {
+    hb_ctx *ctx = pl->ctx;
+    if (pl->fs1 || getenv("HB_NO_QUICK_PLAN") || getenv("HB_NO_QUICK")) return;
+    PointTable *pt = nullptr;
+    FsLayout a, b;
+    if (point_table(ctx, pl->x.data(), pl->n, &pt, s) == HB_OK && fs_layout(ctx, pt, pl->d, pl->n_check, 1, &a) == HB_OK &&
+        fs_layout(ctx, pt, pl->d, pl->n_check, pl->d, &b) == HB_OK) {
+        uint8_t *b1 = nullptr, *b2 = nullptr;
+        int qrc = HB_OK;
+        if (hipMalloc(&b1, a.need) != hipSuccess || hipMalloc(&b2, b.need) != hipSuccess) qrc = HB_ERR_HIP;
+        const int32_t *zcp = pl->n_check > 0 ? pl->zc.data() : pl->z.data();
+        if (!qrc) qrc = fs_build(ctx, pt, pl->z.data(), zcp, a, b1, FS_BUILD_Z | FS_BUILD_ZC, pl->mismatch_dev, s);
+        if (!qrc) qrc = fs_build(ctx, pt, pl->z.data(), zcp, b, b2, FS_BUILD_Z | FS_BUILD_ZC, pl->mismatch_dev, s);
+        if (!qrc) { pl->fs1 = b1; pl->fs2 = b2; pl->fl1 = a; pl->fl2 = b; pl->fused_pending = 0; }
+        else { if (b1) (void)hipFree(b1); if (b2) (void)hipFree(b2); }
+    }
+    ctx->err.clear();
+}
 
 // the digit planes of the integer-VALU kernels (2 x 36 B per share): plans on the matrix cores never touch them
 static int valu_planes(hb_open_plan *pl) {
@@ -232,23 +277,12 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     // for the third time (ensure_fused), or at once on request (set_option)
     pl->fused_pending = ((pl->V8 || pl->Winv8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") && !getenv("HB_NO_FUSED_VALIDATE") &&
                          !getenv("HB_NO_MFMA_WIDE") && ctx->n_limbs == 4 && prescale_params(ctx)) ? 1 : 0;
-    if (pl->fused_pending && !getenv("HB_NO_QUICK_PLAN")) {
-        QuickLayout a, b;
-        if (quick_layout(ctx, n, d, n_check, 1, &a) == HB_OK && quick_layout(ctx, n, d, n_check, d, &b) == HB_OK) {
-            uint8_t *b1 = nullptr, *b2 = nullptr;
-            const Mm8wShared *sh = nullptr;
-            int qrc = HB_OK;
-            if (hipMalloc(&b1, a.need) != hipSuccess || hipMalloc(&b2, b.need) != hipSuccess) qrc = HB_ERR_HIP;
-            const int32_t *zcp = n_check > 0 ? zc_host : z_host;      // (unused when n_check == 0)
-            if (!qrc) qrc = quick_build(ctx, x_host, z_host, zcp, a, b1, &sh, s);
-            if (!qrc) qrc = quick_build(ctx, x_host, z_host, zcp, b, b2, &sh, s);
-            if (!qrc) { pl->q1 = b1; pl->q2 = b2; pl->l1 = a; pl->l2 = b; pl->qsh = sh; pl->fused_pending = 0; }
-            else { if (b1) (void)hipFree(b1); if (b2) (void)hipFree(b2); }   // repeated points, overlapping index sets, ...: the host-built path stays
-        }
-        ctx->err.clear();                    // "unsupported" from the device builder is not this call's error
-    }
     PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
+    if (pl->fused_pending) {
+        build_fused_small(pl, s);
+        if (!pl->fs1) build_quick_wide(pl, s);
+    }
 #undef PLAN_HIP
 done:
     if (xd) (void)hipFree(xd);
@@ -287,6 +321,12 @@ static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64
         // it fails for any reason (out of memory while building F1 / F2, ...) the decode goes on unfused and the error is dropped.
         // ensure_fused clears fused_pending first, so a failure is not retried on every call.
         if (ensure_fused(pl, s) != HB_OK) pl->ctx->err.clear();
+    }
+    if (pl->fs1 && pl->fs2 && pl->use_v8 && pl->use_fused == 1 && (pk_rows == 1 || pk_rows == pl->d)) {
+        // small-integer points: [N ; P] over the received columns, divided by den_j inside the kernel
+        const bool r1 = pk_rows == 1 && pl->d > 1;
+        return fs_launch(pl->ctx, r1 ? pl->fl1 : pl->fl2, r1 ? pl->fs1 : pl->fs2, (const uint32_t *)cols_dev, pm, pk_dst, pv, pk_count, pl->mismatch_dev,
+                         nullptr, nullptr, C, s);
     }
     if (pl->q1 && pl->q2 && pl->use_v8 && pl->use_fused && (pk_rows == 1 || pk_rows == pl->d)) {
         // device-built images: ONE launch decodes the rows the caller wants and compares the predictions of the later arrivals
@@ -415,8 +455,9 @@ int hb_open_plan_set_option(hb_open_plan *pl, int option, int value) { HB_API_GU
     }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { pl->use_v8 = value ? 1 : 0; return HB_OK; }
     if (option == HB_OPEN_OPT_FUSED_VALIDATE) {
-        pl->use_fused = value ? 1 : 0;
-        if (value && !pl->F1 && !pl->q1) {
+        pl->use_fused = value == 2 ? 2 : (value ? 1 : 0);
+        if (value == 2 && pl->fs1 && !pl->q1) build_quick_wide(pl, 0);        // the full-size kernel where the small-entry one is the default
+        if (value && !pl->F1 && !pl->q1 && !(pl->fs1 && value == 1)) {
             // asked for explicitly: built now instead of at the third decode
             int rc = ensure_fused(pl, 0);
             if (rc) return rc;
@@ -430,7 +471,9 @@ int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) { HB_API_G
     if (!pl || !value) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { *value = pl->validate_arrived_only; return HB_OK; }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = ((pl->V8 || pl->Winv8 || pl->Vw8) && pl->use_v8) ? 1 : 0; return HB_OK; }
-    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (((pl->F1 && pl->F2) || (pl->q1 && pl->q2) || pl->fused_pending) && pl->use_v8 && pl->use_fused) ? 1 : 0; return HB_OK; }
+    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (((pl->F1 && pl->F2) || (pl->q1 && pl->q2) || pl->fused_pending) && pl->use_v8 && pl->use_fused) ? 1 : 0;
+        if (pl->fs1 && pl->fs2 && pl->use_v8 && pl->use_fused == 1) *value = 3;          // ... on the small-entry kernel
+        return HB_OK; }
     return HB_ERR_BAD_ARG;
 }
 
@@ -449,6 +492,8 @@ void hb_open_plan_destroy(hb_open_plan *pl) { HB_API_GUARD((pl ? pl->ctx : nullp
     mm8w_free(pl->F1); mm8w_free(pl->F2);
     if (pl->q1) (void)hipFree(pl->q1);
     if (pl->q2) (void)hipFree(pl->q2);
+    if (pl->fs1) (void)hipFree(pl->fs1);
+    if (pl->fs2) (void)hipFree(pl->fs2);
     if (pl->fmap1) (void)hipFree(pl->fmap1);
     if (pl->fmap2) (void)hipFree(pl->fmap2);
     if (pl->Winv) matrix_unref(pl->Winv);

@@ -596,13 +596,6 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
     }
 }
 
-struct PointTable {
-    int n, S;
-    uint32_t *xm, *inv, *pw;
-    bool usable;
-    int refs;             // the cache's reference + one per probe that works on this table
-};
-
 static void point_table_unref(PointTable *pt) {
     if (!pt || --pt->refs > 0) return;
     (void)hipFree(pt->xm); (void)hipFree(pt->inv); (void)hipFree(pt->pw);
@@ -612,12 +605,18 @@ static void point_table_unref(PointTable *pt) {
 // per (context, point set): an entry of the context's LRU like every other table (n^2 elements: 2.4 MB at n = 256), so a caller that
 // keeps inventing point sets cannot grow it without bound; a probe holds its own reference (cache_trim synchronises the device
 // before it drops anything, and only the outermost entry point trims)
-static int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hipStream_t s) {
+int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hipStream_t s) {
     std::string key = table_key("PT", ctx, x_host, n, 0);
     auto it = ctx->ptcache.find(key);
     if (it != ctx->ptcache.end()) { cache_touch(ctx, "pt|" + key); *out = static_cast<PointTable *>(it->second); return HB_OK; }
     PointTable *pt = new PointTable();
     pt->n = n; pt->S = n + 2; pt->xm = pt->inv = pt->pw = nullptr; pt->usable = false; pt->refs = 1;
+    pt->small = ctx->n_limbs == 4;
+    for (int i = 0; i < n && pt->small; i++) {
+        const uint64_t *e = x_host + (size_t)i * 4;
+        if (e[0] >= 65536 || e[1] || e[2] || e[3]) pt->small = false; else pt->xs.push_back((uint16_t)e[0]);
+    }
+    if (!pt->small) pt->xs.clear();
     const int NLr = ctx->nl();
     uint32_t *xd = nullptr;
     int32_t *bad = nullptr;
@@ -775,26 +774,51 @@ int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const 
     if (!cols_dev || (nc > 0 && !status_dev)) return HB_ERR_BAD_ARG;
     hipStream_t s = (hipStream_t)stream;
     cache_trim(ctx);
+    // one slot of the context's ring: image, row constants, scratch, index arrays
+    auto take_slot = [&](size_t need, hb_ctx::QuickSlot **out) -> int {
+        if (ctx->qslots.empty()) ctx->qslots.resize(4);
+        hb_ctx::QuickSlot &sl = ctx->qslots[ctx->qnext++ % ctx->qslots.size()];
+        if (sl.ev) HB_HIP(ctx, hipEventSynchronize((hipEvent_t)sl.ev));      // the launch that last used this slot is over
+        else { hipEvent_t ev; HB_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); sl.ev = ev; }
+        if (sl.cap < need) {
+            if (sl.buf) HB_HIP(ctx, hipFree(sl.buf));
+            sl.buf = nullptr; sl.cap = 0;
+            HB_HIP(ctx, hipMalloc(&sl.buf, need));
+            sl.cap = need;
+        }
+        *out = &sl;
+        return HB_OK;
+    };
+    const int64_t cnt = chunk_hi - chunk_lo;
+    const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
+    hb_view pm{1, C}, dv{d, 1};
+    // points that are small integers: [N ; P] on the small-entry kernel, the inputs divided by den_j inside it (hb_mfma_fused.hip)
+    if (ctx->n_limbs == 4 && !getenv("HB_NO_QUICK")) {
+        PointTable *pt = nullptr;
+        FsLayout F;
+        int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
+        if (fs_layout(ctx, pt, d, nc, coeffs_dev ? d : 1, &F) == HB_OK) {
+            hb_ctx::QuickSlot *sl = nullptr;
+            rc = take_slot(F.need, &sl); if (rc) return rc;
+            uint8_t *base = static_cast<uint8_t *>(sl->buf);
+            rc = fs_build(ctx, pt, z, zc, F, base, FS_BUILD_Z | FS_BUILD_ZC, status_dev, s); if (rc) return rc;
+            uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * d * 8 : nullptr;
+            rc = fs_launch(ctx, F, base, in, pm, out, dv, coeffs_dev ? cnt * (int64_t)d : 0, status_dev, (nc > 0 && status_dev) ? status_dev + 1 : nullptr,
+                           nc > 0 ? bad_map_dev : nullptr, cnt, s);
+            if (rc) return rc;
+            HB_HIP(ctx, hipEventRecord((hipEvent_t)sl->ev, s));
+            return HB_OK;
+        }
+    }
     QuickLayout L;
     int rc = quick_layout(ctx, n, d, nc, coeffs_dev ? d : 1, &L); if (rc) return rc;     // nothing to store: one coefficient row keeps the kernel's shapes simple
-    // one slot of the context's ring: image, row constants, scratch, index arrays
-    if (ctx->qslots.empty()) ctx->qslots.resize(4);
-    hb_ctx::QuickSlot &sl = ctx->qslots[ctx->qnext++ % ctx->qslots.size()];
-    if (sl.ev) HB_HIP(ctx, hipEventSynchronize((hipEvent_t)sl.ev));      // the launch that last used this slot is over
-    else { hipEvent_t ev; HB_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming)); sl.ev = ev; }
-    if (sl.cap < L.need) {
-        if (sl.buf) HB_HIP(ctx, hipFree(sl.buf));
-        sl.buf = nullptr; sl.cap = 0;
-        HB_HIP(ctx, hipMalloc(&sl.buf, L.need));
-        sl.cap = L.need;
-    }
+    hb_ctx::QuickSlot *slp = nullptr;
+    rc = take_slot(L.need, &slp); if (rc) return rc;
+    hb_ctx::QuickSlot &sl = *slp;
     uint8_t *base = static_cast<uint8_t *>(sl.buf);
     const Mm8wShared *sh = nullptr;
     rc = quick_build(ctx, x_host, z, zc, L, base, &sh, s); if (rc) return rc;
     // chunks [chunk_lo, chunk_hi): the views keep the buffer's row stride C, the bases move to chunk_lo
-    hb_view pm{1, C}, dv{d, 1};
-    const int64_t cnt = chunk_hi - chunk_lo;
-    const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
     uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * d * 8 : (uint32_t *)(base + L.o_mcan);       // n_store = 0 when there is nothing to store
     rc = quick_launch(ctx, L, base, sh, in, pm, out, dv, coeffs_dev ? cnt * (int64_t)d : 0, coeffs_dev ? d : 0, status_dev, status_dev ? status_dev + 1 : nullptr, cnt, s, bad_map_dev);
     if (rc) return rc;
@@ -848,26 +872,36 @@ static int probe_launch(hb_probe *pr, const int32_t *idx, int count, const uint6
     if ((int)pr->fed.size() + count > pr->n) return fail(ctx, HB_ERR_BAD_ARG, "probe: more points than parties");
     ProbeIdx ix;
     memset(&ix, 0, sizeof ix);
+    // validate first, remember only what a launch was enqueued for: a refused call leaves the probe as it was
     for (int i = 0; i < count; i++) {
-        if (idx[i] < 0 || idx[i] >= pr->n || std::find(pr->fed.begin(), pr->fed.end(), idx[i]) != pr->fed.end()) return fail(ctx, HB_ERR_BAD_ARG, "probe: point fed twice or out of range");
+        if (idx[i] < 0 || idx[i] >= pr->n || std::find(pr->fed.begin(), pr->fed.end(), idx[i]) != pr->fed.end() || std::find(idx, idx + i, idx[i]) != idx + i)
+            return fail(ctx, HB_ERR_BAD_ARG, "probe: point fed twice or out of range");
         ix.idx[i] = (uint16_t)idx[i];
-        pr->fed.push_back(idx[i]);
     }
-    pr->poly = poly;
     if (count == 0 && reset) return fail(ctx, HB_ERR_BAD_ARG, "probe: nothing fed yet");
     const int S = pr->pt->S, NLr = ctx->nl();
-    const int seq = ++pr->seq;
+    const int seq = pr->seq + 1;
+    // (5 S + 256) NL words: 55.7 KB at the 256-point limit, below the 64 KB a launch may ask for without an attribute
     const size_t lds = ((size_t)5 * S * NLr + (size_t)256 * NLr) * 4;
-#define PROBE_LAUNCH(NLV, NWV, PARAMS)                                                                                                     \
-    do {                                                                                                                                   \
-        static bool attr_done = false;                                                                                                     \
-        if (!attr_done) { HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_feed<NLV, NWV>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); attr_done = true; } \
-        k_probe_feed<NLV, NWV><<<1, 256, lds, s>>>(PARAMS, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,        \
-                                                   (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq);       \
-    } while (0)
-    if (ctx->n_limbs == 4) PROBE_LAUNCH(9, 8, ctx->pw); else PROBE_LAUNCH(3, 2, ctx->pn);
-#undef PROBE_LAUNCH
-    HB_LAUNCH_CHECK(ctx);
+    if (ctx->n_limbs == 4)
+        k_probe_feed<9, 8><<<1, 256, lds, s>>>(ctx->pw, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
+                                               (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq);
+    else
+        k_probe_feed<3, 2><<<1, 256, lds, s>>>(ctx->pn, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
+                                               (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq);
+    {
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) {
+            // nothing ran: whatever the device state holds is no longer described by `fed` -- the next call starts from a reset
+            pr->fed.clear();
+            pr->poly = -1;
+            ctx->err = std::string("probe launch: ") + hipGetErrorString(le);
+            return HB_ERR_HIP;
+        }
+    }
+    pr->seq = seq;
+    pr->poly = poly;
+    for (int i = 0; i < count; i++) pr->fed.push_back(idx[i]);
     *seq_out = seq;
     return HB_OK;
 }

@@ -266,7 +266,9 @@ class _Probe:
         rc = ctx.lib.hb_probe_create(ctx.h, np_ptr(xh_all), n, k, ctypes.byref(self.h), ctx.stream())
         if rc != HB_OK:
             self.h = None
-            raise _Unsupported()
+            if rc == HB_ERR_UNSUPPORTED:
+                raise _Unsupported()
+            ctx.check(rc, "hb_probe_create")        # out of memory, bad arguments: real errors, not a reason to change paths
         self.fed, self.poly = [], -1
         self._ok = ctypes.c_int32(0)
         self._mask = np.zeros(n, dtype=np.uint8)
@@ -284,6 +286,11 @@ class _Probe:
         if not self._ok.value:
             return None
         return np.nonzero(self._mask)[0].tolist()
+
+    def reset(self):
+        """forget everything fed: the next decide() starts a new codeword (a probe changes hands through the pool)"""
+        self.ctx.check(self.ctx.lib.hb_probe_reset(self.h), "hb_probe_reset")
+        self.fed, self.poly = [], -1
 
     def close(self):
         if self.h is not None:
@@ -520,7 +527,13 @@ class DeviceIncrementalDecoder:
         if self._probe_obj is None:
             key = (self.ctx.modulus, self.ctx.device, self.n, self.degree + 1, self.use_omega_powers)
             idle = _probe_pool.idle.setdefault(key, [])
-            self._probe_obj = idle.pop() if idle else _Probe(self.ctx, self._xh_all, self.n, self.degree + 1)
+            if idle:
+                # a pooled probe still holds its last owner's points (host list, C-side list and device state): same polynomial index
+                # and an arrival list that extends the old one would otherwise skip decide()'s reset and judge another open's data
+                self._probe_obj = idle.pop()
+                self._probe_obj.reset()
+            else:
+                self._probe_obj = _Probe(self.ctx, self._xh_all, self.n, self.degree + 1)
             self._probe_key = key
         return self._probe_obj
 
@@ -529,6 +542,7 @@ class DeviceIncrementalDecoder:
         if pr is not None and pr.h is not None:
             idle = _probe_pool.idle.setdefault(self._probe_key, [])
             if len(idle) < 8:
+                pr.reset()
                 idle.append(pr)
             else:
                 pr.close()

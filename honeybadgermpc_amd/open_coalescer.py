@@ -95,6 +95,7 @@ class OpenCoalescer:
         self._tasks = {}            # (degree, batch id) -> task resolving to the list of per-open results (until all are delivered)
         self._undelivered = {}      # (degree, batch id) -> indices not yet delivered
         self._next_id = 0
+        self._orphans = set()       # exchanges nobody waits for (strong references until they finish)
         self.opens, self.batches = 0, 0     # counters (diagnostics)
 
     @staticmethod
@@ -146,11 +147,18 @@ class OpenCoalescer:
         if not parts:
             return
         bid = self._batch_id.pop(degree)
-        self.batches += 1
+        self.batches += 1           # every party counts the same cuts, whoever is still interested in the results
         task = asyncio.ensure_future(self._run(parts, degree, bid))
         # a failed batch nobody awaits must not end as "Task exception was never retrieved"
         task.add_done_callback(lambda tk: tk.cancelled() or tk.exception())
-        self._tasks[(degree, bid)] = task
+        if self._undelivered.get((degree, bid)):
+            self._tasks[(degree, bid)] = task
+        else:
+            # every open of this batch was dropped before the cut (garbage-collected, never awaited): the exchange still runs -- the other
+            # parties count on this party's messages -- but nothing keeps its results
+            self._undelivered.pop((degree, bid), None)
+            self._orphans.add(task)
+            task.add_done_callback(self._orphans.discard)
 
     async def _run(self, parts, degree, bid):
         torch = self.ctx.torch
@@ -178,10 +186,20 @@ class OpenCoalescer:
                     "depend on scheduling and differ between parties.  Cut such batches with flush() or max_pending_shares "
                     "(cut_on_await=False makes this the rule).")
             self._cut(degree)                      # first await on this batch: everything queued so far goes out together
+        task = self._tasks.get(batch)
+        if task is None:
+            raise RuntimeError("OpenCoalescer: this open's batch has been released (every open of it was delivered or abandoned)")
         try:
-            results = await self._tasks[batch]
-        finally:
-            self._delivered(batch, index)          # handed over (or failed for good): this open no longer pins the batch
+            # shield: a caller that gives up (asyncio.wait_for) cancels its own wait, not the exchange the other opens of the batch share
+            results = await asyncio.shield(task)
+        except asyncio.CancelledError:
+            if task.cancelled():
+                self._delivered(batch, index)      # the batch itself is gone for good
+            raise                                  # only this wait was cancelled: the open stays undelivered and can be awaited again
+        except BaseException:
+            self._delivered(batch, index)          # failed for good: this open no longer pins the batch
+            raise
+        self._delivered(batch, index)              # handed over
         return results[index]
 
     def _delivered(self, batch, index):
