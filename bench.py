@@ -855,6 +855,45 @@ def main():
         assert ok3 and all(torch.equal(o[2], secrets) for o in outs)
         del pipe, outs
 
+    # ---- secondary (untimed for `value`): the protocol path at FIRST SIGHT of every arrival pattern ----------------
+    # What batch_reconstruct_device runs (device_reconstruction.py): the R1 encode, then one DeviceIncrementalDecoder per round, fed
+    # column by column in a fresh seeded arrival order every step; nothing is kept per arrival pattern (no open plan: the matrices of
+    # an arrival set are built on the device while the columns come in, as the reference rebuilds V^-1 inside every
+    # vandermonde_batch_interpolate call, hbmpc_ntl_helpers.pyx:139-197).  The columns are received in place (`columns=`): the
+    # decoder is told which row of the party-major buffer has landed.
+    dt_first, first_cols = None, None
+    if world == 1 and not args.no_matrix_cores:
+        from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+
+        r1v, r2v = r1_cols.view(n, C, 4), r2_cols.view(n, C, 4)
+        rng = np.random.Generator(np.random.PCG64(77))
+
+        def first_sight(order1, order2):
+            op.r1_encode(shares0, out=r1_out)
+            used = 0
+            outs_ = []
+            for order_, cols_, want_ in ((order1, r1v, "constant"), (order2, r2v, "all")):
+                dec_ = DeviceIncrementalDecoder(BLS, n, t, batch_size=C, use_omega_powers=use_omega, device=local_rank, columns=cols_, want=want_)
+                for idx_ in order_:
+                    dec_.add(idx_)
+                    used += 1
+                    if dec_.done():
+                        break
+                outs_.append(dec_.get_results()[0])
+            return outs_[0], outs_[1], used
+
+        orders = [(rng.permutation(n).tolist(), rng.permutation(n).tolist()) for _ in range(args.steps + 3)]
+        for o_ in orders[:3]:
+            first_sight(*o_)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for o_ in orders[3:]:
+            msg_, res_, first_cols = first_sight(*o_)
+        torch.cuda.synchronize()
+        dt_first = time.perf_counter() - t3
+        assert msg_ is not None and res_ is not None, "a fault-free open did not finish"
+        assert torch.equal(res_.reshape(-1, 4)[:B], secrets) and torch.equal(msg_[:, 0, :], r2_cols[:C]), "first-sight open differs from the secrets"
+
     # ---- correctness of what was timed (untimed) --------------------------------------
     assert torch.equal(result, secrets), "reconstructed shares differ from the secrets"
     sec_pad = secrets
@@ -951,6 +990,10 @@ def main():
                 "shares_per_s_per_gpu_two_opens_in_flight": (B * args.steps / dt_two) if dt_two else None,
                 "two_opens_in_flight_note": "same opens issued alternately on two streams with two plans (independent batches overlap); "
                                             "`value` is one open at a time on one stream",
+                "shares_per_s_per_gpu_first_sight_protocol_path": (B * args.steps / dt_first) if dt_first else None,
+                "first_sight_note": "R1 encode + one DeviceIncrementalDecoder per round fed column by column in a fresh seeded arrival order every step "
+                                    f"({first_cols} columns announced per open), columns received in place, nothing cached per arrival pattern: what "
+                                    "batch_reconstruct_device runs; `value` is the same open through an open plan whose arrival set is fixed at plan creation",
                 "shares_per_s_per_gpu_integer_valu_path": (B * args.steps / dt_other) if dt_other else None,
                 "integer_valu_path_note": "same open with HB_OPEN_OPT_MATRIX_CORES = 0 (second-generation integer-VALU kernels), same validation; bit-identical results",
             },

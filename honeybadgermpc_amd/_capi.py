@@ -63,6 +63,10 @@ SYMBOLS = {
     "hb_reduce": (_i, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "hb_quick_interp_check": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "hb_quick_interp_check_map": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "hb_quick_dec_create": (_i, [_vp, _vp, _i, _pp, _vp]),
+    "hb_quick_dec_arrivals": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "hb_quick_dec_decide": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "hb_quick_dec_destroy": (None, [_vp]),
     "hb_probe_create": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
     "hb_probe_feed": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _vp, _vp]),
     "hb_probe_reset": (_i, [_vp]),

@@ -271,8 +271,12 @@ struct FsLayout {
 constexpr int FS_BUILD_Z = 1, FS_BUILD_ZC = 2;
 int fs_layout(hb_ctx *ctx, const PointTable *pt, int d, int nc, int n_coef, FsLayout *L);
 int fs_build(hb_ctx *ctx, const PointTable *pt, const int32_t *z, const int32_t *zc, const FsLayout &L, uint8_t *base, int flags, int32_t *status_dev, hipStream_t s);
+// completion signal of a launch whose caller waits for the verdict: a device counter of finished workgroups, the pinned (device-visible)
+// record the last one fills in, the sequence number it writes last
+struct FsVerdict { int32_t flag, first, seq, pad; };
+struct FsDone { int32_t *counter; FsVerdict *host; int32_t seq; };
 int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov, int64_t out_count,
-              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s);
+              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s, const FsDone *done = nullptr);
 // the wide image of a generic matrix, built on first use (nullptr when the path does not apply)
 const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *m, hipStream_t s);
 

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
                                                           int64_t in_count, int d, const int32_t *__restrict__ rowmode,
                                                           uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                           int32_t *__restrict__ mismatch, int32_t *__restrict__ first_bad, uint32_t *__restrict__ bad_map,
-                                                          int n_out, int n_rt, int64_t n_chunks, int64_t n_units, BarrettParams bp) {
+                                                          int n_out, int n_rt, int64_t n_chunks, int64_t n_units, BarrettParams bp, const FsDone done) {
     constexpr int NT = 64 * FS_WAVES, NL = 9, NW = 8;
     extern __shared__ uint4 fs_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -321,6 +321,23 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
             }
         }
     }
+    // a caller that waits for the verdict: the last workgroup to finish hands the status words to pinned host memory (and resets
+    // them for the next launch), the sequence number last -- the host polls that word instead of synchronising the stream
+    if (done.counter) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
+                const int32_t fl = mismatch ? atomicExch(mismatch, 0) : 0;
+                const int32_t fb = first_bad ? atomicExch(first_bad, INT32_MAX) : INT32_MAX;
+                atomicExch(done.counter, 0);
+                done.host->flag = fl;
+                done.host->first = fb;
+                __threadfence_system();
+                *reinterpret_cast<volatile int32_t *>(&done.host->seq) = done.seq;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -567,7 +584,10 @@ int fs_build(hb_ctx *ctx, const PointTable *pt, const int32_t *z, const int32_t 
 // the launch over a built image: rows with a store mode go to `out` (view ov, clipped at out_count), rows with a compare mode are
 // checked against the rows of `cols` they name
 int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov, int64_t out_count,
-              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s) {
+              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s, const FsDone *done_p) {
+    FsDone done;
+    memset(&done, 0, sizeof done);
+    if (done_p) done = *done_p;
     if (C <= 0) return HB_OK;
     const Mm8Shared *sh = nullptr;
     int rc = mm8_shared(ctx, &sh, s); if (rc) return rc;
@@ -581,7 +601,7 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
         if (!attr_done) { HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8f<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
         k_mm8f<NKB><<<dim3((unsigned)blocks), dim3(64 * FS_WAVES), lds, s>>>((const int4 *)(base + L.o_a8), (const uint32_t *)(base + L.o_crow), sh->fold_dev,        \
             (const uint32_t *)(base + L.o_kt), ctx->psc, cols, cv.stride_c, cv.stride_l, (const int32_t *)(base + L.o_z), INT64_MAX, L.d, (const int32_t *)(base + L.o_mode), \
-            out, ov.stride_c, ov.stride_l, out_count, mismatch_dev, first_bad_dev, bad_map_dev, L.n_out, L.n_rt, C, n_units, sh->bp);     \
+            out, ov.stride_c, ov.stride_l, out_count, mismatch_dev, first_bad_dev, bad_map_dev, L.n_out, L.n_rt, C, n_units, sh->bp, done); \
     } while (0)
     switch (L.nkb) {
         case 1: FS_LAUNCH(1); break;

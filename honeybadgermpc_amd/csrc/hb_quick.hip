@@ -826,6 +826,133 @@ int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const 
     return HB_OK;
 }
 
+}  // extern "C"
+
+struct hb_quick_dec {
+    hb_ctx *ctx;
+    int n;
+    PointTable *pt;
+    FsLayout L;
+    uint8_t *buf;
+    size_t cap;
+    int32_t *status;              // device: disagreement flag, first disagreeing chunk, finished workgroups
+    FsVerdict *res_host, *res_dev;
+    int seq;
+    bool prepared;
+    std::vector<int32_t> z;
+};
+
+extern "C" {
+
+int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec **out, void *stream) { HB_API_GUARD(ctx);
+    if (!ctx || !x_host || !out || n < 1) return HB_ERR_BAD_ARG;
+    *out = nullptr;
+    if (ctx->n_limbs != 4 || getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "quick decoder: narrow context or disabled");
+    hipStream_t s = (hipStream_t)stream;
+    cache_trim(ctx);
+    PointTable *pt = nullptr;
+    int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
+    if (!pt->usable || !pt->small) return fail(ctx, HB_ERR_UNSUPPORTED, "quick decoder: the points are not distinct small integers");
+    hb_quick_dec *qd = new hb_quick_dec();
+    qd->ctx = ctx; qd->n = n; qd->pt = pt; qd->buf = nullptr; qd->cap = 0; qd->status = nullptr; qd->res_host = qd->res_dev = nullptr; qd->seq = 0; qd->prepared = false;
+    const int32_t init[4] = {0, INT32_MAX, 0, 0};
+    hipError_t e = hipMalloc(&qd->status, sizeof init);
+    if (e == hipSuccess) e = hipMemcpyAsync(qd->status, init, sizeof init, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);          // (init is on this stack)
+    if (e == hipSuccess) e = hipHostMalloc((void **)&qd->res_host, sizeof(FsVerdict), hipHostMallocMapped);
+    if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&qd->res_dev, qd->res_host, 0);
+    if (e != hipSuccess) {
+        if (qd->status) (void)hipFree(qd->status);
+        if (qd->res_host) (void)hipHostFree(qd->res_host);
+        delete qd;
+        ctx->err = std::string("quick decoder: ") + hipGetErrorString(e);
+        return HB_ERR_HIP;
+    }
+    memset(qd->res_host, 0, sizeof(FsVerdict));
+    pt->refs++;                                // the table outlives its cache entry while this decoder lives
+    *out = qd;
+    return HB_OK;
+}
+
+int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int n_coef, void *stream) { HB_API_GUARD((qd ? qd->ctx : nullptr));
+    if (!qd || !z || d < 1 || d > qd->n || nc < 0 || n_coef < 1 || n_coef > d) return HB_ERR_BAD_ARG;
+    hb_ctx *ctx = qd->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    qd->prepared = false;
+    FsLayout L;
+    int rc = fs_layout(ctx, qd->pt, d, nc, n_coef, &L);
+    if (rc) return fail(ctx, rc, "quick decoder: shape");
+    if (qd->cap < L.need) {
+        // (a launch of this decoder may still read the old buffer: decide() waits for its verdict, so only an abandoned one can)
+        if (qd->buf) { HB_HIP(ctx, hipStreamSynchronize(s)); HB_HIP(ctx, hipFree(qd->buf)); }
+        qd->buf = nullptr; qd->cap = 0;
+        HB_HIP(ctx, hipMalloc(&qd->buf, L.need));
+        qd->cap = L.need;
+    }
+    rc = fs_build(ctx, qd->pt, z, nullptr, L, qd->buf, FS_BUILD_Z, qd->status, s); if (rc) return rc;
+    qd->L = L;
+    qd->z.assign(z, z + d);
+    qd->prepared = true;
+    return HB_OK;
+}
+
+// the enqueue half of decide, under the context's mutex
+static int quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
+                            uint64_t *coeffs_dev, void *stream, int *seq_out) { HB_API_GUARD((qd ? qd->ctx : nullptr));
+    if (!qd || !qd->prepared || nc != qd->L.nc || (nc > 0 && !zc) || !cols_dev || C < 1 || chunk_lo < 0 || chunk_hi > C || chunk_lo >= chunk_hi) return HB_ERR_BAD_ARG;
+    hb_ctx *ctx = qd->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    const FsLayout &L = qd->L;
+    int rc = HB_OK;
+    if (nc > 0) { rc = fs_build(ctx, qd->pt, qd->z.data(), zc, L, qd->buf, FS_BUILD_ZC, qd->status, s); if (rc) return rc; }
+    const int64_t cnt = chunk_hi - chunk_lo;
+    hb_view pm{1, C}, ov = L.n_coef == 1 ? hb_view{1, C} : hb_view{L.d, 1};
+    const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
+    uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * L.n_coef * 8 : nullptr;
+    FsDone done{qd->status + 2, qd->res_dev, qd->seq + 1};
+    rc = fs_launch(ctx, L, qd->buf, in, pm, out, ov, coeffs_dev ? (L.n_coef == 1 ? cnt : cnt * (int64_t)L.d) : 0, qd->status, qd->status + 1, nullptr, cnt, s, &done);
+    if (rc) return rc;
+    qd->seq += 1;
+    qd->prepared = false;                      // one verdict per set of arrivals
+    *seq_out = qd->seq;
+    return HB_OK;
+}
+
+int hb_quick_dec_decide(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
+                        uint64_t *coeffs_dev, int32_t *flag, int32_t *first, void *stream) {
+    if (!flag || !first) return HB_ERR_BAD_ARG;
+    int seq = 0;
+    const int rc = quick_dec_launch(qd, zc, nc, cols_dev, C, chunk_lo, chunk_hi, coeffs_dev, stream, &seq);
+    if (rc) return rc;
+    hb_ctx *ctx = qd->ctx;
+    hipStream_t s = (hipStream_t)stream;
+    // outside the context's mutex: poll the sequence number the last workgroup writes after the verdict; past 2 ms, synchronise
+    volatile int32_t *word = &qd->res_host->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (*word != seq) {
+        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            HB_HIP(ctx, hipStreamSynchronize(s));
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*word != seq) return fail(ctx, HB_ERR_HIP, "quick decoder: the kernel finished without a verdict");
+    *flag = qd->res_host->flag;
+    *first = qd->res_host->first;
+    return HB_OK;
+}
+
+void hb_quick_dec_destroy(hb_quick_dec *qd) { HB_API_GUARD((qd ? qd->ctx : nullptr));
+    if (!qd) return;
+    (void)hipDeviceSynchronize();              // an abandoned launch may still be running
+    if (qd->buf) (void)hipFree(qd->buf);
+    if (qd->status) (void)hipFree(qd->status);
+    if (qd->res_host) (void)hipHostFree(qd->res_host);
+    point_table_unref(qd->pt);
+    delete qd;
+}
+
 int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe **out, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !x_host || !out || n < 1 || k < 1 || k > n) return HB_ERR_BAD_ARG;
     *out = nullptr;

@@ -254,6 +254,7 @@ def cached_batch_open(modulus, n, t, z, zc, use_omega_powers=False, degree=None,
 
 
 INT32_MAX = (1 << 31) - 1
+_points_cache = {}          # (modulus, n, omega powers?) -> (points as ints, packed host array)
 
 
 class _Probe:
@@ -304,6 +305,52 @@ class _Probe:
             pass
 
 
+class _QuickDec:
+    """hb_quick_dec_*: the optimistic step of one decoder in two halves (include/hbmpc_hip.h) -- what depends on the first degree+1
+    arrivals is enqueued when the last of them lands, the verdict comes back through pinned memory"""
+
+    OVERFLOW = 0x40000000
+
+    def __init__(self, ctx, xh_all, n):
+        self.ctx = ctx
+        self.h = ctypes.c_void_p()
+        rc = ctx.lib.hb_quick_dec_create(ctx.h, np_ptr(xh_all), n, ctypes.byref(self.h), ctx.stream())
+        if rc != HB_OK:
+            self.h = None
+            if rc == HB_ERR_UNSUPPORTED:
+                raise _Unsupported()
+            ctx.check(rc, "hb_quick_dec_create")
+        self._flag, self._first = ctypes.c_int32(0), ctypes.c_int32(0)
+
+    def arrivals(self, z, nc, n_coef):
+        za = np.array(z, dtype=np.int32)
+        rc = self.ctx.lib.hb_quick_dec_arrivals(self.h, np_ptr(za), len(z), nc, n_coef, self.ctx.stream())
+        if rc == HB_ERR_UNSUPPORTED:
+            raise _Unsupported()
+        self.ctx.check(rc, "hb_quick_dec_arrivals")
+
+    def decide(self, zc, cols, c, out):
+        """-> (some compared column disagrees?, first disagreeing chunk)"""
+        zca = np.array(zc if zc else [0], dtype=np.int32)
+        rc = self.ctx.lib.hb_quick_dec_decide(self.h, np_ptr(zca), len(zc), self.ctx.ptr(cols), c, 0, c, self.ctx.ptr(out),
+                                              ctypes.byref(self._flag), ctypes.byref(self._first), self.ctx.stream())
+        self.ctx.check(rc, "hb_quick_dec_decide")
+        if self._flag.value & self.OVERFLOW:
+            raise RuntimeError("fused decode: a matrix entry left the range its host-side bound promised")
+        return bool(self._flag.value), self._first.value
+
+    def close(self):
+        if self.h is not None:
+            self.ctx.lib.hb_quick_dec_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
 class _Unsupported(Exception):
     """the plan-free path does not take this context / shape: the caller uses open plans"""
 
@@ -314,6 +361,7 @@ class _ProbePool(threading.local):
 
     def __init__(self):
         self.idle = {}
+        self.quick = {}             # idle _QuickDec objects by (modulus, device, n, point policy); None = this point set does not qualify
 
 
 _probe_pool = _ProbePool()
@@ -352,7 +400,13 @@ class DeviceIncrementalDecoder:
         probe moves on to that chunk.
     """
 
-    def __init__(self, modulus, n, t, degree=None, batch_size=1, use_omega_powers=False, confirmed_errors=None, device=None, robust="gao"):
+    def __init__(self, modulus, n, t, degree=None, batch_size=1, use_omega_powers=False, confirmed_errors=None, device=None, robust="gao",
+                 columns=None, want="all"):
+        """columns: an (n, batch_size, limbs) party-major tensor the transport receives into (row j = what party j sent); a column that
+        has landed there is announced with add(j) -- no copy.  Without it the decoder keeps a buffer of its own, `slot(j)` is row j of it,
+        and add(j, column) copies.
+        want: "all" -- get_results() yields every coefficient, (C, degree+1, limbs); "constant" -- only the constant terms are needed
+        (what R1 forwards, batch_reconstruction.py:194): a decoder that finishes on its optimistic step then yields (C, 1, limbs)."""
         from .field import GF
         from .polynomial import EvalPoint
 
@@ -364,11 +418,24 @@ class DeviceIncrementalDecoder:
         self.batch_size = int(batch_size)
         self.robust = robust
         self.use_omega_powers = use_omega_powers
-        point = EvalPoint(GF(modulus), n, use_omega_powers=use_omega_powers)
-        self.x = [point(i).value for i in range(n)]
-        self._xh_all = ctx.host_elems(self.x)
+        # the party points and their packed form: per (field, n, policy), not per decoder (a decoder is made per open and per round)
+        pk = (int(modulus), n, bool(use_omega_powers))
+        pts = _points_cache.get(pk)
+        if pts is None:
+            point = EvalPoint(GF(modulus), n, use_omega_powers=use_omega_powers)
+            xs = [point(i).value for i in range(n)]
+            pts = _points_cache[pk] = (xs, ctx.host_elems(xs))
+        self.x, self._xh_all = pts
         self.L = ctx.n_limbs
-        self._cols = ctx.empty(n * self.batch_size).view(n, self.batch_size, self.L)
+        if want not in ("all", "constant"):
+            raise ValueError("want must be 'all' or 'constant'")
+        self._want_all = want == "all"
+        if columns is None:
+            self._cols = ctx.empty(n * self.batch_size).view(n, self.batch_size, self.L)
+        else:
+            if tuple(columns.shape) != (n, self.batch_size, self.L):
+                raise ValueError("columns must be an (n, batch_size, limbs) tensor")
+            self._cols = ctx.elems(columns.view(n * self.batch_size, self.L), n * self.batch_size, what="columns").view(n, self.batch_size, self.L)
         self._confirmed_errors = set() if confirmed_errors is None else confirmed_errors
         self._available_points = set()
         self._z = []
@@ -376,13 +443,15 @@ class DeviceIncrementalDecoder:
         self._guess_decoded = None      # (C, d, limbs)
         self._guess_encoded = None      # (n, C, limbs)
         self._num_decoded = 0
-        self._partial = ctx.empty(self.batch_size * (self.degree + 1)).view(self.batch_size, self.degree + 1, self.L)
+        self._partial_buf = None        # (C, degree+1, limbs): allocated by the robust phase, which alone fills it piecewise
         self._result = None
         self._last_status = None
         self._probe_memo = None         # (polynomial index, arrival list, coefficient ints, error set) of the last successful probe
         self._fast = ctx.n_limbs == 4 and (self.degree + 1) >= 4 and not os.environ.get("HB_NO_QUICK")   # cleared at the first UNSUPPORTED
         self._status = None             # (2,) int32 on the device: disagreement flag, first disagreeing chunk
         self._probe_obj = None
+        self._qdec = None               # _QuickDec borrowed for the optimistic step (None: hb_quick_interp_check)
+        self._qdec_ready = False        # its first half has been enqueued for the current first degree+1 arrivals
         self._settled = None            # polynomial whose verdict is in (its errors expelled) but which is not accepted yet
         self._memo = None               # (polynomial, arrival list, candidate, who disagreed) settled inside the radius while short of columns
         self._memo_ev = None            # (candidate, its values at the n points)
@@ -396,6 +465,20 @@ class DeviceIncrementalDecoder:
         self.launches = 0               # batched robust-decode launches so far (diagnostic)
         self.plan_accepts = 0           # batches accepted by one interpolate-and-check launch (diagnostic)
         self.quick_launches = 0         # plan-free interpolate-and-check launches (diagnostic)
+
+    @property
+    def _partial(self):
+        if self._partial_buf is None:
+            self._partial_buf = self.ctx.empty(self.batch_size * (self.degree + 1)).view(self.batch_size, self.degree + 1, self.L)
+        return self._partial_buf
+
+    @_partial.setter
+    def _partial(self, value):
+        self._partial_buf = value
+
+    def slot(self, idx):
+        """row idx of the party-major buffer: where party idx's column is received; add(idx) announces it"""
+        return self._cols[idx]
 
     # -- kernels ---------------------------------------------------------------------------------
     def _plan(self, z, zc):
@@ -550,19 +633,74 @@ class DeviceIncrementalDecoder:
     def __del__(self):
         try:
             self._return_probe()
+            self._return_qdec()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
     def _fast_optimistic(self):
         """enough columns to finish: the guess from the first degree+1 arrivals against every later one.  True = done."""
         d = self.degree + 1
-        dec, agree, first = self._quick(self._z[:d], self._z[d:])
+        if self._qdec is not None and self._qdec_ready:
+            n_coef = d if self._want_all else 1
+            out = self.ctx.empty(self.batch_size * n_coef)
+            disagree, first = self._qdec.decide(self._z[d:], self._cols, self.batch_size, out)
+            self.quick_launches += 1
+            self._qdec_ready = False
+            self._return_qdec()
+            dec, agree = out.view(self.batch_size, n_coef, self.L), not disagree
+            if not self._want_all and not agree:
+                dec = None                                  # one coefficient row is no use to the robust phase
+        else:
+            dec, agree, first = self._quick(self._z[:d], self._z[d:])
         if agree:
             self._result = dec
             return True
         self._optimistic = False
-        self._checked = (list(self._z), 0, dec, first)      # the robust phase starts from this very launch
+        if dec is not None:
+            self._checked = (list(self._z), 0, dec, first)      # the robust phase starts from this very launch
         return False
+
+    def _borrow_qdec(self):
+        """a _QuickDec for this decoder's point set from the thread's pool (None when the point set / context does not qualify)"""
+        key = (self.ctx.modulus, self.ctx.device, self.n, self.use_omega_powers)
+        idle = _probe_pool.quick.get(key)
+        if idle is None:
+            idle = _probe_pool.quick[key] = []
+        if idle == "no":
+            return None
+        if idle:
+            return idle.pop()
+        try:
+            return _QuickDec(self.ctx, self._xh_all, self.n)
+        except _Unsupported:
+            _probe_pool.quick[key] = "no"
+            return None
+
+    def _return_qdec(self):
+        qd, self._qdec = self._qdec, None
+        if qd is not None and qd.h is not None:
+            idle = _probe_pool.quick.get((self.ctx.modulus, self.ctx.device, self.n, self.use_omega_powers))
+            if isinstance(idle, list) and len(idle) < 8:
+                idle.append(qd)
+            else:
+                qd.close()
+
+    def _first_half(self):
+        """the first degree+1 arrivals are in (and more are needed to finish): enqueue what depends on them alone"""
+        need = self._min_points_required()
+        d = self.degree + 1
+        nc = need - d
+        if nc < 0 or self._qdec_ready:
+            return
+        if self._qdec is None:
+            self._qdec = self._borrow_qdec()
+        if self._qdec is None:
+            return
+        try:
+            self._qdec.arrivals(self._z[:d], nc, d if self._want_all else 1)
+            self._qdec_ready = True
+        except _Unsupported:
+            self._return_qdec()
 
     def _disagreeing(self, coeffs):
         """the arrived senders whose symbol of ONE polynomial differs from `coeffs` ((d, limbs)) evaluated at their point"""
@@ -846,22 +984,31 @@ class DeviceIncrementalDecoder:
         if self._num_decoded == self.batch_size:
             self._result = self._partial
 
-    def add(self, idx, column):
-        """column: (C, limbs) limb tensor on the device, or a list of C ints."""
-        if self.done() or idx in self._available_points or idx in self._confirmed_errors:
+    def add(self, idx, column=None):
+        """column: (C, limbs) limb tensor on the device, or a list of C ints; None: the column has been received into slot(idx)
+        (row idx of the `columns` buffer)."""
+        if self._result is not None or idx in self._available_points or idx in self._confirmed_errors:
             return
-        if not hasattr(column, "shape"):
-            if len(column) != self.batch_size:
+        if column is not None:
+            if not hasattr(column, "shape"):
+                if len(column) != self.batch_size:
+                    raise ValueError("Incorrect length of data")
+                column = self.ctx.upload_ints(column)
+            if tuple(column.shape) != (self.batch_size, self.L):
                 raise ValueError("Incorrect length of data")
-            column = self.ctx.upload_ints(column)
-        if tuple(column.shape) != (self.batch_size, self.L):
-            raise ValueError("Incorrect length of data")
-        column = self.ctx.elems(column, self.batch_size, what="column")
+            column = self.ctx.elems(column, self.batch_size, what="column")
+            self._cols[idx] = column
         self._available_points.add(idx)
         self._z.append(idx)
-        self._cols[idx] = column
-        if len(self._available_points) <= self.degree:
+        k = len(self._z)
+        if k <= self.degree:
             return
+        if self._fast and self._optimistic:
+            # nothing is computed before enough columns are in to finish; the arrivals the guess is made from are known earlier
+            if k < self.degree + 1 + self.max_errors - len(self._confirmed_errors):
+                if k == self.degree + 1:
+                    self._first_half()
+                return
         if self._fast:
             try:
                 return self._fast_add()

@@ -137,6 +137,21 @@ int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const 
                               const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev,
                               uint32_t *bad_map_dev, void *stream);
 
+/* The optimistic step of ONE IncrementalDecoder (reed_solomon.py:305-330) in two halves, for points that are small integers (the
+ * production points 1 .. n) on wide contexts: what depends on the first d arrivals alone is built when the d-th column lands
+ * (hb_quick_dec_arrivals: enqueued, nothing waited for), and when the last column lands hb_quick_dec_decide builds the rows of the
+ * compared senders, launches decode + validate (hb_mfma_fused.hip) over chunks [chunk_lo, chunk_hi) of the party-major buffer and
+ * WAITS for the verdict, which the kernel hands over in pinned memory: *flag != 0 -- some compared column disagrees, *first = the
+ * first disagreeing chunk - chunk_lo (INT32_MAX when none).  n_coef = d: all coefficients go chunk-major to coeffs_dev ((C, d)
+ * elements); n_coef = 1: only the constant terms, to coeffs_dev[0 .. C) (what R1 forwards, batch_reconstruction.py:194).
+ * HB_ERR_UNSUPPORTED from _create / _arrivals: the shape is not this kernel's; use hb_quick_interp_check. */
+typedef struct hb_quick_dec hb_quick_dec;
+int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec **out, void *stream);
+int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int n_coef, void *stream);
+int hb_quick_dec_decide(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
+                        uint64_t *coeffs_dev, int32_t *flag, int32_t *first, void *stream);
+void hb_quick_dec_destroy(hb_quick_dec *qd);
+
 /* gao_interpolate for ONE codeword, incremental in its points (rsdecode_impl.h:325-363 as GaoRobustDecoder.robust_decode
  * runs it per polynomial, reed_solomon.py:151-186, 334-365): the probe keeps a reduced basis of the interpolation module of
  * the points fed so far (Koetter / Welch-Berlekamp; one workgroup, O(n') multiplications per new point) and decides exactly
