@@ -102,9 +102,17 @@ class BatchOpen:
     FUSED_VALIDATE = 3
 
     def set_fused_validate(self, on):
-        """Allow (default) or forbid the one-launch decode + validate of plans with full-size matrix entries
-        (include/hbmpc_hip.h, HB_OPEN_OPT_FUSED_VALIDATE); off = decode, re-encode all n points, compare."""
-        self.ctx.check(self.ctx.lib.hb_open_plan_set_option(self.h, self.FUSED_VALIDATE, 1 if on else 0), "set_option")
+        """Allow (default) or forbid the one-launch decode + validate (include/hbmpc_hip.h, HB_OPEN_OPT_FUSED_VALIDATE); off = decode,
+        re-encode all n points, compare.  on = "wide": the full-size kernel (hb_mfma_wide.hip) even where the small-entry kernel
+        with the division inside (hb_mfma_fused.hip: points that are small integers) would be the default."""
+        v = 2 if on == "wide" else (1 if on else 0)
+        self.ctx.check(self.ctx.lib.hb_open_plan_set_option(self.h, self.FUSED_VALIDATE, v), "set_option")
+
+    def fused_validate_kernel(self):
+        """which kernel decodes + validates in one launch for this plan: "small", "wide" or None"""
+        v = ctypes.c_int(0)
+        self.ctx.check(self.ctx.lib.hb_open_plan_get_option(self.h, self.FUSED_VALIDATE, ctypes.byref(v)), "get_option")
+        return {0: None, 3: "small"}.get(v.value, "wide")
 
     def uses_fused_validate(self):
         v = ctypes.c_int(0)
