@@ -337,7 +337,8 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
 #pragma unroll
                         for (int k = 0; k < 8; k++) diff |= ew[k] ^ ow[k];
                         asm volatile("" : "+v"(diff));
-                        if (cmp && diff) atomicOr(mismatch, 1);
+                        // once per wave, and only while the flag is still clear: a sender that corrupts everything must not queue a million atomics
+                        if (__builtin_amdgcn_ballot_w64(cmp && diff) != 0 && lane == 0 && *reinterpret_cast<volatile int32_t *>(mismatch) == 0) atomicOr(mismatch, 1);
                     } else {
                         // keep the reduction outside the store's exec mask: hipcc otherwise wraps the whole output in a
                         // divergent branch, and the register copies at its join spill

@@ -267,7 +267,8 @@ _points_cache = {}          # (modulus, n, omega powers?) -> (points as ints, pa
 
 class _Probe:
     """hb_probe_*: the reference's per-polynomial Gao decode (reed_solomon.py:151-186) for ONE codeword of the party-major
-    buffer, incremental in the arrivals (include/hbmpc_hip.h)."""
+    buffer, incremental in the arrivals (include/hbmpc_hip.h).  A probe works on a stream of its own: its kernels (one workgroup)
+    only read the columns, so feeding it can start -- `feed_ahead` -- while the decoder's own launches and bookkeeping go on."""
 
     def __init__(self, ctx, xh_all, n, k):
         self.ctx, self.n, self.k = ctx, n, k
@@ -281,17 +282,31 @@ class _Probe:
         self.fed, self.poly = [], -1
         self._ok = ctypes.c_int32(0)
         self._mask = np.zeros(n, dtype=np.uint8)
+        with ctx.torch.cuda.device(ctx.tdev):
+            self.side = ctx.torch.cuda.Stream()
 
-    def decide(self, z, cols, c, poly):
-        """the verdict over the arrival list z for polynomial `poly`: None, or the sorted list of senders in error"""
+    def _feed(self, z, cols, c, poly, decide, after_current):
         if poly != self.poly or z[: len(self.fed)] != self.fed:
             self.ctx.check(self.ctx.lib.hb_probe_reset(self.h), "hb_probe_reset")
             self.fed, self.poly = [], poly
         new = z[len(self.fed):]
+        if not new and not decide:
+            return
+        if after_current:
+            self.side.wait_stream(self.ctx.torch.cuda.current_stream())      # the columns were copied in on the caller's stream
         ia = np.array(new if new else [0], dtype=np.int32)
-        rc = self.ctx.lib.hb_probe_feed(self.h, np_ptr(ia), len(new), self.ctx.ptr(cols), c, poly, 1, ctypes.byref(self._ok), np_ptr(self._mask), self.ctx.stream())
+        rc = self.ctx.lib.hb_probe_feed(self.h, np_ptr(ia), len(new), self.ctx.ptr(cols), c, poly, 1 if decide else 0, ctypes.byref(self._ok), np_ptr(self._mask),
+                                        ctypes.c_void_p(self.side.cuda_stream))
         self.ctx.check(rc, "hb_probe_feed")
         self.fed = list(z)
+
+    def feed_ahead(self, z, cols, c, poly, after_current=True):
+        """enqueue the points of the arrival list z that have not been fed, without asking for a verdict"""
+        self._feed(z, cols, c, poly, False, after_current)
+
+    def decide(self, z, cols, c, poly, after_current=True):
+        """the verdict over the arrival list z for polynomial `poly`: None, or the sorted list of senders in error"""
+        self._feed(z, cols, c, poly, True, after_current)
         if not self._ok.value:
             return None
         return np.nonzero(self._mask)[0].tolist()
@@ -438,6 +453,7 @@ class DeviceIncrementalDecoder:
         if want not in ("all", "constant"):
             raise ValueError("want must be 'all' or 'constant'")
         self._want_all = want == "all"
+        self._in_place = columns is not None
         if columns is None:
             self._cols = ctx.empty(n * self.batch_size).view(n, self.batch_size, self.L)
         else:
@@ -668,6 +684,16 @@ class DeviceIncrementalDecoder:
             self._checked = (list(self._z), 0, dec, first)      # the robust phase starts from this very launch
         return False
 
+    def _probe_ahead(self, poly):
+        """polynomial `poly` disagrees: its Gao verdict may be needed in a moment (when no candidate of the batched launch lies within the
+        radius).  The probe catches up with the arrival list on its own stream meanwhile -- one workgroup, it only reads the columns."""
+        if self.robust != "gao" or not self._fast or poly >= self.batch_size:
+            return
+        try:
+            self._borrow_probe().feed_ahead(self._z, self._cols, self.batch_size, poly, after_current=not self._in_place)
+        except _Unsupported:
+            pass
+
     def _borrow_qdec(self):
         """a _QuickDec for this decoder's point set from the thread's pool (None when the point set / context does not qualify)"""
         key = (self.ctx.modulus, self.ctx.device, self.n, self.use_omega_powers)
@@ -817,7 +843,7 @@ class DeviceIncrementalDecoder:
                 if self.robust == "gao":
                     pr = self._borrow_probe()
                     self.probes += 1
-                    errors = pr.decide(self._z, self._cols, self.batch_size, lo)
+                    errors = pr.decide(self._z, self._cols, self.batch_size, lo, after_current=not self._in_place)
                     if errors is None:
                         return                               # (None, None): more columns needed
                 else:
@@ -871,6 +897,7 @@ class DeviceIncrementalDecoder:
             first_split, dec2 = tail_split, None
             errors = self._scan_errors(dec, first)
             if len(errors) > radius and len(self._z) > d:
+                self._probe_ahead(first)                 # (a second candidate is tried first; the probe catches up meanwhile)
                 tail_split = not tail_split
                 dec2, _, _ = self._quick(*self._split(tail_split), lo=first, hi=first + 1)      # this one polynomial only
                 errors = self._candidate_errors(dec2[first], first)

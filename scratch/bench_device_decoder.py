@@ -7,6 +7,7 @@ from honeybadgermpc_amd._capi import Context, HbView, np_ptr
 from honeybadgermpc_amd import device
 from honeybadgermpc_amd.device import DeviceIncrementalDecoder
 import ctypes
+INPLACE = '--copy' not in sys.argv       # columns received in place (the decoder is told which row has landed) or copied in by add()
 P = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 n, t = 64, 21
 d = t + 1
@@ -35,13 +36,13 @@ for robust in ("gao", "wb"):
         for rep in range(3):              # warm-up (one-time initialisation: point table, kernels), first sight of the pattern (plan cache cleared), once more
             if rep == 1:
                 device._plan_cache.plans.clear()
-            dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, robust=robust)
+            dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, robust=robust, columns=data if INPLACE else None)
             torch.cuda.synchronize(); t0 = time.perf_counter()
             used = 0
             failed = None
             try:
                 for idx in order:
-                    dec.add(idx, data[idx]); used += 1
+                    dec.add(idx) if INPLACE else dec.add(idx, data[idx]); used += 1
                     if dec.done(): break
             except Exception as e:      # the reference's Welch-Berlekamp robust decoder re-raises "No solution" (reed_solomon.py:205-212)
                 failed = repr(e)
@@ -49,7 +50,7 @@ for robust in ("gao", "wb"):
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             times.append(dt)
         if failed:
-            print(f"{robust}: {liars} liars{' (late chunks only)' if late else ''}: raised {failed} after {used} columns, as the reference's decoder does beyond the radius", flush=True)
+            print(f"{'in place' if INPLACE else 'copied'} {robust}: {liars} liars{' (late chunks only)' if late else ''}: raised {failed} after {used} columns, as the reference's decoder does beyond the radius", flush=True)
             continue
         ok = torch.equal(res.reshape(-1, 4), coef)
-        print(f"{robust}: {liars} liars{' (late chunks only)' if late else ''}: {dt*1e3:.1f} ms for 2^20 shares = {B/dt/1e6:.1f} M shares/s (third run of the pattern; FIRST sight of it, plan cache cleared: {times[1]*1e3:.1f} ms = {B/times[1]/1e6:.1f} M shares/s -- the plan-free path keeps nothing per pattern, the wb rows' robust phase does), {used} columns used, errors {sorted(errs)}, launches {dec.launches}, plan accepts {dec.plan_accepts}, probes {dec.probes}, quick launches {dec.quick_launches}, settled inside the radius {dec.radius_verdicts}, exact {ok}", flush=True)
+        print(f"{'in place' if INPLACE else 'copied'} {robust}: {liars} liars{' (late chunks only)' if late else ''}: {dt*1e3:.1f} ms for 2^20 shares = {B/dt/1e6:.1f} M shares/s (third run of the pattern; FIRST sight of it, plan cache cleared: {times[1]*1e3:.1f} ms = {B/times[1]/1e6:.1f} M shares/s -- the plan-free path keeps nothing per pattern, the wb rows' robust phase does), {used} columns used, errors {sorted(errs)}, launches {dec.launches}, plan accepts {dec.plan_accepts}, probes {dec.probes}, quick launches {dec.quick_launches}, settled inside the radius {dec.radius_verdicts}, exact {ok}", flush=True)

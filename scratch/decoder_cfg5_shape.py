@@ -21,11 +21,11 @@ for liars in (0, 10, 85):
         data[i] = rand(C)
     order = list(range(n))
     for rep in range(3):
-        dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, use_omega_powers=True)
+        dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, use_omega_powers=True, columns=data)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         used = 0
         for idx in order:
-            dec.add(idx, data[idx]); used += 1
+            dec.add(idx); used += 1
             if dec.done(): break
         res, errs = dec.get_results()
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
