@@ -14,14 +14,14 @@ from conftest import REPO
 pytestmark = pytest.mark.gpu
 
 
-def _run(extra, timeout=900):
+def _run(extra, timeout=900, nproc=2):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HB_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-sample", "0"] + extra
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", str(nproc), "--steps", "3", "--warmup", "1", "--cpu-sample", "0"] + extra
     res = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=timeout)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -88,3 +88,21 @@ def test_two_ranks_sharded_open_with_gather(mode):
     assert out["detail"]["gather_mode"] == mode and out["detail"]["allgather_ms_per_step_max_over_ranks"] >= 0
     assert out["distributed"]["backend"] == "gloo" and out["distributed"]["world_size"] == 2
     assert out["detail"]["bit_exact_vs_secrets"] and out["detail"]["matrix_core_path"]
+
+
+# ---- eight ranks (sharing the one GPU of the test box): the driver's N = 8 run must not be the first time rank 7 exists ----------
+@pytest.mark.parametrize("mode", ["direct", "collective"])
+def test_eight_ranks_sharded_open_with_gather(mode):
+    """cfg5-mini split over EIGHT ranks (762 chunks -> 96, 96, 95, ...: uneven like config 5's 48 771), both gathers; bench.py
+    asserts every rank's slice and the gathered vector bit for bit before it prints"""
+    out = _run(["--workload", "cfg5-mini", "--gather", mode], nproc=8, timeout=1500)
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["shares_total"] == 1 << 16 and out["config"]["shares_this_rank"] <= (1 << 13) + 86
+    assert out["detail"]["gather_mode"] == mode and out["distributed"]["world_size"] == 8
+    assert out["detail"]["bit_exact_vs_secrets"]
+
+
+def test_eight_ranks_weak_scaling_path():
+    out = _run(["--workload", "tiny", "--no-two-streams-extra"], nproc=8, timeout=1500)
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["detail"]["bit_exact_vs_secrets"]
+    assert out["distributed"]["world_size"] == 8

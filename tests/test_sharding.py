@@ -242,3 +242,86 @@ def test_gather_inside_a_subgroup(mode):
         p.join(180)
         assert p.exitcode == 0
     assert all(ret[r] for r in range(3))
+
+
+# ---- world 8: the first hardware scaling run must not be the first time rank 7 exists -------------------
+def test_config5_split_over_eight_ranks():
+    """BASELINE config 5: 2^22 shares, d = 86 -> 48 771 chunks; over 8 ranks that is uneven (48 771 = 8 * 6096 + 3)"""
+    b, d, w = 1 << 22, 86, 8
+    bounds = [shard_bounds(b, d, w, r) for r in range(w)]
+    chunks = [(hi - lo + d - 1) // d for lo, hi in bounds]
+    assert chunks == [6097, 6097, 6097, 6096, 6096, 6096, 6096, 6096] and sum(chunks) == 48771
+    assert bounds[0] == (0, 6097 * 86) and bounds[-1][1] == b
+    assert bounds[-1][1] - bounds[-1][0] == b - (3 * 6097 + 4 * 6096) * 86          # the last rank's slice ends inside its last chunk
+    for (lo, hi), (lo2, _) in zip(bounds, bounds[1:]):
+        assert hi == lo2 and lo % d == 0
+
+
+def _worker_gather_real_split(rank, world, port, b, d, mode, ret):
+    """all_gather_opened with config 5's real slice lengths; element (i, j) = 4 i + j so every position is checkable"""
+    from honeybadgermpc_amd.sharding import all_gather_opened
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_bounds(b, d, world, rank)
+    local = (torch.arange(lo, hi, dtype=torch.int64).unsqueeze(1) * 4 + torch.arange(4, dtype=torch.int64).unsqueeze(0)).contiguous()
+    full = all_gather_opened(local, b, d, mode=mode)
+    # spot checks instead of a second 134 MB tensor: the ends of every rank's slice and a stride through the middle
+    idx = torch.tensor(sorted({0, b - 1} | {p for r in range(world) for p in shard_bounds(b, d, world, r) if 0 <= p < b}
+                              | {p - 1 for r in range(world) for p in shard_bounds(b, d, world, r) if p > 0} | set(range(0, b, 100003))))
+    good = bool(torch.equal(full[idx], idx.unsqueeze(1) * 4 + torch.arange(4).unsqueeze(0))) and tuple(full.shape) == (b, 4)
+    ret[rank] = good
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,b", [("direct", 1 << 22), ("collective", 1 << 22)])
+def test_gather_with_config5_real_split_world_8(mode, b):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_gather_real_split, args=(r, 8, port, b, 86, mode, ret)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert all(ret[r] for r in range(8))
+
+
+@pytest.mark.parametrize("mode", ["direct", "collective"])
+def test_sharded_open_class_world_8_uneven(mode):
+    """sharding.ShardedOpen on eight ranks with a chunk count that splits as config 5's does (8 k + 3 chunks), stand-in opener"""
+    import oracle
+
+    b = 56                                         # d = 3 -> 19 chunks = 8 * 2 + 3, the last one short
+    rnd = random.Random(8)
+    n, t = 7, 2
+    d = t + 1
+    c = (b + d - 1) // d
+    x = list(range(1, n + 1))
+    polys1 = [[rnd.randrange(BLS) for _ in range(d)] for _ in range(c)]
+    polys2 = [[rnd.randrange(BLS) for _ in range(d)] for _ in range(c)]
+    e1 = oracle.vandermonde_batch_evaluate(x, polys1, BLS)
+    e2 = oracle.vandermonde_batch_evaluate(x, polys2, BLS)
+    r1_cols = [[e1[k][j] for k in range(c)] for j in range(n)]
+    r2_cols = [[e2[k][j] for k in range(c)] for j in range(n)]
+    shares = [rnd.randrange(BLS) for _ in range(b)]
+    expect = [v for row in polys2 for v in row][:b]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    procs = [ctx.Process(target=_worker_sharded_open, args=(r, 8, port, b, n, t, shares, r1_cols, r2_cols, expect, mode, ret)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert all(ret[r] for r in range(8))
