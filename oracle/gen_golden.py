@@ -407,6 +407,85 @@ def gen_batch_reconstruct():
     dump("batch_reconstruct.json", S({"runs": runs}))
 
 
+# --------------------------------------------------------------------------- H
+def gen_gao_cofactor():
+    """Gao's outputs pinned WITHOUT the oracle: the recurrence of partial_gcd and the acceptance
+    test of gao_interpolate (rsdecode_impl.h:281-363) executed with the REFERENCE's own Polynomial class -- its interpolate, __mul__,
+    __sub__ and __divmod__ (polynomial.py:85-108, 202-234).  What is written: for each word (points, values with None = erasure, k)
+    the coefficient list and the un-normalised cofactor v = t_i exactly as the recurrence leaves it, or null / null where the
+    reference returns (None, None).  Words inside, at and beyond the unique-decoding radius, with and without erasures."""
+    fp = GF(BLS)
+    poly = polynomials_over(fp)
+    rnd = random.Random(20240928)
+    one, zero = poly([fp(1)]), poly([])
+
+    def deg(p_):
+        return -1 if p_.is_zero() else p_.degree()          # NTL's deg(0) = -1; the reference's Python class keeps [0] for zero (degree 0)
+
+    def divrem(a, b):
+        """NTL's DivRem with the reference's Polynomial arithmetic; a constant divisor is handled here (the class's own __divmod__
+        does not terminate on it: its zero remainder has degree 0 >= 0)"""
+        if deg(b) == 0:
+            return a * poly([fp(1) / b.coeffs[0]]), zero
+        if deg(a) < deg(b):
+            return zero, a
+        return divmod(a, b)
+
+    def gao(xs, ys, k):
+        pts = [(fp(x), fp(y)) for x, y in zip(xs, ys) if y is not None]          # hbmpc_ntl_helpers.pyx:399-403 drops erasures
+        n = len(pts)
+        g0 = one
+        for x, _ in pts:
+            g0 = g0 * poly([fp(0) - x, fp(1)])
+        g1 = poly.interpolate(pts)
+        thr = (n + k) // 2
+        r0, r1, t0, t1 = g0, g1, zero, one
+        if deg(r0) < thr:
+            r, v = r0, t0
+        elif deg(r1) < thr:
+            r, v = r1, t1
+        else:
+            while True:
+                q, r2 = divrem(r0, r1)
+                t2 = t0 - q * t1
+                if deg(r2) < thr:
+                    r, v = r2, t2
+                    break
+                r0, r1, t0, t1 = r1, r2, t1, t2
+        f1, rem = divrem(r, v)
+        if not rem.is_zero() or deg(f1) >= k:
+            return None, None
+        fc = [] if f1.is_zero() else [c.value for c in f1.coeffs]
+        coeffs = fc + [0] * (k - len(fc))                                         # exactly k, zero padded (rsdecode_impl.h:351-354)
+        return coeffs, [c.value for c in v.coeffs]
+
+    cases = []
+    shapes = [(7, 3), (10, 4), (16, 6), (16, 6), (22, 8), (31, 11)]
+    for n, k in shapes:
+        xs = list(range(1, n + 1)) if rnd.random() < 0.6 else rnd.sample(range(1, 200), n)
+        for kind in ("none", "one", "half", "radius", "radius", "beyond", "beyond2", "erasures", "erasures+errors"):
+            msg = [rnd.randrange(BLS) for _ in range(k)]
+            if kind == "none" and rnd.random() < 0.3:
+                msg[-1] = 0                                                       # a message of lower degree
+            ys = [int(poly([fp(c) for c in msg])(fp(x)).value) for x in xs]
+            n_er = 0
+            if kind.startswith("erasures"):
+                n_er = rnd.randrange(1, max(2, (n - k) // 2))
+                for pos in rnd.sample(range(n), n_er):
+                    ys[pos] = None
+            radius = (n - n_er - k) // 2
+            n_err = {"none": 0, "one": min(1, radius), "half": radius // 2, "radius": radius, "beyond": radius + 1, "beyond2": radius + 2,
+                     "erasures": 0, "erasures+errors": radius}[kind]
+            live = [i for i in range(n) if ys[i] is not None]
+            for pos in rnd.sample(live, min(n_err, len(live))):
+                ys[pos] = (ys[pos] + 1 + rnd.randrange(BLS - 1)) % BLS
+            coeffs, v = gao(xs, ys, k)
+            cases.append({"x": xs, "y": ys, "k": k, "kind": kind, "errors": n_err, "erasures": n_er, "coeffs": coeffs, "v": v})
+    ok = sum(1 for c in cases if c["coeffs"] is not None)
+    print(f"gao cofactor: {len(cases)} words, {ok} decode, {len(cases) - ok} do not")
+    dump("gao_cofactor.json", S({"cases": cases}))
+
+
 if __name__ == "__main__":
     gen_constants()
     gen_vandermonde()
@@ -417,3 +496,4 @@ if __name__ == "__main__":
     gen_misc()
     gen_incremental()
     gen_batch_reconstruct()
+    gen_gao_cofactor()

@@ -830,3 +830,23 @@ def test_interpolation_points_including_zero(hip):
         assert hip.vandermonde_batch_interpolate(x, rows, P) == want
         more = list(range(d + 1, 2 * d + 1))
         assert hip.vandermonde_batch_evaluate(more, want, P) == oracle.vandermonde_batch_evaluate(more, want, P)
+
+
+def test_gao_cofactor_pinned_by_the_references_polynomial_class(hip, golden):
+    """tests/golden/gao_cofactor.json: coefficients, the un-normalised EEA cofactor and the (None, None) decisions from the reference's
+    own Polynomial class running partial_gcd's recurrence (oracle/gen_golden.py section H) -- the HIP decoder (fraction-free Euclid
+    + one inversion, hb_gao.hip) reproduces them coefficient for coefficient, one word at a time and as batches"""
+    cases = golden("gao_cofactor.json")["cases"]
+    for c in cases:
+        got = hip.gao_interpolate(c["x"], c["y"], c["k"], P)
+        assert got == ((c["coeffs"], c["v"]) if c["coeffs"] is not None else (None, None)), (c["kind"], c["k"], len(c["x"]))
+    # words over the same points and without erasures, as one launch
+    groups = {}
+    for c in cases:
+        if None not in c["y"]:
+            groups.setdefault((tuple(c["x"]), c["k"]), []).append(c)
+    assert groups
+    for (x, k), cs in groups.items():
+        got = hip.gao_interpolate_batch(list(x), [c["y"] for c in cs], k, P)
+        for g, c in zip(got, cs):
+            assert tuple(g) == ((c["coeffs"], c["v"]) if c["coeffs"] is not None else (None, None)), (c["kind"], k)

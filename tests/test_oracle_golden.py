@@ -229,3 +229,15 @@ def test_golden_wb_vs_gao(golden):
         assert co == want
         roots = [i for i in range(len(x)) if case["word"][i] is not None and peval(err, x[i], p) == 0] if len(err) > 1 else []
         assert roots == case["errpos"]
+
+
+def test_golden_gao_cofactor_from_the_references_polynomial_class(golden):
+    """the coefficients AND the un-normalised cofactor of Gao's decoder, and its (None, None) decisions, as the
+    reference's own Polynomial class produces them when it runs partial_gcd's recurrence (oracle/gen_golden.py section H;
+    rsdecode_impl.h:281-363 over polynomial.py:85-108, 202-234) -- nothing of this repo took part in the expected values."""
+    cases = golden("gao_cofactor.json")["cases"]
+    assert len(cases) >= 50 and sum(c["coeffs"] is None for c in cases) >= 8
+    for c in cases:
+        co, v = oracle.gao_interpolate(c["x"], c["y"], c["k"], P)
+        assert co == c["coeffs"], (c["kind"], c["k"], len(c["x"]))
+        assert v == c["v"], (c["kind"], c["k"], len(c["x"]))
