@@ -282,8 +282,7 @@ def host_cpu_facts():
         facts = json.loads(res.stdout.strip().splitlines()[-1])
     except Exception as e:  # noqa: BLE001 - informational
         facts = {"error": f"{type(e).__name__}: {e}"}
-    facts["affinity_cpus_after_openmp_pinning"] = facts.get("affinity_cpus")     # what a child of the pinned thread inherits
-    facts["affinity_cpus"] = len(_START_AFFINITY)
+    facts["affinity_cpus"] = len(_START_AFFINITY)      # the mask this process started with (a child of the OpenMP-pinned thread would report one place)
     facts["affinity_first_last"] = [_START_AFFINITY[0], _START_AFFINITY[-1]] if _START_AFFINITY else None
     return facts
 
@@ -373,6 +372,55 @@ def cpu_baseline(n, t, use_omega, sample_b, seed=7):
         "affinity_cpus": facts.get("affinity_cpus"), "host": facts, "table_monotone": bool(mono),
         "one_thread_shares_per_s": rates.get(1),
     }
+    # ---- the same open through the reference's OWN boundary: lists of Python ints in, lists of lists out (SURVEY 8d's second variant) ---
+    # vandermonde_batch_evaluate x3 / vandermonde_batch_interpolate x2 as batch_reconstruct calls them (batch_reconstruction.py:158-227,
+    # reed_solomon.py:305-326), marshalling included -- what a user of honeybadgermpc.ntl experiences.  Vandermonde points only.
+    if not use_omega:
+        try:
+            oracle.SetNumThreads(cores)
+            sample_py = int(min(sample_b, 1 << 16))
+            c_py = (sample_py + d - 1) // d
+            rng = np.random.Generator(np.random.PCG64(seed + 1))
+            as_int = lambda row: int.from_bytes(row.tobytes(), "little") % BLS  # noqa: E731
+            raw = rng.integers(0, 1 << 63, size=(c_py * d, 4), dtype=np.uint64)
+            chunks = [[as_int(raw[k * d + m]) for m in range(d)] for k in range(c_py)]
+            xz = [x[i] for i in z]
+            t0 = time.perf_counter()
+            enc = oracle.vandermonde_batch_evaluate(x, chunks, BLS)                       # R1 encode: [C][n]
+            for _ in range(2):                                                            # R1 and R2: decode, re-encode, compare
+                cols_z = [[row[i] for i in z] for row in enc]
+                dec = oracle.vandermonde_batch_interpolate(xz, cols_z, BLS)
+                re = oracle.vandermonde_batch_evaluate(x, dec, BLS)
+                assert all(re[k][j] == enc[k][j] for k in (0, c_py - 1) for j in zc)
+            el = time.perf_counter() - t0
+            assert dec[0] == chunks[0] and dec[-1] == chunks[-1]
+            out["python_boundary_shares_per_s"] = sample_py / el
+            out["python_boundary_note"] = (f"{sample_py} shares through oracle.vandermonde_batch_evaluate / _interpolate with list-of-int arguments and results "
+                                           f"(3 encodes + 2 decodes, {cores} threads): the kernel-only figure above keeps the operands packed")
+        except Exception as e:  # noqa: BLE001 - informational
+            out["python_boundary_shares_per_s"] = None
+            out["python_boundary_note"] = f"failed: {e}"
+    # ---- BASELINE config 1 (the reference's own CPU-runnable case, benchmark/test_benchmark_reed_solomon.py): n = 4, t = 1, 256 polynomials ----
+    try:
+        rng = np.random.Generator(np.random.PCG64(1))
+        polys1 = [[int.from_bytes(rng.bytes(32), "little") % BLS for _ in range(2)] for _ in range(256)]
+        x4 = [1, 2, 3, 4]
+        oracle.SetNumThreads(1)
+        best_e = best_d = None
+        for _ in range(5):
+            t0 = time.perf_counter()
+            e4 = oracle.vandermonde_batch_evaluate(x4, polys1, BLS)
+            t1 = time.perf_counter()
+            d4 = oracle.vandermonde_batch_interpolate(x4[:2], [row[:2] for row in e4], BLS)
+            t2 = time.perf_counter()
+            best_e = t1 - t0 if best_e is None else min(best_e, t1 - t0)
+            best_d = t2 - t1 if best_d is None else min(best_d, t2 - t1)
+        assert d4 == polys1
+        out["cfg1"] = {"workload": "Vandermonde encode_batch / decode_batch, n=4, t=1, 256 polynomials, list-of-int boundary, one thread",
+                       "encode_us": best_e * 1e6, "decode_us": best_d * 1e6, "polys_per_s_encode": 256 / best_e, "polys_per_s_decode": 256 / best_d}
+    except Exception as e:  # noqa: BLE001 - informational
+        out["cfg1"] = {"error": str(e)}
+    oracle.SetNumThreads(cores)
     if isinstance(ntl, float) and ntl > 0:
         out["ntl_open_shares_per_s"] = table[cores]["sample_shares"] / ntl
         out["sample"] += f"; the reference's NTL call sequence through oracle/ntl_open_baseline.cpp: {ntl:.2f} s"
