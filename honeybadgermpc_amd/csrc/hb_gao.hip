@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
         }
         if (idx < npts) {
             uint32_t yd[NL];
-            load_digits<NL, NW>(yd, g1buf + ((size_t)idx * C + c) * NW);
+            load_digits<NL, NW>(yd, g1buf + ((size_t)c * npts + idx) * NW);      // chunk-major: a wave reads its codeword's 32 npts bytes in one piece
             to_mont(m, yd, P);
             lds_put<NL>(R1 + (size_t)idx * NL, m);
         } else lds_put<NL>(R1 + (size_t)idx * NL, z);
@@ -402,10 +402,10 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
         ctx->dcache[key] = g0;
         cache_note(ctx, "d|" + key, [ctx, key]() { auto f = ctx->dcache.find(key); if (f != ctx->dcache.end()) { (void)hipFree(f->second); ctx->dcache.erase(f); } });
     }
-    // g1 for every codeword: coefficient-major [npts][C]
+    // g1 for every codeword: chunk-major [C][npts] (coefficient-major made every 32-byte read of k_gao fetch a whole 128-byte line: 12.5 KB per codeword for 3.2)
     uint32_t *g1 = nullptr;
     HB_HIP(ctx, hipMalloc(&g1, (size_t)npts * C * ctx->elem_words() * 4));
-    hb_view iv{npts, 1}, ov{1, C};
+    hb_view iv{npts, 1}, ov{npts, 1};
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (rc) { (void)hipFree(g1); return rc; }
     size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3)) * NLr * 4;

@@ -11,23 +11,42 @@ def main(path, workload, source):
     lines = open(path).read().splitlines()
     hdr = lines[0].split()
     cols = hdr[3:-2]                       # counters between 'launches' and 'HBM bytes/launch'
-    rows = []
-    for ln in lines[1:]:
-        if not ln.startswith("hb::k_mm8w<true"):
-            continue
-        name = ln[:44].strip()
-        f = ln[44:].split()
-        vals = dict(zip(cols, map(float, f[2:2 + len(cols)])))
-        vals["hbm_mb"] = float(f[2 + len(cols)]) if len(f) > 2 + len(cols) else None
-        rows.append((name, vals))
+    def parse(prefixes):
+        rows = []
+        for ln in lines[1:]:
+            if not any(ln.startswith(p) for p in prefixes):
+                continue
+            name = ln[:44].strip()
+            f = ln[44:].split()
+            vals = dict(zip(cols, map(float, f[2:2 + len(cols)])))
+            vals["hbm_mb"] = float(f[2 + len(cols)]) if len(f) > 2 + len(cols) else None
+            rows.append((name, vals))
+        return rows
+
+    if workload.startswith("cfg4"):
+        # one decode call = the interpolant on k_mm8w, k_gao, k_gao_finish: bytes of a call = the sum over its kernels' launches
+        rows = parse(("hb::k_mm8w<false", "k_gao<", "k_gao_finish<"))
+        if not rows:
+            raise SystemExit("no Gao kernels in " + path)
+        total = sum(v["hbm_mb"] for _, v in rows if v.get("hbm_mb") is not None)
+        print(json.dumps({"workload": workload, "kernel": "k_mm8w<false,...> (interpolant g1 = V^-1 y) + k_gao (fraction-free extended Euclid + pseudo-division, one wave per "
+                          "codeword) + k_gao_finish (one field inversion per codeword): the launches of one decode call",
+                          "hbm_bytes_per_launch": total * 1e6, "per_kernel_MB": {n: v["hbm_mb"] for n, v in rows}, "source": source}, indent=1))
+        return
+    # plans at small-integer points decode + validate on k_mm8f (hb_mfma_fused.hip); the others on k_mm8w<true, PEEL>
+    rows = parse(("hb::k_mm8f<",))
+    small = bool(rows)
     if not rows:
-        raise SystemExit("no k_mm8w<true,...> row in " + path)
+        rows = parse(("hb::k_mm8w<true",))
+    if not rows:
+        raise SystemExit("no k_mm8f / k_mm8w<true,...> row in " + path)
     name, v = max(rows, key=lambda r: r[1].get("WRITE_SIZE", 0.0))
     simds, ses = 1024, 32                  # SQ_BUSY_CYCLES sums 32 shader-engine instances, instruction counters all 1024 SIMDs
     cycles = v["SQ_BUSY_CYCLES"] / ses
     out = {
         "workload": workload,
-        "kernel": f"{name} (R2: fused decode + validate; the sums of a pass are reduced, stored and compared inside the next pass)",
+        "kernel": (f"{name} (R2: decode + validate as [N ; P] (y ./ den) on the small-entry kernel, the division by den_j inside the kernel)" if small else
+                   f"{name} (R2: fused decode + validate; the sums of a pass are reduced, stored and compared inside the next pass)"),
         "hbm_bytes_per_launch": v["hbm_mb"] * 1e6 if v["hbm_mb"] is not None else None,
         "valu_wave_instr_per_launch": int(v["SQ_INSTS_VALU"]),
         "mfma_per_launch": int(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 16),

@@ -23,8 +23,8 @@ rng = np.random.Generator(np.random.PCG64(5))
 acc = {}
 def T(name, t0):
     acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
-for want in ("all", "constant"):
-    acc.clear()
+for want in (sys.argv[1:] or ["all", "constant"]):
+    acc.clear(); lasts = []
     reps = 200
     for rep in range(reps + 5):
         if rep == 5:
@@ -37,6 +37,8 @@ for want in ("all", "constant"):
             t0 = time.perf_counter()
             dec.add(idx)
             T("add_d" if k == d - 1 else ("add_last" if k == d + t - 1 else "add_other"), t0)
+            if k == d + t - 1:
+                lasts.append(time.perf_counter() - t0)
             if dec.done():
                 break
         t0 = time.perf_counter()
@@ -44,6 +46,7 @@ for want in ("all", "constant"):
         T("results", t0)
     torch.cuda.synchronize()
     tot = (time.perf_counter() - t_all) / reps
-    print(want, f"total {tot*1e6:.1f} us per decode;", {k: round(v / reps * 1e6, 1) for k, v in acc.items()})
+    ls = [round(v * 1e6) for v in lasts[5:]]
+    print(want, f"total {tot*1e6:.1f} us per decode;", {k: round(v / reps * 1e6, 1) for k, v in acc.items()}, "add_last us: first 8", ls[:8], "sorted deciles", sorted(ls)[::20])
     if want == "all":
         assert torch.equal(res.reshape(-1, 4), coef)
