@@ -35,6 +35,7 @@ namespace hb {
 constexpr int QUICK_MAX = 128;       // interpolation points (the kernel's inner dimension)
 constexpr int QUICK_MAXC = 256;      // compared rows
 constexpr int PROBE_MAXN = 256;      // party points of a probe
+constexpr int PROBE_NT = 1024;       // threads of the probe's workgroup: one item of a point's update each (2 (n + 3) coefficients + 2 n values)
 
 struct QuickIdx { uint16_t z[QUICK_MAX], zc[QUICK_MAXC]; };
 struct ProbeIdx { uint16_t idx[PROBE_MAXN]; };
@@ -303,161 +304,163 @@ template <int NL> __device__ __forceinline__ bool lds_nonzero(const uint32_t *p)
     return o != 0;
 }
 
+// The state of a probe: the four polynomials by their COEFFICIENTS (the decision reads degrees and the locator's roots off them) and by
+// their VALUES at all n party points.  With the values at hand the discrepancy of a new point is a look-up, A_j(x_a) + y_a B_j(x_a),
+// and a point costs two dependent multiplications (discrepancy, update) where evaluating the polynomials at it cost four and a
+// 64-lane reduction (round 3: 9 us a point at n = 64, 20 at n = 256); the update
+//     Q_jo <- d_js Q_jo - d_jo Q_js,     Q_js <- (X - x_a) Q_js
+// acts on values pointwise (val_js[i] <- (x_i - x_a) val_js[i]) and on coefficients as before, all items of a point in one phase.
 template <int NL, int NW>
-__global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ pw, int n, int S,
+__global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ pw, int n, int S,
                                                     uint32_t *__restrict__ state, const ProbeIdx ix, int count, int reset,
                                                     const uint32_t *__restrict__ cols, int64_t C, int64_t poly, int k, int decide,
                                                     ProbeResult *__restrict__ result, int seq) {
-    extern __shared__ uint32_t p_lds[];
-    // coef[q][i][NL], q: 0 = A_0, 1 = B_0, 2 = A_1, 3 = B_1; two scratch polynomials for the decision; the reduction buffer
+    extern __shared__ __attribute__((aligned(16))) uint32_t p_lds[];
+    // coef[q][i][NL], q: 0 = A_0, 1 = B_0, 2 = A_1, 3 = B_1; val[q][party][NL]; a scratch polynomial for the decision; the reduction buffer
     uint32_t *coef = p_lds;
-    uint32_t *scr = coef + (size_t)4 * S * NL;               // [S][NL]: the locator the decision looks at
-    uint32_t *red = scr + (size_t)S * NL;                    // [256][NL]
+    uint32_t *val = coef + (size_t)4 * S * NL;               // [4][n][NL]
+    uint32_t *scr = val + (size_t)4 * n * NL;                // [S][NL]: the locator the decision looks at
+    uint32_t *xl = scr + (size_t)S * NL;                     // [n][NL]: the party points (Montgomery), read by every value update
     __shared__ int deg[4], ctl[8], sdeg[2];
     __shared__ uint16_t fedl[PROBE_MAXN];                     // the parties fed so far, in order (persisted with the state)
     __shared__ uint32_t serr[PROBE_MAXN / 4];                 // the verdict's error bytes, gathered before they cross to the host
     __shared__ uint32_t dl[2][NL], yv[NL];
     const int tid = threadIdx.x;
-    const size_t words = (size_t)4 * S * NL;
+    const size_t cwords = (size_t)4 * S * NL, vwords = (size_t)4 * n * NL, words = cwords + vwords;
+    for (int i = tid; i < n * NL; i += PROBE_NT) xl[i] = xm[i];
     int32_t *st_i = reinterpret_cast<int32_t *>(state + words);   // [0..3] degrees, [4] points fed, [8 + i] the i-th party fed
     if (reset) {
-        for (size_t i = tid; i < words; i += 256) coef[i] = 0;
+        for (size_t i = tid; i < cwords; i += PROBE_NT) coef[i] = 0;
+        // Q_0 = (1, 0), Q_1 = (0, 1): A_0 = 1 and B_1 = 1 everywhere, A_1 = B_0 = 0
+        for (size_t i = tid; i < vwords; i += PROBE_NT) {
+            const int q = (int)(i / ((size_t)n * NL)), w = (int)(i % NL);
+            val[i] = (q == 0 || q == 3) ? P.one[w] : 0u;
+        }
         __syncthreads();
         if (tid < NL) { coef[(size_t)0 * S * NL + tid] = P.one[tid]; coef[(size_t)3 * S * NL + tid] = P.one[tid]; }   // Q_0 = 1, Q_1 = Y
         if (tid == 0) { deg[0] = 0; deg[1] = -1; deg[2] = -1; deg[3] = 0; ctl[6] = 0; }
     } else {
-        for (size_t i = tid; i < words; i += 256) coef[i] = state[i];
+        // (val follows coef in LDS as in the state; both are multiples of four words.)  Several loads in flight per thread: one word at a
+        // time this prologue was a chain of dependent round trips
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(state);
+            uint4 *dst = reinterpret_cast<uint4 *>(coef);
+            const int nq = (int)(words / 4);
+            for (int base = 0; base < nq; base += PROBE_NT * 4) {
+                uint4 tmp[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int i = base + u * PROBE_NT + tid; if (i < nq) tmp[u] = src[i]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int i = base + u * PROBE_NT + tid; if (i < nq) dst[i] = tmp[u]; }
+            }
+        }
         if (tid < 4) deg[tid] = st_i[tid];
         if (tid == 0) ctl[6] = st_i[4];
-        fedl[tid] = (uint16_t)st_i[8 + tid];
+        if (tid < PROBE_MAXN) fedl[tid] = (uint16_t)st_i[8 + tid];
     }
     __syncthreads();
-    const int q = tid >> 6, lane = tid & 63;
-    // the operands of a point that come from HBM / L2 (its power row, its x, the received symbol) are requested one point ahead:
-    // a microsecond or two of latency per point would otherwise sit in front of every evaluation
-    uint32_t xp_pre[NL], xa_pre[NL], y_pre[NW];
-    auto prefetch = [&](int pt) {
-        const int a = ix.idx[pt];
-        ldg<NL>(xp_pre, pw + ((size_t)a * S + (lane < S ? lane : S - 1)) * NL);      // inside the row also for short rows
-        ldg<NL>(xa_pre, xm + (size_t)a * NL);
-        if (tid == 0) load_words<NW>(y_pre, cols + ((size_t)a * (size_t)C + (size_t)poly) * NW);
-    };
-    if (count > 0) prefetch(0);
+    // the received symbols of all the points of this launch, in Montgomery form, up front and in parallel (whatever words a sender
+    // packed mean their residue: the reference reduces at its boundary); a point's x comes from the LDS table
+    uint32_t *yml = xl + (size_t)n * NL;                     // [count][NL]
+    for (int pt = tid; pt < count; pt += PROBE_NT) {
+        uint32_t yw[NW], yd[NL], ym[NL];
+        load_words<NW>(yw, cols + ((size_t)ix.idx[pt] * (size_t)C + (size_t)poly) * NW);
+        unpack<NL, NW>(yd, yw);
+        to_mont(ym, yd, P);
+        stg<NL>(yml + (size_t)pt * NL, ym);
+    }
+    __syncthreads();
     for (int pt = 0; pt < count; pt++) {
         const int a = ix.idx[pt];
-        const uint32_t *pwr = pw + (size_t)a * S * NL;
-        uint32_t xp0[NL], xa[NL], yw[NW];
-        fp_set(xp0, xp_pre);
-        fp_set(xa, xa_pre);
-#pragma unroll
-        for (int i = 0; i < NW; i++) yw[i] = y_pre[i];
-        if (pt + 1 < count) prefetch(pt + 1);
-        // partial sums of the four evaluations at x_a: wave q owns polynomial q, a lane its coefficients lane, lane + 64, ...
-        {
-            uint32_t acc[NL];
-#pragma unroll
-            for (int i = 0; i < NL; i++) acc[i] = 0;
-            const int dq = deg[q];
-            for (int i = lane; i <= dq; i += 64) {
-                uint32_t c[NL], xp[NL], m[NL];
-                ldg<NL>(c, coef + ((size_t)q * S + i) * NL);
-                if (i == lane) fp_set(xp, xp0); else ldg<NL>(xp, pwr + (size_t)i * NL);
-                mont_mul(m, c, xp, P);
-                fp_add(acc, acc, m, P);
-            }
-            stg<NL>(red + (size_t)tid * NL, acc);
-        }
-        if (tid == 0) {
-            uint32_t yd[NL], ym[NL];
-            unpack<NL, NW>(yd, yw);
-            // whatever words the sender packed: their residue (the reference reduces at its boundary)
-            to_mont(ym, yd, P);
-            stg<NL>(yv, ym);
-        }
-        // the 64 partial sums of a polynomial live in ONE wave: reduced with wave-level synchronisation only
-        for (int s = 32; s >= 1; s >>= 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lane < s) {
-                uint32_t u[NL], v[NL];
-                ldg<NL>(u, red + (size_t)tid * NL);
-                ldg<NL>(v, red + (size_t)(tid + s) * NL);
-                fp_add(u, u, v, P);
-                stg<NL>(red + (size_t)tid * NL, u);
-            }
-        }
-        __syncthreads();
+        uint32_t xa[NL];
+        ldg<NL>(xa, xl + (size_t)a * NL);
         if (tid < 2) {
-            // discrepancy of Q_tid at the new point
-            uint32_t sa[NL], sb[NL], y[NL], m[NL], dd[NL];
-            ldg<NL>(sa, red + (size_t)(2 * tid) * 64 * NL);
-            ldg<NL>(sb, red + (size_t)(2 * tid + 1) * 64 * NL);
-            ldg<NL>(y, yv);
-            mont_mul(m, y, sb, P);
-            fp_add(dd, sa, m, P);
+            // discrepancy of Q_tid at the new point: A(x_a) + y B(x_a) from the value table
+            uint32_t ym[NL], va[NL], vb[NL], m[NL], dd[NL];
+            ldg<NL>(ym, yml + (size_t)pt * NL);
+            ldg<NL>(va, val + ((size_t)(2 * tid) * n + a) * NL);
+            ldg<NL>(vb, val + ((size_t)(2 * tid + 1) * n + a) * NL);
+            mont_mul(m, ym, vb, P);
+            fp_add(dd, va, m, P);
             stg<NL>(dl[tid], dd);
             ctl[tid] = fp_is_zero(dd) ? 0 : 1;
         }
         __syncthreads();
-        if (tid == 0) {
-            // the pair of smaller leading monomial among those with a discrepancy; (1, k-1)-weighted degree, ties: Y terms larger
-            int js = -1, best_w = 0, best_y = 0;
+        // the pair of smaller leading monomial among those with a discrepancy; (1, k-1)-weighted degree, ties: Y terms larger
+        // (every thread works it out for itself from the shared flags and degrees)
+        int js = -1;
+        {
+            int best_w = 0, best_y = 0;
             for (int j = 0; j < 2; j++) {
                 if (!ctl[j]) continue;
                 const int wa = deg[2 * j], wb = deg[2 * j + 1] >= 0 ? deg[2 * j + 1] + k - 1 : -1;
                 const int w = wa > wb ? wa : wb, yy = wb >= wa ? 1 : 0;
                 if (js < 0 || w < best_w || (w == best_w && yy < best_y)) { js = j; best_w = w; best_y = yy; }
             }
-            ctl[2] = js;
-            fedl[ctl[6]] = (uint16_t)a;
-            ctl[6] += 1;
         }
-        __syncthreads();
-        const int js = ctl[2];
+        if (tid == 0) { fedl[ctl[6]] = (uint16_t)a; ctl[6] += 1; }
         if (js >= 0) {
             const int jo = 1 - js;
             const int top = max(max(deg[0], deg[1]), max(deg[2], deg[3])) + 1;      // highest index any polynomial reaches after this step
-            if (ctl[jo]) {
-                // Q_jo <- dl[js] Q_jo - dl[jo] Q_js
-                uint32_t ds[NL], dj[NL];
-                ldg<NL>(ds, dl[js]);
+            const bool upd_o = ctl[jo] != 0;
+            uint32_t ds[NL], ndj[NL];
+            ldg<NL>(ds, dl[js]);
+            {
+                uint32_t dj[NL];
                 ldg<NL>(dj, dl[jo]);
-                for (int e = tid; e < 2 * (top + 1); e += 256) {
-                    const int part = e / (top + 1), i = e - part * (top + 1);
-                    uint32_t u[NL], v[NL], m1[NL], m2[NL], r[NL];
-                    uint32_t *po = coef + ((size_t)(2 * jo + part) * S + i) * NL;
+                fp_neg(ndj, dj, P);
+            }
+            // items: coefficient i of part `part` (A or B) for i <= top, then the value at party i of part `part`.  Q_jo's item is
+            // rewritten in place (it reads its own index of both pairs); the value of Q_js too; the COEFFICIENT of Q_js takes its
+            // lower neighbour, so it is held back until every thread has read: at most one a thread (2 (n + 3) <= PROBE_NT)
+            const int nce = 2 * (top + 1), nitems = nce + 2 * n;
+            uint32_t keep[3][NL];
+            int kept = 0;
+            for (int e = tid; e < nitems; e += PROBE_NT) {
+                const bool is_coef = e < nce;
+                const int ee = is_coef ? e : e - nce, span = is_coef ? top + 1 : n;
+                const int part = ee / span, i = ee - part * span;
+                uint32_t *po = (is_coef ? coef + ((size_t)(2 * jo + part) * S + i) * NL : val + ((size_t)(2 * jo + part) * n + i) * NL);
+                uint32_t *ps = (is_coef ? coef + ((size_t)(2 * js + part) * S + i) * NL : val + ((size_t)(2 * js + part) * n + i) * NL);
+                uint32_t v[NL];
+                ldg<NL>(v, ps);
+                if (upd_o) {
+                    // Q_jo <- d_js Q_jo - d_jo Q_js: one reduction for the two products
+                    uint32_t u[NL], r[NL];
+                    uint64_t col[2 * NL];
                     ldg<NL>(u, po);
-                    ldg<NL>(v, coef + ((size_t)(2 * js + part) * S + i) * NL);
-                    mont_mul(m1, ds, u, P);
-                    mont_mul(m2, dj, v, P);
-                    fp_sub(r, m1, m2, P);
+                    col_zero(col);
+                    mac<NL>(col, ds, u);
+                    mac<NL>(col, ndj, v);
+                    redc(r, col, P);
+                    cond_sub_p(r, P);
                     stg<NL>(po, r);
                 }
-            }
-            __syncthreads();
-            // Q_js <- (X - x_a) Q_js: values first, the barrier, then the stores
-            {
-                uint32_t keep[3][NL];     // 2 (n + 3) values over 256 threads: at most three each
-                int cnt = 0;
-                for (int e = tid; e < 2 * (top + 1); e += 256, cnt++) {
-                    const int part = e / (top + 1), i = e - part * (top + 1);
-                    const uint32_t *ps = coef + ((size_t)(2 * js + part) * S) * NL;
-                    uint32_t cur[NL], prev[NL], m[NL];
-                    ldg<NL>(cur, ps + (size_t)i * NL);
-                    if (i > 0) ldg<NL>(prev, ps + (size_t)(i - 1) * NL);
+                if (is_coef) {
+                    // Q_js <- (X - x_a) Q_js
+                    uint32_t prev[NL], m[NL];
+                    if (i > 0) ldg<NL>(prev, ps - NL);
                     else {
 #pragma unroll
                         for (int w = 0; w < NL; w++) prev[w] = 0;
                     }
-                    mont_mul(m, xa, cur, P);
-                    if (cnt < 3) fp_sub(keep[cnt], prev, m, P);
+                    mont_mul(m, xa, v, P);
+                    if (kept < 3) fp_sub(keep[kept], prev, m, P);
+                    kept++;
+                } else {
+                    uint32_t xi[NL], df[NL], m[NL];
+                    ldg<NL>(xi, xl + (size_t)i * NL);
+                    fp_sub(df, xi, xa, P);
+                    mont_mul(m, df, v, P);
+                    stg<NL>(ps, m);
                 }
-                __syncthreads();
-                cnt = 0;
-                for (int e = tid; e < 2 * (top + 1); e += 256, cnt++) {
-                    const int part = e / (top + 1), i = e - part * (top + 1);
-                    if (cnt < 3) stg<NL>(coef + ((size_t)(2 * js + part) * S + i) * NL, keep[cnt]);
-                }
+            }
+            __syncthreads();
+            kept = 0;
+            for (int e = tid; e < nce; e += PROBE_NT) {
+                const int part = e / (top + 1), i = e - part * (top + 1);
+                if (kept < 3) stg<NL>(coef + ((size_t)(2 * js + part) * S + i) * NL, keep[kept]);
+                kept++;
             }
             __syncthreads();
             // new degrees: the pivot's parts grow by one, the other pair's parts become the larger of the two; a scan only when a
@@ -467,7 +470,7 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
                 for (int part = 0; part < 2; part++) {
                     const int djs = deg[2 * js + part], djo = deg[2 * jo + part];
                     nd[2 * js + part] = djs >= 0 ? djs + 1 : -1;
-                    nd[2 * jo + part] = ctl[jo] ? (djs > djo ? djs : djo) : djo;
+                    nd[2 * jo + part] = upd_o ? (djs > djo ? djs : djo) : djo;
                 }
                 for (int x = 0; x < 4; x++) {
                     if (nd[x] >= 0 && !lds_nonzero<NL>(coef + ((size_t)x * S + nd[x]) * NL)) rescan = 1;
@@ -479,19 +482,27 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
             if (ctl[3]) {
                 if (tid < 4) deg[tid] = -1;
                 __syncthreads();
-                for (int e = tid; e < 4 * (top + 1); e += 256) {
+                for (int e = tid; e < 4 * (top + 1); e += PROBE_NT) {
                     const int part = e / (top + 1), i = e - part * (top + 1);
                     if (lds_nonzero<NL>(coef + ((size_t)part * S + i) * NL)) atomicMax(&deg[part], i);
                 }
                 __syncthreads();
             }
+        } else {
+            __syncthreads();          // (the list of fed parties and the flags are read again by the next point)
         }
     }
     // persistent state back (the decision below works on copies)
-    for (size_t i = tid; i < words; i += 256) state[i] = coef[i];
+    __syncthreads();
+    {
+        uint4 *dst = reinterpret_cast<uint4 *>(state);
+        const uint4 *src = reinterpret_cast<const uint4 *>(coef);
+        const int nq = (int)(words / 4);
+        for (int i = tid; i < nq; i += PROBE_NT) dst[i] = src[i];
+    }
     if (tid < 4) st_i[tid] = deg[tid];
     if (tid == 0) st_i[4] = ctl[6];
-    st_i[8 + tid] = fedl[tid];
+    if (tid < PROBE_MAXN) st_i[8 + tid] = fedl[tid];
     if (!decide) return;
     __syncthreads();
     // ---- the reference's outcome for the points fed so far -----------------------------------------------------------
@@ -519,7 +530,7 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
             uint32_t c0[NL], c1[NL];
             ldg<NL>(c0, coef + ((size_t)(2 * j0) * S + T) * NL);
             ldg<NL>(c1, coef + ((size_t)(2 * j1) * S + T) * NL);
-            for (int i = tid; i < S; i += 256) {
+            for (int i = tid; i < S; i += PROBE_NT) {
                 uint32_t u[NL], v[NL], m1[NL], m2[NL], r[NL];
                 ldg<NL>(u, coef + ((size_t)(2 * j1 + 1) * S + i) * NL);
                 ldg<NL>(v, coef + ((size_t)(2 * j0 + 1) * S + i) * NL);
@@ -529,7 +540,7 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
                 stg<NL>(Bd + (size_t)i * NL, r);
             }
         } else {
-            for (int i = tid; i < S; i += 256) {
+            for (int i = tid; i < S; i += PROBE_NT) {
                 uint32_t u[NL];
                 ldg<NL>(u, coef + ((size_t)(2 * j1 + 1) * S + i) * NL);
                 stg<NL>(Bd + (size_t)i * NL, u);
@@ -538,7 +549,7 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
         if (tid < 2) sdeg[tid] = -1;
         if (tid == 0) ctl[0] = 0;
         __syncthreads();
-        for (int e = tid; e < S; e += 256)
+        for (int e = tid; e < S; e += PROBE_NT)
             if (lds_nonzero<NL>(Bd + (size_t)e * NL)) atomicMax(&sdeg[1], e);
         __syncthreads();
     }
@@ -550,40 +561,38 @@ __global__ void __launch_bounds__(256) k_probe_feed(const FpParams<NL> P, const 
     __syncthreads();
     const int db = fine ? sdeg[1] : -1;
     if (fine) {
-        for (int base = 0; base < npts; base += 64) {
-            const int pi = base + (tid >> 2), part = tid & 3;
-            uint32_t acc[NL];
-#pragma unroll
-            for (int i = 0; i < NL; i++) acc[i] = 0;
-            int a = -1;
-            if (pi < npts) {
-                a = fedl[pi];
-                const uint32_t *pwr = pw + (size_t)a * S * NL;
-                for (int i = part; i <= db; i += 4) {
-                    uint32_t c[NL], xp[NL], m[NL];
-                    ldg<NL>(c, Bd + (size_t)i * NL);
-                    ldg<NL>(xp, pwr + (size_t)i * NL);
-                    mont_mul(m, c, xp, P);
-                    fp_add(acc, acc, m, P);
-                }
-            }
-            stg<NL>(red + (size_t)tid * NL, acc);
-            __syncthreads();
-            if (pi < npts && part == 0) {
-                uint32_t u[NL];
-                ldg<NL>(u, red + (size_t)tid * NL);
-                for (int w = 1; w < 4; w++) {
-                    uint32_t v[NL];
-                    ldg<NL>(v, red + (size_t)(tid + w) * NL);
-                    fp_add(u, u, v, P);
-                }
-                if (fp_is_zero(u) && db >= 1) {            // a constant locator names nobody
-                    atomicOr(&serr[a >> 2], 1u << (8 * (a & 3)));
-                    atomicAdd(&ctl[0], 1);
-                }
-            }
-            __syncthreads();
+        // the locator's values at the points fed are in the value table (B_1 itself, or the same combination of the two B's that
+        // reduced it in the tie case): a root is a zero there -- no evaluation
+        uint32_t c0[NL], nc1[NL];
+        const bool tie = ctl[7] != 0;
+        if (tie) {
+            const int T = (npts + k) / 2;
+            uint32_t c1[NL];
+            ldg<NL>(c0, coef + ((size_t)(2 * j0) * S + T) * NL);
+            ldg<NL>(c1, coef + ((size_t)(2 * j1) * S + T) * NL);
+            fp_neg(nc1, c1, P);
         }
+        for (int pi = tid; pi < npts; pi += PROBE_NT) {
+            const int a = fedl[pi];
+            uint32_t v[NL];
+            ldg<NL>(v, val + ((size_t)(2 * j1 + 1) * n + a) * NL);
+            if (tie) {
+                uint32_t v0[NL], r[NL];
+                uint64_t col[2 * NL];
+                ldg<NL>(v0, val + ((size_t)(2 * j0 + 1) * n + a) * NL);
+                col_zero(col);
+                mac<NL>(col, c0, v);
+                mac<NL>(col, nc1, v0);
+                redc(r, col, P);
+                cond_sub_p(r, P);
+                fp_set(v, r);
+            }
+            if (fp_is_zero(v) && db >= 1) {            // a constant locator names nobody
+                atomicOr(&serr[a >> 2], 1u << (8 * (a & 3)));
+                atomicAdd(&ctl[0], 1);
+            }
+        }
+        __syncthreads();
         if (db < 0 || ctl[0] != (db >= 1 ? db : 0)) fine = false;
     }
     __syncthreads();
@@ -966,8 +975,16 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     pt->refs++;                                // this probe's reference: the table outlives its cache entry while the probe lives
     hb_probe *pr = new hb_probe();
     pr->ctx = ctx; pr->n = n; pr->k = k; pr->pt = pt; pr->poly = -1; pr->seq = 0;
-    pr->state_bytes = ((size_t)4 * pt->S * ctx->nl() + 8 + PROBE_MAXN) * 4;
-    const size_t pool_bytes = ((size_t)4 * (PROBE_MAXN + 2) * 9 + 8 + PROBE_MAXN) * 4;     // pooled states are all of the largest size
+    pr->state_bytes = ((size_t)4 * (pt->S + n) * ctx->nl() + 8 + PROBE_MAXN) * 4;
+    const size_t pool_bytes = ((size_t)4 * (2 * PROBE_MAXN + 2) * 9 + 8 + PROBE_MAXN) * 4;     // pooled states are all of the largest size: coefficients + values
+    {
+        // (5 S + 4 n + 256) NL words of LDS: 92 KB at the 256-point limit -- above the 64 KB a launch may ask for without saying so.  Per
+        // device, not per process: set whenever a probe is created
+        const int lim = 128 * 1024;
+        hipError_t ae = ctx->n_limbs == 4 ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_feed<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+                                          : hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_feed<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (ae != hipSuccess) { point_table_unref(pt); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipFuncSetAttribute"); }
+    }
     pr->state = nullptr; pr->res_host = nullptr; pr->res_dev = nullptr;
     if (!ctx->probe_pool.empty()) { pr->state = (uint32_t *)ctx->probe_pool.back(); ctx->probe_pool.pop_back(); }
     else if (hipMalloc(&pr->state, pool_bytes) != hipSuccess) { point_table_unref(pt); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipMalloc"); }
@@ -1008,13 +1025,12 @@ static int probe_launch(hb_probe *pr, const int32_t *idx, int count, const uint6
     if (count == 0 && reset) return fail(ctx, HB_ERR_BAD_ARG, "probe: nothing fed yet");
     const int S = pr->pt->S, NLr = ctx->nl();
     const int seq = pr->seq + 1;
-    // (5 S + 256) NL words: 55.7 KB at the 256-point limit, below the 64 KB a launch may ask for without an attribute
-    const size_t lds = ((size_t)5 * S * NLr + (size_t)256 * NLr) * 4;
+    const size_t lds = ((size_t)(5 * S + 6 * pr->n) * NLr) * 4;      // coefficients, values, the decision's scratch polynomial, the points, this launch's symbols
     if (ctx->n_limbs == 4)
-        k_probe_feed<9, 8><<<1, 256, lds, s>>>(ctx->pw, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
+        k_probe_feed<9, 8><<<1, PROBE_NT, lds, s>>>(ctx->pw, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
                                                (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq);
     else
-        k_probe_feed<3, 2><<<1, 256, lds, s>>>(ctx->pn, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
+        k_probe_feed<3, 2><<<1, PROBE_NT, lds, s>>>(ctx->pn, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
                                                (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq);
     {
         const hipError_t le = hipGetLastError();
