@@ -453,6 +453,45 @@ int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, h
 }  // namespace hb
 
 namespace {
+
+// ---- four-step transform for orders beyond the LDS kernel (reference benchmark/test_benchmark_polynomial.py:22-48
+// runs fft up to n = 2^20 through rsdecode_impl.h:125-192) ---------------------------------------------------------------------------
+// n = n1 n2, j = j1 n2 + j2, i = i1 + i2 n1:   omega^(i j) = (omega^n2)^(i1 j1) * omega^(i1 j2) * (omega^n1)^(i2 j2)
+//   1. for every j2: the n1-point transform over j1 (root omega^n2)            -> A[i1][j2]        k_ntt_lds, strided views
+//   2. A[i1][j2] *= omega^(i1 j2)                                               k_ntt_twist (this kernel)
+//   3. for every i1: the n2-point transform over j2 (root omega^n1)            -> out[i1 + i2 n1]  k_ntt_lds, strided views
+// Three passes over HBM where the stage loop makes log2(n) + 2.
+template <int NL, int NW>
+__global__ void k_ntt_twist(const FpParams<NL> P, const uint32_t *__restrict__ tw, uint32_t *__restrict__ a, int n, int n2, int64_t count) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const int64_t i1 = e / n2, j2 = e - i1 * n2;
+    const int64_t ex = (i1 * j2) & (int64_t)(n - 1);          // exponent mod n
+    if (ex == 0) return;
+    uint32_t x[NL], w[NL], r[NL];
+    load_digits<NL, NW>(x, a + e * NW);
+    const bool negw = ex >= n / 2;                              // omega^(n/2) = -1
+    const uint32_t *wp = tw + (size_t)(negw ? ex - n / 2 : ex) * NL;
+#pragma unroll
+    for (int q = 0; q < NL; q++) w[q] = wp[q];
+    mont_mul(r, x, w, P);                                       // canonical x times a Montgomery-form twiddle: canonical
+    if (negw) fp_neg(r, r, P);
+    store_digits<NL, NW>(a + e * NW, r);
+}
+
+// w^(2^e) mod p on the host with the kernels' own arithmetic (canonical limbs in and out)
+template <int NL, int NW>
+void host_pow2(const FpParams<NL> &P, const uint64_t *w_limbs, int e, uint64_t *out_limbs) {
+    uint32_t ww[NW], d[NL], m[NL];
+    for (int i = 0; i < NW; i++) ww[i] = (uint32_t)(w_limbs[i / 2] >> (32 * (i & 1)));
+    unpack<NL, NW>(d, ww);
+    to_mont(m, d, P);
+    for (int i = 0; i < e; i++) mont_mul(m, m, m, P);
+    from_mont(d, m, P);
+    pack<NL, NW>(ww, d);
+    for (int i = 0; i < NW / 2; i++) out_limbs[i] = (uint64_t)ww[2 * i] | ((uint64_t)ww[2 * i + 1] << 32);
+}
+
 }  // namespace
 
 extern "C" {
@@ -497,7 +536,44 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, co
         hb_view iv{d, 1}, ov{k, 1};
         return launch_ntt_lds(ctx, tw, n, (const uint32_t *)coeffs_dev, iv, INT64_MAX, d, k, (uint32_t *)out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
     }
-    // large order: stage-by-stage over a digit buffer in HBM
+    // large order: four steps over the LDS kernel (n = n1 n2, both factors at most 2048), one polynomial at a time
+    if (logn <= 22 && !getenv("HB_NTT_STAGE_LOOP")) {
+        const int l1 = (logn + 1) / 2, l2 = logn - l1, n1 = 1 << l1, n2 = 1 << l2;
+        uint64_t w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};           // omega^n2 (order n1), omega^n1 (order n2)
+        if (ctx->n_limbs == 4) { host_pow2<9, 8>(ctx->pw, omega_host, l2, w1); host_pow2<9, 8>(ctx->pw, omega_host, l1, w2); }
+        else { host_pow2<3, 2>(ctx->pn, omega_host, l2, w1); host_pow2<3, 2>(ctx->pn, omega_host, l1, w2); }
+        uint32_t *tw1 = nullptr, *tw2 = nullptr;
+        rc = get_twiddles(ctx, w1, n1, &tw1, s); if (rc) return rc;
+        rc = get_twiddles(ctx, w2, n2, &tw2, s); if (rc) return rc;
+        const int NWr = ctx->elem_words();
+        // the n-element scratch between the steps: kept per context, order and stream (a transform of this size is not called once)
+        uint32_t *A = nullptr;
+        {
+            const std::string skey = "ntt4:" + std::to_string(n) + ":" + std::to_string((uintptr_t)stream);      // per stream: launches of one stream are ordered
+            auto sit = ctx->dcache.find(skey);
+            if (sit != ctx->dcache.end()) A = (uint32_t *)sit->second;
+            else {
+                HB_HIP(ctx, hipMalloc(&A, (size_t)n * NWr * 4));
+                ctx->dcache[skey] = A;
+            }
+        }
+        const int d1 = (dd + n2 - 1) / n2 < n1 ? (dd + n2 - 1) / n2 : n1;          // coefficients a column of the first step can hold
+        const int rows3 = k < n1 ? k : n1;                                          // outputs i = i1 + i2 n1 < k need i1 < k
+        for (int64_t c = 0; c < C && !rc; c++) {
+            const uint32_t *in_c = (const uint32_t *)coeffs_dev + (size_t)c * d * NWr;
+            uint32_t *out_c = (uint32_t *)out_dev + (size_t)c * k * NWr;
+            rc = launch_ntt_lds(ctx, tw1, n1, in_c, hb_view{1, n2}, dd, d1, n1, A, hb_view{1, n2}, INT64_MAX, nullptr, nullptr, n2, s);
+            if (rc) break;
+            const int64_t cnt = (int64_t)n;
+            if (ctx->n_limbs == 4) k_ntt_twist<9, 8><<<(unsigned)((cnt + 255) / 256), 256, 0, s>>>(ctx->pw, tw, A, n, n2, cnt);
+            else k_ntt_twist<3, 2><<<(unsigned)((cnt + 255) / 256), 256, 0, s>>>(ctx->pn, tw, A, n, n2, cnt);
+            rc = launch_ntt_lds(ctx, tw2, n2, A, hb_view{n2, 1}, INT64_MAX, n2, n2, out_c, hb_view{1, n1}, k, nullptr, nullptr, rows3, s);
+        }
+        if (rc) return rc;
+        HB_LAUNCH_CHECK(ctx);
+        return HB_OK;                                   // asynchronous like the LDS path: the scratch is only touched in stream order
+    }
+    // (HB_NTT_STAGE_LOOP=1, orders beyond 2^22: stage by stage over a digit buffer in HBM)
     if ((double)C * n * elem_lds > 64.0e9) return fail(ctx, HB_ERR_UNSUPPORTED, "fft: scratch too large");
     uint32_t *buf = nullptr;
     HB_HIP(ctx, hipMalloc(&buf, (size_t)C * n * elem_lds));

@@ -573,10 +573,13 @@ def test_fft_reference_vectors(hip, golden):
 
 @pytest.mark.parametrize("n,d,k,c", [(2, 1, 2, 3), (4, 2, 4, 70), (16, 6, 16, 300), (16, 16, 11, 5), (32, 20, 25, 64),
                                      (64, 22, 64, 130), (128, 34, 100, 9), (256, 86, 256, 7), (1024, 300, 1000, 2),
-                                     (4096, 4096, 4096, 1), (8192, 100, 8192, 1), (16, 40, 16, 3)])
+                                     (4096, 4096, 4096, 1), (8192, 100, 8192, 1), (16, 40, 16, 3),
+                                     (4096, 100, 300, 2), (8192, 8192, 5000, 2), (1 << 16, 1 << 16, 1 << 16, 1), (1 << 16, 70000, 777, 1),
+                                     (1 << 20, 1 << 20, 1 << 20, 1), (1 << 20, 3000, 1 << 20, 1)])
 def test_fft_vs_oracle(hip, golden, n, d, k, c):
-    """covers the mat-vec route (small n), the LDS NTT (n <= 4096), the HBM multi-pass NTT
-    (n = 8192) and truncation of coefficient lists longer than n (rsdecode_impl.h:173)"""
+    """covers the mat-vec route (small n), the LDS NTT (n <= 2048), the four-step transform over it (4096 <= n <= 2^22: the
+    reference benchmarks fft up to 2^20, benchmark/test_benchmark_polynomial.py:22-48), partial outputs, few coefficients, and
+    truncation of coefficient lists longer than n (rsdecode_impl.h:173)"""
     from honeybadgermpc_amd.field import GF
     from honeybadgermpc_amd.polynomial import get_omega
 
@@ -585,6 +588,28 @@ def test_fft_vs_oracle(hip, golden, n, d, k, c):
     coeffs = rand_rows(rnd, P, c, d)
     coeffs[0] = [0] * d
     assert hip.fft_batch_evaluate(coeffs, omega, P, n, k) == oracle.fft_batch_evaluate(coeffs, omega, P, n, k)
+
+
+def test_fft_four_step_equals_the_stage_loop_and_narrow_contexts(hip, monkeypatch):
+    """the four-step transform against the stage-by-stage loop it replaces (HB_NTT_STAGE_LOOP=1), and on a 1-limb context
+    (p = 2^64 - 2^32 + 1, 2-adicity 32)"""
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import get_omega
+
+    n = 1 << 14
+    omega = get_omega(GF(P), n, seed=0).value
+    rnd = random.Random(14)
+    rows = rand_rows(rnd, P, 2, 9000)
+    got = hip.fft_batch_evaluate(rows, omega, P, n, n)
+    monkeypatch.setenv("HB_NTT_STAGE_LOOP", "1")
+    assert hip.fft_batch_evaluate(rows, omega, P, n, n) == got
+    monkeypatch.delenv("HB_NTT_STAGE_LOOP")
+    gold = (1 << 64) - (1 << 32) + 1
+    g = 7
+    om = pow(g, (gold - 1) // 8192, gold)
+    assert pow(om, 4096, gold) == gold - 1
+    rows = rand_rows(rnd, gold, 3, 5000)
+    assert hip.fft_batch_evaluate(rows, om, gold, 8192, 8192) == oracle.fft_batch_evaluate(rows, om, gold, 8192, 8192)
 
 
 def test_fft_small_primes(hip):
