@@ -229,11 +229,26 @@ def valu_roofline(workload, launch_ms):
             "pmc_kernel_cycles": pc.get("kernel_cycles"),
             "note": "frac is against the nominal 2.4 GHz and one wave-instruction per 4 cycles per SIMD; the PMC pass counts the kernel's busy cycles "
                     "(pmc_kernel_cycles; / duration = the clock it sustained, ~2.1 GHz), of which the same instruction stream is the "
-                    "pmc_valu_busy fraction.  A kernel that runs ONE wave per SIMD (k_mm8w) issues an instruction every ~5 cycles at best "
-                    "and an MFMA holds the SIMD for its whole 16 cycles (profiles/r01_mad_issue_rate_vs_occupancy.txt, "
-                    "profiles/r02_issue_rate_of_the_pass_mix.txt, the zero-group skip of k_mm8 in DESIGN.md section 11): for it ~0.5 on this scale is the ceiling.  Round 3 took 29 % of the R2 launch's "
-                    "instructions out (24.75 M -> 17.55 M) for 5 % of its cycles: this fraction FELL with a faster kernel -- it is a count of "
-                    "issue slots used, not a measure of how close the kernel is to a bound (DESIGN.md section 11)"}
+                    "pmc_valu_busy fraction.  An int8 MFMA holds the SIMD for its whole 16+ cycles and nothing rides under it "
+                    "(profiles/r01_mad_issue_rate_vs_occupancy.txt, profiles/r02_issue_rate_of_the_pass_mix.txt, the zero-group skip of k_mm8 in "
+                    "docs/history/DESIGN_r03.md section 11), so this fraction is a count of issue slots used, not a measure of how close the kernel is to a bound"}
+
+
+def int8_usefulness(second, n_rows, d, chunks, digits, launch_ms):
+    """what part of the matrix pipe's int8 ceiling is USEFUL work -- rows x terms x chunks products of a 32-byte element
+    with a `digits`-digit entry, 2 ops each -- next to what the launch issues (every MFMA is 16 x 16 x 64 x 2 ops)."""
+    if second is None:
+        return None
+    peak = 3.94e15                                  # dense int8 on the matrix cores (MI355X_MICROARCH.md)
+    useful = float(n_rows) * d * chunks * 32 * digits * 2
+    second = dict(second)
+    second["useful_int8_ops_per_launch"] = useful
+    second["useful_int8_frac_of_peak"] = useful / (launch_ms * 1e-3) / peak
+    if second.get("mfma_per_launch"):
+        second["issued_int8_frac_of_peak"] = second["mfma_per_launch"] * 32768.0 / (launch_ms * 1e-3) / peak
+    second["int8_note"] = (f"useful = {n_rows} rows x {d} terms x {chunks} chunks x 32 bytes x {digits} digits x 2; issued = MFMAs x 16 x 16 x 64 x 2; "
+                           "against 3.94 POPS dense int8")
+    return second
 
 
 def ntl_baseline(n, t, sample_b, threads):
@@ -1141,7 +1156,8 @@ def main():
     sec_pad = secrets
     assert torch.equal(r2_msg, r2_cols[:C]), "R2 message != what party 0 would broadcast"
 
-    fused_default = dt_unfused is not None         # the plan decodes + validates in one k_mm8w launch by default
+    fused_default = dt_unfused is not None         # the plan decodes + validates in one launch by default
+    fused_kernel = op.fused_validate_kernel() if fused_default else None      # "small": k_mm8f (hb_mfma_fused.hip); "wide": k_mm8w
     assert fused_default == time_r2 or args.no_matrix_cores, "the events bracketed the wrong launch"
     enc_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps if not time_r2 else None
     r2_ms = sum(a.elapsed_time(b) for a, b in zip(ev2, ev3)) / args.steps if time_r2 else None
@@ -1187,18 +1203,25 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic_from_profiles(args.workload if mfma else args.workload + "_valu"),
                 "kernel": (profile_counters(args.workload).get("kernel") or
-                           "k_mm8w<true,PEEL> (R2: fused decode + validate, (d + n_check) x d full-size entries as a byte-split int8 GEMM; "
-                           "the next pass reduces, stores and compares the sums of the pass before)") if fused_default else
+                           ("k_mm8f<NKB> (R2: decode + validate as [N ; P] (y ./ den): small-integer numerators on the small-entry kernel, the division by den_j inside it)"
+                            if fused_kernel == "small" else
+                            "k_mm8w<true,PEEL> (R2: fused decode + validate, (d + n_check) x d full-size entries as a byte-split int8 GEMM; "
+                            "the next pass reduces, stores and compares the sums of the pass before)")) if fused_default else
                           ("k_mm8<NKB,false> (R1 encode: n x d small-entry Vandermonde mat-vec as a byte-split int8 GEMM + Barrett; "
                            "the validating re-encodes are the same kernel in CHECK mode, the decodes the same kernel over the factored inverse's numerators)" if mfma else
                            "k_matvec3<9,8,false> (R1 encode: fused pre-scale + n x d small-entry Vandermonde mat-vec)"),
                 "algorithmic_bytes_per_launch": alg_bytes_enc, "avg_launch_ms": enc_ms,
                 "copy_GBps_measured": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
-                "second": valu_roofline(args.workload if mfma else args.workload + "_valu", enc_ms),
-                "note": ("instruction-issue bound: one wave per SIMD (all 63 int32 columns of a 16 x 16 pass live in AGPRs); a pass at d = 22 is 532 MFMAs "
-                         "(468 of the product, 64 of the fold of the sums' high halves) at ~17 cycles of the SIMD each -- nothing rides under an int8 MFMA -- "
-                         "and ~1600 other instructions at ~4 (DESIGN.md sections 4c and 11); "
-                         "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/); see DESIGN.md section 4c") if fused_default else
+                "second": (int8_usefulness(valu_roofline(args.workload, enc_ms), d + len(zc), d, C, 16 if fused_kernel == "small" else 32, enc_ms)
+                           if fused_default and mfma else valu_roofline(args.workload if mfma else args.workload + "_valu", enc_ms)),
+                "note": (("instruction-issue bound: workgroups of eight waves, two per SIMD; a unit of 64 chunks is 4 x n_rt passes of the small-entry GEMM (16-digit entries, 47 int32 "
+                          "columns, ~195 MFMAs at ~17 cycles of the SIMD each + ~170 instructions per output) plus the division of its d x 64 input elements by den_l (one modular "
+                          "multiplication each, done by the waves that have a pass less) -- DESIGN.md section 3c; "
+                          "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/)") if fused_kernel == "small" else
+                         ("instruction-issue bound: one wave per SIMD (all 63 int32 columns of a 16 x 16 pass live in AGPRs); a pass at d = 22 is 532 MFMAs "
+                          "(468 of the product, 64 of the fold of the sums' high halves) at ~17 cycles of the SIMD each -- nothing rides under an int8 MFMA -- "
+                          "and ~1600 other instructions at ~4 (DESIGN.md section 3b); "
+                          "traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes (profiles/)")) if fused_default else
                         ("neither HBM nor the matrix pipe binds: per 16x16 tile 47 int32 columns x (d/4) MFMAs are followed by a 390-bit "
                          "reduction per output (its high words folded on the matrix cores, the rest on the VALU: instruction-issue bound, DESIGN.md section 4b); "
                          if mfma else
@@ -1223,9 +1246,11 @@ def main():
                 "validate_arrived_only_note": "plan option on the unfused pipeline (decode, re-encode, compare): the guess is re-evaluated at the t compared "
                                               "points only (same accept/reject)",
                 "fused_decode_validate": dt_unfused is not None,
+                "fused_decode_validate_kernel": fused_kernel,
                 "shares_per_s_per_gpu_three_full_encodes": (B * args.steps / dt_unfused) if dt_unfused else None,
                 "fused_decode_validate_note": "each decode launch also produces the guess's values at the compared points as (V[zc] Vinv) y and compares them "
-                                              "(HB_OPEN_OPT_FUSED_VALIDATE, default on; same results, "
+                                              "(HB_OPEN_OPT_FUSED_VALIDATE, default on: at points that are small integers as [N ; P] (y ./ den) on k_mm8f, otherwise as "
+                                              "[Vinv ; V[zc] Vinv] on k_mm8w; same results, "
                                               "same accept/reject as the reference's decode + encode_batch + compare); three_full_encodes = the option off: "
                                               "decode, re-encode ALL n points on the plan's own kernels, compare -- the round-1 definition of `value`",
                 "shares_per_s_per_gpu_fused_validate_on_request": (B * args.steps / dt_fused_optin) if dt_fused_optin else None,
