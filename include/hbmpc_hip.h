@@ -234,7 +234,12 @@ int hb_open_status(hb_open_plan *plan, void *stream);
  * reject).  The two matrices are built on the device when the plan is created (hb_quick.hip: enqueued, nothing waited for);
  * where that builder does not apply (p >= 0x7f 2^248, repeated points) they are built through the host (1-2.5 ms) when the plan
  * decodes for the third time, or at once when the option is set to 1.
- * 0: decode, then re-encode all n points (NTT or mat-vec) and compare.  get_option: enabled and available for this plan. */
+ * At points that are distinct integers below 2^16 (the production points 1 .. n; 4 <= d <= 22) the two products factor as
+ * [N ; P] (y ./ den) with matrices of small INTEGERS (numerators of the Lagrange basis and its values at the compared points):
+ * such plans decode + validate on the small-entry kernel with the division by den_j inside it (csrc/hb_mfma_fused.hip) -- value 2
+ * selects the full-size kernel for them all the same.
+ * 0: decode, then re-encode all n points (NTT or mat-vec) and compare.  get_option: 0 = off / unavailable, 1 = on (full-size
+ * kernel), 3 = on (small-entry kernel). */
 #define HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY 1
 #define HB_OPEN_OPT_MATRIX_CORES 2
 #define HB_OPEN_OPT_FUSED_VALIDATE 3
