@@ -504,6 +504,11 @@ class DeviceIncrementalDecoder:
         """row idx of the party-major buffer: where party idx's column is received; add(idx) announces it"""
         return self._cols[idx]
 
+    def accepts(self, idx):
+        """would add(idx) count this sender's column?  (not once the decoder is done, nor a sender already counted or confirmed in error:
+        reference reed_solomon.py:369-372) -- a transport that receives in place asks BEFORE it writes into slot(idx)"""
+        return self._result is None and idx not in self._available_points and idx not in self._confirmed_errors
+
     # -- kernels ---------------------------------------------------------------------------------
     def _plan(self, z, zc):
         return cached_batch_open(self.ctx.modulus, self.n, self.max_errors, z, zc, use_omega_powers=self.use_omega_powers,

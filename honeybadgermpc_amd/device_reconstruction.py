@@ -50,10 +50,14 @@ async def _incremental_decode_device(receivers, make_decoder, device):
                     raise ValueError("column of non-integers")
                 inc.add(idx, list(blob))
             else:
-                col = wire.wire_to_tensor(blob, device)
-                if col.dim() == 2 and col.shape[1] == inc.ctx.n_limbs and col.shape[0]:
-                    inc.ctx.reduce_(col)     # a sender's words at or above p mean their residues, as at the reference's boundary
-                inc.add(idx, col)
+                # received in place: the payload goes straight into row idx of the decoder's party-major buffer (a payload of any other
+                # shape raises), its words at or above p become their residues there, as at the reference's boundary, and only then is
+                # the column announced
+                if not inc.accepts(idx):
+                    continue                 # a second message of a sender already counted (or expelled) must not touch its stored column
+                col = wire.wire_to_tensor(blob, device, out=inc.slot(idx))
+                inc.ctx.reduce_(col)
+                inc.add(idx)
         except (ValueError, TypeError, OverflowError, struct.error):
             # one Byzantine sender must not abort an honest party's open: whatever it sent, it is not a column
             logging.error("[BatchReconstructDevice] malformed column from %d dropped", idx)
@@ -89,8 +93,8 @@ async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_
     op = _encoder(p, n, t, degree, use_omega_powers, ctx.device, max(b, 1))
     c = op.chunks(b)
 
-    def make_decoder():
-        return DeviceIncrementalDecoder(p, n, t, degree=degree, batch_size=c, use_omega_powers=use_omega_powers, device=ctx.device)
+    def make_decoder(want="all"):
+        return DeviceIncrementalDecoder(p, n, t, degree=degree, batch_size=c, use_omega_powers=use_omega_powers, device=ctx.device, want=want)
 
     # R1: every chunk evaluated at the n points; row j of the party-major result is party j's message
     encoded = op.r1_encode(shares).view(n, c, ctx.n_limbs).cpu()
@@ -99,7 +103,8 @@ async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_
 
     recons_r2 = None
     try:
-        recons_r2 = await _incremental_decode_device(data_r1, make_decoder, ctx.tdev)
+        # R1 only forwards the constant terms (batch_reconstruction.py:194): the optimistic step computes nothing else
+        recons_r2 = await _incremental_decode_device(data_r1, lambda: make_decoder("constant"), ctx.tdev)
     except asyncio.CancelledError:
         # the reference falls through here with recons_r2 unbound (batch_reconstruction.py:178-183); cancelling the
         # open must cancel it: clean up and let the cancellation propagate

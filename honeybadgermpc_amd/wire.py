@@ -66,11 +66,18 @@ def tensor_to_wire(t):
     return pack_limbs(t.detach().cpu().numpy().view(np.uint64))
 
 
-def wire_to_tensor(blob, device=None):
+def wire_to_tensor(blob, device=None, out=None):
+    """bytes -> (count, limbs) int64 tensor.  out: a tensor of that shape to receive into (a row of a decoder's party-major buffer:
+    one H2D copy straight to where the kernels read it); a payload of another shape raises ValueError."""
     import torch
 
     a = unpack_limbs(blob)
     t = torch.from_numpy(a.view(np.int64).copy())
+    if out is not None:
+        if tuple(out.shape) != tuple(t.shape):
+            raise ValueError("payload does not have the receiving buffer's shape")
+        out.copy_(t, non_blocking=False)
+        return out
     return t.to(device) if device is not None else t
 
 
