@@ -250,6 +250,7 @@ struct PointTable {
     int refs;             // the cache's reference + one per probe that works on this table
     bool small;           // every point is an integer below 2^16 (the production points 1 .. n): xs holds them
     std::vector<uint16_t> xs;
+    uint16_t *xs_dev;     // ... and a device copy, made when a candidate store first needs it
 };
 int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hipStream_t s);
 // device-built images of [rows of V^-1(z) ; V[zc] V^-1(z)] (hb_quick.hip): layout of one image's buffer, its build, its launch
@@ -266,7 +267,7 @@ int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const M
 // halves (what depends on the arrivals z alone; the rows of the compared senders zc), its launch
 struct FsLayout {
     int n, d, nc, n_coef, n_out, n_rt, nkb;
-    size_t o_a8, o_crow, o_kt, o_mode, o_z, need;
+    size_t o_a8, o_crow, o_kt, o_mode, o_z, o_cand, o_cand_crow, need;      // o_cand: the per-party candidate rows (0 when the point set is too large for them)
 };
 constexpr int FS_BUILD_Z = 1, FS_BUILD_ZC = 2;
 int fs_layout(hb_ctx *ctx, const PointTable *pt, int d, int nc, int n_coef, FsLayout *L);
@@ -276,7 +277,11 @@ int fs_build(hb_ctx *ctx, const PointTable *pt, const int32_t *z, const int32_t 
 struct FsVerdict { int32_t flag, first, seq, pad; };
 struct FsDone { int32_t *counter; FsVerdict *host; int32_t seq; };
 int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov, int64_t out_count,
-              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s, const FsDone *done = nullptr);
+              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s, const FsDone *done = nullptr,
+              const int32_t *pick_zc = nullptr);
+// the compared senders' rows for EVERY party, from the first d arrivals alone (L.o_cand != 0): a launch then names its compared senders
+// (fs_launch's pick_zc) instead of waiting for a second build
+int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout &L, uint8_t *base, int32_t *status_dev, hipStream_t s);
 // the wide image of a generic matrix, built on first use (nullptr when the path does not apply)
 const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *m, hipStream_t s);
 

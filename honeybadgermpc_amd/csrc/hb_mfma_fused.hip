@@ -48,6 +48,10 @@ constexpr int FS_MAXD = 24, FS_MAXC = 104;      // terms (three K-blocks), compa
 constexpr size_t FS_LDS_LIMIT = 156 * 1024;
 
 struct FsIdx { uint16_t z[FS_MAXD], xz[FS_MAXD], zc[FS_MAXC], xzc[FS_MAXC]; };
+// the compared senders of a launch whose rows come from the per-party candidate store (k_fs_cand): rows n_coef .. n_coef + nc - 1 of the
+// matrix are the candidates of parties zc[0 .. nc)
+struct FsPick { const uint4 *cand; const uint32_t *cand_crow; int n_coef, nc; uint16_t zc[FS_MAXC]; };
+constexpr int FS_CAND_MAXN = 128;               // parties a candidate store is built for (n d 128-bit entries in the builder's LDS)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // the kernel
@@ -66,7 +70,7 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
                                                           int64_t in_count, int d, const int32_t *__restrict__ rowmode,
                                                           uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                           int32_t *__restrict__ mismatch, int32_t *__restrict__ first_bad, uint32_t *__restrict__ bad_map,
-                                                          int n_out, int n_rt, int64_t n_chunks, int64_t n_units, BarrettParams bp, const FsDone done) {
+                                                          int n_out, int n_rt, int64_t n_chunks, int64_t n_units, BarrettParams bp, const FsDone done, const FsPick pick) {
     constexpr int NT = 64 * FS_WAVES, NL = 9, NW = 8;
     extern __shared__ uint4 fs_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -89,6 +93,22 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
     for (int i = threadIdx.x; i < n_rt * NKB * 2 * 64; i += NT) abuf[i] = a8[i];
     for (int i = threadIdx.x; i < 2 * bufsz; i += NT) xbuf[i] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < MM8_FOLD_Q) foldl[threadIdx.x] = foldg[threadIdx.x];
+    if (pick.cand) {
+        // the rows of the compared senders were built per PARTY when the first d arrivals were known (k_fs_cand); which of them this
+        // launch compares, and in which row, is only known now: gather their digit pieces, row constants and compare targets
+        __syncthreads();
+        for (int e = threadIdx.x; e < pick.nc * NKB * 8; e += NT) {
+            const int j = e / (NKB * 8), pc = e - j * (NKB * 8);
+            const int ri = pick.n_coef + j, rt = ri >> 4, r16 = ri & 15, r = 4 * (r16 & 3) + (r16 >> 2);
+            const int kb = pc >> 3, grp = (pc >> 2) & 1, gg = pc & 3;
+            reinterpret_cast<uint4 *>(abuf)[((rt * NKB + kb) * 2 + grp) * 64 + r + 16 * gg] = pick.cand[(size_t)pick.zc[j] * (NKB * 8) + pc];
+        }
+        for (int e = threadIdx.x; e < pick.nc * 4; e += NT) {
+            const int j = e >> 2, q = e & 3;
+            fs_lds[(pick.n_coef + j) * 4 + q] = reinterpret_cast<const uint4 *>(pick.cand_crow)[(size_t)pick.zc[j] * 4 + q];
+        }
+        for (int j = threadIdx.x; j < pick.nc; j += NT) maskl[pick.n_coef + j] = (int32_t)pick.zc[j] + 1;
+    }
     __syncthreads();
 
     // (tile, row tile) pairs of a unit: wave w takes w, w + 8, ...; the waves with a pass less than the others scale the next
@@ -364,6 +384,40 @@ __device__ __forceinline__ size_t fs_digit_addr(int i, int l, int b, int nkb) {
     return ((((size_t)(i / 16) * nkb + l / 8) * 2 + grp) * 64 + (size_t)lane_) * 16 + 4 * (2 * hi + el) + bi;
 }
 
+// the constant of one matrix row from its d entries: (0x80..80 * sum - bias sum) mod p as eight pairs [bias of the fold's columns + word]
+__device__ __forceinline__ void fs_row_constant(const FpParams<9> &P, const FsConsts &cs, const i128 *row, int d, uint32_t *dst16) {
+    constexpr int NL = 9, NW = 8;
+    uint32_t s5[5] = {0, 0, 0, 0, 0};                   // the row sum in 160 bits two's complement
+    for (int l = 0; l < d; l++) {
+        const i128 v = row[l];
+        const uint32_t vw[5] = {(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)(v >> 64), (uint32_t)(v >> 96), (uint32_t)(v >> 127 >> 1)};
+        unsigned cy = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) s5[k] = __builtin_addc(s5[k], vw[k], cy, &cy);
+    }
+    const bool negs = (s5[4] >> 31) != 0;
+    if (negs) {
+        unsigned cy = 1;
+#pragma unroll
+        for (int k = 0; k < 5; k++) s5[k] = __builtin_addc(~s5[k], 0u, cy, &cy);
+    }
+    uint32_t w8[NW] = {s5[0], s5[1], s5[2], s5[3], s5[4], 0, 0, 0}, fe[NL], prod[NL], corr[NL], k80[NL], bm[NL];
+    unpack<NL, NW>(fe, w8);
+    if (negs) fp_neg(fe, fe, P);
+#pragma unroll
+    for (int k = 0; k < NL; k++) { k80[k] = cs.c80r[k]; bm[k] = cs.biasmod[k]; }
+    mont_mul(prod, fe, k80, P);
+    fp_sub(corr, prod, bm, P);
+    uint32_t cw[NW];
+    pack<NL, NW>(cw, corr);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint64_t pair = (uint64_t)cw[k] + ((0x1010ull << 32) | 0x10100000ull);
+        dst16[2 * k] = (uint32_t)pair;
+        dst16[2 * k + 1] = (uint32_t)(pair >> 32);
+    }
+}
+
 // One workgroup of 1024.  Roles of the first phase:
 //   wave 0        A(X) = prod_q (X - x_zq) over the integers (coefficient t on lane t), then per arrival j the coefficients of
 //                 A_j = A / (X - x_zj) by synthetic division                                                    [Z]
@@ -469,38 +523,7 @@ __global__ void __launch_bounds__(1024) k_fs_build(const FpParams<9> P, const ui
         if (carry != (negv ? 1 : 0) && status) atomicOr(status, FS_OVERFLOW);
     }
     // ---- row constants: (0x80..80 * sum_l M[i][l] - bias sum) mod p as eight pairs [bias of the fold's columns + word] --------
-    for (int i = tid + row_lo; i < row_hi; i += 1024) {
-        // the row sum in 160 bits two's complement
-        uint32_t s5[5] = {0, 0, 0, 0, 0};
-        for (int l = 0; l < d; l++) {
-            const i128 v = ent[(size_t)i * d + l];
-            const uint32_t vw[5] = {(uint32_t)v, (uint32_t)(v >> 32), (uint32_t)(v >> 64), (uint32_t)(v >> 96), (uint32_t)(v >> 127 >> 1)};
-            unsigned cy = 0;
-#pragma unroll
-            for (int k = 0; k < 5; k++) s5[k] = __builtin_addc(s5[k], vw[k], cy, &cy);
-        }
-        const bool negs = (s5[4] >> 31) != 0;
-        if (negs) {
-            unsigned cy = 1;
-#pragma unroll
-            for (int k = 0; k < 5; k++) s5[k] = __builtin_addc(~s5[k], 0u, cy, &cy);
-        }
-        uint32_t w8[NW] = {s5[0], s5[1], s5[2], s5[3], s5[4], 0, 0, 0}, fe[NL], prod[NL], corr[NL], k80[NL], bm[NL];
-        unpack<NL, NW>(fe, w8);
-        if (negs) fp_neg(fe, fe, P);
-#pragma unroll
-        for (int k = 0; k < NL; k++) { k80[k] = cs.c80r[k]; bm[k] = cs.biasmod[k]; }
-        mont_mul(prod, fe, k80, P);
-        fp_sub(corr, prod, bm, P);
-        uint32_t cw[NW];
-        pack<NL, NW>(cw, corr);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint64_t pair = (uint64_t)cw[k] + ((0x1010ull << 32) | 0x10100000ull);
-            crow[(size_t)i * 16 + 2 * k] = (uint32_t)pair;
-            crow[(size_t)i * 16 + 2 * k + 1] = (uint32_t)(pair >> 32);
-        }
-    }
+    for (int i = tid + row_lo; i < row_hi; i += 1024) fs_row_constant(P, cs, ent + (size_t)i * d, d, crow + (size_t)i * 16);
     if (do_zc)
         for (int i = tid; i < nc; i += 1024) rowmode[n_coef + i] = (int32_t)ix.zc[i] + 1;
     if (do_z) {
@@ -515,6 +538,43 @@ __global__ void __launch_bounds__(1024) k_fs_build(const FpParams<9> P, const ui
             for (int k = 0; k < NL; k++) KT[((size_t)l * NL + q) * NL + k] = tq[k];
         }
     }
+}
+
+// The rows of the compared senders before anybody knows who they will be: P[i][j] = prod_{q != j} (x_i - x_zq) for EVERY party i, its 16
+// digits per entry laid out as the 8 NKB sixteen-byte pieces a row occupies in the image, and its row constant -- a candidate store
+// indexed by party (k_mm8f gathers the rows it compares in its prologue: FsPick).  Depends on the first d arrivals alone.
+__global__ void __launch_bounds__(1024) k_fs_cand(const FpParams<9> P, int n, const uint16_t *__restrict__ xs, const FsIdx ix, int d, const FsConsts cs,
+                                                  uint8_t *__restrict__ cand, uint32_t *__restrict__ cand_crow, int32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fc_lds[];
+    i128 *ent = reinterpret_cast<i128 *>(fc_lds);                      // [n][d]
+    const int tid = threadIdx.x, nkb = (d + 7) / 8;
+    const size_t row_bytes = (size_t)nkb * 8 * 16;
+    for (size_t i = tid; i < (size_t)n * row_bytes / 16; i += 1024) reinterpret_cast<uint4 *>(cand)[i] = make_uint4(0, 0, 0, 0);
+    for (int e = tid; e < n * d; e += 1024) {
+        const int i = e / d, j = e - i * d;
+        const int64_t xi = xs[i];
+        i128 v = 1;
+        for (int q = 0; q < d; q++)
+            if (q != j) v *= (i128)(xi - (int64_t)ix.xz[q]);
+        ent[e] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * d; e += 1024) {
+        const int i = e / d, l = e - i * d;
+        const i128 v = ent[e];
+        const bool negv = v < 0;
+        const int kb = l >> 3, gg = (l & 7) >> 1, el = l & 1;
+        int carry = 0;
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            int t = (int)((uint32_t)(v >> (8 * b)) & 0xffu) + carry;
+            if (t > 127) { t -= 256; carry = 1; } else carry = 0;
+            const int grp = b >> 3, r7 = 7 - (b & 7), hi = r7 >> 2, bi = r7 & 3;
+            cand[(size_t)i * row_bytes + (size_t)(((kb * 2 + grp) * 4 + gg) * 16) + 4 * (2 * hi + el) + bi] = (uint8_t)(int8_t)t;
+        }
+        if (carry != (negv ? 1 : 0) && status) atomicOr(status, FS_OVERFLOW);
+    }
+    for (int i = tid; i < n; i += 1024) fs_row_constant(P, cs, ent + (size_t)i * d, d, cand_crow + (size_t)i * 16);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -557,6 +617,12 @@ int fs_layout(hb_ctx *ctx, const PointTable *pt, int d, int nc, int n_coef, FsLa
     L->o_mode = L->o_kt + al((size_t)d * 81 * 4);
     L->o_z = L->o_mode + al((size_t)L->n_rt * 16 * 4);
     L->need = L->o_z + al((size_t)FS_MAXD * 4);
+    L->o_cand = L->o_cand_crow = 0;
+    if (pt->n <= FS_CAND_MAXN && nc > 0) {
+        L->o_cand = L->need;
+        L->o_cand_crow = L->o_cand + al((size_t)pt->n * L->nkb * 8 * 16);
+        L->need = L->o_cand_crow + al((size_t)pt->n * 16 * 4);
+    }
     return HB_OK;
 }
 
@@ -590,13 +656,41 @@ int fs_build(hb_ctx *ctx, const PointTable *pt, const int32_t *z, const int32_t 
     return HB_OK;
 }
 
+int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout &L, uint8_t *base, int32_t *status_dev, hipStream_t s) {
+    if (!L.o_cand) return fail(ctx, HB_ERR_BAD_ARG, "fused decode: no candidate store in this layout");
+    if (!pt->xs_dev) {
+        HB_HIP(ctx, hipMalloc(&pt->xs_dev, (size_t)pt->n * 2));
+        int rc = upload_table(ctx, pt->xs_dev, pt->xs.data(), (size_t)pt->n * 2, s);      // (synchronises; once per point set)
+        if (rc) { (void)hipFree(pt->xs_dev); pt->xs_dev = nullptr; return rc; }
+    }
+    FsIdx ix;
+    memset(&ix, 0, sizeof ix);
+    for (int i = 0; i < L.d; i++) { ix.z[i] = (uint16_t)z[i]; ix.xz[i] = pt->xs[z[i]]; }
+    const Mm8Shared *sh = nullptr;
+    int rc = mm8_shared(ctx, &sh, s); if (rc) return rc;
+    FsConsts cs;
+    memcpy(cs.c80r, sh->c80r, sizeof cs.c80r);
+    memcpy(cs.biasmod, sh->biasmod, sizeof cs.biasmod);
+    k_fs_cand<<<1, 1024, (size_t)pt->n * L.d * 16, s>>>(ctx->pw, pt->n, pt->xs_dev, ix, L.d, cs, base + L.o_cand, (uint32_t *)(base + L.o_cand_crow), status_dev);
+    HB_LAUNCH_CHECK(ctx);
+    return HB_OK;
+}
+
 // the launch over a built image: rows with a store mode go to `out` (view ov, clipped at out_count), rows with a compare mode are
 // checked against the rows of `cols` they name
 int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov, int64_t out_count,
-              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s, const FsDone *done_p) {
+              int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s, const FsDone *done_p, const int32_t *pick_zc) {
     FsDone done;
     memset(&done, 0, sizeof done);
     if (done_p) done = *done_p;
+    FsPick pick;
+    memset(&pick, 0, sizeof pick);
+    if (pick_zc) {
+        if (!L.o_cand) return fail(ctx, HB_ERR_BAD_ARG, "fused decode: no candidate store to pick from");
+        pick.cand = (const uint4 *)(base + L.o_cand); pick.cand_crow = (const uint32_t *)(base + L.o_cand_crow);
+        pick.n_coef = L.n_coef; pick.nc = L.nc;
+        for (int j = 0; j < L.nc; j++) pick.zc[j] = (uint16_t)pick_zc[j];
+    }
     if (C <= 0) return HB_OK;
     const Mm8Shared *sh = nullptr;
     int rc = mm8_shared(ctx, &sh, s); if (rc) return rc;
@@ -610,7 +704,7 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
         if (!attr_done) { HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8f<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
         k_mm8f<NKB><<<dim3((unsigned)blocks), dim3(64 * FS_WAVES), lds, s>>>((const int4 *)(base + L.o_a8), (const uint32_t *)(base + L.o_crow), sh->fold_dev,        \
             (const uint32_t *)(base + L.o_kt), ctx->psc, cols, cv.stride_c, cv.stride_l, (const int32_t *)(base + L.o_z), INT64_MAX, L.d, (const int32_t *)(base + L.o_mode), \
-            out, ov.stride_c, ov.stride_l, out_count, mismatch_dev, first_bad_dev, bad_map_dev, L.n_out, L.n_rt, C, n_units, sh->bp, done); \
+            out, ov.stride_c, ov.stride_l, out_count, mismatch_dev, first_bad_dev, bad_map_dev, L.n_out, L.n_rt, C, n_units, sh->bp, done, pick); \
     } while (0)
     switch (L.nkb) {
         case 1: FS_LAUNCH(1); break;

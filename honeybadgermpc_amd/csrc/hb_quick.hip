@@ -608,6 +608,7 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
 static void point_table_unref(PointTable *pt) {
     if (!pt || --pt->refs > 0) return;
     (void)hipFree(pt->xm); (void)hipFree(pt->inv); (void)hipFree(pt->pw);
+    if (pt->xs_dev) (void)hipFree(pt->xs_dev);
     delete pt;
 }
 
@@ -619,7 +620,7 @@ int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hi
     auto it = ctx->ptcache.find(key);
     if (it != ctx->ptcache.end()) { cache_touch(ctx, "pt|" + key); *out = static_cast<PointTable *>(it->second); return HB_OK; }
     PointTable *pt = new PointTable();
-    pt->n = n; pt->S = n + 2; pt->xm = pt->inv = pt->pw = nullptr; pt->usable = false; pt->refs = 1;
+    pt->n = n; pt->S = n + 2; pt->xm = pt->inv = pt->pw = nullptr; pt->usable = false; pt->refs = 1; pt->xs_dev = nullptr;
     pt->small = ctx->n_limbs == 4;
     for (int i = 0; i < n && pt->small; i++) {
         const uint64_t *e = x_host + (size_t)i * 4;
@@ -899,6 +900,7 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
         qd->cap = L.need;
     }
     rc = fs_build(ctx, qd->pt, z, nullptr, L, qd->buf, FS_BUILD_Z, qd->status, s); if (rc) return rc;
+    if (L.o_cand && nc > 0) { rc = fs_build_cand(ctx, qd->pt, z, L, qd->buf, qd->status, s); if (rc) return rc; }
     qd->L = L;
     qd->z.assign(z, z + d);
     qd->prepared = true;
@@ -913,13 +915,24 @@ static int quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const u
     hipStream_t s = (hipStream_t)stream;
     const FsLayout &L = qd->L;
     int rc = HB_OK;
-    if (nc > 0) { rc = fs_build(ctx, qd->pt, qd->z.data(), zc, L, qd->buf, FS_BUILD_ZC, qd->status, s); if (rc) return rc; }
+    const bool picked = L.o_cand != 0 && nc > 0;          // the compared senders' rows are waiting in the candidate store
+    if (nc > 0 && !picked) { rc = fs_build(ctx, qd->pt, qd->z.data(), zc, L, qd->buf, FS_BUILD_ZC, qd->status, s); if (rc) return rc; }
+    if (picked) {
+        uint64_t seen[4] = {0, 0, 0, 0};                   // (a candidate store exists for at most 128 parties)
+        for (int v : qd->z) seen[v >> 6] |= 1ull << (v & 63);
+        for (int j = 0; j < nc; j++) {
+            const int v = zc[j];
+            if (v < 0 || v >= qd->n || (seen[v >> 6] >> (v & 63) & 1)) return fail(ctx, HB_ERR_BAD_ARG, "quick decoder: compared indices");
+            seen[v >> 6] |= 1ull << (v & 63);
+        }
+    }
     const int64_t cnt = chunk_hi - chunk_lo;
     hb_view pm{1, C}, ov = L.n_coef == 1 ? hb_view{1, C} : hb_view{L.d, 1};
     const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
     uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * L.n_coef * 8 : nullptr;
     FsDone done{qd->status + 2, qd->res_dev, qd->seq + 1};
-    rc = fs_launch(ctx, L, qd->buf, in, pm, out, ov, coeffs_dev ? (L.n_coef == 1 ? cnt : cnt * (int64_t)L.d) : 0, qd->status, qd->status + 1, nullptr, cnt, s, &done);
+    rc = fs_launch(ctx, L, qd->buf, in, pm, out, ov, coeffs_dev ? (L.n_coef == 1 ? cnt : cnt * (int64_t)L.d) : 0, qd->status, qd->status + 1, nullptr, cnt, s, &done,
+                   picked ? zc : nullptr);
     if (rc) return rc;
     qd->seq += 1;
     qd->prepared = false;                      // one verdict per set of arrivals

@@ -60,6 +60,7 @@ def _codewords(rnd, x, d, c, p):
     (P, list(range(1, 8)), 3, 70),                        # d = 4: the smallest shape
     (P, list(range(1, 41)), 12, 200),                     # d = 13: two K-blocks
     (P, [3, 50, 7, 19, 200, 101, 64, 1, 999, 12, 77, 5, 31, 444, 2, 650], 4, 129),     # distinct small integers in no order
+    (P, list(range(1, 201)), 4, 150),                     # more than 128 parties: no candidate store, the compared rows are built at the end
     (SECP_N, list(range(1, 33)), 10, 900),                # p > 2^255: the scaled element is made canonical before it is packed
     ((1 << 255) + 95, list(range(1, 25)), 5, 257),
 ])
