@@ -259,7 +259,8 @@ struct QuickLayout {
     size_t o_a8, o_crow, o_wj, o_full, o_nraw, o_mcan, o_z, o_map, need;
 };
 int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L);
-int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s);
+int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s,
+                int flags = 3 /* 1: what depends on z alone, 2: the compared senders' rows */);
 int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const Mm8wShared *sh, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov,
                  int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s, uint32_t *bad_map_dev = nullptr);
 // decode + validate at small-integer points on the small-entry kernel with the 1 / den_j scaling inside (hb_mfma_fused.hip):

@@ -117,11 +117,33 @@ __global__ void k_pt_inv(const FpParams<NL> P, const uint32_t *__restrict__ xm, 
 template <int NL>
 __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ inv, int n,
                                                       const QuickIdx ix, int d, int nc, int n_coef, uint32_t *__restrict__ wj, uint32_t *__restrict__ full,
-                                                      uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap) {
+                                                      uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap, int flags) {
     extern __shared__ uint32_t q_lds[];
     uint32_t *Ac = q_lds;                               // [(d + 1)][NL]
     const int tid = threadIdx.x;
     const bool one_wave = d <= 63;
+    // flags: QUICK_Z -- what depends on the arrivals z alone (A, the N_j, the w_j, the row map of the coefficient rows); QUICK_ZC -- the
+    // compared senders' full_i and their rows of the map.  A decoder builds the first half when its (degree+1)-th column lands.
+    const bool do_z = flags & 1, do_zc = flags & 2;
+    if (!do_z) {
+        if (tid >= 256) {
+            const int i = tid - 256;
+            for (int r = i; r < nc; r += 256) fmap[n_coef + r] = (int32_t)ix.zc[r] + 1;
+            if (i < nc) {
+                uint32_t xi[NL], f[NL];
+                ldg<NL>(xi, xm + (size_t)ix.zc[i] * NL);
+                fp_set(f, P.one);
+                for (int q = 0; q < d; q++) {
+                    uint32_t xq[NL], df[NL];
+                    ldg<NL>(xq, xm + (size_t)ix.z[q] * NL);
+                    fp_sub(df, xi, xq, P);
+                    mont_mul(f, f, df, P);
+                }
+                stg<NL>(full + (size_t)i * NL, f);
+            }
+        }
+        return;
+    }
     // ---- A(X): coefficient t on thread t < 128 (d <= 127 ... the d-th on thread d) -------------------------------------
     if (tid <= d && tid < 128 + 1) {
         uint32_t v[NL];
@@ -211,8 +233,8 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
     } else {
         const int i = tid - 256;
         if (i < d) z_dev[i] = ix.z[i];
-        for (int r = i; r <= n_coef + nc; r += 256) fmap[r] = (r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0;
-        if (i < nc) {
+        for (int r = i; r <= n_coef + nc; r += 256) fmap[r] = (do_zc && r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0;
+        if (do_zc && i < nc) {
             uint32_t xi[NL], f[NL];
             ldg<NL>(xi, xm + (size_t)ix.zc[i] * NL);
             fp_set(f, P.one);
@@ -231,11 +253,10 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
 // (the layout of mm8w_from_host, hb_mfma_wide.hip)
 __global__ void k_quick_image(const FpParams<9> P, const uint32_t *__restrict__ inv, int n, const QuickIdx ix, int d, int nc, int n_coef,
                               const uint32_t *__restrict__ wj, const uint32_t *__restrict__ full, const uint32_t *__restrict__ nraw,
-                              uint32_t *__restrict__ mcan, uint8_t *__restrict__ a8, int tile_rows, int nkb) {
+                              uint32_t *__restrict__ mcan, uint8_t *__restrict__ a8, int tile_rows, int nkb, int row_lo, int row_hi) {
     constexpr int NL = 9, NW = 8;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n_out = n_coef + nc;
-    if (e >= n_out * d) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x + row_lo * d;
+    if (e >= row_hi * d) return;
     const int i = e / d, l = e - i * d;
     uint32_t w[NL], v[NL];
     ldg<NL>(w, wj + (size_t)l * NL);
@@ -269,11 +290,11 @@ __global__ void k_quick_image(const FpParams<9> P, const uint32_t *__restrict__ 
 // per row: the constant that takes the XOR-0x80 input bias and the accumulator bias back out,
 // (0x80..80 * sum_l M[i][l] - bias * sum_c 2^(8c)) mod p, as 9 digits in the kernel's row-constant slot
 struct QuickRowConst { uint32_t c80r[9], biasmod[9]; };
-__global__ void k_quick_rows(const FpParams<9> P, const uint32_t *__restrict__ mcan, int n_out, int d, const QuickRowConst rc,
+__global__ void k_quick_rows(const FpParams<9> P, const uint32_t *__restrict__ mcan, int row_lo, int row_hi, int d, const QuickRowConst rc,
                              uint32_t *__restrict__ crow, int tile_rows) {
     constexpr int NL = 9, NW = 8;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_out) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x + row_lo;
+    if (i >= row_hi) return;
     uint32_t sum[NL];
 #pragma unroll
     for (int q = 0; q < NL; q++) sum[q] = 0;
@@ -728,32 +749,39 @@ int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L) 
 }
 
 // enqueue the build of that image into `base` (L.need bytes, the caller's): a memset and three small kernels, nothing waited for
-int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s) {
+int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s, int flags) {
     const int n = L.n, d = L.d, nc = L.nc;
+    const bool do_z = flags & 1, do_zc = flags & 2;
     std::vector<uint8_t> seen((size_t)n, 0);
     for (int i = 0; i < d; i++) { if (z[i] < 0 || z[i] >= n || seen[z[i]]) return fail(ctx, HB_ERR_BAD_ARG, "quick: arrival indices"); seen[z[i]] = 1; }
-    for (int j = 0; j < nc; j++) { if (zc[j] < 0 || zc[j] >= n || seen[zc[j]]) return fail(ctx, HB_ERR_BAD_ARG, "quick: compared indices"); seen[zc[j]] = 1; }
+    if (do_zc)
+        for (int j = 0; j < nc; j++) { if (zc[j] < 0 || zc[j] >= n || seen[zc[j]]) return fail(ctx, HB_ERR_BAD_ARG, "quick: compared indices"); seen[zc[j]] = 1; }
     PointTable *pt = nullptr;
     int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
     if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: repeated points");
     const Mm8wShared *sh = nullptr;
     rc = mm8w_shared(ctx, d, &sh, s); if (rc) return rc;
     *shared = sh;
-    HB_HIP(ctx, hipMemsetAsync(base, 0, L.o_wj, s));                    // image and row constants: padding rows / terms are zero
+    if (do_z) HB_HIP(ctx, hipMemsetAsync(base, 0, L.o_wj, s));          // image and row constants: padding rows / terms are zero
     QuickIdx ix;
     memset(&ix, 0, sizeof ix);
     for (int i = 0; i < d; i++) ix.z[i] = (uint16_t)z[i];
-    for (int j = 0; j < nc; j++) ix.zc[j] = (uint16_t)zc[j];
+    if (do_zc) for (int j = 0; j < nc; j++) ix.zc[j] = (uint16_t)zc[j];
     uint32_t *wj = (uint32_t *)(base + L.o_wj), *full = (uint32_t *)(base + L.o_full), *nraw = (uint32_t *)(base + L.o_nraw), *mcan = (uint32_t *)(base + L.o_mcan);
-    k_quick_matrix<9><<<1, 512, (size_t)(d + 2) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map));
+    // the rows this call owns: the coefficient rows with the first half, the compared senders' rows with the second
+    const int row_lo = do_z ? 0 : L.n_coef, row_hi = do_zc ? L.n_out : L.n_coef;
+    if (do_z || nc > 0)
+        k_quick_matrix<9><<<1, 512, (size_t)(d + 2) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map), flags);
     HB_LAUNCH_CHECK(ctx);
-    k_quick_image<<<(unsigned)((L.n_out * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, mcan, base + L.o_a8, L.tile_rows, L.nkb);
-    HB_LAUNCH_CHECK(ctx);
-    QuickRowConst rcs;
-    memcpy(rcs.c80r, sh->c80r, sizeof rcs.c80r);
-    memcpy(rcs.biasmod, sh->biasmod, sizeof rcs.biasmod);
-    k_quick_rows<<<(unsigned)((L.n_out + 63) / 64), 64, 0, s>>>(ctx->pw, mcan, L.n_out, d, rcs, (uint32_t *)(base + L.o_crow), L.tile_rows);
-    HB_LAUNCH_CHECK(ctx);
+    if (row_hi > row_lo) {
+        k_quick_image<<<(unsigned)(((row_hi - row_lo) * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, mcan, base + L.o_a8, L.tile_rows, L.nkb, row_lo, row_hi);
+        HB_LAUNCH_CHECK(ctx);
+        QuickRowConst rcs;
+        memcpy(rcs.c80r, sh->c80r, sizeof rcs.c80r);
+        memcpy(rcs.biasmod, sh->biasmod, sizeof rcs.biasmod);
+        k_quick_rows<<<(unsigned)((row_hi - row_lo + 63) / 64), 64, 0, s>>>(ctx->pw, mcan, row_lo, row_hi, d, rcs, (uint32_t *)(base + L.o_crow), L.tile_rows);
+        HB_LAUNCH_CHECK(ctx);
+    }
     return HB_OK;
 }
 
@@ -838,10 +866,25 @@ int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const 
 
 }  // extern "C"
 
+// the verdict of a launch that cannot hand it over itself (the full-size kernel): status words -> pinned record, sequence number last
+__global__ void k_publish_verdict(int32_t *status, FsVerdict *host, int seq) {
+    const int32_t fl = status[0], fb = status[1];
+    status[0] = 0;
+    status[1] = INT32_MAX;
+    host->flag = fl;
+    host->first = fb;
+    __threadfence_system();
+    *reinterpret_cast<volatile int32_t *>(&host->seq) = seq;
+}
+
 struct hb_quick_dec {
     hb_ctx *ctx;
     int n;
     PointTable *pt;
+    bool wide;                    // this set of arrivals goes through the full-size kernel (points that are not small integers, shapes hb_mfma_fused.hip does not take)
+    QuickLayout Q;
+    const Mm8wShared *qsh;
+    std::vector<uint64_t> x;      // the points (the full-size builder looks its tables up by them)
     FsLayout L;
     uint8_t *buf;
     size_t cap;
@@ -862,9 +905,10 @@ int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec
     cache_trim(ctx);
     PointTable *pt = nullptr;
     int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
-    if (!pt->usable || !pt->small) return fail(ctx, HB_ERR_UNSUPPORTED, "quick decoder: the points are not distinct small integers");
+    if (!pt->usable) return fail(ctx, HB_ERR_UNSUPPORTED, "quick decoder: repeated points");
+    if (n > 65535) return fail(ctx, HB_ERR_UNSUPPORTED, "quick decoder: more than 65535 points");
     hb_quick_dec *qd = new hb_quick_dec();
-    qd->ctx = ctx; qd->n = n; qd->pt = pt; qd->buf = nullptr; qd->cap = 0; qd->status = nullptr; qd->res_host = qd->res_dev = nullptr; qd->seq = 0; qd->prepared = false;
+    qd->ctx = ctx; qd->n = n; qd->pt = pt; qd->wide = false; qd->qsh = nullptr; qd->x.assign(x_host, x_host + (size_t)n * 4); qd->buf = nullptr; qd->cap = 0; qd->status = nullptr; qd->res_host = qd->res_dev = nullptr; qd->seq = 0; qd->prepared = false;
     const int32_t init[4] = {0, INT32_MAX, 0, 0};
     hipError_t e = hipMalloc(&qd->status, sizeof init);
     if (e == hipSuccess) e = hipMemcpyAsync(qd->status, init, sizeof init, hipMemcpyHostToDevice, s);
@@ -891,7 +935,25 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
     qd->prepared = false;
     FsLayout L;
     int rc = fs_layout(ctx, qd->pt, d, nc, n_coef, &L);
-    if (rc) return fail(ctx, rc, "quick decoder: shape");
+    if (rc) {
+        // not a small-integer shape: the full-size kernel's image, built in the same two halves (hb_quick_interp_check's builder)
+        QuickLayout Q;
+        rc = quick_layout(ctx, qd->n, d, nc, n_coef, &Q);
+        if (rc) return rc;
+        if (qd->cap < Q.need) {
+            if (qd->buf) { HB_HIP(ctx, hipStreamSynchronize(s)); HB_HIP(ctx, hipFree(qd->buf)); }
+            qd->buf = nullptr; qd->cap = 0;
+            HB_HIP(ctx, hipMalloc(&qd->buf, Q.need));
+            qd->cap = Q.need;
+        }
+        rc = quick_build(ctx, qd->x.data(), z, nullptr, Q, qd->buf, &qd->qsh, s, 1); if (rc) return rc;
+        qd->Q = Q;
+        qd->wide = true;
+        qd->z.assign(z, z + d);
+        qd->prepared = true;
+        return HB_OK;
+    }
+    qd->wide = false;
     if (qd->cap < L.need) {
         // (a launch of this decoder may still read the old buffer: decide() waits for its verdict, so only an abandoned one can)
         if (qd->buf) { HB_HIP(ctx, hipStreamSynchronize(s)); HB_HIP(ctx, hipFree(qd->buf)); }
@@ -910,9 +972,27 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
 // the enqueue half of decide, under the context's mutex
 static int quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
                             uint64_t *coeffs_dev, void *stream, int *seq_out) { HB_API_GUARD((qd ? qd->ctx : nullptr));
-    if (!qd || !qd->prepared || nc != qd->L.nc || (nc > 0 && !zc) || !cols_dev || C < 1 || chunk_lo < 0 || chunk_hi > C || chunk_lo >= chunk_hi) return HB_ERR_BAD_ARG;
+    if (!qd || !qd->prepared || nc != (qd->wide ? qd->Q.nc : qd->L.nc) || (nc > 0 && !zc) || !cols_dev || C < 1 || chunk_lo < 0 || chunk_hi > C || chunk_lo >= chunk_hi) return HB_ERR_BAD_ARG;
     hb_ctx *ctx = qd->ctx;
     hipStream_t s = (hipStream_t)stream;
+    if (qd->wide) {
+        const QuickLayout &Q = qd->Q;
+        int rc = HB_OK;
+        if (nc > 0) { rc = quick_build(ctx, qd->x.data(), qd->z.data(), zc, Q, qd->buf, &qd->qsh, s, 2); if (rc) return rc; }
+        const int64_t cnt = chunk_hi - chunk_lo;
+        hb_view pm{1, C}, ov = Q.n_coef == 1 ? hb_view{1, C} : hb_view{Q.d, 1};
+        const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
+        uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * Q.n_coef * 8 : (uint32_t *)(qd->buf + Q.o_mcan);
+        rc = quick_launch(ctx, Q, qd->buf, qd->qsh, in, pm, out, ov, coeffs_dev ? (Q.n_coef == 1 ? cnt : cnt * (int64_t)Q.d) : 0, coeffs_dev ? Q.n_coef : 0,
+                          qd->status, qd->status + 1, cnt, s, nullptr);
+        if (rc) return rc;
+        k_publish_verdict<<<1, 1, 0, s>>>(qd->status, qd->res_dev, qd->seq + 1);
+        HB_LAUNCH_CHECK(ctx);
+        qd->seq += 1;
+        qd->prepared = false;
+        *seq_out = qd->seq;
+        return HB_OK;
+    }
     const FsLayout &L = qd->L;
     int rc = HB_OK;
     const bool picked = L.o_cand != 0 && nc > 0;          // the compared senders' rows are waiting in the candidate store

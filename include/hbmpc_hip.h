@@ -137,14 +137,16 @@ int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const 
                               const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi, uint64_t *coeffs_dev, int32_t *status_dev,
                               uint32_t *bad_map_dev, void *stream);
 
-/* The optimistic step of ONE IncrementalDecoder (reed_solomon.py:305-330) in two halves, for points that are small integers (the
- * production points 1 .. n) on wide contexts: what depends on the first d arrivals alone is built when the d-th column lands
+/* The optimistic step of ONE IncrementalDecoder (reed_solomon.py:305-330) in two halves, on wide contexts (points that are small
+ * integers -- the production points 1 .. n -- on the small-entry kernel, hb_mfma_fused.hip; any other point set on the full-size one
+ * with hb_quick_interp_check's device-built image): what depends on the first d arrivals alone is built when the d-th column lands
  * (hb_quick_dec_arrivals: enqueued, nothing waited for), and when the last column lands hb_quick_dec_decide builds the rows of the
  * compared senders, launches decode + validate (hb_mfma_fused.hip) over chunks [chunk_lo, chunk_hi) of the party-major buffer and
  * WAITS for the verdict, which the kernel hands over in pinned memory: *flag != 0 -- some compared column disagrees, *first = the
  * first disagreeing chunk - chunk_lo (INT32_MAX when none).  n_coef = d: all coefficients go chunk-major to coeffs_dev ((C, d)
  * elements); n_coef = 1: only the constant terms, to coeffs_dev[0 .. C) (what R1 forwards, batch_reconstruction.py:194).
- * HB_ERR_UNSUPPORTED from _create / _arrivals: the shape is not this kernel's; use hb_quick_interp_check. */
+ * HB_ERR_UNSUPPORTED from _create / _arrivals (narrow contexts, repeated points, fewer than 4 coefficients, more than 128, moduli
+ * outside the matrix-core kernels' range): use an open plan. */
 typedef struct hb_quick_dec hb_quick_dec;
 int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec **out, void *stream);
 int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int n_coef, void *stream);

@@ -54,7 +54,18 @@ def _codewords(rnd, x, d, c, p):
     return polys, [enc[k][j] for j in range(len(x)) for k in range(c)]
 
 
+def _omega_points(n):
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+
+    point = EvalPoint(GF(P), n, use_omega_powers=True)
+    return [point(i).value for i in range(n)]
+
+
 @pytest.mark.parametrize("p,x,t,c", [
+    (P, "omega64", 21, 600),                              # omega points: full-size entries -- the same two halves on the full-size kernel
+    (P, "omega256", 85, 260),
+    (P, list(range(1, 101)), 33, 300),                    # 100^33 does not fit 16 digits: the full-size kernel too
     (P, list(range(1, 65)), 21, 1500),                    # config 3's shape: 43 rows = three row tiles, 12 passes for 8 waves
     (P, list(range(1, 17)), 5, 333),                      # one row tile: four passes, four waves only scale
     (P, list(range(1, 8)), 3, 70),                        # d = 4: the smallest shape
@@ -69,6 +80,8 @@ def test_quick_dec_vs_oracle(p, x, t, c):
 
     if pow(2, p - 1, p) != 1:
         pytest.skip("not a prime")
+    if isinstance(x, str):
+        x = _omega_points(int(x[5:]))
     ctx = Context.get(p)
     rnd = random.Random(len(x) * 1000 + t)
     n, d = len(x), t + 1
@@ -133,32 +146,30 @@ def test_quick_dec_vs_oracle(p, x, t, c):
 
 
 def test_quick_dec_says_what_it_does_not_take():
-    from honeybadgermpc_amd._capi import HB_ERR_BAD_ARG, HB_ERR_UNSUPPORTED, HB_OK, Context
-    from honeybadgermpc_amd.field import GF
-    from honeybadgermpc_amd.polynomial import EvalPoint
+    from honeybadgermpc_amd._capi import HB_ERR_BAD_ARG, HB_ERR_UNSUPPORTED, HB_OK, Context, np_ptr
 
     ctx = Context.get(P)
-    point = EvalPoint(GF(P), 64, use_omega_powers=True)
-    qd = _QDec(ctx, [point(i).value for i in range(64)])          # omega powers: full-size residues
-    assert qd.rc == HB_ERR_UNSUPPORTED
     qd = _QDec(ctx, list(range(1, 101)))
     assert qd.rc == HB_OK
-    assert qd.arrivals(list(range(34)), 33, 34) == HB_ERR_UNSUPPORTED          # 100^33 does not fit 16 digits: the full-size kernel's
-    assert qd.arrivals(list(range(22)), 21, 22) == HB_ERR_UNSUPPORTED          # bounds: 99 * 99 * 98 * ... over 21 factors exceeds 2^124.5
+    assert qd.arrivals(list(range(34)), 33, 34) == HB_OK                       # (the full-size kernel: 100^33 does not fit 16 digits)
+    assert qd.arrivals([0, 1, 2], 2, 3) == HB_ERR_UNSUPPORTED                  # fewer than four coefficients: neither kernel
     assert qd.arrivals([0, 1, 2, 2], 3, 4) == HB_ERR_BAD_ARG                   # a repeated arrival
     assert qd.arrivals([0, 1, 2, 3], 2, 4) == HB_OK
     import torch
 
     cols = ctx.upload_ints([1] * 100 * 8)
     zc = np.array([2, 9], dtype=np.int32)                                       # overlaps the arrivals
-    from honeybadgermpc_amd._capi import np_ptr
-
     flag, first = ctypes.c_int32(0), ctypes.c_int32(0)
     out = ctx.empty(8 * 4)
     rc = ctx.lib.hb_quick_dec_decide(qd.h, np_ptr(zc), 2, ctx.ptr(cols), 8, 0, 8, ctx.ptr(out), ctypes.byref(flag), ctypes.byref(first), ctx.stream())
     assert rc == HB_ERR_BAD_ARG
+    zc = np.array([7, 9, 11], dtype=np.int32)                                   # not the number of compared senders announced
+    assert qd.arrivals([0, 1, 2, 3], 2, 4) == HB_OK
+    rc = ctx.lib.hb_quick_dec_decide(qd.h, np_ptr(zc), 3, ctx.ptr(cols), 8, 0, 8, ctx.ptr(out), ctypes.byref(flag), ctypes.byref(first), ctx.stream())
+    assert rc == HB_ERR_BAD_ARG
     torch.cuda.synchronize()
     qd.close()
+    assert _QDec(ctx, [1, 2, 3, 3, 5, 6, 7, 8]).rc == HB_ERR_UNSUPPORTED        # repeated points
     narrow = Context.get((1 << 61) - 1)
     assert _QDec(narrow, list(range(1, 9))).rc == HB_ERR_UNSUPPORTED
 
