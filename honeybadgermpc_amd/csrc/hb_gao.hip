@@ -94,6 +94,23 @@ template <int NL> __device__ int poly_degree(const uint32_t *p, int hi, int lane
     return wave_max(best);
 }
 
+// Montgomery REDC of SIGNED columns (a sum of products some of which were subtracted; the total is non-negative by construction):
+// the same steps as fp29.hpp's redc with arithmetic shifts for the carries.
+template <int NL> __device__ __forceinline__ void redc_signed(uint32_t (&r)[NL], int64_t (&c)[2 * NL], const FpParams<NL> &P) {
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        const uint32_t m = ((uint32_t)c[i] * P.n0) & DMASK;
+#pragma unroll
+        for (int j = 0; j < NL; j++) c[i + j] += (int64_t)((uint64_t)m * P.p[j]);
+        c[i + 1] += c[i] >> LB;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) { c[k + 1] += c[k] >> LB; r[k - NL] = (uint32_t)c[k] & DMASK; }
+    r[NL - 1] = (uint32_t)c[2 * NL - 1];
+}
+// 2 p^2 in radix-2^29 digits: what the fused Euclid step adds to m0 u - m1 w1 - m2 w0 (each product below p^2) so that the sum is never negative
+template <int NL> struct GaoConsts { uint32_t k2pp[2 * NL]; };
+
 // One wave per codeword (at least three to a SIMD: the kernel waits on LDS round trips more than it computes -- 152 registers instead of
 // 194 took config 4 from 40.6 to 37.7 ms, 128 with spills to 38.2).  The kernel stops short of the ONE field inversion a codeword needs (Fermat: 255 squarings + ~128
 // multiplications, every lane computing the same thing -- it cost as much as everything else here together, 47 of 102 ms at config 4):
@@ -104,7 +121,7 @@ template <int NL> __device__ int poly_degree(const uint32_t *p, int hi, int lane
 template <int NL, int NW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_gao(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
                                             int npts, int k, int64_t C, uint32_t *__restrict__ coeffs, uint32_t *__restrict__ errloc,
-                                            int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag, uint32_t *__restrict__ side) {
+                                            int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag, uint32_t *__restrict__ side, const GaoConsts<NL> GK) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x;
     const int64_t c = blockIdx.x;
@@ -113,6 +130,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
     // npts - D, so their arrays are short -- 10 KB of LDS per codeword instead of 14.5 at n = 100: 16 resident waves per CU, not 11
     const int lenT = npts - (npts + k) / 2 + 3;
     uint32_t *R0 = smem, *R1 = R0 + (size_t)len * NL, *T0 = R1 + (size_t)len * NL, *T1 = T0 + (size_t)lenT * NL;
+    uint32_t *ZERO = T1 + (size_t)lenT * NL, *SC = ZERO + NL;          // a zero element; the three scalars of a fused Euclid step (L^2, L a1, a0)
+    if (lane < NL) ZERO[lane] = 0;
 
     for (int idx = lane; idx < len; idx += 64) {
         uint32_t a[NL], z[NL], m[NL];
@@ -141,10 +160,118 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
     } else if (dR1 < D) {              // rsdecode_impl.h:296-301
         rp = R1; vp = T1; dr = dR1; dvb = dT1; fp_set(cs, c1);
     } else {
+        bool have_sc = false;               // SC holds the scalars of the coming fused step (computed by the previous one)
         for (;;) {
             const int delta = dR0 - dR1;
             uint32_t L[NL];
             lds_get<NL>(L, R1 + (size_t)dR1 * NL);
+            // The generic division step (degrees drop one at a time), fused: its two pseudo-division sub-steps
+            //     r' = L r0 - a1 X r1,   a0 = r'[deg r1],   r'' = L r' - a0 r1
+            // are ONE update r''[i] = L^2 r0[i] - (L a1) r1[i-1] - a0 r1[i] (the same on the cofactor; c0 <- L^2 c0): three products and one
+            // reduction per coefficient where the sub-steps take four and two.  The three scalars of a step cost four modular
+            // multiplications -- executed by the whole wave they would eat the gain (round 4 measured it: 45 ms against 38) -- so the scalars
+            // of the NEXT step are computed by three otherwise idle lanes of this step's second round: the first round takes the TOP 64
+            // coefficients of the remainder, so the two leading coefficients of r'' the next scalars need are there when the second
+            // round (the rest of the remainder, the cofactor, c0, the three jobs) starts.  job1 = X X, job2 = X Y, job3 = X Z - Y W with
+            // (X, Y, Z, W) = (lc r'', L, r1[deg r1 - 1], r''[deg r'' - 1]).  Subtracted products use negated multiplier digits and signed
+            // multiply-adds; 2 p^2 in the columns keeps the sum non-negative.  Values identical to the sub-steps', term by term.
+            const int ttop_f = max(dT0, dT1 + 1), n2_f = max(0, dR1 - 64);
+            if (delta == 1 && dR1 >= 2 && n2_f + ttop_f + 1 <= 60) {
+                const int top = dR1, ttop = ttop_f, n2 = n2_f;
+                uint32_t sL2[NL];
+                int32_t nLa1[NL], na0[NL];
+#pragma unroll
+                for (int q = 0; q < NL; q++) { sL2[q] = 0; nLa1[q] = 0; na0[q] = 0; }
+                for (int st = have_sc ? 1 : 0; st < 3; st++) {
+                    const int rd = st == 0 ? 2 : st - 1;          // 2: the scalars of THIS step alone (first step, or after a degree anomaly); 0, 1: the two rounds
+                    if (rd == 0) {
+                        uint32_t t1[NL], t2[NL];
+                        lds_get<NL>(sL2, SC);
+                        lds_get<NL>(t1, SC + NL);
+                        lds_get<NL>(t2, SC + 2 * NL);
+#pragma unroll
+                        for (int q = 0; q < NL; q++) { nLa1[q] = -(int32_t)t1[q]; na0[q] = -(int32_t)t2[q]; }
+                    }
+                    // what this lane does in this round
+                    enum { IDLE, REM, COF, JOB, C0L };
+                    int role = IDLE, idx = 0;
+                    if (rd == 0) { if (lane < min(64, top)) { role = REM; idx = top - 1 - lane; } }
+                    else if (rd == 1) {
+                        if (lane < n2) { role = REM; idx = n2 - 1 - lane; }
+                        else if (lane <= n2 + ttop) { role = COF; idx = lane - n2; }
+                        else if (lane >= 60 && lane < 63) role = JOB;
+                        else if (lane == 63) role = C0L;
+                    } else if (lane >= 60 && lane < 63) role = JOB;
+                    const uint32_t *Xa = rd == 1 ? R0 + (size_t)(top - 1) * NL : R1 + (size_t)dR1 * NL;
+                    const uint32_t *Ya = rd == 1 ? R1 + (size_t)dR1 * NL : R0 + (size_t)(dR1 + 1) * NL;
+                    const uint32_t *Za = rd == 1 ? R1 + (size_t)(dR1 - 1) * NL : R0 + (size_t)dR1 * NL;
+                    const uint32_t *Wa = rd == 1 ? R0 + (size_t)(top - 2) * NL : R1 + (size_t)(dR1 - 1) * NL;
+                    const int jb = lane - 60;
+                    const uint32_t *pu = ZERO, *pw1 = ZERO, *pw0 = ZERO;
+                    uint32_t *dst = nullptr;
+                    if (role == REM) { pu = R0 + (size_t)idx * NL; pw1 = idx >= 1 ? R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = R1 + (size_t)idx * NL; dst = R0 + (size_t)idx * NL; }
+                    else if (role == COF) {
+                        pu = T0 + (size_t)idx * NL;
+                        pw1 = (idx >= 1 && idx - 1 <= dT1) ? T1 + (size_t)(idx - 1) * NL : ZERO;
+                        pw0 = idx <= dT1 ? T1 + (size_t)idx * NL : ZERO;
+                        dst = T0 + (size_t)idx * NL;
+                    } else if (role == JOB) { pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za); pw1 = jb == 2 ? Wa : ZERO; dst = SC + (size_t)jb * NL; }
+                    const bool isN = role == REM || role == COF, isJ = role == JOB, isJ3 = isJ && jb == 2;
+                    uint32_t u[NL], w1[NL], w0[NL];
+                    int32_t m0[NL], m1[NL], m2[NL];
+                    lds_get<NL>(u, pu);
+                    lds_get<NL>(w1, pw1);
+                    lds_get<NL>(w0, pw0);
+                    if (role == C0L) fp_set(u, c0);
+                    if (rd != 0) {
+                        uint32_t Xv[NL], Yv[NL];
+                        lds_get<NL>(Xv, Xa);
+                        lds_get<NL>(Yv, Ya);
+#pragma unroll
+                        for (int q = 0; q < NL; q++) {
+                            m0[q] = isJ ? (int32_t)Xv[q] : (int32_t)sL2[q];
+                            m1[q] = isN ? nLa1[q] : (isJ3 ? -(int32_t)Yv[q] : 0);
+                            m2[q] = isN ? na0[q] : 0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < NL; q++) { m0[q] = (int32_t)sL2[q]; m1[q] = nLa1[q]; m2[q] = na0[q]; }
+                    }
+                    int64_t col[2 * NL];
+#pragma unroll
+                    for (int q = 0; q < 2 * NL; q++) col[q] = (int64_t)GK.k2pp[q];
+#pragma unroll
+                    for (int i = 0; i < NL; i++)
+#pragma unroll
+                        for (int j = 0; j < NL; j++) col[i + j] += (int64_t)m0[i] * (int32_t)u[j];
+#pragma unroll
+                    for (int i = 0; i < NL; i++)
+#pragma unroll
+                        for (int j = 0; j < NL; j++) col[i + j] += (int64_t)m1[i] * (int32_t)w1[j];
+#pragma unroll
+                    for (int i = 0; i < NL; i++)
+#pragma unroll
+                        for (int j = 0; j < NL; j++) col[i + j] += (int64_t)m2[i] * (int32_t)w0[j];
+                    uint32_t r[NL];
+                    redc_signed<NL>(r, col, P);
+                    cond_sub_p(r, P);
+                    __syncthreads();             // (one wave: orders this round's LDS reads before its writes -- the jobs read what round A wrote, a lane's neighbour reads R1 only)
+                    if (dst) lds_put<NL>(dst, r);
+                    if (rd == 1) {
+#pragma unroll
+                        for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)r[q], 63);
+                    }
+                    __syncthreads();
+                }
+                if (lane < 2) {
+#pragma unroll
+                    for (int q = 0; q < NL; q++) R0[(size_t)(top + lane) * NL + q] = 0;
+                }
+                dT0 = ttop;
+                have_sc = true;                  // (withdrawn below if the degree did not drop by exactly one)
+                __syncthreads();
+            } else {
+            have_sc = false;
             for (int j = delta; j >= 0; j--) {
                 uint32_t a[NL], an[NL];
                 lds_get<NL>(a, R0 + (size_t)(dR1 + j) * NL);
@@ -232,10 +359,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
                 dT0 = ttop;
                 __syncthreads();
             }
+            }
             {   // the degree drops by exactly one as a rule: look at that coefficient before scanning the polynomial
                 uint32_t topc[NL];
                 if (dR1 >= 1) lds_get<NL>(topc, R0 + (size_t)(dR1 - 1) * NL);
                 dR0 = (dR1 >= 1 && !fp_is_zero(topc)) ? dR1 - 1 : poly_degree<NL>(R0, dR1 - 1, lane);
+                if (dR0 != dR1 - 1) have_sc = false;     // the next step's scalars were computed for a remainder of degree deg r1 - 1
             }
             if (dR0 < D) { rp = R0; vp = T0; dr = dR0; dvb = dT0; fp_set(cs, c0); break; }
             // (r0, r1) <- (r1, r2)
@@ -408,19 +537,43 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     hb_view iv{npts, 1}, ov{npts, 1};
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (rc) { (void)hipFree(g1); return rc; }
-    size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3)) * NLr * 4;
+    size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 4) * NLr * 4;      // R0, R1, T0, T1, a zero element, three scalars
     // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one
     uint32_t *side = nullptr;
     const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
     if (hipMalloc(&side, (size_t)C * side_words * 4) != hipSuccess) { (void)hipFree(g1); return fail(ctx, HB_ERR_HIP, "gao: side buffer"); }
     const unsigned fin_blocks = (unsigned)((C + 63) / 64);
+    // 2 p^2 in radix-2^29 digits (schoolbook on 32-bit words)
+    uint32_t k2pp[18];
+    {
+        const int W = ctx->n_limbs * 2;
+        uint32_t pw32[8], sq[17];
+        for (int i = 0; i < W; i++) pw32[i] = (uint32_t)(ctx->p_limbs[i / 2] >> (32 * (i & 1)));
+        memset(sq, 0, sizeof sq);
+        for (int i = 0; i < W; i++) {
+            uint64_t cy = 0;
+            for (int j = 0; j < W; j++) { const uint64_t t = (uint64_t)pw32[i] * pw32[j] + sq[i + j] + cy; sq[i + j] = (uint32_t)t; cy = t >> 32; }
+            sq[i + W] = (uint32_t)cy;
+        }
+        for (int i = 2 * W; i > 0; i--) sq[i] = (sq[i] << 1) | (sq[i - 1] >> 31);      // times two (sq[2 W] was zero)
+        sq[0] <<= 1;
+        for (int q = 0; q < 2 * NLr; q++) {
+            const int bit = 29 * q, j = bit >> 5, sft = bit & 31;
+            const uint64_t v = (uint64_t)(j < 17 ? sq[j] : 0) | ((uint64_t)(j + 1 < 17 ? sq[j + 1] : 0) << 32);
+            k2pp[q] = (uint32_t)(v >> sft) & DMASK;
+        }
+    }
     if (ctx->n_limbs == 4) {
+        GaoConsts<9> gk;
+        memcpy(gk.k2pp, k2pp, sizeof gk.k2pp);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
+        k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
         k_gao_finish<9, 8><<<fin_blocks, 64, 0, s>>>(ctx->pw, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
+        GaoConsts<3> gk;
+        memcpy(gk.k2pp, k2pp, sizeof gk.k2pp);
+        k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
         k_gao_finish<3, 2><<<fin_blocks, 64, 0, s>>>(ctx->pn, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
     }
     const hipError_t le = hipGetLastError();
