@@ -67,6 +67,7 @@ SYMBOLS = {
     "hb_quick_dec_arrivals": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "hb_quick_dec_decide": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "hb_quick_dec_destroy": (None, [_vp]),
+    "hb_symbols_fetch": (_i, [_vp, _vp, _i64, _i64, _vp, _i, _vp, _vp]),
     "hb_probe_create": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
     "hb_probe_feed": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _vp, _vp]),
     "hb_probe_reset": (_i, [_vp]),
@@ -232,9 +233,15 @@ class Context:
             raise HbmpcBackendError(f"hb_ctx_create failed: {_STATUS_NAMES.get(rc, rc)}")
         self.h = h
         self.tdev = torch.device("cuda", self.device)
+        self._raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
     # -- plumbing ----------------------------------------------------------
     def stream(self):
+        """torch's CURRENT stream on this context's device, as the void* the C ABI takes (asked anew at every call: callers switch
+        streams; the raw getter costs a fraction of a microsecond where building a torch.cuda.Stream object cost three)"""
+        raw = self._raw_stream
+        if raw is not None:
+            return ctypes.c_void_p(raw(self.device))
         return ctypes.c_void_p(self.torch.cuda.current_stream(self.tdev).cuda_stream)
 
     def check(self, rc, what):

@@ -103,6 +103,8 @@ struct hb_ctx {
     std::vector<QuickSlot> qslots;
     unsigned qnext = 0;
     std::vector<void *> probe_pool, probe_host_pool;
+    void *fetch_host = nullptr, *fetch_dev = nullptr; // hb_symbols_fetch: pinned, device-visible hand-over buffer (hb::SymFetch)
+    int fetch_seq = 0;
     std::map<int, void *> wide_shared;                // d -> hb::Mm8wShared *
     std::map<std::string, std::vector<int>> wide_shapes;   // launch geometry per (row tiles, K-blocks, chunk tiles)
     void *mm8_shared = nullptr;                       // hb::Mm8Shared *: constants of the small-entry matrix-core kernels (hb_mm8.hpp)

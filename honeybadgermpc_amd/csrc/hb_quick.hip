@@ -706,6 +706,21 @@ void point_tables_free(hb_ctx *ctx) {
     ctx->probe_pool.clear();
     for (void *p : ctx->probe_host_pool) (void)hipHostFree(p);
     ctx->probe_host_pool.clear();
+    if (ctx->fetch_host) (void)hipHostFree(ctx->fetch_host);
+    ctx->fetch_host = ctx->fetch_dev = nullptr;
+}
+
+// hb_symbols_fetch: a few symbols of one polynomial cross to the host through pinned memory, the sequence number last
+constexpr int FETCH_MAX = 64;
+struct SymFetch { uint64_t w[FETCH_MAX * 4]; int32_t seq; };
+struct FetchIdx { int32_t idx[FETCH_MAX]; };
+__global__ void __launch_bounds__(256) k_symbols_fetch(const uint64_t *__restrict__ cols, int64_t C, int64_t chunk, int L, const FetchIdx ix, int count,
+                                                       SymFetch *__restrict__ out, int seq) {
+    const int t = threadIdx.x;
+    if (t < count * L) out->w[t] = cols[((size_t)ix.idx[t / L] * (size_t)C + (size_t)chunk) * L + t % L];
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) *reinterpret_cast<volatile int32_t *>(&out->seq) = seq;
 }
 
 }  // namespace hb
@@ -1168,6 +1183,39 @@ int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *c
     *ok = pr->res_host->ok;
     memcpy(err_mask, pr->res_host->err, (size_t)pr->n);
     if (!*ok) memset(err_mask, 0, (size_t)pr->n);
+    return HB_OK;
+}
+
+int hb_symbols_fetch(hb_ctx *ctx, const uint64_t *cols_dev, int64_t C, int64_t chunk, const int32_t *idx, int count, uint64_t *out_host, void *stream) {
+    HB_API_GUARD(ctx);
+    if (!ctx || !cols_dev || !idx || !out_host || count < 1 || count > FETCH_MAX || C < 1 || chunk < 0 || chunk >= C) return fail(ctx, HB_ERR_BAD_ARG, "symbols_fetch: arguments");
+    if (!ctx->fetch_host) {
+        void *h = nullptr, *dv = nullptr;
+        HB_HIP(ctx, hipHostMalloc(&h, sizeof(SymFetch), hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess) { (void)hipHostFree(h); return fail(ctx, HB_ERR_HIP, "symbols_fetch: device pointer"); }
+        memset(h, 0, sizeof(SymFetch));
+        ctx->fetch_host = h; ctx->fetch_dev = dv;
+    }
+    SymFetch *host = static_cast<SymFetch *>(ctx->fetch_host);
+    FetchIdx ix;
+    for (int i = 0; i < count; i++) ix.idx[i] = idx[i];
+    const int L = ctx->n_limbs, seq = ++ctx->fetch_seq;
+    hipStream_t s = (hipStream_t)stream;
+    k_symbols_fetch<<<1, 256, 0, s>>>(cols_dev, C, chunk, L, ix, count, static_cast<SymFetch *>(ctx->fetch_dev), seq);
+    HB_LAUNCH_CHECK(ctx);
+    // (the buffer belongs to the context: the wait stays inside its mutex -- it is a few microseconds; past 2 ms, synchronise)
+    volatile int32_t *flag = &host->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (*flag != seq) {
+        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            HB_HIP(ctx, hipStreamSynchronize(s));
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*flag != seq) return fail(ctx, HB_ERR_HIP, "symbols_fetch: the kernel finished without handing over");
+    memcpy(out_host, host->w, (size_t)count * L * sizeof(uint64_t));
     return HB_OK;
 }
 

@@ -463,6 +463,8 @@ class DeviceIncrementalDecoder:
         self._confirmed_errors = set() if confirmed_errors is None else confirmed_errors
         self._available_points = set()
         self._z = []
+        self._fetch1 = None
+        self._z_epoch = 0               # bumps whenever senders LEAVE the arrival list (between bumps it only grows at the end)
         self._optimistic = True
         self._guess_decoded = None      # (C, d, limbs)
         self._guess_encoded = None      # (n, C, limbs)
@@ -477,8 +479,7 @@ class DeviceIncrementalDecoder:
         self._qdec = None               # _QuickDec borrowed for the optimistic step (None: hb_quick_interp_check)
         self._qdec_ready = False        # its first half has been enqueued for the current first degree+1 arrivals
         self._settled = None            # polynomial whose verdict is in (its errors expelled) but which is not accepted yet
-        self._memo = None               # (polynomial, arrival list, candidate, who disagreed) settled inside the radius while short of columns
-        self._memo_ev = None            # (candidate, its values at the n points)
+        self._memo = None               # (polynomial, (arrivals seen, their epoch), candidates [coefficients, who disagrees, values at the n points]) waiting for support
         self._prefer_tail = False       # robust phase: interpolate from the newest arrivals (True) or the oldest
         self._stalled = None            # polynomial the last robust update could not decode (the probe is on it)
         self._checked = None            # (arrival list, first chunk, coefficients, first disagreeing chunk) of a launch the robust phase may reuse
@@ -754,18 +755,50 @@ class DeviceIncrementalDecoder:
         d = self.degree + 1
         return (self._z[-d:], self._z[:-d]) if tail else (self._z[:d], self._z[d:])
 
-    def _disagreeing_among(self, coeffs, chunk, senders):
-        """those of `senders` (in their order) whose symbol of `chunk` differs from the candidate `coeffs` at their point; the candidate's
-        values at all n points are kept beside it (one small launch the first time)"""
-        if not senders:
-            return []
-        t = self.ctx.torch
-        if self._memo_ev is None or self._memo_ev[0] is not coeffs:
-            self._memo_ev = (coeffs, self._disagreeing(coeffs))
-        ev = self._memo_ev[1]
-        st = t.tensor(senders, dtype=t.int64, device=self.ctx.tdev)
-        differs = (ev.index_select(0, st) != self._cols[:, chunk, :].index_select(0, st)).any(dim=1).tolist()
-        return [s_ for s_, df in zip(senders, differs) if df]
+    def _candidate_cap(self, radius):
+        """How many disagreeing senders a candidate may have and still decide the reference's verdicts (reed_solomon.py:334-346).
+        The reference accepts a robust decode (Q, errors) only when |z| - |errors| >= need = degree + 1 + max_errors - confirmed
+        (:343-345) and otherwise waits with nothing changed.  Let P be ANY polynomial of degree <= `degree` that disagrees with E of
+        the arrived senders, E <= need - (degree + 1) = max_errors - confirmed.  An accepted Q agrees with >= need of the |z| columns and P
+        with |z| - E of them, so they agree with each other on >= need - E >= degree + 1 points: Q = P.  And once |z| - E >= need, E <=
+        (|z| - degree - 1) / 2: P is inside Gao's unique-decoding radius, so Gao returns exactly P with exactly those E senders.  Hence
+        while E stays within the cap, "accept P when |z| - E >= need, else wait" IS the reference's behaviour -- whatever Gao would have said
+        in between (None, or some other polynomial short of support) changes nothing.  A candidate from ANY degree + 1 columns serves;
+        with the liars among the first arrivals the newest columns give the true polynomial and no incremental decode runs at all.
+        Welch-Berlekamp answers (or raises) in its own way beyond the radius: for it the cap is the radius."""
+        return max(radius, self.max_errors - len(self._confirmed_errors)) if self.robust == "gao" else radius
+
+    def _symbols(self, chunk, senders):
+        """the symbols of `chunk` in the columns of `senders`, on the host: (len(senders), limbs)"""
+        ctx = self.ctx
+        if len(senders) == 1:
+            # one arrival, the case that repeats: buffers and their addresses are kept
+            fx = self._fetch1
+            if fx is None:
+                ia, out = np.empty(1, dtype=np.int32), np.empty((1, self.L), dtype=np.int64)
+                fx = self._fetch1 = (ia, out, np_ptr(ia), np_ptr(out), ctx.ptr(self._cols))
+            fx[0][0] = senders[0]
+            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, fx[4], self.batch_size, chunk, fx[2], 1, fx[3], ctx.stream()), "hb_symbols_fetch")
+            return fx[1]
+        out = np.empty((len(senders), self.L), dtype=np.int64)
+        for lo in range(0, len(senders), 64):
+            part = np.asarray(senders[lo:lo + 64], dtype=np.int32)
+            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(self._cols), self.batch_size, chunk, np_ptr(part), len(part), np_ptr(out[lo:lo + 64]), ctx.stream()),
+                      "hb_symbols_fetch")
+        return out
+
+    def _track_candidates(self, cands, chunk, senders):
+        """each candidate [coeffs, errors, values at the n points (host, made on first use)] with `senders` (new arrivals) judged; those
+        whose disagreements left the cap are dropped"""
+        if senders:
+            sym = self._symbols(chunk, senders)
+            for cand in cands:
+                if cand[2] is None:
+                    cand[2] = self._disagreeing(cand[0]).cpu().numpy()
+                ev = cand[2]
+                cand[1] = cand[1] + [s_ for j, s_ in enumerate(senders) if (sym[j] != ev[s_]).any()]
+        cap = self._candidate_cap((len(self._z) - self.degree - 1) // 2)
+        return [cand for cand in cands if len(cand[1]) <= cap]
 
     def _candidate_errors(self, coeffs, chunk):
         t = self.ctx.torch
@@ -825,6 +858,7 @@ class DeviceIncrementalDecoder:
         self._confirmed_errors |= es
         self._available_points -= es
         self._z = [i for i in self._z if i not in es]
+        self._z_epoch += 1
 
     def _fast_robust_update(self):
         """reference :334-365, plan-free (see the class docstring); robust decoder Gao or Welch-Berlekamp.
@@ -864,18 +898,22 @@ class DeviceIncrementalDecoder:
                 self._expel(errors)
                 self._settled = lo
             memo, self._memo = self._memo, None
-            if memo is not None and memo[0] == lo and self._z[: len(memo[1])] == memo[1]:
-                # the previous call settled this polynomial inside the radius but was short of columns: the same candidate, with
-                # whatever the newer arrivals add to its disagreements, stays Gao's answer while they fit the (larger) radius.
-                # Who disagreed among the columns of then is known (memo[3]); only the columns that arrived since are compared.
-                errors = memo[3] + self._disagreeing_among(memo[2], lo, self._z[len(memo[1]):])
-                if len(errors) <= (len(self._z) - d) // 2:
-                    if len(self._available_points) - len(errors) < self._min_points_required():
-                        self._memo = (lo, list(self._z), memo[2], errors)
-                        return
+            if memo is not None and memo[0] == lo and memo[1][1] == self._z_epoch:
+                # Candidates found earlier for this polynomial, each with the senders that disagree with it (see _candidate_cap for
+                # why such a candidate decides Gao's verdicts while its disagreements stay within max_errors - confirmed): only the
+                # columns that arrived since are compared, one 32-byte symbol each.
+                alive, accepted = self._track_candidates(memo[2], lo, self._z[memo[1][0]:]), None
+                for cand in alive:
+                    if len(self._available_points) - len(cand[1]) >= self._min_points_required():
+                        accepted = cand
+                        break
+                if accepted is not None:
                     self.radius_verdicts += 1
-                    self._expel(errors)
+                    self._expel(accepted[1])
                     self._settled = lo
+                elif alive:
+                    self._memo = (lo, (len(self._z), self._z_epoch), alive)
+                    return
             self._wb_refusal(lo)                             # the list may just have shrunk (expulsions above)
             chk, self._checked = self._checked, None
             tail_split = self._prefer_tail
@@ -899,22 +937,32 @@ class DeviceIncrementalDecoder:
             # interpolate a candidate; a sender that lies in this chunk may sit among them, so the other end of the arrival
             # list gets one try too (whichever end worked is tried first from then on).
             radius = (len(self._z) - d) // 2
-            first_split, dec2 = tail_split, None
+            cap = self._candidate_cap(radius)
+            cands = []
             errors = self._scan_errors(dec, first)
+            if len(errors) <= cap:
+                cands.append([dec[first].clone(), list(errors), None])
             if len(errors) > radius and len(self._z) > d:
-                self._probe_ahead(first)                 # (a second candidate is tried first; the probe catches up meanwhile)
+                if len(errors) > cap:
+                    self._probe_ahead(first)             # (a second candidate is tried first; the probe catches up meanwhile)
                 tail_split = not tail_split
                 dec2, _, _ = self._quick(*self._split(tail_split), lo=first, hi=first + 1)      # this one polynomial only
                 errors = self._candidate_errors(dec2[first], first)
+                if len(errors) <= cap:
+                    cands.insert(0 if len(errors) <= radius else len(cands), [dec2[first].clone(), list(errors), None])
             if len(errors) <= radius:
                 self._prefer_tail = tail_split
                 if len(self._available_points) - len(errors) < self._min_points_required():
-                    self._memo = (first, list(self._z), (dec2 if tail_split != first_split else dec)[first].clone(), list(errors))
+                    self._memo = (first, (len(self._z), self._z_epoch), cands)
                     return
                 self.radius_verdicts += 1
                 self._expel(errors)
                 self._settled = first
                 continue
+            if cands:
+                # outside the radius today, but Gao can accept nothing else while these stand (_candidate_cap): no probe, wait
+                self._memo = (first, (len(self._z), self._z_epoch), cands)
+                return
             self._stalled = first                        # only the probe can say when it becomes decodable
         if self._num_decoded == self.batch_size:
             self._result = self._partial
@@ -945,6 +993,7 @@ class DeviceIncrementalDecoder:
             self._confirmed_errors |= set(errors)
             self._available_points -= set(errors)
             self._z = [i for i in self._z if i not in errors]
+            self._z_epoch += 1
 
     def _probe(self):
         """The reference's next robust_decode (one polynomial over the current arrival set): -> (coeffs (d, limbs) | None, errors).

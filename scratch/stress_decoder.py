@@ -28,12 +28,32 @@ while time.time() < t_end:
     xs = [point(i).value for i in range(n)]
     polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
     cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
-    liars = rnd.sample(range(n), rnd.randrange(0, t + 2))          # sometimes one liar too many
+    liars = rnd.sample(range(n), min(n, rnd.randrange(0, t + 2) + (rnd.randrange(0, t) if rnd.random() < 0.1 else 0)))          # sometimes one liar too many, now and then many
+    # half of the runs: the liars are coordinated -- on the chunks they hit they all send the values of ONE other polynomial (which may
+    # share up to t points with the true one: then honest senders "agree" with the fake too), the word Gao may decode to instead
+    fake = None
+    if rnd.random() < 0.5:
+        fake = []
+        for poly in polys:
+            shared = rnd.sample(range(n), rnd.randrange(0, t + 1))
+            # true + m(X) prod (X - x_s): equal to the true polynomial at the shared points, degree <= t
+            q = [rnd.randrange(1, P)] + [0] * t
+            deg = 0
+            for s_ in shared:
+                nq = [0] * (t + 1)
+                for e in range(deg + 1):
+                    nq[e + 1] = (nq[e + 1] + q[e]) % P
+                    nq[e] = (nq[e] - q[e] * xs[s_]) % P
+                q, deg = nq, deg + 1
+            fake.append([(a + b) % P for a, b in zip(poly, q)])
     for i in liars:
         kind = rnd.randrange(4)
         hit = {0: range(c), 1: [c - 1], 2: [rnd.randrange(c)], 3: rnd.sample(range(c), max(1, c // 3))}[kind]
         for j in hit:
-            cols[i][j] = (cols[i][j] + 1 + rnd.randrange(P - 1)) % P
+            if fake is not None:
+                cols[i][j] = sum(co * pow(xs[i], e, P) for e, co in enumerate(fake[j])) % P
+            else:
+                cols[i][j] = (cols[i][j] + 1 + rnd.randrange(P - 1)) % P
     order = list(range(n))
     rnd.shuffle(order)
     if rnd.random() < 0.5:

@@ -281,7 +281,10 @@ def test_pooled_probe_starts_from_a_reset():
     x = list(range(1, n + 1))
     device._probe_pool.idle.clear()
     liars = [0, 1, 2, 3, 4]
-    order = liars + [i for i in range(n) if i not in liars]          # the liars arrive first: the probe runs from the 11th column on
+    # the liars arrive spread out, one among every six consecutive arrivals: a candidate interpolated from either end of the arrival
+    # list is contaminated, so no candidate stands (device.py _candidate_cap) and the probe has to decide
+    honest = [i for i in range(n) if i not in liars]
+    order = [0] + honest[:4] + [1] + honest[4:7] + [2, 3] + honest[7:10] + [4] + honest[10:]
     results = []
     for rep in range(2):
         polys, flat = _codewords(rnd, x, d, c, P)

@@ -342,7 +342,8 @@ def test_device_decoder_worst_case_adversaries(n, t, c, pattern):
     assert dev.quick_launches > 0 and dev.launches == 0          # the plan-free path did it: no batched Gao launch, no plan
     # every polynomial that had errors was settled either by the probe or by a batched candidate inside the radius
     if pattern != "late-same":
-        assert dev.probes + dev.radius_verdicts >= (t if pattern == "everywhere" else len({1 + (r * 7) % (c - 1) for r in range(t)}))
+        # ("everywhere", liars first: the candidate from the newest columns names all t of them at the first polynomial -- one verdict)
+        assert dev.probes + dev.radius_verdicts >= (1 if pattern == "everywhere" else len({1 + (r * 7) % (c - 1) for r in range(t)}))
 
 
 def test_device_decoder_randomised_vs_host_mirror():
