@@ -194,11 +194,14 @@ def traffic_from_profiles(workload):
 SIMDS, NOMINAL_HZ = 1024, 2.4e9       # 256 CUs x 4 SIMDs; nominal shader clock (MI355X_MICROARCH.md)
 
 
-def prewarm(step, sync, seconds):
+def prewarm(step, sync, seconds, agree=None):
     """The same untimed steps the W warm-up steps are, until `seconds` of wall clock have passed: after the CPU baseline (or a cold start)
     the GPU sits in a low power state and takes some tens of milliseconds of load to reach the clocks it then holds -- 20 timed steps
     straight after 5 warm-up steps (5 ms in all) measured 4.9-5.1 G shares/s where 200 steps measure 5.5 G and 20 steps after 200 warm-up
-    steps 5.8 G (profiles/r03_bench_steps_and_warmup.txt).  Never inside the timed region; its length is reported in `detail`."""
+    steps 5.8 G (profiles/r03_bench_steps_and_warmup.txt).  Never inside the timed region; its length is reported in `detail`.
+    agree: when a step holds a collective (the sharded open's gather) every rank must run the SAME number of steps -- each rank's own
+    clock would let one rank leave a block of 20 ahead of the others and the next gather would wait for it for ever (seen as a hang in
+    one of seven 8-rank launches); `agree(done) -> bool` is then the ranks' common decision (rank 0's clock)."""
     if seconds <= 0:
         return 0, 0.0
     t0 = time.perf_counter()
@@ -209,7 +212,10 @@ def prewarm(step, sync, seconds):
         n += 20
         sync()
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 5000:
+        done = el >= seconds or n >= 5000
+        if agree is not None:
+            done = agree(done)
+        if done:
             return n, el * 1e3
 
 
@@ -574,7 +580,14 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
             evs[3][i].record()
         return res
 
-    pre_steps, pre_ms = prewarm(step, torch.cuda.synchronize, args.prewarm)
+    def agree(done):
+        # rank 0 decides for everybody (a host-side broadcast: gloo carries it under either backend's process group ... the default
+        # group's backend moves device tensors only with nccl, host tensors only with gloo)
+        flag = torch.tensor([1 if done else 0], dtype=torch.int32, device=(torch.device("cuda", local_rank) if backend == "nccl" else "cpu"))
+        dist.broadcast(flag, src=0)
+        return bool(flag.item())
+
+    pre_steps, pre_ms = prewarm(step, torch.cuda.synchronize, args.prewarm, agree if (dist is not None and world > 1) else None)
     for _ in range(args.warmup):
         step()
     assert so.ok(), "validation mismatch during warmup"
@@ -845,6 +858,10 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
 
 
 def main():
+    if os.environ.get("HB_BENCH_DUMP_AFTER"):
+        # debugging aid for a rank that stops making progress: every thread's Python stack to stderr after that many seconds (and again)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["HB_BENCH_DUMP_AFTER"]), repeat=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)

@@ -24,6 +24,7 @@
 #include <algorithm>
 
 #include "hb_common.hpp"
+#include <type_traits>
 
 using namespace hb;
 
@@ -182,8 +183,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
                 int32_t nLa1[NL], na0[NL];
 #pragma unroll
                 for (int q = 0; q < NL; q++) { sL2[q] = 0; nLa1[q] = 0; na0[q] = 0; }
-                for (int st = have_sc ? 1 : 0; st < 3; st++) {
-                    const int rd = st == 0 ? 2 : st - 1;          // 2: the scalars of THIS step alone (first step, or after a degree anomaly); 0, 1: the two rounds
+                // one round, its kind a compile-time constant (the first round's code then has no roles, no selects, no job operands):
+                // 2: the scalars of THIS step alone (first step, or after a degree anomaly); 0, 1: the two rounds
+                auto round = [&](auto rd_c) {
+                    constexpr int rd = decltype(rd_c)::value;
                     if (rd == 0) {
                         uint32_t t1[NL], t2[NL];
                         lds_get<NL>(sL2, SC);
@@ -262,7 +265,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
                         for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)r[q], 63);
                     }
                     __syncthreads();
-                }
+                };
+                if (!have_sc) round(std::integral_constant<int, 2>{});
+                round(std::integral_constant<int, 0>{});
+                round(std::integral_constant<int, 1>{});
                 if (lane < 2) {
 #pragma unroll
                     for (int q = 0; q < NL; q++) R0[(size_t)(top + lane) * NL + q] = 0;
@@ -445,45 +451,89 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
     if (lane == 0) { okflag[c] = ok ? 1 : 0; errlen[c] = ok ? dv + 1 : 0; }
 }
 
-// One lane per codeword: w = cs l, ONE inversion each -- 64 different ones per wave -- then 1 / cs = l / w scales the cofactor into
-// the reference's un-normalised error locator, and powers of 1 / l = cs / w turn the raw quotient digits into coefficients:
-// f_i = c_i / l^(dq - i + 1).  In place, canonical on the way out.
+// One lane per GAO_FIN_G codewords: w_j = cs_j l_j and ONE inversion for the group (Montgomery's trick: prefix products, invert the last,
+// peel backwards -- an inversion is ~380 multiplications, the three per codeword that replace it are not), then 1 / cs = l / w scales
+// the cofactor into the reference's un-normalised error locator, and powers of 1 / l = cs / w turn the raw quotient digits into
+// coefficients: f_i = c_i / l^(dq - i + 1).  In place, canonical on the way out: the scale factors are taken OUT of Montgomery form once,
+// so that one multiplication both scales an element and converts it.  (One lane per codeword, an inversion each: 1.18 ms at config 4.)
+#ifndef GAO_FIN_GROUP
+#define GAO_FIN_GROUP 4
+#endif
+constexpr int GAO_FIN_G = GAO_FIN_GROUP;
 template <int NL, int NW>
 __global__ void __launch_bounds__(64) k_gao_finish(const FpParams<NL> P, int npts, int k, int64_t C, uint32_t *__restrict__ coeffs,
                                                    uint32_t *__restrict__ errloc, const int32_t *__restrict__ errlen,
                                                    const uint8_t *__restrict__ okflag, const uint32_t *__restrict__ side) {
-    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (c >= C || !okflag[c]) return;
-    uint32_t cs[NL], l[NL], w[NL], winv[NL], inv_c[NL], linv[NL];
-    load_digits<NL, NW>(cs, side + (size_t)c * (2 * NW + 4));
-    load_digits<NL, NW>(l, side + (size_t)c * (2 * NW + 4) + NW);
-    const int dq = (int)side[(size_t)c * (2 * NW + 4) + 2 * NW], df = (int)side[(size_t)c * (2 * NW + 4) + 2 * NW + 1];
-    mont_mul(w, cs, l, P);
-    fp_inv(winv, w, P);
-    mont_mul(inv_c, winv, l, P);               // 1 / cs
-    mont_mul(linv, winv, cs, P);               // 1 / l
-    const int nloc = errlen[c];
-    for (int j = 0; j < nloc; j++) {
-        uint32_t u[NL], e[NL], ec[NL];
-        uint32_t *pj = errloc + ((size_t)c * (npts + 1) + j) * NW;
-        load_digits<NL, NW>(u, pj);
-        mont_mul(e, u, inv_c, P);
-        from_mont(ec, e, P);
-        store_digits<NL, NW>(pj, ec);
-    }
-    // i = dq .. 0: the power of 1 / l grows by one per step; only i <= df < k carry a non-zero digit
-    uint32_t pw[NL];
-    fp_set(pw, linv);
-    for (int i = dq; i >= 0; i--) {
-        if (i <= df) {
-            uint32_t u[NL], f[NL], o[NL];
-            uint32_t *pi = coeffs + ((size_t)c * k + i) * NW;
-            load_digits<NL, NW>(u, pi);
-            mont_mul(f, u, pw, P);
-            from_mont(o, f, P);
-            store_digits<NL, NW>(pi, o);
+    const int64_t base = ((int64_t)blockIdx.x * 64 + threadIdx.x) * GAO_FIN_G;
+    if (base >= C) return;
+    const int cnt = (int)min((int64_t)GAO_FIN_G, C - base);
+    uint32_t pref[GAO_FIN_G][NL];            // pref[j] = w_0 ... w_j over the decoded codewords (the others contribute 1)
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < GAO_FIN_G; j++) {
+        uint32_t w[NL];
+        fp_set(w, P.one);
+        if (j < cnt && okflag[base + j]) {
+            uint32_t cs[NL], l[NL];
+            load_digits<NL, NW>(cs, side + (size_t)(base + j) * (2 * NW + 4));
+            load_digits<NL, NW>(l, side + (size_t)(base + j) * (2 * NW + 4) + NW);
+            mont_mul(w, cs, l, P);
+            any = true;
         }
-        if (i > 0) mont_mul(pw, pw, linv, P);
+        if (j == 0) fp_set(pref[0], w); else mont_mul(pref[j], pref[j - 1], w, P);
+    }
+    if (!any) return;
+    uint32_t run[NL];                        // 1 / (w_0 ... w_j) while codeword j is being finished
+    fp_inv(run, pref[GAO_FIN_G - 1], P);
+#pragma unroll
+    for (int j = GAO_FIN_G - 1; j >= 0; j--) {
+        if (j >= cnt || !okflag[base + j]) continue;          // (its factor was 1)
+        const int64_t c = base + j;
+        uint32_t cs[NL], l[NL], w[NL], winv[NL], inv_c[NL], linv[NL];
+        load_digits<NL, NW>(cs, side + (size_t)c * (2 * NW + 4));
+        load_digits<NL, NW>(l, side + (size_t)c * (2 * NW + 4) + NW);
+        const int dq = (int)side[(size_t)c * (2 * NW + 4) + 2 * NW], df = (int)side[(size_t)c * (2 * NW + 4) + 2 * NW + 1];
+        if (j > 0) mont_mul(winv, run, pref[j - 1], P); else fp_set(winv, run);
+        mont_mul(w, cs, l, P);
+        mont_mul(run, run, w, P);
+        mont_mul(inv_c, winv, l, P);               // 1 / cs
+        mont_mul(linv, winv, cs, P);               // 1 / l
+        uint32_t inv_c_plain[NL], pw[NL];
+        from_mont(inv_c_plain, inv_c, P);          // out of Montgomery form: (u R) b / R = u b, canonical
+        from_mont(pw, linv, P);
+        const int nloc = errlen[c];
+        // (four elements' loads in flight at a time: in place, so the compiler will not move a load above the previous store by itself)
+        for (int e0 = 0; e0 < nloc; e0 += 4) {
+            uint32_t u[4][NL];
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                if (e0 + v < nloc) load_digits<NL, NW>(u[v], errloc + ((size_t)c * (npts + 1) + e0 + v) * NW);
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                if (e0 + v < nloc) {
+                    uint32_t e[NL];
+                    mont_mul(e, u[v], inv_c_plain, P);
+                    store_digits<NL, NW>(errloc + ((size_t)c * (npts + 1) + e0 + v) * NW, e);
+                }
+        }
+        // i = dq .. 0: the power of 1 / l grows by one per step; only i <= df < k carry a non-zero digit
+        for (int i0 = dq; i0 >= 0; i0 -= 4) {
+            uint32_t u[4][NL];
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+                if (i0 - v >= 0 && i0 - v <= df) load_digits<NL, NW>(u[v], coeffs + ((size_t)c * k + i0 - v) * NW);
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                const int i = i0 - v;
+                if (i < 0) break;
+                if (i <= df) {
+                    uint32_t f[NL];
+                    mont_mul(f, u[v], pw, P);
+                    store_digits<NL, NW>(coeffs + ((size_t)c * k + i) * NW, f);
+                }
+                if (i > 0) mont_mul(pw, pw, linv, P);
+            }
+        }
     }
 }
 
@@ -542,7 +592,7 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     uint32_t *side = nullptr;
     const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
     if (hipMalloc(&side, (size_t)C * side_words * 4) != hipSuccess) { (void)hipFree(g1); return fail(ctx, HB_ERR_HIP, "gao: side buffer"); }
-    const unsigned fin_blocks = (unsigned)((C + 63) / 64);
+    const unsigned fin_blocks = (unsigned)(((C + GAO_FIN_G - 1) / GAO_FIN_G + 63) / 64);
     // 2 p^2 in radix-2^29 digits (schoolbook on 32-bit words)
     uint32_t k2pp[18];
     {

@@ -346,6 +346,87 @@ def test_device_decoder_worst_case_adversaries(n, t, c, pattern):
         assert dev.probes + dev.radius_verdicts >= (1 if pattern == "everywhere" else len({1 + (r * 7) % (c - 1) for r in range(t)}))
 
 
+def test_symbols_fetch_matches_the_buffer():
+    """hb_symbols_fetch: the symbols of one polynomial in a few columns, through pinned memory -- against plain indexing of the same buffer;
+    bad arguments are refused"""
+    import numpy as np
+    import torch
+
+    from honeybadgermpc_amd._capi import HB_ERR_BAD_ARG, Context, np_ptr
+
+    ctx = Context.get(P)
+    rnd = random.Random(17)
+    n, c = 70, 37
+    cols = ctx.upload_ints([rnd.randrange(P) for _ in range(n * c)]).view(n, c, 4)
+    host = cols.cpu().numpy()
+    for count in (1, 2, 5, 64):
+        for chunk in (0, 11, c - 1):
+            idx = np.asarray([rnd.randrange(n) for _ in range(count)], dtype=np.int32)
+            out = np.full((count, 4), -1, dtype=np.int64)
+            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), c, chunk, np_ptr(idx), count, np_ptr(out), ctx.stream()), "hb_symbols_fetch")
+            assert (out == host[idx, chunk]).all(), (count, chunk)
+    idx = np.zeros(65, dtype=np.int32)
+    out = np.zeros((65, 4), dtype=np.int64)
+    for count, chunk in ((0, 0), (65, 0), (1, c), (1, -1)):
+        assert ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), c, chunk, np_ptr(idx), count, np_ptr(out), ctx.stream()) == HB_ERR_BAD_ARG
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("shared", [0, 3, 5])
+def test_device_decoder_candidates_against_coordinated_liars(shared):
+    """The liars all send the values of ONE other polynomial of the right degree (equal to the true one at `shared` honest points, so that
+    those honest senders "agree" with the fake too) and arrive first, then t + 1 of them: the word Gao is offered decodes to the fake at some
+    prefixes.  The decoder's waiting candidates (device.py _candidate_cap: no incremental decode while a candidate's disagreements stay
+    within max_errors - confirmed) must take the reference's decisions column by column -- against the host mirror of IncrementalDecoder."""
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+    from honeybadgermpc_amd.reed_solomon import Algorithm, DecoderFactory, EncoderFactory, IncrementalDecoder, RobustDecoderFactory
+
+    ctx = Context.get(P)
+    rnd = random.Random(100 + shared)
+    n, t, c = 16, 5, 7
+    point = EvalPoint(GF(P), n)
+    xs = [point(i).value for i in range(n)]
+    ev = lambda poly, x: sum(co * pow(x, e, P) for e, co in enumerate(poly)) % P  # noqa: E731
+    for liar_count in (t, t + 1):
+        polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+        liars = rnd.sample(range(n), liar_count)
+        honest = [i for i in range(n) if i not in liars]
+        rnd.shuffle(honest)
+        fakes = []
+        for poly in polys:
+            q, deg = [rnd.randrange(1, P)] + [0] * t, 0
+            for s_ in honest[:shared]:
+                nq = [0] * (t + 1)
+                for e in range(deg + 1):
+                    nq[e + 1] = (nq[e + 1] + q[e]) % P
+                    nq[e] = (nq[e] - q[e] * xs[s_]) % P
+                q, deg = nq, deg + 1
+            fakes.append([(a + b) % P for a, b in zip(poly, q)])
+        cols = [[ev(fakes[j] if i in liars else polys[j], xs[i]) for j in range(c)] for i in range(n)]
+        order = liars + honest
+        host = IncrementalDecoder(EncoderFactory.get(point, Algorithm.VANDERMONDE), DecoderFactory.get(point, Algorithm.VANDERMONDE),
+                                  RobustDecoderFactory.get(t, point, algorithm=Algorithm.GAO), degree=t, batch_size=c, max_errors=t)
+        dev = DeviceIncrementalDecoder(P, n, t, batch_size=c)
+        for step, idx in enumerate(order):
+            host.add(idx, cols[idx])
+            dev.add(idx, ctx.upload_ints(cols[idx]))
+            assert dev.done() == host.done(), (liar_count, step)
+            assert dev._confirmed_errors == host._confirmed_errors and dev._z == host._z and dev._num_decoded == host._num_decoded, (liar_count, step)
+            if host.done():
+                break
+        assert host.done() == dev.done()
+        if host.done():
+            hres, herr = host.get_results()
+            dres, derr = dev.get_results()
+            assert derr == herr
+            assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in hres for v in row]
+        if liar_count == t and shared == 0:
+            assert dev.probes == 0 and dev.radius_verdicts >= 1          # the newest columns gave the true polynomial: nothing incremental ran
+
+
 def test_device_decoder_randomised_vs_host_mirror():
     """~20 s, seeded: the bounded twin of scratch/stress_decoder.py (which found a missed Welch-Berlekamp refusal in the first
     version of the plan-free path: 94 divergences in 36 444 decodes, all of that one kind; 0 in 22 898 after the fix).  Random
