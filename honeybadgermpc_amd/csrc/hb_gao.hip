@@ -24,7 +24,6 @@
 #include <algorithm>
 
 #include "hb_common.hpp"
-#include <type_traits>
 
 using namespace hb;
 
@@ -119,8 +118,11 @@ template <int NL> struct GaoConsts { uint32_t k2pp[2 * NL]; };
 // digit is q_i = c_i / l^(dq - i + 1)), the raw c_i and V leave in Montgomery form, packed, in the output buffers, with cs and l in
 // a side record -- and k_gao_finish, one LANE per codeword, inverts w = cs l (64 different inversions per wave for the price of
 // one) and scales the outputs in place.
+#ifndef GAO_WAVES_PER_EU
+#define GAO_WAVES_PER_EU 3
+#endif
 template <int NL, int NW>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_gao(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAVES_PER_EU))) k_gao(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
                                             int npts, int k, int64_t C, uint32_t *__restrict__ coeffs, uint32_t *__restrict__ errloc,
                                             int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag, uint32_t *__restrict__ side, const GaoConsts<NL> GK) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -183,10 +185,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
                 int32_t nLa1[NL], na0[NL];
 #pragma unroll
                 for (int q = 0; q < NL; q++) { sL2[q] = 0; nLa1[q] = 0; na0[q] = 0; }
-                // one round, its kind a compile-time constant (the first round's code then has no roles, no selects, no job operands):
-                // 2: the scalars of THIS step alone (first step, or after a degree anomaly); 0, 1: the two rounds
-                auto round = [&](auto rd_c) {
-                    constexpr int rd = decltype(rd_c)::value;
+                for (int st = have_sc ? 1 : 0; st < 3; st++) {
+                    // (one body for the three kinds of round: with the kind a compile-time constant -- three copies, the first without roles,
+                    // selects and job operands -- the kernel spilled 112 bytes and ran 24.8 ms against 23.7)
+                    const int rd = st == 0 ? 2 : st - 1;          // 2: the scalars of THIS step alone (first step, or after a degree anomaly); 0, 1: the two rounds
                     if (rd == 0) {
                         uint32_t t1[NL], t2[NL];
                         lds_get<NL>(sL2, SC);
@@ -265,10 +267,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) k_
                         for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)r[q], 63);
                     }
                     __syncthreads();
-                };
-                if (!have_sc) round(std::integral_constant<int, 2>{});
-                round(std::integral_constant<int, 0>{});
-                round(std::integral_constant<int, 1>{});
+                }
                 if (lane < 2) {
 #pragma unroll
                     for (int q = 0; q < NL; q++) R0[(size_t)(top + lane) * NL + q] = 0;
