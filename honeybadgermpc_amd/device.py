@@ -801,11 +801,12 @@ class DeviceIncrementalDecoder:
         return [cand for cand in cands if len(cand[1]) <= cap]
 
     def _candidate_errors(self, coeffs, chunk):
-        t = self.ctx.torch
-        ev = self._disagreeing(coeffs)
-        zt = t.tensor(self._z, dtype=t.int64, device=self.ctx.tdev)
-        differs = (ev.index_select(0, zt) != self._cols[:, chunk, :].index_select(0, zt)).any(dim=1)
-        return [self._z[i] for i in t.nonzero(differs).flatten().tolist()]
+        """-> (the arrived senders whose symbol of `chunk` differs from the candidate at their point, the candidate's values at the n points
+        on the host): one small evaluation, its values and the arrived symbols of the chunk brought over, compared there"""
+        ev = self._disagreeing(coeffs).cpu().numpy()
+        sym = self._symbols(chunk, self._z)
+        differs = (sym != ev[np.asarray(self._z, dtype=np.int64)]).any(axis=1)
+        return [s_ for s_, df in zip(self._z, differs) if df], ev
 
     # One launch names EVERY chunk some compared sender disagrees on (hb_quick_interp_check_map), and the candidates of an interpolation
     # set do not change when a compared sender is expelled: while the interpolation set stands and no new column has arrived, the
@@ -842,9 +843,10 @@ class DeviceIncrementalDecoder:
         return {c: {s for s in np.nonzero(differs[:, j])[0].tolist() if s in arrived} for j, c in enumerate(chunks)}
 
     def _scan_errors(self, dec, first):
+        """-> (errors, the candidate's values at the n points or None when the table answered)"""
         sc = self._scan
         if sc is not None and dec is sc["dec"] and first in sc["table"]:
-            return [s for s in self._z if s in sc["table"][first]]
+            return [s for s in self._z if s in sc["table"][first]], None
         return self._candidate_errors(dec[first], first)
 
     def _wb_refusal(self, lo):
@@ -939,17 +941,17 @@ class DeviceIncrementalDecoder:
             radius = (len(self._z) - d) // 2
             cap = self._candidate_cap(radius)
             cands = []
-            errors = self._scan_errors(dec, first)
+            errors, ev = self._scan_errors(dec, first)
             if len(errors) <= cap:
-                cands.append([dec[first].clone(), list(errors), None])
+                cands.append([dec[first].clone() if ev is None else None, list(errors), ev])   # (the coefficients only serve to make ev)
             if len(errors) > radius and len(self._z) > d:
                 if len(errors) > cap:
                     self._probe_ahead(first)             # (a second candidate is tried first; the probe catches up meanwhile)
                 tail_split = not tail_split
                 dec2, _, _ = self._quick(*self._split(tail_split), lo=first, hi=first + 1)      # this one polynomial only
-                errors = self._candidate_errors(dec2[first], first)
+                errors, ev = self._candidate_errors(dec2[first], first)
                 if len(errors) <= cap:
-                    cands.insert(0 if len(errors) <= radius else len(cands), [dec2[first].clone(), list(errors), None])
+                    cands.insert(0 if len(errors) <= radius else len(cands), [None, list(errors), ev])
             if len(errors) <= radius:
                 self._prefer_tail = tail_split
                 if len(self._available_points) - len(errors) < self._min_points_required():
