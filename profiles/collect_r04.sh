@@ -33,8 +33,18 @@ timeout 900 python scratch/bench_device_decoder.py > "$OUT/device_decoder.txt" 2
 timeout 900 python scratch/bench_device_decoder.py --copy > "$OUT/device_decoder_copied_columns.txt" 2>&1
 timeout 600 python scratch/decoder_cfg5_shape.py > "$OUT/decoder_cfg5_shape.txt" 2>&1
 timeout 600 python scratch/time_first_sight.py > "$OUT/first_sight_host_phases.txt" 2>&1
+timeout 600 python scratch/first_sight_outliers.py 1500 all > "$OUT/first_sight_outliers.txt" 2>&1
+timeout 600 python scratch/first_sight_outliers.py 1500 all nogc >> "$OUT/first_sight_outliers.txt" 2>&1
+timeout 300 python scratch/dec21.py > "$OUT/dec21_cfg3.txt" 2>&1
+timeout 300 python scratch/dec21.py 256 85 > "$OUT/dec21_cfg5.txt" 2>&1
+timeout 300 python scratch/time_fetch.py > "$OUT/symbols_fetch.txt" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dec21" -o run -- python scratch/dec21.py 256 85 > "$OUT/stats_dec21.log" 2>&1
+python profiles/summarize_rocpd.py "$OUT/stats_dec21/run_results.db" > "$OUT/kernel_stats_dec21_cfg5.txt" 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d "$OUT/c4_sq" -o p -- python bench.py --workload cfg4 --steps 2 --warmup 1 --cpu-sample 0 > "$OUT/c4_sq.log" 2>&1
+timeout 900 python profiles/summarize_pmc.py "$OUT"/c4_sq > "$OUT/pmc_sq_cfg4.txt" 2>&1
+timeout 400 python scratch/stress_decoder.py 240 31 > "$OUT/stress_decoder.txt" 2>&1
 timeout 900 python scratch/bench_coalescer.py > "$OUT/coalescer.txt" 2>&1
 timeout 900 python scratch/boundary_rates.py > "$OUT/boundary_rates.txt" 2>&1
 # the raw traces (rocpd databases, counter CSVs) stay on the box: gpurun brings back 64 MiB at most, and the summaries above are what profiles/ keeps
-rm -rf "$OUT"/stats "$OUT"/stats_* "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_WAVES "$OUT"/c4_pmc_*
+rm -rf "$OUT"/stats "$OUT"/stats_cfg4 "$OUT"/stats_dec21 "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_SQ_WAVES "$OUT"/c4_pmc_* "$OUT"/c4_sq
 tail -1 "$OUT/bench_default.json" | cut -c1-300

@@ -372,8 +372,8 @@ def test_symbols_fetch_matches_the_buffer():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("shared", [0, 3, 5])
-def test_device_decoder_candidates_against_coordinated_liars(shared):
+@pytest.mark.parametrize("n, t, c, use_omega, shared", [(16, 5, 7, False, 0), (16, 5, 7, False, 3), (16, 5, 7, False, 5), (16, 5, 4, True, 2), (64, 21, 2, False, 9)])
+def test_device_decoder_candidates_against_coordinated_liars(n, t, c, use_omega, shared):
     """The liars all send the values of ONE other polynomial of the right degree (equal to the true one at `shared` honest points, so that
     those honest senders "agree" with the fake too) and arrive first, then t + 1 of them: the word Gao is offered decodes to the fake at some
     prefixes.  The decoder's waiting candidates (device.py _candidate_cap: no incremental decode while a candidate's disagreements stay
@@ -385,9 +385,9 @@ def test_device_decoder_candidates_against_coordinated_liars(shared):
     from honeybadgermpc_amd.reed_solomon import Algorithm, DecoderFactory, EncoderFactory, IncrementalDecoder, RobustDecoderFactory
 
     ctx = Context.get(P)
-    rnd = random.Random(100 + shared)
-    n, t, c = 16, 5, 7
-    point = EvalPoint(GF(P), n)
+    rnd = random.Random(100 + shared + n)
+    point = EvalPoint(GF(P), n, use_omega_powers=use_omega)
+    codec = Algorithm.FFT if use_omega else Algorithm.VANDERMONDE
     xs = [point(i).value for i in range(n)]
     ev = lambda poly, x: sum(co * pow(x, e, P) for e, co in enumerate(poly)) % P  # noqa: E731
     for liar_count in (t, t + 1):
@@ -407,9 +407,9 @@ def test_device_decoder_candidates_against_coordinated_liars(shared):
             fakes.append([(a + b) % P for a, b in zip(poly, q)])
         cols = [[ev(fakes[j] if i in liars else polys[j], xs[i]) for j in range(c)] for i in range(n)]
         order = liars + honest
-        host = IncrementalDecoder(EncoderFactory.get(point, Algorithm.VANDERMONDE), DecoderFactory.get(point, Algorithm.VANDERMONDE),
+        host = IncrementalDecoder(EncoderFactory.get(point, codec), DecoderFactory.get(point, codec),
                                   RobustDecoderFactory.get(t, point, algorithm=Algorithm.GAO), degree=t, batch_size=c, max_errors=t)
-        dev = DeviceIncrementalDecoder(P, n, t, batch_size=c)
+        dev = DeviceIncrementalDecoder(P, n, t, batch_size=c, use_omega_powers=use_omega)
         for step, idx in enumerate(order):
             host.add(idx, cols[idx])
             dev.add(idx, ctx.upload_ints(cols[idx]))
