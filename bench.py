@@ -811,9 +811,13 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
         return
     alg_bytes = 32 * C * (n + k)
     achieved = alg_bytes / (call_ms * 1e-3) / 1e9
-    # arithmetic of one codeword (fraction-free EEA + pseudo-division): t + 1 division steps of two sub-steps over ~n coefficients
-    # (remainder + cofactor) with two products each, then t + 1 quotient digits over ~(n + k) / 2 coefficients, two products each
-    mulmods_cw = (t + 1) * 2 * n * 2 + (t + 1) * ((n + k) // 2) * 2
+    # arithmetic of one codeword as k_gao / k_gao_finish are built, in 64-bit multiply-adds of useful lanes (a 9 x 9-digit product is
+    # 81 of them, a Montgomery reduction 81 more): t Euclid steps, each ONE update of the remainder's n - 1 - s coefficients, the cofactor's s + 2,
+    # the scale factor and the three scalars of the next step -- n + 5 elements, three products and one reduction each; k quotient digits of the
+    # fraction-free division over i + t coefficients, two products and one reduction each; n symbols into Montgomery form; the finisher's 2 (t + 1)
+    # scalings, five multiplications and a quarter of a 380-multiplication inversion
+    mads_cw = t * (n + 5) * 4 * 81 + sum(i + t for i in range(k)) * 3 * 81 + n * 2 * 81 + (2 * (t + 1) + 5 + 380 // 4) * 2 * 81
+    mad_peak = 1024 * 64 * 2.4e9 / 4.4
     counters = profile_counters(args.workload if args.workload == "cfg4" else "cfg4")
     line = {
         "metric": f"codewords robust-decoded/sec (Welch-Berlekamp, t injected errors, n={n} t={t})", "value": world * C * steps / dt, "unit": "codewords/s",
@@ -831,13 +835,16 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": call_ms,
             "launch_note": "one hb_wb_decode call (synchronous: three kernels + the radius bookkeeping), bracketed by HIP events on the call's stream; "
                            "SURVEY 8d's 32 C (n + k) bytes; the kernel-by-kernel split is in profiles/",
-            "second": {"bound": "mulmod-issue", "achieved": C * mulmods_cw / (call_ms * 1e-3) / 1e9, "unit": "G mulmod/s",
-                       "mulmods_per_codeword": mulmods_cw,
-                       "peak": 1024 * 64 * 2.4 / 4.4 / (2 * 81 + 60) * 1e0,
-                       "peak_note": "1024 SIMDs x 64 lanes x 2.4 GHz / 4.4 cycles per v_mad_u64_u32 wave-instruction (half rate, profiles/r01_instruction_rates_ubench.txt) "
-                                    "/ ~222 multiply-adds per modular multiplication with its share of a reduction (81 for the product, 81 + carries for REDC)",
-                       "frac": (C * mulmods_cw / (call_ms * 1e-3) / 1e9) / (1024 * 64 * 2.4 / 4.4 / (2 * 81 + 60))},
-            "note": "purely arithmetic-bound: ~1.6 10^4 modular multiplications per 4.3 KB codeword; the HBM fraction is what SURVEY 8d asks for, the mulmod rate says how busy the chip is",
+            "second": {"bound": "multiply-add issue", "achieved": C * mads_cw / (call_ms * 1e-3) / 1e12, "unit": "T 64-bit multiply-adds/s (useful lanes)",
+                       "multiply_adds_per_codeword": mads_cw,
+                       "peak": mad_peak / 1e12,
+                       "peak_note": "1024 SIMDs x 64 lanes x 2.4 GHz / 4.4 cycles per v_mad_u64_u32 wave-instruction (half rate, profiles/r01_instruction_rates_ubench.txt)",
+                       "frac": C * mads_cw / (call_ms * 1e-3) / mad_peak,
+                       "frac_note": "what separates it from 1: a round of 64 lanes runs for ~105 elements of a step (0.82), the multiply-adds are 47 % of the "
+                                    "wave-instructions k_gao issues (profiles/r04_pmc_cfg4.txt: carries, selects, LDS, the conditional subtraction), the "
+                                    "interpolant's matrix-core launch is in the time and not in the count.  Round 3's line counted the two-sub-step algorithm's "
+                                    "multiplications (2.6 times as many multiply-adds per codeword): its fraction is not comparable"},
+            "note": "purely arithmetic-bound: ~1.6 10^6 multiply-adds per 4.3 KB codeword; the HBM fraction is what SURVEY 8d asks for, the multiply-add rate says how busy the chip is",
         },
         "detail": {"shares_equivalent_per_s": world * C * k * steps / dt,
                    "gao_codewords_per_s_per_gpu": C * steps / dt_gao, "gao_ms_per_step": dt_gao * 1e3 / steps,

@@ -1186,9 +1186,11 @@ int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *c
     return HB_OK;
 }
 
-int hb_symbols_fetch(hb_ctx *ctx, const uint64_t *cols_dev, int64_t C, int64_t chunk, const int32_t *idx, int count, uint64_t *out_host, void *stream) {
+int hb_symbols_fetch(hb_ctx *ctx, const uint64_t *cols_dev, int n, int64_t C, int64_t chunk, const int32_t *idx, int count, uint64_t *out_host, void *stream) {
     HB_API_GUARD(ctx);
-    if (!ctx || !cols_dev || !idx || !out_host || count < 1 || count > FETCH_MAX || C < 1 || chunk < 0 || chunk >= C) return fail(ctx, HB_ERR_BAD_ARG, "symbols_fetch: arguments");
+    if (!ctx || !cols_dev || !idx || !out_host || n < 1 || count < 1 || count > FETCH_MAX || C < 1 || chunk < 0 || chunk >= C) return fail(ctx, HB_ERR_BAD_ARG, "symbols_fetch: arguments");
+    for (int i = 0; i < count; i++)
+        if (idx[i] < 0 || idx[i] >= n) return fail(ctx, HB_ERR_BAD_ARG, "symbols_fetch: party index out of range");
     if (!ctx->fetch_host) {
         void *h = nullptr, *dv = nullptr;
         HB_HIP(ctx, hipHostMalloc(&h, sizeof(SymFetch), hipHostMallocMapped));

@@ -778,12 +778,12 @@ class DeviceIncrementalDecoder:
                 ia, out = np.empty(1, dtype=np.int32), np.empty((1, self.L), dtype=np.int64)
                 fx = self._fetch1 = (ia, out, np_ptr(ia), np_ptr(out), ctx.ptr(self._cols))
             fx[0][0] = senders[0]
-            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, fx[4], self.batch_size, chunk, fx[2], 1, fx[3], ctx.stream()), "hb_symbols_fetch")
+            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, fx[4], self.n, self.batch_size, chunk, fx[2], 1, fx[3], ctx.stream()), "hb_symbols_fetch")
             return fx[1]
         out = np.empty((len(senders), self.L), dtype=np.int64)
         for lo in range(0, len(senders), 64):
             part = np.asarray(senders[lo:lo + 64], dtype=np.int32)
-            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(self._cols), self.batch_size, chunk, np_ptr(part), len(part), np_ptr(out[lo:lo + 64]), ctx.stream()),
+            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(self._cols), self.n, self.batch_size, chunk, np_ptr(part), len(part), np_ptr(out[lo:lo + 64]), ctx.stream()),
                       "hb_symbols_fetch")
         return out
 

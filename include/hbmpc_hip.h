@@ -154,11 +154,11 @@ int hb_quick_dec_decide(hb_quick_dec *qd, const int32_t *zc, int nc, const uint6
                         uint64_t *coeffs_dev, int32_t *flag, int32_t *first, void *stream);
 void hb_quick_dec_destroy(hb_quick_dec *qd);
 
-/* The symbols of polynomial `chunk` in the columns of parties idx[0..count), count <= 64, of the party-major buffer cols_dev [n][C], to
+/* The symbols of polynomial `chunk` in the columns of parties idx[0..count) (each in [0, n), count <= 64) of the party-major buffer cols_dev [n][C], to
  * out_host[count][limbs]: what IncrementalDecoder compares a new sender's share with (reed_solomon.py:318-321, data[i] against the guess) when
  * the guess is a candidate for ONE polynomial (device.py _candidate_cap).  One launch that writes pinned memory the call polls: the answer
  * is on the host a few microseconds after the columns are, where a synchronous 32-byte copy costs a stream synchronisation. */
-int hb_symbols_fetch(hb_ctx *ctx, const uint64_t *cols_dev, int64_t C, int64_t chunk, const int32_t *idx, int count, uint64_t *out_host, void *stream);
+int hb_symbols_fetch(hb_ctx *ctx, const uint64_t *cols_dev, int n, int64_t C, int64_t chunk, const int32_t *idx, int count, uint64_t *out_host, void *stream);
 
 /* gao_interpolate for ONE codeword, incremental in its points (rsdecode_impl.h:325-363 as GaoRobustDecoder.robust_decode
  * runs it per polynomial, reed_solomon.py:151-186, 334-365): the probe keeps a reduced basis of the interpolation module of

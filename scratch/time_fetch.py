@@ -21,13 +21,13 @@ torch.cuda.synchronize()
 for rep in range(3):
     t0 = time.perf_counter()
     for i in range(1000):
-        ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), C, 7, np_ptr(ia), 1, np_ptr(out), ctx.stream())
+        ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), n, C, 7, np_ptr(ia), 1, np_ptr(out), ctx.stream())
     dt = time.perf_counter() - t0
     print(f"hb_symbols_fetch: {dt * 1e3:.2f} us per call (incl. ctx.ptr / ctx.stream / np_ptr)")
 st = ctx.stream(); pc = ctx.ptr(cols); pi = np_ptr(ia); po = np_ptr(out)
 t0 = time.perf_counter()
 for i in range(1000):
-    ctx.lib.hb_symbols_fetch(ctx.h, pc, C, 7, pi, 1, po, st)
+    ctx.lib.hb_symbols_fetch(ctx.h, pc, n, C, 7, pi, 1, po, st)
 print(f"hb_symbols_fetch, arguments prepared: {(time.perf_counter() - t0) * 1e3:.2f} us per call")
 data = cols.clone()
 for i in range(t):

@@ -363,12 +363,14 @@ def test_symbols_fetch_matches_the_buffer():
         for chunk in (0, 11, c - 1):
             idx = np.asarray([rnd.randrange(n) for _ in range(count)], dtype=np.int32)
             out = np.full((count, 4), -1, dtype=np.int64)
-            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), c, chunk, np_ptr(idx), count, np_ptr(out), ctx.stream()), "hb_symbols_fetch")
+            ctx.check(ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), n, c, chunk, np_ptr(idx), count, np_ptr(out), ctx.stream()), "hb_symbols_fetch")
             assert (out == host[idx, chunk]).all(), (count, chunk)
     idx = np.zeros(65, dtype=np.int32)
     out = np.zeros((65, 4), dtype=np.int64)
     for count, chunk in ((0, 0), (65, 0), (1, c), (1, -1)):
-        assert ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), c, chunk, np_ptr(idx), count, np_ptr(out), ctx.stream()) == HB_ERR_BAD_ARG
+        assert ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), n, c, chunk, np_ptr(idx), count, np_ptr(out), ctx.stream()) == HB_ERR_BAD_ARG
+    idx[0] = n
+    assert ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), n, c, 0, np_ptr(idx), 1, np_ptr(out), ctx.stream()) == HB_ERR_BAD_ARG
     torch.cuda.synchronize()
 
 
