@@ -103,6 +103,9 @@ struct hb_ctx {
     std::vector<QuickSlot> qslots;
     unsigned qnext = 0;
     std::vector<void *> probe_pool, probe_host_pool;
+    // Scratch of the batched robust decoders (hb_gao_decode / hb_wb_decode: interpolants, locators, side records -- 0.85 GB each at config 4),
+    // kept with the context and reused by the next call: ctx_scratch() below
+    std::map<std::string, std::pair<void *, size_t>> scratch;
     void *fetch_host = nullptr, *fetch_dev = nullptr; // hb_symbols_fetch: pinned, device-visible hand-over buffer (hb::SymFetch)
     int fetch_seq = 0;
     std::map<int, void *> wide_shared;                // d -> hb::Mm8wShared *
@@ -123,6 +126,27 @@ struct hb_api_guard {
     hb_api_guard &operator=(const hb_api_guard &) = delete;
 };
 #define HB_API_GUARD(ctxexpr) hb_api_guard hb_api_guard__(ctxexpr)
+
+// A named device buffer of at least `bytes` that lives as long as the context (or until hb_ctx_cache_clear): grown when a call asks for more.
+// For the temporaries of entry points that (a) hold the context's mutex from start to finish and (b) synchronise their stream before they
+// return -- so no two calls ever use a slot at once and nothing is in flight when the next call reuses or regrows it.  A hipMalloc + hipFree
+// pair of config 4's sizes cost 5-14 ms of a 27 ms decode on some boxes (profiles/r04_bench_cfg4*: 41 ms a call against 27).
+inline int ctx_scratch(hb_ctx *ctx, const char *slot, size_t bytes, void **out) {
+    auto &e = ctx->scratch[slot];
+    if (e.second < bytes || !e.first) {
+        if (e.first) { (void)hipFree(e.first); e.first = nullptr; e.second = 0; }
+        const size_t want = bytes ? bytes : 4;
+        const hipError_t err = hipMalloc(&e.first, want);
+        if (err != hipSuccess) { e.first = nullptr; ctx->err = std::string("scratch ") + slot + ": " + hipGetErrorString(err); return HB_ERR_HIP; }
+        e.second = want;
+    }
+    *out = e.first;
+    return HB_OK;
+}
+inline void ctx_scratch_free(hb_ctx *ctx) {
+    for (auto &kv : ctx->scratch) if (kv.second.first) (void)hipFree(kv.second.first);
+    ctx->scratch.clear();
+}
 
 #define HB_HIP(ctx, call)                                                                         \
     do {                                                                                          \

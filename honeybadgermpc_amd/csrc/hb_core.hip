@@ -525,6 +525,7 @@ void hb_ctx_destroy(hb_ctx *ctx) {
     point_tables_free(ctx);
     mm8w_shared_free(ctx);
     mm8_shared_free(ctx);
+    ctx_scratch_free(ctx);
     delete ctx;
 }
 
@@ -935,6 +936,8 @@ int hb_ctx_cache_clear(hb_ctx *ctx) { HB_API_GUARD(ctx);
     if (!ctx) return HB_ERR_BAD_ARG;
     (void)hipSetDevice(ctx->device);
     cache_drop_down_to(ctx, 0);
+    (void)hipDeviceSynchronize();
+    ctx_scratch_free(ctx);                  // (the robust decoders' scratch: regrown by their next call)
     return HB_OK;
 }
 // number of table-cache entries currently resident (pinned ones included)

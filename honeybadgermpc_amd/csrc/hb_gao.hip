@@ -581,16 +581,17 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
         cache_note(ctx, "d|" + key, [ctx, key]() { auto f = ctx->dcache.find(key); if (f != ctx->dcache.end()) { (void)hipFree(f->second); ctx->dcache.erase(f); } });
     }
     // g1 for every codeword: chunk-major [C][npts] (coefficient-major made every 32-byte read of k_gao fetch a whole 128-byte line: 12.5 KB per codeword for 3.2)
+    // (g1 and the side records are context scratch -- ctx_scratch, hb_common.hpp: this call holds the context's mutex and synchronises before it returns)
     uint32_t *g1 = nullptr;
-    HB_HIP(ctx, hipMalloc(&g1, (size_t)npts * C * ctx->elem_words() * 4));
+    rc = ctx_scratch(ctx, "gao.g1", (size_t)npts * C * ctx->elem_words() * 4, (void **)&g1); if (rc) return rc;
     hb_view iv{npts, 1}, ov{npts, 1};
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
-    if (rc) { (void)hipFree(g1); return rc; }
+    if (rc) return rc;
     size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 4) * NLr * 4;      // R0, R1, T0, T1, a zero element, three scalars
     // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one
     uint32_t *side = nullptr;
     const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
-    if (hipMalloc(&side, (size_t)C * side_words * 4) != hipSuccess) { (void)hipFree(g1); return fail(ctx, HB_ERR_HIP, "gao: side buffer"); }
+    rc = ctx_scratch(ctx, "gao.side", (size_t)C * side_words * 4, (void **)&side); if (rc) return rc;
     const unsigned fin_blocks = (unsigned)(((C + GAO_FIN_G - 1) / GAO_FIN_G + 63) / 64);
     // 2 p^2 in radix-2^29 digits (schoolbook on 32-bit words)
     uint32_t k2pp[18];
@@ -627,8 +628,6 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     }
     const hipError_t le = hipGetLastError();
     const hipError_t se = hipStreamSynchronize(s);
-    (void)hipFree(g1);
-    (void)hipFree(side);
     if (le != hipSuccess || se != hipSuccess) { ctx->err = std::string("gao: ") + hipGetErrorString(le != hipSuccess ? le : se); return HB_ERR_HIP; }
     return HB_OK;
 }
