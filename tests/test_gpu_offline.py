@@ -372,6 +372,20 @@ def test_symbols_fetch_matches_the_buffer():
     idx[0] = n
     assert ctx.lib.hb_symbols_fetch(ctx.h, ctx.ptr(cols), n, c, 0, np_ptr(idx), 1, np_ptr(out), ctx.stream()) == HB_ERR_BAD_ARG
     torch.cuda.synchronize()
+    # a one-limb context (p < 2^64): one word per symbol
+    import ctypes
+
+    from honeybadgermpc_amd._capi import ints_to_limbs, load_library
+
+    lib, p64 = load_library(), (1 << 64) - 59
+    h = ctypes.c_void_p()
+    assert lib.hb_ctx_create(ctypes.byref(h), np_ptr(ints_to_limbs([p64], p64 + 1, 8)), 1, 0) == 0
+    narrow = torch.from_numpy(np.array([rnd.randrange(p64) for _ in range(n * c)], dtype=np.uint64).view(np.int64).copy()).cuda().view(n, c, 1)
+    idx = np.asarray([5, 0, n - 1], dtype=np.int32)
+    out = np.zeros((3, 1), dtype=np.int64)
+    assert lib.hb_symbols_fetch(h, ctypes.c_void_p(narrow.data_ptr()), n, c, 7, np_ptr(idx), 3, np_ptr(out), None) == 0
+    assert (out == narrow.cpu().numpy()[idx, 7]).all()
+    lib.hb_ctx_destroy(h)
 
 
 @pytest.mark.parametrize("n, t, c, use_omega, shared", [(16, 5, 7, False, 0), (16, 5, 7, False, 3), (16, 5, 7, False, 5), (16, 5, 4, True, 2), (64, 21, 2, False, 9)])
