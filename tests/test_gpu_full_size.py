@@ -156,6 +156,61 @@ def test_full_size_open_cfg5_shard():
 
 
 # ---------------------------------------------------------------------------------------------- bounded stress
+@pytest.mark.parametrize("n, t, b, use_omega, spread", [(64, 21, 1 << 20, False, False), (256, 85, (1 << 22) // 8, True, False), (64, 21, 1 << 18, False, True)])
+def test_full_size_decoder_under_attack(n, t, b, use_omega, spread):
+    """The device decoder at config 3's / config 5's shard shape with t liars that send garbage in every chunk: arriving FIRST (the newest
+    columns give a candidate that decides, device.py _candidate_cap: no incremental decode) or spread over the arrival list (no candidate
+    stands: the probe decides).  Size-independent checks: every shared polynomial comes back bit for bit, exactly the liars are named, and
+    nothing is final before the last needed column (with t liars among the arrivals the reference needs all n)."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen, DeviceIncrementalDecoder
+
+    d = t + 1
+    c = (b + d - 1) // d
+    ctx = Context.get(P)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(n + t)
+
+    def rand(count):
+        v = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 4), dtype=torch.int64, device="cuda", generator=gen)
+        v[:, 3] &= (1 << 61) - 1
+        return v
+
+    coef = rand(c * d)
+    enc = BatchOpen(P, n, t, use_omega_powers=use_omega, max_shares=c * d)
+    cols = enc.r1_encode(coef).view(n, c, 4).clone()
+    rng = np.random.Generator(np.random.PCG64(n))
+    liars = sorted(rng.choice(n, size=t, replace=False).tolist())
+    for j in liars:
+        cols[j] = rand(c)
+    honest = [j for j in rng.permutation(n).tolist() if j not in liars]
+    if spread:
+        step = len(honest) // (t + 1)
+        order = []
+        for i, j in enumerate(liars):
+            order += honest[i * step:(i + 1) * step] + [j]
+        order += honest[t * step:]
+    else:
+        order = liars + honest
+    dec = DeviceIncrementalDecoder(P, n, t, batch_size=c, use_omega_powers=use_omega, columns=cols)
+    used = 0
+    for j in order:
+        assert not dec.done()
+        dec.add(j)
+        used += 1
+        if dec.done():
+            break
+    res, errs = dec.get_results()
+    assert used == n and errs == set(liars)
+    assert torch.equal(res.reshape(-1, 4), coef)
+    if spread:
+        assert dec.probes > 0
+    else:
+        assert dec.probes == 0 and dec.radius_verdicts >= 1
+
+
 def test_randomised_differential_open_paths():
     """~60 s (HB_STRESS_SECONDS), seeded: random shapes / arrival orders / edge-heavy inputs through the matrix-core and the integer-VALU
     kernels (scratch/stress_open_paths.py ran 248 k such opens in round 1; this is its bounded twin inside the suite),
