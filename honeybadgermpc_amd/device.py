@@ -482,6 +482,7 @@ class DeviceIncrementalDecoder:
         self._memo = None               # (polynomial, (arrivals seen, their epoch), candidates [coefficients, who disagrees, values at the n points]) waiting for support
         self._prefer_tail = False       # robust phase: interpolate from the newest arrivals (True) or the oldest
         self._stalled = None            # polynomial the last robust update could not decode (the probe is on it)
+        self._probe_next = None         # (polynomial, arrival-list epoch, columns needed before the probe's verdict can matter)
         self._checked = None            # (arrival list, first chunk, coefficients, first disagreeing chunk) of a launch the robust phase may reuse
         self._scan = None               # robust phase: one launch's coefficients, ALL its disagreeing chunks and who disagrees on each (_Scan)
         self.radius_verdicts = 0        # polynomials settled by the batched launch's own candidate (diagnostic)
@@ -882,11 +883,22 @@ class DeviceIncrementalDecoder:
             self._wb_refusal(lo)
             if self._stalled == lo:
                 if self.robust == "gao":
+                    # A verdict that cannot change anything is not asked for.  If Gao failed over m columns, every polynomial is contradicted by
+                    # more than r = (m - degree - 1) // 2 of them, and by no fewer as more arrive; if it decoded with e errors, that polynomial
+                    # is the only one within r >= e, so every polynomial has at least e: either way the reference, which accepts only when
+                    # |z| - |errors| >= need (reed_solomon.py:343-345) and otherwise waits with nothing changed, waits until need + (that
+                    # bound) columns are in.  The columns that arrive meanwhile are fed to the probe in one launch at the next verdict
+                    # (85 liars spread over the arrival list at n = 256: 8 verdicts instead of 85).
+                    pn = self._probe_next
+                    if pn is not None and pn[0] == lo and pn[1] == self._z_epoch and len(self._z) < pn[2]:
+                        return
                     pr = self._borrow_probe()
                     self.probes += 1
                     errors = pr.decide(self._z, self._cols, self.batch_size, lo, after_current=not self._in_place)
                     if errors is None:
+                        self._probe_next = (lo, self._z_epoch, self._min_points_required() + (len(self._z) - d) // 2 + 1)
                         return                               # (None, None): more columns needed
+                    self._probe_next = (lo, self._z_epoch, self._min_points_required() + len(errors))
                 else:
                     # Welch-Berlekamp beyond the unique-decoding radius answers in its own way (or raises): always the real decode
                     ok, _, errs = self._robust_batch(1)
@@ -916,6 +928,11 @@ class DeviceIncrementalDecoder:
                 elif alive:
                     self._memo = (lo, (len(self._z), self._z_epoch), alive)
                     return
+                elif self.robust == "gao" and self._probe_obj is not None and self._probe_obj.poly == lo:
+                    # every candidate fell and the probe has been following this polynomial in the background (below): its verdict is the
+                    # reference's, two more batched launches for fresh candidates are not worth their 0.2-1.1 ms
+                    self._stalled = lo
+                    continue
             self._wb_refusal(lo)                             # the list may just have shrunk (expulsions above)
             chk, self._checked = self._checked, None
             tail_split = self._prefer_tail
@@ -962,7 +979,10 @@ class DeviceIncrementalDecoder:
                 self._settled = first
                 continue
             if cands:
-                # outside the radius today, but Gao can accept nothing else while these stand (_candidate_cap): no probe, wait
+                # outside the radius today, but Gao can accept nothing else while these stand (_candidate_cap): no probe verdict, wait.  The
+                # wait lasts several arrivals (|z| - E >= need is far), so the probe catches up on its own stream meanwhile: should the
+                # candidates fall -- liars that do not arrive first -- its verdict is at hand without the 43 / 171-point feed on the path
+                self._probe_ahead(first)
                 self._memo = (first, (len(self._z), self._z_epoch), cands)
                 return
             self._stalled = first                        # only the probe can say when it becomes decodable

@@ -1,4 +1,5 @@
-"""The 21-liar open at config 3's shape alone (for kernel traces): liars send garbage everywhere and arrive first."""
+"""The 21-liar open at config 3's shape alone (for kernel traces): liars send garbage everywhere and arrive first
+(third argument `spread`: one liar after every few honest senders instead -- no candidate stands, the probe decides)."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, '.')
@@ -27,6 +28,14 @@ data = cols.clone()
 for i in range(t):
     data[i] = rand(C)
 order = list(range(n))
+if len(sys.argv) > 3 and sys.argv[3] == 'spread':
+    honest = list(range(t, n)); step = len(honest) // (t + 1); order = []
+    for i in range(t):
+        order += honest[i * step:(i + 1) * step] + [i]
+    order += honest[t * step:]
+import gc
+if len(sys.argv) > 4 and sys.argv[4] == "freeze":
+    gc.collect(); gc.freeze()
 for rep in range(6):
     dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, columns=data, use_omega_powers=omega)
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -35,4 +44,4 @@ for rep in range(6):
         t1 = time.perf_counter(); dec.add(idx); marks.append(time.perf_counter() - t1)
         if dec.done(): break
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"{dt*1e3:.2f} ms; add() times us:", [round(m * 1e6) for m in marks])
+print(f"{dt*1e3:.2f} ms ({B / dt / 1e6:.0f} M shares/s; probes {dec.probes}, quick {dec.quick_launches}, in-radius {dec.radius_verdicts}); add() times us:", [round(m * 1e6) for m in marks])

@@ -84,3 +84,40 @@ def test_candidate_rule_is_the_reference_loop():
             if want is not None:
                 break                                                            # the polynomial is settled; the reference moves on
     assert prefixes > 3000 and governed > 2500 and accepted > 300 and fake_accepted > 10 and dropped > 200, (prefixes, governed, accepted, fake_accepted, dropped)
+
+
+def test_no_acceptance_before_the_bound_a_verdict_implies():
+    """The rule that lets the decoder skip probe verdicts (device.py, the stalled branch): Gao failing over m columns, or decoding with e
+    errors short of support, implies the reference accepts nothing before need + ((m - degree - 1) // 2 + 1), respectively need + e,
+    columns are in.  Every prefix of random words (garbage liars, coordinated liars, too many liars), the oracle's Gao as the decoder."""
+    rnd = random.Random(21)
+    implied = checked = accepted = 0
+    for trial in range(500):
+        p = rnd.choice([BLS, 257, 10007])
+        t = rnd.randrange(1, 8)
+        n = rnd.randrange(3 * t + 1, 3 * t + 6)
+        k = t + 1
+        need = k + t
+        xs_all = rnd.sample(range(1, min(p, 10 ** 6)), n)
+        true = [rnd.randrange(p) for _ in range(k)]
+        liars = set(rnd.sample(range(n), min(n, rnd.choice([1, t, t, t, t + 1, rnd.randrange(0, n + 1)]))))
+        fake = [rnd.randrange(p) for _ in range(k)] if rnd.random() < 0.5 else None
+        word = [(ev(fake, xs_all[j], p) if fake is not None else rnd.randrange(p)) if j in liars else ev(true, xs_all[j], p) for j in range(n)]
+        order = list(range(n))
+        rnd.shuffle(order)
+        earliest = 0                                   # no acceptance may happen with fewer columns than this
+        for m in range(k, n + 1):
+            xs, ys = [xs_all[j] for j in order[:m]], [word[j] for j in order[:m]]
+            co, el = oracle.gao_interpolate(xs, ys, k, p)
+            errors = None if co is None else ([j for j, x in enumerate(xs) if ev(el, x, p) == 0] if len(el) > 1 else [])
+            ok = errors is not None and m - len(errors) >= need
+            checked += 1
+            if ok:
+                assert m >= earliest, (trial, m, earliest)
+                accepted += 1
+                break
+            bound = need + ((m - k) // 2 + 1 if errors is None else len(errors))
+            if bound > m + 1:
+                implied += 1
+            earliest = max(earliest, bound)
+    assert checked > 2000 and implied > 300 and accepted > 100, (checked, implied, accepted)
