@@ -74,6 +74,8 @@ def main(src):
              ("decoder_cfg5_shape.txt", "scratch/decoder_cfg5_shape.py (n = 256, t = 85, one GPU's shard of config 5, omega points)"),
              ("dec21_cfg3.txt", "scratch/dec21.py (the 21-liar open at config 3's shape alone: wall clock of the sixth, add() times)"),
              ("dec21_cfg5.txt", "scratch/dec21.py 256 85 (the 85-liar open at config 5's shard shape)"),
+             ("dec21_cfg3_spread.txt", "scratch/dec21.py 64 21 spread freeze (the 21 liars one after every two honest senders: no candidate stands, the probe decides)"),
+             ("dec21_cfg5_spread.txt", "scratch/dec21.py 256 85 spread freeze (the same at config 5's shard shape)"),
              ("kernel_stats_dec21_cfg5.txt", "rocprofv3 --kernel-trace --stats -- python scratch/dec21.py 256 85 (six 85-liar opens)"),
              ("symbols_fetch.txt", "scratch/time_fetch.py (hb_symbols_fetch alone; one add() while a candidate waits, by its parts)"),
              ("first_sight_host_phases.txt", "scratch/time_first_sight.py (where the host time of a fault-free first-sight decode goes)"),

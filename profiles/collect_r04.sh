@@ -37,6 +37,8 @@ timeout 600 python scratch/first_sight_outliers.py 1500 all > "$OUT/first_sight_
 timeout 600 python scratch/first_sight_outliers.py 1500 all nogc >> "$OUT/first_sight_outliers.txt" 2>&1
 timeout 300 python scratch/dec21.py > "$OUT/dec21_cfg3.txt" 2>&1
 timeout 300 python scratch/dec21.py 256 85 > "$OUT/dec21_cfg5.txt" 2>&1
+timeout 300 python scratch/dec21.py 64 21 spread freeze > "$OUT/dec21_cfg3_spread.txt" 2>&1
+timeout 300 python scratch/dec21.py 256 85 spread freeze > "$OUT/dec21_cfg5_spread.txt" 2>&1
 timeout 300 python scratch/time_fetch.py > "$OUT/symbols_fetch.txt" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dec21" -o run -- python scratch/dec21.py 256 85 > "$OUT/stats_dec21.log" 2>&1
 python profiles/summarize_rocpd.py "$OUT/stats_dec21/run_results.db" > "$OUT/kernel_stats_dec21_cfg5.txt" 2>&1

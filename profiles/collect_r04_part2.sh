@@ -7,12 +7,13 @@ OUT="gpurun_out/$TAG"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 exec < /dev/null
-timeout 900 python bench.py --workload cfg4 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"
 timeout 900 python scratch/bench_device_decoder.py > "$OUT/device_decoder.txt" 2>&1
 timeout 900 python scratch/bench_device_decoder.py --copy > "$OUT/device_decoder_copied_columns.txt" 2>&1
 timeout 600 python scratch/decoder_cfg5_shape.py > "$OUT/decoder_cfg5_shape.txt" 2>&1
 timeout 300 python scratch/dec21.py > "$OUT/dec21_cfg3.txt" 2>&1
 timeout 300 python scratch/dec21.py 256 85 > "$OUT/dec21_cfg5.txt" 2>&1
+timeout 300 python scratch/dec21.py 64 21 spread freeze > "$OUT/dec21_cfg3_spread.txt" 2>&1
+timeout 300 python scratch/dec21.py 256 85 spread freeze > "$OUT/dec21_cfg5_spread.txt" 2>&1
 timeout 300 python scratch/time_fetch.py > "$OUT/symbols_fetch.txt" 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dec21" -o run -- python scratch/dec21.py 256 85 > "$OUT/stats_dec21.log" 2>&1
 python profiles/summarize_rocpd.py "$OUT/stats_dec21/run_results.db" > "$OUT/kernel_stats_dec21_cfg5.txt" 2>&1
