@@ -435,8 +435,10 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
             // rewritten in place (it reads its own index of both pairs); the value of Q_js too; the COEFFICIENT of Q_js takes its
             // lower neighbour, so it is held back until every thread has read: at most one a thread (2 (n + 3) <= PROBE_NT)
             const int nce = 2 * (top + 1), nitems = nce + 2 * n;
-            uint32_t keep[3][NL];
-            int kept = 0;
+            // (ONE held-back coefficient a thread: 2 (top + 1) <= 2 (n + 3) < PROBE_NT coefficient items, so a thread's second item, if any,
+            // is a value.  An array indexed by a counter here lived in scratch memory: 80 bytes a lane, a round trip to L2 per access)
+            uint32_t keep[NL];
+            bool kept = false;
             for (int e = tid; e < nitems; e += PROBE_NT) {
                 const bool is_coef = e < nce;
                 const int ee = is_coef ? e : e - nce, span = is_coef ? top + 1 : n;
@@ -466,8 +468,8 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
                         for (int w = 0; w < NL; w++) prev[w] = 0;
                     }
                     mont_mul(m, xa, v, P);
-                    if (kept < 3) fp_sub(keep[kept], prev, m, P);
-                    kept++;
+                    fp_sub(keep, prev, m, P);
+                    kept = true;
                 } else {
                     uint32_t xi[NL], df[NL], m[NL];
                     ldg<NL>(xi, xl + (size_t)i * NL);
@@ -477,11 +479,9 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
                 }
             }
             __syncthreads();
-            kept = 0;
-            for (int e = tid; e < nce; e += PROBE_NT) {
-                const int part = e / (top + 1), i = e - part * (top + 1);
-                if (kept < 3) stg<NL>(coef + ((size_t)(2 * js + part) * S + i) * NL, keep[kept]);
-                kept++;
+            if (kept) {                                   // (tid < nce: its one coefficient item)
+                const int part = tid / (top + 1), i = tid - part * (top + 1);
+                stg<NL>(coef + ((size_t)(2 * js + part) * S + i) * NL, keep);
             }
             __syncthreads();
             // new degrees: the pivot's parts grow by one, the other pair's parts become the larger of the two; a scan only when a
