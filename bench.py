@@ -1142,7 +1142,7 @@ def main():
     # an arrival set are built on the device while the columns come in, as the reference rebuilds V^-1 inside every
     # vandermonde_batch_interpolate call, hbmpc_ntl_helpers.pyx:139-197).  The columns are received in place (`columns=`): the
     # decoder is told which row of the party-major buffer has landed.
-    dt_first, first_cols = None, None
+    dt_first, first_cols, adv = None, None, None
     if world == 1 and not args.no_matrix_cores:
         from honeybadgermpc_amd.device import DeviceIncrementalDecoder
 
@@ -1180,6 +1180,41 @@ def main():
         dt_first = time.perf_counter() - t3
         assert msg_ is not None and res_ is not None, "a fault-free open did not finish"
         assert torch.equal(res_.reshape(-1, 4)[:B], secrets) and torch.equal(msg_[:, 0, :], r2_cols[:C]), "first-sight open differs from the secrets"
+
+        # The same R2 decode under attack, at first sight: t senders send garbage in every chunk -- arriving FIRST (a candidate from the
+        # newest columns decides, device.py _candidate_cap) or SPREAD over the arrival list (the probe decides); every column is needed,
+        # the decoder must name exactly the liars and return the secrets.  A few opens each: they are milliseconds.
+        adv = {}
+        gen_ = torch.Generator(device="cuda")
+        gen_.manual_seed(99)
+        bad_cols = r2v.clone()
+        liars_ = sorted(rng.choice(n, size=t, replace=False).tolist())
+        for j_ in liars_:
+            v_ = torch.randint(-(1 << 63), (1 << 63) - 1, (C, 4), dtype=torch.int64, device="cuda", generator=gen_)
+            v_[:, 3] &= (1 << 61) - 1
+            bad_cols[j_] = v_
+        honest_ = [j_ for j_ in rng.permutation(n).tolist() if j_ not in liars_]
+        stp_ = max(1, len(honest_) // (t + 1))
+        spread_ = []
+        for i_, j_ in enumerate(liars_):
+            spread_ += honest_[i_ * stp_:(i_ + 1) * stp_] + [j_]
+        spread_ += honest_[t * stp_:]
+        for name_, order_ in (("liars_first", liars_ + honest_), ("liars_spread", spread_)):
+            reps_ = 6
+            for rep_ in range(reps_ + 2):
+                if rep_ == 2:
+                    torch.cuda.synchronize()
+                    t4 = time.perf_counter()
+                dec_ = DeviceIncrementalDecoder(BLS, n, t, batch_size=C, use_omega_powers=use_omega, device=local_rank, columns=bad_cols)
+                for idx_ in order_:
+                    dec_.add(idx_)
+                    if dec_.done():
+                        break
+                res_a, errs_a = dec_.get_results()
+            torch.cuda.synchronize()
+            dt_a = (time.perf_counter() - t4) / reps_
+            assert errs_a == set(liars_) and torch.equal(res_a.reshape(-1, 4)[:B], secrets), f"decode under attack ({name_}) differs"
+            adv[name_] = {"shares_per_s": B / dt_a, "ms_per_decode": dt_a * 1e3, "probe_verdicts": dec_.probes, "batched_launches": dec_.quick_launches}
 
     # ---- correctness of what was timed (untimed) --------------------------------------
     assert torch.equal(result, secrets), "reconstructed shares differ from the secrets"
@@ -1291,6 +1326,10 @@ def main():
                 "first_sight_note": "(gc.freeze() after set-up: the interpreter's full collections are kept out of the timed loop) R1 encode + one DeviceIncrementalDecoder per round fed column by column in a fresh seeded arrival order every step "
                                     f"({first_cols} columns announced per open), columns received in place, nothing cached per arrival pattern: what "
                                     "batch_reconstruct_device runs; `value` is the same open through an open plan whose arrival set is fixed at plan creation",
+                "r2_decode_under_attack_first_sight": adv if dt_first else None,
+                "under_attack_note": f"ONE DeviceIncrementalDecoder decode of the R2 columns with t = {t} senders sending garbage in every chunk, fed column by column, nothing "
+                                     "cached: liars_first = they arrive before every honest sender (the reference's worst case: all n columns are needed); "
+                                     "liars_spread = one of them after every few honest senders.  shares_per_s counts the B shares of the one decode",
                 "shares_per_s_per_gpu_integer_valu_path": (B * args.steps / dt_other) if dt_other else None,
                 "integer_valu_path_note": "same open with HB_OPEN_OPT_MATRIX_CORES = 0 (second-generation integer-VALU kernels), same validation; bit-identical results",
             },
