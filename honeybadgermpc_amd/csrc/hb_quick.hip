@@ -119,9 +119,13 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
                                                       const QuickIdx ix, int d, int nc, int n_coef, uint32_t *__restrict__ wj, uint32_t *__restrict__ full,
                                                       uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap, int flags) {
     extern __shared__ uint32_t q_lds[];
-    uint32_t *Ac = q_lds;                               // [(d + 1)][NL]
+    uint32_t *Ac = q_lds;                               // [(d + 2)][NL]
+    uint32_t *xz = q_lds + (size_t)(d + 2) * NL;        // [d][NL]: the arrivals' points.  Every chain below multiplies by one of them per step:
+    // read from the table in global memory inside the step (as round 3 did) each of the d dependent steps waited for an L2 round trip
     const int tid = threadIdx.x;
     const bool one_wave = d <= 63;
+    for (int e = tid; e < d * NL; e += 512) xz[e] = xm[(size_t)ix.z[e / NL] * NL + e % NL];
+    __syncthreads();
     // flags: QUICK_Z -- what depends on the arrivals z alone (A, the N_j, the w_j, the row map of the coefficient rows); QUICK_ZC -- the
     // compared senders' full_i and their rows of the map.  A decoder builds the first half when its (degree+1)-th column lands.
     const bool do_z = flags & 1, do_zc = flags & 2;
@@ -135,7 +139,7 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
                 fp_set(f, P.one);
                 for (int q = 0; q < d; q++) {
                     uint32_t xq[NL], df[NL];
-                    ldg<NL>(xq, xm + (size_t)ix.z[q] * NL);
+                    ldg<NL>(xq, xz + (size_t)q * NL);
                     fp_sub(df, xi, xq, P);
                     mont_mul(f, f, df, P);
                 }
@@ -160,7 +164,7 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
                 const bool act = tid <= q + 1;
                 if (act) {
                     uint32_t xq[NL], cur[NL], prev[NL], m[NL];
-                    ldg<NL>(xq, xm + (size_t)ix.z[q] * NL);
+                    ldg<NL>(xq, xz + (size_t)q * NL);
                     ldg<NL>(cur, Ac + (size_t)tid * NL);
                     mont_mul(m, xq, cur, P);
                     if (tid > 0) ldg<NL>(prev, Ac + (size_t)(tid - 1) * NL);
@@ -184,7 +188,7 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
             const bool act = tid <= q + 1 && tid <= 128;
             if (act) {
                 uint32_t xq[NL], cur[NL], prev[NL], m[NL];
-                ldg<NL>(xq, xm + (size_t)ix.z[q] * NL);
+                ldg<NL>(xq, xz + (size_t)q * NL);
                 ldg<NL>(cur, Ac + (size_t)tid * NL);
                 mont_mul(m, xq, cur, P);
                 if (tid > 0) ldg<NL>(prev, Ac + (size_t)(tid - 1) * NL);
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
             // N_j[d-1] = A[d] = 1, N_j[m-1] = A[m] + x_j N_j[m]
             const int j = tid;
             uint32_t xj[NL], cur[NL];
-            ldg<NL>(xj, xm + (size_t)ix.z[j] * NL);
+            ldg<NL>(xj, xz + (size_t)j * NL);
             fp_set(cur, P.one);
             for (int m = d - 1; m >= 0; m--) {
                 if (m < n_coef) stg<NL>(nraw + ((size_t)m * d + j) * NL, cur);
@@ -219,14 +223,15 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
     } else if (tid < 256) {
         const int j = tid - 128;
         if (j < d) {
-            uint32_t w[NL];
+            // (the factor of the next step is requested before this step's multiplication: the loads do not depend on the chain)
+            uint32_t w[NL], f[NL], fn[NL];
             fp_set(w, P.one);
             const uint32_t *row = inv + (size_t)ix.z[j] * n * NL;
+            ldg<NL>(f, row + (size_t)ix.z[0] * NL);
             for (int q = 0; q < d; q++) {
-                if (q == j) continue;
-                uint32_t f[NL];
-                ldg<NL>(f, row + (size_t)ix.z[q] * NL);
-                mont_mul(w, w, f, P);
+                if (q + 1 < d) ldg<NL>(fn, row + (size_t)ix.z[q + 1] * NL);
+                if (q != j) mont_mul(w, w, f, P);
+                fp_set(f, fn);
             }
             stg<NL>(wj + (size_t)j * NL, w);
         }
@@ -240,7 +245,7 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
             fp_set(f, P.one);
             for (int q = 0; q < d; q++) {
                 uint32_t xq[NL], df[NL];
-                ldg<NL>(xq, xm + (size_t)ix.z[q] * NL);
+                ldg<NL>(xq, xz + (size_t)q * NL);
                 fp_sub(df, xi, xq, P);
                 mont_mul(f, f, df, P);
             }
@@ -786,7 +791,7 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
     // the rows this call owns: the coefficient rows with the first half, the compared senders' rows with the second
     const int row_lo = do_z ? 0 : L.n_coef, row_hi = do_zc ? L.n_out : L.n_coef;
     if (do_z || nc > 0)
-        k_quick_matrix<9><<<1, 512, (size_t)(d + 2) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map), flags);
+        k_quick_matrix<9><<<1, 512, (size_t)(2 * d + 2) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map), flags);
     HB_LAUNCH_CHECK(ctx);
     if (row_hi > row_lo) {
         k_quick_image<<<(unsigned)(((row_hi - row_lo) * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, mcan, base + L.o_a8, L.tile_rows, L.nkb, row_lo, row_hi);
