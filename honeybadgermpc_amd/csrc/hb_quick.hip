@@ -118,137 +118,167 @@ template <int NL>
 __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ inv, int n,
                                                       const QuickIdx ix, int d, int nc, int n_coef, uint32_t *__restrict__ wj, uint32_t *__restrict__ full,
                                                       uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap, int flags) {
-    extern __shared__ uint32_t q_lds[];
-    uint32_t *Ac = q_lds;                               // [(d + 2)][NL]
-    uint32_t *xz = q_lds + (size_t)(d + 2) * NL;        // [d][NL]: the arrivals' points.  Every chain below multiplies by one of them per step:
-    // read from the table in global memory inside the step (as round 3 did) each of the d dependent steps waited for an L2 round trip
-    const int tid = threadIdx.x;
-    const bool one_wave = d <= 63;
-    for (int e = tid; e < d * NL; e += 512) xz[e] = xm[(size_t)ix.z[e / NL] * NL + e % NL];
-    __syncthreads();
+    // Three workgroups, each a set of SHORT chains of dependent multiplications (rounds 3 and 4 ran one workgroup of d-step chains: A(X) by
+    // d sequential multiplications by (X - x_q) with two barriers each, then d-step Horner / product chains per thread -- 177 us at d = 86):
+    //   block 0: A(X) = prod (X - x_q) by a PRODUCT TREE in LDS (log2 d levels; a level multiplies adjacent monic polynomials, one output
+    //            coefficient a thread: a lazily accumulated dot product and ONE reduction), then the N_j by Horner cut into QM_SEG segments
+    //            (segment sums in parallel, their combination through x_j^Ls, the segments' own steps in parallel: 2 d / QM_SEG + QM_SEG steps);
+    //   block 1: w_j = prod_{q != j} 1 / (x_j - x_q), QM_SEG partial products a row, three multiplications to join them; the arrival list;
+    //   block 2: full_i = prod_q (x_i - x_q) for the compared senders, two partial products each; the row map.
     // flags: QUICK_Z -- what depends on the arrivals z alone (A, the N_j, the w_j, the row map of the coefficient rows); QUICK_ZC -- the
     // compared senders' full_i and their rows of the map.  A decoder builds the first half when its (degree+1)-th column lands.
+    constexpr int QM_SEG = 4;
+    extern __shared__ uint32_t q_lds[];
+    const int tid = threadIdx.x;
     const bool do_z = flags & 1, do_zc = flags & 2;
-    if (!do_z) {
-        if (tid >= 256) {
-            const int i = tid - 256;
-            for (int r = i; r < nc; r += 256) fmap[n_coef + r] = (int32_t)ix.zc[r] + 1;
-            if (i < nc) {
-                uint32_t xi[NL], f[NL];
-                ldg<NL>(xi, xm + (size_t)ix.zc[i] * NL);
-                fp_set(f, P.one);
-                for (int q = 0; q < d; q++) {
-                    uint32_t xq[NL], df[NL];
-                    ldg<NL>(xq, xz + (size_t)q * NL);
-                    fp_sub(df, xi, xq, P);
-                    mont_mul(f, f, df, P);
+    uint32_t *xz = q_lds;                               // [d][NL]: the arrivals' points (every block's chains read them)
+    if (blockIdx.x == 0 && !do_z) return;
+    if (blockIdx.x == 1 && !do_z) return;
+    for (int e = tid; e < d * NL; e += 512) xz[e] = xm[(size_t)ix.z[e / NL] * NL + e % NL];
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        uint32_t *B0 = xz + (size_t)d * NL, *B1 = B0 + (size_t)d * NL;      // [d][NL] each: the level's monic polynomials without their leading 1
+        uint32_t *Ac = B1 + (size_t)d * NL;                                   // [d + 1][NL]
+        uint32_t *Tb = Ac + (size_t)(d + 1) * NL;                             // [d][QM_SEG][NL]: segment sums
+        if (tid < d) {
+            uint32_t x[NL], nx[NL];
+            ldg<NL>(x, xz + (size_t)tid * NL);
+            fp_neg(nx, x, P);
+            stg<NL>(B0 + (size_t)tid * NL, nx);                              // X - x_q
+        }
+        __syncthreads();
+        uint32_t *src = B0, *dst = B1;
+        for (int len = 1; len < d; len <<= 1) {
+            // polynomial i of this level: stored coefficients [i len, min((i + 1) len, d)); pair (2 i', 2 i' + 1) -> [2 i' len, ...) of the next
+            if (tid < d) {
+                const int base = (tid / (2 * len)) * 2 * len, c = tid - base;
+                const int m = min(len, d - base), k = min(len, d - base - m);
+                uint32_t r[NL];
+                if (k == 0) ldg<NL>(r, src + (size_t)tid * NL);             // no partner: carried over
+                else {
+                    // (X^m + p)(X^k + q) = X^(m+k) + [p q + X^m q + X^k p]: coefficient c of the bracket
+                    const uint32_t *pp = src + (size_t)base * NL, *qq = pp + (size_t)m * NL;
+                    uint64_t col[2 * NL];
+                    col_zero(col);
+                    int cnt = 0;
+                    for (int a_ = max(0, c - k + 1); a_ <= min(m - 1, c); a_++) {
+                        uint32_t u[NL], v[NL];
+                        ldg<NL>(u, pp + (size_t)a_ * NL);
+                        ldg<NL>(v, qq + (size_t)(c - a_) * NL);
+                        mac<NL>(col, u, v);
+                        if ((++cnt & 3) == 0) carry(col);                    // four products of canonical elements fit a column
+                    }
+                    finish<NL>(r, col, P, 1);                                // at most 64 products below p^2: < 2 p before the subtraction
+                    if (c >= m) { uint32_t v[NL]; ldg<NL>(v, qq + (size_t)(c - m) * NL); fp_add(r, r, v, P); }
+                    if (c >= k) { uint32_t u[NL]; ldg<NL>(u, pp + (size_t)(c - k) * NL); fp_add(r, r, u, P); }
                 }
-                stg<NL>(full + (size_t)i * NL, f);
+                stg<NL>(dst + (size_t)tid * NL, r);
+            }
+            __syncthreads();
+            uint32_t *t_ = src; src = dst; dst = t_;
+        }
+        if (tid < d) { uint32_t v[NL]; ldg<NL>(v, src + (size_t)tid * NL); stg<NL>(Ac + (size_t)tid * NL, v); }
+        if (tid == 0) stg<NL>(Ac + (size_t)d * NL, P.one);
+        __syncthreads();
+        // N(m) := N_j[m - 1] = sum_{k >= m} A[k] x_j^(k - m), m = 1 .. d; segment g holds k in [lo, hi)
+        const int Ls = (d + QM_SEG - 1) / QM_SEG;
+        const int j = tid / QM_SEG, g = tid % QM_SEG;
+        const int lo = 1 + g * Ls, hi = min(1 + (g + 1) * Ls, d + 1);
+        const bool live = j < d && lo < hi;
+        uint32_t xj[NL], y[NL], v[NL];
+        fp_set(y, P.one);
+#pragma unroll
+        for (int q = 0; q < NL; q++) v[q] = 0;
+        if (j < d) {
+            ldg<NL>(xj, xz + (size_t)j * NL);
+            for (int k = hi - 1; k >= lo; k--) {                             // T_g = sum_{k in segment} A[k] x^(k - lo), and y = x^Ls beside it
+                uint32_t a_[NL], pr[NL];
+                ldg<NL>(a_, Ac + (size_t)k * NL);
+                mont_mul(pr, xj, v, P);
+                fp_add(v, a_, pr, P);
+            }
+            for (int e = 0; e < Ls; e++) mont_mul(y, y, xj, P);
+            stg<NL>(Tb + ((size_t)j * QM_SEG + g) * NL, v);
+        }
+        __syncthreads();
+        if (live) {
+            // S = N(hi) = T_{g+1} + y (T_{g+2} + y (...)): the segments above, top first (a segment below the top one is Ls long)
+            uint32_t S[NL];
+#pragma unroll
+            for (int q = 0; q < NL; q++) S[q] = 0;
+            for (int g2 = QM_SEG - 1; g2 > g; g2--) {
+                uint32_t t2[NL], pr[NL];
+                ldg<NL>(t2, Tb + ((size_t)j * QM_SEG + g2) * NL);
+                mont_mul(pr, y, S, P);
+                fp_add(S, t2, pr, P);
+            }
+            for (int k = hi - 1; k >= lo; k--) {                             // N(k) = A[k] + x N(k + 1)
+                uint32_t a_[NL], pr[NL];
+                ldg<NL>(a_, Ac + (size_t)k * NL);
+                mont_mul(pr, xj, S, P);
+                fp_add(S, a_, pr, P);
+                if (k - 1 < n_coef) stg<NL>(nraw + ((size_t)(k - 1) * d + j) * NL, S);
             }
         }
         return;
     }
-    // ---- A(X): coefficient t on thread t < 128 (d <= 127 ... the d-th on thread d) -------------------------------------
-    if (tid <= d && tid < 128 + 1) {
-        uint32_t v[NL];
-#pragma unroll
-        for (int i = 0; i < NL; i++) v[i] = (tid == 0) ? P.one[i] : 0u;
-        stg<NL>(Ac + (size_t)tid * NL, v);
-    }
-    if (one_wave) {
-        if (tid < 64) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            for (int q = 0; q < d; q++) {
-                uint32_t nv[NL];
-                const bool act = tid <= q + 1;
-                if (act) {
-                    uint32_t xq[NL], cur[NL], prev[NL], m[NL];
-                    ldg<NL>(xq, xz + (size_t)q * NL);
-                    ldg<NL>(cur, Ac + (size_t)tid * NL);
-                    mont_mul(m, xq, cur, P);
-                    if (tid > 0) ldg<NL>(prev, Ac + (size_t)(tid - 1) * NL);
-                    else {
-#pragma unroll
-                        for (int i = 0; i < NL; i++) prev[i] = 0;
-                    }
-                    fp_sub(nv, prev, m, P);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (act) stg<NL>(Ac + (size_t)tid * NL, nv);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-    } else {
-        __syncthreads();
-        for (int q = 0; q < d; q++) {
-            uint32_t nv[NL];
-            const bool act = tid <= q + 1 && tid <= 128;
-            if (act) {
-                uint32_t xq[NL], cur[NL], prev[NL], m[NL];
-                ldg<NL>(xq, xz + (size_t)q * NL);
-                ldg<NL>(cur, Ac + (size_t)tid * NL);
-                mont_mul(m, xq, cur, P);
-                if (tid > 0) ldg<NL>(prev, Ac + (size_t)(tid - 1) * NL);
-                else {
-#pragma unroll
-                    for (int i = 0; i < NL; i++) prev[i] = 0;
-                }
-                fp_sub(nv, prev, m, P);
-            }
-            __syncthreads();
-            if (act) stg<NL>(Ac + (size_t)tid * NL, nv);
-            __syncthreads();
-        }
-    }
-    if (tid < 128) {
-        if (tid < d) {
-            // N_j[d-1] = A[d] = 1, N_j[m-1] = A[m] + x_j N_j[m]
-            const int j = tid;
-            uint32_t xj[NL], cur[NL];
-            ldg<NL>(xj, xz + (size_t)j * NL);
-            fp_set(cur, P.one);
-            for (int m = d - 1; m >= 0; m--) {
-                if (m < n_coef) stg<NL>(nraw + ((size_t)m * d + j) * NL, cur);
-                if (m > 0) {
-                    uint32_t a[NL], pr[NL];
-                    ldg<NL>(a, Ac + (size_t)m * NL);
-                    mont_mul(pr, xj, cur, P);
-                    fp_add(cur, a, pr, P);
-                }
-            }
-        }
-    } else if (tid < 256) {
-        const int j = tid - 128;
+    if (blockIdx.x == 1) {
+        uint32_t *Wp = xz + (size_t)d * NL;                                   // [d][QM_SEG][NL]
+        const int Ls = (d + QM_SEG - 1) / QM_SEG;
+        const int j = tid / QM_SEG, g = tid % QM_SEG;
         if (j < d) {
-            // (the factor of the next step is requested before this step's multiplication: the loads do not depend on the chain)
+            const int lo = g * Ls, hi = min((g + 1) * Ls, d);
             uint32_t w[NL], f[NL], fn[NL];
             fp_set(w, P.one);
             const uint32_t *row = inv + (size_t)ix.z[j] * n * NL;
-            ldg<NL>(f, row + (size_t)ix.z[0] * NL);
-            for (int q = 0; q < d; q++) {
-                if (q + 1 < d) ldg<NL>(fn, row + (size_t)ix.z[q + 1] * NL);
+            if (lo < hi) ldg<NL>(f, row + (size_t)ix.z[lo] * NL);
+            for (int q = lo; q < hi; q++) {                                  // (the next factor is requested before this multiplication)
+                if (q + 1 < hi) ldg<NL>(fn, row + (size_t)ix.z[q + 1] * NL);
                 if (q != j) mont_mul(w, w, f, P);
                 fp_set(f, fn);
             }
+            stg<NL>(Wp + ((size_t)j * QM_SEG + g) * NL, w);
+        }
+        __syncthreads();
+        if (j < d && g == 0) {
+            uint32_t w[NL];
+            ldg<NL>(w, Wp + (size_t)j * QM_SEG * NL);
+            for (int g2 = 1; g2 < QM_SEG; g2++) {
+                uint32_t f[NL];
+                ldg<NL>(f, Wp + ((size_t)j * QM_SEG + g2) * NL);
+                mont_mul(w, w, f, P);
+            }
             stg<NL>(wj + (size_t)j * NL, w);
         }
-    } else {
-        const int i = tid - 256;
-        if (i < d) z_dev[i] = ix.z[i];
-        for (int r = i; r <= n_coef + nc; r += 256) fmap[r] = (do_zc && r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0;
-        if (do_zc && i < nc) {
+        if (tid < d) z_dev[tid] = ix.z[tid];
+        return;
+    }
+    // block 2: the compared senders' full_i (two partial products each), the row map
+    {
+        uint32_t *Fp = xz + (size_t)d * NL;                                   // [nc][2][NL]
+        if (do_z) { for (int r = tid; r <= n_coef + nc; r += 512) fmap[r] = (do_zc && r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0; }
+        else { for (int r = tid; r < nc; r += 512) fmap[n_coef + r] = (int32_t)ix.zc[r] + 1; }
+        if (!do_zc && do_z) return;
+        const int i = tid >> 1, g = tid & 1, half = (d + 1) / 2;
+        if (i < nc) {
+            const int lo = g * half, hi = min((g + 1) * half, d);
             uint32_t xi[NL], f[NL];
             ldg<NL>(xi, xm + (size_t)ix.zc[i] * NL);
             fp_set(f, P.one);
-            for (int q = 0; q < d; q++) {
+            for (int q = lo; q < hi; q++) {
                 uint32_t xq[NL], df[NL];
                 ldg<NL>(xq, xz + (size_t)q * NL);
                 fp_sub(df, xi, xq, P);
                 mont_mul(f, f, df, P);
             }
+            stg<NL>(Fp + ((size_t)i * 2 + g) * NL, f);
+        }
+        __syncthreads();
+        if (i < nc && g == 0) {
+            uint32_t f0[NL], f1[NL], f[NL];
+            ldg<NL>(f0, Fp + (size_t)i * 2 * NL);
+            ldg<NL>(f1, Fp + ((size_t)i * 2 + 1) * NL);
+            mont_mul(f, f0, f1, P);
             stg<NL>(full + (size_t)i * NL, f);
         }
     }
@@ -791,7 +821,7 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
     // the rows this call owns: the coefficient rows with the first half, the compared senders' rows with the second
     const int row_lo = do_z ? 0 : L.n_coef, row_hi = do_zc ? L.n_out : L.n_coef;
     if (do_z || nc > 0)
-        k_quick_matrix<9><<<1, 512, (size_t)(2 * d + 2) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map), flags);
+        k_quick_matrix<9><<<3, 512, (size_t)std::max(8 * d + 1, d + 2 * nc) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map), flags);
     HB_LAUNCH_CHECK(ctx);
     if (row_hi > row_lo) {
         k_quick_image<<<(unsigned)(((row_hi - row_lo) * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, mcan, base + L.o_a8, L.tile_rows, L.nkb, row_lo, row_hi);
