@@ -114,8 +114,9 @@ __global__ void k_pt_inv(const FpParams<NL> P, const uint32_t *__restrict__ xm, 
 // Up to 63 interpolation points the first role is ONE wave working through LDS with wave-level synchronisation only, and the three
 // roles run side by side on three SIMDs: the critical path is the 2 d dependent multiplications of the first role.  Beyond that
 // A is built with workgroup barriers first and the roles follow.
+constexpr int QM_NT = 1024, QM_SEG = 8, QM_FSEG = 4, QM_TS = 4;     // k_quick_matrix: threads a workgroup; Horner / w_j segments (d QM_SEG <= QM_NT); partial products of a full_i (nc QM_FSEG <= QM_NT); lanes per coefficient of a tree level (d QM_TS <= QM_NT)
 template <int NL>
-__global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ inv, int n,
+__global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ inv, int n,
                                                       const QuickIdx ix, int d, int nc, int n_coef, uint32_t *__restrict__ wj, uint32_t *__restrict__ full,
                                                       uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap, int flags) {
     // Three workgroups, each a set of SHORT chains of dependent multiplications (rounds 3 and 4 ran one workgroup of d-step chains: A(X) by
@@ -123,18 +124,17 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
     //   block 0: A(X) = prod (X - x_q) by a PRODUCT TREE in LDS (log2 d levels; a level multiplies adjacent monic polynomials, one output
     //            coefficient a thread: a lazily accumulated dot product and ONE reduction), then the N_j by Horner cut into QM_SEG segments
     //            (segment sums in parallel, their combination through x_j^Ls, the segments' own steps in parallel: 2 d / QM_SEG + QM_SEG steps);
-    //   block 1: w_j = prod_{q != j} 1 / (x_j - x_q), QM_SEG partial products a row, three multiplications to join them; the arrival list;
-    //   block 2: full_i = prod_q (x_i - x_q) for the compared senders, two partial products each; the row map.
+    //   block 1: w_j = prod_{q != j} 1 / (x_j - x_q), QM_SEG partial products a row, QM_SEG - 1 multiplications to join them; the arrival list;
+    //   block 2: full_i = prod_q (x_i - x_q) for the compared senders, QM_FSEG partial products each; the row map.
     // flags: QUICK_Z -- what depends on the arrivals z alone (A, the N_j, the w_j, the row map of the coefficient rows); QUICK_ZC -- the
     // compared senders' full_i and their rows of the map.  A decoder builds the first half when its (degree+1)-th column lands.
-    constexpr int QM_SEG = 4;
     extern __shared__ uint32_t q_lds[];
     const int tid = threadIdx.x;
     const bool do_z = flags & 1, do_zc = flags & 2;
     uint32_t *xz = q_lds;                               // [d][NL]: the arrivals' points (every block's chains read them)
     if (blockIdx.x == 0 && !do_z) return;
     if (blockIdx.x == 1 && !do_z) return;
-    for (int e = tid; e < d * NL; e += 512) xz[e] = xm[(size_t)ix.z[e / NL] * NL + e % NL];
+    for (int e = tid; e < d * NL; e += QM_NT) xz[e] = xm[(size_t)ix.z[e / NL] * NL + e % NL];
     __syncthreads();
     if (blockIdx.x == 0) {
         uint32_t *B0 = xz + (size_t)d * NL, *B1 = B0 + (size_t)d * NL;      // [d][NL] each: the level's monic polynomials without their leading 1
@@ -149,30 +149,42 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
         __syncthreads();
         uint32_t *src = B0, *dst = B1;
         for (int len = 1; len < d; len <<= 1) {
-            // polynomial i of this level: stored coefficients [i len, min((i + 1) len, d)); pair (2 i', 2 i' + 1) -> [2 i' len, ...) of the next
-            if (tid < d) {
-                const int base = (tid / (2 * len)) * 2 * len, c = tid - base;
+            // polynomial i of this level: stored coefficients [i len, min((i + 1) len, d)); pair (2 i', 2 i' + 1) -> [2 i' len, ...) of the next.
+            // QM_TS adjacent lanes share an output coefficient: each takes every QM_TS-th term of its dot product (up to 64 terms at the
+            // last level), the carried columns are summed across the lanes, the first of them reduces and stores
+            const int o = tid / QM_TS, part = tid % QM_TS;
+            if (o < d) {                                                     // (whole groups of QM_TS lanes: the shuffles below stay inside a group)
+                const int base = (o / (2 * len)) * 2 * len, c = o - base;
                 const int m = min(len, d - base), k = min(len, d - base - m);
                 uint32_t r[NL];
-                if (k == 0) ldg<NL>(r, src + (size_t)tid * NL);             // no partner: carried over
+                if (k == 0) ldg<NL>(r, src + (size_t)o * NL);               // no partner: carried over
                 else {
                     // (X^m + p)(X^k + q) = X^(m+k) + [p q + X^m q + X^k p]: coefficient c of the bracket
                     const uint32_t *pp = src + (size_t)base * NL, *qq = pp + (size_t)m * NL;
                     uint64_t col[2 * NL];
                     col_zero(col);
                     int cnt = 0;
-                    for (int a_ = max(0, c - k + 1); a_ <= min(m - 1, c); a_++) {
+                    for (int a_ = max(0, c - k + 1) + part; a_ <= min(m - 1, c); a_ += QM_TS) {
                         uint32_t u[NL], v[NL];
                         ldg<NL>(u, pp + (size_t)a_ * NL);
                         ldg<NL>(v, qq + (size_t)(c - a_) * NL);
                         mac<NL>(col, u, v);
                         if ((++cnt & 3) == 0) carry(col);                    // four products of canonical elements fit a column
                     }
+                    carry(col);                                              // columns below 2^29 (the top one below 2^36): QM_TS of them add up
+#pragma unroll
+                    for (int q = 0; q < 2 * NL; q++) {
+#pragma unroll
+                        for (int sh = 1; sh < QM_TS; sh <<= 1) {
+                            const uint32_t lo_ = (uint32_t)__shfl_xor((int)(uint32_t)col[q], sh), hi_ = (uint32_t)__shfl_xor((int)(uint32_t)(col[q] >> 32), sh);
+                            col[q] += ((uint64_t)hi_ << 32) | lo_;
+                        }
+                    }
                     finish<NL>(r, col, P, 1);                                // at most 64 products below p^2: < 2 p before the subtraction
                     if (c >= m) { uint32_t v[NL]; ldg<NL>(v, qq + (size_t)(c - m) * NL); fp_add(r, r, v, P); }
                     if (c >= k) { uint32_t u[NL]; ldg<NL>(u, pp + (size_t)(c - k) * NL); fp_add(r, r, u, P); }
                 }
-                stg<NL>(dst + (size_t)tid * NL, r);
+                if (part == 0) stg<NL>(dst + (size_t)o * NL, r);
             }
             __syncthreads();
             uint32_t *t_ = src; src = dst; dst = t_;
@@ -253,15 +265,15 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
         if (tid < d) z_dev[tid] = ix.z[tid];
         return;
     }
-    // block 2: the compared senders' full_i (two partial products each), the row map
+    // block 2: the compared senders' full_i (QM_FSEG partial products each), the row map
     {
-        uint32_t *Fp = xz + (size_t)d * NL;                                   // [nc][2][NL]
-        if (do_z) { for (int r = tid; r <= n_coef + nc; r += 512) fmap[r] = (do_zc && r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0; }
-        else { for (int r = tid; r < nc; r += 512) fmap[n_coef + r] = (int32_t)ix.zc[r] + 1; }
+        uint32_t *Fp = xz + (size_t)d * NL;                                   // [nc][QM_FSEG][NL]
+        if (do_z) { for (int r = tid; r <= n_coef + nc; r += QM_NT) fmap[r] = (do_zc && r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0; }
+        else { for (int r = tid; r < nc; r += QM_NT) fmap[n_coef + r] = (int32_t)ix.zc[r] + 1; }
         if (!do_zc && do_z) return;
-        const int i = tid >> 1, g = tid & 1, half = (d + 1) / 2;
+        const int i = tid / QM_FSEG, g = tid % QM_FSEG, part = (d + QM_FSEG - 1) / QM_FSEG;
         if (i < nc) {
-            const int lo = g * half, hi = min((g + 1) * half, d);
+            const int lo = g * part, hi = min((g + 1) * part, d);
             uint32_t xi[NL], f[NL];
             ldg<NL>(xi, xm + (size_t)ix.zc[i] * NL);
             fp_set(f, P.one);
@@ -271,14 +283,17 @@ __global__ void __launch_bounds__(512) k_quick_matrix(const FpParams<NL> P, cons
                 fp_sub(df, xi, xq, P);
                 mont_mul(f, f, df, P);
             }
-            stg<NL>(Fp + ((size_t)i * 2 + g) * NL, f);
+            stg<NL>(Fp + ((size_t)i * QM_FSEG + g) * NL, f);
         }
         __syncthreads();
         if (i < nc && g == 0) {
-            uint32_t f0[NL], f1[NL], f[NL];
-            ldg<NL>(f0, Fp + (size_t)i * 2 * NL);
-            ldg<NL>(f1, Fp + ((size_t)i * 2 + 1) * NL);
-            mont_mul(f, f0, f1, P);
+            uint32_t f[NL];
+            ldg<NL>(f, Fp + (size_t)i * QM_FSEG * NL);
+            for (int g2 = 1; g2 < QM_FSEG; g2++) {
+                uint32_t f1[NL];
+                ldg<NL>(f1, Fp + ((size_t)i * QM_FSEG + g2) * NL);
+                mont_mul(f, f, f1, P);
+            }
             stg<NL>(full + (size_t)i * NL, f);
         }
     }
@@ -821,7 +836,7 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
     // the rows this call owns: the coefficient rows with the first half, the compared senders' rows with the second
     const int row_lo = do_z ? 0 : L.n_coef, row_hi = do_zc ? L.n_out : L.n_coef;
     if (do_z || nc > 0)
-        k_quick_matrix<9><<<3, 512, (size_t)std::max(8 * d + 1, d + 2 * nc) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map), flags);
+        k_quick_matrix<9><<<3, QM_NT, (size_t)std::max((4 + QM_SEG) * d + 1, d + QM_FSEG * nc) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map), flags);
     HB_LAUNCH_CHECK(ctx);
     if (row_hi > row_lo) {
         k_quick_image<<<(unsigned)(((row_hi - row_lo) * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, mcan, base + L.o_a8, L.tile_rows, L.nkb, row_lo, row_hi);
