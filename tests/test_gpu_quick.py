@@ -30,7 +30,8 @@ def _quick(ctx, x, z, zc, cols, c, store=True, lo=0, hi=None):
     return out, st[0], st[1]
 
 
-@pytest.mark.parametrize("n,t,c,omega", [(16, 5, 300, False), (64, 21, 2000, False), (64, 21, 777, True), (100, 33, 500, False), (256, 85, 260, True), (7, 3, 40, False)])
+@pytest.mark.parametrize("n,t,c,omega", [(16, 5, 300, False), (64, 21, 2000, False), (64, 21, 777, True), (100, 33, 500, False), (256, 85, 260, True), (7, 3, 40, False),
+                                        (384, 127, 40, False), (200, 64, 60, False), (130, 42, 50, False), (381, 126, 30, False)])
 def test_quick_interp_check_vs_oracle(n, t, c, omega):
     from honeybadgermpc_amd._capi import Context
     from honeybadgermpc_amd.field import GF
