@@ -586,12 +586,13 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     rc = ctx_scratch(ctx, "gao.g1", (size_t)npts * C * ctx->elem_words() * 4, (void **)&g1); if (rc) return rc;
     hb_view iv{npts, 1}, ov{npts, 1};
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
-    if (rc) return rc;
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }          // (nothing of this call may still be writing the scratch when the next one starts)
     size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 4) * NLr * 4;      // R0, R1, T0, T1, a zero element, three scalars
     // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one
     uint32_t *side = nullptr;
     const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
-    rc = ctx_scratch(ctx, "gao.side", (size_t)C * side_words * 4, (void **)&side); if (rc) return rc;
+    rc = ctx_scratch(ctx, "gao.side", (size_t)C * side_words * 4, (void **)&side);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
     const unsigned fin_blocks = (unsigned)(((C + GAO_FIN_G - 1) / GAO_FIN_G + 63) / 64);
     // 2 p^2 in radix-2^29 digits (schoolbook on 32-bit words)
     uint32_t k2pp[18];
