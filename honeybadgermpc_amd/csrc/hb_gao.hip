@@ -108,16 +108,67 @@ template <int NL> __device__ __forceinline__ void redc_signed(uint32_t (&r)[NL],
     for (int k = NL; k < 2 * NL - 1; k++) { c[k + 1] += c[k] >> LB; r[k - NL] = (uint32_t)c[k] & DMASK; }
     r[NL - 1] = (uint32_t)c[2 * NL - 1];
 }
-// 2 p^2 in radix-2^29 digits: what the fused Euclid step adds to m0 u - m1 w1 - m2 w0 (each product below p^2) so that the sum is never negative
+// 2 p^2 in radix-2^29 digits: what a round adds to its signed sum of products so that the total is never negative
 template <int NL> struct GaoConsts { uint32_t k2pp[2 * NL]; };
 
-// One wave per codeword (at least three to a SIMD: the kernel waits on LDS round trips more than it computes -- 152 registers instead of
-// 194 took config 4 from 40.6 to 37.7 ms, 128 with spills to 38.2).  The kernel stops short of the ONE field inversion a codeword needs (Fermat: 255 squarings + ~128
+// col += m * v with SIGNED digits (a negated multiplier is the digit-wise negation of a residue)
+template <int NL> __device__ __forceinline__ void mac_s(int64_t (&col)[2 * NL], const uint32_t (&m)[NL], const uint32_t (&v)[NL]) {
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) col[i + j] += (int64_t)(int32_t)m[i] * (int32_t)v[j];
+}
+// ONE round of the Euclid loop / the division for one lane: r = (2 p^2 + m0 u + m1 w1 + m2 w0) / R mod p, every operand read from LDS through
+// a pointer of the lane's own (a lane without a term points at the zero element).  No conditional subtraction: the kernel's
+// residues are LAZY -- with operands below 1.2 p the sum stays below 6.4 p^2 < p R / 5 (R = 2^(29 NL) >= 32 p), so REDC returns a
+// value below 1.2 p again, in normalised digits (a multiple of p comes out as 0 or as p itself: is_zero_lazy).
+template <int NL> __device__ __forceinline__ void gao_round(uint32_t (&r)[NL], const uint32_t *pm0, const uint32_t *pu, const uint32_t *pm1, const uint32_t *pw1,
+                                                            const uint32_t *pm2, const uint32_t *pw0, const GaoConsts<NL> &GK, const FpParams<NL> &P) {
+    int64_t col[2 * NL];
+#pragma unroll
+    for (int q = 0; q < 2 * NL; q++) col[q] = (int64_t)GK.k2pp[q];
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm0); lds_get<NL>(v, pu); mac_s<NL>(col, m, v); }
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm1); lds_get<NL>(v, pw1); mac_s<NL>(col, m, v); }
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm2); lds_get<NL>(v, pw0); mac_s<NL>(col, m, v); }
+    redc_signed<NL>(r, col, P);
+}
+template <int NL> __device__ __forceinline__ void gao_round2(uint32_t (&r)[NL], const uint32_t *pm0, const uint32_t *pu, const uint32_t *pm1, const uint32_t *pw1,
+                                                             const GaoConsts<NL> &GK, const FpParams<NL> &P) {
+    int64_t col[2 * NL];
+#pragma unroll
+    for (int q = 0; q < 2 * NL; q++) col[q] = (int64_t)GK.k2pp[q];
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm0); lds_get<NL>(v, pu); mac_s<NL>(col, m, v); }
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm1); lds_get<NL>(v, pw1); mac_s<NL>(col, m, v); }
+    redc_signed<NL>(r, col, P);
+}
+// a lazy residue is zero when its digits are all zero or are p's
+template <int NL> __device__ __forceinline__ bool is_zero_lazy(const uint32_t (&a)[NL], const FpParams<NL> &P) {
+    uint32_t o = 0, e = 0;
+#pragma unroll
+    for (int q = 0; q < NL; q++) { o |= a[q]; e |= a[q] ^ P.p[q]; }
+    return o == 0 || e == 0;
+}
+// exact degree of the polynomial of lazy residues in LDS (coefficients 0..hi), -1 for zero
+template <int NL> __device__ int poly_degree_lazy(const uint32_t *p, int hi, int lane, const FpParams<NL> &P) {
+    int best = -1;
+    for (int idx = lane; idx <= hi; idx += 64) {
+        uint32_t a[NL];
+        lds_get<NL>(a, p + (size_t)idx * NL);
+        if (!is_zero_lazy<NL>(a, P)) best = idx;
+    }
+    return wave_max(best);
+}
+
+// One wave per codeword (three to a SIMD).  The kernel stops short of the ONE field inversion a codeword needs (Fermat: 255 squarings + ~128
 // multiplications, every lane computing the same thing -- it cost as much as everything else here together, 47 of 102 ms at config 4):
 // the division f = r / v runs as a PSEUDO-division by the un-normalised cofactor V (r <- l r - c_i x^i V, l = lc(V): the true quotient
 // digit is q_i = c_i / l^(dq - i + 1)), the raw c_i and V leave in Montgomery form, packed, in the output buffers, with cs and l in
-// a side record -- and k_gao_finish, one LANE per codeword, inverts w = cs l (64 different inversions per wave for the price of
-// one) and scales the outputs in place.
+// a side record -- and k_gao_finish, one LANE per group of codewords, inverts w = cs l and scales the outputs in place.
+//
+// Everything a round multiplies lives in LDS and is reached through per-lane pointers: the step's three multipliers (S), the scale
+// factors c0 / c1 (CA / CB), the jobs' operands.  A lane's role in a round is nothing but its seven pointers -- no selects between
+// register files, no negations in the round (round 4's first version of the fused step spent ~150 of a round's ~600 vector
+// instructions on them) -- and residues stay lazy (gao_round), so a round is 243 multiply-adds + REDC and little else.
 #ifndef GAO_WAVES_PER_EU
 #define GAO_WAVES_PER_EU 3
 #endif
@@ -133,8 +184,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
     // npts - D, so their arrays are short -- 10 KB of LDS per codeword instead of 14.5 at n = 100: 16 resident waves per CU, not 11
     const int lenT = npts - (npts + k) / 2 + 3;
     uint32_t *R0 = smem, *R1 = R0 + (size_t)len * NL, *T0 = R1 + (size_t)len * NL, *T1 = T0 + (size_t)lenT * NL;
-    uint32_t *ZERO = T1 + (size_t)lenT * NL, *SC = ZERO + NL;          // a zero element; the three scalars of a fused Euclid step (L^2, L a1, a0)
-    if (lane < NL) ZERO[lane] = 0;
+    uint32_t *ZERO = T1 + (size_t)lenT * NL;       // a zero element
+    uint32_t *S = ZERO + NL;                       // the three multipliers of a fused Euclid step: L^2, -(L a1), -a0 (residues)
+    uint32_t *NEGX = S + 3 * NL;                   // digit-wise negation of the newest leading coefficient (the jobs' subtracted multiplier)
+    uint32_t *CA = NEGX + NL, *CB = CA + NL;       // the scale factors c0, c1 of the fraction-free loop
+    if (lane < NL) { ZERO[lane] = 0; CA[lane] = P.one[lane]; CB[lane] = P.one[lane]; }
 
     for (int idx = lane; idx < len; idx += 64) {
         uint32_t a[NL], z[NL], m[NL];
@@ -154,134 +208,101 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
     }
     __syncthreads();
     int dR0 = npts, dR1 = poly_degree<NL>(R1, npts - 1, lane), dT0 = -1, dT1 = 0;
-    uint32_t c0[NL], c1[NL];
-    fp_set(c0, P.one); fp_set(c1, P.one);
     const int D = (npts + k) / 2;
-    uint32_t *rp, *vp; int dr, dvb; uint32_t cs[NL];
+    uint32_t *rp, *vp, *csp; int dr, dvb;
     if (dR0 < D) {                     // rsdecode_impl.h:289-294 (cannot fire: deg g0 = n >= D)
-        rp = R0; vp = T0; dr = dR0; dvb = dT0; fp_set(cs, c0);
+        rp = R0; vp = T0; dr = dR0; dvb = dT0; csp = CA;
     } else if (dR1 < D) {              // rsdecode_impl.h:296-301
-        rp = R1; vp = T1; dr = dR1; dvb = dT1; fp_set(cs, c1);
+        rp = R1; vp = T1; dr = dR1; dvb = dT1; csp = CB;
     } else {
-        bool have_sc = false;               // SC holds the scalars of the coming fused step (computed by the previous one)
+        bool have_sc = false;               // S holds the multipliers of the coming fused step (computed by the previous one) and NEGX = -lc(r1)
         for (;;) {
             const int delta = dR0 - dR1;
-            uint32_t L[NL];
-            lds_get<NL>(L, R1 + (size_t)dR1 * NL);
             // The generic division step (degrees drop one at a time), fused: its two pseudo-division sub-steps
             //     r' = L r0 - a1 X r1,   a0 = r'[deg r1],   r'' = L r' - a0 r1
             // are ONE update r''[i] = L^2 r0[i] - (L a1) r1[i-1] - a0 r1[i] (the same on the cofactor; c0 <- L^2 c0): three products and one
-            // reduction per coefficient where the sub-steps take four and two.  The three scalars of a step cost four modular
-            // multiplications -- executed by the whole wave they would eat the gain (round 4 measured it: 45 ms against 38) -- so the scalars
+            // reduction per coefficient where the sub-steps take four and two.  The three multipliers of a step cost four modular
+            // multiplications -- executed by the whole wave they would eat the gain (round 4 measured it: 45 ms against 38) -- so those
             // of the NEXT step are computed by three otherwise idle lanes of this step's second round: the first round takes the TOP 64
-            // coefficients of the remainder, so the two leading coefficients of r'' the next scalars need are there when the second
-            // round (the rest of the remainder, the cofactor, c0, the three jobs) starts.  job1 = X X, job2 = X Y, job3 = X Z - Y W with
-            // (X, Y, Z, W) = (lc r'', L, r1[deg r1 - 1], r''[deg r'' - 1]).  Subtracted products use negated multiplier digits and signed
-            // multiply-adds; 2 p^2 in the columns keeps the sum non-negative.  Values identical to the sub-steps', term by term.
+            // coefficients of the remainder, so the two leading coefficients of r'' the next multipliers need are there when the second
+            // round (the rest of the remainder, the cofactor, c0, the three jobs) starts.  With (X, Y, Z, W) = (lc r'', L, r1[deg r1 - 1],
+            // r''[deg r'' - 1]): job0 = X X, job1 = -X Y, job2 = Y W - X Z -- the residues of the NEGATED multipliers, so that the
+            // update is a plain sum S0 u + S1 w1 + S2 w0; the jobs subtract through NEGX, the digit-wise negation of X that the lane which
+            // computed X left in LDS (signed multiply-adds, 2 p^2 in the columns).  Values equal to the sub-steps' mod p, term by term.
             const int ttop_f = max(dT0, dT1 + 1), n2_f = max(0, dR1 - 64);
             if (delta == 1 && dR1 >= 2 && n2_f + ttop_f + 1 <= 60) {
                 const int top = dR1, ttop = ttop_f, n2 = n2_f;
-                uint32_t sL2[NL];
-                int32_t nLa1[NL], na0[NL];
-#pragma unroll
-                for (int q = 0; q < NL; q++) { sL2[q] = 0; nLa1[q] = 0; na0[q] = 0; }
-                for (int st = have_sc ? 1 : 0; st < 3; st++) {
-                    // (one body for the three kinds of round: with the kind a compile-time constant -- three copies, the first without roles,
-                    // selects and job operands -- the kernel spilled 112 bytes and ran 24.8 ms against 23.7)
-                    const int rd = st == 0 ? 2 : st - 1;          // 2: the scalars of THIS step alone (first step, or after a degree anomaly); 0, 1: the two rounds
-                    if (rd == 0) {
-                        uint32_t t1[NL], t2[NL];
-                        lds_get<NL>(sL2, SC);
-                        lds_get<NL>(t1, SC + NL);
-                        lds_get<NL>(t2, SC + 2 * NL);
-#pragma unroll
-                        for (int q = 0; q < NL; q++) { nLa1[q] = -(int32_t)t1[q]; na0[q] = -(int32_t)t2[q]; }
-                    }
-                    // what this lane does in this round
-                    enum { IDLE, REM, COF, JOB, C0L };
-                    int role = IDLE, idx = 0;
-                    if (rd == 0) { if (lane < min(64, top)) { role = REM; idx = top - 1 - lane; } }
-                    else if (rd == 1) {
-                        if (lane < n2) { role = REM; idx = n2 - 1 - lane; }
-                        else if (lane <= n2 + ttop) { role = COF; idx = lane - n2; }
-                        else if (lane >= 60 && lane < 63) role = JOB;
-                        else if (lane == 63) role = C0L;
-                    } else if (lane >= 60 && lane < 63) role = JOB;
-                    const uint32_t *Xa = rd == 1 ? R0 + (size_t)(top - 1) * NL : R1 + (size_t)dR1 * NL;
-                    const uint32_t *Ya = rd == 1 ? R1 + (size_t)dR1 * NL : R0 + (size_t)(dR1 + 1) * NL;
-                    const uint32_t *Za = rd == 1 ? R1 + (size_t)(dR1 - 1) * NL : R0 + (size_t)dR1 * NL;
-                    const uint32_t *Wa = rd == 1 ? R0 + (size_t)(top - 2) * NL : R1 + (size_t)(dR1 - 1) * NL;
-                    const int jb = lane - 60;
-                    const uint32_t *pu = ZERO, *pw1 = ZERO, *pw0 = ZERO;
-                    uint32_t *dst = nullptr;
-                    if (role == REM) { pu = R0 + (size_t)idx * NL; pw1 = idx >= 1 ? R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = R1 + (size_t)idx * NL; dst = R0 + (size_t)idx * NL; }
-                    else if (role == COF) {
-                        pu = T0 + (size_t)idx * NL;
-                        pw1 = (idx >= 1 && idx - 1 <= dT1) ? T1 + (size_t)(idx - 1) * NL : ZERO;
-                        pw0 = idx <= dT1 ? T1 + (size_t)idx * NL : ZERO;
-                        dst = T0 + (size_t)idx * NL;
-                    } else if (role == JOB) { pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za); pw1 = jb == 2 ? Wa : ZERO; dst = SC + (size_t)jb * NL; }
-                    const bool isN = role == REM || role == COF, isJ = role == JOB, isJ3 = isJ && jb == 2;
-                    uint32_t u[NL], w1[NL], w0[NL];
-                    int32_t m0[NL], m1[NL], m2[NL];
-                    lds_get<NL>(u, pu);
-                    lds_get<NL>(w1, pw1);
-                    lds_get<NL>(w0, pw0);
-                    if (role == C0L) fp_set(u, c0);
-                    if (rd != 0) {
-                        uint32_t Xv[NL], Yv[NL];
-                        lds_get<NL>(Xv, Xa);
-                        lds_get<NL>(Yv, Ya);
-#pragma unroll
-                        for (int q = 0; q < NL; q++) {
-                            m0[q] = isJ ? (int32_t)Xv[q] : (int32_t)sL2[q];
-                            m1[q] = isN ? nLa1[q] : (isJ3 ? -(int32_t)Yv[q] : 0);
-                            m2[q] = isN ? na0[q] : 0;
-                        }
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < NL; q++) { m0[q] = (int32_t)sL2[q]; m1[q] = nLa1[q]; m2[q] = na0[q]; }
-                    }
-                    int64_t col[2 * NL];
-#pragma unroll
-                    for (int q = 0; q < 2 * NL; q++) col[q] = (int64_t)GK.k2pp[q];
-#pragma unroll
-                    for (int i = 0; i < NL; i++)
-#pragma unroll
-                        for (int j = 0; j < NL; j++) col[i + j] += (int64_t)m0[i] * (int32_t)u[j];
-#pragma unroll
-                    for (int i = 0; i < NL; i++)
-#pragma unroll
-                        for (int j = 0; j < NL; j++) col[i + j] += (int64_t)m1[i] * (int32_t)w1[j];
-#pragma unroll
-                    for (int i = 0; i < NL; i++)
-#pragma unroll
-                        for (int j = 0; j < NL; j++) col[i + j] += (int64_t)m2[i] * (int32_t)w0[j];
+                const int jb = lane - 60;
+                const bool isJ = lane >= 60 && lane < 63;
+                if (!have_sc) {
+                    // the multipliers of THIS step alone (first step, or after a degree anomaly): (X, Y, Z, W) = (L, lc r0, r0[deg r1], r1[deg r1 - 1])
+                    if (lane < NL) NEGX[lane] = 0u - R1[(size_t)dR1 * NL + lane];
+                    __syncthreads();
+                    const uint32_t *Xa = R1 + (size_t)dR1 * NL, *Ya = R0 + (size_t)(dR1 + 1) * NL, *Za = R0 + (size_t)dR1 * NL, *Wa = R1 + (size_t)(dR1 - 1) * NL;
+                    const uint32_t *pm0 = ZERO, *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO;
+                    if (isJ) { pm0 = jb == 0 ? Xa : NEGX; pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za); if (jb == 2) { pm1 = Ya; pw1 = Wa; } }
                     uint32_t r[NL];
-                    redc_signed<NL>(r, col, P);
-                    cond_sub_p(r, P);
-                    __syncthreads();             // (one wave: orders this round's LDS reads before its writes -- the jobs read what round A wrote, a lane's neighbour reads R1 only)
-                    if (dst) lds_put<NL>(dst, r);
-                    if (rd == 1) {
+                    gao_round2<NL>(r, pm0, pu, pm1, pw1, GK, P);
+                    if (isJ) lds_put<NL>(S + (size_t)jb * NL, r);
+                    __syncthreads();
+                }
+                {   // first round: the top 64 coefficients of the remainder; lane 0's is X = lc r''
+                    const bool act = lane < min(64, top);
+                    const int idx = top - 1 - lane;
+                    const uint32_t *pu = ZERO, *pw1 = ZERO, *pw0 = ZERO;
+                    if (act) { pu = R0 + (size_t)idx * NL; pw1 = idx >= 1 ? R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = R1 + (size_t)idx * NL; }
+                    uint32_t r[NL];
+                    gao_round<NL>(r, S, pu, S + NL, pw1, S + 2 * NL, pw0, GK, P);
+                    __syncthreads();             // (one wave: orders this round's LDS reads before its writes -- a lane's neighbour reads R1 only, but lane 0 overwrites NEGX)
+                    if (act) lds_put<NL>(R0 + (size_t)idx * NL, r);
+                    if (lane == 0) {
 #pragma unroll
-                        for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)r[q], 63);
+                        for (int q = 0; q < NL; q++) NEGX[q] = 0u - r[q];
                     }
                     __syncthreads();
                 }
-                if (lane < 2) {
+                {   // second round: the rest of the remainder, the cofactor, c0, and the next step's multipliers
+                    const uint32_t *Xa = R0 + (size_t)(top - 1) * NL, *Ya = R1 + (size_t)dR1 * NL, *Za = R1 + (size_t)(dR1 - 1) * NL, *Wa = R0 + (size_t)(top - 2) * NL;
+                    const uint32_t *pm0 = S, *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO, *pm2 = ZERO, *pw0 = ZERO;
+                    uint32_t *dst = nullptr;
+                    if (lane < n2) {
+                        const int idx = n2 - 1 - lane;
+                        pu = R0 + (size_t)idx * NL; pw1 = idx >= 1 ? R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = R1 + (size_t)idx * NL;
+                        pm1 = S + NL; pm2 = S + 2 * NL; dst = R0 + (size_t)idx * NL;
+                    } else if (lane <= n2 + ttop) {
+                        const int idx = lane - n2;
+                        pu = T0 + (size_t)idx * NL;
+                        pw1 = (idx >= 1 && idx - 1 <= dT1) ? T1 + (size_t)(idx - 1) * NL : ZERO;
+                        pw0 = idx <= dT1 ? T1 + (size_t)idx * NL : ZERO;
+                        pm1 = S + NL; pm2 = S + 2 * NL; dst = T0 + (size_t)idx * NL;
+                    } else if (isJ) {
+                        pm0 = jb == 0 ? Xa : NEGX; pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za);
+                        if (jb == 2) { pm1 = Ya; pw1 = Wa; }
+                        dst = S + (size_t)jb * NL;
+                    } else if (lane == 63) { pu = CA; dst = CA; }          // c0 <- L^2 c0
+                    uint32_t r[NL];
+                    gao_round<NL>(r, pm0, pu, pm1, pw1, pm2, pw0, GK, P);
+                    __syncthreads();             // (the jobs overwrite the multipliers every other lane has just read)
+                    if (dst) lds_put<NL>(dst, r);
+                    if (lane < 2) {
 #pragma unroll
-                    for (int q = 0; q < NL; q++) R0[(size_t)(top + lane) * NL + q] = 0;
+                        for (int q = 0; q < NL; q++) R0[(size_t)(top + lane) * NL + q] = 0;
+                    }
+                    __syncthreads();
                 }
                 dT0 = ttop;
                 have_sc = true;                  // (withdrawn below if the degree did not drop by exactly one)
-                __syncthreads();
             } else {
             have_sc = false;
+            uint32_t L[NL], c0[NL];
+            lds_get<NL>(L, R1 + (size_t)dR1 * NL);
+            lds_get<NL>(c0, CA);
             for (int j = delta; j >= 0; j--) {
                 uint32_t a[NL], an[NL];
                 lds_get<NL>(a, R0 + (size_t)(dR1 + j) * NL);
+                cond_sub_p(a, P);                 // (lazy residues: canonical before the negation)
                 fp_neg(an, a, P);                 // L u - a w = L u + (p - a) w: ONE reduction for the two products (columns stay below
-                                                  // 3 NL 2^58 < 2^63; the sum is < 2 p^2 < p R / 16, so REDC leaves < 2p: one conditional subtraction)
+                                                  // 3 NL 2^58 < 2^63; the sum is < 3 p^2 < p R / 8, so REDC leaves < 2p: one conditional subtraction)
                 __syncthreads();
                 const int top = dR1 + j;
                 const int ttop = max(dT0, dT1 + j);
@@ -364,67 +385,62 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
                 dT0 = ttop;
                 __syncthreads();
             }
+            if (lane == 0) lds_put<NL>(CA, c0);
+            __syncthreads();
             }
             {   // the degree drops by exactly one as a rule: look at that coefficient before scanning the polynomial
                 uint32_t topc[NL];
-                if (dR1 >= 1) lds_get<NL>(topc, R0 + (size_t)(dR1 - 1) * NL);
-                dR0 = (dR1 >= 1 && !fp_is_zero(topc)) ? dR1 - 1 : poly_degree<NL>(R0, dR1 - 1, lane);
-                if (dR0 != dR1 - 1) have_sc = false;     // the next step's scalars were computed for a remainder of degree deg r1 - 1
+                bool nz = false;
+                if (dR1 >= 1) { lds_get<NL>(topc, R0 + (size_t)(dR1 - 1) * NL); nz = !is_zero_lazy<NL>(topc, P); }
+                dR0 = nz ? dR1 - 1 : poly_degree_lazy<NL>(R0, dR1 - 1, lane, P);
+                if (dR0 != dR1 - 1) have_sc = false;     // the next step's multipliers were computed for a remainder of degree deg r1 - 1
             }
-            if (dR0 < D) { rp = R0; vp = T0; dr = dR0; dvb = dT0; fp_set(cs, c0); break; }
+            if (dR0 < D) { rp = R0; vp = T0; dr = dR0; dvb = dT0; csp = CA; break; }
             // (r0, r1) <- (r1, r2)
             uint32_t *tp = R0; R0 = R1; R1 = tp;
             tp = T0; T0 = T1; T1 = tp;
+            tp = CA; CA = CB; CB = tp;
             int ti = dR0; dR0 = dR1; dR1 = ti;
             ti = dT0; dT0 = dT1; dT1 = ti;
-            uint32_t tc[NL]; fp_set(tc, c0); fp_set(c0, c1); fp_set(c1, tc);
         }
     }
     // ---- f = r / v (exact, deg f < k), v = V / cs: everything but the inversion ------------
-    const int dv = poly_degree<NL>(vp, dvb, lane);
+    const int dv = poly_degree_lazy<NL>(vp, dvb, lane, P);
     bool ok = dv >= 0;
-    uint32_t lcv[NL];
-    fp_set(lcv, P.one);
     uint32_t *F = (rp == R0) ? R1 : R0;            // the remainder array not in use: the raw quotient digits c_i (up to D of them)
+    uint32_t *LV = S, *CN = S + NL;                // lc(V) and the negated quotient digit of the round, where the Euclid loop kept its multipliers
     int df = -1, dq = -1;
     if (ok) {
-        lds_get<NL>(lcv, vp + (size_t)dv * NL);
-        // the cofactor V as it is (Montgomery form, packed): k_gao_finish scales it by 1 / cs
+        // the cofactor V as it is (Montgomery form, packed, canonical): k_gao_finish scales it by 1 / cs
         for (int idx = lane; idx <= dv; idx += 64) {
             uint32_t u[NL];
             lds_get<NL>(u, vp + (size_t)idx * NL);
+            cond_sub_p(u, P);
             store_digits<NL, NW>(errloc + ((size_t)c * (npts + 1) + idx) * NW, u);
         }
         if (dr >= 0) {
             if (dr < dv) ok = false;               // non-zero remainder
             else {
                 dq = dr - dv;
+                __syncthreads();
+                if (lane < NL) LV[lane] = vp[(size_t)dv * NL + lane];
                 for (int i = dq; i >= 0; i--) {
-                    uint32_t coef[NL], cn[NL];
-                    lds_get<NL>(coef, rp + (size_t)(i + dv) * NL);
-                    fp_neg(cn, coef, P);
-                    __syncthreads();
-                    if (lane == 0) lds_put<NL>(F + (size_t)i * NL, coef);
                     // r <- l r - c_i x^i V below the leading term (which cancels): every remaining coefficient takes the factor l
-                    for (int idx = lane; idx < i + dv; idx += 64) {
-                        uint32_t u[NL], r[NL];
-                        uint64_t col[2 * NL];
-                        lds_get<NL>(u, rp + (size_t)idx * NL);
-                        col_zero(col);
-                        mac<NL>(col, lcv, u);
-                        if (idx >= i) {
-                            uint32_t w[NL];
-                            lds_get<NL>(w, vp + (size_t)(idx - i) * NL);
-                            mac<NL>(col, cn, w);
-                        }
-                        redc(r, col, P);
-                        cond_sub_p(r, P);
-                        lds_put<NL>(rp + (size_t)idx * NL, r);
+                    if (lane < NL) { const uint32_t cq = rp[(size_t)(i + dv) * NL + lane]; F[(size_t)i * NL + lane] = cq; CN[lane] = 0u - cq; }
+                    __syncthreads();
+                    for (int base = 0; base < i + dv; base += 64) {
+                        const int idx = base + lane;
+                        const bool act = idx < i + dv;
+                        const uint32_t *pu = act ? rp + (size_t)idx * NL : ZERO;
+                        const uint32_t *pw = (act && idx >= i) ? vp + (size_t)(idx - i) * NL : ZERO;
+                        uint32_t r[NL];
+                        gao_round2<NL>(r, LV, pu, CN, pw, GK, P);
+                        if (act) lds_put<NL>(rp + (size_t)idx * NL, r);         // (a lane reads and writes its own coefficient of r; V is read only)
                     }
                     __syncthreads();
                 }
-                if (poly_degree<NL>(rp, dv - 1, lane) >= 0) ok = false;   // remainder must vanish (l != 0: scaled or not)
-                df = poly_degree<NL>(F, dq, lane);                        // c_i = l^(dq - i + 1) q_i: zero exactly where q_i is
+                if (poly_degree_lazy<NL>(rp, dv - 1, lane, P) >= 0) ok = false;   // remainder must vanish (l != 0: scaled or not)
+                df = poly_degree_lazy<NL>(F, dq, lane, P);                        // c_i = l^(dq - i + 1) q_i: zero exactly where q_i is
                 if (df >= k) ok = false;
             }
         }
@@ -432,15 +448,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
     if (ok) {
         for (int i = lane; i < k; i += 64) {
             uint32_t o[NL];
-            if (i <= df) lds_get<NL>(o, F + (size_t)i * NL);
+            if (i <= df) { lds_get<NL>(o, F + (size_t)i * NL); cond_sub_p(o, P); }
             else {
 #pragma unroll
                 for (int q = 0; q < NL; q++) o[q] = 0;
             }
             store_digits<NL, NW>(coeffs + ((size_t)c * k + i) * NW, o);
         }
-        // side record: cs, l (Montgomery form, packed), dq
+        // side record: cs, l (Montgomery form, packed, canonical), dq
         if (lane == 0) {
+            uint32_t cs[NL], lcv[NL];
+            lds_get<NL>(cs, csp);
+            cond_sub_p(cs, P);
+            if (dv >= 0) lds_get<NL>(lcv, vp + (size_t)dv * NL); else fp_set(lcv, P.one);
+            cond_sub_p(lcv, P);
             store_digits<NL, NW>(side + (size_t)c * (2 * NW + 4), cs);
             store_digits<NL, NW>(side + (size_t)c * (2 * NW + 4) + NW, lcv);
             side[(size_t)c * (2 * NW + 4) + 2 * NW] = (uint32_t)dq;
@@ -587,7 +608,7 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     hb_view iv{npts, 1}, ov{npts, 1};
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }          // (nothing of this call may still be writing the scratch when the next one starts)
-    size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 4) * NLr * 4;      // R0, R1, T0, T1, a zero element, three scalars
+    size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 7) * NLr * 4;      // R0, R1, T0, T1, a zero element, three multipliers, -X, c0, c1
     // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one
     uint32_t *side = nullptr;
     const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
