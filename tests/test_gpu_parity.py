@@ -778,6 +778,30 @@ def test_wb_golden_cfg4_shape_hip(golden):
         assert len(err) - 1 == len(case["errpos"])
 
 
+@pytest.mark.parametrize("p,n,k", [(13, 12, 4), (53, 22, 8), (257, 70, 20), (65537, 100, 34), ((1 << 256) - 189, 100, 34), ((1 << 64) - 59, 40, 10)])
+def test_gao_lazy_residues_many_words(hip, p, n, k):
+    """k_gao keeps its residues lazy (a multiple of p may sit in LDS as p itself) and tests for zero accordingly: in small fields
+    remainders, cofactor coefficients and quotient digits that vanish are common, at the top of the range the lazy values pass 2^256.
+    Every error count 0 .. radius + 2, erased words aside (the batch entry point takes complete words), against the oracle."""
+    rnd = random.Random(p % 1000 + n)
+    x = list(range(1, n + 1)) if p > n else list(range(n))
+    emax = (n - k) // 2
+    words = []
+    for trial in range(400 if n <= 40 else 160):
+        msg = [rnd.randrange(p) for _ in range(k)]
+        if trial % 7 == 0:
+            msg = [0] * rnd.randrange(k + 1) + msg[:0]
+            msg += [0] * (k - len(msg))
+        if trial % 11 == 0:
+            msg = [rnd.randrange(p)] + [0] * (k - 1)                 # a constant polynomial
+        enc = oracle.vandermonde_batch_evaluate(x, [msg], p)[0]
+        ne = min(trial % (emax + 3), n)
+        words.append(_corrupt(rnd, enc, ne, 0, p)[0])
+    got = hip.gao_interpolate_batch(x, words, k, p)
+    want = oracle.gao_interpolate_batch(x, words, k, p)
+    assert got == want
+
+
 @pytest.mark.parametrize("p,n,k,reps", [(P, 100, 34, 6), (P, 64, 22, 8), (53, 22, 8, 40), (13, 10, 3, 40), (P, 7, 1, 6)])
 def test_wb_batch_vs_oracle(p, n, k, reps):
     from honeybadgermpc_amd.device import wb_decode_batch
