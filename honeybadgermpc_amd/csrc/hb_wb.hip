@@ -354,15 +354,19 @@ __global__ void k_wb_any_erasure(const uint8_t *__restrict__ present, int64_t to
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total && present[i] == 0) atomicOr(flag, 1);
 }
-// Gao's coefficient rows -> the reference's outcome for the codewords it decoded: status 0 and the length after
-// stripping trailing zeros (polynomial.py:14-20); the others are left to k_wb
+// Gao's coefficient rows -> the reference's outcome for the codewords it decoded WITHIN THE RADIUS: status 0 and the length after
+// stripping trailing zeros (polynomial.py:14-20); the others are left to k_wb.  Gao's acceptance alone is not enough: a message of
+// low degree (leading coefficients zero) is decoded by Gao with MORE than floor((n - k) / 2) errors (deg r = deg f + e stays below
+// (n + k) / 2), and out there the reference's solver is on its own -- at e' = 11 of n = 25, k = 4 it meets an underdetermined system,
+// takes a particular solution that does not divide and ends in "found no divisors!" where Gao returns the constant polynomial
+// (scratch/stress_gao.py found the word).  So: only locators of degree <= emax count.
 template <int NW>
-__global__ void k_wb_take_gao(const uint8_t *__restrict__ ok, const uint32_t *__restrict__ coeffs, int k, int64_t C,
+__global__ void k_wb_take_gao(const uint8_t *__restrict__ ok, const int32_t *__restrict__ errlen, int emax, const uint32_t *__restrict__ coeffs, int k, int64_t C,
                               int32_t *__restrict__ coeff_len, int32_t *__restrict__ status, int32_t *__restrict__ rejected,
                               int32_t *__restrict__ todo) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    if (!ok[c]) { todo[atomicAdd(rejected, 1)] = (int32_t)c; return; }   // the row reduction's work list (any order: codewords are independent)
+    if (!ok[c] || errlen[c] - 1 > emax) { todo[atomicAdd(rejected, 1)] = (int32_t)c; return; }   // the row reduction's work list (any order: codewords are independent)
     int len = k;
     while (len > 0) {
         const uint32_t *e = coeffs + ((size_t)c * k + (len - 1)) * NW;
@@ -432,8 +436,8 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
             rc = ctx_scratch(ctx, "wb.todo", (size_t)C * sizeof(int32_t), (void **)&todo); if (rc) return rc;
             rc = hb_gao_decode(ctx, x_host, n, k, ys_dev, C, coeffs_dev, (uint64_t *)errloc, errlen, gao_ok, stream);
             if (rc) return rc;
-            if (ctx->n_limbs == 4) k_wb_take_gao<8><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
-            else k_wb_take_gao<2><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
+            if (ctx->n_limbs == 4) k_wb_take_gao<8><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (n - k) / 2, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
+            else k_wb_take_gao<2><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (n - k) / 2, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
             HB_LAUNCH_CHECK(ctx);
             int32_t rej = 0;
             HB_HIP(ctx, hipMemcpyAsync(&rej, ctx->flag_dev + 1, sizeof rej, hipMemcpyDeviceToHost, s));

@@ -298,6 +298,47 @@ def gen_wb_cfg4():
 
 
 # --------------------------------------------------------------------------- F
+def gen_wb_low_degree():
+    """Words Gao's decoder accepts BEYOND floor((n - k) / 2) errors -- the message has leading zeros, so deg f + e stays below
+    (n + k) / 2 -- judged by the reference's own Welch-Berlekamp decoder: out there its descending-e' loop and the particular
+    solution it takes decide (n = 25, k = 4, a constant message, 11 errors: "found no divisors!"), and a batched decoder that
+    shortcuts through Gao must not take Gao's word for them.  Small shapes: the reference's pure Python runs them in seconds."""
+    rnd = random.Random(1414)
+    cases = []
+    for p, n, k in [(53, 25, 4), (53, 22, 8), (257, 16, 5), (BLS, 13, 3), (BLS, 25, 4), (BLS, 20, 7)]:
+        enc, dec, _ = make_wb_encoder_decoder(n, k, p)
+        x = list(range(1, n + 1))
+        emax = (n - k) // 2
+        fpw = GF(p)
+        for keep in range(0, k):                                  # the message's degree + 1
+            for extra in (1, 2, 3):
+                ne = emax + extra
+                if keep + ne >= (n + k + 1) // 2 + 1 or ne > n:    # (a little past what Gao still decodes, too)
+                    continue
+                for _ in range(2):
+                    msg = [rnd.randrange(1, p) for _ in range(keep)] + [0] * (k - keep)
+                    encoded = [v.value for v in enc(msg)]
+                    word, errpos = corrupt(rnd, encoded, ne, 0, p)
+                    try:
+                        out = dec([fpw(w) for w in word], debug=False)
+                        res = {"coeffs": [c.value for c in out], "error": None}
+                    except Exception as e:  # noqa: BLE001 - the reference raises bare Exceptions
+                        res = {"coeffs": None, "error": str(e)}
+                    cases.append({"p": p, "n": n, "k": k, "x": x, "msg": msg, "word": word, "errpos": errpos, "beyond_radius": True, **res})
+    # the word scratch/stress_gao.py met first
+    p, n, k = 53, 25, 4
+    enc, dec, _ = make_wb_encoder_decoder(n, k, p)
+    word = [11, 11, 11, 11, 11, 11, 47, 11, 11, 51, 43, 13, 11, 36, 11, 21, 11, 11, 38, 13, 10, 38, 11, 11, 51]
+    fpw = GF(p)
+    try:
+        out = dec([fpw(w) for w in word], debug=False)
+        res = {"coeffs": [c.value for c in out], "error": None}
+    except Exception as e:  # noqa: BLE001
+        res = {"coeffs": None, "error": str(e)}
+    cases.append({"p": p, "n": n, "k": k, "x": list(range(1, n + 1)), "msg": [11, 0, 0, 0], "word": word, "errpos": None, "beyond_radius": True, **res})
+    dump("welch_berlekamp_low_degree.json", S({"cases": cases}))
+
+
 def gen_misc():
     out = {
         "chunk_data": [
@@ -493,6 +534,7 @@ if __name__ == "__main__":
     gen_fft_interpolate()
     gen_wb()
     gen_wb_cfg4()
+    gen_wb_low_degree()
     gen_misc()
     gen_incremental()
     gen_batch_reconstruct()

@@ -758,6 +758,25 @@ def test_wb_golden_hip(golden):
     assert seen == {None, "No solution", "found no divisors!"}
 
 
+def test_wb_low_degree_messages_beyond_the_radius_hip(golden):
+    """hb_wb_decode sends complete words through Gao's kernel first.  Gao decodes a message with leading zeros past
+    floor((n - k) / 2) errors; the reference's Welch-Berlekamp decoder (the fixture is its output) refuses those words, so Gao's
+    acceptance counts only within the radius (k_wb_take_gao) -- 41 of these 167 words came back decoded before that."""
+    from honeybadgermpc_amd.device import wb_decode_batch
+
+    cases = golden("welch_berlekamp_low_degree.json")["cases"]
+    groups = {}
+    for case in cases:
+        groups.setdefault((case["p"], case["n"], case["k"]), []).append(case)
+    for (p, n, k), group in groups.items():
+        res = wb_decode_batch(group[0]["x"], k, [c["word"] for c in group], p)
+        for case, (coeffs, status) in zip(group, res):
+            if case["error"] is None:
+                assert status == 0 and coeffs == case["coeffs"], (p, n, k, case["word"])
+            else:
+                assert coeffs is None and oracle.WB_MESSAGES[status] == case["error"], (p, n, k, case["word"], coeffs, status)
+
+
 def test_wb_golden_cfg4_shape_hip(golden):
     """the reference's own Welch-Berlekamp outcomes at config 4's shape (n = 100, k = 34: 33 errors, erasures + errors, a
     stripped result, one word beyond the radius) through hb_wb_decode, and the error-free-erasure cases through hb_gao_decode"""

@@ -217,6 +217,23 @@ def test_golden_welch_berlekamp_cfg4_shape(golden):
     assert outcomes == {None, "No solution"}
 
 
+def test_golden_welch_berlekamp_low_degree_messages(golden):
+    """Words with MORE than floor((n - k) / 2) errors whose message has leading zeros: Gao's decoder still accepts many of them
+    (deg f + e < (n + k) / 2), the reference's Welch-Berlekamp decoder -- whose outcomes these are -- does not.  The oracle's WB
+    must follow the reference; its Gao must decode a fair share (that is what makes the fixture bite on a Gao shortcut)."""
+    cases = golden("welch_berlekamp_low_degree.json")["cases"]
+    assert len(cases) > 100
+    gao_decodes = 0
+    for case in cases:
+        res, status = oracle.wb_decode_batch(case["x"], case["k"], [case["word"]], case["p"])[0]
+        if case["error"] is None:
+            assert status == 0 and res == case["coeffs"], case
+        else:
+            assert res is None and oracle.WB_MESSAGES[status] == case["error"], (status, case["error"])
+        gao_decodes += oracle.gao_interpolate(case["x"], case["word"], case["k"], case["p"])[0] is not None
+    assert gao_decodes >= 30
+
+
 def test_golden_wb_vs_gao(golden):
     """Inside the decoding radius Gao must return what the reference's WB returns, and the
     roots of its error locator must be exactly the corrupted positions."""
