@@ -27,6 +27,13 @@ while time.time() < t_end:
     point = EvalPoint(GF(P), n, use_omega_powers=use_omega)
     xs = [point(i).value for i in range(n)]
     polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+    if rnd.random() < 0.4:
+        # polynomials with leading zeros: what chunk_data's zero padding makes of the last chunk of every open (utils/misc.py:33-48), and
+        # where Gao decodes past floor((n' - k) / 2) errors while Welch-Berlekamp does not (tests/golden/welch_berlekamp_low_degree.json)
+        for j in ([c - 1] if rnd.random() < 0.5 else range(c)):
+            if rnd.random() < 0.7:
+                keep = rnd.randrange(0, t + 1)
+                polys[j] = polys[j][:keep] + [0] * (t + 1 - keep)
     cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
     liars = rnd.sample(range(n), min(n, rnd.randrange(0, t + 2) + (rnd.randrange(0, t) if rnd.random() < 0.1 else 0)))          # sometimes one liar too many, now and then many
     # half of the runs: the liars are coordinated -- on the chunks they hit they all send the values of ONE other polynomial (which may
@@ -83,7 +90,9 @@ while time.time() < t_end:
         if host.done():
             hres, _ = host.get_results()
             dres, _ = dev.get_results()
-            if ctx.download_ints(dres.reshape(-1, 4)) != [v for row in hres for v in row]:
+            # (the reference's Welch-Berlekamp rows come with their trailing zeros stripped, reed_solomon_wb.py:151 over polynomial.py:14-20;
+            # the device decoder's result is a (C, degree + 1, limbs) tensor: compared padded)
+            if ctx.download_ints(dres.reshape(-1, 4)) != [v for row in hres for v in list(row) + [0] * (t + 1 - len(row))]:
                 bad = ("result", step)
             break
     robust_runs += dev.probes + dev.radius_verdicts + dev.launches > 0

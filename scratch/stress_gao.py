@@ -49,6 +49,13 @@ while time.time() < t_end:
         print(f"stress_gao: MISMATCH (gao) p={p} n={n} k={k} x={x} word={words[bad]} got={got[bad]} want={want[bad]}")
         sys.exit(1)
     if n <= 40 or len(words) <= 7:               # (the oracle's Welch-Berlekamp is cubic in n)
+        cmax = n - 2 * (k - 1) - 1                # erasures the reference's decoder admits (reed_solomon_wb.py:131)
+        if cmax > 0 and rnd.random() < 0.5:       # ... in half of the batches some words lose symbols (the row reduction takes those throughout)
+            words = [list(w) for w in words]
+            for w in words:
+                if rnd.random() < 0.6:
+                    for i in rnd.sample(range(n), rnd.randrange(1, cmax + 1)):
+                        w[i] = None
         gw = wb_decode_batch(x, k, words, p)
         ww = oracle.wb_decode_batch(x, k, words, p)
         if gw != ww:
