@@ -187,10 +187,15 @@ class Context:
     """One (modulus, device) pair: owns an ``hb_ctx`` and does the torch plumbing."""
 
     _cache = {}
+    _seen = {}          # the (modulus, device, n_limbs) triples as callers spell them -> context
 
     @classmethod
     def get(cls, modulus, device=None, n_limbs=None):
         """n_limbs: 1 (8-byte elements, p < 2^64) or 4 (32-byte elements); default = the narrowest that holds p."""
+        # (a decoder is made per open and per round: the context it asks for is found without touching torch)
+        ctx = cls._seen.get((modulus, device, n_limbs)) if device is not None else None
+        if ctx is not None:
+            return ctx
         import torch
 
         if not torch.cuda.is_available():
@@ -198,6 +203,7 @@ class Context:
                 "honeybadgermpc_amd needs an MI355X (gfx950) GPU: torch.cuda.is_available() is False "
                 "and there is no CPU fallback."
             )
+        asked = (modulus, device, n_limbs) if device is not None else None
         if device is None:
             device = torch.cuda.current_device()
         if n_limbs is None:
@@ -207,6 +213,8 @@ class Context:
         if ctx is None:
             ctx = cls(modulus, device, n_limbs)
             cls._cache[key] = ctx
+        if asked is not None and isinstance(device, int) and len(cls._seen) < 64:
+            cls._seen[asked] = ctx
         return ctx
 
     def __init__(self, modulus, device, n_limbs=4):

@@ -8,6 +8,7 @@ limbs of canonical residues -- the layout of the C ABI (include/hbmpc_hip.h).
 import ctypes
 import os
 import threading
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -263,6 +264,7 @@ def cached_batch_open(modulus, n, t, z, zc, use_omega_powers=False, degree=None,
 
 INT32_MAX = (1 << 31) - 1
 _points_cache = {}          # (modulus, n, omega powers?) -> (points as ints, packed host array)
+_checked_columns = {}       # id(receive buffer) -> (weak reference to it, the shape / device it was checked for)
 
 
 class _Probe:
@@ -457,9 +459,18 @@ class DeviceIncrementalDecoder:
         if columns is None:
             self._cols = ctx.empty(n * self.batch_size).view(n, self.batch_size, self.L)
         else:
-            if tuple(columns.shape) != (n, self.batch_size, self.L):
-                raise ValueError("columns must be an (n, batch_size, limbs) tensor")
-            self._cols = ctx.elems(columns.view(n * self.batch_size, self.L), n * self.batch_size, what="columns").view(n, self.batch_size, self.L)
+            # (a transport hands the same receive buffer to the decoder of every open: its checks are made once per buffer)
+            seen = _checked_columns.get(id(columns))
+            if seen is not None and seen[0]() is columns and seen[1] == (n, self.batch_size, self.L, ctx.device):
+                self._cols = columns
+            else:
+                if tuple(columns.shape) != (n, self.batch_size, self.L):
+                    raise ValueError("columns must be an (n, batch_size, limbs) tensor")
+                self._cols = ctx.elems(columns.view(n * self.batch_size, self.L), n * self.batch_size, what="columns").view(n, self.batch_size, self.L)
+                if columns.is_contiguous():
+                    if len(_checked_columns) >= 16:
+                        _checked_columns.clear()
+                    _checked_columns[id(columns)] = (weakref.ref(columns), (n, self.batch_size, self.L, ctx.device))
         self._confirmed_errors = set() if confirmed_errors is None else confirmed_errors
         self._available_points = set()
         self._z = []
