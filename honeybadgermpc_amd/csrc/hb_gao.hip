@@ -94,52 +94,35 @@ template <int NL> __device__ int poly_degree(const uint32_t *p, int hi, int lane
     return wave_max(best);
 }
 
-// Montgomery REDC of SIGNED columns (a sum of products some of which were subtracted; the total is non-negative by construction):
-// the same steps as fp29.hpp's redc with arithmetic shifts for the carries.
-template <int NL> __device__ __forceinline__ void redc_signed(uint32_t (&r)[NL], int64_t (&c)[2 * NL], const FpParams<NL> &P) {
-#pragma unroll
-    for (int i = 0; i < NL; i++) {
-        const uint32_t m = ((uint32_t)c[i] * P.n0) & DMASK;
-#pragma unroll
-        for (int j = 0; j < NL; j++) c[i + j] += (int64_t)((uint64_t)m * P.p[j]);
-        c[i + 1] += c[i] >> LB;
-    }
-#pragma unroll
-    for (int k = NL; k < 2 * NL - 1; k++) { c[k + 1] += c[k] >> LB; r[k - NL] = (uint32_t)c[k] & DMASK; }
-    r[NL - 1] = (uint32_t)c[2 * NL - 1];
-}
-// 2 p^2 in radix-2^29 digits: what a round adds to its signed sum of products so that the total is never negative
-template <int NL> struct GaoConsts { uint32_t k2pp[2 * NL]; };
+// K = p 2^j, the multiple of p with 29 (NL - 1) + 27 bits, in REDUNDANT digits: every digit but the top one at least 2^29 - 1 (a unit
+// borrowed from the next digit), the top one at least 2^26 - 1.  K - x, digit by digit, is then a non-negative representation of
+// -x mod p for any lazy residue x (digits below 2^29, top digit below 2^25): what a round subtracts it multiplies by such a
+// negation, so every sum of products is a sum of non-negative terms -- unsigned columns starting from zero, no offset, no signed
+// carries.  (Round 4's first pointer-driven version added 2 p^2 to signed columns: 36 SGPRs of zero-extended constants, and a middle
+// column's worst case, 35 products of 2^58, did not fit 63 bits.)
+template <int NL> struct GaoConsts { uint32_t kd[NL]; };
 
-// col += m * v with SIGNED digits (a negated multiplier is the digit-wise negation of a residue)
-template <int NL> __device__ __forceinline__ void mac_s(int64_t (&col)[2 * NL], const uint32_t (&m)[NL], const uint32_t (&v)[NL]) {
-#pragma unroll
-    for (int i = 0; i < NL; i++)
-#pragma unroll
-        for (int j = 0; j < NL; j++) col[i + j] += (int64_t)(int32_t)m[i] * (int32_t)v[j];
-}
-// ONE round of the Euclid loop / the division for one lane: r = (2 p^2 + m0 u + m1 w1 + m2 w0) / R mod p, every operand read from LDS through
+// ONE round of the Euclid loop / the division for one lane: r = (m0 u + m1 w1 + m2 w0) / R mod p, every operand read from LDS through
 // a pointer of the lane's own (a lane without a term points at the zero element).  No conditional subtraction: the kernel's
-// residues are LAZY -- with operands below 1.2 p the sum stays below 6.4 p^2 < p R / 5 (R = 2^(29 NL) >= 32 p), so REDC returns a
-// value below 1.2 p again, in normalised digits (a multiple of p comes out as 0 or as p itself: is_zero_lazy).
+// residues are LAZY -- with operands below 1.5 p (and K < R / 4) the sum stays below 6.8 p^2 + 1.5 p K < p R / 2, so REDC returns a
+// value below 1.45 p again (R = 2^(29 NL) >= 32 p), in normalised digits (a multiple of p comes out as 0 or as p itself:
+// is_zero_lazy).  Columns: a negation's digits are below 2^30, so a column holds at most 9 (2^59 + 2^58 + 2^58) + REDC's 9 2^58 < 2^64.
 template <int NL> __device__ __forceinline__ void gao_round(uint32_t (&r)[NL], const uint32_t *pm0, const uint32_t *pu, const uint32_t *pm1, const uint32_t *pw1,
-                                                            const uint32_t *pm2, const uint32_t *pw0, const GaoConsts<NL> &GK, const FpParams<NL> &P) {
-    int64_t col[2 * NL];
-#pragma unroll
-    for (int q = 0; q < 2 * NL; q++) col[q] = (int64_t)GK.k2pp[q];
-    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm0); lds_get<NL>(v, pu); mac_s<NL>(col, m, v); }
-    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm1); lds_get<NL>(v, pw1); mac_s<NL>(col, m, v); }
-    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm2); lds_get<NL>(v, pw0); mac_s<NL>(col, m, v); }
-    redc_signed<NL>(r, col, P);
+                                                            const uint32_t *pm2, const uint32_t *pw0, const FpParams<NL> &P) {
+    uint64_t col[2 * NL];
+    col_zero(col);
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm0); lds_get<NL>(v, pu); mac<NL>(col, m, v); }
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm1); lds_get<NL>(v, pw1); mac<NL>(col, m, v); }
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm2); lds_get<NL>(v, pw0); mac<NL>(col, m, v); }
+    redc(r, col, P);
 }
 template <int NL> __device__ __forceinline__ void gao_round2(uint32_t (&r)[NL], const uint32_t *pm0, const uint32_t *pu, const uint32_t *pm1, const uint32_t *pw1,
-                                                             const GaoConsts<NL> &GK, const FpParams<NL> &P) {
-    int64_t col[2 * NL];
-#pragma unroll
-    for (int q = 0; q < 2 * NL; q++) col[q] = (int64_t)GK.k2pp[q];
-    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm0); lds_get<NL>(v, pu); mac_s<NL>(col, m, v); }
-    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm1); lds_get<NL>(v, pw1); mac_s<NL>(col, m, v); }
-    redc_signed<NL>(r, col, P);
+                                                             const FpParams<NL> &P) {
+    uint64_t col[2 * NL];
+    col_zero(col);
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm0); lds_get<NL>(v, pu); mac<NL>(col, m, v); }
+    { uint32_t m[NL], v[NL]; lds_get<NL>(m, pm1); lds_get<NL>(v, pw1); mac<NL>(col, m, v); }
+    redc(r, col, P);
 }
 // a lazy residue is zero when its digits are all zero or are p's
 template <int NL> __device__ __forceinline__ bool is_zero_lazy(const uint32_t (&a)[NL], const FpParams<NL> &P) {
@@ -186,9 +169,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
     uint32_t *R0 = smem, *R1 = R0 + (size_t)len * NL, *T0 = R1 + (size_t)len * NL, *T1 = T0 + (size_t)lenT * NL;
     uint32_t *ZERO = T1 + (size_t)lenT * NL;       // a zero element
     uint32_t *S = ZERO + NL;                       // the three multipliers of a fused Euclid step: L^2, -(L a1), -a0 (residues)
-    uint32_t *NEGX = S + 3 * NL;                   // digit-wise negation of the newest leading coefficient (the jobs' subtracted multiplier)
+    uint32_t *NEGX = S + 3 * NL;                   // K - X, digit by digit, for the newest leading coefficient X (the jobs' subtracted multiplier)
     uint32_t *CA = NEGX + NL, *CB = CA + NL;       // the scale factors c0, c1 of the fraction-free loop
-    if (lane < NL) { ZERO[lane] = 0; CA[lane] = P.one[lane]; CB[lane] = P.one[lane]; }
+    uint32_t *KD = CB + NL;                        // K's redundant digits, for the lanes that negate element-wise
+    if (lane < NL) {
+        uint32_t kq = 0;
+#pragma unroll
+        for (int q = 0; q < NL; q++) kq = lane == q ? GK.kd[q] : kq;
+        ZERO[lane] = 0; CA[lane] = P.one[lane]; CB[lane] = P.one[lane]; KD[lane] = kq;
+    }
 
     for (int idx = lane; idx < len; idx += 64) {
         uint32_t a[NL], z[NL], m[NL];
@@ -228,7 +217,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
             // round (the rest of the remainder, the cofactor, c0, the three jobs) starts.  With (X, Y, Z, W) = (lc r'', L, r1[deg r1 - 1],
             // r''[deg r'' - 1]): job0 = X X, job1 = -X Y, job2 = Y W - X Z -- the residues of the NEGATED multipliers, so that the
             // update is a plain sum S0 u + S1 w1 + S2 w0; the jobs subtract through NEGX, the digit-wise negation of X that the lane which
-            // computed X left in LDS (signed multiply-adds, 2 p^2 in the columns).  Values equal to the sub-steps' mod p, term by term.
+            // computed X left in LDS (K - X in K's redundant digits: GaoConsts).  Values equal to the sub-steps' mod p, term by term.
             const int ttop_f = max(dT0, dT1 + 1), n2_f = max(0, dR1 - 64);
             if (delta == 1 && dR1 >= 2 && n2_f + ttop_f + 1 <= 60) {
                 const int top = dR1, ttop = ttop_f, n2 = n2_f;
@@ -236,13 +225,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
                 const bool isJ = lane >= 60 && lane < 63;
                 if (!have_sc) {
                     // the multipliers of THIS step alone (first step, or after a degree anomaly): (X, Y, Z, W) = (L, lc r0, r0[deg r1], r1[deg r1 - 1])
-                    if (lane < NL) NEGX[lane] = 0u - R1[(size_t)dR1 * NL + lane];
+                    __syncthreads();
+                    if (lane < NL) NEGX[lane] = KD[lane] - R1[(size_t)dR1 * NL + lane];
                     __syncthreads();
                     const uint32_t *Xa = R1 + (size_t)dR1 * NL, *Ya = R0 + (size_t)(dR1 + 1) * NL, *Za = R0 + (size_t)dR1 * NL, *Wa = R1 + (size_t)(dR1 - 1) * NL;
                     const uint32_t *pm0 = ZERO, *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO;
                     if (isJ) { pm0 = jb == 0 ? Xa : NEGX; pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za); if (jb == 2) { pm1 = Ya; pw1 = Wa; } }
                     uint32_t r[NL];
-                    gao_round2<NL>(r, pm0, pu, pm1, pw1, GK, P);
+                    gao_round2<NL>(r, pm0, pu, pm1, pw1, P);
                     if (isJ) lds_put<NL>(S + (size_t)jb * NL, r);
                     __syncthreads();
                 }
@@ -252,12 +242,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
                     const uint32_t *pu = ZERO, *pw1 = ZERO, *pw0 = ZERO;
                     if (act) { pu = R0 + (size_t)idx * NL; pw1 = idx >= 1 ? R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = R1 + (size_t)idx * NL; }
                     uint32_t r[NL];
-                    gao_round<NL>(r, S, pu, S + NL, pw1, S + 2 * NL, pw0, GK, P);
+                    gao_round<NL>(r, S, pu, S + NL, pw1, S + 2 * NL, pw0, P);
                     __syncthreads();             // (one wave: orders this round's LDS reads before its writes -- a lane's neighbour reads R1 only, but lane 0 overwrites NEGX)
                     if (act) lds_put<NL>(R0 + (size_t)idx * NL, r);
                     if (lane == 0) {
 #pragma unroll
-                        for (int q = 0; q < NL; q++) NEGX[q] = 0u - r[q];
+                        for (int q = 0; q < NL; q++) NEGX[q] = GK.kd[q] - r[q];
                     }
                     __syncthreads();
                 }
@@ -281,7 +271,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
                         dst = S + (size_t)jb * NL;
                     } else if (lane == 63) { pu = CA; dst = CA; }          // c0 <- L^2 c0
                     uint32_t r[NL];
-                    gao_round<NL>(r, pm0, pu, pm1, pw1, pm2, pw0, GK, P);
+                    gao_round<NL>(r, pm0, pu, pm1, pw1, pm2, pw0, P);
                     __syncthreads();             // (the jobs overwrite the multipliers every other lane has just read)
                     if (dst) lds_put<NL>(dst, r);
                     if (lane < 2) {
@@ -426,7 +416,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
                 if (lane < NL) LV[lane] = vp[(size_t)dv * NL + lane];
                 for (int i = dq; i >= 0; i--) {
                     // r <- l r - c_i x^i V below the leading term (which cancels): every remaining coefficient takes the factor l
-                    if (lane < NL) { const uint32_t cq = rp[(size_t)(i + dv) * NL + lane]; F[(size_t)i * NL + lane] = cq; CN[lane] = 0u - cq; }
+                    if (lane < NL) { const uint32_t cq = rp[(size_t)(i + dv) * NL + lane]; F[(size_t)i * NL + lane] = cq; CN[lane] = KD[lane] - cq; }
                     __syncthreads();
                     for (int base = 0; base < i + dv; base += 64) {
                         const int idx = base + lane;
@@ -434,7 +424,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
                         const uint32_t *pu = act ? rp + (size_t)idx * NL : ZERO;
                         const uint32_t *pw = (act && idx >= i) ? vp + (size_t)(idx - i) * NL : ZERO;
                         uint32_t r[NL];
-                        gao_round2<NL>(r, LV, pu, CN, pw, GK, P);
+                        gao_round2<NL>(r, LV, pu, CN, pw, P);
                         if (act) lds_put<NL>(rp + (size_t)idx * NL, r);         // (a lane reads and writes its own coefficient of r; V is read only)
                     }
                     __syncthreads();
@@ -608,43 +598,46 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
     hb_view iv{npts, 1}, ov{npts, 1};
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }          // (nothing of this call may still be writing the scratch when the next one starts)
-    size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 7) * NLr * 4;      // R0, R1, T0, T1, a zero element, three multipliers, -X, c0, c1
+    size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 8) * NLr * 4;      // R0, R1, T0, T1, a zero element, three multipliers, -X, c0, c1, K
     // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one
     uint32_t *side = nullptr;
     const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
     rc = ctx_scratch(ctx, "gao.side", (size_t)C * side_words * 4, (void **)&side);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
     const unsigned fin_blocks = (unsigned)(((C + GAO_FIN_G - 1) / GAO_FIN_G + 63) / 64);
-    // 2 p^2 in radix-2^29 digits (schoolbook on 32-bit words)
-    uint32_t k2pp[18];
+    // K = p 2^j with 29 (NL - 1) + 27 bits, in redundant radix-2^29 digits (GaoConsts): a unit of every digit above the lowest lent to the digit below
+    uint32_t kd[9];
     {
-        const int W = ctx->n_limbs * 2;
-        uint32_t pw32[8], sq[17];
+        const int W = ctx->n_limbs * 2;                       // p as 32-bit words
+        uint32_t pw32[8], kw[10];
         for (int i = 0; i < W; i++) pw32[i] = (uint32_t)(ctx->p_limbs[i / 2] >> (32 * (i & 1)));
-        memset(sq, 0, sizeof sq);
+        int bits = 0;
+        for (int i = W - 1; i >= 0 && !bits; i--)
+            if (pw32[i]) bits = 32 * i + (32 - __builtin_clz(pw32[i]));
+        const int j = 29 * (NLr - 1) + 27 - bits, jw = j >> 5, jb = j & 31;      // (bits <= 32 W <= 29 (NL - 1) + 27: j >= 0)
+        memset(kw, 0, sizeof kw);
         for (int i = 0; i < W; i++) {
-            uint64_t cy = 0;
-            for (int j = 0; j < W; j++) { const uint64_t t = (uint64_t)pw32[i] * pw32[j] + sq[i + j] + cy; sq[i + j] = (uint32_t)t; cy = t >> 32; }
-            sq[i + W] = (uint32_t)cy;
+            const uint64_t v = (uint64_t)pw32[i] << jb;
+            if (i + jw < 10) kw[i + jw] |= (uint32_t)v;
+            if (i + jw + 1 < 10) kw[i + jw + 1] |= (uint32_t)(v >> 32);
         }
-        for (int i = 2 * W; i > 0; i--) sq[i] = (sq[i] << 1) | (sq[i - 1] >> 31);      // times two (sq[2 W] was zero)
-        sq[0] <<= 1;
-        for (int q = 0; q < 2 * NLr; q++) {
-            const int bit = 29 * q, j = bit >> 5, sft = bit & 31;
-            const uint64_t v = (uint64_t)(j < 17 ? sq[j] : 0) | ((uint64_t)(j + 1 < 17 ? sq[j + 1] : 0) << 32);
-            k2pp[q] = (uint32_t)(v >> sft) & DMASK;
+        for (int q = 0; q < NLr; q++) {
+            const int bit = 29 * q, w = bit >> 5, sft = bit & 31;
+            const uint64_t v = (uint64_t)kw[w] | ((uint64_t)(w + 1 < 10 ? kw[w + 1] : 0) << 32);
+            const uint32_t d = q < NLr - 1 ? (uint32_t)(v >> sft) & DMASK : (uint32_t)(v >> sft);
+            kd[q] = q == 0 ? d + (1u << LB) : (q < NLr - 1 ? d + (1u << LB) - 1 : d - 1);
         }
     }
     if (ctx->n_limbs == 4) {
         GaoConsts<9> gk;
-        memcpy(gk.k2pp, k2pp, sizeof gk.k2pp);
+        memcpy(gk.kd, kd, sizeof gk.kd);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
         k_gao_finish<9, 8><<<fin_blocks, 64, 0, s>>>(ctx->pw, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         GaoConsts<3> gk;
-        memcpy(gk.k2pp, k2pp, sizeof gk.k2pp);
+        memcpy(gk.kd, kd, sizeof gk.kd);
         k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
         k_gao_finish<3, 2><<<fin_blocks, 64, 0, s>>>(ctx->pn, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
     }
