@@ -402,7 +402,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
     int df = -1, dq = -1;
     if (ok) {
         // the cofactor V as it is (Montgomery form, packed, canonical): k_gao_finish scales it by 1 / cs
-        for (int idx = lane; idx <= dv; idx += 64) {
+        // (errloc == nullptr: the caller wants the locator's degree only -- hb_wb_decode)
+        for (int idx = lane; errloc && idx <= dv; idx += 64) {
             uint32_t u[NL];
             lds_get<NL>(u, vp + (size_t)idx * NL);
             cond_sub_p(u, P);
@@ -511,7 +512,7 @@ __global__ void __launch_bounds__(64) k_gao_finish(const FpParams<NL> P, int npt
         uint32_t inv_c_plain[NL], pw[NL];
         from_mont(inv_c_plain, inv_c, P);          // out of Montgomery form: (u R) b / R = u b, canonical
         from_mont(pw, linv, P);
-        const int nloc = errlen[c];
+        const int nloc = errloc ? errlen[c] : 0;
         // (four elements' loads in flight at a time: in place, so the compiler will not move a load above the previous store by itself)
         for (int e0 = 0; e0 < nloc; e0 += 4) {
             uint32_t u[4][NL];
@@ -550,10 +551,18 @@ __global__ void __launch_bounds__(64) k_gao_finish(const FpParams<NL> P, int npt
 }  // namespace
 
 extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const uint64_t *ys_dev, int64_t C,
-                             uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream) { HB_API_GUARD(ctx);
+                             uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream) {
+    if (C > 0 && !errloc_dev) return HB_ERR_BAD_ARG;
+    return hb::gao_decode(ctx, x_host, npts, k, ys_dev, C, coeffs_dev, errloc_dev, errloc_len_dev, ok_dev, stream);
+}
+
+// errloc_dev == nullptr: the error locators are not written (nor scaled by the finishing kernel), their lengths are -- what
+// hb_wb_decode's pre-pass needs of them (3.3 KB of HBM traffic per codeword at config 4 and a third of the finisher's work)
+int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const uint64_t *ys_dev, int64_t C,
+                   uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !x_host || npts < 1 || k < 0 || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0) return HB_OK;
-    if (!ys_dev || !coeffs_dev || !errloc_dev || !errloc_len_dev || !ok_dev) return HB_ERR_BAD_ARG;
+    if (!ys_dev || !coeffs_dev || !errloc_len_dev || !ok_dev) return HB_ERR_BAD_ARG;
     if (npts > 1023) return fail(ctx, HB_ERR_UNSUPPORTED, "gao: more than 1023 points");
     if (C > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "gao: batch too large");
     hipStream_t s = (hipStream_t)stream;

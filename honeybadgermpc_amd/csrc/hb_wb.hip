@@ -427,14 +427,12 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
         HB_HIP(ctx, hipMemcpyAsync(&erased, ctx->flag_dev, sizeof erased, hipMemcpyDeviceToHost, s));
         HB_HIP(ctx, hipStreamSynchronize(s));
         if (!erased) {
-            uint32_t *errloc = nullptr;
             int32_t *errlen = nullptr;
-            // (context scratch, reused by the next call: the locators alone are 0.85 GB at config 4 -- ctx_scratch, hb_common.hpp)
+            // (context scratch, reused by the next call -- ctx_scratch, hb_common.hpp)
             rc = ctx_scratch(ctx, "wb.gao_ok", (size_t)C, (void **)&gao_ok); if (rc) return rc;
-            rc = ctx_scratch(ctx, "wb.errloc", (size_t)C * (n + 1) * ctx->elem_words() * 4, (void **)&errloc); if (rc) return rc;
             rc = ctx_scratch(ctx, "wb.errlen", (size_t)C * sizeof(int32_t), (void **)&errlen); if (rc) return rc;
             rc = ctx_scratch(ctx, "wb.todo", (size_t)C * sizeof(int32_t), (void **)&todo); if (rc) return rc;
-            rc = hb_gao_decode(ctx, x_host, n, k, ys_dev, C, coeffs_dev, (uint64_t *)errloc, errlen, gao_ok, stream);
+            rc = hb::gao_decode(ctx, x_host, n, k, ys_dev, C, coeffs_dev, nullptr, errlen, gao_ok, stream);      // (the locators' lengths, not the locators)
             if (rc) return rc;
             if (ctx->n_limbs == 4) k_wb_take_gao<8><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (n - k) / 2, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
             else k_wb_take_gao<2><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (n - k) / 2, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
