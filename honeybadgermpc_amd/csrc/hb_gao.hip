@@ -196,7 +196,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
         } else lds_put<NL>(R1 + (size_t)idx * NL, z);
     }
     __syncthreads();
-    int dR0 = npts, dR1 = poly_degree<NL>(R1, npts - 1, lane), dT0 = -1, dT1 = 0;
+    // (degrees are the same in every lane: said to the compiler, so that the loop's control and pointer arithmetic stay scalar)
+    int dR0 = npts, dR1 = __builtin_amdgcn_readfirstlane(poly_degree<NL>(R1, npts - 1, lane)), dT0 = -1, dT1 = 0;
     const int D = (npts + k) / 2;
     uint32_t *rp, *vp, *csp; int dr, dvb;
     if (dR0 < D) {                     // rsdecode_impl.h:289-294 (cannot fire: deg g0 = n >= D)
@@ -382,7 +383,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
                 uint32_t topc[NL];
                 bool nz = false;
                 if (dR1 >= 1) { lds_get<NL>(topc, R0 + (size_t)(dR1 - 1) * NL); nz = !is_zero_lazy<NL>(topc, P); }
-                dR0 = nz ? dR1 - 1 : poly_degree_lazy<NL>(R0, dR1 - 1, lane, P);
+                dR0 = __builtin_amdgcn_readfirstlane(nz ? dR1 - 1 : poly_degree_lazy<NL>(R0, dR1 - 1, lane, P));
                 if (dR0 != dR1 - 1) have_sc = false;     // the next step's multipliers were computed for a remainder of degree deg r1 - 1
             }
             if (dR0 < D) { rp = R0; vp = T0; dr = dR0; dvb = dT0; csp = CA; break; }
@@ -395,7 +396,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
         }
     }
     // ---- f = r / v (exact, deg f < k), v = V / cs: everything but the inversion ------------
-    const int dv = poly_degree_lazy<NL>(vp, dvb, lane, P);
+    const int dv = __builtin_amdgcn_readfirstlane(poly_degree_lazy<NL>(vp, dvb, lane, P));
     bool ok = dv >= 0;
     uint32_t *F = (rp == R0) ? R1 : R0;            // the remainder array not in use: the raw quotient digits c_i (up to D of them)
     uint32_t *LV = S, *CN = S + NL;                // lc(V) and the negated quotient digit of the round, where the Euclid loop kept its multipliers
