@@ -831,7 +831,7 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic_from_profiles("cfg4"),
             "kernel": counters.get("kernel") or "k_gao (one wave per codeword: fraction-free extended Euclid + pseudo-division in LDS) behind k_mm8w (the interpolant g1 = V^-1 y) and before "
-                                                "k_gao_finish (one field inversion per codeword, one lane each); hb_wb_decode runs exactly these inside the unique-decoding radius",
+                                                "k_gao_finish (one field inversion per four codewords, one lane each); hb_wb_decode runs exactly these inside the unique-decoding radius",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": call_ms,
             "launch_note": "one hb_wb_decode call (synchronous: three kernels + the radius bookkeeping), bracketed by HIP events on the call's stream; "
                            "SURVEY 8d's 32 C (n + k) bytes; the kernel-by-kernel split is in profiles/",
@@ -840,9 +840,10 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
                        "peak": mad_peak / 1e12,
                        "peak_note": "1024 SIMDs x 64 lanes x 2.4 GHz / 4.4 cycles per v_mad_u64_u32 wave-instruction (half rate, profiles/r01_instruction_rates_ubench.txt)",
                        "frac": C * mads_cw / (call_ms * 1e-3) / mad_peak,
-                       "frac_note": "what separates it from 1: a round of 64 lanes runs for ~105 elements of a step (0.82), the multiply-adds are 47 % of the "
-                                    "wave-instructions k_gao issues (profiles/r04_pmc_cfg4.txt: carries, selects, LDS, the conditional subtraction), the "
-                                    "interpolant's matrix-core launch is in the time and not in the count.  Round 3's line counted the two-sub-step algorithm's "
+                       "frac_note": "what separates it from 1: a round of 64 lanes runs for ~105 elements of a step (0.82; ~50 of 64 in the division), the "
+                                    "multiply-adds are 70 % of the vector instructions k_gao issues (profiles/r04_pmc_cfg4.txt: 43.3 k per codeword, 30.5 k of them "
+                                    "multiply-adds; the rest is REDC's carries and pointer set-up), the interpolant's matrix-core launch and the finisher are in the "
+                                    "time and not in the count.  Round 3's line counted the two-sub-step algorithm's "
                                     "multiplications (2.6 times as many multiply-adds per codeword): its fraction is not comparable"},
             "note": "purely arithmetic-bound: ~1.6 10^6 multiply-adds per 4.3 KB codeword; the HBM fraction is what SURVEY 8d asks for, the multiply-add rate says how busy the chip is",
         },
