@@ -399,14 +399,7 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
             return HB_OK;
         }
     } tmp;
-    uint32_t *xd = nullptr, *xm = nullptr;
-    int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
-    tmp.bufs.push_back(xd);
-    rc = tmp.alloc(ctx, (void **)&xm, (size_t)n * NLr * 4); if (rc) return rc;
-    HB_DISPATCH(ctx,
-        (k_points_to_mont<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, xd, n, xm)),
-        (k_points_to_mont<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, xd, n, xm)));
-    HB_LAUNCH_CHECK(ctx);
+    int rc = HB_OK;
     // worst-case slab: (n+1) rows x (2e+k+2) columns with e <= (n - k + 1) / 2
     const int emax = (n - (k - 1)) / 2;
     const size_t slab_words = (size_t)(n + 1) * (size_t)(2 * emax + k + 2) * NLr;
@@ -446,6 +439,16 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
     if (rejected > 0) {
         // the slab-resident row reduction: one block per codeword in turn; no more blocks (and slabs) than codewords left for it
         int64_t blocks = rejected < 1024 ? rejected : 1024;
+        // the points in Montgomery form: only the row reduction reads them (a batch Gao's kernels settle entirely pays for no
+        // upload, no allocation and no synchronous hipFree)
+        uint32_t *xd = nullptr, *xm = nullptr;
+        rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
+        tmp.bufs.push_back(xd);
+        rc = tmp.alloc(ctx, (void **)&xm, (size_t)n * NLr * 4); if (rc) return rc;
+        HB_DISPATCH(ctx,
+            (k_points_to_mont<9, 8><<<(n + 63) / 64, 64, 0, s>>>(ctx->pw, xd, n, xm)),
+            (k_points_to_mont<3, 2><<<(n + 63) / 64, 64, 0, s>>>(ctx->pn, xd, n, xm)));
+        HB_LAUNCH_CHECK(ctx);
         uint32_t *scratch = nullptr;
         rc = tmp.alloc(ctx, (void **)&scratch, slab_words * 4 * (size_t)blocks); if (rc) return rc;
         HB_DISPATCH(ctx,
