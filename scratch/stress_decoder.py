@@ -69,7 +69,12 @@ while time.time() < t_end:
     host = IncrementalDecoder(EncoderFactory.get(point, codec), DecoderFactory.get(point, codec),
                               RobustDecoderFactory.get(t, point, algorithm=Algorithm.GAO if robust == "gao" else Algorithm.WELCH_BERLEKAMP),
                               degree=t, batch_size=c, max_errors=t)
-    dev = DeviceIncrementalDecoder(P, n, t, batch_size=c, robust=robust, use_omega_powers=use_omega)
+    # the two ways a transport feeds the decoder (copied columns / received in place) and the two things a round asks of it (every
+    # coefficient / the constant terms only: what R1 forwards) -- all four combinations
+    in_place = rnd.random() < 0.5
+    want = "constant" if rnd.random() < 0.35 else "all"
+    buf = ctx.empty(n * c).view(n, c, 4) if in_place else None
+    dev = DeviceIncrementalDecoder(P, n, t, batch_size=c, robust=robust, use_omega_powers=use_omega, columns=buf, want=want)
     bad = None
     for step, idx in enumerate(order):
         hexc = dexc = None
@@ -78,7 +83,12 @@ while time.time() < t_end:
         except BaseException as e:  # noqa: BLE001
             hexc = e
         try:
-            dev.add(idx, ctx.upload_ints(cols[idx]))
+            if in_place:
+                if dev.accepts(idx):
+                    dev.slot(idx).copy_(ctx.upload_ints(cols[idx]))
+                dev.add(idx)
+            else:
+                dev.add(idx, ctx.upload_ints(cols[idx]))
         except BaseException as e:  # noqa: BLE001
             dexc = e
         if (hexc is None) != (dexc is None) or (hexc is not None and type(hexc) is not type(dexc)):
@@ -92,7 +102,8 @@ while time.time() < t_end:
             dres, _ = dev.get_results()
             # (the reference's Welch-Berlekamp rows come with their trailing zeros stripped, reed_solomon_wb.py:151 over polynomial.py:14-20;
             # the device decoder's result is a (C, degree + 1, limbs) tensor: compared padded)
-            if ctx.download_ints(dres.reshape(-1, 4)) != [v for row in hres for v in list(row) + [0] * (t + 1 - len(row))]:
+            width = dres.shape[1]                 # 1: a constant-term decoder that finished on its optimistic step
+            if ctx.download_ints(dres.reshape(-1, 4)) != [v for row in hres for v in (list(row) + [0] * (t + 1 - len(row)))[:width]]:
                 bad = ("result", step)
             break
     robust_runs += dev.probes + dev.radius_verdicts + dev.launches > 0
