@@ -336,6 +336,22 @@ def gen_wb_low_degree():
     except Exception as e:  # noqa: BLE001
         res = {"coeffs": None, "error": str(e)}
     cases.append({"p": p, "n": n, "k": k, "x": list(range(1, n + 1)), "msg": [11, 0, 0, 0], "word": word, "errpos": None, "beyond_radius": True, **res})
+    # t = 0 with a single symbol present: the decoder's e = 0 branch interpolates (reed_solomon_wb.py:142-145), and the reference's
+    # Polynomial returns the ZERO polynomial of that branch as [0] (strip_trailing_zeros keeps one zero of an all-zero list,
+    # polynomial.py:14-20) -- oracle/diff_wb_vs_reference.py met it
+    for p, n in [(53, 4), (257, 3), (BLS, 5)]:
+        enc, dec, _ = make_wb_encoder_decoder(n, 1, p)
+        fpw = GF(p)
+        for val in (0, 7):
+            for pos in (0, n - 1):
+                word = [None] * n
+                word[pos] = val
+                try:
+                    out = dec([None if w is None else fpw(w) for w in word], debug=False)
+                    res = {"coeffs": [c.value for c in out], "error": None}
+                except Exception as e:  # noqa: BLE001
+                    res = {"coeffs": None, "error": str(e)}
+                cases.append({"p": p, "n": n, "k": 1, "x": list(range(1, n + 1)), "msg": [val], "word": word, "errpos": [], "beyond_radius": False, **res})
     dump("welch_berlekamp_low_degree.json", S({"cases": cases}))
 
 
@@ -449,15 +465,11 @@ def gen_batch_reconstruct():
 
 
 # --------------------------------------------------------------------------- H
-def gen_gao_cofactor():
-    """Gao's outputs pinned WITHOUT the oracle (SURVEY 8c(5), VERDICT r3 item 6): the recurrence of partial_gcd and the acceptance
-    test of gao_interpolate (rsdecode_impl.h:281-363) executed with the REFERENCE's own Polynomial class -- its interpolate, __mul__,
-    __sub__ and __divmod__ (polynomial.py:85-108, 202-234).  What is written: for each word (points, values with None = erasure, k)
-    the coefficient list and the un-normalised cofactor v = t_i exactly as the recurrence leaves it, or null / null where the
-    reference returns (None, None).  Words inside, at and beyond the unique-decoding radius, with and without erasures."""
-    fp = GF(BLS)
+def reference_polynomial_gao(p):
+    """-> gao(xs, ys, k): partial_gcd's recurrence and gao_interpolate's acceptance test (rsdecode_impl.h:281-363) executed with the
+    REFERENCE's own Polynomial class over GF(p) (used by gen_gao_cofactor and by oracle/diff_gao_vs_reference_polynomial.py)"""
+    fp = GF(p)
     poly = polynomials_over(fp)
-    rnd = random.Random(20240928)
     one, zero = poly([fp(1)]), poly([])
 
     def deg(p_):
@@ -500,6 +512,19 @@ def gen_gao_cofactor():
         coeffs = fc + [0] * (k - len(fc))                                         # exactly k, zero padded (rsdecode_impl.h:351-354)
         return coeffs, [c.value for c in v.coeffs]
 
+    return gao
+
+
+def gen_gao_cofactor():
+    """Gao's outputs pinned WITHOUT the oracle (SURVEY 8c(5), VERDICT r3 item 6): the recurrence of partial_gcd and the acceptance
+    test of gao_interpolate (rsdecode_impl.h:281-363) executed with the REFERENCE's own Polynomial class -- its interpolate, __mul__,
+    __sub__ and __divmod__ (polynomial.py:85-108, 202-234).  What is written: for each word (points, values with None = erasure, k)
+    the coefficient list and the un-normalised cofactor v = t_i exactly as the recurrence leaves it, or null / null where the
+    reference returns (None, None).  Words inside, at and beyond the unique-decoding radius, with and without erasures."""
+    rnd = random.Random(20240928)
+    fp = GF(BLS)
+    poly = polynomials_over(fp)
+    gao = reference_polynomial_gao(BLS)
     cases = []
     shapes = [(7, 3), (10, 4), (16, 6), (16, 6), (22, 8), (31, 11)]
     for n, k in shapes:

@@ -784,6 +784,9 @@ static int wb_decode_one(const field_t *F, const fe *xs, int n, int k, const fe 
         poly P; poly_init(&P, np + 1);
         poly_interpolate(F, &P, a, b, np);
         *out_len = P.deg + 1; for (int i = 0; i <= P.deg; i++) out[i] = P.c[i];
+        /* the reference's Polynomial.interpolate starts from cls([0]) and strip_trailing_zeros keeps ONE zero of an all-zero list
+         * (polynomial.py:14-20, 106-109): the zero polynomial leaves this branch as [0], not [] (oracle/diff_wb_vs_reference.py) */
+        if (*out_len == 0) { memset(&out[0], 0, sizeof out[0]); *out_len = 1; }
         poly_free(&P); free(a); free(b);
         return 0;
     }
