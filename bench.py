@@ -1256,6 +1256,9 @@ def main():
             "metric": "shares reconstructed/sec (batch open, n=64 t=21)" if args.workload.startswith("cfg3") else f"shares reconstructed/sec (batch open, n={n} t={t})",
             "value": value, "unit": "shares/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            # the same open as batch_reconstruct_device runs it: nothing kept per arrival pattern, one decoder per round fed column by column
+            # (detail.first_sight_note); `value` is the plan API, whose arrival set is fixed at plan creation
+            "value_first_sight_protocol_path": (B * args.steps / dt_first) if dt_first else None,
             "dtype": ("u256 (integer mod p): exact int8 x int8 -> int32 byte-split GEMM on the matrix cores; the high half of every sum folded mod p on the matrix cores too, one-word Barrett quotient"
                       if mfma else "u256 (integer mod p, 9 x 29-bit digits in u32, 64-bit accumulators)"), "data": "synthetic",
             "config": {
@@ -1325,6 +1328,7 @@ def main():
                                             "`value` is one open at a time on one stream",
                 "shares_per_s_per_gpu_first_sight_protocol_path": (B * args.steps / dt_first) if dt_first else None,
                 "first_sight_note": "(gc.freeze() after set-up: the interpreter's full collections are kept out of the timed loop) R1 encode + one DeviceIncrementalDecoder per round fed column by column in a fresh seeded arrival order every step "
+                                    "(its optimistic phase is an hb_dec object behind the C ABI: add(idx) is one call of hb_dec_arrived1, the verdict is waited for in C) "
                                     f"({first_cols} columns announced per open), columns received in place, nothing cached per arrival pattern: what "
                                     "batch_reconstruct_device runs; `value` is the same open through an open plan whose arrival set is fixed at plan creation",
                 "r2_decode_under_attack_first_sight": adv if dt_first else None,

@@ -19,6 +19,7 @@ LIB_PATH = os.environ.get("HBMPC_HIP_LIB") or os.path.join(_HERE, "lib", "libhbm
 
 HB_OK, HB_ERR_SINGULAR, HB_ERR_BAD_ARG, HB_ERR_UNSUPPORTED = 0, 1, 2, 3
 HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_MISMATCH = 4, 5, 6
+HB_DEC_COLLECTING, HB_DEC_DONE, HB_DEC_DISAGREE, HB_DEC_UNSUPPORTED = 0, 1, 2, 3
 
 _STATUS_NAMES = {
     1: "HB_ERR_SINGULAR",
@@ -67,6 +68,13 @@ SYMBOLS = {
     "hb_quick_dec_arrivals": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "hb_quick_dec_decide": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "hb_quick_dec_destroy": (None, [_vp]),
+    "hb_dec_create": (_i, [_vp, _vp, _i, _i, _i, _pp, _vp]),
+    "hb_dec_begin": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i, _vp]),
+    "hb_dec_arrived1": (_i, [_vp, _i]),
+    "hb_dec_arrived": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "hb_dec_verdict": (_i, [_vp, _vp, _vp]),
+    "hb_dec_arrivals_list": (_i, [_vp, _vp, _i, _vp]),
+    "hb_dec_destroy": (None, [_vp]),
     "hb_symbols_fetch": (_i, [_vp, _vp, _i, _i64, _i64, _vp, _i, _vp, _vp]),
     "hb_probe_create": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
     "hb_probe_feed": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _vp, _vp]),
@@ -128,6 +136,8 @@ def load_library():
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib
+    if _marshal is not None and hasattr(_marshal, "bind_dec"):
+        _marshal.bind_dec(ctypes.cast(lib.hb_dec_arrived1, ctypes.c_void_p).value)      # DeviceIncrementalDecoder.add calls it without ctypes
     return lib
 
 

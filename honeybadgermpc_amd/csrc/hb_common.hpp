@@ -311,7 +311,11 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
               const int32_t *pick_zc = nullptr);
 // the compared senders' rows for EVERY party, from the first d arrivals alone (L.o_cand != 0): a launch then names its compared senders
 // (fs_launch's pick_zc) instead of waiting for a second build
-int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout &L, uint8_t *base, int32_t *status_dev, hipStream_t s);
+// with_z: the same launch also builds what fs_build(FS_BUILD_Z) builds (two workgroups of one kernel)
+int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout &L, uint8_t *base, int32_t *status_dev, hipStream_t s, bool with_z = false);
+// would hb_quick_dec_arrivals take this shape (d arrivals, nc compared senders, n_coef rows stored) on this decoder's point set?  HB_OK or
+// HB_ERR_UNSUPPORTED -- no launch, nothing allocated (hb_dec_begin asks before it commits a round to the plan-free kernels)
+int quick_dec_supported(hb_quick_dec *qd, int d, int nc, int n_coef);
 // the wide image of a generic matrix, built on first use (nullptr when the path does not apply)
 const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *m, hipStream_t s);
 

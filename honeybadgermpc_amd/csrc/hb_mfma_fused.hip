@@ -424,11 +424,10 @@ __device__ __forceinline__ void fs_row_constant(const FpParams<9> &P, const FsCo
 //   waves 1, 2    1 / den_j = prod_{q != j} 1 / (x_zj - x_zq): four lanes per arrival, a quarter of the factors each      [Z]
 //   waves 3 ..    P[i][j] = prod_{q != j} (x_zci - x_zq), one thread per entry                                         [ZC]
 // Second phase: a thread per entry writes its 16 balanced digits; a thread per row its constant; 9 d threads the T tables.
-__global__ void __launch_bounds__(1024) k_fs_build(const FpParams<9> P, const uint32_t *__restrict__ inv, int n, const FsIdx ix, int d, int nc, int n_coef,
-                                                   int flags, const FsConsts cs, uint8_t *__restrict__ a8, uint32_t *__restrict__ crow, uint32_t *__restrict__ KT,
-                                                   int32_t *__restrict__ rowmode, int32_t *__restrict__ z_dev, int32_t *__restrict__ status) {
+__device__ __forceinline__ void fs_build_body(uint8_t *fb_lds, const FpParams<9> &P, const uint32_t *__restrict__ inv, int n, const FsIdx &ix, int d, int nc, int n_coef,
+                                              int flags, const FsConsts &cs, uint8_t *__restrict__ a8, uint32_t *__restrict__ crow, uint32_t *__restrict__ KT,
+                                              int32_t *__restrict__ rowmode, int32_t *__restrict__ z_dev, int32_t *__restrict__ status) {
     constexpr int NL = 9, NW = 8;
-    extern __shared__ __attribute__((aligned(16))) uint8_t fb_lds[];
     const int n_out = n_coef + nc, nkb = (d + 7) / 8, n_rt = (n_out + 15) / 16;
     i128 *ent = reinterpret_cast<i128 *>(fb_lds);                       // [n_out][d]
     i128 *Ac = ent + (size_t)n_out * d;                                 // [d + 1]
@@ -543,9 +542,8 @@ __global__ void __launch_bounds__(1024) k_fs_build(const FpParams<9> P, const ui
 // The rows of the compared senders before anybody knows who they will be: P[i][j] = prod_{q != j} (x_i - x_zq) for EVERY party i, its 16
 // digits per entry laid out as the 8 NKB sixteen-byte pieces a row occupies in the image, and its row constant -- a candidate store
 // indexed by party (k_mm8f gathers the rows it compares in its prologue: FsPick).  Depends on the first d arrivals alone.
-__global__ void __launch_bounds__(1024) k_fs_cand(const FpParams<9> P, int n, const uint16_t *__restrict__ xs, const FsIdx ix, int d, const FsConsts cs,
-                                                  uint8_t *__restrict__ cand, uint32_t *__restrict__ cand_crow, int32_t *__restrict__ status) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t fc_lds[];
+__device__ __forceinline__ void fs_cand_body(uint8_t *fc_lds, const FpParams<9> &P, int n, const uint16_t *__restrict__ xs, const FsIdx &ix, int d, const FsConsts &cs,
+                                             uint8_t *__restrict__ cand, uint32_t *__restrict__ cand_crow, int32_t *__restrict__ status) {
     i128 *ent = reinterpret_cast<i128 *>(fc_lds);                      // [n][d]
     const int tid = threadIdx.x, nkb = (d + 7) / 8;
     const size_t row_bytes = (size_t)nkb * 8 * 16;
@@ -575,6 +573,31 @@ __global__ void __launch_bounds__(1024) k_fs_cand(const FpParams<9> P, int n, co
         if (carry != (negv ? 1 : 0) && status) atomicOr(status, FS_OVERFLOW);
     }
     for (int i = tid; i < n; i += 1024) fs_row_constant(P, cs, ent + (size_t)i * d, d, cand_crow + (size_t)i * 16);
+}
+
+__global__ void __launch_bounds__(1024) k_fs_build(const FpParams<9> P, const uint32_t *__restrict__ inv, int n, const FsIdx ix, int d, int nc, int n_coef,
+                                                   int flags, const FsConsts cs, uint8_t *__restrict__ a8, uint32_t *__restrict__ crow, uint32_t *__restrict__ KT,
+                                                   int32_t *__restrict__ rowmode, int32_t *__restrict__ z_dev, int32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fs_b_lds[];
+    fs_build_body(fs_b_lds, P, inv, n, ix, d, nc, n_coef, flags, cs, a8, crow, KT, rowmode, z_dev, status);
+}
+
+__global__ void __launch_bounds__(1024) k_fs_cand(const FpParams<9> P, int n, const uint16_t *__restrict__ xs, const FsIdx ix, int d, const FsConsts cs,
+                                                  uint8_t *__restrict__ cand, uint32_t *__restrict__ cand_crow, int32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fs_c_lds[];
+    fs_cand_body(fs_c_lds, P, n, xs, ix, d, cs, cand, cand_crow, status);
+}
+
+// What a decoder enqueues when its (degree + 1)-th column lands, as ONE launch of two workgroups: block 0 builds everything that depends on the
+// arrivals alone (k_fs_build with FS_BUILD_Z), block 1 the candidate store (k_fs_cand) -- the two are independent, and as two launches
+// the second waited for the first (8 us + a dispatch gap on the path of the column that completes the quorum).
+__global__ void __launch_bounds__(1024) k_fs_build_z_cand(const FpParams<9> P, const uint32_t *__restrict__ inv, int n, const uint16_t *__restrict__ xs, const FsIdx ix, int d, int nc,
+                                                          int n_coef, const FsConsts cs, uint8_t *__restrict__ a8, uint32_t *__restrict__ crow, uint32_t *__restrict__ KT,
+                                                          int32_t *__restrict__ rowmode, int32_t *__restrict__ z_dev, uint8_t *__restrict__ cand, uint32_t *__restrict__ cand_crow,
+                                                          int32_t *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t fs_zc_lds[];
+    if (blockIdx.x == 0) fs_build_body(fs_zc_lds, P, inv, n, ix, d, nc, n_coef, FS_BUILD_Z, cs, a8, crow, KT, rowmode, z_dev, status);
+    else fs_cand_body(fs_zc_lds, P, n, xs, ix, d, cs, cand, cand_crow, status);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -655,7 +678,7 @@ int fs_build(hb_ctx *ctx, const PointTable *pt, const int32_t *z, const int32_t 
     return HB_OK;
 }
 
-int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout &L, uint8_t *base, int32_t *status_dev, hipStream_t s) {
+int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout &L, uint8_t *base, int32_t *status_dev, hipStream_t s, bool with_z) {
     if (!L.o_cand) return fail(ctx, HB_ERR_BAD_ARG, "fused decode: no candidate store in this layout");
     if (!pt->xs_dev) {
         HB_HIP(ctx, hipMalloc(&pt->xs_dev, (size_t)pt->n * 2));
@@ -664,12 +687,26 @@ int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout 
     }
     FsIdx ix;
     memset(&ix, 0, sizeof ix);
-    for (int i = 0; i < L.d; i++) { ix.z[i] = (uint16_t)z[i]; ix.xz[i] = pt->xs[z[i]]; }
+    uint64_t seen[2] = {0, 0};                  // (a candidate store exists for at most 128 parties)
+    for (int i = 0; i < L.d; i++) {
+        const int v = z[i];
+        if (v < 0 || v >= pt->n || (seen[v >> 6] >> (v & 63) & 1)) return fail(ctx, HB_ERR_BAD_ARG, "fused decode: arrival indices");
+        seen[v >> 6] |= 1ull << (v & 63);
+        ix.z[i] = (uint16_t)v; ix.xz[i] = pt->xs[v];
+    }
     const Mm8Shared *sh = nullptr;
     int rc = mm8_shared(ctx, &sh, s); if (rc) return rc;
     FsConsts cs;
     memcpy(cs.c80r, sh->c80r, sizeof cs.c80r);
     memcpy(cs.biasmod, sh->biasmod, sizeof cs.biasmod);
+    if (with_z) {
+        const size_t lds_b = ((size_t)L.n_out * L.d + L.d + 1) * 16 + ((size_t)L.d * 9 + (size_t)L.d * 4 * 9) * 4, lds_c = (size_t)pt->n * L.d * 16;
+        k_fs_build_z_cand<<<2, 1024, std::max(lds_b, lds_c), s>>>(ctx->pw, pt->inv, pt->n, pt->xs_dev, ix, L.d, L.nc, L.n_coef, cs, base + L.o_a8, (uint32_t *)(base + L.o_crow),
+                                                                  (uint32_t *)(base + L.o_kt), (int32_t *)(base + L.o_mode), (int32_t *)(base + L.o_z), base + L.o_cand,
+                                                                  (uint32_t *)(base + L.o_cand_crow), status_dev);
+        HB_LAUNCH_CHECK(ctx);
+        return HB_OK;
+    }
     k_fs_cand<<<1, 1024, (size_t)pt->n * L.d * 16, s>>>(ctx->pw, pt->n, pt->xs_dev, ix, L.d, cs, base + L.o_cand, (uint32_t *)(base + L.o_cand_crow), status_dev);
     HB_LAUNCH_CHECK(ctx);
     return HB_OK;

@@ -960,6 +960,16 @@ struct hb_quick_dec {
     std::vector<int32_t> z;
 };
 
+namespace hb {
+int quick_dec_supported(hb_quick_dec *qd, int d, int nc, int n_coef) { HB_API_GUARD((qd ? qd->ctx : nullptr));
+    if (!qd || d < 1 || d > qd->n || nc < 0 || n_coef < 1 || n_coef > d) return HB_ERR_BAD_ARG;
+    FsLayout L;
+    if (fs_layout(qd->ctx, qd->pt, d, nc, n_coef, &L) == HB_OK) return HB_OK;
+    QuickLayout Q;
+    return quick_layout(qd->ctx, qd->n, d, nc, n_coef, &Q);
+}
+}  // namespace hb
+
 extern "C" {
 
 int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec **out, void *stream) { HB_API_GUARD(ctx);
@@ -1026,8 +1036,8 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
         HB_HIP(ctx, hipMalloc(&qd->buf, L.need));
         qd->cap = L.need;
     }
-    rc = fs_build(ctx, qd->pt, z, nullptr, L, qd->buf, FS_BUILD_Z, qd->status, s); if (rc) return rc;
-    if (L.o_cand && nc > 0) { rc = fs_build_cand(ctx, qd->pt, z, L, qd->buf, qd->status, s); if (rc) return rc; }
+    if (L.o_cand && nc > 0) { rc = fs_build_cand(ctx, qd->pt, z, L, qd->buf, qd->status, s, true); if (rc) return rc; }      // one launch, two workgroups
+    else { rc = fs_build(ctx, qd->pt, z, nullptr, L, qd->buf, FS_BUILD_Z, qd->status, s); if (rc) return rc; }
     qd->L = L;
     qd->z.assign(z, z + d);
     qd->prepared = true;

@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from ._capi import HB_ERR_MISMATCH, HB_ERR_UNSUPPORTED, HB_OK, Context, np_ptr
+from ._capi import HB_DEC_DISAGREE, HB_DEC_DONE, HB_DEC_UNSUPPORTED, HB_ERR_MISMATCH, HB_ERR_UNSUPPORTED, HB_OK, Context, _marshal, np_ptr
 
 
 def wb_decode_batch(x, k, rows, modulus):
@@ -295,7 +295,9 @@ class _Probe:
         if not new and not decide:
             return
         if after_current:
-            self.side.wait_stream(self.ctx.torch.cuda.current_stream())      # the columns were copied in on the caller's stream
+            # the columns were written on the caller's stream -- copied in by add(idx, column), or received in place and reduced there
+            # (ctx.reduce_) before add(idx): the probe's stream always waits for it (one event)
+            self.side.wait_stream(self.ctx.torch.cuda.current_stream())
         ia = np.array(new if new else [0], dtype=np.int32)
         rc = self.ctx.lib.hb_probe_feed(self.h, np_ptr(ia), len(new), self.ctx.ptr(cols), c, poly, 1 if decide else 0, ctypes.byref(self._ok), np_ptr(self._mask),
                                         ctypes.c_void_p(self.side.cuda_stream))
@@ -330,43 +332,47 @@ class _Probe:
             pass
 
 
-class _QuickDec:
-    """hb_quick_dec_*: the optimistic step of one decoder in two halves (include/hbmpc_hip.h) -- what depends on the first degree+1
-    arrivals is enqueued when the last of them lands, the verdict comes back through pinned memory"""
+class _CDec:
+    """hb_dec_* (include/hbmpc_hip.h): the optimistic phase of one IncrementalDecoder round behind the C ABI -- arrivals are announced by
+    index, the object enqueues what depends on the first degree+1 of them, launches decode + validate behind the column that completes
+    the quorum and waits for the verdict.  Reusable: begin() starts the next round; pooled per (field, device, points, degree, t)."""
 
-    OVERFLOW = 0x40000000
-
-    def __init__(self, ctx, xh_all, n):
+    def __init__(self, ctx, xh_all, n, degree, max_errors):
         self.ctx = ctx
         self.h = ctypes.c_void_p()
-        rc = ctx.lib.hb_quick_dec_create(ctx.h, np_ptr(xh_all), n, ctypes.byref(self.h), ctx.stream())
+        rc = ctx.lib.hb_dec_create(ctx.h, np_ptr(xh_all), n, degree, max_errors, ctypes.byref(self.h), ctx.stream())
         if rc != HB_OK:
             self.h = None
             if rc == HB_ERR_UNSUPPORTED:
                 raise _Unsupported()
-            ctx.check(rc, "hb_quick_dec_create")
-        self._flag, self._first = ctypes.c_int32(0), ctypes.c_int32(0)
+            ctx.check(rc, "hb_dec_create")
+        self.addr = self.h.value
+        self._zbuf = np.empty(n, dtype=np.int32)
+        self._zptr = np_ptr(self._zbuf)
+        self._cnt = ctypes.c_int32(0)
+        self._state, self._first = ctypes.c_int32(0), ctypes.c_int32(0)
 
-    def arrivals(self, z, nc, n_coef):
-        za = np.array(z, dtype=np.int32)
-        rc = self.ctx.lib.hb_quick_dec_arrivals(self.h, np_ptr(za), len(z), nc, n_coef, self.ctx.stream())
+    def begin(self, cols, c, n_coef, out, excluded):
+        ex = np.array(sorted(excluded), dtype=np.int32) if excluded else None
+        rc = self.ctx.lib.hb_dec_begin(self.h, self.ctx.ptr(cols), c, n_coef, self.ctx.ptr(out), np_ptr(ex) if ex is not None else None,
+                                       len(excluded) if excluded else 0, self.ctx.stream())
         if rc == HB_ERR_UNSUPPORTED:
-            raise _Unsupported()
-        self.ctx.check(rc, "hb_quick_dec_arrivals")
+            return False
+        self.ctx.check(rc, "hb_dec_begin")
+        return True
 
-    def decide(self, zc, cols, c, out):
-        """-> (some compared column disagrees?, first disagreeing chunk)"""
-        zca = np.array(zc if zc else [0], dtype=np.int32)
-        rc = self.ctx.lib.hb_quick_dec_decide(self.h, np_ptr(zca), len(zc), self.ctx.ptr(cols), c, 0, c, self.ctx.ptr(out),
-                                              ctypes.byref(self._flag), ctypes.byref(self._first), self.ctx.stream())
-        self.ctx.check(rc, "hb_quick_dec_decide")
-        if self._flag.value & self.OVERFLOW:
-            raise RuntimeError("fused decode: a matrix entry left the range its host-side bound promised")
-        return bool(self._flag.value), self._first.value
+    def arrivals(self):
+        """the senders counted so far, in arrival order"""
+        self.ctx.check(self.ctx.lib.hb_dec_arrivals_list(self.h, self._zptr, len(self._zbuf), ctypes.byref(self._cnt)), "hb_dec_arrivals_list")
+        return self._zbuf[: self._cnt.value].tolist()
+
+    def first_bad(self):
+        self.ctx.check(self.ctx.lib.hb_dec_verdict(self.h, ctypes.byref(self._state), ctypes.byref(self._first)), "hb_dec_verdict")
+        return self._first.value
 
     def close(self):
         if self.h is not None:
-            self.ctx.lib.hb_quick_dec_destroy(self.h)
+            self.ctx.lib.hb_dec_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -386,7 +392,7 @@ class _ProbePool(threading.local):
 
     def __init__(self):
         self.idle = {}
-        self.quick = {}             # idle _QuickDec objects by (modulus, device, n, point policy); None = this point set does not qualify
+        self.quick = {}             # idle _CDec objects by (modulus, device, n, point policy, degree, t); "no" = this point set / context does not qualify
 
 
 _probe_pool = _ProbePool()
@@ -425,6 +431,36 @@ class DeviceIncrementalDecoder:
         probe moves on to that chunk.
     """
 
+    # state with an immutable initial value lives on the class until an instance changes it (a decoder is made per open and per round:
+    # its constructor is on the path of every open)
+    _ch = None                 # address of the hb_dec that runs this round's optimistic phase (None: the Python state machine below)
+    _cdec = None
+    _fetch1 = None
+    _z_epoch = 0               # bumps whenever senders LEAVE the arrival list (between bumps it only grows at the end)
+    _optimistic = True
+    _guess_decoded = None      # (C, d, limbs)
+    _guess_encoded = None      # (n, C, limbs)
+    _num_decoded = 0
+    _partial_buf = None        # (C, degree+1, limbs): allocated by the robust phase, which alone fills it piecewise
+    _result = None
+    _last_status = None
+    _probe_memo = None         # (polynomial index, arrival list, coefficient ints, error set) of the last successful probe
+    _status = None             # (2,) int32 on the device: disagreement flag, first disagreeing chunk
+    _probe_obj = None
+    _settled = None            # polynomial whose verdict is in (its errors expelled) but which is not accepted yet
+    _memo = None               # (polynomial, (arrivals seen, their epoch), candidates [coefficients, who disagrees, values at the n points]) waiting for support
+    _prefer_tail = False       # robust phase: interpolate from the newest arrivals (True) or the oldest
+    _stalled = None            # polynomial the last robust update could not decode (the probe is on it)
+    _probe_next = None         # (polynomial, arrival-list epoch, columns needed before the probe's verdict can matter)
+    _checked = None            # (arrival list, first chunk, coefficients, first disagreeing chunk) of a launch the robust phase may reuse
+    _scan = None               # robust phase: one launch's coefficients, ALL its disagreeing chunks and who disagrees on each (_Scan)
+    radius_verdicts = 0        # polynomials settled by the batched launch's own candidate (diagnostic)
+    probes = 0                 # single-codeword robust decodes so far (diagnostic)
+    probes_replayed = 0        # probes answered from the previous one (diagnostic)
+    launches = 0               # batched robust-decode launches so far (diagnostic)
+    plan_accepts = 0           # batches accepted by one interpolate-and-check launch (diagnostic)
+    quick_launches = 0         # plan-free interpolate-and-check launches (diagnostic)
+
     def __init__(self, modulus, n, t, degree=None, batch_size=1, use_omega_powers=False, confirmed_errors=None, device=None, robust="gao",
                  columns=None, want="all"):
         """columns: an (n, batch_size, limbs) party-major tensor the transport receives into (row j = what party j sent); a column that
@@ -432,9 +468,6 @@ class DeviceIncrementalDecoder:
         and add(j, column) copies.
         want: "all" -- get_results() yields every coefficient, (C, degree+1, limbs); "constant" -- only the constant terms are needed
         (what R1 forwards, batch_reconstruction.py:194): a decoder that finishes on its optimistic step then yields (C, 1, limbs)."""
-        from .field import GF
-        from .polynomial import EvalPoint
-
         if robust not in ("gao", "wb"):
             raise ValueError("robust must be 'gao' or 'wb'")
         self.ctx = ctx = Context.get(modulus, device)
@@ -447,6 +480,9 @@ class DeviceIncrementalDecoder:
         pk = (int(modulus), n, bool(use_omega_powers))
         pts = _points_cache.get(pk)
         if pts is None:
+            from .field import GF
+            from .polynomial import EvalPoint
+
             point = EvalPoint(GF(modulus), n, use_omega_powers=use_omega_powers)
             xs = [point(i).value for i in range(n)]
             pts = _points_cache[pk] = (xs, ctx.host_elems(xs))
@@ -472,36 +508,101 @@ class DeviceIncrementalDecoder:
                         _checked_columns.clear()
                     _checked_columns[id(columns)] = (weakref.ref(columns), (n, self.batch_size, self.L, ctx.device))
         self._confirmed_errors = set() if confirmed_errors is None else confirmed_errors
-        self._available_points = set()
-        self._z = []
-        self._fetch1 = None
-        self._z_epoch = 0               # bumps whenever senders LEAVE the arrival list (between bumps it only grows at the end)
-        self._optimistic = True
-        self._guess_decoded = None      # (C, d, limbs)
-        self._guess_encoded = None      # (n, C, limbs)
-        self._num_decoded = 0
-        self._partial_buf = None        # (C, degree+1, limbs): allocated by the robust phase, which alone fills it piecewise
-        self._result = None
-        self._last_status = None
-        self._probe_memo = None         # (polynomial index, arrival list, coefficient ints, error set) of the last successful probe
+        self._avl = set()               # senders counted (reference: _available_points); a property while the C decoder counts them
+        self._zl = []                   # ... in arrival order (reference: _z)
         self._fast = ctx.n_limbs == 4 and (self.degree + 1) >= 4 and not os.environ.get("HB_NO_QUICK")   # cleared at the first UNSUPPORTED
-        self._status = None             # (2,) int32 on the device: disagreement flag, first disagreeing chunk
-        self._probe_obj = None
-        self._qdec = None               # _QuickDec borrowed for the optimistic step (None: hb_quick_interp_check)
-        self._qdec_ready = False        # its first half has been enqueued for the current first degree+1 arrivals
-        self._settled = None            # polynomial whose verdict is in (its errors expelled) but which is not accepted yet
-        self._memo = None               # (polynomial, (arrivals seen, their epoch), candidates [coefficients, who disagrees, values at the n points]) waiting for support
-        self._prefer_tail = False       # robust phase: interpolate from the newest arrivals (True) or the oldest
-        self._stalled = None            # polynomial the last robust update could not decode (the probe is on it)
-        self._probe_next = None         # (polynomial, arrival-list epoch, columns needed before the probe's verdict can matter)
-        self._checked = None            # (arrival list, first chunk, coefficients, first disagreeing chunk) of a launch the robust phase may reuse
-        self._scan = None               # robust phase: one launch's coefficients, ALL its disagreeing chunks and who disagrees on each (_Scan)
-        self.radius_verdicts = 0        # polynomials settled by the batched launch's own candidate (diagnostic)
-        self.probes = 0                 # single-codeword robust decodes so far (diagnostic)
-        self.probes_replayed = 0        # probes answered from the previous one (diagnostic)
-        self.launches = 0               # batched robust-decode launches so far (diagnostic)
-        self.plan_accepts = 0           # batches accepted by one interpolate-and-check launch (diagnostic)
-        self.quick_launches = 0         # plan-free interpolate-and-check launches (diagnostic)
+        if self._fast:
+            self._c_begin()
+
+    # -- the optimistic phase behind the C ABI (hb_dec_*) ---------------------------------------------------------------------------
+    def _c_begin(self):
+        """hand this round's optimistic phase to a pooled hb_dec: add(idx) is then one C call per arrival (reference reed_solomon.py:367-403
+        up to the first verdict); any state change comes back through _c_event"""
+        key = (self.ctx.modulus, self.ctx.device, self.n, self.use_omega_powers, self.degree, self.max_errors)
+        idle = _probe_pool.quick.get(key)
+        if idle is None:
+            idle = _probe_pool.quick[key] = []
+        if idle == "no":
+            return
+        if idle:
+            cd = idle.pop()
+        else:
+            try:
+                cd = _CDec(self.ctx, self._xh_all, self.n, self.degree, self.max_errors)
+            except _Unsupported:
+                _probe_pool.quick[key] = "no"
+                return
+        n_coef = self.degree + 1 if self._want_all else 1
+        out = self.ctx.empty(self.batch_size * n_coef)
+        excluded = [i for i in self._confirmed_errors if 0 <= i < self.n]
+        if not cd.begin(self._cols, self.batch_size, n_coef, out, excluded):
+            idle.append(cd)                  # this shape (nothing to compare, too many coefficients, ...): the Python path; the object serves others
+            return
+        self._cdec, self._ch, self._cout, self._ckey = cd, cd.addr, out, key
+
+    def _leave_c(self):
+        """the C decoder's part is over: its arrival list becomes this object's, the hb_dec goes back to the pool"""
+        cd, self._cdec, self._ch = self._cdec, None, None
+        self._zl = cd.arrivals()
+        self._avl = set(self._zl)
+        idle = _probe_pool.quick.get(self._ckey)
+        if isinstance(idle, list) and len(idle) < 8:
+            idle.append(cd)
+        else:
+            cd.close()
+        return cd
+
+    @property
+    def _z(self):
+        return self._cdec.arrivals() if self._cdec is not None else self._zl
+
+    @_z.setter
+    def _z(self, value):
+        self._zl = value
+
+    @property
+    def _available_points(self):
+        return set(self._cdec.arrivals()) if self._cdec is not None else self._avl
+
+    @_available_points.setter
+    def _available_points(self, value):
+        self._avl = value
+
+    def _c_event(self, state, idx):
+        """hb_dec_arrived1 left HB_DEC_COLLECTING at the arrival of `idx` (or failed: state < 0)"""
+        if state < 0:
+            self.ctx.check(-state, "hb_dec_arrived1")
+        d = self.degree + 1
+        if state == HB_DEC_DONE:
+            self.quick_launches += 1
+            self._leave_c()
+            self._result = self._cout.view(self.batch_size, d if self._want_all else 1, self.L)
+            return
+        if state == HB_DEC_DISAGREE:
+            self.quick_launches += 1
+            first = self._cdec.first_bad()
+            self._leave_c()
+            self._optimistic = False
+            # (a set of confirmed errors shared with other decoders may have grown since this round began: those senders are dropped
+            # before the robust phase looks at the list, as the reference drops them at its next add)
+            late = [i for i in self._zl if i in self._confirmed_errors]
+            if late:
+                self._zl = [i for i in self._zl if i not in self._confirmed_errors]
+                self._avl = set(self._zl)
+                self._z_epoch += 1
+            elif self._want_all:
+                self._checked = (list(self._zl), 0, self._cout.view(self.batch_size, d, self.L), first)      # the robust phase starts from this very launch
+            if len(self._avl) >= self._min_points_required():
+                try:
+                    self._fast_robust_update()
+                except _Unsupported:
+                    self._fast = False
+                    self._robust_update()
+            return
+        if state == HB_DEC_UNSUPPORTED:
+            self._leave_c()
+            return self._after_arrival(idx)
+        raise RuntimeError(f"hb_dec_arrived1: unknown state {state}")
 
     @property
     def _partial(self):
@@ -520,7 +621,7 @@ class DeviceIncrementalDecoder:
     def accepts(self, idx):
         """would add(idx) count this sender's column?  (not once the decoder is done, nor a sender already counted or confirmed in error:
         reference reed_solomon.py:369-372) -- a transport that receives in place asks BEFORE it writes into slot(idx)"""
-        return self._result is None and idx not in self._available_points and idx not in self._confirmed_errors
+        return self._result is None and idx not in self._confirmed_errors and idx not in self._available_points
 
     # -- kernels ---------------------------------------------------------------------------------
     def _plan(self, z, zc):
@@ -675,25 +776,16 @@ class DeviceIncrementalDecoder:
     def __del__(self):
         try:
             self._return_probe()
-            self._return_qdec()
+            if self._cdec is not None:
+                self._leave_c()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 
     def _fast_optimistic(self):
-        """enough columns to finish: the guess from the first degree+1 arrivals against every later one.  True = done."""
+        """enough columns to finish: the guess from the first degree+1 arrivals against every later one.  True = done.  (Rounds the C
+        decoder does not take: hb_dec_begin answered HB_ERR_UNSUPPORTED.)"""
         d = self.degree + 1
-        if self._qdec is not None and self._qdec_ready:
-            n_coef = d if self._want_all else 1
-            out = self.ctx.empty(self.batch_size * n_coef)
-            disagree, first = self._qdec.decide(self._z[d:], self._cols, self.batch_size, out)
-            self.quick_launches += 1
-            self._qdec_ready = False
-            self._return_qdec()
-            dec, agree = out.view(self.batch_size, n_coef, self.L), not disagree
-            if not self._want_all and not agree:
-                dec = None                                  # one coefficient row is no use to the robust phase
-        else:
-            dec, agree, first = self._quick(self._z[:d], self._z[d:])
+        dec, agree, first = self._quick(self._z[:d], self._z[d:])
         if agree:
             self._result = dec
             return True
@@ -708,51 +800,9 @@ class DeviceIncrementalDecoder:
         if self.robust != "gao" or not self._fast or poly >= self.batch_size:
             return
         try:
-            self._borrow_probe().feed_ahead(self._z, self._cols, self.batch_size, poly, after_current=not self._in_place)
+            self._borrow_probe().feed_ahead(self._z, self._cols, self.batch_size, poly)
         except _Unsupported:
             pass
-
-    def _borrow_qdec(self):
-        """a _QuickDec for this decoder's point set from the thread's pool (None when the point set / context does not qualify)"""
-        key = (self.ctx.modulus, self.ctx.device, self.n, self.use_omega_powers)
-        idle = _probe_pool.quick.get(key)
-        if idle is None:
-            idle = _probe_pool.quick[key] = []
-        if idle == "no":
-            return None
-        if idle:
-            return idle.pop()
-        try:
-            return _QuickDec(self.ctx, self._xh_all, self.n)
-        except _Unsupported:
-            _probe_pool.quick[key] = "no"
-            return None
-
-    def _return_qdec(self):
-        qd, self._qdec = self._qdec, None
-        if qd is not None and qd.h is not None:
-            idle = _probe_pool.quick.get((self.ctx.modulus, self.ctx.device, self.n, self.use_omega_powers))
-            if isinstance(idle, list) and len(idle) < 8:
-                idle.append(qd)
-            else:
-                qd.close()
-
-    def _first_half(self):
-        """the first degree+1 arrivals are in (and more are needed to finish): enqueue what depends on them alone"""
-        need = self._min_points_required()
-        d = self.degree + 1
-        nc = need - d
-        if nc < 0 or self._qdec_ready:
-            return
-        if self._qdec is None:
-            self._qdec = self._borrow_qdec()
-        if self._qdec is None:
-            return
-        try:
-            self._qdec.arrivals(self._z[:d], nc, d if self._want_all else 1)
-            self._qdec_ready = True
-        except _Unsupported:
-            self._return_qdec()
 
     def _disagreeing(self, coeffs):
         """the arrived senders whose symbol of ONE polynomial differs from `coeffs` ((d, limbs)) evaluated at their point"""
@@ -905,7 +955,7 @@ class DeviceIncrementalDecoder:
                         return
                     pr = self._borrow_probe()
                     self.probes += 1
-                    errors = pr.decide(self._z, self._cols, self.batch_size, lo, after_current=not self._in_place)
+                    errors = pr.decide(self._z, self._cols, self.batch_size, lo)
                     if errors is None:
                         self._probe_next = (lo, self._z_epoch, self._min_points_required() + (len(self._z) - d) // 2 + 1)
                         return                               # (None, None): more columns needed
@@ -1106,10 +1156,14 @@ class DeviceIncrementalDecoder:
         if self._num_decoded == self.batch_size:
             self._result = self._partial
 
-    def add(self, idx, column=None):
+    def _add_slow(self, idx, column=None):
         """column: (C, limbs) limb tensor on the device, or a list of C ints; None: the column has been received into slot(idx)
-        (row idx of the `columns` buffer)."""
-        if self._result is not None or idx in self._available_points or idx in self._confirmed_errors:
+        (row idx of the `columns` buffer).  (`add` itself is the C binding below: an in-place arrival while the C decoder runs the
+        optimistic phase never gets here.)"""
+        if self._result is not None or idx in self._confirmed_errors:
+            return
+        cd = self._cdec
+        if idx in (self._available_points if cd is None else cd.arrivals()):
             return
         if column is not None:
             if not hasattr(column, "shape"):
@@ -1120,16 +1174,23 @@ class DeviceIncrementalDecoder:
                 raise ValueError("Incorrect length of data")
             column = self.ctx.elems(column, self.batch_size, what="column")
             self._cols[idx] = column
-        self._available_points.add(idx)
-        self._z.append(idx)
-        k = len(self._z)
+        if cd is not None:
+            st = self.ctx.lib.hb_dec_arrived1(cd.h, idx)
+            if st:
+                self._c_event(st, idx)
+            return
+        self._avl.add(idx)
+        self._zl.append(idx)
+        return self._after_arrival(idx)
+
+    def _after_arrival(self, idx):
+        """`idx` has just been appended to the arrival list (reference :374-403)"""
+        k = len(self._zl)
         if k <= self.degree:
             return
         if self._fast and self._optimistic:
-            # nothing is computed before enough columns are in to finish; the arrivals the guess is made from are known earlier
+            # nothing is computed before enough columns are in to finish (until then the reference's guess has been compared with nothing)
             if k < self.degree + 1 + self.max_errors - len(self._confirmed_errors):
-                if k == self.degree + 1:
-                    self._first_half()
                 return
         if self._fast:
             try:
@@ -1147,6 +1208,19 @@ class DeviceIncrementalDecoder:
             return
         if len(self._available_points) >= self._min_points_required():
             self._robust_update()
+
+    # add(idx, column=None) -- reference IncrementalDecoder.add (reed_solomon.py:367-403).  Bound in C (csrc/hb_pymarshal.c, dec_add): while
+    # self._ch names an hb_dec and the column was received in place, the call is hb_dec_arrived1(self._ch, idx) and nothing else; a state
+    # change is handed to _c_event, everything else to _add_slow.  Without the helper library the same dispatch in Python:
+    def _add_py(self, idx, column=None):
+        if column is None and self._ch is not None:
+            st = self.ctx.lib.hb_dec_arrived1(self._cdec.h, idx)
+            if st:
+                self._c_event(st, idx)
+            return
+        return self._add_slow(idx, column)
+
+    add = _marshal.as_method(_marshal.dec_add) if _marshal is not None and hasattr(_marshal, "dec_add") else _add_py
 
     def _fast_add(self):
         enough = len(self._available_points) >= self._min_points_required()

@@ -154,6 +154,40 @@ int hb_quick_dec_decide(hb_quick_dec *qd, const int32_t *zc, int nc, const uint6
                         uint64_t *coeffs_dev, int32_t *flag, int32_t *first, void *stream);
 void hb_quick_dec_destroy(hb_quick_dec *qd);
 
+/* ---- IncrementalDecoder's optimistic phase as an object (hb_dec.hip) ------------------------------------------------------------
+ * Replaces, for one round of one open, the state machine of IncrementalDecoder.add (reed_solomon.py:367-403) up to its first verdict:
+ * _validate / duplicate and confirmed-error filtering (:288-300, :369-372), the optimistic decode + re-encode from the first degree + 1
+ * arrivals (:305-313), the comparison of the later arrivals (:316-326) and the quorum test degree + 1 + max_errors - |confirmed|
+ * (:302-303, :328-330) -- as batch_reconstruct drives it, one add() per received message (batch_reconstruction.py:43-61).
+ * The host announces arrivals BY INDEX: party idx's column has landed in row idx of the party-major buffer cols_dev [n][C].  The
+ * object enqueues what depends on the first degree + 1 arrivals when the last of them is announced, launches decode + validate when
+ * the quorum is complete and waits for the verdict (pinned memory; the stream is not synchronised).  A decoder object is reusable:
+ * hb_dec_begin starts the next round (another buffer, another set of confirmed errors).
+ *   n_coef = degree + 1: all coefficients, chunk-major (C, degree + 1) to coeffs_dev;  n_coef = 1: the constant terms only, (C) elements
+ *   (what R1 forwards, batch_reconstruction.py:194).  excluded[0..n_excluded): senders confirmed in error before this round
+ *   (their arrivals are ignored; each lowers the quorum by one).
+ * hb_dec_create / hb_dec_begin return HB_ERR_UNSUPPORTED for contexts / point sets / shapes outside the plan-free kernels
+ * (hb_quick_dec_*'s conditions; also max_errors - n_excluded < 1: nothing to compare) -- callers keep their own path for those. */
+#define HB_DEC_COLLECTING 0   /* more columns needed */
+#define HB_DEC_DONE 1         /* every compared column agreed: the results are in coeffs_dev */
+#define HB_DEC_DISAGREE 2     /* a compared column differs from the guess (reed_solomon.py:321-326): the robust phase takes over from
+                                 hb_dec_arrivals_list; with n_coef = degree + 1 the refuted guess is in coeffs_dev and hb_dec_verdict
+                                 gives the first disagreeing chunk */
+#define HB_DEC_UNSUPPORTED 3  /* found at the (degree + 1)-th arrival: decode the arrival list another way */
+typedef struct hb_dec hb_dec;
+int hb_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, int degree, int max_errors, hb_dec **out, void *stream);
+int hb_dec_begin(hb_dec *dec, const uint64_t *cols_dev, int64_t C, int n_coef, uint64_t *coeffs_dev, const int32_t *excluded, int n_excluded,
+                 void *stream);
+/* one arrival: returns the state (HB_DEC_*) after it, or -(hb_status) on an error.  A sender already counted or excluded is ignored;
+ * so is every arrival once the state has left HB_DEC_COLLECTING.  The call that completes the quorum returns when the verdict is in. */
+int hb_dec_arrived1(hb_dec *dec, int32_t idx);
+/* a burst of arrivals in order; stops at the first one that changes the state (*consumed = how many were taken) */
+int hb_dec_arrived(hb_dec *dec, const int32_t *idx, int count, int32_t *consumed, int32_t *state);
+int hb_dec_verdict(const hb_dec *dec, int32_t *state, int32_t *first_bad);
+/* the senders counted so far, in arrival order (reed_solomon.py's _z): *count of them, the first min(cap, *count) copied */
+int hb_dec_arrivals_list(const hb_dec *dec, int32_t *out, int cap, int32_t *count);
+void hb_dec_destroy(hb_dec *dec);
+
 /* The symbols of polynomial `chunk` in the columns of parties idx[0..count) (each in [0, n), count <= 64) of the party-major buffer cols_dev [n][C], to
  * out_host[count][limbs]: what IncrementalDecoder compares a new sender's share with (reed_solomon.py:318-321, data[i] against the guess) when
  * the guess is a candidate for ONE polynomial (device.py _candidate_cap).  One launch that writes pinned memory the call polls: the answer
