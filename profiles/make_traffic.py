@@ -10,7 +10,9 @@ import sys
 def main(path, workload, source):
     lines = open(path).read().splitlines()
     hdr = lines[0].split()
-    cols = hdr[3:-2]                       # counters between 'launches' and 'HBM bytes/launch'
+    has_lds = hdr[2] == "lds"              # summaries since round 5 carry the dispatch's dynamic LDS size after the grid
+    skip = 3 if has_lds else 2
+    cols = hdr[skip + 1:-2]                # counters between 'launches' and 'HBM bytes/launch'
     def parse(prefixes):
         rows = []
         for ln in lines[1:]:
@@ -18,8 +20,9 @@ def main(path, workload, source):
                 continue
             name = ln[:44].strip()
             f = ln[44:].split()
-            vals = dict(zip(cols, map(float, f[2:2 + len(cols)])))
-            vals["hbm_mb"] = float(f[2 + len(cols)]) if len(f) > 2 + len(cols) else None
+            vals = dict(zip(cols, map(float, f[skip:skip + len(cols)])))
+            vals["hbm_mb"] = float(f[skip + len(cols)]) if len(f) > skip + len(cols) else None
+            vals["launches"] = int(f[skip - 1])
             rows.append((name, vals))
         return rows
 
@@ -50,6 +53,11 @@ def main(path, workload, source):
     if not rows:
         raise SystemExit("no k_mm8f / k_mm8w<true,...> row in " + path)
     name, v = max(rows, key=lambda r: r[1].get("WRITE_SIZE", 0.0))
+    # the R2 launch writes the d coefficient rows of every chunk, 32 C d bytes: a row that is a MIX of launches (R1's write one row) shows here
+    expect_kb = {"cfg3": 32 * 47663 * 22, "cfg3-omega": 32 * 47663 * 22, "cfg5-shard": 32 * 6097 * 86}.get(workload)
+    if expect_kb is not None:
+        expect_kb /= 1024.0
+        assert abs(v["WRITE_SIZE"] - expect_kb) <= 0.05 * expect_kb, f"the chosen row writes {v['WRITE_SIZE']:.0f} KB a launch, the R2 launch of {workload} {expect_kb:.0f} KB: not the R2 launch alone"
     simds, ses = 1024, 32                  # SQ_BUSY_CYCLES sums 32 shader-engine instances, instruction counters all 1024 SIMDs
     cycles = v["SQ_BUSY_CYCLES"] / ses
     out = {
@@ -57,6 +65,7 @@ def main(path, workload, source):
         "kernel": (f"{name} (R2: decode + validate as [N ; P] (y ./ den) on the small-entry kernel, the division by den_j inside the kernel)" if small else
                    f"{name} (R2: fused decode + validate; the sums of a pass are reduced, stored and compared inside the next pass)"),
         "hbm_bytes_per_launch": v["hbm_mb"] * 1e6 if v["hbm_mb"] is not None else None,
+        "launches_averaged": v.get("launches"),
         "valu_wave_instr_per_launch": int(v["SQ_INSTS_VALU"]),
         "mfma_per_launch": int(v["SQ_VALU_MFMA_BUSY_CYCLES"] / 16),
         "valu_busy_frac": round(4 * v["SQ_INSTS_VALU"] / simds / cycles, 4),

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """Per-kernel averages of rocprofv3 --pmc passes (csv output).  Usage:
     python profiles/summarize_pmc.py gpurun_out/pmc_fetch gpurun_out/pmc_write gpurun_out/pmc_sq
-Kernels are keyed by short name + grid, and launches of one kernel whose written bytes / instruction counts differ (two
-significant digits) are separate rows (the fused R1 / R2 decodes of an open, the input generator): launch i of one pass is
-matched with launch i of the others.  Every counter found in the given directories is averaged over the launches of a row.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB units; gfx950 FETCH_SIZE
+Kernels are keyed by short name + grid + dynamic LDS size (what every pass records for a dispatch whatever its counters: the R1 and
+R2 launches of the fused decode, k_mm8f, share name and grid and differ in their LDS image -- round 4's summary averaged the two
+when the passes' launch counts differed), and launches of one kernel whose written bytes / instruction counts differ (two
+significant digits) are separate rows where the passes have the same number of launches (launch i of one pass is then
+matched with launch i of the others).  Every counter found in the given directories is averaged over the launches of a row.  HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (KiB units; gfx950 FETCH_SIZE
 reports half of a wide coalesced read: MI355X_MICROARCH.md, HBM section)."""
 import csv
 import glob
@@ -39,7 +41,7 @@ def main(dirs):
             for row in csv.DictReader(open(path)):
                 disp = int(row["Dispatch_Id"])
                 per_dispatch[disp][row["Counter_Name"]] += float(row["Counter_Value"])
-                meta[disp] = (short(row["Kernel_Name"]), int(row["Grid_Size"]))
+                meta[disp] = (short(row["Kernel_Name"]), int(row["Grid_Size"]), int(float(row.get("LDS_Block_Size") or 0)))
             by_kernel = defaultdict(list)
             for disp in sorted(per_dispatch):
                 by_kernel[meta[disp]].append(dict(per_dispatch[disp]))
@@ -65,12 +67,12 @@ def main(dirs):
                         acc[k + ((),)][c].append(v)
     keep = [k for k in acc if any(s in k[0] for s in ("k_mm8", "k_prescale", "k_matvec3", "k_decode_check", "k_ntt", "k_gao", "k_wb", "k_matvec2"))]
     ctrs = sorted({c for k in keep for c in acc[k]})
-    print(f"{'kernel':<44} {'grid':>9} {'launches':>8} " + " ".join(f"{c:>24}" for c in ctrs) + f" {'HBM bytes/launch':>18}")
-    for k in sorted(keep, key=lambda k: (k[0], k[1], -sum(acc[k].get("WRITE_SIZE", [0])) / max(1, len(acc[k].get("WRITE_SIZE", [0]))))):
+    print(f"{'kernel':<44} {'grid':>9} {'lds':>7} {'launches':>8} " + " ".join(f"{c:>24}" for c in ctrs) + f" {'HBM bytes/launch':>18}")
+    for k in sorted(keep, key=lambda k: (k[0], k[1], k[2], -sum(acc[k].get("WRITE_SIZE", [0])) / max(1, len(acc[k].get("WRITE_SIZE", [0]))))):
         vals = {c: sum(v) / len(v) for c, v in acc[k].items()}
         n = max(len(v) for v in acc[k].values())
         hbm = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals else None
-        print(f"{k[0]:<44} {k[1]:>9} {n:>8} " + " ".join(f"{vals.get(c, float('nan')):>24.1f}" for c in ctrs)
+        print(f"{k[0]:<44} {k[1]:>9} {k[2]:>7} {n:>8} " + " ".join(f"{vals.get(c, float('nan')):>24.1f}" for c in ctrs)
               + (f" {hbm / 1e6:>15.2f} MB" if hbm else ""))
 
 
