@@ -40,6 +40,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 BLS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+PROGRESS = None          # Progress of this rank (multi-rank runs note their phases: a timeout names the straggler)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
 
 WORKLOADS = {
@@ -53,7 +54,11 @@ WORKLOADS = {
     "tiny": (4, 1, 256, False),
     "cfg4": (100, 33, 1 << 18, False),       # BASELINE config 4: robust decode (Welch-Berlekamp / Gao) with t injected errors; B = codewords
     "cfg4-mini": (100, 33, 1 << 12, False),  # the same at test size
+    "cfg3-p64": (64, 21, 1 << 20, False),    # config 3's open over the 64-BIT prime of the north star (2^64 - 59): 8-byte elements, the 1-limb kernels
+    "cfg3-p64-mini": (64, 21, 1 << 14, False),
 }
+P64 = (1 << 64) - 59
+NARROW = {"cfg3-p64", "cfg3-p64-mini"}
 ROBUST = {"cfg4", "cfg4-mini"}
 SHARDED = {"cfg5", "cfg5-mini"}                           # total work fixed: the batch is split with sharding.shard_bounds, the opened shares are all-gathered
 
@@ -467,6 +472,61 @@ def self_launch(args_list, nproc):
     return subprocess.call(cmd, env=env, cwd=os.getcwd())
 
 
+class Progress:
+    """Which rank is where: every rank notes its phase in a small file (one per rank, keyed by the rendezvous port), and a watchdog thread ends the
+    run after --timeout-s seconds with a line that NAMES the rank that fell behind -- a wedged collective on an 8-GPU node then costs the limit, not
+    the node, and says who never arrived."""
+
+    def __init__(self, rank, world, limit_s):
+        import tempfile
+        import threading
+
+        self.rank, self.world, self.t0 = rank, world, time.time()
+        self.dir = os.path.join(tempfile.gettempdir(), f"hb_bench_{os.environ.get('MASTER_PORT', 'single')}")
+        os.makedirs(self.dir, exist_ok=True)
+        self.path = os.path.join(self.dir, f"rank{rank}.txt")
+        self.done = False
+        self.note("start")
+        if limit_s and limit_s > 0 and world > 1:
+            th = threading.Thread(target=self._watch, args=(float(limit_s),), daemon=True)
+            th.start()
+
+    def note(self, phase):
+        try:
+            with open(self.path, "w") as f:
+                f.write(f"{time.time():.3f} {phase}\n")
+        except OSError:
+            pass
+
+    def report(self):
+        rows = []
+        for r in range(self.world):
+            try:
+                ts, phase = open(os.path.join(self.dir, f"rank{r}.txt")).read().strip().split(" ", 1)
+                rows.append((r, float(ts), phase))
+            except (OSError, ValueError):
+                rows.append((r, 0.0, "never started"))
+        return rows
+
+    def _watch(self, limit_s):
+        while not self.done and time.time() - self.t0 < limit_s:
+            time.sleep(0.5)
+        if self.done:
+            return
+        rows = self.report()
+        now = time.time()
+        behind = min(rows, key=lambda r_: r_[1])
+        print(f"bench.py: rank {self.rank}: no result after {limit_s:.0f} s; straggler = rank {behind[0]} (last phase '{behind[2]}', "
+              f"{now - behind[1]:.0f} s ago); all ranks: " + "; ".join(f"rank {r}: '{ph}' {now - ts:.0f} s ago" for r, ts, ph in rows), file=sys.stderr, flush=True)
+        import faulthandler
+        faulthandler.dump_traceback(file=sys.stderr)
+        os._exit(3)
+
+    def finish(self):
+        self.done = True
+        self.note("done")
+
+
 def dist_info(torch, dist, backend, args, world):
     """what the process group actually is, for the JSON line: the judge reads here that RCCL saw N ranks"""
     info = {"backend": backend if dist is not None else None,
@@ -505,17 +565,20 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
     full = ctx.empty(B)
 
     def gather(local, out):
-        if world == 1:
-            return local
+        if dist is None:
+            return local                            # plain `python bench.py`: no process group
         if backend == "gloo":                       # HB_BENCH_SHARE_GPU test hook: stage through the host
-            return so.gather(local.cpu(), out=None).to(local.device)
-        return so.gather(local, out=out)
+            return so.gather(local.cpu(), out=None, through_collective=True).to(local.device)
+        # under a launcher even ONE rank goes through RCCL (all_gather_into_tensor / batch_isend_irecv with no peers): the N = 1 point of a scaling
+        # run makes the same calls as N = 8
+        return so.gather(local, out=out, through_collective=True)
 
     # ---- which gather: probe the candidates once, outside the timed region, and agree on one across the ranks --------------
     # `direct` (batch_isend_irecv, uneven slices) is the faster shape on the xGMI mesh on paper; if it raises, returns wrong
     # data, or is slower than RCCL's all_gather on this node, the run falls back to `collective` and says why.
     gather_report = {"requested": args.gather, "used": args.gather if args.gather != "auto" else "direct", "probe_ms": {}, "fallback_reason": None}
-    if world > 1:
+    if dist is not None:
+        PROGRESS.note("gather probe")
         flag_dev = "cuda" if backend == "nccl" else "cpu"
         so.gather_mode = "collective"
         want_all = gather(secrets, ctx.empty(B)).clone()          # all_gather_into_tensor: the reference result of the probe
@@ -587,10 +650,12 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
         dist.broadcast(flag, src=0)
         return bool(flag.item())
 
+    PROGRESS.note("prewarm")
     pre_steps, pre_ms = prewarm(step, torch.cuda.synchronize, args.prewarm, agree if (dist is not None and world > 1) else None)
     for _ in range(args.warmup):
         step()
     assert so.ok(), "validation mismatch during warmup"
+    PROGRESS.note("timed steps")
 
     def barrier():
         if dist is not None:
@@ -608,8 +673,14 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
                           sum(a.elapsed_time(b) for a, b in zip(evs[0], evs[2])) / args.steps,
                           sum(a.elapsed_time(b) for a, b in zip(evs[2], evs[3])) / args.steps,
                           sum(a.elapsed_time(b) for a, b in zip(evs[0], evs[1])) / args.steps], dtype=torch.float64)
+    per_rank = [[float(v) for v in times]]
     if dist is not None:
-        tt = times.to("cuda" if backend == "nccl" else "cpu")
+        PROGRESS.note("reducing the times")
+        mine = times.to("cuda" if backend == "nccl" else "cpu")
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [[float(v) for v in e.cpu()] for e in every]
+        tt = mine.clone()
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         times = tt.cpu()
     dt, compute_ms, gather_ms, enc_ms = (float(v) for v in times)
@@ -618,7 +689,8 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
     assert torch.equal(result, secrets), "this rank's reconstructed slice differs from its secrets"
     assert torch.equal(r2_msg, r2_cols[:c_loc]), "R2 message != what party 0 would broadcast"
     all_secrets = gather(secrets, ctx.empty(B))
-    assert torch.equal(got if world > 1 else result, all_secrets if world > 1 else secrets), "gathered result differs from the gathered secrets"
+    assert torch.equal(got, all_secrets), "gathered result differs from the gathered secrets"
+    PROGRESS.finish()
 
     if rank == 0:
         C = (B + d - 1) // d
@@ -639,7 +711,9 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
                                + ("one isend/irecv pair per peer, all posted at once" if gather_used == "direct" else "all_gather_into_tensor") + ")",
                 "arrival_order": "seeded random permutation of the parties (first t+1 decode, next t validate), the same on every rank",
             },
-            "distributed": dict(dist_info(torch, dist, backend, args, world), gather_mode=gather_used, gather=gather_report),
+            "distributed": dict(dist_info(torch, dist, backend, args, world), gather_mode=gather_used, gather=gather_report,
+                                per_rank=[{"rank": r, "wall_ms_per_step": v[0] * 1e3 / args.steps, "compute_ms_per_step": v[1], "gather_ms_per_step": v[2]}
+                                          for r, v in enumerate(per_rank)]),
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic_from_profiles(args.workload),
@@ -666,6 +740,167 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main_p64(args, torch, dist, backend, rank, local_rank, world, n, t, B):
+    """Config 3's per-party open over the 64-bit prime p = 2^64 - 59 (north star: "the 64/256-bit prime"): the 1-limb instantiation of every
+    kernel (3 digits of 29 bits, 8-byte elements, integer VALU -- the matrix-core kernels are built for 256-bit elements).  Same call
+    sequence and checks as the headline: R1 encode, R1 decode + validate, R2 decode + validate through an open plan, results bit-exact
+    against the secrets; here the path moves 8 C (3 n + 7 d) = 132 MB per 2^20 shares and should sit much closer to the HBM roofline."""
+    from honeybadgermpc_amd._capi import Context, HbView, np_ptr
+    from honeybadgermpc_amd.device import BatchOpen
+
+    d = t + 1
+    C = (B + d - 1) // d
+    ctx = Context.get(P64, local_rank, 1)
+    lib = ctx.lib
+    x = list(range(1, n + 1))
+    xh = ctx.host_elems(x)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(6400 + rank)
+
+    def rnd(count):
+        v = torch.randint(-(1 << 63), (1 << 63) - 1, (count, 1), dtype=torch.int64, device="cuda", generator=gen)
+        return ctx.reduce_(v)
+
+    # make_inputs_light's construction at one limb: S_c = the chunk of the secrets, G_c(0) = S_c(x_0)
+    secrets, shares0 = rnd(B), rnd(B)
+    pad = C * d - B
+    sec_pad = secrets if not pad else torch.cat([secrets, torch.zeros((pad, 1), dtype=torch.int64, device="cuda")])
+    V = ctypes.c_void_p()
+    ctx.check(lib.hb_vand_matrix_create(ctx.h, np_ptr(xh), n, d, ctypes.byref(V), ctx.stream()), "V")
+    r2_cols = ctx.empty(n * C)
+    ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(sec_pad), HbView(d, 1), None, ctx.ptr(r2_cols), HbView(1, C), C, ctx.stream()), "r2cols")
+    g = rnd(d * C)
+    g[:C] = r2_cols[:C]
+    r1_cols = ctx.empty(n * C)
+    ctx.check(lib.hb_matvec(ctx.h, V, ctx.ptr(g), HbView(1, C), None, ctx.ptr(r1_cols), HbView(1, C), C, ctx.stream()), "r1cols")
+    torch.cuda.synchronize()
+    lib.hb_matrix_destroy(V)
+    order = np.random.Generator(np.random.PCG64(2024 + rank)).permutation(n).tolist()
+    z, zc = order[:d], order[d : d + t]
+    op = BatchOpen(P64, n, t, z=z, zc=zc, max_shares=B, device=local_rank)
+    r1_out, r2_msg, result = ctx.empty(n * C), ctx.empty(C), ctx.empty(B)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] for _ in range(4)]
+
+    def step(i=None):
+        if i is not None:
+            evs[0][i].record()
+        op.r1_encode(shares0, out=r1_out)
+        if i is not None:
+            evs[1][i].record()
+        op.r1_decode(r1_cols, B, out=r2_msg)
+        if i is not None:
+            evs[2][i].record()
+        op.r2_decode(r2_cols, B, out=result)
+        if i is not None:
+            evs[3][i].record()
+
+    pre_steps, pre_ms = prewarm(step, torch.cuda.synchronize, args.prewarm)
+    for _ in range(args.warmup):
+        step()
+    assert op.ok(), "validation mismatch during warmup"
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    ok = op.ok()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert ok and torch.equal(result, secrets) and torch.equal(r2_msg, r2_cols[:C]), "the 64-bit open differs from the secrets"
+    seg_ms = [sum(a.elapsed_time(b) for a, b in zip(evs[k], evs[k + 1])) / args.steps for k in range(3)]
+    seg_bytes = [8 * C * (d + n), 8 * C * (3 * d + n), 8 * C * (3 * d + n)]      # SURVEY 8d at 8-byte elements: encode 8 C (d + n); decode 8 C 2d + validating re-encode 8 C (d + n)
+    names = ["R1 encode (n x d Vandermonde mat-vec)", "R1 decode + validating re-encode + compare", "R2 decode + validating re-encode + compare"]
+    dom = max(range(3), key=lambda k: seg_ms[k])
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    alg_open = 8 * C * (3 * n + 7 * d)
+    achieved = seg_bytes[dom] / (seg_ms[dom] * 1e-3) / 1e9
+    line = {
+        "metric": f"shares reconstructed/sec (batch open, n={n} t={t}, 64-bit prime)", "value": world * B * args.steps / dt, "unit": "shares/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u64 (integer mod p < 2^64, 3 x 29-bit digits in u32, 64-bit accumulators)", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: batch_reconstruct per-party open, n={n}, t={t}, B={B} shares per GPU, points=i+1, p=2^64-59 (8-byte elements, 1-limb context)",
+                   "n": n, "t": t, "shares_per_gpu": B, "chunks": C, "parallelism": f"chunk-sharded x{world}, no data-path collective"},
+        "distributed": dist_info(torch, dist, backend, args, world),
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(args.workload),
+                     "kernel": f"the slowest of the open's three segments: {names[dom]} (integer-VALU family at one limb: k_matvec3 / k_decode_check / k_matvec2, hb_fast.hip, hb_core.hip)",
+                     "algorithmic_bytes_per_launch": seg_bytes[dom], "avg_launch_ms": seg_ms[dom],
+                     "launch_note": "HIP events on the plan's stream around each of the three calls of a step; a segment may be more than one kernel (pre-scale + mat-vec): "
+                                    "the kernel-by-kernel split is in profiles/",
+                     "segments": [{"what": names[k], "ms": seg_ms[k], "algorithmic_bytes": seg_bytes[k], "GBps": seg_bytes[k] / (seg_ms[k] * 1e-3) / 1e9} for k in range(3)]},
+        "detail": {"prewarm_steps": pre_steps, "prewarm_ms": pre_ms, "algorithmic_bytes_per_open": alg_open,
+                   "open_algorithmic_GBps_reference_formula": alg_open / (dt / args.steps) / 1e9,
+                   "mulmods_per_open": C * (3 * n * d + 2 * d * d), "mulmod_per_s": world * C * (3 * n * d + 2 * d * d) * args.steps / dt,
+                   "bit_exact_vs_secrets": True},
+    }
+    if args.cpu_sample > 0 and world == 1:
+        try:
+            line["cpu_baseline"] = cpu_baseline_p64(n, t, min(args.cpu_sample, B), z, zc)
+            line["detail"]["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        except Exception as e:  # noqa: BLE001 - the baseline is a reported extra, never the measurement
+            line["cpu_baseline"] = {"value": None, "unit": "shares/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_p64(n, t, sample_b, z, zc, seed=9):
+    """the same open over p = 2^64 - 59 on the host cores: oracle.batch_open_u64 (orc_batch_open_u64, oracle/hbmpc_oracle.c: the reference's call sequence
+    restated for a word-size modulus with 128-bit products -- what NTL's ZZ_p costs at one limb is not available here either), timed as a whole at
+    several thread counts, fastest = `value`"""
+    import psutil
+
+    import oracle
+
+    d = t + 1
+    phys = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    x = list(range(1, n + 1))
+    rng = np.random.Generator(np.random.PCG64(seed))
+    c = (sample_b + d - 1) // d
+    secrets = rng.integers(0, P64, size=sample_b, dtype=np.uint64)
+    shares = rng.integers(0, P64, size=sample_b, dtype=np.uint64)
+    sec_pad = np.concatenate([secrets, np.zeros(c * d - sample_b, dtype=np.uint64)])
+    # consistent columns: the oracle's own 256-bit evaluate on the padded secrets (set-up, untimed)
+    enc = oracle.lib()
+    xl = oracle._limbs(x, P64)
+    pad4 = np.zeros((c * d, 4), dtype=np.uint64)
+    pad4[:, 0] = sec_pad
+    r2 = np.zeros((c * n, 4), dtype=np.uint64)
+    enc.orc_vandermonde_batch_evaluate(oracle._ptr(oracle._p(P64)), oracle._ptr(xl), n, oracle._ptr(pad4), ctypes.c_long(c), d, oracle._ptr(r2))
+    cols = np.ascontiguousarray(r2[:, 0].reshape(c, n).T).reshape(n * c)
+    table, bufs = {}, None
+    th = phys
+    while th >= 1:
+        oracle.SetNumThreads(th)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc, a1, a2, res = oracle.batch_open_u64(P64, n, d, x, shares, cols, cols, z, zc, out=bufs)
+            el = time.perf_counter() - t0
+            bufs = (a1, a2, res)
+            best = el if best is None else min(best, el)
+            assert rc == 0, f"cpu baseline open failed rc={rc}"
+        assert np.array_equal(res, secrets), "cpu baseline result mismatch"
+        table[th] = sample_b / best
+        th //= 2
+    cores = max(table, key=lambda k: table[k])
+    return {"value": table[cores], "unit": "shares/s", "cores": int(cores), "kind": "port",
+            "sample": f"one fault-free per-party open of {sample_b} shares (n={n}, t={t}, p=2^64-59) by oracle/hbmpc_oracle.c orc_batch_open_u64 (plain C, 128-bit products, OpenMP), "
+                      f"timed as a whole at {sorted(table, reverse=True)} threads, fastest = {cores}; NTL is not installed on this host",
+            "open_shares_per_s_by_threads": {str(k): table[k] for k in sorted(table)}, "host": host_cpu_facts()}
 
 
 def cpu_baseline_robust(n, t, sample_cw, wb_python_cw, seed=11):
@@ -881,6 +1116,8 @@ def main():
     ap.add_argument("--no-two-streams-extra", dest="two_streams_extra", action="store_false",
                     help="skip the secondary (untimed for `value`) two-opens-in-flight measurement")
     ap.add_argument("--no-matrix-cores", action="store_true", help="time the integer-VALU kernels instead of the int8 matrix-core path")
+    ap.add_argument("--timeout-s", type=float, default=900.0,
+                    help="multi-rank runs: seconds after which every rank's watchdog ends the run and names the rank that fell behind (0 = none)")
     ap.add_argument("--gather", default="auto", choices=["auto", "direct", "collective"],
                     help="sharded workloads (cfg5): how the opened slices are all-gathered (per-peer sends on the xGMI mesh / RCCL all_gather); "
                          "auto = probe both outside the timed region and use the faster usable one; direct falls back to collective if it fails")
@@ -952,10 +1189,14 @@ def main():
 
     n, t, B, use_omega = WORKLOADS[args.workload]
     d = t + 1
+    global PROGRESS
+    PROGRESS = Progress(rank, world, args.timeout_s)
     if args.workload in SHARDED:
         return main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, use_omega)
     if args.workload in ROBUST:
         return main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, B)
+    if args.workload in NARROW:
+        return main_p64(args, torch, dist, backend, rank, local_rank, world, n, t, B)
     C = (B + d - 1) // d
     ctx = Context.get(BLS, local_rank)
     shares0, r1_cols, r2_cols, secrets, x = make_inputs(torch, ctx, n, t, B, use_omega, seed=1000 + rank)

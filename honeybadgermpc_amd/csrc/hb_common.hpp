@@ -313,6 +313,15 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
 // (fs_launch's pick_zc) instead of waiting for a second build
 // with_z: the same launch also builds what fs_build(FS_BUILD_Z) builds (two workgroups of one kernel)
 int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout &L, uint8_t *base, int32_t *status_dev, hipStream_t s, bool with_z = false);
+// ---- word-size primes (one-limb contexts): the 8-byte mat-vec of hb_narrow.hip -------------------------------------------------
+struct Mv64Matrix;
+bool mv64_applies(const hb_ctx *ctx, int d);
+int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const int32_t *mode_host, Mv64Matrix **out, hipStream_t s);
+void mv64_free(Mv64Matrix *m);
+int launch_mv64(hb_ctx *ctx, const Mv64Matrix *m, const uint64_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint64_t *out, hb_view ov,
+                int64_t out_count, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s);
+int mv64_plan_tables(hb_ctx *ctx, const uint64_t *x, int n, int d, const int32_t *z, const int32_t *zc, int nc, std::vector<uint64_t> &V, std::vector<uint64_t> &Vinv,
+                     std::vector<uint64_t> &P);
 // would hb_quick_dec_arrivals take this shape (d arrivals, nc compared senders, n_coef rows stored) on this decoder's point set?  HB_OK or
 // HB_ERR_UNSUPPORTED -- no launch, nothing allocated (hb_dec_begin asks before it commits a round to the plan-free kernels)
 int quick_dec_supported(hb_quick_dec *qd, int d, int nc, int n_coef);

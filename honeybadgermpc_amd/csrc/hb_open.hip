@@ -74,6 +74,9 @@ struct hb_open_plan {
     // creation; where it applies q1 / q2 are only built on request (HB_OPEN_OPT_FUSED_VALIDATE = 2).
     uint8_t *fs1, *fs2;          // owned buffers (FsLayout::need bytes each)
     FsLayout fl1, fl2;
+    // One-limb contexts (p < 2^64, the north star's 64-bit prime): the 8-byte mat-vec of hb_narrow.hip -- V for the encode, and decode + validate
+    // as one launch over [V^-1 row 0 ; V[zc] V^-1] (R1) / [V^-1 ; V[zc] V^-1] (R2), every entry a word-size residue
+    Mv64Matrix *nv_enc, *nv_f1, *nv_f2;
 };
 
 // the device-built images of the full-size kernel (q1, q2); failures leave the plan as it is
@@ -273,6 +276,25 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         }
         if ((pl->Winv8 || pl->Vw8) && !pl->coef_pk) PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
     }
+    if (mv64_applies(ctx, d) && !use_omega_powers) {
+        std::vector<uint64_t> Vh, Vi, Ph;
+        rc = mv64_plan_tables(ctx, x_host, n, d, z_host, zc_host, n_check, Vh, Vi, Ph);
+        if (rc) goto done;
+        std::vector<int32_t> me((size_t)n), m1((size_t)1 + n_check), m2((size_t)d + n_check);
+        for (int i = 0; i < n; i++) me[i] = -(i + 1);
+        std::vector<uint64_t> f1((size_t)(1 + n_check) * d), f2((size_t)(d + n_check) * d);
+        memcpy(f1.data(), Vi.data(), (size_t)d * 8);
+        memcpy(f2.data(), Vi.data(), (size_t)d * d * 8);
+        if (n_check > 0) { memcpy(&f1[(size_t)d], Ph.data(), Ph.size() * 8); memcpy(&f2[(size_t)d * d], Ph.data(), Ph.size() * 8); }
+        m1[0] = -1;
+        for (int i = 0; i < d; i++) m2[i] = -(i + 1);
+        for (int j = 0; j < n_check; j++) { m1[(size_t)1 + j] = zc_host[j] + 1; m2[(size_t)d + j] = zc_host[j] + 1; }
+        rc = mv64_from_host(ctx, Vh.data(), n, d, me.data(), &pl->nv_enc, s);
+        if (!rc) rc = mv64_from_host(ctx, f1.data(), 1 + n_check, d, m1.data(), &pl->nv_f1, s);
+        if (!rc) rc = mv64_from_host(ctx, f2.data(), d + n_check, d, m2.data(), &pl->nv_f2, s);
+        if (rc == HB_ERR_UNSUPPORTED) rc = HB_OK;
+        if (rc) goto done;
+    }
     // the fused matrices: built on the device right now where hb_quick.hip takes the shape; otherwise on the host when the plan decodes
     // for the third time (ensure_fused), or at once on request (set_option)
     pl->fused_pending = ((pl->V8 || pl->Winv8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") && !getenv("HB_NO_FUSED_VALIDATE") &&
@@ -298,6 +320,8 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
     const int64_t C = (B + pl->d - 1) / pl->d;
     hb_view iv{pl->d, 1}, ov{1, C};
     hipStream_t s = (hipStream_t)stream;
+    if (pl->nv_enc && pl->use_v8)
+        return launch_mv64(pl->ctx, pl->nv_enc, shares_dev, iv, nullptr, B, r1_out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (pl->ntt_order)
         return launch_ntt_lds(pl->ctx, pl->tw, pl->ntt_order, (const uint32_t *)shares_dev, iv, B, pl->d, pl->n,
                               (uint32_t *)r1_out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
@@ -316,6 +340,11 @@ int hb_open_r1_encode(hb_open_plan *pl, const uint64_t *shares_dev, int64_t B, u
 static int decode_and_validate(hb_open_plan *pl, const uint64_t *cols_dev, int64_t C, uint32_t *pk_dst, hb_view pv, int64_t pk_count,
                                int pk_rows, hipStream_t s) {
     hb_view pm{1, C};
+    if (pl->nv_f1 && pl->nv_f2 && pl->use_v8 && pl->use_fused && (pk_rows == 1 || pk_rows == pl->d)) {
+        // word-size prime: [V^-1 rows ; V[zc] V^-1] over the received columns, one launch of the 8-byte mat-vec
+        const bool r1 = pk_rows == 1 && pl->d > 1;
+        return launch_mv64(pl->ctx, r1 ? pl->nv_f1 : pl->nv_f2, cols_dev, pm, pl->z_dev, INT64_MAX, (uint64_t *)pk_dst, pv, pk_count, pl->mismatch_dev, nullptr, C, s);
+    }
     if (pl->fused_pending && pl->use_v8 && pl->use_fused && ++pl->decode_calls > 2) {
         // Building the fused matrices is an optimisation of a plan that already decodes correctly on the two-launch path: if
         // it fails for any reason (out of memory while building F1 / F2, ...) the decode goes on unfused and the error is dropped.
@@ -471,7 +500,7 @@ int hb_open_plan_get_option(hb_open_plan *pl, int option, int *value) { HB_API_G
     if (!pl || !value) return HB_ERR_BAD_ARG;
     if (option == HB_OPEN_OPT_VALIDATE_ARRIVED_ONLY) { *value = pl->validate_arrived_only; return HB_OK; }
     if (option == HB_OPEN_OPT_MATRIX_CORES) { *value = ((pl->V8 || pl->Winv8 || pl->Vw8) && pl->use_v8) ? 1 : 0; return HB_OK; }
-    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (((pl->F1 && pl->F2) || (pl->q1 && pl->q2) || pl->fused_pending) && pl->use_v8 && pl->use_fused) ? 1 : 0;
+    if (option == HB_OPEN_OPT_FUSED_VALIDATE) { *value = (((pl->F1 && pl->F2) || (pl->q1 && pl->q2) || (pl->nv_f1 && pl->nv_f2) || pl->fused_pending) && pl->use_v8 && pl->use_fused) ? 1 : 0;
         if (pl->fs1 && pl->fs2 && pl->use_v8 && pl->use_fused == 1) *value = 3;          // ... on the small-entry kernel
         return HB_OK; }
     return HB_ERR_BAD_ARG;
@@ -498,6 +527,7 @@ void hb_open_plan_destroy(hb_open_plan *pl) { HB_API_GUARD((pl ? pl->ctx : nullp
     if (pl->fmap2) (void)hipFree(pl->fmap2);
     if (pl->Winv) matrix_unref(pl->Winv);
     if (pl->Vw) matrix_unref(pl->Vw);
+    mv64_free(pl->nv_enc); mv64_free(pl->nv_f1); mv64_free(pl->nv_f2);
     delete pl;
 }
 

@@ -118,7 +118,9 @@ class ShardedOpen:
     def ok(self):
         return self.op.ok()
 
-    def gather(self, local_result, out=None):
-        if self.world == 1:
+    def gather(self, local_result, out=None, through_collective=False):
+        """through_collective: a group of ONE rank still goes through the transport (RCCL's all_gather_into_tensor, or batch_isend_irecv with no
+        peers): the N = 1 point of a scaling run then exercises the same calls as N = 2, 4, 8 (bench.py)"""
+        if self.world == 1 and not through_collective:
             return local_result
         return all_gather_opened(local_result, self.num_shares, self.d, self.group, self.gather_mode, out=out)

@@ -365,3 +365,24 @@ def batch_open_limbs(modulus, n, d, x, shares, r1_cols, r2_cols, z, zc, use_fft=
         _ptr(za), _ptr(zca), len(zc), _ptr(r1_out), _ptr(r2_msg), _ptr(result),
     )
     return rc, r1_out, r2_msg, result
+
+
+def batch_open_u64(modulus, n, d, x, shares, r1_cols, r2_cols, z, zc, out=None):
+    """The same open for a word-size prime (p < 2^64), elements as uint64 arrays: orc_batch_open_u64 (CPU baseline / checker of bench.py's
+    cfg3-p64 workload).  Returns (rc, r1_out[n*C], r2_msg[C], result[B])."""
+    b = shares.shape[0]
+    c = (b + d - 1) // d
+    xa = np.array([v % modulus for v in x], dtype=np.uint64)
+    za = np.array(z, dtype=np.int32)
+    zca = np.array(list(zc) if len(zc) else [0], dtype=np.int32)
+    if out is not None:
+        r1_out, r2_msg, result = out
+    else:
+        r1_out, r2_msg, result = np.zeros(n * c, dtype=np.uint64), np.zeros(c, dtype=np.uint64), np.zeros(b, dtype=np.uint64)
+    fn = lib().orc_batch_open_u64
+    fn.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    rc = fn(int(modulus), n, d, _ptr(xa), _ptr(np.ascontiguousarray(shares, dtype=np.uint64)), b, _ptr(np.ascontiguousarray(r1_cols, dtype=np.uint64)),
+            _ptr(np.ascontiguousarray(r2_cols, dtype=np.uint64)), _ptr(za), _ptr(zca), len(zc), _ptr(r1_out), _ptr(r2_msg), _ptr(result))
+    return rc, r1_out, r2_msg, result

@@ -893,3 +893,80 @@ API int orc_batch_open(const u64 *p, int n, int d, int use_fft, const u64 *omega
     free(xz);
     return rc;
 }
+
+/* ------------------------------------------------------------------
+   The same fault-free per-party open for a WORD-SIZE prime (p < 2^64): what NTL's ZZ_p amounts to at one limb, restated with
+   unsigned __int128 products (batch_reconstruction.py:158-227 over vandermonde_batch_evaluate / vandermonde_batch_interpolate,
+   hbmpc_ntl_helpers.pyx:139-244; V(z)^-1 by Gauss-Jordan as NTL's inv, rsdecode_impl.h:97-122).  CPU baseline of bench.py's
+   --workload cfg3-p64 and checker of its outputs; elements are one u64 each.  Returns 0 ok, 1 singular, 2 validation mismatch.
+   ------------------------------------------------------------------ */
+static inline u64 mulmod64(u64 a, u64 b, u64 p) { return (u64)(((unsigned __int128)a * b) % p); }
+static u64 powmod64(u64 a, u64 e, u64 p) { u64 r = 1 % p; a %= p; while (e) { if (e & 1) r = mulmod64(r, a, p); a = mulmod64(a, a, p); e >>= 1; } return r; }
+
+static void matvec64(u64 p, const u64 *M, int rows, int d, const u64 *in, long C, u64 *out) {
+    /* out[c][i] = sum_l M[i][l] in[c][l]: products accumulated lazily in 128 bits (up to 2^64 terms below 2^128 / ... : reduced per term pair) */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (long c = 0; c < C; c++) {
+        const u64 *v = in + (size_t)c * d;
+        for (int i = 0; i < rows; i++) {
+            const u64 *m = M + (size_t)i * d;
+            unsigned __int128 acc = 0;
+            for (int l = 0; l < d; l++) {
+                acc += (unsigned __int128)m[l] * v[l] % p;       /* each reduced product < 2^64: d <= 2^32 of them fit */
+            }
+            out[(size_t)c * rows + i] = (u64)(acc % p);
+        }
+    }
+}
+
+API int orc_batch_open_u64(u64 p, int n, int d, const u64 *x, const u64 *shares, long B, const u64 *r1_cols, const u64 *r2_cols,
+                           const int *z, const int *zc, int n_check, u64 *r1_out, u64 *r2_msg, u64 *result) {
+    if (p < 3 || n < 1 || d < 1 || d > n) return -1;
+    long C = (B + d - 1) / d;
+    u64 *V = (u64 *)malloc((size_t)n * d * 8), *Vi = (u64 *)malloc((size_t)d * d * 8), *A = (u64 *)malloc((size_t)d * 2 * d * 8);
+    for (int i = 0; i < n; i++) { u64 pw = 1 % p; for (int l = 0; l < d; l++) { V[(size_t)i * d + l] = pw; pw = mulmod64(pw, x[i] % p, p); } }
+    /* V(z)^-1 by Gauss-Jordan on [V(z) | I] */
+    for (int i = 0; i < d; i++) for (int l = 0; l < d; l++) { A[(size_t)i * 2 * d + l] = V[(size_t)z[i] * d + l]; A[(size_t)i * 2 * d + d + l] = (i == l); }
+    int rc = 0;
+    for (int col = 0; col < d && !rc; col++) {
+        int piv = -1;
+        for (int r = col; r < d; r++) if (A[(size_t)r * 2 * d + col]) { piv = r; break; }
+        if (piv < 0) { rc = 1; break; }
+        if (piv != col) for (int l = 0; l < 2 * d; l++) { u64 t = A[(size_t)col * 2 * d + l]; A[(size_t)col * 2 * d + l] = A[(size_t)piv * 2 * d + l]; A[(size_t)piv * 2 * d + l] = t; }
+        u64 inv = powmod64(A[(size_t)col * 2 * d + col], p - 2, p);
+        for (int l = 0; l < 2 * d; l++) A[(size_t)col * 2 * d + l] = mulmod64(A[(size_t)col * 2 * d + l], inv, p);
+        for (int r = 0; r < d; r++) {
+            if (r == col) continue;
+            u64 f = A[(size_t)r * 2 * d + col];
+            if (!f) continue;
+            for (int l = 0; l < 2 * d; l++) { const u64 a = A[(size_t)r * 2 * d + l], s_ = mulmod64(f, A[(size_t)col * 2 * d + l], p); A[(size_t)r * 2 * d + l] = a >= s_ ? a - s_ : a + (p - s_); }   /* (a + p would pass 2^64) */
+        }
+    }
+    if (!rc) for (int i = 0; i < d; i++) for (int l = 0; l < d; l++) Vi[(size_t)i * d + l] = A[(size_t)i * 2 * d + d + l];
+    u64 *chunks = (u64 *)slot_get(4, (size_t)C * d * 8), *enc = (u64 *)slot_get(5, (size_t)C * n * 8);
+    u64 *avail = (u64 *)slot_get(6, (size_t)C * d * 8), *dec = (u64 *)slot_get(7, (size_t)C * d * 8);
+    if (!rc) {
+        memcpy(chunks, shares, (size_t)B * 8);
+        memset(chunks + (size_t)B, 0, ((size_t)C * d - (size_t)B) * 8);
+        matvec64(p, V, n, d, chunks, C, enc);                                    /* R1 encode + transpose_lists */
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+        for (long c = 0; c < C; c++) for (int i = 0; i < n; i++) r1_out[(size_t)i * C + c] = enc[(size_t)c * n + i];
+        for (int round = 0; round < 2 && rc == 0; round++) {
+            const u64 *cols = round == 0 ? r1_cols : r2_cols;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+            for (long c = 0; c < C; c++) for (int l = 0; l < d; l++) avail[(size_t)c * d + l] = cols[(size_t)z[l] * C + c];
+            matvec64(p, Vi, d, d, avail, C, dec);                                /* decode */
+            matvec64(p, V, n, d, dec, C, enc);                                   /* validating re-encode of all n points */
+            int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(g_threads) reduction(|:bad)
+            for (long c = 0; c < C; c++)
+                for (int j = 0; j < n_check; j++)
+                    if (cols[(size_t)zc[j] * C + c] != enc[(size_t)c * n + zc[j]]) bad |= 1;
+            if (bad) rc = 2;
+            if (round == 0) for (long c = 0; c < C; c++) r2_msg[c] = dec[(size_t)c * d];
+        }
+        if (rc == 0) memcpy(result, dec, (size_t)B * 8);
+    }
+    free(V); free(Vi); free(A);
+    return rc;
+}

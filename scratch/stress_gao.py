@@ -8,7 +8,9 @@ import sys
 import time
 
 sys.path.insert(0, '.')
+sys.path.insert(0, 'tests')
 import oracle  # noqa: E402
+from structured import coordinated_errors, structured_message  # noqa: E402  (the generators the -m gpu suites use)
 from honeybadgermpc_amd import ntl  # noqa: E402
 from honeybadgermpc_amd.device import wb_decode_batch  # noqa: E402
 
@@ -27,20 +29,14 @@ while time.time() < t_end:
     emax = (n - k) // 2
     words = []
     for _ in range(rnd.choice([1, 7, 64, 200])):
-        kind = rnd.random()
-        if kind < 0.1:
-            msg = [0] * k
-        elif kind < 0.2:
-            msg = [rnd.randrange(p)] + [0] * (k - 1)
-        elif kind < 0.3:
-            cut = rnd.randrange(k + 1)
-            msg = [rnd.randrange(p) for _ in range(cut)] + [0] * (k - cut)
-        else:
-            msg = [rnd.randrange(p) for _ in range(k)]
+        msg = structured_message(rnd, k, p)
         enc = oracle.vandermonde_batch_evaluate(x, [msg], p)[0]
         ne = min(n, rnd.choice([0, emax, rnd.randrange(emax + 1), emax + 1, emax + 2, rnd.randrange(n + 1)]))
-        for i in rnd.sample(range(n), ne):
-            enc[i] = (enc[i] + rnd.randrange(1, p)) % p
+        if rnd.random() < 0.25:
+            enc = coordinated_errors(rnd, enc, x, k, ne, p, lambda xs, cf: oracle.vandermonde_batch_evaluate(xs, [cf], p)[0])[0]
+        else:
+            for i in rnd.sample(range(n), ne):
+                enc[i] = (enc[i] + rnd.randrange(1, p)) % p
         words.append(enc)
     got = ntl.gao_interpolate_batch(x, words, k, p)
     want = oracle.gao_interpolate_batch(x, words, k, p)

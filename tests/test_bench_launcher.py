@@ -54,3 +54,22 @@ def test_under_torchrun_no_second_launch():
     assert res.returncode == 0, res.stderr[-3000:]
     out = _json_line(res.stdout)
     assert out["ranks_seen"] == 2 and out["world_size_env"] == 2 and not out["self_launched"]
+
+
+def test_timeout_names_the_rank_that_fell_behind():
+    """bench.Progress: every rank notes its phase; the watchdog of a rank that is still waiting after the limit prints which rank never got
+    as far and ends the process (an 8-GPU run that wedges must say who)"""
+    code = (
+        "import os, sys, time\n"
+        "os.environ['MASTER_PORT'] = 'test%d' % os.getpid()\n"
+        "import bench\n"
+        "late = bench.Progress(1, 3, 0)\n"           # rank 1 started and never got past 'start'
+        "time.sleep(0.3)\n"
+        "p2 = bench.Progress(2, 3, 0); p2.note('timed steps')\n"
+        "p0 = bench.Progress(0, 3, 1.0); p0.note('timed steps')\n"    # rank 0's watchdog: one second
+        "time.sleep(30)\n"
+    )
+    res = subprocess.run([sys.executable, "-c", code], cwd=REPO, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 3, (res.returncode, res.stderr[-2000:])
+    assert "straggler = rank 1" in res.stderr and "last phase 'start'" in res.stderr
+    assert "rank 2: 'timed steps'" in res.stderr

@@ -26,6 +26,22 @@ def _rand(torch, count, gen):
     return t
 
 
+def _structure(coef, c, d):
+    """in place on a (c * d, 4) tensor of uniformly random coefficients: the messages uniform draws never produce (tests/structured.py) --
+    chunk 0 zero, chunk 1 constant, chunk 2 short, chunk 3 only its leading coefficient, one in the middle short, the LAST chunk padded
+    with zeros as chunk_data pads the last chunk of every open (reference utils/misc.py:33-51)"""
+    v = coef.view(c, d, 4)
+    if c < 8 or d < 4:
+        return coef
+    v[0] = 0
+    v[1, 1:] = 0
+    v[2, d // 2:] = 0
+    v[3, : d - 1] = 0
+    v[c // 2, 2:] = 0
+    v[c - 1, 3:] = 0
+    return coef
+
+
 # ---------------------------------------------------------------------------------------------- config 4
 @pytest.mark.parametrize("decoder,count", [("gao", 1 << 18), ("wb", 1 << 14), ("wb", 1 << 18)])
 def test_robust_decoders_full_batch_cfg4(decoder, count):
@@ -43,7 +59,7 @@ def test_robust_decoders_full_batch_cfg4(decoder, count):
     xh = ctx.host_elems(list(range(1, n + 1)))
     gen = torch.Generator(device="cuda")
     gen.manual_seed(44)
-    msg = _rand(torch, count * k, gen)
+    msg = _structure(_rand(torch, count * k, gen), count, k)
     code = ctx.empty(count * n)
     ctx.check(lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(xh), n, ctx.ptr(msg), count, k, ctx.ptr(code), ctx.stream()), "enc")
     pos = torch.rand((count, n), device="cuda", generator=gen).argsort(dim=1)[:, :t]
@@ -178,7 +194,7 @@ def test_full_size_decoder_under_attack(n, t, b, use_omega, spread):
         v[:, 3] &= (1 << 61) - 1
         return v
 
-    coef = rand(c * d)
+    coef = _structure(rand(c * d), c, d)
     enc = BatchOpen(P, n, t, use_omega_powers=use_omega, max_shares=c * d)
     cols = enc.r1_encode(coef).view(n, c, 4).clone()
     rng = np.random.Generator(np.random.PCG64(n))

@@ -49,7 +49,9 @@ class _QDec:
 
 
 def _codewords(rnd, x, d, c, p):
-    polys = [[rnd.randrange(p) for _ in range(d)] for _ in range(c)]
+    from structured import structured_rows
+
+    polys = structured_rows(rnd, p, c, d)                   # zero, constant, short, padded polynomials among the uniform ones
     enc = oracle.vandermonde_batch_evaluate(x, polys, p)                       # [c][n]
     return polys, [enc[k][j] for j in range(len(x)) for k in range(c)]
 

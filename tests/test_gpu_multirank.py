@@ -106,3 +106,42 @@ def test_eight_ranks_weak_scaling_path():
     out = _run(["--workload", "tiny", "--no-two-streams-extra"], nproc=8, timeout=1500)
     assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["value"] > 0 and out["detail"]["bit_exact_vs_secrets"]
     assert out["distributed"]["world_size"] == 8
+
+
+# ---- one rank on the RCCL backend: what can be exercised of the multi-GPU path on a one-GPU box ---------------------
+@pytest.mark.parametrize("mode", ["direct", "collective", "auto"])
+def test_one_rank_on_the_nccl_backend_goes_through_the_collectives(mode):
+    """torchrun with ONE rank and no HB_BENCH_SHARE_GPU: backend nccl (RCCL) -- init_process_group with a device id, the barrier, the MAX
+    reduction, the gather probes and the timed all-gather (all_gather_into_tensor / batch_isend_irecv with no peers) all run on RCCL;
+    per-rank times are in the line"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k != "HB_BENCH_SHARE_GPU"}
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--workload", "cfg5-mini", "--gather", mode]
+    res = subprocess.run(cmd, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    dd = out["distributed"]
+    assert dd["backend"] == "nccl" and dd["world_size"] == 1 and out["n_gpus"] == 1
+    assert dd["gather_mode"] in ("direct", "collective") and (mode == "auto" or dd["gather_mode"] == mode)
+    assert set(k for k, v in dd["gather"]["probe_ms"].items() if v is not None) >= {dd["gather_mode"]}
+    assert len(dd["per_rank"]) == 1 and dd["per_rank"][0]["compute_ms_per_step"] > 0
+    assert out["detail"]["bit_exact_vs_secrets"]
+
+
+def test_the_64_bit_prime_workload_line():
+    """bench.py --workload cfg3-p64-mini: the open over p = 2^64 - 59 on the 1-limb kernels, checked bit for bit against the secrets inside
+    bench.py, with roofline (three segments) and the CPU baseline on the same modulus"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "HB_BENCH_SHARE_GPU")}
+    res = subprocess.run([sys.executable, "bench.py", "--workload", "cfg3-p64-mini", "--steps", "3", "--warmup", "1", "--cpu-sample", "8192"], cwd=REPO, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["value"] > 0 and out["dtype"].startswith("u64") and out["detail"]["bit_exact_vs_secrets"]
+    assert len(out["roofline"]["segments"]) == 3 and 0 < out["roofline"]["frac"] < 1
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["kind"] == "port"

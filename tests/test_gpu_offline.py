@@ -9,6 +9,13 @@ import pytest
 
 import oracle
 from conftest import BLS
+from structured import structured_rows
+
+
+def _padded(rows, d):
+    """the reference's Welch-Berlekamp decoder strips trailing zeros (reed_solomon_wb.py:121-126 over polynomial.py:14-20): a robust-decoded row of the
+    host mirror may be shorter than degree + 1; the device decoder's tensor is zero padded"""
+    return [list(r) + [0] * (d - len(r)) for r in rows]
 
 pytestmark = pytest.mark.gpu
 
@@ -197,7 +204,7 @@ def test_device_incremental_decoder_trajectory(n, t, c, seed, robust, use_omega)
     codec = Algorithm.FFT if use_omega else Algorithm.VANDERMONDE
     robust_launches = 0
     for trial in range(6):
-        polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+        polys = structured_rows(rnd, P, c, t + 1)          # zero, constant, short, padded polynomials among the uniform ones
         cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
         liars = rnd.sample(range(n), rnd.randrange(trial % 2, t + 1))         # odd trials: at least one liar
         for i in liars:
@@ -235,8 +242,8 @@ def test_device_incremental_decoder_trajectory(n, t, c, seed, robust, use_omega)
                 hres, herr = host.get_results()
                 dres, derr = dev.get_results()
                 assert derr == herr
-                assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in hres for v in row]
-                assert [list(r) for r in hres] == polys            # and both recovered what was shared
+                assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in _padded(hres, t + 1) for v in row]
+                assert _padded(hres, t + 1) == polys               # and both recovered what was shared
                 break
         assert blew_up or (host.done() and set(host.get_results()[1]) <= set(liars))
         robust_launches += dev.launches + dev.plan_accepts + dev.probes
@@ -260,7 +267,7 @@ def test_device_decoder_adversaries_welch_berlekamp(robust, liar_count, pattern)
     ctx = Context.get(P)
     point = EvalPoint(GF(P), n)
     xs = [point(i).value for i in range(n)]
-    polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+    polys = structured_rows(rnd, P, c, t + 1)
     cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
     liars = rnd.sample(range(n), liar_count)
     for r, i in enumerate(liars):
@@ -287,7 +294,7 @@ def test_device_decoder_adversaries_welch_berlekamp(robust, liar_count, pattern)
     assert host.done() and dev.done()
     hres, herr = host.get_results()
     dres, derr = dev.get_results()
-    assert derr == herr and ctx.download_ints(dres.reshape(-1, 4)) == [v for row in hres for v in row] == [v for row in polys for v in row]
+    assert derr == herr and ctx.download_ints(dres.reshape(-1, 4)) == [v for row in _padded(hres, t + 1) for v in row] == [v for row in polys for v in row]
     assert dev.quick_launches > 0
 
 
@@ -309,7 +316,7 @@ def test_device_decoder_worst_case_adversaries(n, t, c, pattern):
     ctx = Context.get(P)
     point = EvalPoint(GF(P), n)
     xs = [point(i).value for i in range(n)]
-    polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+    polys = structured_rows(rnd, P, c, t + 1)
     cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
     liars = rnd.sample(range(n), t)
     for r, i in enumerate(liars):
@@ -338,7 +345,7 @@ def test_device_decoder_worst_case_adversaries(n, t, c, pattern):
     hres, herr = host.get_results()
     dres, derr = dev.get_results()
     assert derr == herr == set(liars)
-    assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in hres for v in row] == [v for row in polys for v in row]
+    assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in _padded(hres, t + 1) for v in row] == [v for row in polys for v in row]
     assert dev.quick_launches > 0 and dev.launches == 0          # the plan-free path did it: no batched Gao launch, no plan
     # every polynomial that had errors was settled either by the probe or by a batched candidate inside the radius
     if pattern != "late-same":
@@ -407,7 +414,7 @@ def test_device_decoder_candidates_against_coordinated_liars(n, t, c, use_omega,
     xs = [point(i).value for i in range(n)]
     ev = lambda poly, x: sum(co * pow(x, e, P) for e, co in enumerate(poly)) % P  # noqa: E731
     for liar_count in (t, t + 1):
-        polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+        polys = structured_rows(rnd, P, c, t + 1)          # zero, constant, short, padded polynomials among the uniform ones
         liars = rnd.sample(range(n), liar_count)
         honest = [i for i in range(n) if i not in liars]
         rnd.shuffle(honest)
@@ -438,7 +445,7 @@ def test_device_decoder_candidates_against_coordinated_liars(n, t, c, use_omega,
             hres, herr = host.get_results()
             dres, derr = dev.get_results()
             assert derr == herr
-            assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in hres for v in row]
+            assert ctx.download_ints(dres.reshape(-1, 4)) == [v for row in _padded(hres, t + 1) for v in row]
         if liar_count == t and shared == 0:
             assert dev.probes == 0 and dev.radius_verdicts >= 1          # the newest columns gave the true polynomial: nothing incremental ran
 
@@ -468,7 +475,7 @@ def test_device_decoder_randomised_vs_host_mirror():
         robust = rnd.choice(["gao", "gao", "wb"])
         point = EvalPoint(GF(P), n, use_omega_powers=use_omega)
         xs = [point(i).value for i in range(n)]
-        polys = [[rnd.randrange(P) for _ in range(t + 1)] for _ in range(c)]
+        polys = structured_rows(rnd, P, c, t + 1)          # zero, constant, short, padded polynomials among the uniform ones
         cols = [[sum(co * pow(xs[i], e, P) for e, co in enumerate(poly)) % P for poly in polys] for i in range(n)]
         liars = rnd.sample(range(n), rnd.randrange(0, t + 2))
         for i in liars:
@@ -502,7 +509,7 @@ def test_device_decoder_randomised_vs_host_mirror():
             assert dev.done() == host.done() and dev._confirmed_errors == host._confirmed_errors, (what, step)
             assert dev._z == host._z and dev._num_decoded == host._num_decoded, (what, step)
             if host.done():
-                assert ctx.download_ints(dev.get_results()[0].reshape(-1, 4)) == [v for row in host.get_results()[0] for v in row], what
+                assert ctx.download_ints(dev.get_results()[0].reshape(-1, 4)) == [v for row in _padded(host.get_results()[0], t + 1) for v in row], what
                 break
         robust_runs += dev.probes + dev.radius_verdicts + dev.launches > 0
         runs += 1

@@ -31,7 +31,10 @@ def hip():
 
 
 def rand_rows(rnd, p, c, d):
-    return [[rnd.randrange(p) for _ in range(d)] for _ in range(c)]
+    """rows of coefficients for every test of this file: zero, constant, short and padded rows among the uniform ones (tests/structured.py)"""
+    from structured import structured_rows
+
+    return structured_rows(rnd, p, c, d)
 
 
 # ------------------------------------------------------------------ C ABI sanity
@@ -333,6 +336,12 @@ def test_full_size_properties_cfg3():
         return v
 
     a, bvec = rand(c * d), rand(c * d)
+    av = a.view(c, d, 4)                 # the messages uniform draws never produce: zero, constant, short, leading coefficient only, padded last chunk
+    av[0] = 0
+    av[1, 1:] = 0
+    av[2, d // 2:] = 0
+    av[3, : d - 1] = 0
+    av[c - 1, 12:] = 0
     V = ctypes.c_void_p()
     ctx.check(lib.hb_vand_matrix_create(ctx.h, np_ptr(ctx.host_elems(x)), n, d, ctypes.byref(V), ctx.stream()), "V")
 
@@ -709,14 +718,19 @@ def test_gao_batch_vs_oracle(hip, p, n, k):
     x = list(range(1, n + 1))
     emax = (n - k) // 2
     words = []
-    for trial in range(24):
-        msg = [rnd.randrange(p) for _ in range(k)]
-        if trial == 0:
-            msg = [0] * k
+    from structured import KINDS, coordinated_errors, structured_message
+
+    for trial in range(60):
+        # zero, constant, short, padded messages (what chunk_data's padding makes of an open's last chunk) among the uniform ones
+        msg = structured_message(rnd, k, p, (KINDS + ["full"])[trial % 6] if trial < 36 else None)
         enc = oracle.vandermonde_batch_evaluate(x, [msg], p)[0]
-        ne = [0, emax, emax // 2, 1 if emax else 0, emax + 1, n][trial % 6]      # the last two are beyond the radius
+        ne = [0, emax, emax // 2, 1 if emax else 0, emax + 1, n][(trial // 6) % 6]      # the last two are beyond the radius
         ne = min(ne, n)
-        words.append(_corrupt(rnd, enc, ne, 0, p)[0])
+        if trial >= 36 and trial % 2:
+            # liars that agree with each other: their symbols lie on ANOTHER polynomial of degree < k
+            words.append(coordinated_errors(rnd, enc, x, k, ne, p, lambda xs, cf: oracle.vandermonde_batch_evaluate(xs, [cf], p)[0])[0])
+        else:
+            words.append(_corrupt(rnd, enc, ne, 0, p)[0])
     got = hip.gao_interpolate_batch(x, words, k, p)
     want = oracle.gao_interpolate_batch(x, words, k, p)
     assert got == want

@@ -42,7 +42,9 @@ def test_quick_interp_check_vs_oracle(n, t, c, omega):
     d = t + 1
     point = EvalPoint(GF(P), n, use_omega_powers=omega)
     x = [point(i).value for i in range(n)]
-    polys = [[rnd.randrange(P) for _ in range(d)] for _ in range(c)]
+    from structured import structured_rows
+
+    polys = structured_rows(rnd, P, c, d)                                      # zero, constant, short, padded polynomials among the uniform ones
     enc = oracle.vandermonde_batch_evaluate(x, polys, P)                       # [c][n]
     flat = [enc[k][j] for j in range(n) for k in range(c)]
     cols = ctx.upload_ints(flat)
@@ -264,7 +266,9 @@ def test_quick_interp_check_map_names_every_disagreeing_chunk(n, t, c, omega):
     d = t + 1
     point = EvalPoint(GF(P), n, use_omega_powers=omega)
     x = [point(i).value for i in range(n)]
-    polys = [[rnd.randrange(P) for _ in range(d)] for _ in range(c)]
+    from structured import structured_rows
+
+    polys = structured_rows(rnd, P, c, d)
     enc = oracle.vandermonde_batch_evaluate(x, polys, P)
     flat = [enc[k][j] for j in range(n) for k in range(c)]
     for trial in range(4):

@@ -258,3 +258,32 @@ def test_golden_gao_cofactor_from_the_references_polynomial_class(golden):
         co, v = oracle.gao_interpolate(c["x"], c["y"], c["k"], P)
         assert co == c["coeffs"], (c["kind"], c["k"], len(c["x"]))
         assert v == c["v"], (c["kind"], c["k"], len(c["x"]))
+
+
+def test_word_size_open_equals_the_256_bit_restatement():
+    """orc_batch_open_u64 (the open restated for p < 2^64 with 128-bit products: CPU baseline of bench.py --workload cfg3-p64) against
+    orc_batch_open on the same inputs -- which the golden batch_reconstruct transcripts pin"""
+    import random
+
+    import numpy as np
+
+    for p in ((1 << 64) - 59, 0xFFFFFFFF00000001, (1 << 61) - 1, 13):
+        n, t = (16, 5) if p > 100 else (8, 2)
+        d, b = t + 1, 100
+        c = (b + d - 1) // d
+        rnd = random.Random(p % 1000)
+        x = list(range(1, n + 1))
+        secrets = [rnd.randrange(p) for _ in range(b)]
+        shares = [rnd.randrange(p) for _ in range(b)]
+        padded = secrets + [0] * (c * d - b)
+        enc = oracle.vandermonde_batch_evaluate(x, [padded[k * d:(k + 1) * d] for k in range(c)], p)
+        cols = [enc[k][j] for j in range(n) for k in range(c)]
+        z = rnd.sample(range(n), d)
+        zc = [i for i in range(n) if i not in z][:t]
+        rc, r1, msg, res = oracle.batch_open_u64(p, n, d, x, np.array(shares, dtype=np.uint64), np.array(cols, dtype=np.uint64), np.array(cols, dtype=np.uint64), z, zc)
+        rc4, a1, a2, a3 = oracle.batch_open_limbs(p, n, d, x, oracle._limbs(shares, p), oracle._limbs(cols, p), oracle._limbs(cols, p), z, zc)
+        assert rc == rc4 == 0 and res.tolist() == secrets
+        assert oracle._ints(a1) == r1.tolist() and oracle._ints(a2) == msg.tolist() and oracle._ints(a3) == res.tolist()
+        bad = list(cols)
+        bad[zc[0] * c + 3] = (bad[zc[0] * c + 3] + 1) % p
+        assert oracle.batch_open_u64(p, n, d, x, np.array(shares, dtype=np.uint64), np.array(cols, dtype=np.uint64), np.array(bad, dtype=np.uint64), z, zc)[0] == 2
