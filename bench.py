@@ -983,13 +983,24 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
     msg = rand_elements(torch, C * k, gen)
     code = ctx.empty(C * n)
     ctx.check(lib.hb_vandermonde_batch_evaluate(ctx.h, np_ptr(xh), n, ctx.ptr(msg), C, k, ctx.ptr(code), ctx.stream()), "encode")
-    # exactly t distinct positions per codeword: the t smallest of n seeded uniforms
-    pos = torch.rand((C, n), device="cuda", generator=gen).argsort(dim=1)[:, :t]
+    # exactly n_err distinct positions per codeword: the n_err smallest of n seeded uniforms (erased positions pushed to the end)
+    n_era = max(0, min(int(args.erasures), n - k - 1))
+    n_err = t if n_era == 0 else (n - n_era - k) // 2
+    erased_pos = sorted(np.random.Generator(np.random.PCG64(404)).choice(n, size=n_era, replace=False).tolist()) if n_era else []
+    keys = torch.rand((C, n), device="cuda", generator=gen)
+    if n_era:
+        keys[:, torch.tensor(erased_pos, device="cuda")] = 2.0
+    pos = keys.argsort(dim=1)[:, :n_err]
     idx = (torch.arange(C, device="cuda").unsqueeze(1) * n + pos).reshape(-1)
     bad = code.clone()
-    bad[idx] = rand_elements(torch, C * t, gen)
-    del code, pos
-    present = torch.ones(C * n, dtype=torch.uint8, device="cuda")
+    bad[idx] = rand_elements(torch, C * n_err, gen)
+    present = torch.ones((C, n), dtype=torch.uint8, device="cuda")
+    if n_era:
+        ep = torch.tensor(erased_pos, device="cuda")
+        present[:, ep] = 0
+        bad.view(C, n, 4)[:, ep] = rand_elements(torch, C * n_era, gen).view(C, n_era, 4)      # what lies in an erased slot is never read
+    present = present.reshape(-1)
+    del code, pos, keys
     out = ctx.empty(C * k)
     olen = torch.zeros(C, dtype=torch.int32, device="cuda")
     st = torch.zeros(C, dtype=torch.int32, device="cuda")
@@ -1031,15 +1042,17 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
     assert bool((st == 0).all().item()) and torch.equal(out, msg), "Welch-Berlekamp: wrong coefficients in the timed region"
     call_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / steps
     # the Gao entry point on the same words (untimed for `value`)
-    out.zero_()
-    gao()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(steps):
+    dt_gao = None
+    if not n_era:               # (the Gao entry point takes no erasure mask: callers hand it the surviving points, ntl.gao_interpolate drops them per word)
+        out.zero_()
         gao()
-    torch.cuda.synchronize()
-    dt_gao = time.perf_counter() - t1
-    assert bool(okf.all().item()) and bool((elen == t + 1).all().item()) and torch.equal(out, msg), "Gao: wrong coefficients / locator degree"
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            gao()
+        torch.cuda.synchronize()
+        dt_gao = time.perf_counter() - t1
+    assert n_era or (bool(okf.all().item()) and bool((elen == t + 1).all().item()) and torch.equal(out, msg)), "Gao: wrong coefficients / locator degree"
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -1058,8 +1071,9 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
         "metric": f"codewords robust-decoded/sec (Welch-Berlekamp, t injected errors, n={n} t={t})", "value": world * C * steps / dt, "unit": "codewords/s",
         "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 3)), "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u256 (integer mod p, 9 x 29-bit digits in u32, 64-bit accumulators; the interpolant on the int8 matrix cores)", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: batched robust decode of {C} codewords per GPU, n={n}, k={k}, exactly {t} random positions of each codeword "
-                               "replaced by random field elements, no erasures, points 1..n, p=BLS12-381 r",
+        "config": {"workload": f"{args.workload}: batched robust decode of {C} codewords per GPU, n={n}, k={k}, exactly {n_err} random positions of each codeword "
+                               f"replaced by random field elements, {'no erasures' if not n_era else str(n_era) + ' symbols of every codeword erased (the same positions)'}, points 1..n, p=BLS12-381 r",
+                   "erasures": n_era, "errors_per_codeword": n_err,
                    "n": n, "t": t, "codewords_per_gpu": C, "parallelism": f"codeword-sharded x{world}, no data-path collective"},
         "distributed": dist_info(torch, dist, backend, args, world),
         "roofline": {
@@ -1083,7 +1097,7 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
             "note": "purely arithmetic-bound: ~1.6 10^6 multiply-adds per 4.3 KB codeword; the HBM fraction is what SURVEY 8d asks for, the multiply-add rate says how busy the chip is",
         },
         "detail": {"shares_equivalent_per_s": world * C * k * steps / dt,
-                   "gao_codewords_per_s_per_gpu": C * steps / dt_gao, "gao_ms_per_step": dt_gao * 1e3 / steps,
+                   "gao_codewords_per_s_per_gpu": (C * steps / dt_gao) if dt_gao else None, "gao_ms_per_step": (dt_gao * 1e3 / steps) if dt_gao else None,
                    "bit_exact_vs_generating_polynomials": True,
                    "welch_berlekamp_note": "inside the unique-decoding radius the polynomial the reference's solver returns is the closest codeword's whatever the solver, so "
                                            "hb_wb_decode takes the Gao kernels' result there (trailing zeros stripped as the reference does) and row-reduces only what they "
@@ -1118,6 +1132,9 @@ def main():
     ap.add_argument("--no-matrix-cores", action="store_true", help="time the integer-VALU kernels instead of the int8 matrix-core path")
     ap.add_argument("--timeout-s", type=float, default=900.0,
                     help="multi-rank runs: seconds after which every rank's watchdog ends the run and names the rank that fell behind (0 = none)")
+    ap.add_argument("--erasures", type=int, default=0,
+                    help="cfg4: this many symbols of EVERY codeword are erased (the same positions: the parties that have not arrived, reed_solomon.py:201-204) "
+                         "and floor((n - erasures - k) / 2) of the others replaced by random field elements")
     ap.add_argument("--gather", default="auto", choices=["auto", "direct", "collective"],
                     help="sharded workloads (cfg5): how the opened slices are all-gathered (per-peer sends on the xGMI mesh / RCCL all_gather); "
                          "auto = probe both outside the timed region and use the faster usable one; direct falls back to collective if it fails")

@@ -197,7 +197,7 @@ int vinv_from_dev(hb_ctx *ctx, const std::string &key, const uint32_t *x_dev, in
 // out(c,i) = sum_l M[i][l] * in(c, rows[l]); CHECK mode when check_mask_dev != nullptr (out = expected values)
 // hb_gao_decode with the locators optional (hb_gao.hip; errloc_dev == nullptr: only their lengths are produced)
 int gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const uint64_t *ys_dev, int64_t C,
-               uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream);
+               uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream, int ys_stride = 0, const int32_t *sel_host = nullptr);
 int launch_matvec(hb_ctx *ctx, const hb_matrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                   uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
                   int64_t C, hipStream_t s);

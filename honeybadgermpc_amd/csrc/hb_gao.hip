@@ -463,17 +463,126 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
     if (lane == 0) { okflag[c] = ok ? 1 : 0; errlen[c] = ok ? dv + 1 : 0; }
 }
 
-// One lane per GAO_FIN_G codewords: w_j = cs_j l_j and ONE inversion for the group (Montgomery's trick: prefix products, invert the last,
-// peel backwards -- an inversion is ~380 multiplications, the three per codeword that replace it are not), then 1 / cs = l / w scales
-// the cofactor into the reference's un-normalised error locator, and powers of 1 / l = cs / w turn the raw quotient digits into
-// coefficients: f_i = c_i / l^(dq - i + 1).  In place, canonical on the way out: the scale factors are taken OUT of Montgomery form once,
-// so that one multiplication both scales an element and converts it.  (One lane per codeword, an inversion each: 1.18 ms at config 4.)
+// A workgroup of one wave finishes 64 GAO_FIN_G consecutive codewords.  Lane t owns codewords base + t, base + 64 + t, ... (GAO_FIN_G of them):
+// w_j = cs_j l_j and ONE inversion for the lane's group (Montgomery's trick: prefix products, invert the last, peel backwards -- an inversion is
+// ~380 multiplications, the three per codeword that replace it are not), then 1 / cs = l / w scales the cofactor into the reference's
+// un-normalised error locator, and powers of 1 / l = cs / w turn the raw quotient digits into coefficients: f_i = c_i / l^(dq - i + 1).
+// The scale factors are taken OUT of Montgomery form once, so that one multiplication both scales an element and converts it.
+// Rounds 3-4 let every lane walk its own codewords' elements in place -- 32-byte accesses 1 KB apart across the wave: 0.86 ms at config 4, bound
+// by the 36 M uncoalesced requests, not by the arithmetic.  Now a lane only produces its codeword's FACTORS (the chain of powers, into LDS);
+// the wave then scales the 64 codewords of slice j together: their coefficients are one contiguous run of 64 k elements, element e on lane
+// e mod 64 -- coalesced in, coalesced out.
 #ifndef GAO_FIN_GROUP
 #define GAO_FIN_GROUP 4
 #endif
 constexpr int GAO_FIN_G = GAO_FIN_GROUP;
 template <int NL, int NW>
 __global__ void __launch_bounds__(64) k_gao_finish(const FpParams<NL> P, int npts, int k, int64_t C, uint32_t *__restrict__ coeffs,
+                                                   uint32_t *__restrict__ errloc, const int32_t *__restrict__ errlen,
+                                                   const uint8_t *__restrict__ okflag, const uint32_t *__restrict__ side, int kp) {
+    extern __shared__ uint32_t fin_lds[];
+    uint32_t *T = fin_lds;                                   // [64][kp][NL]: codeword t's factor of coefficient lo + i (plain, not Montgomery)
+    uint32_t *IC = T + (size_t)64 * kp * NL;                 // [64][NL]: 1 / cs
+    int32_t *DF = reinterpret_cast<int32_t *>(IC + 64 * NL); // [64]: df, or -2 for a codeword that did not decode
+    const int lane = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * 64 * GAO_FIN_G;
+    if (base >= C) return;
+    uint32_t pref[GAO_FIN_G][NL];            // pref[j] = w_0 ... w_j over the lane's decoded codewords (the others contribute 1)
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < GAO_FIN_G; j++) {
+        const int64_t c = base + (int64_t)j * 64 + lane;
+        uint32_t w[NL];
+        fp_set(w, P.one);
+        if (c < C && okflag[c]) {
+            uint32_t cs[NL], l[NL];
+            load_digits<NL, NW>(cs, side + (size_t)c * (2 * NW + 4));
+            load_digits<NL, NW>(l, side + (size_t)c * (2 * NW + 4) + NW);
+            mont_mul(w, cs, l, P);
+            any = true;
+        }
+        if (j == 0) fp_set(pref[0], w); else mont_mul(pref[j], pref[j - 1], w, P);
+    }
+    uint32_t run[NL];                        // 1 / (w_0 ... w_j) while codeword j is being finished
+    if (any) fp_inv(run, pref[GAO_FIN_G - 1], P); else fp_set(run, P.one);
+#pragma unroll
+    for (int j = GAO_FIN_G - 1; j >= 0; j--) {
+        const int64_t c = base + (int64_t)j * 64 + lane;
+        const bool live = c < C && okflag[c];
+        int df = -2, dq = -1;
+        uint32_t pw[NL], linv[NL];
+        if (live) {
+            uint32_t cs[NL], l[NL], w[NL], winv[NL], inv_c[NL];
+            load_digits<NL, NW>(cs, side + (size_t)c * (2 * NW + 4));
+            load_digits<NL, NW>(l, side + (size_t)c * (2 * NW + 4) + NW);
+            dq = (int)side[(size_t)c * (2 * NW + 4) + 2 * NW];
+            df = (int)side[(size_t)c * (2 * NW + 4) + 2 * NW + 1];
+            if (j > 0) mont_mul(winv, run, pref[j - 1], P); else fp_set(winv, run);
+            mont_mul(w, cs, l, P);
+            mont_mul(run, run, w, P);
+            mont_mul(inv_c, winv, l, P);               // 1 / cs
+            mont_mul(linv, winv, cs, P);               // 1 / l
+            uint32_t inv_c_plain[NL];
+            from_mont(inv_c_plain, inv_c, P);          // out of Montgomery form: (u R) b / R = u b, canonical
+            from_mont(pw, linv, P);
+#pragma unroll
+            for (int q = 0; q < NL; q++) IC[lane * NL + q] = inv_c_plain[q];
+            // the chain runs i = dq .. 0, the power of 1 / l growing by one per step: the steps above the table's reach first
+            for (int i = dq; i >= k; i--) mont_mul(pw, pw, linv, P);
+        }
+        DF[lane] = df;
+        const int64_t c0 = base + (int64_t)j * 64;
+        const int cnt = (int)min((int64_t)64, C - c0);
+        // the coefficients in parts of kp (the factor table of a whole codeword slice does not leave room for four workgroups a CU, and the
+        // inversion's latency wants them all resident): coefficients [lo, hi) from the top, the chain continuing from part to part
+        for (int hi = k; hi > 0; hi -= kp) {
+            const int lo = max(hi - kp, 0);
+            if (live) {
+                for (int i = min(hi - 1, dq); i >= lo; i--) {
+                    if (i <= df) {
+#pragma unroll
+                        for (int q = 0; q < NL; q++) T[((size_t)lane * kp + (i - lo)) * NL + q] = pw[q];
+                    }
+                    if (i > 0) mont_mul(pw, pw, linv, P);
+                }
+            }
+            __syncthreads();
+            const int wdt = hi - lo;
+            for (int e = lane; e < cnt * wdt; e += 64) {
+                const int t = e / wdt, i = lo + (e - t * wdt);
+                if (i <= DF[t]) {
+                    uint32_t u[NL], f[NL], fac[NL];
+                    load_digits<NL, NW>(u, coeffs + (((size_t)c0 + t) * k + i) * NW);
+#pragma unroll
+                    for (int q = 0; q < NL; q++) fac[q] = T[((size_t)t * kp + (i - lo)) * NL + q];
+                    mont_mul(f, u, fac, P);
+                    store_digits<NL, NW>(coeffs + (((size_t)c0 + t) * k + i) * NW, f);
+                }
+            }
+            __syncthreads();
+        }
+        if (errloc) {
+            const int W = npts + 1;
+            for (int e = lane; e < cnt * W; e += 64) {
+                const int t = e / W, i = e - t * W;
+                if (DF[t] != -2 && i < errlen[c0 + t]) {
+                    uint32_t u[NL], f[NL], fac[NL];
+                    load_digits<NL, NW>(u, errloc + ((size_t)c0 * W + e) * NW);
+#pragma unroll
+                    for (int q = 0; q < NL; q++) fac[q] = IC[t * NL + q];
+                    mont_mul(f, u, fac, P);
+                    store_digits<NL, NW>(errloc + ((size_t)c0 * W + e) * NW, f);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// The walk of rounds 3-4 (one lane per GAO_FIN_G consecutive codewords, every element visited in place by its codeword's lane): kept for message
+// lengths whose factor table does not fit the LDS (k > 66 at 32-byte elements).
+template <int NL, int NW>
+__global__ void __launch_bounds__(64) k_gao_finish_walk(const FpParams<NL> P, int npts, int k, int64_t C, uint32_t *__restrict__ coeffs,
                                                    uint32_t *__restrict__ errloc, const int32_t *__restrict__ errlen,
                                                    const uint8_t *__restrict__ okflag, const uint32_t *__restrict__ side) {
     const int64_t base = ((int64_t)blockIdx.x * 64 + threadIdx.x) * GAO_FIN_G;
@@ -559,8 +668,11 @@ extern "C" int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int 
 
 // errloc_dev == nullptr: the error locators are not written (nor scaled by the finishing kernel), their lengths are -- what
 // hb_wb_decode's pre-pass needs of them (3.3 KB of HBM traffic per codeword at config 4 and a third of the finisher's work)
+// sel_host != nullptr: the codewords lie in rows of ys_stride symbols and symbol i of a word is its column sel_host[i] (a batch whose codewords
+// all lost the SAME symbols: the reference drops the erasures and decodes over the points that are left, hbmpc_ntl_helpers.pyx:399-403,
+// reed_solomon.py:201-204 -- here the interpolant's launch simply reads the surviving columns in place)
 int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const uint64_t *ys_dev, int64_t C,
-                   uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream) { HB_API_GUARD(ctx);
+                   uint64_t *coeffs_dev, uint64_t *errloc_dev, int32_t *errloc_len_dev, uint8_t *ok_dev, void *stream, int ys_stride, const int32_t *sel_host) { HB_API_GUARD(ctx);
     if (!ctx || !x_host || npts < 1 || k < 0 || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0) return HB_OK;
     if (!ys_dev || !coeffs_dev || !errloc_len_dev || !ok_dev) return HB_ERR_BAD_ARG;
@@ -605,8 +717,10 @@ int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const u
     // (g1 and the side records are context scratch -- ctx_scratch, hb_common.hpp: this call holds the context's mutex and synchronises before it returns)
     uint32_t *g1 = nullptr;
     rc = ctx_scratch(ctx, "gao.g1", (size_t)npts * C * ctx->elem_words() * 4, (void **)&g1); if (rc) return rc;
-    hb_view iv{npts, 1}, ov{npts, 1};
-    rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, nullptr, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
+    hb_view iv{sel_host ? ys_stride : npts, 1}, ov{npts, 1};
+    int32_t *sel_dev = nullptr;
+    if (sel_host) { rc = get_int_array(ctx, sel_host, npts, &sel_dev, s); if (rc) return rc; }
+    rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, sel_dev, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }          // (nothing of this call may still be writing the scratch when the next one starts)
     size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 8) * NLr * 4;      // R0, R1, T0, T1, a zero element, three multipliers, -X, c0, c1, K
     // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one
@@ -614,7 +728,12 @@ int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const u
     const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
     rc = ctx_scratch(ctx, "gao.side", (size_t)C * side_words * 4, (void **)&side);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }
-    const unsigned fin_blocks = (unsigned)(((C + GAO_FIN_G - 1) / GAO_FIN_G + 63) / 64);
+    const unsigned fin_blocks = (unsigned)((C + 64 * GAO_FIN_G - 1) / (64 * GAO_FIN_G));
+    // the finisher's factor table: kp coefficients of 64 codewords at a time, sized so that four workgroups share a CU's LDS
+    const int kp = std::max(1, std::min(k, (int)((28 * 1024 - 64 * NLr * 4 - 256) / (64 * NLr * 4))));
+    const size_t fin_lds = ((size_t)64 * kp * NLr + 64 * NLr + 64) * 4;
+    const bool fin_walk = false;
+    const unsigned walk_blocks = (unsigned)(((C + GAO_FIN_G - 1) / GAO_FIN_G + 63) / 64);
     // K = p 2^j with 29 (NL - 1) + 27 bits, in redundant radix-2^29 digits (GaoConsts): a unit of every digit above the lowest lent to the digit below
     uint32_t kd[9];
     {
@@ -642,14 +761,18 @@ int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const u
         GaoConsts<9> gk;
         memcpy(gk.kd, kd, sizeof gk.kd);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (!fin_walk) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao_finish<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
         k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
-        k_gao_finish<9, 8><<<fin_blocks, 64, 0, s>>>(ctx->pw, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
+        if (fin_walk) k_gao_finish_walk<9, 8><<<walk_blocks, 64, 0, s>>>(ctx->pw, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
+        else k_gao_finish<9, 8><<<fin_blocks, 64, fin_lds, s>>>(ctx->pw, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, kp);
     } else {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (!fin_walk) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao_finish<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
         GaoConsts<3> gk;
         memcpy(gk.kd, kd, sizeof gk.kd);
         k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
-        k_gao_finish<3, 2><<<fin_blocks, 64, 0, s>>>(ctx->pn, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
+        if (fin_walk) k_gao_finish_walk<3, 2><<<walk_blocks, 64, 0, s>>>(ctx->pn, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
+        else k_gao_finish<3, 2><<<fin_blocks, 64, fin_lds, s>>>(ctx->pn, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, kp);
     }
     const hipError_t le = hipGetLastError();
     const hipError_t se = hipStreamSynchronize(s);

@@ -349,10 +349,13 @@ __global__ void k_points_to_mont(const FpParams<NL> P, const uint32_t *__restric
 
 }  // namespace
 
-// any erasure in the batch?
-__global__ void k_wb_any_erasure(const uint8_t *__restrict__ present, int64_t total, int32_t *__restrict__ flag) {
+// any erasure in the batch (bit 0)?  does some codeword's pattern differ from the first one's (bit 1)?
+__global__ void k_wb_erasure_pattern(const uint8_t *__restrict__ present, int64_t total, int n, int32_t *__restrict__ flag) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total && present[i] == 0) atomicOr(flag, 1);
+    if (i >= total) return;
+    const bool here = present[i] != 0, first = present[i % n] != 0;
+    int bits = (here ? 0 : 1) | (here != first ? 2 : 0);
+    if (bits && (*reinterpret_cast<volatile int32_t *>(flag) & bits) != bits) atomicOr(flag, bits);
 }
 // Gao's coefficient rows -> the reference's outcome for the codewords it decoded WITHIN THE RADIUS: status 0 and the length after
 // stripping trailing zeros (polynomial.py:14-20); the others are left to k_wb.  Gao's acceptance alone is not enough: a message of
@@ -407,7 +410,10 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
     // (SURVEY appendix C): a codeword with at most floor((n' - k) / 2) errors is decoded by the Gao kernel (hb_gao.hip),
     // three orders of magnitude cheaper than an (n+1) x (2e+k+2) elimination, and only what it rejects -- where the
     // reference's particular solution, its descending-e' loop and its two failure messages matter -- goes through the
-    // row reduction below.  Batches with erasures (per-codeword point sets) take the row reduction throughout.
+    // row reduction below.  A batch whose codewords all lost the SAME symbols -- the protocol's case: the erasures are the parties that have
+    // not arrived, one set for the whole batch (reed_solomon.py:201-204) -- is a batch over the points that are left: Gao's kernels on the
+    // reduced point set (the interpolant's launch reads the surviving columns in place), radius floor((n' - k) / 2).  Only per-codeword
+    // erasure patterns take the row reduction throughout (round 4: any erasure did -- 72 k codewords/s where the kernels do millions).
     uint8_t *gao_ok = nullptr;
     int32_t *todo = nullptr;
     int64_t rejected = C;                            // codewords the row reduction still has to look at
@@ -415,20 +421,35 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
         int32_t erased = 0;
         HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, 2 * sizeof(int32_t), s));
         const int64_t tot = C * n;
-        k_wb_any_erasure<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(present_dev, tot, ctx->flag_dev);
+        k_wb_erasure_pattern<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(present_dev, tot, n, ctx->flag_dev);
         HB_LAUNCH_CHECK(ctx);
         HB_HIP(ctx, hipMemcpyAsync(&erased, ctx->flag_dev, sizeof erased, hipMemcpyDeviceToHost, s));
         HB_HIP(ctx, hipStreamSynchronize(s));
+        // the shared pattern, if there is one: the points that are left, in party order (as the reference enumerates them)
+        std::vector<int32_t> sel;
+        std::vector<uint64_t> xsel;
+        int ns = n;
+        if (erased == 1 && !getenv("HB_WB_NO_UNIFORM")) {
+            std::vector<uint8_t> pat((size_t)n);
+            HB_HIP(ctx, hipMemcpyAsync(pat.data(), present_dev, (size_t)n, hipMemcpyDeviceToHost, s));
+            HB_HIP(ctx, hipStreamSynchronize(s));
+            for (int i = 0; i < n; i++)
+                if (pat[i]) { sel.push_back(i); for (int q = 0; q < ctx->n_limbs; q++) xsel.push_back(x_host[(size_t)i * ctx->n_limbs + q]); }
+            ns = (int)sel.size();
+            if (ns - k < 1 || 2 * (k - 1) + 1 > ns) { sel.clear(); ns = n; erased = 3; }          // too few points left: the row reduction's refusals
+            else erased = 0;
+        }
         if (!erased) {
             int32_t *errlen = nullptr;
             // (context scratch, reused by the next call -- ctx_scratch, hb_common.hpp)
             rc = ctx_scratch(ctx, "wb.gao_ok", (size_t)C, (void **)&gao_ok); if (rc) return rc;
             rc = ctx_scratch(ctx, "wb.errlen", (size_t)C * sizeof(int32_t), (void **)&errlen); if (rc) return rc;
             rc = ctx_scratch(ctx, "wb.todo", (size_t)C * sizeof(int32_t), (void **)&todo); if (rc) return rc;
-            rc = hb::gao_decode(ctx, x_host, n, k, ys_dev, C, coeffs_dev, nullptr, errlen, gao_ok, stream);      // (the locators' lengths, not the locators)
+            if (sel.empty()) rc = hb::gao_decode(ctx, x_host, n, k, ys_dev, C, coeffs_dev, nullptr, errlen, gao_ok, stream);      // (the locators' lengths, not the locators)
+            else rc = hb::gao_decode(ctx, xsel.data(), ns, k, ys_dev, C, coeffs_dev, nullptr, errlen, gao_ok, stream, n, sel.data());
             if (rc) return rc;
-            if (ctx->n_limbs == 4) k_wb_take_gao<8><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (n - k) / 2, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
-            else k_wb_take_gao<2><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (n - k) / 2, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
+            if (ctx->n_limbs == 4) k_wb_take_gao<8><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (ns - k) / 2, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
+            else k_wb_take_gao<2><<<(unsigned)((C + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (ns - k) / 2, (const uint32_t *)coeffs_dev, k, C, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
             HB_LAUNCH_CHECK(ctx);
             int32_t rej = 0;
             HB_HIP(ctx, hipMemcpyAsync(&rej, ctx->flag_dev + 1, sizeof rej, hipMemcpyDeviceToHost, s));

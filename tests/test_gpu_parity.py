@@ -932,3 +932,50 @@ def test_gao_cofactor_pinned_by_the_references_polynomial_class(hip, golden):
         got = hip.gao_interpolate_batch(list(x), [c["y"] for c in cs], k, P)
         for g, c in zip(got, cs):
             assert tuple(g) == ((c["coeffs"], c["v"]) if c["coeffs"] is not None else (None, None)), (c["kind"], k)
+
+
+@pytest.mark.parametrize("p,n,k,words", [(P, 100, 34, 6), (P, 64, 22, 8), (P, 25, 4, 40), (53, 22, 8, 60), (13, 12, 3, 40), ((1 << 64) - 59, 40, 10, 24)])
+def test_wb_batches_with_one_erasure_pattern_vs_oracle(p, n, k, words):
+    """A batch whose codewords all lost the SAME symbols (the protocol's case: the parties that have not arrived, reed_solomon.py:201-204) is
+    decoded by Gao's kernels over the points that are left; whatever they do not settle -- beyond the radius of the REDUCED word, too few
+    points, low-degree messages -- keeps the row reduction's outcomes.  Against the oracle's restatement of the reference's decoder, with the
+    structured messages of tests/structured.py, errors up to and beyond the reduced radius, coordinated liars; and against a batch with
+    per-codeword patterns (the row reduction throughout)."""
+    from structured import coordinated_errors, structured_message
+
+    from honeybadgermpc_amd.device import wb_decode_batch
+
+    rnd = random.Random(n * 131 + k)
+    x = list(range(1, n + 1))
+    cmax = n - 2 * (k - 1) - 1                       # erasures the reference's decoder admits (reed_solomon_wb.py:131)
+    for trial in range(4):
+        c = [1, max(1, cmax // 2), cmax, min(n - k, cmax + 2)][trial] if cmax > 0 else 0
+        if c <= 0:
+            continue
+        erased = rnd.sample(range(n), c)
+        emax = max(0, (n - c - k) // 2)
+        rows = []
+        for w in range(words):
+            msg = structured_message(rnd, k, p)
+            enc = oracle.vandermonde_batch_evaluate(x, [msg], p)[0]
+            ne = min(n - c, [0, emax, emax // 2, emax + 1, emax + 2, 1][w % 6])
+            alive = [i for i in range(n) if i not in erased]
+            if w % 4 == 3:
+                other = coordinated_errors(rnd, enc, x, k, 0, p, lambda xs, cf: oracle.vandermonde_batch_evaluate(xs, [cf], p)[0])[0]
+                liar_vals = oracle.vandermonde_batch_evaluate(x, [[rnd.randrange(p) for _ in range(k)]], p)[0]
+                for i in rnd.sample(alive, ne):
+                    other[i] = liar_vals[i]
+                enc = other
+            else:
+                for i in rnd.sample(alive, ne):
+                    enc[i] = (enc[i] + rnd.randrange(1, p)) % p
+            rows.append([None if i in erased else enc[i] for i in range(n)])
+        got = wb_decode_batch(x, k, rows, p)
+        want = oracle.wb_decode_batch(x, k, rows, p)
+        assert got == want, (trial, c, next(i for i in range(words) if got[i] != want[i]))
+        # the same words with ONE codeword losing another symbol: no shared pattern, the row reduction decides everything -- same outcomes
+        if n - c - 1 >= k:
+            mixed = [list(r) for r in rows]
+            extra = next(i for i in range(n) if mixed[0][i] is not None)
+            mixed[0][extra] = None
+            assert wb_decode_batch(x, k, mixed, p)[1:] == want[1:]
