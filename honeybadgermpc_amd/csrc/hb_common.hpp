@@ -261,6 +261,10 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
 // borrowed buffers; first_bad_dev (CHECK mode, optional): atomicMin of the first chunk whose compare failed
 // the fold of a sum's high bytes on the matrix cores (hb_mfma_wide.hip): table rows of 272 bytes, eight per 16 bytes of H
 bool fold_tables(hb_ctx *ctx, int n_bytes, uint8_t *fold, uint32_t *top8, uint32_t *mu, uint32_t *shift8);
+// completion signal of a launch whose caller waits for the verdict: a device counter of finished workgroups, the pinned (device-visible)
+// record the last one fills in, the sequence number it writes last
+struct FsVerdict { int32_t flag, first, seq, pad; };
+struct FsDone { int32_t *counter; FsVerdict *host; int32_t seq; };
 struct Mm8wShared { uint32_t bias; uint32_t c80r[9], biasmod[9]; void *wp; uint32_t *zero; };
 int mm8w_geometry(int n_out, int d, int *tile_rows, int *n_rt, int *nkb, size_t *a8_bytes, size_t *crow_words);
 int mm8w_shared(hb_ctx *ctx, int d, const Mm8wShared **out, hipStream_t s);
@@ -268,7 +272,7 @@ void mm8w_shared_free(hb_ctx *ctx);
 int launch_mm8w_raw(hb_ctx *ctx, int n_out, int d, int tile_rows, const void *a8, const uint32_t *crow, const Mm8wShared *sh,
                     const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *out, hb_view ov, int64_t out_count,
                     const int32_t *check_mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store,
-                    int32_t *first_bad_dev, uint32_t *bad_map_dev = nullptr);
+                    int32_t *first_bad_dev, uint32_t *bad_map_dev = nullptr, const FsDone *done = nullptr);
 void point_tables_free(hb_ctx *ctx);
 void mm8_shared_free(hb_ctx *ctx);
 // per point set: x (Montgomery digits), the powers x_a^i and 1 / (x_a - x_b); for sets of small integers also their values
@@ -286,12 +290,19 @@ int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hi
 struct QuickLayout {
     int n, d, nc, n_coef, n_out, tile_rows, nkb;
     size_t o_a8, o_crow, o_wj, o_full, o_nraw, o_mcan, o_z, o_map, need;
+    // a decoder's image in two halves keeps, per PARTY, the row it would contribute as a compared sender (built with the first half, from the
+    // first degree + 1 arrivals alone): o_cand = the rows' digit pieces [n][nkb * 16] x 16 B, o_cand_crow = their row constants [n][16 words];
+    // 0 = no candidate store (more than 256 parties, nothing to compare)
+    size_t o_cand, o_cand_crow;
 };
 int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L);
 int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s,
-                int flags = 3 /* 1: what depends on z alone, 2: the compared senders' rows */);
+                int flags = 3 /* 1: what depends on z alone, 2: the compared senders' rows; 1 | 4: ... and a candidate row for every party, 2 | 4: the
+                                 compared senders' rows picked from that store */);
+int quick_layout_cand(hb_ctx *ctx, QuickLayout *L);      // add the candidate store to a layout (HB_OK, or HB_ERR_UNSUPPORTED: the layout stays as it was)
 int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const Mm8wShared *sh, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov,
-                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s, uint32_t *bad_map_dev = nullptr);
+                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s, uint32_t *bad_map_dev = nullptr,
+                 const FsDone *done = nullptr);
 // decode + validate at small-integer points on the small-entry kernel with the 1 / den_j scaling inside (hb_mfma_fused.hip):
 // layout of one image's buffer (HB_ERR_UNSUPPORTED when the shape / point set / modulus does not qualify), its build in one or two
 // halves (what depends on the arrivals z alone; the rows of the compared senders zc), its launch
@@ -304,8 +315,6 @@ int fs_layout(hb_ctx *ctx, const PointTable *pt, int d, int nc, int n_coef, FsLa
 int fs_build(hb_ctx *ctx, const PointTable *pt, const int32_t *z, const int32_t *zc, const FsLayout &L, uint8_t *base, int flags, int32_t *status_dev, hipStream_t s);
 // completion signal of a launch whose caller waits for the verdict: a device counter of finished workgroups, the pinned (device-visible)
 // record the last one fills in, the sequence number it writes last
-struct FsVerdict { int32_t flag, first, seq, pad; };
-struct FsDone { int32_t *counter; FsVerdict *host; int32_t seq; };
 int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov, int64_t out_count,
               int32_t *mismatch_dev, int32_t *first_bad_dev, uint32_t *bad_map_dev, int64_t C, hipStream_t s, const FsDone *done = nullptr,
               const int32_t *pick_zc = nullptr);

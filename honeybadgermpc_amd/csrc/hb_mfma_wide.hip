@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
                                                  const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
                                                  const uint32_t *__restrict__ cmp_pk, int64_t cmp_sc, int64_t cmp_sl, int mask_is_map, int n_store,
                                                  int n_out, int n_rt, int nkb, int tpw, int nbuf, int rq, int64_t n_chunks, int64_t n_units,
-                                                 uint32_t bias, const WideParams *__restrict__ wpp, int32_t *__restrict__ first_bad, uint32_t *__restrict__ bad_map) {
+                                                 uint32_t bias, const WideParams *__restrict__ wpp, int32_t *__restrict__ first_bad, uint32_t *__restrict__ bad_map,
+                                                 const FsDone done) {
     extern __shared__ uint4 mm8w_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 15, g = lane >> 4;
@@ -317,6 +318,26 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
 #ifdef HB_MM8_TIMING
     if (lane == 0 && blockIdx.x < 256) for (int k = 0; k < 8; k++) g_mm8w_t[(blockIdx.x * 4 + wave) * 8 + k] = tacc[k];
 #endif
+    // a caller that waits for the verdict (hb_quick_dec_decide at points that are not small integers): the last workgroup to finish hands the
+    // status words to pinned host memory and resets them, the sequence number last -- as k_mm8f does (a one-thread kernel behind this launch
+    // did it until round 5: a dispatch and its gap on the path of every first-sight decode)
+    if constexpr (CHECK) {
+        if (done.counter) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
+                    const int32_t fl = mismatch ? atomicExch(mismatch, 0) : 0;
+                    const int32_t fb = first_bad ? atomicExch(first_bad, INT32_MAX) : INT32_MAX;
+                    atomicExch(done.counter, 0);
+                    done.host->flag = fl;
+                    done.host->first = fb;
+                    __threadfence_system();
+                    *reinterpret_cast<volatile int32_t *>(&done.host->seq) = done.seq;
+                }
+            }
+        }
+    }
 }
 
 }  // namespace hb
@@ -636,7 +657,8 @@ int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8
 // result, stored to out when i < n_store): the fused decode + validate of hb_open.hip
 static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                             uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev, uint32_t *bad_map_dev);
+                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev, uint32_t *bad_map_dev,
+                            const FsDone *done_p = nullptr);
 
 int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                 uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
@@ -646,8 +668,12 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
 
 static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count,
                             uint32_t *out, hb_view ov, int64_t out_count, const int32_t *check_mask_dev, int32_t *mismatch_dev,
-                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev, uint32_t *bad_map_dev) {
+                            int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store, int32_t *first_bad_dev, uint32_t *bad_map_dev,
+                            const FsDone *done_p) {
     if (C <= 0) return HB_OK;
+    FsDone done;
+    memset(&done, 0, sizeof done);
+    if (done_p) done = *done_p;
     int tpw = 1, nbuf = 1, rq = m->n_rt;
     const int64_t n_tiles = (C + 15) / 16;
     if (m->shape_tiles == n_tiles) { tpw = m->shape_tpw; nbuf = m->shape_nbuf; rq = m->shape_rq; }
@@ -678,7 +704,7 @@ static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in
         hipLaunchKernelGGL((k_mm8w<CHK, PL, KK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \
                            cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
-                           m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp, first_bad_dev, bad_map_dev);            \
+                           m->n_out, m->n_rt, m->nkb, tpw, nbuf, rq, C, n_units, m->bias, m->wp, first_bad_dev, bad_map_dev, done);      \
     } while (0)
     // K-blocks written out with a share of the reduction each (gen_mm8w.py); the rest is a loop of two-block bodies
     const int peel = m->nkb <= 2 ? m->nkb : ((m->nkb & 1) ? 3 : 4);
@@ -774,12 +800,12 @@ void mm8w_shared_free(hb_ctx *ctx) {
 int launch_mm8w_raw(hb_ctx *ctx, int n_out, int d, int tile_rows, const void *a8, const uint32_t *crow, const Mm8wShared *sh,
                     const uint32_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint32_t *out, hb_view ov, int64_t out_count,
                     const int32_t *check_mask_dev, int32_t *mismatch_dev, int64_t C, hipStream_t s, const uint32_t *cmp, hb_view cv, int n_store,
-                    int32_t *first_bad_dev, uint32_t *bad_map_dev) {
+                    int32_t *first_bad_dev, uint32_t *bad_map_dev, const FsDone *done) {
     Mm8wMatrix m;
     m.n_out = n_out; m.d = d; m.nkb = (d + 7) / 8; m.tile_rows = tile_rows; m.n_rt = (n_out + tile_rows - 1) / tile_rows;
     m.shape_tiles = -1; m.shape_tpw = m.shape_nbuf = m.shape_rq = 0;
     m.a8 = (int4 *)const_cast<void *>(a8); m.crow = const_cast<uint32_t *>(crow); m.zero = sh->zero; m.bias = sh->bias; m.wp = (WideParams *)sh->wp;
-    return launch_mm8w_impl(ctx, &m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, first_bad_dev, bad_map_dev);
+    return launch_mm8w_impl(ctx, &m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, first_bad_dev, bad_map_dev, done);
 }
 
 }  // namespace hb

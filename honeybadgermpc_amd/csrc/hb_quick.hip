@@ -118,7 +118,8 @@ constexpr int QM_NT = 1024, QM_SEG = 8, QM_FSEG = 4, QM_TS = 4;     // k_quick_m
 template <int NL>
 __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ inv, int n,
                                                       const QuickIdx ix, int d, int nc, int n_coef, uint32_t *__restrict__ wj, uint32_t *__restrict__ full,
-                                                      uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap, int flags) {
+                                                      uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap, int flags,
+                                                      uint4 *__restrict__ zero_base, int zero_q, uint4 *__restrict__ zero2_base, int zero2_q) {
     // Three workgroups, each a set of SHORT chains of dependent multiplications (rounds 3 and 4 ran one workgroup of d-step chains: A(X) by
     // d sequential multiplications by (X - x_q) with two barriers each, then d-step Horner / product chains per thread -- 177 us at d = 86):
     //   block 0: A(X) = prod (X - x_q) by a PRODUCT TREE in LDS (log2 d levels; a level multiplies adjacent monic polynomials, one output
@@ -128,14 +129,55 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
     //   block 2: full_i = prod_q (x_i - x_q) for the compared senders, QM_FSEG partial products each; the row map.
     // flags: QUICK_Z -- what depends on the arrivals z alone (A, the N_j, the w_j, the row map of the coefficient rows); QUICK_ZC -- the
     // compared senders' full_i and their rows of the map.  A decoder builds the first half when its (degree+1)-th column lands.
+    //   block 3 (first half only): the image and the row constants start from zero (padding rows and terms) -- a hipMemsetAsync before the
+    //            launch cost a dispatch of its own (5 us on the path of a first-sight decode).
+    // flags & 4 (with QUICK_Z): block 2 computes full_i for EVERY party (a decoder's candidate store: k_quick_fill makes a row of each), not
+    // for the compared senders, who are not known yet.
     extern __shared__ uint32_t q_lds[];
     const int tid = threadIdx.x;
-    const bool do_z = flags & 1, do_zc = flags & 2;
+    const bool do_z = flags & 1, do_zc = flags & 2, do_cand = flags & 4;
     uint32_t *xz = q_lds;                               // [d][NL]: the arrivals' points (every block's chains read them)
+    if (blockIdx.x == 3) {
+        for (int i = tid; i < zero_q; i += QM_NT) zero_base[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < zero2_q; i += QM_NT) zero2_base[i] = make_uint4(0, 0, 0, 0);      // (the candidate rows' padding terms: d .. 8 nkb - 1)
+        return;
+    }
     if (blockIdx.x == 0 && !do_z) return;
     if (blockIdx.x == 1 && !do_z) return;
     for (int e = tid; e < d * NL; e += QM_NT) xz[e] = xm[(size_t)ix.z[e / NL] * NL + e % NL];
     __syncthreads();
+    if (blockIdx.x == 0 && n_coef == 1) {
+        // only the constant terms are wanted (what R1 forwards): N_j[0] = prod_{q != j} (-x_q), QM_SEG partial products a row and their
+        // join -- no A(X), no Horner (a third of the chain)
+        uint32_t *Wp = xz + (size_t)d * NL;                                   // [d][QM_SEG][NL]
+        const int Ls = (d + QM_SEG - 1) / QM_SEG;
+        const int j = tid / QM_SEG, g = tid % QM_SEG;
+        if (j < d) {
+            const int lo = g * Ls, hi = min((g + 1) * Ls, d);
+            uint32_t w[NL];
+            fp_set(w, P.one);
+            for (int q = lo; q < hi; q++) {
+                if (q == j) continue;
+                uint32_t x[NL], nx[NL];
+                ldg<NL>(x, xz + (size_t)q * NL);
+                fp_neg(nx, x, P);
+                mont_mul(w, w, nx, P);
+            }
+            stg<NL>(Wp + ((size_t)j * QM_SEG + g) * NL, w);
+        }
+        __syncthreads();
+        if (j < d && g == 0) {
+            uint32_t w[NL];
+            ldg<NL>(w, Wp + (size_t)j * QM_SEG * NL);
+            for (int g2 = 1; g2 < QM_SEG; g2++) {
+                uint32_t f[NL];
+                ldg<NL>(f, Wp + ((size_t)j * QM_SEG + g2) * NL);
+                mont_mul(w, w, f, P);
+            }
+            stg<NL>(nraw + (size_t)j * NL, w);
+        }
+        return;
+    }
     if (blockIdx.x == 0) {
         uint32_t *B0 = xz + (size_t)d * NL, *B1 = B0 + (size_t)d * NL;      // [d][NL] each: the level's monic polynomials without their leading 1
         uint32_t *Ac = B1 + (size_t)d * NL;                                   // [d + 1][NL]
@@ -270,12 +312,13 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
         uint32_t *Fp = xz + (size_t)d * NL;                                   // [nc][QM_FSEG][NL]
         if (do_z) { for (int r = tid; r <= n_coef + nc; r += QM_NT) fmap[r] = (do_zc && r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0; }
         else { for (int r = tid; r < nc; r += QM_NT) fmap[n_coef + r] = (int32_t)ix.zc[r] + 1; }
-        if (!do_zc && do_z) return;
+        if (!do_zc && do_z && !do_cand) return;
+        const int rows = do_cand ? n : nc;                                  // (n QM_FSEG <= QM_NT where a candidate store exists)
         const int i = tid / QM_FSEG, g = tid % QM_FSEG, part = (d + QM_FSEG - 1) / QM_FSEG;
-        if (i < nc) {
+        if (i < rows) {
             const int lo = g * part, hi = min((g + 1) * part, d);
             uint32_t xi[NL], f[NL];
-            ldg<NL>(xi, xm + (size_t)ix.zc[i] * NL);
+            ldg<NL>(xi, xm + (size_t)(do_cand ? i : (int)ix.zc[i]) * NL);
             fp_set(f, P.one);
             for (int q = lo; q < hi; q++) {
                 uint32_t xq[NL], df[NL];
@@ -286,7 +329,7 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
             stg<NL>(Fp + ((size_t)i * QM_FSEG + g) * NL, f);
         }
         __syncthreads();
-        if (i < nc && g == 0) {
+        if (i < rows && g == 0) {
             uint32_t f[NL];
             ldg<NL>(f, Fp + (size_t)i * QM_FSEG * NL);
             for (int g2 = 1; g2 < QM_FSEG; g2++) {
@@ -361,6 +404,116 @@ __global__ void k_quick_rows(const FpParams<9> P, const uint32_t *__restrict__ m
     uint32_t *dst = crow + ((size_t)(i / tile_rows) * 16 + i % tile_rows) * 16;
 #pragma unroll
     for (int q = 0; q < NL; q++) dst[q] = corr[q];
+}
+
+// A decoder's first half in ONE launch behind k_quick_matrix: block b < n_coef makes coefficient row b of the image (entry, canonical value, 32
+// balanced digits at their place, and the row's constant by a tree of additions over the block); block n_coef + i makes the row party i WOULD
+// contribute as a compared sender -- (V[i] V^-1)[l] = full_i w_l / (x_i - x_zl) -- into the candidate store: its digit pieces in image order and
+// its row constant.  Parties among the arrivals have no such row (they are never compared): their blocks leave at once.
+// (k_quick_image + k_quick_rows: two launches, the row constants one thread a row over d sequential loads: 33 us at d = 86.)
+constexpr int QF_NT = 128;
+__global__ void __launch_bounds__(QF_NT) k_quick_fill(const FpParams<9> P, const uint32_t *__restrict__ inv, int n, const QuickIdx ix, int d, int n_coef,
+                                                     const uint32_t *__restrict__ wj, const uint32_t *__restrict__ full, const uint32_t *__restrict__ nraw,
+                                                     uint8_t *__restrict__ a8, uint32_t *__restrict__ crow, int tile_rows, int nkb, const QuickRowConst rc,
+                                                     uint8_t *__restrict__ cand, uint32_t *__restrict__ cand_crow) {
+    constexpr int NL = 9, NW = 8;
+    __shared__ uint32_t red[QF_NT][NL];
+    __shared__ int among;
+    const int b = blockIdx.x, l = threadIdx.x;
+    const bool coef = b < n_coef;
+    const int party = b - n_coef;
+    if (!coef) {
+        if (l == 0) among = 0;
+        __syncthreads();
+        if (l < d && ix.z[l] == party) among = 1;
+        __syncthreads();
+        if (among) return;
+    }
+    uint32_t cd[NL];
+#pragma unroll
+    for (int q = 0; q < NL; q++) cd[q] = 0;
+    if (l < d) {
+        uint32_t w[NL], v[NL];
+        ldg<NL>(w, wj + (size_t)l * NL);
+        if (coef) {
+            uint32_t c[NL];
+            ldg<NL>(c, nraw + ((size_t)b * d + l) * NL);
+            mont_mul(v, c, w, P);
+        } else {
+            uint32_t f[NL], g[NL], t[NL];
+            ldg<NL>(f, full + (size_t)party * NL);
+            ldg<NL>(g, inv + ((size_t)party * n + ix.z[l]) * NL);
+            mont_mul(t, f, g, P);
+            mont_mul(v, t, w, P);
+        }
+        uint32_t cw[NW];
+        from_mont(cd, v, P);
+        pack<NL, NW>(cw, cd);
+        const int kb = l / 8, g = (l % 8) / 2, el = l & 1;
+        // where the row's 16-byte piece (kb, grp, g) lies: in the image at lane position r + 16 g of its row tile, in the store at piece index
+        size_t base4[4];
+        if (coef) {
+            const int rt = b / tile_rows, j16 = b % tile_rows, r = 4 * (j16 % 4) + j16 / 4;
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) base4[grp] = ((((size_t)rt * nkb + kb) * 4 + grp) * 64 + (size_t)(r + 16 * g)) * 16;
+        } else {
+#pragma unroll
+            for (int grp = 0; grp < 4; grp++) base4[grp] = ((size_t)party * nkb * 16 + (size_t)((kb * 4 + grp) * 4 + g)) * 16;
+        }
+        uint8_t *dst = coef ? a8 : cand;
+        int carry = 0;
+#pragma unroll
+        for (int bb = 0; bb < 32; bb++) {
+            int tt = (int)((cw[bb >> 2] >> (8 * (bb & 3))) & 0xffu) + carry;
+            if (tt > 127) { tt -= 256; carry = 1; } else carry = 0;
+            const int grp = bb >> 3, r7 = 7 - (bb & 7), hi = r7 >> 2, bi = r7 & 3;
+            dst[base4[grp] + 4 * (2 * hi + el) + bi] = (uint8_t)(int8_t)tt;
+        }
+    }
+    // the row constant: (0x80..80 * sum_l M[l] - bias * sum_c 2^(8c)) mod p -- the sum over the block by halving
+#pragma unroll
+    for (int q = 0; q < NL; q++) red[l][q] = cd[q];
+    __syncthreads();
+    for (int half = QF_NT / 2; half >= 1; half >>= 1) {
+        if (l < half) {
+            uint32_t a[NL], c[NL];
+#pragma unroll
+            for (int q = 0; q < NL; q++) { a[q] = red[l][q]; c[q] = red[l + half][q]; }
+            fp_add(a, a, c, P);
+#pragma unroll
+            for (int q = 0; q < NL; q++) red[l][q] = a[q];
+        }
+        __syncthreads();
+    }
+    if (l == 0) {
+        uint32_t sum[NL], k[NL], bm[NL], prod[NL], corr[NL];
+#pragma unroll
+        for (int q = 0; q < NL; q++) { sum[q] = red[0][q]; k[q] = rc.c80r[q]; bm[q] = rc.biasmod[q]; }
+        mont_mul(prod, sum, k, P);
+        fp_sub(corr, prod, bm, P);
+        uint32_t *dstc = coef ? crow + ((size_t)(b / tile_rows) * 16 + b % tile_rows) * 16 : cand_crow + (size_t)party * 16;
+#pragma unroll
+        for (int q = 0; q < NL; q++) dstc[q] = corr[q];
+    }
+}
+
+// ... and the second half: the rows of the senders that DID become compared ones, copied from the candidate store to rows n_coef .. of the
+// image, with their constants and their entries of the row map (one small launch behind the column that completes the quorum)
+__global__ void k_quick_pick(const QuickIdx ix, int nc, int n_coef, int tile_rows, int nkb, const uint4 *__restrict__ cand, const uint32_t *__restrict__ cand_crow,
+                             uint4 *__restrict__ a8, uint32_t *__restrict__ crow, int32_t *__restrict__ fmap) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = nkb * 16;
+    if (e < nc * per) {
+        const int j = e / per, pc = e - j * per;
+        const int i = n_coef + j, rt = i / tile_rows, j16 = i % tile_rows, r = 4 * (j16 % 4) + j16 / 4;
+        const int g = pc & 3, kg = pc >> 2;                 // kg = kb * 4 + grp
+        a8[((size_t)rt * nkb * 4 + kg) * 64 + (size_t)(r + 16 * g)] = cand[(size_t)ix.zc[j] * per + pc];
+    }
+    if (e < nc * 9) {
+        const int j = e / 9, q = e - j * 9, i = n_coef + j;
+        crow[((size_t)(i / tile_rows) * 16 + i % tile_rows) * 16 + q] = cand_crow[(size_t)ix.zc[j] * 16 + q];
+    }
+    if (e < nc) fmap[n_coef + e] = (int32_t)ix.zc[e] + 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -810,13 +963,26 @@ int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L) 
     L->o_a8 = 0; L->o_crow = L->o_a8 + al(a8_bytes); L->o_wj = L->o_crow + al(crow_words * 4); L->o_full = L->o_wj + al((size_t)d * 36);
     L->o_nraw = L->o_full + al((size_t)(nc ? nc : 1) * 36); L->o_mcan = L->o_nraw + al((size_t)n_coef * d * 36);
     L->o_z = L->o_mcan + al((size_t)L->n_out * d * 32); L->o_map = L->o_z + al((size_t)d * 4); L->need = L->o_map + al((size_t)(L->n_out + 2) * 4);
+    L->o_cand = L->o_cand_crow = 0;
     return HB_OK;
 }
 
-// enqueue the build of that image into `base` (L.need bytes, the caller's): a memset and three small kernels, nothing waited for
+int quick_layout_cand(hb_ctx *ctx, QuickLayout *L) {
+    (void)ctx;
+    if (L->nc < 1 || L->n * QM_FSEG > QM_NT || L->d > QF_NT || getenv("HB_QUICK_NO_CAND")) return HB_ERR_UNSUPPORTED;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    // full_i for every party takes the place of the compared senders' (o_full is sized for nc): moved to the end with the store
+    L->o_full = L->need;
+    L->o_cand = L->o_full + al((size_t)L->n * 36);
+    L->o_cand_crow = L->o_cand + al((size_t)L->n * L->nkb * 16 * 16);
+    L->need = L->o_cand_crow + al((size_t)L->n * 16 * 4);
+    return HB_OK;
+}
+
+// enqueue the build of that image into `base` (L.need bytes, the caller's): two to three small kernels, nothing waited for
 int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int32_t *zc, const QuickLayout &L, uint8_t *base, const Mm8wShared **shared, hipStream_t s, int flags) {
     const int n = L.n, d = L.d, nc = L.nc;
-    const bool do_z = flags & 1, do_zc = flags & 2;
+    const bool do_z = flags & 1, do_zc = flags & 2, cand = (flags & 4) && L.o_cand;
     std::vector<uint8_t> seen((size_t)n, 0);
     for (int i = 0; i < d; i++) { if (z[i] < 0 || z[i] >= n || seen[z[i]]) return fail(ctx, HB_ERR_BAD_ARG, "quick: arrival indices"); seen[z[i]] = 1; }
     if (do_zc)
@@ -827,23 +993,44 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
     const Mm8wShared *sh = nullptr;
     rc = mm8w_shared(ctx, d, &sh, s); if (rc) return rc;
     *shared = sh;
-    if (do_z) HB_HIP(ctx, hipMemsetAsync(base, 0, L.o_wj, s));          // image and row constants: padding rows / terms are zero
     QuickIdx ix;
     memset(&ix, 0, sizeof ix);
     for (int i = 0; i < d; i++) ix.z[i] = (uint16_t)z[i];
     if (do_zc) for (int j = 0; j < nc; j++) ix.zc[j] = (uint16_t)zc[j];
     uint32_t *wj = (uint32_t *)(base + L.o_wj), *full = (uint32_t *)(base + L.o_full), *nraw = (uint32_t *)(base + L.o_nraw), *mcan = (uint32_t *)(base + L.o_mcan);
+    QuickRowConst rcs;
+    memcpy(rcs.c80r, sh->c80r, sizeof rcs.c80r);
+    memcpy(rcs.biasmod, sh->biasmod, sizeof rcs.biasmod);
+    if (cand && do_zc && !do_z) {
+        // second half of a decoder with a candidate store: the compared senders' rows are there already
+        if (nc > 0) {
+            k_quick_pick<<<(unsigned)((nc * L.nkb * 16 + 255) / 256), 256, 0, s>>>(ix, nc, L.n_coef, L.tile_rows, L.nkb, (const uint4 *)(base + L.o_cand),
+                                                                                 (const uint32_t *)(base + L.o_cand_crow), (uint4 *)(base + L.o_a8), (uint32_t *)(base + L.o_crow),
+                                                                                 (int32_t *)(base + L.o_map));
+            HB_LAUNCH_CHECK(ctx);
+        }
+        return HB_OK;
+    }
     // the rows this call owns: the coefficient rows with the first half, the compared senders' rows with the second
     const int row_lo = do_z ? 0 : L.n_coef, row_hi = do_zc ? L.n_out : L.n_coef;
-    if (do_z || nc > 0)
-        k_quick_matrix<9><<<3, QM_NT, (size_t)std::max((4 + QM_SEG) * d + 1, d + QM_FSEG * nc) * 36, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z), (int32_t *)(base + L.o_map), flags);
+    const int frows = (cand && do_z) ? n : nc;                               // rows block 2 computes a full_i for
+    if (do_z || nc > 0) {
+        // (the image and the row constants are zeroed by the launch's fourth workgroup when it builds the first half: padding rows / terms)
+        const size_t lds = (size_t)std::max((4 + QM_SEG) * d + 1, d + QM_FSEG * frows) * 36;
+        k_quick_matrix<9><<<do_z ? 4 : 3, QM_NT, lds, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z),
+                                                          (int32_t *)(base + L.o_map), (flags & 3) | (cand && do_z ? 4 : 0), (uint4 *)base, (int)(L.o_wj / 16),
+                                                          (uint4 *)(base + L.o_cand), (cand && do_z) ? (int)((L.o_cand_crow - L.o_cand) / 16) : 0);
+    }
     HB_LAUNCH_CHECK(ctx);
+    if (cand && do_z) {
+        k_quick_fill<<<(unsigned)(L.n_coef + n), QF_NT, 0, s>>>(ctx->pw, pt->inv, n, ix, d, L.n_coef, wj, full, nraw, base + L.o_a8, (uint32_t *)(base + L.o_crow),
+                                                               L.tile_rows, L.nkb, rcs, base + L.o_cand, (uint32_t *)(base + L.o_cand_crow));
+        HB_LAUNCH_CHECK(ctx);
+        return HB_OK;
+    }
     if (row_hi > row_lo) {
         k_quick_image<<<(unsigned)(((row_hi - row_lo) * d + 255) / 256), 256, 0, s>>>(ctx->pw, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, mcan, base + L.o_a8, L.tile_rows, L.nkb, row_lo, row_hi);
         HB_LAUNCH_CHECK(ctx);
-        QuickRowConst rcs;
-        memcpy(rcs.c80r, sh->c80r, sizeof rcs.c80r);
-        memcpy(rcs.biasmod, sh->biasmod, sizeof rcs.biasmod);
         k_quick_rows<<<(unsigned)((row_hi - row_lo + 63) / 64), 64, 0, s>>>(ctx->pw, mcan, row_lo, row_hi, d, rcs, (uint32_t *)(base + L.o_crow), L.tile_rows);
         HB_LAUNCH_CHECK(ctx);
     }
@@ -853,11 +1040,12 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
 // the launch over a built image: n_store coefficient rows go to out (view ov, out_count elements), the compared rows (if any) are
 // checked against the rows of `cols` they belong to
 int quick_launch(hb_ctx *ctx, const QuickLayout &L, const uint8_t *base, const Mm8wShared *sh, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov,
-                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s, uint32_t *bad_map_dev) {
+                 int64_t out_count, int n_store, int32_t *mismatch_dev, int32_t *first_bad_dev, int64_t C, hipStream_t s, uint32_t *bad_map_dev, const FsDone *done) {
     const int32_t *fmap = (const int32_t *)(base + L.o_map);
     return launch_mm8w_raw(ctx, L.n_out, L.d, L.tile_rows, (const void *)(base + L.o_a8), (const uint32_t *)(base + L.o_crow), sh,
                            cols, cv, (const int32_t *)(base + L.o_z), INT64_MAX, out, ov, out_count,
-                           L.nc > 0 ? fmap : nullptr, mismatch_dev, C, s, cols, cv, n_store, L.nc > 0 ? first_bad_dev : nullptr, L.nc > 0 ? bad_map_dev : nullptr);
+                           L.nc > 0 ? fmap : nullptr, mismatch_dev, C, s, cols, cv, n_store, L.nc > 0 ? first_bad_dev : nullptr, L.nc > 0 ? bad_map_dev : nullptr,
+                           L.nc > 0 ? done : nullptr);
 }
 
 }  // namespace hb
@@ -1015,13 +1203,14 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
         QuickLayout Q;
         rc = quick_layout(ctx, qd->n, d, nc, n_coef, &Q);
         if (rc) return rc;
+        (void)quick_layout_cand(ctx, &Q);          // a row per party with the first half, where the point set allows it: nothing is built behind the last column
         if (qd->cap < Q.need) {
             if (qd->buf) { HB_HIP(ctx, hipStreamSynchronize(s)); HB_HIP(ctx, hipFree(qd->buf)); }
             qd->buf = nullptr; qd->cap = 0;
             HB_HIP(ctx, hipMalloc(&qd->buf, Q.need));
             qd->cap = Q.need;
         }
-        rc = quick_build(ctx, qd->x.data(), z, nullptr, Q, qd->buf, &qd->qsh, s, 1); if (rc) return rc;
+        rc = quick_build(ctx, qd->x.data(), z, nullptr, Q, qd->buf, &qd->qsh, s, 1 | 4); if (rc) return rc;
         qd->Q = Q;
         qd->wide = true;
         qd->z.assign(z, z + d);
@@ -1053,16 +1242,17 @@ static int quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const u
     if (qd->wide) {
         const QuickLayout &Q = qd->Q;
         int rc = HB_OK;
-        if (nc > 0) { rc = quick_build(ctx, qd->x.data(), qd->z.data(), zc, Q, qd->buf, &qd->qsh, s, 2); if (rc) return rc; }
+        if (nc > 0) { rc = quick_build(ctx, qd->x.data(), qd->z.data(), zc, Q, qd->buf, &qd->qsh, s, 2 | 4); if (rc) return rc; }
         const int64_t cnt = chunk_hi - chunk_lo;
         hb_view pm{1, C}, ov = Q.n_coef == 1 ? hb_view{1, C} : hb_view{Q.d, 1};
         const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
         uint32_t *out = coeffs_dev ? (uint32_t *)coeffs_dev + (size_t)chunk_lo * Q.n_coef * 8 : (uint32_t *)(qd->buf + Q.o_mcan);
+        // (the launch's last workgroup publishes the verdict itself when it compares anything; a launch with nothing to compare has none to give)
+        FsDone done{qd->status + 2, qd->res_dev, qd->seq + 1};
         rc = quick_launch(ctx, Q, qd->buf, qd->qsh, in, pm, out, ov, coeffs_dev ? (Q.n_coef == 1 ? cnt : cnt * (int64_t)Q.d) : 0, coeffs_dev ? Q.n_coef : 0,
-                          qd->status, qd->status + 1, cnt, s, nullptr);
+                          qd->status, qd->status + 1, cnt, s, nullptr, &done);
         if (rc) return rc;
-        k_publish_verdict<<<1, 1, 0, s>>>(qd->status, qd->res_dev, qd->seq + 1);
-        HB_LAUNCH_CHECK(ctx);
+        if (Q.nc == 0) { k_publish_verdict<<<1, 1, 0, s>>>(qd->status, qd->res_dev, qd->seq + 1); HB_LAUNCH_CHECK(ctx); }
         qd->seq += 1;
         qd->prepared = false;
         *seq_out = qd->seq;

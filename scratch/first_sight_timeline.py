@@ -1,0 +1,74 @@
+"""GPU timeline of first-sight opens (config 3's shape): run under rocprofv3 --kernel-trace, then
+    python scratch/first_sight_timeline.py --analyse <results.db>
+prints, per open, the kernels in order with the idle gaps between them."""
+import sys
+if len(sys.argv) > 2 and sys.argv[1] == "--analyse":
+    import sqlite3
+    db = sqlite3.connect(sys.argv[2])
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)").fetchall()]
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    # the last 40 opens: an open = k_mm8<...> (encode) then two k_mm8f
+    seq = [(n.split("(")[0].replace("void ", "")[:28], s, e) for n, s, e in rows]
+    idx = [i for i, r in enumerate(seq) if r[0].startswith("hb::k_mm8<")]
+    idx = idx[-41:]
+    tot = {}
+    cnt = 0
+    for a, b in zip(idx[:-1], idx[1:]):
+        part = seq[a:b]
+        if len(part) != 5:
+            continue
+        cnt += 1
+        prev_end = None
+        for j, (nm, s, e) in enumerate(part):
+            key = f"{j}:{nm}"
+            tot.setdefault(key, [0.0, 0.0])
+            tot[key][0] += (e - s) / 1e3
+            if prev_end is not None:
+                tot[key][1] += (s - prev_end) / 1e3
+            prev_end = e
+        tot.setdefault("open", [0.0, 0.0])
+        tot["open"][0] += (seq[b][1] - part[0][1]) / 1e3
+    print(f"{cnt} opens; per open: kernel us (idle gap before it us)")
+    for k, (d, g) in tot.items():
+        print(f"  {k:<40} {d / cnt:8.1f}  ({g / cnt:6.1f})")
+    sys.exit(0)
+import gc
+import numpy as np, torch
+sys.path.insert(0, '.')
+import bench
+from honeybadgermpc_amd._capi import Context
+from honeybadgermpc_amd.device import BatchOpen, DeviceIncrementalDecoder
+P = bench.BLS
+n, t, B = 64, 21, 1 << 20
+d = t + 1
+C = (B + d - 1) // d
+ctx = Context.get(P, 0)
+shares0, r1_cols, r2_cols, secrets, x = bench.make_inputs_light(torch, ctx, n, t, B, False, seed=1000)
+op = BatchOpen(P, n, t, max_shares=B, device=0)
+r1_out = ctx.empty(n * C)
+r1v, r2v = r1_cols.view(n, C, 4), r2_cols.view(n, C, 4)
+rng = np.random.Generator(np.random.PCG64(77))
+def first_sight(o1, o2):
+    op.r1_encode(shares0, out=r1_out)
+    outs = []
+    for order_, cols_, want_ in ((o1, r1v, "constant"), (o2, r2v, "all")):
+        dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, device=0, columns=cols_, want=want_)
+        for idx in order_:
+            dec.add(idx)
+            if dec.done():
+                break
+        outs.append(dec.get_results()[0])
+    return outs
+orders = [(rng.permutation(n).tolist(), rng.permutation(n).tolist()) for _ in range(120)]
+for o in orders[:10]:
+    first_sight(*o)
+gc.collect(); gc.freeze()
+torch.cuda.synchronize()
+import time
+t0 = time.perf_counter()
+for o in orders[10:]:
+    res = first_sight(*o)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 110
+print(f"first-sight open: {dt*1e6:.1f} us = {B/dt/1e9:.2f} G shares/s")
+assert torch.equal(res[1].reshape(-1, 4)[:B], secrets)
