@@ -289,7 +289,7 @@ int point_table(hb_ctx *ctx, const uint64_t *x_host, int n, PointTable **out, hi
 // device-built images of [rows of V^-1(z) ; V[zc] V^-1(z)] (hb_quick.hip): layout of one image's buffer, its build, its launch
 struct QuickLayout {
     int n, d, nc, n_coef, n_out, tile_rows, nkb;
-    size_t o_a8, o_crow, o_wj, o_full, o_nraw, o_mcan, o_z, o_map, need;
+    size_t o_a8, o_crow, o_wj, o_full, o_nraw, o_mcan, o_z, o_map, o_sync, need;
     // a decoder's image in two halves keeps, per PARTY, the row it would contribute as a compared sender (built with the first half, from the
     // first degree + 1 arrivals alone): o_cand = the rows' digit pieces [n][nkb * 16] x 16 B, o_cand_crow = their row constants [n][16 words];
     // 0 = no candidate store (more than 256 parties, nothing to compare)

@@ -114,12 +114,14 @@ __global__ void k_pt_inv(const FpParams<NL> P, const uint32_t *__restrict__ xm, 
 // Up to 63 interpolation points the first role is ONE wave working through LDS with wave-level synchronisation only, and the three
 // roles run side by side on three SIMDs: the critical path is the 2 d dependent multiplications of the first role.  Beyond that
 // A is built with workgroup barriers first and the roles follow.
-constexpr int QM_NT = 1024, QM_SEG = 8, QM_FSEG = 4, QM_TS = 4;     // k_quick_matrix: threads a workgroup; Horner / w_j segments (d QM_SEG <= QM_NT); partial products of a full_i (nc QM_FSEG <= QM_NT); lanes per coefficient of a tree level (d QM_TS <= QM_NT)
+constexpr int QM_NT = 1024, QM_SEG = 8, QM_FSEG = 16, QM_FPB = 32, QM_TS = 4;      // (QM_FPB rows x QM_FSEG partial products = 512 threads of a row-product workgroup: two waves a SIMD)     // k_quick_matrix: threads a workgroup; Horner / w_j segments (d QM_SEG <= QM_NT); partial products of a full_i (nc QM_FSEG <= QM_NT); lanes per coefficient of a tree level (d QM_TS <= QM_NT)
 template <int NL>
 __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ inv, int n,
                                                       const QuickIdx ix, int d, int nc, int n_coef, uint32_t *__restrict__ wj, uint32_t *__restrict__ full,
                                                       uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap, int flags,
-                                                      uint4 *__restrict__ zero_base, int zero_q, uint4 *__restrict__ zero2_base, int zero2_q) {
+                                                      uint4 *__restrict__ zero_base, int zero_q, uint4 *__restrict__ zero2_base, int zero2_q,
+                                                      int nh, int nw, int nf, uint32_t *__restrict__ Ag, unsigned long long *__restrict__ a_flag, unsigned long long token,
+                                                      const uint32_t *__restrict__ pwt, int S) {
     // Three workgroups, each a set of SHORT chains of dependent multiplications (rounds 3 and 4 ran one workgroup of d-step chains: A(X) by
     // d sequential multiplications by (X - x_q) with two barriers each, then d-step Horner / product chains per thread -- 177 us at d = 86):
     //   block 0: A(X) = prod (X - x_q) by a PRODUCT TREE in LDS (log2 d levels; a level multiplies adjacent monic polynomials, one output
@@ -133,55 +135,70 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
     //            launch cost a dispatch of its own (5 us on the path of a first-sight decode).
     // flags & 4 (with QUICK_Z): block 2 computes full_i for EVERY party (a decoder's candidate store: k_quick_fill makes a row of each), not
     // for the compared senders, who are not known yet.
+    // Round 5: the chains of ONE workgroup are issue-bound on their CU once there are a thousand of them (config 5's shard: 256 parties x 86
+    // factors of full_i = 49 us of multiply-adds on one CU; 86 x 8 Horner segments = 29 us).  So: workgroups 0 .. nh - 1 share the N_j (block 0
+    // builds A(X), publishes it through `Ag` + `a_flag` and the helpers wait for it: the grid is a dozen workgroups, all resident); workgroup nh
+    // is the w_j; workgroups nh + 1 .. nh + nf take QM_FPB parties' full_i each (QM_FSEG partial products joined by a tree); the last one zeroes.
     extern __shared__ uint32_t q_lds[];
     const int tid = threadIdx.x;
     const bool do_z = flags & 1, do_zc = flags & 2, do_cand = flags & 4;
     uint32_t *xz = q_lds;                               // [d][NL]: the arrivals' points (every block's chains read them)
-    if (blockIdx.x == 3) {
+    const int b_w = nh, b_f0 = nh + nw, b_zero = nh + nw + nf;
+    if ((int)blockIdx.x == b_zero) {
         for (int i = tid; i < zero_q; i += QM_NT) zero_base[i] = make_uint4(0, 0, 0, 0);
         for (int i = tid; i < zero2_q; i += QM_NT) zero2_base[i] = make_uint4(0, 0, 0, 0);      // (the candidate rows' padding terms: d .. 8 nkb - 1)
         return;
     }
-    if (blockIdx.x == 0 && !do_z) return;
-    if (blockIdx.x == 1 && !do_z) return;
+    if ((int)blockIdx.x < b_f0 && !do_z) return;
     for (int e = tid; e < d * NL; e += QM_NT) xz[e] = xm[(size_t)ix.z[e / NL] * NL + e % NL];
     __syncthreads();
-    if (blockIdx.x == 0 && n_coef == 1) {
-        // only the constant terms are wanted (what R1 forwards): N_j[0] = prod_{q != j} (-x_q), QM_SEG partial products a row and their
-        // join -- no A(X), no Horner (a third of the chain)
-        uint32_t *Wp = xz + (size_t)d * NL;                                   // [d][QM_SEG][NL]
-        const int Ls = (d + QM_SEG - 1) / QM_SEG;
-        const int j = tid / QM_SEG, g = tid % QM_SEG;
-        if (j < d) {
-            const int lo = g * Ls, hi = min((g + 1) * Ls, d);
-            uint32_t w[NL];
-            fp_set(w, P.one);
+    // A row product: out[r] = prod_{q < d, q != skip(r)} factor(r, q), QM_FSEG partial products a row joined by a tree through LDS, QM_FPB rows a
+    // workgroup (512 threads: a step of dependent multiplications costs what its waves issue, so the rows are spread thin).  Three users:
+    // the constant terms N_j[0] = prod_{q != j} (-x_q) (R1 decoders: no A(X), no Horner), the w_j, the full_i.
+    auto row_products = [&](int rb, int rows, int kind, uint32_t *__restrict__ out) {
+        uint32_t *Fp = xz + (size_t)d * NL;                                   // [QM_FPB][QM_FSEG][NL]
+        const int il = tid / QM_FSEG, g = tid % QM_FSEG, part = (d + QM_FSEG - 1) / QM_FSEG;
+        const int r = rb * QM_FPB + il;
+        const bool act = il < QM_FPB && r < rows;
+        if (act) {
+            const int lo = g * part, hi = min((g + 1) * part, d);
+            uint32_t xi[NL], f[NL];
+            fp_set(f, P.one);
+            const uint32_t *irow = nullptr;
+            if (kind == 2) ldg<NL>(xi, xm + (size_t)(do_cand ? r : (int)ix.zc[r]) * NL);
+            if (kind == 1) irow = inv + (size_t)ix.z[r] * n * NL;
             for (int q = lo; q < hi; q++) {
-                if (q == j) continue;
-                uint32_t x[NL], nx[NL];
-                ldg<NL>(x, xz + (size_t)q * NL);
-                fp_neg(nx, x, P);
-                mont_mul(w, w, nx, P);
+                uint32_t fac[NL];
+                if (kind == 0) { uint32_t xq[NL]; ldg<NL>(xq, xz + (size_t)q * NL); fp_neg(fac, xq, P); }
+                else if (kind == 1) ldg<NL>(fac, irow + (size_t)ix.z[q] * NL);
+                else { uint32_t xq[NL]; ldg<NL>(xq, xz + (size_t)q * NL); fp_sub(fac, xi, xq, P); }
+                if (kind == 2 || q != r) mont_mul(f, f, fac, P);
             }
-            stg<NL>(Wp + ((size_t)j * QM_SEG + g) * NL, w);
+            stg<NL>(Fp + ((size_t)il * QM_FSEG + g) * NL, f);
         }
         __syncthreads();
-        if (j < d && g == 0) {
-            uint32_t w[NL];
-            ldg<NL>(w, Wp + (size_t)j * QM_SEG * NL);
-            for (int g2 = 1; g2 < QM_SEG; g2++) {
-                uint32_t f[NL];
-                ldg<NL>(f, Wp + ((size_t)j * QM_SEG + g2) * NL);
-                mont_mul(w, w, f, P);
+        for (int half = QM_FSEG / 2; half >= 1; half >>= 1) {
+            if (act && g < half) {
+                uint32_t f[NL], f1[NL];
+                ldg<NL>(f, Fp + ((size_t)il * QM_FSEG + g) * NL);
+                ldg<NL>(f1, Fp + ((size_t)il * QM_FSEG + g + half) * NL);
+                mont_mul(f, f, f1, P);
+                if (half == 1) stg<NL>(out + (size_t)r * NL, f);
+                else stg<NL>(Fp + ((size_t)il * QM_FSEG + g) * NL, f);
             }
-            stg<NL>(nraw + (size_t)j * NL, w);
+            __syncthreads();
         }
+    };
+    if ((int)blockIdx.x < nh && n_coef == 1) {
+        // only the constant terms are wanted (what R1 forwards): N_j[0] = prod_{q != j} (-x_q) -- workgroups 0 .. nh - 1 take QM_FPB arrivals each
+        row_products((int)blockIdx.x, d, 0, nraw);
         return;
     }
-    if (blockIdx.x == 0) {
+    if ((int)blockIdx.x < nh) {
         uint32_t *B0 = xz + (size_t)d * NL, *B1 = B0 + (size_t)d * NL;      // [d][NL] each: the level's monic polynomials without their leading 1
         uint32_t *Ac = B1 + (size_t)d * NL;                                   // [d + 1][NL]
         uint32_t *Tb = Ac + (size_t)(d + 1) * NL;                             // [d][QM_SEG][NL]: segment sums
+      if (blockIdx.x == 0) {
         if (tid < d) {
             uint32_t x[NL], nx[NL];
             ldg<NL>(x, xz + (size_t)tid * NL);
@@ -231,12 +248,28 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
             __syncthreads();
             uint32_t *t_ = src; src = dst; dst = t_;
         }
-        if (tid < d) { uint32_t v[NL]; ldg<NL>(v, src + (size_t)tid * NL); stg<NL>(Ac + (size_t)tid * NL, v); }
-        if (tid == 0) stg<NL>(Ac + (size_t)d * NL, P.one);
+        if (tid < d) { uint32_t v[NL]; ldg<NL>(v, src + (size_t)tid * NL); stg<NL>(Ac + (size_t)tid * NL, v); if (nh > 1) stg<NL>(Ag + (size_t)tid * NL, v); }
+        if (tid == 0) { stg<NL>(Ac + (size_t)d * NL, P.one); if (nh > 1) stg<NL>(Ag + (size_t)d * NL, P.one); }
         __syncthreads();
-        // N(m) := N_j[m - 1] = sum_{k >= m} A[k] x_j^(k - m), m = 1 .. d; segment g holds k in [lo, hi)
+        if (nh > 1 && tid == 0) {
+            __threadfence();                                                 // A(X) is in memory before the token is
+            __hip_atomic_store(a_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      } else {
+        // a helper: wait for block 0's A(X) (every workgroup of this launch is resident: a dozen of them)
+        if (tid == 0) {
+            while (__hip_atomic_load(a_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != token) __builtin_amdgcn_s_sleep(4);
+            __threadfence();
+        }
+        __syncthreads();
+        for (int e = tid; e < (d + 1) * NL; e += QM_NT) Ac[e] = __builtin_nontemporal_load(Ag + e);
+        __syncthreads();
+      }
+        // N(m) := N_j[m - 1] = sum_{k >= m} A[k] x_j^(k - m), m = 1 .. d; segment g holds k in [lo, hi); this workgroup's share of the j
         const int Ls = (d + QM_SEG - 1) / QM_SEG;
-        const int j = tid / QM_SEG, g = tid % QM_SEG;
+        const int jb = (d + nh - 1) / nh;
+        const int jl = tid / QM_SEG, g = tid % QM_SEG;
+        const int j = jl < jb ? (int)blockIdx.x * jb + jl : d;
         const int lo = 1 + g * Ls, hi = min(1 + (g + 1) * Ls, d + 1);
         const bool live = j < d && lo < hi;
         uint32_t xj[NL], y[NL], v[NL];
@@ -251,7 +284,7 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
                 mont_mul(pr, xj, v, P);
                 fp_add(v, a_, pr, P);
             }
-            for (int e = 0; e < Ls; e++) mont_mul(y, y, xj, P);
+            ldg<NL>(y, pwt + ((size_t)ix.z[j] * S + Ls) * NL);             // x_j^Ls from the point set's table of powers (Ls <= d <= n < S)
             stg<NL>(Tb + ((size_t)j * QM_SEG + g) * NL, v);
         }
         __syncthreads();
@@ -276,69 +309,21 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
         }
         return;
     }
-    if (blockIdx.x == 1) {
-        uint32_t *Wp = xz + (size_t)d * NL;                                   // [d][QM_SEG][NL]
-        const int Ls = (d + QM_SEG - 1) / QM_SEG;
-        const int j = tid / QM_SEG, g = tid % QM_SEG;
-        if (j < d) {
-            const int lo = g * Ls, hi = min((g + 1) * Ls, d);
-            uint32_t w[NL], f[NL], fn[NL];
-            fp_set(w, P.one);
-            const uint32_t *row = inv + (size_t)ix.z[j] * n * NL;
-            if (lo < hi) ldg<NL>(f, row + (size_t)ix.z[lo] * NL);
-            for (int q = lo; q < hi; q++) {                                  // (the next factor is requested before this multiplication)
-                if (q + 1 < hi) ldg<NL>(fn, row + (size_t)ix.z[q + 1] * NL);
-                if (q != j) mont_mul(w, w, f, P);
-                fp_set(f, fn);
-            }
-            stg<NL>(Wp + ((size_t)j * QM_SEG + g) * NL, w);
-        }
-        __syncthreads();
-        if (j < d && g == 0) {
-            uint32_t w[NL];
-            ldg<NL>(w, Wp + (size_t)j * QM_SEG * NL);
-            for (int g2 = 1; g2 < QM_SEG; g2++) {
-                uint32_t f[NL];
-                ldg<NL>(f, Wp + ((size_t)j * QM_SEG + g2) * NL);
-                mont_mul(w, w, f, P);
-            }
-            stg<NL>(wj + (size_t)j * NL, w);
-        }
-        if (tid < d) z_dev[tid] = ix.z[tid];
+    if ((int)blockIdx.x >= b_w && (int)blockIdx.x < b_f0) {
+        // w_j = prod_{q != j} 1 / (x_j - x_q) from the point set's table of inverse differences; the first of these workgroups also the arrival list
+        if ((int)blockIdx.x == b_w && tid < d) z_dev[tid] = ix.z[tid];
+        row_products((int)blockIdx.x - b_w, d, 1, wj);
         return;
     }
-    // block 2: the compared senders' full_i (QM_FSEG partial products each), the row map
+    // workgroups b_f0 ..: QM_FPB rows' full_i each (QM_FSEG partial products a row, joined by a tree through LDS); the first one also the row map
     {
-        uint32_t *Fp = xz + (size_t)d * NL;                                   // [nc][QM_FSEG][NL]
-        if (do_z) { for (int r = tid; r <= n_coef + nc; r += QM_NT) fmap[r] = (do_zc && r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0; }
-        else { for (int r = tid; r < nc; r += QM_NT) fmap[n_coef + r] = (int32_t)ix.zc[r] + 1; }
+        const int fb = (int)blockIdx.x - b_f0;
+        if (fb == 0) {
+            if (do_z) { for (int r = tid; r <= n_coef + nc; r += QM_NT) fmap[r] = (do_zc && r >= n_coef && r < n_coef + nc) ? (int32_t)ix.zc[r - n_coef] + 1 : 0; }
+            else { for (int r = tid; r < nc; r += QM_NT) fmap[n_coef + r] = (int32_t)ix.zc[r] + 1; }
+        }
         if (!do_zc && do_z && !do_cand) return;
-        const int rows = do_cand ? n : nc;                                  // (n QM_FSEG <= QM_NT where a candidate store exists)
-        const int i = tid / QM_FSEG, g = tid % QM_FSEG, part = (d + QM_FSEG - 1) / QM_FSEG;
-        if (i < rows) {
-            const int lo = g * part, hi = min((g + 1) * part, d);
-            uint32_t xi[NL], f[NL];
-            ldg<NL>(xi, xm + (size_t)(do_cand ? i : (int)ix.zc[i]) * NL);
-            fp_set(f, P.one);
-            for (int q = lo; q < hi; q++) {
-                uint32_t xq[NL], df[NL];
-                ldg<NL>(xq, xz + (size_t)q * NL);
-                fp_sub(df, xi, xq, P);
-                mont_mul(f, f, df, P);
-            }
-            stg<NL>(Fp + ((size_t)i * QM_FSEG + g) * NL, f);
-        }
-        __syncthreads();
-        if (i < rows && g == 0) {
-            uint32_t f[NL];
-            ldg<NL>(f, Fp + (size_t)i * QM_FSEG * NL);
-            for (int g2 = 1; g2 < QM_FSEG; g2++) {
-                uint32_t f1[NL];
-                ldg<NL>(f1, Fp + ((size_t)i * QM_FSEG + g2) * NL);
-                mont_mul(f, f, f1, P);
-            }
-            stg<NL>(full + (size_t)i * NL, f);
-        }
+        row_products(fb, do_cand ? n : nc, 2, full);
     }
 }
 
@@ -962,14 +947,15 @@ int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L) 
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     L->o_a8 = 0; L->o_crow = L->o_a8 + al(a8_bytes); L->o_wj = L->o_crow + al(crow_words * 4); L->o_full = L->o_wj + al((size_t)d * 36);
     L->o_nraw = L->o_full + al((size_t)(nc ? nc : 1) * 36); L->o_mcan = L->o_nraw + al((size_t)n_coef * d * 36);
-    L->o_z = L->o_mcan + al((size_t)L->n_out * d * 32); L->o_map = L->o_z + al((size_t)d * 4); L->need = L->o_map + al((size_t)(L->n_out + 2) * 4);
+    L->o_z = L->o_mcan + al((size_t)L->n_out * d * 32); L->o_map = L->o_z + al((size_t)d * 4); L->o_sync = L->o_map + al((size_t)(L->n_out + 2) * 4);
+    L->need = L->o_sync + al((size_t)(d + 1) * 36 + 64);                    // A(X) for the builder's helper workgroups, and their token
     L->o_cand = L->o_cand_crow = 0;
     return HB_OK;
 }
 
 int quick_layout_cand(hb_ctx *ctx, QuickLayout *L) {
     (void)ctx;
-    if (L->nc < 1 || L->n * QM_FSEG > QM_NT || L->d > QF_NT || getenv("HB_QUICK_NO_CAND")) return HB_ERR_UNSUPPORTED;
+    if (L->nc < 1 || L->n > 1024 || L->d > QF_NT || getenv("HB_QUICK_NO_CAND")) return HB_ERR_UNSUPPORTED;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     // full_i for every party takes the place of the compared senders' (o_full is sized for nc): moved to the end with the store
     L->o_full = L->need;
@@ -1013,13 +999,19 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
     }
     // the rows this call owns: the coefficient rows with the first half, the compared senders' rows with the second
     const int row_lo = do_z ? 0 : L.n_coef, row_hi = do_zc ? L.n_out : L.n_coef;
-    const int frows = (cand && do_z) ? n : nc;                               // rows block 2 computes a full_i for
+    const int frows = (cand && do_z) ? n : nc;                               // rows a full_i is computed for
     if (do_z || nc > 0) {
-        // (the image and the row constants are zeroed by the launch's fourth workgroup when it builds the first half: padding rows / terms)
-        const size_t lds = (size_t)std::max((4 + QM_SEG) * d + 1, d + QM_FSEG * frows) * 36;
-        k_quick_matrix<9><<<do_z ? 4 : 3, QM_NT, lds, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z),
+        // (the image and the row constants are zeroed by the launch's last workgroup when it builds the first half: padding rows / terms)
+        const int nw = (d + QM_FPB - 1) / QM_FPB, nf = std::max(1, (frows + QM_FPB - 1) / QM_FPB);
+        const int nh = L.n_coef == 1 ? nw : ((do_z && d > 40) ? 4 : 1);
+        static std::atomic<unsigned long long> token_ctr{0};
+        const unsigned long long token = 0xA5C3000000000000ull ^ (++token_ctr);
+        const size_t lds = (size_t)std::max((4 + QM_SEG) * d + 1, d + QM_FSEG * QM_FPB) * 36;
+        uint32_t *Ag = (uint32_t *)(base + L.o_sync + 64);
+        k_quick_matrix<9><<<nh + nw + nf + (do_z ? 1 : 0), QM_NT, lds, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z),
                                                           (int32_t *)(base + L.o_map), (flags & 3) | (cand && do_z ? 4 : 0), (uint4 *)base, (int)(L.o_wj / 16),
-                                                          (uint4 *)(base + L.o_cand), (cand && do_z) ? (int)((L.o_cand_crow - L.o_cand) / 16) : 0);
+                                                          (uint4 *)(base + L.o_cand), (cand && do_z) ? (int)((L.o_cand_crow - L.o_cand) / 16) : 0,
+                                                          nh, nw, nf, Ag, (unsigned long long *)(base + L.o_sync), token, pt->pw, pt->S);
     }
     HB_LAUNCH_CHECK(ctx);
     if (cand && do_z) {
