@@ -400,14 +400,16 @@ constexpr int QF_NT = 128;
 __global__ void __launch_bounds__(QF_NT) k_quick_fill(const FpParams<9> P, const uint32_t *__restrict__ inv, int n, const QuickIdx ix, int d, int n_coef,
                                                      const uint32_t *__restrict__ wj, const uint32_t *__restrict__ full, const uint32_t *__restrict__ nraw,
                                                      uint8_t *__restrict__ a8, uint32_t *__restrict__ crow, int tile_rows, int nkb, const QuickRowConst rc,
-                                                     uint8_t *__restrict__ cand, uint32_t *__restrict__ cand_crow) {
+                                                     uint8_t *__restrict__ cand, uint32_t *__restrict__ cand_crow, int direct) {
     constexpr int NL = 9, NW = 8;
     __shared__ uint32_t red[QF_NT][NL];
     __shared__ int among;
+    // direct: the compared senders are known (a plan, a robust-phase launch): block n_coef + j makes row n_coef + j of the image from sender
+    // zc[j] -- full[] is indexed by j then -- instead of a candidate row per party
     const int b = blockIdx.x, l = threadIdx.x;
-    const bool coef = b < n_coef;
-    const int party = b - n_coef;
-    if (!coef) {
+    const bool coef = b < n_coef, into_image = coef || direct;
+    const int party = coef ? 0 : (direct ? (int)ix.zc[b - n_coef] : b - n_coef);
+    if (!coef && !direct) {
         if (l == 0) among = 0;
         __syncthreads();
         if (l < d && ix.z[l] == party) among = 1;
@@ -426,7 +428,7 @@ __global__ void __launch_bounds__(QF_NT) k_quick_fill(const FpParams<9> P, const
             mont_mul(v, c, w, P);
         } else {
             uint32_t f[NL], g[NL], t[NL];
-            ldg<NL>(f, full + (size_t)party * NL);
+            ldg<NL>(f, full + (size_t)(direct ? b - n_coef : party) * NL);
             ldg<NL>(g, inv + ((size_t)party * n + ix.z[l]) * NL);
             mont_mul(t, f, g, P);
             mont_mul(v, t, w, P);
@@ -437,7 +439,7 @@ __global__ void __launch_bounds__(QF_NT) k_quick_fill(const FpParams<9> P, const
         const int kb = l / 8, g = (l % 8) / 2, el = l & 1;
         // where the row's 16-byte piece (kb, grp, g) lies: in the image at lane position r + 16 g of its row tile, in the store at piece index
         size_t base4[4];
-        if (coef) {
+        if (into_image) {
             const int rt = b / tile_rows, j16 = b % tile_rows, r = 4 * (j16 % 4) + j16 / 4;
 #pragma unroll
             for (int grp = 0; grp < 4; grp++) base4[grp] = ((((size_t)rt * nkb + kb) * 4 + grp) * 64 + (size_t)(r + 16 * g)) * 16;
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(QF_NT) k_quick_fill(const FpParams<9> P, const
 #pragma unroll
             for (int grp = 0; grp < 4; grp++) base4[grp] = ((size_t)party * nkb * 16 + (size_t)((kb * 4 + grp) * 4 + g)) * 16;
         }
-        uint8_t *dst = coef ? a8 : cand;
+        uint8_t *dst = into_image ? a8 : cand;
         int carry = 0;
 #pragma unroll
         for (int bb = 0; bb < 32; bb++) {
@@ -476,7 +478,7 @@ __global__ void __launch_bounds__(QF_NT) k_quick_fill(const FpParams<9> P, const
         for (int q = 0; q < NL; q++) { sum[q] = red[0][q]; k[q] = rc.c80r[q]; bm[q] = rc.biasmod[q]; }
         mont_mul(prod, sum, k, P);
         fp_sub(corr, prod, bm, P);
-        uint32_t *dstc = coef ? crow + ((size_t)(b / tile_rows) * 16 + b % tile_rows) * 16 : cand_crow + (size_t)party * 16;
+        uint32_t *dstc = into_image ? crow + ((size_t)(b / tile_rows) * 16 + b % tile_rows) * 16 : cand_crow + (size_t)party * 16;
 #pragma unroll
         for (int q = 0; q < NL; q++) dstc[q] = corr[q];
     }
@@ -1016,7 +1018,14 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
     HB_LAUNCH_CHECK(ctx);
     if (cand && do_z) {
         k_quick_fill<<<(unsigned)(L.n_coef + n), QF_NT, 0, s>>>(ctx->pw, pt->inv, n, ix, d, L.n_coef, wj, full, nraw, base + L.o_a8, (uint32_t *)(base + L.o_crow),
-                                                               L.tile_rows, L.nkb, rcs, base + L.o_cand, (uint32_t *)(base + L.o_cand_crow));
+                                                               L.tile_rows, L.nkb, rcs, base + L.o_cand, (uint32_t *)(base + L.o_cand_crow), 0);
+        HB_LAUNCH_CHECK(ctx);
+        return HB_OK;
+    }
+    if (do_z && do_zc && d <= QF_NT) {
+        // the whole image at once (a plan, a robust-phase launch): coefficient rows and the compared senders' rows by the same launch
+        k_quick_fill<<<(unsigned)L.n_out, QF_NT, 0, s>>>(ctx->pw, pt->inv, n, ix, d, L.n_coef, wj, full, nraw, base + L.o_a8, (uint32_t *)(base + L.o_crow),
+                                                        L.tile_rows, L.nkb, rcs, nullptr, nullptr, 1);
         HB_LAUNCH_CHECK(ctx);
         return HB_OK;
     }
