@@ -590,12 +590,11 @@ static inline int f_tiles(int n_out, int ot) { return (n_out + ot - 1) / ot; }
 // (scratch/ubench_occ.hip), so occupancy matters: 2 outputs per tile need 92 VGPRs (5 waves/SIMD)
 // against 164 (3 waves/SIMD) for 4.  Measured on config 3 the two are within noise (the 50 KB of LDS
 // per workgroup caps residency at 3 workgroups per CU either way, and 2-output tiles halve the
-// MADs per LDS read), so 4 stays the default; HB_FAST_OT=2 selects the other instantiation.
+// MADs per LDS read), so 4 stays the default.
 static int pick_ot(hb_ctx *ctx, int n_in) {
     const size_t lds = (size_t)n_in * ctx->nl() * 64 * 4;
     if (lds > 72 * 1024) return 4;
     int ot = 4;
-    if (const char *e = getenv("HB_FAST_OT")) { int v = atoi(e); if (v == 2 || v == 4) ot = v; }
     return ot;
 }
 
@@ -693,9 +692,8 @@ int launch_prescale_pk(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in, hb_
     if (C <= 0 || m->n_in == 0) return HB_OK;
     if (!m->K1) return fail(ctx, HB_ERR_BAD_ARG, "prescale: not a factored inverse");
     int ept = 1;   // measured on config 3: 19.6 / 20.1 / 23.0 us for 1 / 2 / 4 elements per thread
-    if (const char *e = getenv("HB_PRESCALE_EPT")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) ept = v; }   // tuning hook
     dim3 grid((unsigned)((C + 256 * ept - 1) / (256 * ept)), (unsigned)m->n_in);
-    if (ctx->n_limbs == 4 && m->KT && !getenv("HB_PRESCALE_MONT") && prescale_params(ctx)) {
+    if (ctx->n_limbs == 4 && m->KT && prescale_params(ctx)) {
         k_prescale_tab<<<dim3((unsigned)((C + 255) / 256), (unsigned)m->n_in), 256, 0, s>>>(ctx->psc, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->KT, C, out_pk);
     } else if (ctx->n_limbs == 4) {
         if (ept == 1) k_prescale_pk<9, 8, 1><<<grid, 256, 0, s>>>(ctx->pw, in, iv.stride_c, iv.stride_l, rows_dev, in_count, m->K1, m->n_in, C, out_pk);
@@ -719,7 +717,6 @@ int launch_decode_check(hb_ctx *ctx, const FastMatrix *dec, const FastMatrix *en
     const size_t lds_d = (size_t)dec->n_in * ctx->nl() * 64 * 4, lds_e = (size_t)enc->n_in * ctx->nl() * 64 * 4;
     const size_t lds = lds_d > lds_e ? lds_d : lds_e;
     if (tiles_d > max_tpb || tiles_e > max_tpb || lds > 72 * 1024 || dec->n_in == 0) return HB_ERR_UNSUPPORTED;
-    if (getenv("HB_NO_FUSED_DECODE")) return HB_ERR_UNSUPPORTED;
     const int nsub_d = nsub_for(dec->n_in, ctx->nl(), ctx->elem_words()), nsub_e = nsub_for(enc->n_in, ctx->nl(), ctx->elem_words());
     const int64_t groups = (C + 63) / 64;
     int64_t blocks = ((groups + 7) / 8) * 8;
@@ -765,12 +762,10 @@ int launch_matvec2(hb_ctx *ctx, const FastMatrix *m, const uint32_t *in_dg,
         // LDS-staged variant: one workgroup per (64-chunk group, slice of <= 16 tiles), two tiles per wave
         const int max_tpb = 64 / m->ot;          // one workgroup sweeps at most 64 outputs
         int slices = (tiles + max_tpb - 1) / max_tpb;
-        if (const char *e = getenv("HB_MV3_SLICES")) { int v = atoi(e); if (v >= 1 && v <= tiles) slices = v; }
         const int tpb = (tiles + slices - 1) / slices;
         // 164 VGPRs => 3 waves per SIMD = 12 per CU; 50 KB of LDS per workgroup => 3 workgroups per CU:
         // 4-wave workgroups fill both limits
         int W = tpb < 4 ? tpb : 4;   // measured: 4 waves per workgroup beats 3 even for 6 tiles (staging is split 4 ways)
-        if (const char *e = getenv("HB_MV3_W")) { int w = atoi(e); if (w >= 1 && w <= 8) W = w; }          // tuning hooks
         const int64_t n_blocks = groups * slices;
         int64_t blocks = ((n_blocks + 7) / 8) * 8;
         if (blocks > 0x7fffffffLL) return fail(ctx, HB_ERR_UNSUPPORTED, "matvec: batch too large for one launch");

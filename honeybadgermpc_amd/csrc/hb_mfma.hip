@@ -371,7 +371,6 @@ size_t mm8_lds_bytes(int n_rt, int nkb, int tpw);
 // two passes per barrier -- measured the same 65 us as one: the barrier is not what the kernel waits for.)
 int mm8_tpw(int n_rt, int nkb) {
     int tpw = (n_rt == 1) ? 4 : (n_rt == 2) ? 2 : 1;
-    if (const char *e = getenv("HB_MM8_TPW")) { int v = atoi(e); if (v >= 1 && v <= 4 && v * n_rt >= 4 && mm8_lds_bytes(n_rt, nkb, v) <= MM8_LDS_LIMIT) tpw = v; }   // experiment hook
     return tpw;
 }
 size_t mm8_lds_bytes(int n_rt, int nkb, int tpw) {
@@ -641,7 +640,6 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
     const int64_t n_tiles = (C + 15) / 16;
     const int64_t n_units = (n_tiles + tpw - 1) / tpw;
     int64_t blocks = 2 * (int64_t)mm8_num_cus();
-    if (const char *e = getenv("HB_MM8_WGS_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 2) blocks = (int64_t)v * mm8_num_cus(); }   // experiment hook
     if (blocks > n_units) blocks = n_units;
     const size_t lds = mm8_lds_bytes(m->n_rt, m->nkb, tpw);
     const bool check = check_mask_dev != nullptr;

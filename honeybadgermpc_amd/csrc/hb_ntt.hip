@@ -426,7 +426,6 @@ int launch_ntt_lds(hb_ctx *ctx, const uint32_t *tw, int n, const uint32_t *in, h
     // radix-8 units: n / 8 per polynomial and pass; 2048 / n polynomials give the 256 threads one unit each (72 KB of data:
     // two workgroups per CU)
     int PB = n <= 2048 ? 2048 / n : 1; if (PB > 256) PB = 256;
-    if (const char *e = getenv("HB_NTT_PB")) { int v = atoi(e); if (v >= 1 && (size_t)v * n * elem_lds <= 150 * 1024) PB = v; }   // experiment hook
     if ((int64_t)PB > C) PB = (int)C;
     const size_t lds = ((size_t)PB * n + (size_t)(n > 1 ? n / 2 : 1)) * elem_lds + (size_t)PB * 4;
     if (lds > 160 * 1024) return fail(ctx, HB_ERR_UNSUPPORTED, "ntt: order does not fit LDS");

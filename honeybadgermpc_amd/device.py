@@ -540,11 +540,12 @@ class DeviceIncrementalDecoder:
             return
         self._cdec, self._ch, self._cout, self._ckey = cd, cd.addr, out, key
 
-    def _leave_c(self):
-        """the C decoder's part is over: its arrival list becomes this object's, the hb_dec goes back to the pool"""
+    def _leave_c(self, fetch=True):
+        """the C decoder's part is over: its arrival list becomes this object's (fetch), the hb_dec goes back to the pool"""
         cd, self._cdec, self._ch = self._cdec, None, None
-        self._zl = cd.arrivals()
-        self._avl = set(self._zl)
+        if fetch:
+            self._zl = cd.arrivals()
+            self._avl = set(self._zl)
         idle = _probe_pool.quick.get(self._ckey)
         if isinstance(idle, list) and len(idle) < 8:
             idle.append(cd)
@@ -574,8 +575,9 @@ class DeviceIncrementalDecoder:
             self.ctx.check(-state, "hb_dec_arrived1")
         d = self.degree + 1
         if state == HB_DEC_DONE:
+            # (the hb_dec stays with this object until it goes away: its arrival list is only fetched if somebody asks for _z)
             self.quick_launches += 1
-            self._leave_c()
+            self._ch = None
             self._result = self._cout.view(self.batch_size, d if self._want_all else 1, self.L)
             return
         if state == HB_DEC_DISAGREE:
@@ -777,7 +779,7 @@ class DeviceIncrementalDecoder:
         try:
             self._return_probe()
             if self._cdec is not None:
-                self._leave_c()
+                self._leave_c(fetch=False)
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
 

@@ -65,7 +65,7 @@ def main(dirs):
                 for l in p:
                     for c, v in l.items():
                         acc[k + ((),)][c].append(v)
-    keep = [k for k in acc if any(s in k[0] for s in ("k_mm8", "k_prescale", "k_matvec3", "k_decode_check", "k_ntt", "k_gao", "k_wb", "k_matvec2"))]
+    keep = [k for k in acc if any(s in k[0] for s in ("k_mm8", "k_prescale", "k_matvec3", "k_decode_check", "k_ntt", "k_gao", "k_wb", "k_matvec2", "k_mv64"))]
     ctrs = sorted({c for k in keep for c in acc[k]})
     print(f"{'kernel':<44} {'grid':>9} {'lds':>7} {'launches':>8} " + " ".join(f"{c:>24}" for c in ctrs) + f" {'HBM bytes/launch':>18}")
     for k in sorted(keep, key=lambda k: (k[0], k[1], k[2], -sum(acc[k].get("WRITE_SIZE", [0])) / max(1, len(acc[k].get("WRITE_SIZE", [0]))))):

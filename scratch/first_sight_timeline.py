@@ -8,14 +8,20 @@ if len(sys.argv) > 2 and sys.argv[1] == "--analyse":
     cols = [r[1] for r in db.execute("pragma table_info(kernels)").fetchall()]
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
     # the last 40 opens: an open = k_mm8<...> (encode) then two k_mm8f
-    seq = [(n.split("(")[0].replace("void ", "")[:28], s, e) for n, s, e in rows]
-    idx = [i for i, r in enumerate(seq) if r[0].startswith("hb::k_mm8<")]
+    seq = [(n.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:28], s, e) for n, s, e in rows]
+    first = sys.argv[3] if len(sys.argv) > 3 else "hb::k_mm8<"
+    idx = [i for i, r in enumerate(seq) if r[0].startswith(first)]
     idx = idx[-41:]
+    import collections
+    if len(idx) < 3:
+        print("no kernel named", first, "-- kernels seen:", collections.Counter(r[0] for r in seq[-400:]).most_common(12))
+        sys.exit(1)
+    npart = collections.Counter(b - a for a, b in zip(idx[:-1], idx[1:])).most_common(1)[0][0]
     tot = {}
     cnt = 0
     for a, b in zip(idx[:-1], idx[1:]):
         part = seq[a:b]
-        if len(part) != 5:
+        if len(part) != npart:
             continue
         cnt += 1
         prev_end = None
@@ -40,11 +46,14 @@ from honeybadgermpc_amd._capi import Context
 from honeybadgermpc_amd.device import BatchOpen, DeviceIncrementalDecoder
 P = bench.BLS
 n, t, B = 64, 21, 1 << 20
+OMEGA = len(sys.argv) > 1 and sys.argv[1] == "omega"
+if len(sys.argv) > 1 and sys.argv[1] == "cfg5":
+    n, t, B, OMEGA = 256, 85, (1 << 22) // 8, True
 d = t + 1
 C = (B + d - 1) // d
 ctx = Context.get(P, 0)
-shares0, r1_cols, r2_cols, secrets, x = bench.make_inputs_light(torch, ctx, n, t, B, False, seed=1000)
-op = BatchOpen(P, n, t, max_shares=B, device=0)
+shares0, r1_cols, r2_cols, secrets, x = bench.make_inputs_light(torch, ctx, n, t, B, OMEGA, seed=1000)
+op = BatchOpen(P, n, t, max_shares=B, device=0, use_omega_powers=OMEGA)
 r1_out = ctx.empty(n * C)
 r1v, r2v = r1_cols.view(n, C, 4), r2_cols.view(n, C, 4)
 rng = np.random.Generator(np.random.PCG64(77))
@@ -52,7 +61,7 @@ def first_sight(o1, o2):
     op.r1_encode(shares0, out=r1_out)
     outs = []
     for order_, cols_, want_ in ((o1, r1v, "constant"), (o2, r2v, "all")):
-        dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, device=0, columns=cols_, want=want_)
+        dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, device=0, columns=cols_, want=want_, use_omega_powers=OMEGA)
         for idx in order_:
             dec.add(idx)
             if dec.done():
