@@ -29,6 +29,8 @@
 // quotient: 26 + 35 v_mad_u64_u32 and the digit conversions both ways) -- its 32 columns, L, the top word times
 // 2^384 mod p and the per-row constant are gathered per 32-bit word (six MADs a word), a one-word Barrett quotient,
 // R - q p in words, one conditional subtraction.  No Montgomery form anywhere on this path.
+#include <atomic>
+
 #include "hb_mm8.hpp"
 
 namespace hb {
@@ -647,10 +649,10 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
     const bool ragged = !check && (m->n_out % 16) >= 1 && (m->n_out % 16) <= 8;
 #define MM8_LAUNCH_(NKB, CHK, RG, SK)                                                                                 \
     do {                                                                                                          \
-        static bool attr_done = false;                                                                            \
-        if (!attr_done) {                                                                                         \
+        static std::atomic<unsigned long long> attr_done{0};   /* one bit per device: the attribute is per device */                                                                            \
+        if (!((attr_done.load() >> (ctx->device & 63)) & 1ull)) {                                                                                         \
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8<NKB, CHK, RG, SK>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)); \
-            attr_done = true;                                                                                     \
+            attr_done.fetch_or(1ull << (ctx->device & 63));                                                                                     \
         }                                                                                                         \
         hipLaunchKernelGGL((k_mm8<NKB, CHK, RG, SK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, \
                            iv.stride_l, in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count,   \

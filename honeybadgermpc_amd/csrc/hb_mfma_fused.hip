@@ -36,6 +36,7 @@
 #include <math.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "hb_mm8.hpp"
 
@@ -736,8 +737,8 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
     const size_t lds = fs_lds_bytes(L.n_rt, L.nkb);
 #define FS_LAUNCH(NKB)                                                                                                                     \
     do {                                                                                                                                   \
-        static bool attr_done = false;                                                                                                     \
-        if (!attr_done) { HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8f<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done = true; } \
+        static std::atomic<unsigned long long> attr_done{0};   /* one bit per device: the attribute is per device */                                                                                                     \
+        if (!((attr_done.load() >> (ctx->device & 63)) & 1ull)) { HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8f<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done.fetch_or(1ull << (ctx->device & 63)); } \
         k_mm8f<NKB><<<dim3((unsigned)blocks), dim3(64 * FS_WAVES), lds, s>>>((const int4 *)(base + L.o_a8), (const uint32_t *)(base + L.o_crow), sh->fold_dev,        \
             (const uint32_t *)(base + L.o_kt), ctx->psc, cols, cv.stride_c, cv.stride_l, (const int32_t *)(base + L.o_z), INT64_MAX, L.d, (const int32_t *)(base + L.o_mode), \
             out, ov.stride_c, ov.stride_l, out_count, mismatch_dev, first_bad_dev, bad_map_dev, L.n_out, L.n_rt, C, n_units, sh->bp, done, pick); \

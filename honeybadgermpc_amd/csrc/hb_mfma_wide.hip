@@ -26,6 +26,7 @@
 // Inputs are biased by XOR 0x80 (int8 operands are signed); the per-row constant takes that and the accumulator
 // bias back out, mod p.  No Montgomery form anywhere.
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 
 #include "hb_common.hpp"
@@ -696,10 +697,10 @@ static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in
     const bool check = check_mask_dev != nullptr;
 #define MM8W_LAUNCH_K(CHK, PL, KK)                                                                                                    \
     do {                                                                                                                              \
-        static bool attr_done = false;                                                                                                \
-        if (!attr_done) {                                                                                                             \
+        static std::atomic<unsigned long long> attr_done{0};   /* one bit per device: the attribute is per device */                                                                                                \
+        if (!((attr_done.load() >> (ctx->device & 63)) & 1ull)) {                                                                                                             \
             HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w<CHK, PL, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-            attr_done = true;                                                                                                         \
+            attr_done.fetch_or(1ull << (ctx->device & 63));                                                                                                         \
         }                                                                                                                             \
         hipLaunchKernelGGL((k_mm8w<CHK, PL, KK>), dim3((unsigned)blocks), dim3(256), lds, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
                            in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,      \

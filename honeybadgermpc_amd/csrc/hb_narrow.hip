@@ -16,7 +16,10 @@
 //     products of 2^54 fit, no carry inside the dot product.  (Measured alternatives, each parity-green: the inputs kept as two halves and the
 //     ENTRY cut into three digits on the scalar unit -- 112 registers instead of 160, 40 % SLOWER: one scalar unit serves a CU's four SIMDs
 //     and 5 scalar operations an entry saturate it; the entry's three digits laid out by the host -- 72 scalar words a row do not fit the
-//     scalar file, the compiler falls back to single-word loads and 212 vector registers.)
+//     scalar file, the compiler falls back to single-word loads and 212 vector registers; the row group's entries as three digits in LDS,
+//     read by broadcast against the inputs' two halves -- 124 registers, four waves a SIMD, 102 us an open against 88: the staged inputs
+//     and the entries share the LDS, and the launches are not issue-bound to begin with -- PMC: a wave lives 3 us of a 16 us launch, the
+//     SIMDs hold 0.6 waves on average: ramp-up and tail of three short launches are a third of the open.)
 //   * entries are kept as M 2^128 mod p, so the sum (< 40 p 2^64) comes back through four 32-bit Montgomery steps (R = 2^128) and one
 //     conditional subtraction: canonical output, no pre-scale, nothing but the inputs and the outputs touches HBM;
 //   * per row a mode as in hb_mfma_fused.hip: store (a coefficient row / an encoded row) or compare with the received row of a later arrival.
@@ -30,9 +33,64 @@
 namespace hb {
 
 constexpr int MV64_DMAX = 40;
-constexpr int MV64_RESIDENT = 768;       // 3 waves a SIMD (160 registers) x 1024 SIMDs / 4 waves a workgroup
+constexpr int MV64_RESIDENT = 768;       // 3 waves a SIMD (160 registers) x 1024 SIMDs / 4 waves a workgroup (1024: 97 us an open instead of 88)
 
 struct Mv64Params { uint32_t p0, p1, pinv32; };          // p = p1 2^32 + p0; pinv32 = -p^-1 mod 2^32
+
+// the six accumulators of a row -> the canonical residue -> stored or compared (shared by the two kernels)
+struct Mv64Out { const uint64_t *in; int64_t in_sc, in_sl; uint64_t *out; int64_t out_sc, out_sl, out_count; int32_t *mismatch, *first_bad; };
+__device__ __forceinline__ void mv64_finish(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t b0, uint64_t b1, uint64_t b2, const Mv64Params &prm, int md, int64_t chunk,
+                                            int64_t cc, bool live, const Mv64Out &o) {
+    const uint64_t *in = o.in; uint64_t *out = o.out;
+    const int64_t in_sc = o.in_sc, in_sl = o.in_sl, out_sc = o.out_sc, out_sl = o.out_sl, out_count = o.out_count;
+    int32_t *mismatch = o.mismatch, *first_bad = o.first_bad;
+    {
+        // S = a0 + a1 2^22 + a2 2^44 + b0 2^32 + b1 2^54 + b2 2^76 as six 32-bit words (S < 40 p 2^64 < 2^134)
+    uint32_t w[6];
+    {
+        // 64-bit pieces by word offset: offset 0: a0 + (a1 << 22) low ...; done with 128-bit-free carries
+        unsigned __int128 s = (unsigned __int128)a0 + ((unsigned __int128)a1 << 22) + ((unsigned __int128)a2 << 44) + ((unsigned __int128)b0 << 32) +
+                              ((unsigned __int128)b1 << 54);
+        // b2 << 76 does not fit 128 bits with the rest: split off the top
+        const unsigned __int128 hi = (unsigned __int128)b2 << 12;        // weight 2^64
+        const uint64_t lo64 = (uint64_t)s;
+        unsigned __int128 up = (s >> 64) + hi;                           // < 2^72
+        w[0] = (uint32_t)lo64; w[1] = (uint32_t)(lo64 >> 32);
+        w[2] = (uint32_t)up; w[3] = (uint32_t)(up >> 32); w[4] = (uint32_t)(up >> 64); w[5] = 0;
+    }
+    // four Montgomery steps of 32 bits: S <- (S + u p) / 2^32, u = w0 pinv32 mod 2^32
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t u = w[0] * prm.pinv32;
+        uint64_t t = (uint64_t)u * prm.p0 + w[0];                        // low word becomes 0
+        t = (t >> 32) + (uint64_t)u * prm.p1 + w[1];
+        w[0] = (uint32_t)t;
+        t = (t >> 32) + w[2];
+        w[1] = (uint32_t)t;
+        t = (t >> 32) + w[3];
+        w[2] = (uint32_t)t;
+        t = (t >> 32) + w[4];
+        w[3] = (uint32_t)t;
+        w[4] = (uint32_t)(t >> 32);
+    }
+    // result < 40 p / 2^64 + p < 2 p in (w0, w1, w2 <= 1)
+    uint64_t r = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    const uint64_t pp = (uint64_t)prm.p0 | ((uint64_t)prm.p1 << 32);
+    if (w[2] || r >= pp) r -= pp;
+    if (md < 0) {
+        const int64_t oidx = chunk * out_sc + (int64_t)(-md - 1) * out_sl;
+        if (live && oidx < out_count) out[oidx] = r;
+    } else {
+        const uint64_t got = in[live ? cc * in_sc + (int64_t)(md - 1) * in_sl : 0];
+        const bool bad = live && got != r;
+        const unsigned long long bl = __builtin_amdgcn_ballot_w64(bad);
+        if (bl && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bl)) {
+            if (*reinterpret_cast<volatile int32_t *>(mismatch) == 0) atomicOr(mismatch, 1);
+            if (first_bad && *reinterpret_cast<volatile int32_t *>(first_bad) > (int32_t)chunk) atomicMin(first_bad, (int32_t)chunk);
+        }
+    }
+    }
+}
 
 // rowmode[i]: 0 = nothing, v > 0: compare the result with row v - 1 of the input buffer, v < 0: store it as output row -v - 1
 template <int DT, bool STAGE>
@@ -95,50 +153,7 @@ __global__ __launch_bounds__(256) void k_mv64(const uint2 *__restrict__ M, const
             b1 += (uint64_t)mr[l].y * x1[l];
             b2 += (uint64_t)mr[l].y * x2[l];
         }
-        // S = a0 + a1 2^22 + a2 2^44 + b0 2^32 + b1 2^54 + b2 2^76 as six 32-bit words (S < 40 p 2^64 < 2^134)
-        uint32_t w[6];
-        {
-            // 64-bit pieces by word offset: offset 0: a0 + (a1 << 22) low ...; done with 128-bit-free carries
-            unsigned __int128 s = (unsigned __int128)a0 + ((unsigned __int128)a1 << 22) + ((unsigned __int128)a2 << 44) + ((unsigned __int128)b0 << 32) +
-                                  ((unsigned __int128)b1 << 54);
-            // b2 << 76 does not fit 128 bits with the rest: split off the top
-            const unsigned __int128 hi = (unsigned __int128)b2 << 12;        // weight 2^64
-            const uint64_t lo64 = (uint64_t)s;
-            unsigned __int128 up = (s >> 64) + hi;                           // < 2^72
-            w[0] = (uint32_t)lo64; w[1] = (uint32_t)(lo64 >> 32);
-            w[2] = (uint32_t)up; w[3] = (uint32_t)(up >> 32); w[4] = (uint32_t)(up >> 64); w[5] = 0;
-        }
-        // four Montgomery steps of 32 bits: S <- (S + u p) / 2^32, u = w0 pinv32 mod 2^32
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t u = w[0] * prm.pinv32;
-            uint64_t t = (uint64_t)u * prm.p0 + w[0];                        // low word becomes 0
-            t = (t >> 32) + (uint64_t)u * prm.p1 + w[1];
-            w[0] = (uint32_t)t;
-            t = (t >> 32) + w[2];
-            w[1] = (uint32_t)t;
-            t = (t >> 32) + w[3];
-            w[2] = (uint32_t)t;
-            t = (t >> 32) + w[4];
-            w[3] = (uint32_t)t;
-            w[4] = (uint32_t)(t >> 32);
-        }
-        // result < 40 p / 2^64 + p < 2 p in (w0, w1, w2 <= 1)
-        uint64_t r = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-        const uint64_t pp = (uint64_t)prm.p0 | ((uint64_t)prm.p1 << 32);
-        if (w[2] || r >= pp) r -= pp;
-        if (md < 0) {
-            const int64_t oidx = chunk * out_sc + (int64_t)(-md - 1) * out_sl;
-            if (live && oidx < out_count) out[oidx] = r;
-        } else {
-            const uint64_t got = in[live ? cc * in_sc + (int64_t)(md - 1) * in_sl : 0];
-            const bool bad = live && got != r;
-            const unsigned long long bl = __builtin_amdgcn_ballot_w64(bad);
-            if (bl && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(bl)) {
-                if (*reinterpret_cast<volatile int32_t *>(mismatch) == 0) atomicOr(mismatch, 1);
-                if (first_bad && *reinterpret_cast<volatile int32_t *>(first_bad) > (int32_t)chunk) atomicMin(first_bad, (int32_t)chunk);
-            }
-        }
+        mv64_finish(a0, a1, a2, b0, b1, b2, prm, md, chunk, cc, live, Mv64Out{in, in_sc, in_sl, out, out_sc, out_sl, out_count, mismatch, first_bad});
     }
 }
 

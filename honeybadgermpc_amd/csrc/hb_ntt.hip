@@ -550,10 +550,13 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, co
         {
             const std::string skey = "ntt4:" + std::to_string(n) + ":" + std::to_string((uintptr_t)stream);      // per stream: launches of one stream are ordered
             auto sit = ctx->dcache.find(skey);
-            if (sit != ctx->dcache.end()) A = (uint32_t *)sit->second;
+            if (sit != ctx->dcache.end()) { A = (uint32_t *)sit->second; cache_touch(ctx, "d|" + skey); }
             else {
+                // an entry of the context's bounded cache like every other table: the LRU trim and hb_ctx_cache_clear drop it (both synchronise the
+                // device first), so a stream that was destroyed and whose address is reused cannot pin 128 MB per order for the context's life
                 HB_HIP(ctx, hipMalloc(&A, (size_t)n * NWr * 4));
                 ctx->dcache[skey] = A;
+                cache_note(ctx, "d|" + skey, [ctx, skey]() { auto f = ctx->dcache.find(skey); if (f != ctx->dcache.end()) { (void)hipFree(f->second); ctx->dcache.erase(f); } });
             }
         }
         const int d1 = (dd + n2 - 1) / n2 < n1 ? (dd + n2 - 1) / n2 : n1;          // coefficients a column of the first step can hold

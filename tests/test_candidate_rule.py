@@ -9,6 +9,7 @@ import random
 
 import oracle
 from conftest import BLS
+from structured import structured_message
 
 
 def ev(f, x, p):
@@ -32,7 +33,7 @@ def reference_step(xs, ys, k, p, need):
 def test_candidate_rule_is_the_reference_loop():
     rnd = random.Random(9)
     prefixes = accepted = governed = fake_accepted = dropped = 0
-    for trial in range(900):
+    for trial in range(1200):
         p = rnd.choice([BLS, BLS, 257, 10007])
         t = rnd.randrange(1, 8)
         n = rnd.randrange(3 * t + 1, 3 * t + 6)
@@ -42,7 +43,9 @@ def test_candidate_rule_is_the_reference_loop():
         cap = t - confirmed
         n_av = n - confirmed                                                     # those senders never count again
         xs_all = rnd.sample(range(1, min(p, 10 ** 6)), n_av)
-        true = [rnd.randrange(p) for _ in range(k)]
+        # (a third of the true polynomials are the structured ones uniform draws never produce -- zero, constant, short, padded: Gao decodes
+        # those BEYOND the radius of a full-degree message, which is where the rule's argument has to hold too)
+        true = structured_message(rnd, k, p) if trial % 3 == 0 else [rnd.randrange(p) for _ in range(k)]
         # the liars' word: garbage, or one fake polynomial equal to the true one at `shared` points
         n_liars = min(n_av, rnd.choice([0, 1, cap, cap, cap, cap + 1, cap + 2, rnd.randrange(0, n_av + 1)]))
         liars = set(rnd.sample(range(n_av), n_liars))
@@ -92,14 +95,14 @@ def test_no_acceptance_before_the_bound_a_verdict_implies():
     columns are in.  Every prefix of random words (garbage liars, coordinated liars, too many liars), the oracle's Gao as the decoder."""
     rnd = random.Random(21)
     implied = checked = accepted = 0
-    for trial in range(500):
+    for trial in range(750):
         p = rnd.choice([BLS, 257, 10007])
         t = rnd.randrange(1, 8)
         n = rnd.randrange(3 * t + 1, 3 * t + 6)
         k = t + 1
         need = k + t
         xs_all = rnd.sample(range(1, min(p, 10 ** 6)), n)
-        true = [rnd.randrange(p) for _ in range(k)]
+        true = structured_message(rnd, k, p) if trial % 3 == 0 else [rnd.randrange(p) for _ in range(k)]
         liars = set(rnd.sample(range(n), min(n, rnd.choice([1, t, t, t, t + 1, rnd.randrange(0, n + 1)]))))
         fake = [rnd.randrange(p) for _ in range(k)] if rnd.random() < 0.5 else None
         word = [(ev(fake, xs_all[j], p) if fake is not None else rnd.randrange(p)) if j in liars else ev(true, xs_all[j], p) for j in range(n)]
