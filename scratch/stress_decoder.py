@@ -18,10 +18,12 @@ t_end = time.time() + budget
 runs = fails = raised = robust_runs = 0
 while time.time() < t_end:
     n = rnd.choice([7, 10, 13, 16, 22, 31])
+    if rnd.random() < 0.08:
+        n = rnd.choice([40, 64, 64, 100, 130])          # three K-blocks on the small-entry kernel; n = 100 and 130: full-size entries, 130: the builder's helper workgroups
     t = rnd.randrange(3, (n - 1) // 3 + 1) if (n - 1) // 3 >= 3 else (n - 1) // 3
     if t < 3:
         continue
-    c = rnd.choice([1, 2, 5, 17, 40])
+    c = rnd.choice([1, 2, 5, 17, 40]) if n <= 31 else rnd.choice([1, 3, 9])
     use_omega = rnd.random() < 0.3
     robust = rnd.choice(["gao", "gao", "wb"])
     point = EvalPoint(GF(P), n, use_omega_powers=use_omega)
