@@ -54,12 +54,13 @@ WORKLOADS = {
     "tiny": (4, 1, 256, False),
     "cfg4": (100, 33, 1 << 18, False),       # BASELINE config 4: robust decode (Welch-Berlekamp / Gao) with t injected errors; B = codewords
     "cfg4-mini": (100, 33, 1 << 12, False),  # the same at test size
+    "cfg4-n64": (64, 21, 1 << 18, False),    # the robust decode at config 3's shape (what an R2 decode under attack runs per chunk): point sets of <= 64 points
     "cfg3-p64": (64, 21, 1 << 20, False),    # config 3's open over the 64-BIT prime of the north star (2^64 - 59): 8-byte elements, the 1-limb kernels
     "cfg3-p64-mini": (64, 21, 1 << 14, False),
 }
 P64 = (1 << 64) - 59
 NARROW = {"cfg3-p64", "cfg3-p64-mini"}
-ROBUST = {"cfg4", "cfg4-mini"}
+ROBUST = {"cfg4", "cfg4-mini", "cfg4-n64"}
 SHARDED = {"cfg5", "cfg5-mini"}                           # total work fixed: the batch is split with sharding.shard_bounds, the opened shares are all-gathered
 
 
@@ -1066,7 +1067,7 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
     # scalings, five multiplications and a quarter of a 380-multiplication inversion
     mads_cw = t * (n + 5) * 4 * 81 + sum(i + t for i in range(k)) * 3 * 81 + n * 2 * 81 + (2 * (t + 1) + 5 + 380 // 4) * 2 * 81
     mad_peak = 1024 * 64 * 2.4e9 / 4.4
-    counters = profile_counters(args.workload if args.workload == "cfg4" else "cfg4")
+    counters = profile_counters("cfg4") if n == 100 else {}
     line = {
         "metric": f"codewords robust-decoded/sec (Welch-Berlekamp, t injected errors, n={n} t={t})", "value": world * C * steps / dt, "unit": "codewords/s",
         "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 3)), "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak",
@@ -1078,8 +1079,8 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
         "distributed": dist_info(torch, dist, backend, args, world),
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic_from_profiles("cfg4"),
-            "kernel": counters.get("kernel") or "k_gao (one wave per codeword: fraction-free extended Euclid + pseudo-division in LDS) behind k_mm8w (the interpolant g1 = V^-1 y) and before "
+            "traffic": traffic_from_profiles("cfg4") if n == 100 else None,
+            "kernel": counters.get("kernel") or ("k_gao (one wave per codeword" if n > 64 else "k_gao_pair (two codewords a wave") + ": fraction-free extended Euclid + pseudo-division in LDS) behind k_mm8w (the interpolant g1 = V^-1 y) and before "
                                                 "k_gao_finish (one field inversion per four codewords, one lane each); hb_wb_decode runs exactly these inside the unique-decoding radius",
             "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": call_ms,
             "launch_note": "one hb_wb_decode call (synchronous: three kernels + the radius bookkeeping), bracketed by HIP events on the call's stream; "
@@ -1089,12 +1090,12 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
                        "peak": mad_peak / 1e12,
                        "peak_note": "1024 SIMDs x 64 lanes x 2.4 GHz / 4.4 cycles per v_mad_u64_u32 wave-instruction (half rate, profiles/r01_instruction_rates_ubench.txt)",
                        "frac": C * mads_cw / (call_ms * 1e-3) / mad_peak,
-                       "frac_note": "what separates it from 1: a round of 64 lanes runs for ~105 elements of a step (0.82; ~50 of 64 in the division), the "
+                       "frac_note": "(n = 100) what separates it from 1: a round of 64 lanes runs for ~105 elements of a step (0.82; ~50 of 64 in the division), the "
                                     "multiply-adds are 70 % of the vector instructions k_gao issues (profiles/r04_pmc_cfg4.txt: 43.3 k per codeword, 30.5 k of them "
                                     "multiply-adds; the rest is REDC's carries and pointer set-up), the interpolant's matrix-core launch and the finisher are in the "
                                     "time and not in the count.  Round 3's line counted the two-sub-step algorithm's "
                                     "multiplications (2.6 times as many multiply-adds per codeword): its fraction is not comparable"},
-            "note": "purely arithmetic-bound: ~1.6 10^6 multiply-adds per 4.3 KB codeword; the HBM fraction is what SURVEY 8d asks for, the multiply-add rate says how busy the chip is",
+            "note": f"purely arithmetic-bound: ~{mads_cw / 1e6:.1f} 10^6 multiply-adds per {32 * (n + k) / 1e3:.1f} KB codeword; the HBM fraction is what SURVEY 8d asks for, the multiply-add rate says how busy the chip is",
         },
         "detail": {"shares_equivalent_per_s": world * C * k * steps / dt,
                    "gao_codewords_per_s_per_gpu": (C * steps / dt_gao) if dt_gao else None, "gao_ms_per_step": (dt_gao * 1e3 / steps) if dt_gao else None,

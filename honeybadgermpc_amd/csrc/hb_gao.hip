@@ -155,6 +155,331 @@ template <int NL> __device__ int poly_degree_lazy(const uint32_t *p, int hi, int
 #ifndef GAO_WAVES_PER_EU
 #define GAO_WAVES_PER_EU 3
 #endif
+// one codeword's state: its arrays in LDS and the (wave-uniform) degrees
+template <int NL> struct GaoCw {
+    uint32_t *R0, *R1, *T0, *T1;                         // this codeword's arrays in LDS (the pairs swap every step)
+    uint32_t *M;                                         // ... and its scalars: three multipliers, -X, the two scale factors
+    int csw;                                             // which of the two scale factors is c0 at the moment
+    __device__ __forceinline__ uint32_t *S() const { return M; }
+    __device__ __forceinline__ uint32_t *NEGX() const { return M + 3 * NL; }
+    __device__ __forceinline__ uint32_t *CA() const { return M + (4 + csw) * NL; }
+    __device__ __forceinline__ uint32_t *CB() const { return M + (5 - csw) * NL; }
+    int dR0, dR1, dT0, dT1;                              // wave-uniform degrees
+    bool have_sc, done;
+    uint32_t *rp, *vp, *csp;                             // what the loop ends with: remainder, cofactor, the scale factor that goes with them
+    int dr, dvb;
+    uint32_t *F;                                         // the division: raw quotient digits, degrees, the round counter
+    int dv, dq, df, i;
+    bool ok, divided;
+};
+
+// words of one codeword's arrays: R0, R1, T0, T1, three multipliers, -X, c0, c1
+template <int NL> __device__ __forceinline__ int gao_cw_words(int len, int lenT) { return (2 * len + 2 * lenT + 6) * NL; }
+
+template <int NL> __device__ __forceinline__ void gao_loop_ends(GaoCw<NL> &w, bool first) {
+    if (first) { w.rp = w.R0; w.vp = w.T0; w.dr = w.dR0; w.dvb = w.dT0; w.csp = w.CA(); }
+    else { w.rp = w.R1; w.vp = w.T1; w.dr = w.dR1; w.dvb = w.dT1; w.csp = w.CB(); }
+    w.done = true;
+}
+
+// arrays of one codeword: g0 -> R0, the interpolant (packed, chunk-major) -> R1 in Montgomery form, T0 = 0, T1 = 1, c0 = c1 = 1
+template <int NL, int NW>
+__device__ __forceinline__ void gao_cw_init(GaoCw<NL> &w, uint32_t *base, int len, int lenT, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1row,
+                                            int npts, int k, int lane, const FpParams<NL> &P) {
+    w.R0 = base; w.R1 = w.R0 + (size_t)len * NL; w.T0 = w.R1 + (size_t)len * NL; w.T1 = w.T0 + (size_t)lenT * NL;
+    w.M = w.T1 + (size_t)lenT * NL; w.csw = 0;
+    if (lane < NL) { w.CA()[lane] = P.one[lane]; w.CB()[lane] = P.one[lane]; }
+    for (int idx = lane; idx < len; idx += 64) {
+        uint32_t a[NL], z[NL], m[NL];
+#pragma unroll
+        for (int q = 0; q < NL; q++) { a[q] = g0[(size_t)idx * NL + q]; z[q] = 0; }
+        lds_put<NL>(w.R0 + (size_t)idx * NL, a);
+        if (idx < lenT) {
+            lds_put<NL>(w.T0 + (size_t)idx * NL, z);
+            if (idx == 0) lds_put<NL>(w.T1, P.one); else lds_put<NL>(w.T1 + (size_t)idx * NL, z);
+        }
+        if (idx < npts) {
+            uint32_t yd[NL];
+            load_digits<NL, NW>(yd, g1row + (size_t)idx * NW);
+            to_mont(m, yd, P);
+            lds_put<NL>(w.R1 + (size_t)idx * NL, m);
+        } else lds_put<NL>(w.R1 + (size_t)idx * NL, z);
+    }
+    __syncthreads();
+    w.dR0 = npts; w.dR1 = __builtin_amdgcn_readfirstlane(poly_degree<NL>(w.R1, npts - 1, lane)); w.dT0 = -1; w.dT1 = 0;
+    w.have_sc = false; w.done = false;
+    const int D = (npts + k) / 2;
+    if (w.dR0 < D) gao_loop_ends<NL>(w, true);              // rsdecode_impl.h:289-294 (cannot fire: deg g0 = n >= D)
+    else if (w.dR1 < D) gao_loop_ends<NL>(w, false);        // rsdecode_impl.h:296-301
+}
+
+// one Euclid step of one codeword: the fused step in its two rounds, or the generic pseudo-division
+template <int NL> __device__ __forceinline__ void gao_step_single(GaoCw<NL> &w, int lane, const uint32_t *ZERO, const uint32_t *KD, const FpParams<NL> &P, const GaoConsts<NL> &GK) {
+    const int delta = w.dR0 - w.dR1;
+    const int dR1 = w.dR1;
+    // The generic division step's common case (the degrees drop one at a time), fused: its two pseudo-division sub-steps
+    //     r' = L r0 - a1 X r1,   a0 = r'[deg r1],   r'' = L r' - a0 r1
+    // are ONE update r''[i] = L^2 r0[i] - (L a1) r1[i-1] - a0 r1[i] (the same on the cofactor; c0 <- L^2 c0): three products and one
+    // reduction per coefficient where the sub-steps take four and two.  The three multipliers of a step cost four modular
+    // multiplications -- executed by the whole wave they would eat the gain (round 4 measured it: 45 ms against 38) -- so those
+    // of the NEXT step are computed by three otherwise idle lanes of this step's second round: the first round takes the TOP 64
+    // coefficients of the remainder, so the two leading coefficients of r'' the next multipliers need are there when the second
+    // round (the rest of the remainder, the cofactor, c0, the three jobs) starts.  With (X, Y, Z, W) = (lc r'', L, r1[deg r1 - 1],
+    // r''[deg r'' - 1]): job0 = X X, job1 = -X Y, job2 = Y W - X Z -- the residues of the NEGATED multipliers, so that the
+    // update is a plain sum S0 u + S1 w1 + S2 w0; the jobs subtract through NEGX, the digit-wise negation of X that the lane which
+    // computed X left in LDS (K - X in K's redundant digits: GaoConsts).  Values equal to the sub-steps' mod p, term by term.
+    const int ttop_f = max(w.dT0, w.dT1 + 1), n2_f = max(0, dR1 - 64);
+    if (delta == 1 && dR1 >= 2 && n2_f + ttop_f + 1 <= 60) {
+        const int top = dR1, ttop = ttop_f, n2 = n2_f;
+        const int jb = lane - 60;
+        const bool isJ = lane >= 60 && lane < 63;
+        if (!w.have_sc) {
+            // the multipliers of THIS step alone (first step, or after a degree anomaly): (X, Y, Z, W) = (L, lc r0, r0[deg r1], r1[deg r1 - 1])
+            __syncthreads();
+            if (lane < NL) w.NEGX()[lane] = KD[lane] - w.R1[(size_t)dR1 * NL + lane];
+            __syncthreads();
+            const uint32_t *Xa = w.R1 + (size_t)dR1 * NL, *Ya = w.R0 + (size_t)(dR1 + 1) * NL, *Za = w.R0 + (size_t)dR1 * NL, *Wa = w.R1 + (size_t)(dR1 - 1) * NL;
+            const uint32_t *pm0 = ZERO, *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO;
+            if (isJ) { pm0 = jb == 0 ? Xa : w.NEGX(); pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za); if (jb == 2) { pm1 = Ya; pw1 = Wa; } }
+            uint32_t r[NL];
+            gao_round2<NL>(r, pm0, pu, pm1, pw1, P);
+            if (isJ) lds_put<NL>(w.S() + (size_t)jb * NL, r);
+            __syncthreads();
+        }
+        {
+            const bool act = lane < min(64, top);
+            const int idx = top - 1 - lane;
+            const uint32_t *pu = ZERO, *pw1 = ZERO, *pw0 = ZERO;
+            if (act) { pu = w.R0 + (size_t)idx * NL; pw1 = idx >= 1 ? w.R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = w.R1 + (size_t)idx * NL; }
+            uint32_t r[NL];
+            gao_round<NL>(r, w.S(), pu, w.S() + NL, pw1, w.S() + 2 * NL, pw0, P);
+            __syncthreads();
+            if (act) lds_put<NL>(w.R0 + (size_t)idx * NL, r);
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < NL; q++) w.NEGX()[q] = GK.kd[q] - r[q];
+            }
+            __syncthreads();
+        }
+        {
+            const uint32_t *Xa = w.R0 + (size_t)(top - 1) * NL, *Ya = w.R1 + (size_t)dR1 * NL, *Za = w.R1 + (size_t)(dR1 - 1) * NL, *Wa = w.R0 + (size_t)(top - 2) * NL;
+            const uint32_t *pm0 = w.S(), *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO, *pm2 = ZERO, *pw0 = ZERO;
+            uint32_t *dst = nullptr;
+            if (lane < n2) {
+                const int idx = n2 - 1 - lane;
+                pu = w.R0 + (size_t)idx * NL; pw1 = idx >= 1 ? w.R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = w.R1 + (size_t)idx * NL;
+                pm1 = w.S() + NL; pm2 = w.S() + 2 * NL; dst = w.R0 + (size_t)idx * NL;
+            } else if (lane <= n2 + ttop) {
+                const int idx = lane - n2;
+                pu = w.T0 + (size_t)idx * NL;
+                pw1 = (idx >= 1 && idx - 1 <= w.dT1) ? w.T1 + (size_t)(idx - 1) * NL : ZERO;
+                pw0 = idx <= w.dT1 ? w.T1 + (size_t)idx * NL : ZERO;
+                pm1 = w.S() + NL; pm2 = w.S() + 2 * NL; dst = w.T0 + (size_t)idx * NL;
+            } else if (isJ) {
+                pm0 = jb == 0 ? Xa : w.NEGX(); pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za);
+                if (jb == 2) { pm1 = Ya; pw1 = Wa; }
+                dst = w.S() + (size_t)jb * NL;
+            } else if (lane == 63) { pu = w.CA(); dst = w.CA(); }
+            uint32_t r[NL];
+            gao_round<NL>(r, pm0, pu, pm1, pw1, pm2, pw0, P);
+            __syncthreads();
+            if (dst) lds_put<NL>(dst, r);
+            if (lane < 2) {
+#pragma unroll
+                for (int q = 0; q < NL; q++) w.R0[(size_t)(top + lane) * NL + q] = 0;
+            }
+            __syncthreads();
+        }
+        w.dT0 = ttop;
+        w.have_sc = true;
+        return;
+    }
+    // The generic division step (degrees drop one at a time): delta + 1 pseudo-division sub-steps r0 <- L r0 - r0[top] X^j r1, the same on
+    // the cofactor, c0 <- L c0 each
+    w.have_sc = false;
+    uint32_t L[NL], c0[NL];
+    lds_get<NL>(L, w.R1 + (size_t)dR1 * NL);
+    lds_get<NL>(c0, w.CA());
+    for (int j = delta; j >= 0; j--) {
+        uint32_t a[NL], an[NL];
+        lds_get<NL>(a, w.R0 + (size_t)(dR1 + j) * NL);
+        cond_sub_p(a, P);                 // (lazy residues: canonical before the negation)
+        fp_neg(an, a, P);                 // L u - a w = L u + (p - a) w: ONE reduction for the two products (columns stay below
+                                          // 3 NL 2^58 < 2^63; the sum is < 3 p^2 < p R / 8, so REDC leaves < 2p: one conditional subtraction)
+        __syncthreads();
+        const int top = dR1 + j;
+        const int ttop = max(w.dT0, w.dT1 + j);
+        // One update, r <- L u + (p - a) w, for every coefficient of the remainder R0 below `top` (w = R1[idx - j]) and of the cofactor
+        // T0 up to `ttop` (w = T1[idx - j]), and c0 <- L c0.  deg R0 + deg T0 stays about npts, so what the remainder leaves of its
+        // last round of 64 lanes holds the whole cofactor AND the scale factor: two rounds a step at n = 100 where three and a
+        // wave-wide multiplication were.
+        int base = 0;
+        for (; base + 64 <= top; base += 64) {
+            const int idx = base + lane;
+            uint32_t u[NL], r[NL];
+            uint64_t col[2 * NL];
+            lds_get<NL>(u, w.R0 + (size_t)idx * NL);
+            col_zero(col);
+            mac<NL>(col, L, u);
+            if (idx >= j) {
+                uint32_t ww[NL];
+                lds_get<NL>(ww, w.R1 + (size_t)(idx - j) * NL);
+                mac<NL>(col, an, ww);
+            }
+            redc(r, col, P);
+            cond_sub_p(r, P);
+            lds_put<NL>(w.R0 + (size_t)idx * NL, r);
+        }
+        const int n2 = top - base;                       // lanes the remainder still needs: 0 .. 63
+        const bool merged = n2 + ttop + 1 <= 63;         // ... and the cofactor beside them, lane 63 for c0
+        {
+            const bool isR = lane < n2, isT = merged && lane >= n2 && lane <= n2 + ttop, cz = merged && lane == 63;
+            uint32_t hand[NL];
+#pragma unroll
+            for (int q = 0; q < NL; q++) hand[q] = 0;
+            if (isR || isT || cz) {
+                uint32_t *A = isR ? w.R0 : w.T0;
+                const uint32_t *B = isR ? w.R1 : w.T1;
+                const int idx = isR ? base + lane : lane - n2;
+                const bool second = isR ? idx >= j : (isT && idx >= j && idx - j <= w.dT1);
+                uint32_t u[NL], r[NL];
+                uint64_t col[2 * NL];
+                if (cz) fp_set(u, c0); else lds_get<NL>(u, A + (size_t)idx * NL);
+                col_zero(col);
+                mac<NL>(col, L, u);
+                if (second) {
+                    uint32_t ww[NL];
+                    lds_get<NL>(ww, B + (size_t)(idx - j) * NL);
+                    mac<NL>(col, an, ww);
+                }
+                redc(r, col, P);
+                cond_sub_p(r, P);
+                if (!cz) lds_put<NL>(A + (size_t)idx * NL, r);
+#pragma unroll
+                for (int q = 0; q < NL; q++) hand[q] = r[q];
+            }
+            if (merged) {
+#pragma unroll
+                for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)hand[q], 63);
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < NL; q++) w.R0[(size_t)top * NL + q] = 0;
+        }
+        if (!merged) {
+            for (int idx = lane; idx <= ttop; idx += 64) {
+                uint32_t u[NL], r[NL];
+                uint64_t col[2 * NL];
+                lds_get<NL>(u, w.T0 + (size_t)idx * NL);
+                col_zero(col);
+                mac<NL>(col, L, u);
+                if (idx >= j && idx - j <= w.dT1) {
+                    uint32_t ww[NL];
+                    lds_get<NL>(ww, w.T1 + (size_t)(idx - j) * NL);
+                    mac<NL>(col, an, ww);
+                }
+                redc(r, col, P);
+                cond_sub_p(r, P);
+                lds_put<NL>(w.T0 + (size_t)idx * NL, r);
+            }
+            mont_mul(c0, c0, L, P);           // c0 <- lc(r1)^(delta+1) * c0, one factor per step
+        }
+        w.dT0 = ttop;
+        __syncthreads();
+    }
+    if (lane == 0) lds_put<NL>(w.CA(), c0);
+    __syncthreads();
+}
+
+// after a step: the new remainder's degree (it drops by exactly one as a rule), the loop's end, (r0, r1) <- (r1, r2)
+template <int NL> __device__ __forceinline__ void gao_after_step(GaoCw<NL> &w, int D, int lane, const FpParams<NL> &P) {
+    uint32_t topc[NL];
+    bool nz = false;
+    if (w.dR1 >= 1) { lds_get<NL>(topc, w.R0 + (size_t)(w.dR1 - 1) * NL); nz = !is_zero_lazy<NL>(topc, P); }
+    w.dR0 = __builtin_amdgcn_readfirstlane(nz ? w.dR1 - 1 : poly_degree_lazy<NL>(w.R0, w.dR1 - 1, lane, P));
+    if (w.dR0 != w.dR1 - 1) w.have_sc = false;
+    if (w.dR0 < D) { gao_loop_ends<NL>(w, true); return; }
+    uint32_t *tp = w.R0; w.R0 = w.R1; w.R1 = tp;
+    tp = w.T0; w.T0 = w.T1; w.T1 = tp;
+    w.csw ^= 1;
+    int ti = w.dR0; w.dR0 = w.dR1; w.dR1 = ti;
+    ti = w.dT0; w.dT0 = w.dT1; w.dT1 = ti;
+}
+
+// the division f = r / v up to its rounds: the cofactor leaves as it is, lc(V) takes the place of the loop's multipliers
+template <int NL, int NW>
+__device__ __forceinline__ void gao_division_begins(GaoCw<NL> &w, int64_t c, int npts, uint32_t *__restrict__ errloc, int lane, const FpParams<NL> &P) {
+    w.dv = __builtin_amdgcn_readfirstlane(poly_degree_lazy<NL>(w.vp, w.dvb, lane, P));
+    w.ok = w.dv >= 0;
+    w.F = (w.rp == w.R0) ? w.R1 : w.R0;
+    w.df = -1; w.dq = -1; w.i = -1; w.divided = false;
+    if (!w.ok) return;
+    for (int idx = lane; errloc && idx <= w.dv; idx += 64) {
+        uint32_t u[NL];
+        lds_get<NL>(u, w.vp + (size_t)idx * NL);
+        cond_sub_p(u, P);
+        store_digits<NL, NW>(errloc + ((size_t)c * (npts + 1) + idx) * NW, u);
+    }
+    if (w.dr < 0) return;
+    if (w.dr < w.dv) { w.ok = false; return; }       // non-zero remainder
+    w.dq = w.dr - w.dv; w.i = w.dq; w.divided = true;
+    __syncthreads();
+    if (lane < NL) w.S()[lane] = w.vp[(size_t)w.dv * NL + lane];
+}
+
+// one round of one codeword's pseudo-division: r <- l r - c_i x^i V below the leading term
+template <int NL> __device__ __forceinline__ void gao_division_round(GaoCw<NL> &w, int lane, const uint32_t *ZERO, const uint32_t *KD, const FpParams<NL> &P) {
+    uint32_t *LV = w.S(), *CN = w.S() + NL;
+    const int i = w.i, dv = w.dv;
+    if (lane < NL) { const uint32_t cq = w.rp[(size_t)(i + dv) * NL + lane]; w.F[(size_t)i * NL + lane] = cq; CN[lane] = KD[lane] - cq; }
+    __syncthreads();
+    for (int base = 0; base < i + dv; base += 64) {
+        const int idx = base + lane;
+        const bool act = idx < i + dv;
+        const uint32_t *pu = act ? w.rp + (size_t)idx * NL : ZERO;
+        const uint32_t *pw = (act && idx >= i) ? w.vp + (size_t)(idx - i) * NL : ZERO;
+        uint32_t r[NL];
+        gao_round2<NL>(r, LV, pu, CN, pw, P);
+        if (act) lds_put<NL>(w.rp + (size_t)idx * NL, r);
+    }
+    __syncthreads();
+    w.i = i - 1;
+}
+
+template <int NL, int NW>
+__device__ __forceinline__ void gao_cw_leaves(GaoCw<NL> &w, int64_t c, int k, uint32_t *__restrict__ coeffs, int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag,
+                                              uint32_t *__restrict__ side, int lane, const FpParams<NL> &P) {
+    if (w.divided) {
+        if (poly_degree_lazy<NL>(w.rp, w.dv - 1, lane, P) >= 0) w.ok = false;      // remainder must vanish (l != 0: scaled or not)
+        w.df = poly_degree_lazy<NL>(w.F, w.dq, lane, P);                            // c_i = l^(dq - i + 1) q_i: zero exactly where q_i is
+        if (w.df >= k) w.ok = false;
+    }
+    if (w.ok) {
+        for (int i = lane; i < k; i += 64) {
+            uint32_t o[NL];
+            if (i <= w.df) { lds_get<NL>(o, w.F + (size_t)i * NL); cond_sub_p(o, P); }
+            else {
+#pragma unroll
+                for (int q = 0; q < NL; q++) o[q] = 0;
+            }
+            store_digits<NL, NW>(coeffs + ((size_t)c * k + i) * NW, o);
+        }
+        if (lane == 0) {
+            uint32_t cs[NL], lcv[NL];
+            lds_get<NL>(cs, w.csp);
+            cond_sub_p(cs, P);
+            if (w.dv >= 0) lds_get<NL>(lcv, w.vp + (size_t)w.dv * NL); else fp_set(lcv, P.one);
+            cond_sub_p(lcv, P);
+            store_digits<NL, NW>(side + (size_t)c * (2 * NW + 4), cs);
+            store_digits<NL, NW>(side + (size_t)c * (2 * NW + 4) + NW, lcv);
+            side[(size_t)c * (2 * NW + 4) + 2 * NW] = (uint32_t)w.dq;
+            side[(size_t)c * (2 * NW + 4) + 2 * NW + 1] = (uint32_t)w.df;
+        }
+    }
+    if (lane == 0) { okflag[c] = w.ok ? 1 : 0; errlen[c] = w.ok ? w.dv + 1 : 0; }
+}
+
 template <int NL, int NW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAVES_PER_EU))) k_gao(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
                                             int npts, int k, int64_t C, uint32_t *__restrict__ coeffs, uint32_t *__restrict__ errloc,
@@ -162,305 +487,200 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAV
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int lane = threadIdx.x;
     const int64_t c = blockIdx.x;
-    const int len = npts + 1;
     // deg t_{i+1} + deg r_i = npts throughout the Euclid loop and it runs while deg r >= D: the cofactors never exceed degree
     // npts - D, so their arrays are short -- 10 KB of LDS per codeword instead of 14.5 at n = 100: 16 resident waves per CU, not 11
-    const int lenT = npts - (npts + k) / 2 + 3;
-    uint32_t *R0 = smem, *R1 = R0 + (size_t)len * NL, *T0 = R1 + (size_t)len * NL, *T1 = T0 + (size_t)lenT * NL;
-    uint32_t *ZERO = T1 + (size_t)lenT * NL;       // a zero element
-    uint32_t *S = ZERO + NL;                       // the three multipliers of a fused Euclid step: L^2, -(L a1), -a0 (residues)
-    uint32_t *NEGX = S + 3 * NL;                   // K - X, digit by digit, for the newest leading coefficient X (the jobs' subtracted multiplier)
-    uint32_t *CA = NEGX + NL, *CB = CA + NL;       // the scale factors c0, c1 of the fraction-free loop
-    uint32_t *KD = CB + NL;                        // K's redundant digits, for the lanes that negate element-wise
+    const int len = npts + 1, lenT = npts - (npts + k) / 2 + 3;
+    uint32_t *ZERO = smem + (size_t)gao_cw_words<NL>(len, lenT), *KD = ZERO + NL;      // a zero element; K's redundant digits, for the lanes that negate element-wise
     if (lane < NL) {
         uint32_t kq = 0;
 #pragma unroll
         for (int q = 0; q < NL; q++) kq = lane == q ? GK.kd[q] : kq;
-        ZERO[lane] = 0; CA[lane] = P.one[lane]; CB[lane] = P.one[lane]; KD[lane] = kq;
+        ZERO[lane] = 0; KD[lane] = kq;
     }
+    const int D = (npts + k) / 2;
+    GaoCw<NL> w;
+    gao_cw_init<NL, NW>(w, smem, len, lenT, g0, g1buf + (size_t)c * npts * NW, npts, k, lane, P);
+    // (degrees are the same in every lane: said to the compiler, so that the loop's control and pointer arithmetic stay scalar)
+    while (!w.done) {
+        gao_step_single<NL>(w, lane, ZERO, KD, P, GK);
+        gao_after_step<NL>(w, D, lane, P);
+    }
+    // ---- f = r / v (exact, deg f < k), v = V / cs: everything but the inversion ------------
+    gao_division_begins<NL, NW>(w, c, npts, errloc, lane, P);
+    while (w.i >= 0) gao_division_round<NL>(w, lane, ZERO, KD, P);
+    gao_cw_leaves<NL, NW>(w, c, k, coeffs, errlen, okflag, side, lane, P);
+}
 
-    for (int idx = lane; idx < len; idx += 64) {
-        uint32_t a[NL], z[NL], m[NL];
+// ---------------------------------------------------------------------------------------------------------------------
+// Two codewords a wave (point sets of at most 64 points): k_gao_pair
+// ---------------------------------------------------------------------------------------------------------------------
+// A fused Euclid step of k_gao is two rounds: the remainder (deg r1 lanes: 63 down to (n + k) / 2) and then the cofactor, the scale factor and
+// the three jobs that prepare the next step's multipliers (deg t + 5 lanes: 6 up to n - (n + k) / 2 + 5) -- the jobs need the first round's
+// two leading coefficients, so the two cannot be one round, and they are 69 lanes anyway.  The second round keeps a third of the wave
+// busy and costs what the first one does.  Here a wave works on TWO codewords: their remainder rounds one after the other, their
+// second rounds as ONE (codeword A's roles in lanes 0-31, codeword B's in lanes 32-63: a lane's role is nothing but its pointers) --
+// three rounds for two steps where k_gao spends four.  The pseudo-division shares its rounds the same way once a codeword's
+// remainder is down to 32 coefficients (the last dv + 11 of its 22 rounds at config 4).  A codeword that leaves the regular pattern
+// (degree anomalies: structured messages, few errors) or finishes early steps alone (gao_step_single: what k_gao runs),
+// and the pairing resumes when both are regular again.  Values are k_gao's, term by term.
+// the multipliers of the coming fused step when the previous step did not leave them (first step, after a degree anomaly); the codewords of
+// `who` (bit 0: A, bit 1: B), A's three jobs in lanes 28-30, B's in lanes 60-62
+template <int NL> __device__ __forceinline__ void gao_pair_multipliers(GaoCw<NL> &A, GaoCw<NL> &B, int who, int lane, const uint32_t *ZERO, const uint32_t *KD, const FpParams<NL> &P) {
+    const bool hb = lane >= 32;
+    const int l32 = lane & 31;
+    const bool mine = hb ? (who & 2) != 0 : (who & 1) != 0;
+    uint32_t *R0 = hb ? B.R0 : A.R0, *R1 = hb ? B.R1 : A.R1, *NEGX = hb ? B.NEGX() : A.NEGX(), *S = hb ? B.S() : A.S();
+    const int dR1 = hb ? B.dR1 : A.dR1;
+    __syncthreads();
+    if (mine && l32 < NL) NEGX[l32] = KD[l32] - R1[(size_t)dR1 * NL + l32];
+    __syncthreads();
+    // (X, Y, Z, W) = (L, lc r0, r0[deg r1], r1[deg r1 - 1])
+    const uint32_t *Xa = R1 + (size_t)dR1 * NL, *Ya = R0 + (size_t)(dR1 + 1) * NL, *Za = R0 + (size_t)dR1 * NL, *Wa = R1 + (size_t)(dR1 - 1) * NL;
+    const int jb = l32 - 28;
+    const bool isJ = mine && jb >= 0 && jb < 3;
+    const uint32_t *pm0 = ZERO, *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO;
+    if (isJ) { pm0 = jb == 0 ? Xa : NEGX; pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za); if (jb == 2) { pm1 = Ya; pw1 = Wa; } }
+    uint32_t r[NL];
+    gao_round2<NL>(r, pm0, pu, pm1, pw1, P);
+    if (isJ) lds_put<NL>(S + (size_t)jb * NL, r);
+    __syncthreads();
+}
+
+constexpr int GAO_PAIR_TTOP = 27;        // a codeword's half of the shared second round: cofactor coefficients 0 .. 27, three jobs, the scale factor
+
+template <int NL> __device__ __forceinline__ bool gao_pair_regular(const GaoCw<NL> &w) {
+    return !w.done && w.dR0 - w.dR1 == 1 && w.dR1 >= 2 && w.dR1 <= 64 && max(w.dT0, w.dT1 + 1) <= GAO_PAIR_TTOP;
+}
+
+// one fused Euclid step of BOTH codewords: three rounds
+template <int NL> __device__ __forceinline__ void gao_step_pair(GaoCw<NL> &A, GaoCw<NL> &B, int lane, const uint32_t *ZERO, const uint32_t *KD, const FpParams<NL> &P, const GaoConsts<NL> &GK) {
+    const int who = (A.have_sc ? 0 : 1) | (B.have_sc ? 0 : 2);
+    if (who) gao_pair_multipliers<NL>(A, B, who, lane, ZERO, KD, P);
+    {   // the two remainder rounds as ONE instruction stream: two independent chains for the scheduler (operand loads of one under the
+        // multiply-adds of the other, two reductions' carry chains interleaved)
+        const int topA = A.dR1, topB = B.dR1;
+        const bool actA = lane < topA, actB = lane < topB;
+        const int ia = topA - 1 - lane, ib = topB - 1 - lane;
+        const uint32_t *puA = ZERO, *pw1A = ZERO, *pw0A = ZERO, *puB = ZERO, *pw1B = ZERO, *pw0B = ZERO;
+        if (actA) { puA = A.R0 + (size_t)ia * NL; pw1A = ia >= 1 ? A.R1 + (size_t)(ia - 1) * NL : ZERO; pw0A = A.R1 + (size_t)ia * NL; }
+        if (actB) { puB = B.R0 + (size_t)ib * NL; pw1B = ib >= 1 ? B.R1 + (size_t)(ib - 1) * NL : ZERO; pw0B = B.R1 + (size_t)ib * NL; }
+        uint32_t ra[NL], rb[NL];
+        uint64_t ca[2 * NL], cb[2 * NL];
+        col_zero(ca); col_zero(cb);
+        { uint32_t m[NL], v[NL], m2[NL], v2[NL]; lds_get<NL>(m, A.S()); lds_get<NL>(v, puA); lds_get<NL>(m2, B.S()); lds_get<NL>(v2, puB); mac<NL>(ca, m, v); mac<NL>(cb, m2, v2); }
+        { uint32_t m[NL], v[NL], m2[NL], v2[NL]; lds_get<NL>(m, A.S() + NL); lds_get<NL>(v, pw1A); lds_get<NL>(m2, B.S() + NL); lds_get<NL>(v2, pw1B); mac<NL>(ca, m, v); mac<NL>(cb, m2, v2); }
+        { uint32_t m[NL], v[NL], m2[NL], v2[NL]; lds_get<NL>(m, A.S() + 2 * NL); lds_get<NL>(v, pw0A); lds_get<NL>(m2, B.S() + 2 * NL); lds_get<NL>(v2, pw0B); mac<NL>(ca, m, v); mac<NL>(cb, m2, v2); }
+        redc(ra, ca, P);
+        redc(rb, cb, P);
+        __syncthreads();
+        if (actA) lds_put<NL>(A.R0 + (size_t)ia * NL, ra);
+        if (actB) lds_put<NL>(B.R0 + (size_t)ib * NL, rb);
+        if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < NL; q++) { a[q] = g0[(size_t)idx * NL + q]; z[q] = 0; }
-        lds_put<NL>(R0 + (size_t)idx * NL, a);
-        if (idx < lenT) {
-            lds_put<NL>(T0 + (size_t)idx * NL, z);
-            if (idx == 0) lds_put<NL>(T1, P.one); else lds_put<NL>(T1 + (size_t)idx * NL, z);
+            for (int q = 0; q < NL; q++) { A.NEGX()[q] = GK.kd[q] - ra[q]; B.NEGX()[q] = GK.kd[q] - rb[q]; }
         }
-        if (idx < npts) {
-            uint32_t yd[NL];
-            load_digits<NL, NW>(yd, g1buf + ((size_t)c * npts + idx) * NW);      // chunk-major: a wave reads its codeword's 32 npts bytes in one piece
-            to_mont(m, yd, P);
-            lds_put<NL>(R1 + (size_t)idx * NL, m);
-        } else lds_put<NL>(R1 + (size_t)idx * NL, z);
     }
     __syncthreads();
-    // (degrees are the same in every lane: said to the compiler, so that the loop's control and pointer arithmetic stay scalar)
-    int dR0 = npts, dR1 = __builtin_amdgcn_readfirstlane(poly_degree<NL>(R1, npts - 1, lane)), dT0 = -1, dT1 = 0;
+    {   // the shared second round: cofactor, c0 <- L^2 c0 and the next step's multipliers, of A in lanes 0-31 and of B in lanes 32-63
+        const bool hb = lane >= 32;
+        const int l32 = lane & 31;
+        uint32_t *R0 = hb ? B.R0 : A.R0, *R1 = hb ? B.R1 : A.R1, *T0 = hb ? B.T0 : A.T0, *T1 = hb ? B.T1 : A.T1;
+        uint32_t *S = hb ? B.S() : A.S(), *NEGX = hb ? B.NEGX() : A.NEGX(), *CA = hb ? B.CA() : A.CA();
+        const int top = hb ? B.dR1 : A.dR1, dT1 = hb ? B.dT1 : A.dT1, dT0 = hb ? B.dT0 : A.dT0;
+        const int ttop = max(dT0, dT1 + 1);
+        const uint32_t *Xa = R0 + (size_t)(top - 1) * NL, *Ya = R1 + (size_t)top * NL, *Za = R1 + (size_t)(top - 1) * NL, *Wa = R0 + (size_t)(top - 2) * NL;
+        const uint32_t *pm0 = S, *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO, *pm2 = ZERO, *pw0 = ZERO;
+        uint32_t *dst = nullptr;
+        const int jb = l32 - 28;
+        if (l32 <= ttop) {
+            const int idx = l32;
+            pu = T0 + (size_t)idx * NL;
+            pw1 = (idx >= 1 && idx - 1 <= dT1) ? T1 + (size_t)(idx - 1) * NL : ZERO;
+            pw0 = idx <= dT1 ? T1 + (size_t)idx * NL : ZERO;
+            pm1 = S + NL; pm2 = S + 2 * NL; dst = T0 + (size_t)idx * NL;
+        } else if (jb >= 0 && jb < 3) {
+            pm0 = jb == 0 ? Xa : NEGX; pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za);
+            if (jb == 2) { pm1 = Ya; pw1 = Wa; }
+            dst = S + (size_t)jb * NL;
+        } else if (l32 == 31) { pu = CA; dst = CA; }
+        uint32_t r[NL];
+        gao_round<NL>(r, pm0, pu, pm1, pw1, pm2, pw0, P);
+        __syncthreads();                 // (the jobs overwrite the multipliers every other lane has just read)
+        if (dst) lds_put<NL>(dst, r);
+        if (l32 < 2) {
+#pragma unroll
+            for (int q = 0; q < NL; q++) R0[(size_t)(top + l32) * NL + q] = 0;
+        }
+        __syncthreads();
+    }
+    A.dT0 = max(A.dT0, A.dT1 + 1); B.dT0 = max(B.dT0, B.dT1 + 1);
+    A.have_sc = true; B.have_sc = true;
+}
+
+// ... and of two codewords whose remainders are down to 32 coefficients each
+template <int NL> __device__ __forceinline__ void gao_division_round_pair(GaoCw<NL> &A, GaoCw<NL> &B, int lane, const uint32_t *ZERO, const uint32_t *KD, const FpParams<NL> &P) {
+    const bool hb = lane >= 32;
+    const int l32 = lane & 31;
+    uint32_t *rp = hb ? B.rp : A.rp, *vp = hb ? B.vp : A.vp, *F = hb ? B.F : A.F, *S = hb ? B.S() : A.S();
+    const int i = hb ? B.i : A.i, dv = hb ? B.dv : A.dv;
+    uint32_t *LV = S, *CN = S + NL;
+    if (l32 < NL) { const uint32_t cq = rp[(size_t)(i + dv) * NL + l32]; F[(size_t)i * NL + l32] = cq; CN[l32] = KD[l32] - cq; }
+    __syncthreads();
+    const bool act = l32 < i + dv;
+    const uint32_t *pu = act ? rp + (size_t)l32 * NL : ZERO;
+    const uint32_t *pw = (act && l32 >= i) ? vp + (size_t)(l32 - i) * NL : ZERO;
+    uint32_t r[NL];
+    gao_round2<NL>(r, LV, pu, CN, pw, P);
+    if (act) lds_put<NL>(rp + (size_t)l32 * NL, r);
+    __syncthreads();
+    A.i -= 1; B.i -= 1;
+}
+
+template <int NL, int NW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GAO_WAVES_PER_EU))) k_gao_pair(const FpParams<NL> P, const uint32_t *__restrict__ g0, const uint32_t *__restrict__ g1buf,
+                                            int npts, int k, int64_t C, uint32_t *__restrict__ coeffs, uint32_t *__restrict__ errloc,
+                                            int32_t *__restrict__ errlen, uint8_t *__restrict__ okflag, uint32_t *__restrict__ side, const GaoConsts<NL> GK) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int lane = threadIdx.x;
+    const int64_t ca = 2 * (int64_t)blockIdx.x, cb = ca + 1;
+    const bool two = cb < C;                                 // (an odd batch's last wave has one codeword)
+    const int len = npts + 1, lenT = npts - (npts + k) / 2 + 3;
+    const int per = gao_cw_words<NL>(len, lenT);
+    uint32_t *ZERO = smem + (size_t)2 * per, *KD = ZERO + NL;
+    if (lane < NL) {
+        uint32_t kq = 0;
+#pragma unroll
+        for (int q = 0; q < NL; q++) kq = lane == q ? GK.kd[q] : kq;
+        ZERO[lane] = 0; KD[lane] = kq;
+    }
     const int D = (npts + k) / 2;
-    uint32_t *rp, *vp, *csp; int dr, dvb;
-    if (dR0 < D) {                     // rsdecode_impl.h:289-294 (cannot fire: deg g0 = n >= D)
-        rp = R0; vp = T0; dr = dR0; dvb = dT0; csp = CA;
-    } else if (dR1 < D) {              // rsdecode_impl.h:296-301
-        rp = R1; vp = T1; dr = dR1; dvb = dT1; csp = CB;
-    } else {
-        bool have_sc = false;               // S holds the multipliers of the coming fused step (computed by the previous one) and NEGX = -lc(r1)
-        for (;;) {
-            const int delta = dR0 - dR1;
-            // The generic division step (degrees drop one at a time), fused: its two pseudo-division sub-steps
-            //     r' = L r0 - a1 X r1,   a0 = r'[deg r1],   r'' = L r' - a0 r1
-            // are ONE update r''[i] = L^2 r0[i] - (L a1) r1[i-1] - a0 r1[i] (the same on the cofactor; c0 <- L^2 c0): three products and one
-            // reduction per coefficient where the sub-steps take four and two.  The three multipliers of a step cost four modular
-            // multiplications -- executed by the whole wave they would eat the gain (round 4 measured it: 45 ms against 38) -- so those
-            // of the NEXT step are computed by three otherwise idle lanes of this step's second round: the first round takes the TOP 64
-            // coefficients of the remainder, so the two leading coefficients of r'' the next multipliers need are there when the second
-            // round (the rest of the remainder, the cofactor, c0, the three jobs) starts.  With (X, Y, Z, W) = (lc r'', L, r1[deg r1 - 1],
-            // r''[deg r'' - 1]): job0 = X X, job1 = -X Y, job2 = Y W - X Z -- the residues of the NEGATED multipliers, so that the
-            // update is a plain sum S0 u + S1 w1 + S2 w0; the jobs subtract through NEGX, the digit-wise negation of X that the lane which
-            // computed X left in LDS (K - X in K's redundant digits: GaoConsts).  Values equal to the sub-steps' mod p, term by term.
-            const int ttop_f = max(dT0, dT1 + 1), n2_f = max(0, dR1 - 64);
-            if (delta == 1 && dR1 >= 2 && n2_f + ttop_f + 1 <= 60) {
-                const int top = dR1, ttop = ttop_f, n2 = n2_f;
-                const int jb = lane - 60;
-                const bool isJ = lane >= 60 && lane < 63;
-                if (!have_sc) {
-                    // the multipliers of THIS step alone (first step, or after a degree anomaly): (X, Y, Z, W) = (L, lc r0, r0[deg r1], r1[deg r1 - 1])
-                    __syncthreads();
-                    if (lane < NL) NEGX[lane] = KD[lane] - R1[(size_t)dR1 * NL + lane];
-                    __syncthreads();
-                    const uint32_t *Xa = R1 + (size_t)dR1 * NL, *Ya = R0 + (size_t)(dR1 + 1) * NL, *Za = R0 + (size_t)dR1 * NL, *Wa = R1 + (size_t)(dR1 - 1) * NL;
-                    const uint32_t *pm0 = ZERO, *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO;
-                    if (isJ) { pm0 = jb == 0 ? Xa : NEGX; pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za); if (jb == 2) { pm1 = Ya; pw1 = Wa; } }
-                    uint32_t r[NL];
-                    gao_round2<NL>(r, pm0, pu, pm1, pw1, P);
-                    if (isJ) lds_put<NL>(S + (size_t)jb * NL, r);
-                    __syncthreads();
-                }
-                {   // first round: the top 64 coefficients of the remainder; lane 0's is X = lc r''
-                    const bool act = lane < min(64, top);
-                    const int idx = top - 1 - lane;
-                    const uint32_t *pu = ZERO, *pw1 = ZERO, *pw0 = ZERO;
-                    if (act) { pu = R0 + (size_t)idx * NL; pw1 = idx >= 1 ? R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = R1 + (size_t)idx * NL; }
-                    uint32_t r[NL];
-                    gao_round<NL>(r, S, pu, S + NL, pw1, S + 2 * NL, pw0, P);
-                    __syncthreads();             // (one wave: orders this round's LDS reads before its writes -- a lane's neighbour reads R1 only, but lane 0 overwrites NEGX)
-                    if (act) lds_put<NL>(R0 + (size_t)idx * NL, r);
-                    if (lane == 0) {
-#pragma unroll
-                        for (int q = 0; q < NL; q++) NEGX[q] = GK.kd[q] - r[q];
-                    }
-                    __syncthreads();
-                }
-                {   // second round: the rest of the remainder, the cofactor, c0, and the next step's multipliers
-                    const uint32_t *Xa = R0 + (size_t)(top - 1) * NL, *Ya = R1 + (size_t)dR1 * NL, *Za = R1 + (size_t)(dR1 - 1) * NL, *Wa = R0 + (size_t)(top - 2) * NL;
-                    const uint32_t *pm0 = S, *pu = ZERO, *pm1 = ZERO, *pw1 = ZERO, *pm2 = ZERO, *pw0 = ZERO;
-                    uint32_t *dst = nullptr;
-                    if (lane < n2) {
-                        const int idx = n2 - 1 - lane;
-                        pu = R0 + (size_t)idx * NL; pw1 = idx >= 1 ? R1 + (size_t)(idx - 1) * NL : ZERO; pw0 = R1 + (size_t)idx * NL;
-                        pm1 = S + NL; pm2 = S + 2 * NL; dst = R0 + (size_t)idx * NL;
-                    } else if (lane <= n2 + ttop) {
-                        const int idx = lane - n2;
-                        pu = T0 + (size_t)idx * NL;
-                        pw1 = (idx >= 1 && idx - 1 <= dT1) ? T1 + (size_t)(idx - 1) * NL : ZERO;
-                        pw0 = idx <= dT1 ? T1 + (size_t)idx * NL : ZERO;
-                        pm1 = S + NL; pm2 = S + 2 * NL; dst = T0 + (size_t)idx * NL;
-                    } else if (isJ) {
-                        pm0 = jb == 0 ? Xa : NEGX; pu = jb == 0 ? Xa : (jb == 1 ? Ya : Za);
-                        if (jb == 2) { pm1 = Ya; pw1 = Wa; }
-                        dst = S + (size_t)jb * NL;
-                    } else if (lane == 63) { pu = CA; dst = CA; }          // c0 <- L^2 c0
-                    uint32_t r[NL];
-                    gao_round<NL>(r, pm0, pu, pm1, pw1, pm2, pw0, P);
-                    __syncthreads();             // (the jobs overwrite the multipliers every other lane has just read)
-                    if (dst) lds_put<NL>(dst, r);
-                    if (lane < 2) {
-#pragma unroll
-                        for (int q = 0; q < NL; q++) R0[(size_t)(top + lane) * NL + q] = 0;
-                    }
-                    __syncthreads();
-                }
-                dT0 = ttop;
-                have_sc = true;                  // (withdrawn below if the degree did not drop by exactly one)
-            } else {
-            have_sc = false;
-            uint32_t L[NL], c0[NL];
-            lds_get<NL>(L, R1 + (size_t)dR1 * NL);
-            lds_get<NL>(c0, CA);
-            for (int j = delta; j >= 0; j--) {
-                uint32_t a[NL], an[NL];
-                lds_get<NL>(a, R0 + (size_t)(dR1 + j) * NL);
-                cond_sub_p(a, P);                 // (lazy residues: canonical before the negation)
-                fp_neg(an, a, P);                 // L u - a w = L u + (p - a) w: ONE reduction for the two products (columns stay below
-                                                  // 3 NL 2^58 < 2^63; the sum is < 3 p^2 < p R / 8, so REDC leaves < 2p: one conditional subtraction)
-                __syncthreads();
-                const int top = dR1 + j;
-                const int ttop = max(dT0, dT1 + j);
-                // One update, r <- L u + (p - a) w, for every coefficient of the remainder R0 below `top` (w = R1[idx - j]) and of the cofactor
-                // T0 up to `ttop` (w = T1[idx - j]), and c0 <- L c0.  deg R0 + deg T0 stays about npts, so what the remainder leaves of its
-                // last round of 64 lanes holds the whole cofactor AND the scale factor: two rounds a step at n = 100 where three and a
-                // wave-wide multiplication were.
-                int base = 0;
-                for (; base + 64 <= top; base += 64) {
-                    const int idx = base + lane;
-                    uint32_t u[NL], r[NL];
-                    uint64_t col[2 * NL];
-                    lds_get<NL>(u, R0 + (size_t)idx * NL);
-                    col_zero(col);
-                    mac<NL>(col, L, u);
-                    if (idx >= j) {
-                        uint32_t w[NL];
-                        lds_get<NL>(w, R1 + (size_t)(idx - j) * NL);
-                        mac<NL>(col, an, w);
-                    }
-                    redc(r, col, P);
-                    cond_sub_p(r, P);
-                    lds_put<NL>(R0 + (size_t)idx * NL, r);
-                }
-                const int n2 = top - base;                       // lanes the remainder still needs: 0 .. 63
-                const bool merged = n2 + ttop + 1 <= 63;         // ... and the cofactor beside them, lane 63 for c0
-                {
-                    const bool isR = lane < n2, isT = merged && lane >= n2 && lane <= n2 + ttop, cz = merged && lane == 63;
-                    uint32_t hand[NL];
-#pragma unroll
-                    for (int q = 0; q < NL; q++) hand[q] = 0;
-                    if (isR || isT || cz) {
-                        uint32_t *A = isR ? R0 : T0;
-                        const uint32_t *B = isR ? R1 : T1;
-                        const int idx = isR ? base + lane : lane - n2;
-                        const bool second = isR ? idx >= j : (isT && idx >= j && idx - j <= dT1);
-                        uint32_t u[NL], r[NL];
-                        uint64_t col[2 * NL];
-                        if (cz) fp_set(u, c0); else lds_get<NL>(u, A + (size_t)idx * NL);
-                        col_zero(col);
-                        mac<NL>(col, L, u);
-                        if (second) {
-                            uint32_t w[NL];
-                            lds_get<NL>(w, B + (size_t)(idx - j) * NL);
-                            mac<NL>(col, an, w);
-                        }
-                        redc(r, col, P);
-                        cond_sub_p(r, P);
-                        if (!cz) lds_put<NL>(A + (size_t)idx * NL, r);
-#pragma unroll
-                        for (int q = 0; q < NL; q++) hand[q] = r[q];
-                    }
-                    if (merged) {
-#pragma unroll
-                        for (int q = 0; q < NL; q++) c0[q] = (uint32_t)__builtin_amdgcn_readlane((int)hand[q], 63);
-                    }
-                }
-                if (lane == 0) {
-#pragma unroll
-                    for (int q = 0; q < NL; q++) R0[(size_t)top * NL + q] = 0;
-                }
-                if (!merged) {
-                    for (int idx = lane; idx <= ttop; idx += 64) {
-                        uint32_t u[NL], r[NL];
-                        uint64_t col[2 * NL];
-                        lds_get<NL>(u, T0 + (size_t)idx * NL);
-                        col_zero(col);
-                        mac<NL>(col, L, u);
-                        if (idx >= j && idx - j <= dT1) {
-                            uint32_t w[NL];
-                            lds_get<NL>(w, T1 + (size_t)(idx - j) * NL);
-                            mac<NL>(col, an, w);
-                        }
-                        redc(r, col, P);
-                        cond_sub_p(r, P);
-                        lds_put<NL>(T0 + (size_t)idx * NL, r);
-                    }
-                    mont_mul(c0, c0, L, P);           // c0 <- lc(r1)^(delta+1) * c0, one factor per step
-                }
-                dT0 = ttop;
-                __syncthreads();
-            }
-            if (lane == 0) lds_put<NL>(CA, c0);
-            __syncthreads();
-            }
-            {   // the degree drops by exactly one as a rule: look at that coefficient before scanning the polynomial
-                uint32_t topc[NL];
-                bool nz = false;
-                if (dR1 >= 1) { lds_get<NL>(topc, R0 + (size_t)(dR1 - 1) * NL); nz = !is_zero_lazy<NL>(topc, P); }
-                dR0 = __builtin_amdgcn_readfirstlane(nz ? dR1 - 1 : poly_degree_lazy<NL>(R0, dR1 - 1, lane, P));
-                if (dR0 != dR1 - 1) have_sc = false;     // the next step's multipliers were computed for a remainder of degree deg r1 - 1
-            }
-            if (dR0 < D) { rp = R0; vp = T0; dr = dR0; dvb = dT0; csp = CA; break; }
-            // (r0, r1) <- (r1, r2)
-            uint32_t *tp = R0; R0 = R1; R1 = tp;
-            tp = T0; T0 = T1; T1 = tp;
-            tp = CA; CA = CB; CB = tp;
-            int ti = dR0; dR0 = dR1; dR1 = ti;
-            ti = dT0; dT0 = dT1; dT1 = ti;
+    GaoCw<NL> A, B;
+    gao_cw_init<NL, NW>(A, smem, len, lenT, g0, g1buf + (size_t)ca * npts * NW, npts, k, lane, P);
+    gao_cw_init<NL, NW>(B, smem + per, len, lenT, g0, g1buf + (size_t)(two ? cb : ca) * npts * NW, npts, k, lane, P);
+    if (!two) gao_loop_ends<NL>(B, true);
+    while (!A.done || !B.done) {
+        if (gao_pair_regular<NL>(A) && gao_pair_regular<NL>(B)) {
+            gao_step_pair<NL>(A, B, lane, ZERO, KD, P, GK);
+            gao_after_step<NL>(A, D, lane, P);
+            gao_after_step<NL>(B, D, lane, P);
+        } else {
+            if (!A.done) { gao_step_single<NL>(A, lane, ZERO, KD, P, GK); gao_after_step<NL>(A, D, lane, P); }
+            if (!B.done) { gao_step_single<NL>(B, lane, ZERO, KD, P, GK); gao_after_step<NL>(B, D, lane, P); }
         }
     }
     // ---- f = r / v (exact, deg f < k), v = V / cs: everything but the inversion ------------
-    const int dv = __builtin_amdgcn_readfirstlane(poly_degree_lazy<NL>(vp, dvb, lane, P));
-    bool ok = dv >= 0;
-    uint32_t *F = (rp == R0) ? R1 : R0;            // the remainder array not in use: the raw quotient digits c_i (up to D of them)
-    uint32_t *LV = S, *CN = S + NL;                // lc(V) and the negated quotient digit of the round, where the Euclid loop kept its multipliers
-    int df = -1, dq = -1;
-    if (ok) {
-        // the cofactor V as it is (Montgomery form, packed, canonical): k_gao_finish scales it by 1 / cs
-        // (errloc == nullptr: the caller wants the locator's degree only -- hb_wb_decode)
-        for (int idx = lane; errloc && idx <= dv; idx += 64) {
-            uint32_t u[NL];
-            lds_get<NL>(u, vp + (size_t)idx * NL);
-            cond_sub_p(u, P);
-            store_digits<NL, NW>(errloc + ((size_t)c * (npts + 1) + idx) * NW, u);
-        }
-        if (dr >= 0) {
-            if (dr < dv) ok = false;               // non-zero remainder
-            else {
-                dq = dr - dv;
-                __syncthreads();
-                if (lane < NL) LV[lane] = vp[(size_t)dv * NL + lane];
-                for (int i = dq; i >= 0; i--) {
-                    // r <- l r - c_i x^i V below the leading term (which cancels): every remaining coefficient takes the factor l
-                    if (lane < NL) { const uint32_t cq = rp[(size_t)(i + dv) * NL + lane]; F[(size_t)i * NL + lane] = cq; CN[lane] = KD[lane] - cq; }
-                    __syncthreads();
-                    for (int base = 0; base < i + dv; base += 64) {
-                        const int idx = base + lane;
-                        const bool act = idx < i + dv;
-                        const uint32_t *pu = act ? rp + (size_t)idx * NL : ZERO;
-                        const uint32_t *pw = (act && idx >= i) ? vp + (size_t)(idx - i) * NL : ZERO;
-                        uint32_t r[NL];
-                        gao_round2<NL>(r, LV, pu, CN, pw, P);
-                        if (act) lds_put<NL>(rp + (size_t)idx * NL, r);         // (a lane reads and writes its own coefficient of r; V is read only)
-                    }
-                    __syncthreads();
-                }
-                if (poly_degree_lazy<NL>(rp, dv - 1, lane, P) >= 0) ok = false;   // remainder must vanish (l != 0: scaled or not)
-                df = poly_degree_lazy<NL>(F, dq, lane, P);                        // c_i = l^(dq - i + 1) q_i: zero exactly where q_i is
-                if (df >= k) ok = false;
-            }
+    gao_division_begins<NL, NW>(A, ca, npts, errloc, lane, P);
+    if (two) gao_division_begins<NL, NW>(B, cb, npts, errloc, lane, P); else { B.i = -1; B.divided = false; B.ok = false; }
+    __syncthreads();
+    while (A.i >= 0 || B.i >= 0) {
+        if (A.i >= 0 && B.i >= 0 && A.i + A.dv <= 32 && B.i + B.dv <= 32) gao_division_round_pair<NL>(A, B, lane, ZERO, KD, P);
+        else {
+            if (A.i >= 0) gao_division_round<NL>(A, lane, ZERO, KD, P);
+            if (B.i >= 0) gao_division_round<NL>(B, lane, ZERO, KD, P);
         }
     }
-    if (ok) {
-        for (int i = lane; i < k; i += 64) {
-            uint32_t o[NL];
-            if (i <= df) { lds_get<NL>(o, F + (size_t)i * NL); cond_sub_p(o, P); }
-            else {
-#pragma unroll
-                for (int q = 0; q < NL; q++) o[q] = 0;
-            }
-            store_digits<NL, NW>(coeffs + ((size_t)c * k + i) * NW, o);
-        }
-        // side record: cs, l (Montgomery form, packed, canonical), dq
-        if (lane == 0) {
-            uint32_t cs[NL], lcv[NL];
-            lds_get<NL>(cs, csp);
-            cond_sub_p(cs, P);
-            if (dv >= 0) lds_get<NL>(lcv, vp + (size_t)dv * NL); else fp_set(lcv, P.one);
-            cond_sub_p(lcv, P);
-            store_digits<NL, NW>(side + (size_t)c * (2 * NW + 4), cs);
-            store_digits<NL, NW>(side + (size_t)c * (2 * NW + 4) + NW, lcv);
-            side[(size_t)c * (2 * NW + 4) + 2 * NW] = (uint32_t)dq;
-            side[(size_t)c * (2 * NW + 4) + 2 * NW + 1] = (uint32_t)df;
-        }
-    }
-    if (lane == 0) { okflag[c] = ok ? 1 : 0; errlen[c] = ok ? dv + 1 : 0; }
+    gao_cw_leaves<NL, NW>(A, ca, k, coeffs, errlen, okflag, side, lane, P);
+    if (two) gao_cw_leaves<NL, NW>(B, cb, k, coeffs, errlen, okflag, side, lane, P);
 }
 
 // A workgroup of one wave finishes 64 GAO_FIN_G consecutive codewords.  Lane t owns codewords base + t, base + 64 + t, ... (GAO_FIN_G of them):
@@ -723,6 +943,12 @@ int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const u
     rc = launch_matvec(ctx, Vi, (const uint32_t *)ys_dev, iv, sel_dev, INT64_MAX, g1, ov, INT64_MAX, nullptr, nullptr, C, s);
     if (rc) { (void)hipStreamSynchronize(s); return rc; }          // (nothing of this call may still be writing the scratch when the next one starts)
     size_t lds = (size_t)(2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 8) * NLr * 4;      // R0, R1, T0, T1, a zero element, three multipliers, -X, c0, c1, K
+    // point sets of at most 64 points, batches that fill the chip several times over: two codewords a wave (k_gao_pair: 19 % fewer vector
+    // instructions a codeword, 11 % less time at n = 64; a wave's own run is 1.4 times longer, so a batch that leaves SIMDs idle anyway keeps
+    // one codeword a wave).  HB_GAO_PAIR=1 / 0 forces the choice (same values either way: tests/test_gpu_parity.py)
+    const char *pair_env = getenv("HB_GAO_PAIR");
+    const bool pair = npts <= 64 && C >= 2 && (pair_env ? pair_env[0] == '1' : C >= 12288);
+    const size_t pair_lds = (size_t)(2 * (2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 6) + 2) * NLr * 4;
     // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one
     uint32_t *side = nullptr;
     const size_t side_words = (size_t)(2 * ctx->elem_words() + 4);      // (16-byte rows)
@@ -762,7 +988,11 @@ int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const u
         memcpy(gk.kd, kd, sizeof gk.kd);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (!fin_walk) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao_finish<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
-        k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
+        if (pair) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao_pair<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds);
+            k_gao_pair<9, 8><<<(unsigned)((C + 1) / 2), 64, pair_lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
+        } else
+            k_gao<9, 8><<<(unsigned)C, 64, lds, s>>>(ctx->pw, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
         if (fin_walk) k_gao_finish_walk<9, 8><<<walk_blocks, 64, 0, s>>>(ctx->pw, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
         else k_gao_finish<9, 8><<<fin_blocks, 64, fin_lds, s>>>(ctx->pw, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, kp);
     } else {
@@ -770,7 +1000,11 @@ int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const u
         if (!fin_walk) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao_finish<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)fin_lds);
         GaoConsts<3> gk;
         memcpy(gk.kd, kd, sizeof gk.kd);
-        k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
+        if (pair) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_gao_pair<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds);
+            k_gao_pair<3, 2><<<(unsigned)((C + 1) / 2), 64, pair_lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
+        } else
+            k_gao<3, 2><<<(unsigned)C, 64, lds, s>>>(ctx->pn, g0, g1, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, gk);
         if (fin_walk) k_gao_finish_walk<3, 2><<<walk_blocks, 64, 0, s>>>(ctx->pn, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side);
         else k_gao_finish<3, 2><<<fin_blocks, 64, fin_lds, s>>>(ctx->pn, npts, k, C, (uint32_t *)coeffs_dev, (uint32_t *)errloc_dev, errloc_len_dev, ok_dev, side, kp);
     }

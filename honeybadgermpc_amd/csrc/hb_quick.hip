@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
     __shared__ int deg[4], ctl[8], sdeg[2];
     __shared__ uint16_t fedl[PROBE_MAXN];                     // the parties fed so far, in order (persisted with the state)
     __shared__ uint32_t serr[PROBE_MAXN / 4];                 // the verdict's error bytes, gathered before they cross to the host
-    __shared__ uint32_t dl[2][NL], yv[NL];
+    __shared__ uint32_t dl[2][NL];
     const int tid = threadIdx.x;
     const size_t cwords = (size_t)4 * S * NL, vwords = (size_t)4 * n * NL, words = cwords + vwords;
     for (int i = tid; i < n * NL; i += PROBE_NT) xl[i] = xm[i];

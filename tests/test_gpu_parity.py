@@ -835,6 +835,54 @@ def test_gao_lazy_residues_many_words(hip, p, n, k):
     assert got == want
 
 
+@pytest.mark.parametrize("p,n,k", [(P, 64, 22), (P, 16, 6), (P, 4, 2), (53, 22, 8), (13, 12, 4), ((1 << 256) - 189, 31, 11), ((1 << 64) - 59, 40, 10), (257, 64, 2)])
+def test_gao_two_codewords_a_wave_vs_oracle(hip, monkeypatch, p, n, k):
+    """k_gao_pair (point sets of at most 64 points: two codewords a wave, their narrow rounds shared) is what large batches run; HB_GAO_PAIR=1
+    selects it for any batch.  Neighbouring codewords of every kind: regular ones that step together, structured messages and small fields whose
+    degree anomalies make a codeword step alone, words beyond the radius that end early, an odd batch (the last wave holds one codeword)."""
+    from structured import KINDS, coordinated_errors, structured_message
+
+    monkeypatch.setenv("HB_GAO_PAIR", "1")
+    rnd = random.Random(n * 131 + k)
+    x = list(range(1, n + 1)) if p > n else list(range(n))
+    emax = (n - k) // 2
+    words = []
+    for trial in range(181):
+        msg = structured_message(rnd, k, p, (KINDS + ["full"])[trial % 6] if trial % 3 == 0 else None)
+        enc = oracle.vandermonde_batch_evaluate(x, [msg], p)[0]
+        ne = min([emax, emax, 0, emax // 2, 1 if emax else 0, emax + 1, emax, n, emax + 2][(trial * 7 + trial // 9) % 9], n)
+        if trial % 10 == 9 and ne:
+            words.append(coordinated_errors(rnd, enc, x, k, ne, p, lambda xs, cf: oracle.vandermonde_batch_evaluate(xs, [cf], p)[0])[0])
+        else:
+            words.append(_corrupt(rnd, enc, ne, 0, p)[0])
+    got = hip.gao_interpolate_batch(x, words, k, p)
+    assert got == oracle.gao_interpolate_batch(x, words, k, p)
+    monkeypatch.setenv("HB_GAO_PAIR", "0")
+    assert hip.gao_interpolate_batch(x, words, k, p) == got
+
+
+def test_gao_large_batches_pair_up_by_themselves(hip, monkeypatch):
+    """the default choice at 16 384 codewords of config 3's shape is two a wave: the same values as one a wave, and the oracle's on a sample"""
+    n, k = 64, 22
+    rnd = random.Random(77)
+    x = list(range(1, n + 1))
+    base = []
+    for ne in (21, 21, 20, 0, 22, 7, 21, 1):
+        msg = [rnd.randrange(P) for _ in range(k)]
+        base.append(_corrupt(rnd, oracle.vandermonde_batch_evaluate(x, [msg], P)[0], ne, 0, P)[0])
+    words = []
+    for i in range(16384 + 1):
+        w = list(base[(i * 5 + i // 8) % 8])
+        w[i % n] = (w[i % n] + i) % P                       # (one more altered symbol: words at the radius go past it, the others stay decodable)
+        words.append(w)
+    monkeypatch.delenv("HB_GAO_PAIR", raising=False)
+    got = hip.gao_interpolate_batch(x, words, k, P)
+    assert got[:96] == oracle.gao_interpolate_batch(x, words[:96], k, P)
+    assert sum(g[0] is None for g in got) > 1000 and sum(g[0] is not None for g in got) > 1000
+    monkeypatch.setenv("HB_GAO_PAIR", "0")
+    assert hip.gao_interpolate_batch(x, words, k, P) == got
+
+
 @pytest.mark.parametrize("p,n,k,reps", [(P, 100, 34, 6), (P, 64, 22, 8), (53, 22, 8, 40), (13, 10, 3, 40), (P, 7, 1, 6)])
 def test_wb_batch_vs_oracle(p, n, k, reps):
     from honeybadgermpc_amd.device import wb_decode_batch
