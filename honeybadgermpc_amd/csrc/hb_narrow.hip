@@ -18,8 +18,9 @@
 //     and 5 scalar operations an entry saturate it; the entry's three digits laid out by the host -- 72 scalar words a row do not fit the
 //     scalar file, the compiler falls back to single-word loads and 212 vector registers; the row group's entries as three digits in LDS,
 //     read by broadcast against the inputs' two halves -- 124 registers, four waves a SIMD, 102 us an open against 88: the staged inputs
-//     and the entries share the LDS, and the launches are not issue-bound to begin with -- PMC: a wave lives 3 us of a 16 us launch, the
-//     SIMDs hold 0.6 waves on average: ramp-up and tail of three short launches are a third of the open.)
+//     and the entries share the LDS.  A term-major nest -- a thread accumulating all rows of its group, inputs and entries fetched a term
+//     ahead -- 27.7 us against 25.6 for the R2 launch.  PMC: 8.4 M vector instructions in that launch are 15 us of issue; a row is 144
+//     multiply-adds and ~100 instructions of assembling and reducing its 134-bit sum.)
 //   * entries are kept as M 2^128 mod p, so the sum (< 40 p 2^64) comes back through four 32-bit Montgomery steps (R = 2^128) and one
 //     conditional subtraction: canonical output, no pre-scale, nothing but the inputs and the outputs touches HBM;
 //   * per row a mode as in hb_mfma_fused.hip: store (a coefficient row / an encoded row) or compare with the received row of a later arrival.
