@@ -508,6 +508,26 @@ __global__ void k_quick_pick(const QuickIdx ix, int nc, int n_coef, int tile_row
 // ---------------------------------------------------------------------------------------------------------------------
 struct ProbeResult { int32_t ok, n_err, npts, seq; uint8_t err[PROBE_MAXN]; };    // seq: written last, the host polls it
 
+// A probe over several workgroups (point sets above PROBE_SPLIT_N points): workgroup 0 holds the coefficients, the others a slice of the
+// value table each.  What they tell each other, per point fed, through global memory (a slot per point of the launch, so nobody overwrites
+// what a slower workgroup has not read; a slot's last word is the sequence number that says it is complete):
+//   the discrepancies of the point (from the workgroup that holds the values at that party): 2 NL words + 2 flags     [PROBE_DW words]
+//   the degrees after the point (from workgroup 0: a leading coefficient may cancel, only the coefficients show it)    [PROBE_GW words]
+// and, at the end of a launch, "my slice is back in the state" from every value workgroup (PROBE_MAXG words).
+constexpr int PROBE_SPLIT_N = 128;
+constexpr int PROBE_MAXG = 8;
+constexpr int PROBE_DW = 24, PROBE_GW = 8;
+constexpr size_t PROBE_MSG_WORDS = (size_t)PROBE_MAXN * (PROBE_DW + PROBE_GW) + PROBE_MAXG;
+constexpr size_t PROBE_STATE_WORDS = (size_t)4 * (2 * PROBE_MAXN + 2) * 9 + 8 + PROBE_MAXN;      // the largest state: coefficients + values of 256 points, degrees, the fed list
+__device__ __forceinline__ void probe_wait(const uint32_t *flag, uint32_t want) {
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
+    __threadfence();
+}
+__device__ __forceinline__ void probe_post(uint32_t *flag, uint32_t value) {
+    __threadfence();
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int NL> __device__ __forceinline__ bool lds_nonzero(const uint32_t *p) {
     uint32_t o = 0;
 #pragma unroll
@@ -521,12 +541,25 @@ template <int NL> __device__ __forceinline__ bool lds_nonzero(const uint32_t *p)
 // 64-lane reduction (round 3: 9 us a point at n = 64, 20 at n = 256); the update
 //     Q_jo <- d_js Q_jo - d_jo Q_js,     Q_js <- (X - x_a) Q_js
 // acts on values pointwise (val_js[i] <- (x_i - x_a) val_js[i]) and on coefficients as before, all items of a point in one phase.
+//
+// One workgroup does all of it up to PROBE_SPLIT_N points.  Above (config 5's 256 parties: 2 (n + 3) coefficient items and 2 n value items of
+// three multiplications each are 3.3 waves a SIMD of ONE CU, 8.4 us a point) the launch is G workgroups -- the grid is 8 (G - 1) + 1 and
+// only the workgroups whose index is a multiple of 8 stay, so that they sit on ONE XCD and talk through its L2 -- and a point is: the
+// workgroup holding the values at the new party computes the discrepancies and posts them; everybody picks the pivot from them and the
+// degrees and updates its own items; workgroup 0 posts the degrees that result.
 template <int NL, int NW>
 __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ pw, int n, int S,
                                                     uint32_t *__restrict__ state, const ProbeIdx ix, int count, int reset,
                                                     const uint32_t *__restrict__ cols, int64_t C, int64_t poly, int k, int decide,
-                                                    ProbeResult *__restrict__ result, int seq) {
+                                                    ProbeResult *__restrict__ result, int seq, uint32_t *__restrict__ msgs, uint32_t uq) {
     extern __shared__ __attribute__((aligned(16))) uint32_t p_lds[];
+    if (gridDim.x > 1 && (blockIdx.x & 7)) return;
+    const int G = gridDim.x > 1 ? (int)(gridDim.x >> 3) + 1 : 1, g = (int)(blockIdx.x >> 3);
+    const bool c_own = g == 0;                               // this workgroup holds the coefficients (and decides)
+    const int v_per = G > 1 ? (n + G - 2) / (G - 1) : n;     // ... and the values at the parties [v_lo, v_hi)
+    const int v_lo = G > 1 ? (c_own ? 0 : min(n, (g - 1) * v_per)) : 0, v_hi = G > 1 ? (c_own ? 0 : min(n, g * v_per)) : n, v_n = v_hi - v_lo;
+    uint32_t *dmsg = msgs, *gmsg = msgs + (size_t)PROBE_MAXN * PROBE_DW, *gdone = gmsg + (size_t)PROBE_MAXN * PROBE_GW;
+    const uint32_t q0 = uq << 9;                             // sequence numbers of this launch's points: q0 + 1 .. (uq: unique among the launches that use this buffer)
     // coef[q][i][NL], q: 0 = A_0, 1 = B_0, 2 = A_1, 3 = B_1; val[q][party][NL]; a scratch polynomial for the decision; the reduction buffer
     uint32_t *coef = p_lds;
     uint32_t *val = coef + (size_t)4 * S * NL;               // [4][n][NL]
@@ -541,15 +574,26 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
     for (int i = tid; i < n * NL; i += PROBE_NT) xl[i] = xm[i];
     int32_t *st_i = reinterpret_cast<int32_t *>(state + words);   // [0..3] degrees, [4] points fed, [8 + i] the i-th party fed
     if (reset) {
-        for (size_t i = tid; i < cwords; i += PROBE_NT) coef[i] = 0;
+        for (size_t i = tid; c_own && i < cwords; i += PROBE_NT) coef[i] = 0;
         // Q_0 = (1, 0), Q_1 = (0, 1): A_0 = 1 and B_1 = 1 everywhere, A_1 = B_0 = 0
-        for (size_t i = tid; i < vwords; i += PROBE_NT) {
-            const int q = (int)(i / ((size_t)n * NL)), w = (int)(i % NL);
-            val[i] = (q == 0 || q == 3) ? P.one[w] : 0u;
+        for (int i = tid; i < 4 * v_n * NL; i += PROBE_NT) {
+            const int q = i / (v_n * NL), r = i - q * (v_n * NL);
+            val[((size_t)q * n + v_lo) * NL + r] = (q == 0 || q == 3) ? P.one[r % NL] : 0u;
         }
         __syncthreads();
-        if (tid < NL) { coef[(size_t)0 * S * NL + tid] = P.one[tid]; coef[(size_t)3 * S * NL + tid] = P.one[tid]; }   // Q_0 = 1, Q_1 = Y
+        if (c_own && tid < NL) { coef[(size_t)0 * S * NL + tid] = P.one[tid]; coef[(size_t)3 * S * NL + tid] = P.one[tid]; }   // Q_0 = 1, Q_1 = Y
         if (tid == 0) { deg[0] = 0; deg[1] = -1; deg[2] = -1; deg[3] = 0; ctl[6] = 0; }
+    } else if (G > 1) {
+        // this workgroup's part of the state: the coefficients, or its parties' rows of the four value tables
+        for (size_t i = tid; c_own && i < cwords; i += PROBE_NT) coef[i] = state[i];
+        for (int i = tid; i < 4 * v_n * NL; i += PROBE_NT) {
+            const int q = i / (v_n * NL), r = i - q * (v_n * NL);
+            const size_t o = ((size_t)q * n + v_lo) * NL + r;
+            val[o] = state[cwords + o];
+        }
+        if (tid < 4) deg[tid] = st_i[tid];
+        if (tid == 0) ctl[6] = st_i[4];
+        if (c_own && tid < PROBE_MAXN) fedl[tid] = (uint16_t)st_i[8 + tid];
     } else {
         // (val follows coef in LDS as in the state; both are multiples of four words.)  Several loads in flight per thread: one word at a
         // time this prologue was a chain of dependent round trips
@@ -585,7 +629,8 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
         const int a = ix.idx[pt];
         uint32_t xa[NL];
         ldg<NL>(xa, xl + (size_t)a * NL);
-        if (tid < 2) {
+        const bool d_own = a >= v_lo && a < v_hi;             // the values at the new party are this workgroup's
+        if (d_own && tid < 2) {
             // discrepancy of Q_tid at the new point: A(x_a) + y B(x_a) from the value table
             uint32_t ym[NL], va[NL], vb[NL], m[NL], dd[NL];
             ldg<NL>(ym, yml + (size_t)pt * NL);
@@ -597,6 +642,29 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
             ctl[tid] = fp_is_zero(dd) ? 0 : 1;
         }
         __syncthreads();
+        if (G > 1) {
+            uint32_t *dm = dmsg + (size_t)pt * PROBE_DW;
+            const uint32_t q = q0 + (uint32_t)pt + 1;
+            if (d_own) {
+                if (tid < 2 * NL) dm[tid] = dl[tid / NL][tid % NL];
+                else if (tid < 2 * NL + 2) dm[tid] = (uint32_t)ctl[tid - 2 * NL];
+                __syncthreads();
+                if (tid == 0) probe_post(dm + PROBE_DW - 1, q);
+            } else {
+                if (tid == 0) probe_wait(dm + PROBE_DW - 1, q);
+                __syncthreads();
+                if (tid < 2 * NL) dl[tid / NL][tid % NL] = __builtin_nontemporal_load(dm + tid);
+                else if (tid < 2 * NL + 2) ctl[tid - 2 * NL] = (int)__builtin_nontemporal_load(dm + tid);
+            }
+            if (!c_own && pt > 0) {
+                // the degrees the previous point left (only the coefficients can tell when a leading one cancelled)
+                const uint32_t *gm = gmsg + (size_t)(pt - 1) * PROBE_GW;
+                if (tid == 0) probe_wait(gm + PROBE_GW - 1, q - 1);
+                __syncthreads();
+                if (tid < 4) deg[tid] = (int)__builtin_nontemporal_load(gm + tid);
+            }
+            __syncthreads();
+        }
         // the pair of smaller leading monomial among those with a discrepancy; (1, k-1)-weighted degree, ties: Y terms larger
         // (every thread works it out for itself from the shared flags and degrees)
         int js = -1;
@@ -609,7 +677,7 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
                 if (js < 0 || w < best_w || (w == best_w && yy < best_y)) { js = j; best_w = w; best_y = yy; }
             }
         }
-        if (tid == 0) { fedl[ctl[6]] = (uint16_t)a; ctl[6] += 1; }
+        if (tid == 0) { if (c_own) fedl[ctl[6]] = (uint16_t)a; ctl[6] += 1; }
         if (js >= 0) {
             const int jo = 1 - js;
             const int top = max(max(deg[0], deg[1]), max(deg[2], deg[3])) + 1;      // highest index any polynomial reaches after this step
@@ -624,15 +692,15 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
             // items: coefficient i of part `part` (A or B) for i <= top, then the value at party i of part `part`.  Q_jo's item is
             // rewritten in place (it reads its own index of both pairs); the value of Q_js too; the COEFFICIENT of Q_js takes its
             // lower neighbour, so it is held back until every thread has read: at most one a thread (2 (n + 3) <= PROBE_NT)
-            const int nce = 2 * (top + 1), nitems = nce + 2 * n;
+            const int nce = c_own ? 2 * (top + 1) : 0, nitems = nce + 2 * v_n;
             // (ONE held-back coefficient a thread: 2 (top + 1) <= 2 (n + 3) < PROBE_NT coefficient items, so a thread's second item, if any,
             // is a value.  An array indexed by a counter here lived in scratch memory: 80 bytes a lane, a round trip to L2 per access)
             uint32_t keep[NL];
             bool kept = false;
             for (int e = tid; e < nitems; e += PROBE_NT) {
                 const bool is_coef = e < nce;
-                const int ee = is_coef ? e : e - nce, span = is_coef ? top + 1 : n;
-                const int part = ee / span, i = ee - part * span;
+                const int ee = is_coef ? e : e - nce, span = is_coef ? top + 1 : v_n;
+                const int part = ee / span, i = ee - part * span + (is_coef ? 0 : v_lo);
                 uint32_t *po = (is_coef ? coef + ((size_t)(2 * jo + part) * S + i) * NL : val + ((size_t)(2 * jo + part) * n + i) * NL);
                 uint32_t *ps = (is_coef ? coef + ((size_t)(2 * js + part) * S + i) * NL : val + ((size_t)(2 * js + part) * n + i) * NL);
                 uint32_t v[NL];
@@ -676,7 +744,7 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
             __syncthreads();
             // new degrees: the pivot's parts grow by one, the other pair's parts become the larger of the two; a scan only when a
             // leading coefficient cancelled (an event of probability ~1/p for random data, but exactness does not gamble)
-            if (tid == 0) {
+            if (tid == 0 && c_own) {
                 int nd[4], rescan = 0;
                 for (int part = 0; part < 2; part++) {
                     const int djs = deg[2 * js + part], djo = deg[2 * jo + part];
@@ -689,6 +757,7 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
                 }
                 ctl[3] = rescan;
             }
+            if (tid == 0 && !c_own) ctl[3] = 0;
             __syncthreads();
             if (ctl[3]) {
                 if (tid < 4) deg[tid] = -1;
@@ -702,18 +771,42 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
         } else {
             __syncthreads();          // (the list of fed parties and the flags are read again by the next point)
         }
+        if (G > 1 && c_own) {
+            uint32_t *gm = gmsg + (size_t)pt * PROBE_GW;
+            if (tid < 4) gm[tid] = (uint32_t)deg[tid];
+            __syncthreads();
+            if (tid == 0) probe_post(gm + PROBE_GW - 1, q0 + (uint32_t)pt + 1);
+        }
     }
     // persistent state back (the decision below works on copies)
     __syncthreads();
-    {
+    if (G == 1) {
         uint4 *dst = reinterpret_cast<uint4 *>(state);
         const uint4 *src = reinterpret_cast<const uint4 *>(coef);
         const int nq = (int)(words / 4);
         for (int i = tid; i < nq; i += PROBE_NT) dst[i] = src[i];
+    } else {
+        for (size_t i = tid; c_own && i < cwords; i += PROBE_NT) state[i] = coef[i];
+        for (int i = tid; i < 4 * v_n * NL; i += PROBE_NT) {
+            const int q = i / (v_n * NL), r = i - q * (v_n * NL);
+            const size_t o = ((size_t)q * n + v_lo) * NL + r;
+            state[cwords + o] = val[o];
+        }
     }
-    if (tid < 4) st_i[tid] = deg[tid];
-    if (tid == 0) st_i[4] = ctl[6];
-    if (tid < PROBE_MAXN) st_i[8 + tid] = fedl[tid];
+    if (c_own) {
+        if (tid < 4) st_i[tid] = deg[tid];
+        if (tid == 0) st_i[4] = ctl[6];
+        if (tid < PROBE_MAXN) st_i[8 + tid] = fedl[tid];
+    }
+    if (G > 1) {
+        // a value workgroup is done once its slice is back in the state; the deciding one reads the whole table from there
+        __syncthreads();
+        if (!c_own) { if (tid == 0) probe_post(gdone + g, uq); return; }
+        if (!decide) return;
+        if (tid > 0 && tid < G) probe_wait(gdone + tid, uq);
+        __syncthreads();
+        for (size_t i = tid; i < vwords; i += PROBE_NT) val[i] = __builtin_nontemporal_load(state + cwords + i);
+    }
     if (!decide) return;
     __syncthreads();
     // ---- the reference's outcome for the points fed so far -----------------------------------------------------------
@@ -926,6 +1019,7 @@ struct hb_probe {
     std::vector<int32_t> fed;
     int64_t poly;
     int seq;                      // launches so far: the kernel echoes it into res_host->seq when its verdict is complete
+    int wgs;                      // workgroups of a launch: 1, or 4 above PROBE_SPLIT_N points (HB_PROBE_WGS overrides: tests)
 };
 
 extern "C" {
@@ -1334,8 +1428,11 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     pt->refs++;                                // this probe's reference: the table outlives its cache entry while the probe lives
     hb_probe *pr = new hb_probe();
     pr->ctx = ctx; pr->n = n; pr->k = k; pr->pt = pt; pr->poly = -1; pr->seq = 0;
+    pr->wgs = n > PROBE_SPLIT_N ? 4 : 1;
+    if (const char *e = getenv("HB_PROBE_WGS")) { const int v = atoi(e); if (v == 1 || (v >= 2 && v <= PROBE_MAXG)) pr->wgs = v; }
     pr->state_bytes = ((size_t)4 * (pt->S + n) * ctx->nl() + 8 + PROBE_MAXN) * 4;
-    const size_t pool_bytes = ((size_t)4 * (2 * PROBE_MAXN + 2) * 9 + 8 + PROBE_MAXN) * 4;     // pooled states are all of the largest size: coefficients + values
+    // pooled states are all of the largest size: coefficients + values, the fed list, the workgroups' messages (probe_msgs)
+    const size_t pool_bytes = (PROBE_STATE_WORDS + PROBE_MSG_WORDS) * 4;
     {
         // (5 S + 4 n + 256) NL words of LDS: 92 KB at the 256-point limit -- above the 64 KB a launch may ask for without saying so.  Per
         // device, not per process: set whenever a probe is created
@@ -1346,7 +1443,10 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     }
     pr->state = nullptr; pr->res_host = nullptr; pr->res_dev = nullptr;
     if (!ctx->probe_pool.empty()) { pr->state = (uint32_t *)ctx->probe_pool.back(); ctx->probe_pool.pop_back(); }
-    else if (hipMalloc(&pr->state, pool_bytes) != hipSuccess) { point_table_unref(pt); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipMalloc"); }
+    else if (hipMalloc(&pr->state, pool_bytes) != hipSuccess || hipMemsetAsync(pr->state + PROBE_STATE_WORDS, 0, PROBE_MSG_WORDS * 4, s) != hipSuccess) {
+        if (pr->state) (void)hipFree(pr->state);
+        point_table_unref(pt); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipMalloc");
+    }
     if (!ctx->probe_host_pool.empty()) { pr->res_host = (ProbeResult *)ctx->probe_host_pool.back(); ctx->probe_host_pool.pop_back(); }
     else if (hipHostMalloc((void **)&pr->res_host, sizeof(ProbeResult), hipHostMallocMapped) != hipSuccess) {
         ctx->probe_pool.push_back(pr->state); point_table_unref(pt); delete pr; return fail(ctx, HB_ERR_HIP, "probe: hipHostMalloc");
@@ -1384,13 +1484,18 @@ static int probe_launch(hb_probe *pr, const int32_t *idx, int count, const uint6
     if (count == 0 && reset) return fail(ctx, HB_ERR_BAD_ARG, "probe: nothing fed yet");
     const int S = pr->pt->S, NLr = ctx->nl();
     const int seq = pr->seq + 1;
+    // (a number no other launch into a pooled state buffer carries: the workgroups' messages are recognised by it)
+    static std::atomic<uint32_t> launches{0};
+    const uint32_t uq = (launches.fetch_add(1) + 1) & 0x7fffffu;
+    uint32_t *msgs = pr->state + PROBE_STATE_WORDS;
+    const unsigned grid = pr->wgs > 1 ? 8u * (unsigned)(pr->wgs - 1) + 1u : 1u;
     const size_t lds = ((size_t)(5 * S + 6 * pr->n) * NLr) * 4;      // coefficients, values, the decision's scratch polynomial, the points, this launch's symbols
     if (ctx->n_limbs == 4)
-        k_probe_feed<9, 8><<<1, PROBE_NT, lds, s>>>(ctx->pw, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
-                                               (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq);
+        k_probe_feed<9, 8><<<grid, PROBE_NT, lds, s>>>(ctx->pw, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
+                                               (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq, msgs, uq);
     else
-        k_probe_feed<3, 2><<<1, PROBE_NT, lds, s>>>(ctx->pn, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
-                                               (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq);
+        k_probe_feed<3, 2><<<grid, PROBE_NT, lds, s>>>(ctx->pn, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
+                                               (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq, msgs, uq);
     {
         const hipError_t le = hipGetLastError();
         if (le != hipSuccess) {

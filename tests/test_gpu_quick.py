@@ -145,12 +145,16 @@ def _ev(a, x, p):
     return r
 
 
-@pytest.mark.parametrize("p", [P, (1 << 61) - 1, 257, 53, 13])
-def test_probe_equals_gao_on_every_prefix(p):
+@pytest.mark.parametrize("p,wgs", [(P, None), ((1 << 61) - 1, None), (257, None), (53, None), (13, None), (P, "4"), (257, "2"), (13, "4"), ((1 << 61) - 1, "3")])
+def test_probe_equals_gao_on_every_prefix(monkeypatch, p, wgs):
     """random codewords, random arrival orders, errors inside / at / beyond the radius: after every arrival the probe's verdict
-    and its error set equal the oracle's Gao over the same prefix (error set = roots of Gao's locator among all party points)"""
+    and its error set equal the oracle's Gao over the same prefix (error set = roots of Gao's locator among all party points).
+    wgs: the probe over that many workgroups (HB_PROBE_WGS; what point sets above 128 parties run by default): workgroup 0 the
+    coefficients, the others a slice of the value table each, discrepancies and degrees exchanged per point."""
     from honeybadgermpc_amd._capi import Context
 
+    if wgs:
+        monkeypatch.setenv("HB_PROBE_WGS", wgs)
     ctx = Context.get(p)
     rnd = random.Random(p % 1009)
     trials = decoded = beyond = 0
@@ -219,6 +223,44 @@ def test_probe_at_config3_shape_with_21_liars():
     for m in range(44, 64):
         assert pr.feed([order[m - 1]], cols, c, 1) is None, m
     assert pr.feed([order[63]], cols, c, 1) == list(range(t))
+    pr.close()
+
+
+@pytest.mark.parametrize("n,t,liars", [(256, 85, "spread"), (200, 66, "first"), (130, 43, "spread")])
+def test_probe_over_several_workgroups_at_full_size(n, t, liars):
+    """point sets above 128 parties: the probe's launches are four workgroups.  t liars (after every two honest senders, or the first t arrivals),
+    d + t points at once and then one at a time: every verdict and error set equal the oracle's Gao over the same prefix; a reset and
+    all points in one launch give the last verdict again."""
+    from honeybadgermpc_amd._capi import Context
+
+    ctx = Context.get(P)
+    rnd = random.Random(n)
+    d, c, poly = t + 1, 2, 1
+    x = list(range(1, n + 1))
+    f = [rnd.randrange(P) for _ in range(d)]
+    order = list(range(n))
+    rnd.shuffle(order)
+    bad = set(order[2::3][:t]) if liars == "spread" else set(order[:t])
+    vals = [[rnd.randrange(P) for _ in range(c)] for _ in range(n)]
+    for i in range(n):
+        vals[i][poly] = rnd.randrange(P) if i in bad else _ev(f, x[i], P)
+    cols = ctx.upload_ints([v for row in vals for v in row])
+    pr = _Probe(ctx, x, d)
+
+    def want(m):
+        co, el = oracle.gao_interpolate([x[i] for i in order[:m]], [vals[i][poly] for i in order[:m]], d, P)
+        return None if co is None else (sorted(i for i in range(n) if _ev(el, x[i], P) == 0) if len(el) > 1 else [])
+
+    first = d + t
+    assert pr.feed(order[:first], cols, c, poly) == want(first)
+    decoded = 0
+    for m in range(first + 1, n + 1):
+        got = pr.feed([order[m - 1]], cols, c, poly)
+        assert got == want(m), m
+        decoded += got is not None
+    assert decoded >= 1 and got == sorted(bad)
+    pr.reset()
+    assert pr.feed(order, cols, c, poly) == sorted(bad)
     pr.close()
 
 
