@@ -510,13 +510,15 @@ struct ProbeResult { int32_t ok, n_err, npts, seq; uint8_t err[PROBE_MAXN]; };  
 
 // A probe over several workgroups (point sets above PROBE_SPLIT_N points): workgroup 0 holds the coefficients, the others a slice of the
 // value table each.  What they tell each other, per point fed, through global memory (a slot per point of the launch, so nobody overwrites
-// what a slower workgroup has not read; a slot's last word is the sequence number that says it is complete):
-//   the discrepancies of the point (from the workgroup that holds the values at that party): 2 NL words + 2 flags     [PROBE_DW words]
+// what a slower workgroup has not read).  Every word of a message travels as 64 bits, the point's sequence number above its 32 bits of
+// payload: a reader polls the word it needs and knows from the word itself that it is this point's -- no flag to wait for before the
+// payload may be read, no fence between them, one trip through the L2 per message:
+//   the discrepancies of the point (from the workgroup that holds the values at that party): 2 NL digits + 2 flags    [PROBE_DW words]
 //   the degrees after the point (from workgroup 0: a leading coefficient may cancel, only the coefficients show it)    [PROBE_GW words]
-// and, at the end of a launch, "my slice is back in the state" from every value workgroup (PROBE_MAXG words).
+// and, at the end of a launch, "my slice is back in the state" from every value workgroup (PROBE_MAXG words, flag + fence).
 constexpr int PROBE_SPLIT_N = 128;
 constexpr int PROBE_MAXG = 8;
-constexpr int PROBE_DW = 24, PROBE_GW = 8;
+constexpr int PROBE_DW = 40, PROBE_GW = 8;
 constexpr size_t PROBE_MSG_WORDS = (size_t)PROBE_MAXN * (PROBE_DW + PROBE_GW) + PROBE_MAXG;
 constexpr size_t PROBE_STATE_WORDS = (size_t)4 * (2 * PROBE_MAXN + 2) * 9 + 8 + PROBE_MAXN;      // the largest state: coefficients + values of 256 points, degrees, the fed list
 __device__ __forceinline__ void probe_wait(const uint32_t *flag, uint32_t want) {
@@ -526,6 +528,15 @@ __device__ __forceinline__ void probe_wait(const uint32_t *flag, uint32_t want) 
 __device__ __forceinline__ void probe_post(uint32_t *flag, uint32_t value) {
     __threadfence();
     __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void probe_send(uint32_t *slot, int word, uint32_t q, uint32_t payload) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot) + word, ((unsigned long long)q << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t probe_recv(const uint32_t *slot, int word, uint32_t q) {
+    const unsigned long long *w = reinterpret_cast<const unsigned long long *>(slot) + word;
+    unsigned long long v;
+    while ((uint32_t)((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != q) __builtin_amdgcn_s_sleep(1);
+    return (uint32_t)v;
 }
 
 template <int NL> __device__ __forceinline__ bool lds_nonzero(const uint32_t *p) {
@@ -555,9 +566,14 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
     extern __shared__ __attribute__((aligned(16))) uint32_t p_lds[];
     if (gridDim.x > 1 && (blockIdx.x & 7)) return;
     const int G = gridDim.x > 1 ? (int)(gridDim.x >> 3) + 1 : 1, g = (int)(blockIdx.x >> 3);
-    const bool c_own = g == 0;                               // this workgroup holds the coefficients (and decides)
-    const int v_per = G > 1 ? (n + G - 2) / (G - 1) : n;     // ... and the values at the parties [v_lo, v_hi)
-    const int v_lo = G > 1 ? (c_own ? 0 : min(n, (g - 1) * v_per)) : 0, v_hi = G > 1 ? (c_own ? 0 : min(n, g * v_per)) : n, v_n = v_hi - v_lo;
+    // who holds what: workgroup 0 the coefficients (and the decision) -- from three workgroups on, workgroup 0 the A parts and workgroup 1 the
+    // B parts (an item of one part never reads the other) --, the rest a slice of the parties' values each
+    const bool leader = g == 0;
+    const int NC = G >= 3 ? 2 : 1;                           // workgroups that hold coefficients
+    const int cp_lo = G >= 3 ? (g < 2 ? g : 0) : 0, cp_hi = G >= 3 ? (g < 2 ? g + 1 : 0) : (leader ? 2 : 0), cp_n = cp_hi - cp_lo;
+    const bool c_own = cp_n > 0;
+    const int v_per = G > 1 ? (n + G - NC - 1) / (G - NC) : n;     // ... and the values at the parties [v_lo, v_hi)
+    const int v_lo = G > 1 ? (c_own ? 0 : min(n, (g - NC) * v_per)) : 0, v_hi = G > 1 ? (c_own ? 0 : min(n, (g - NC + 1) * v_per)) : n, v_n = v_hi - v_lo;
     uint32_t *dmsg = msgs, *gmsg = msgs + (size_t)PROBE_MAXN * PROBE_DW, *gdone = gmsg + (size_t)PROBE_MAXN * PROBE_GW;
     const uint32_t q0 = uq << 9;                             // sequence numbers of this launch's points: q0 + 1 .. (uq: unique among the launches that use this buffer)
     // coef[q][i][NL], q: 0 = A_0, 1 = B_0, 2 = A_1, 3 = B_1; val[q][party][NL]; a scratch polynomial for the decision; the reduction buffer
@@ -574,18 +590,27 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
     for (int i = tid; i < n * NL; i += PROBE_NT) xl[i] = xm[i];
     int32_t *st_i = reinterpret_cast<int32_t *>(state + words);   // [0..3] degrees, [4] points fed, [8 + i] the i-th party fed
     if (reset) {
-        for (size_t i = tid; c_own && i < cwords; i += PROBE_NT) coef[i] = 0;
+        for (int i = tid; i < 2 * cp_n * S * NL; i += PROBE_NT) {
+            const int b_ = i / (S * NL), r = i - b_ * (S * NL), q = 2 * (b_ / cp_n) + cp_lo + b_ % cp_n;
+            coef[(size_t)q * S * NL + r] = 0;
+        }
         // Q_0 = (1, 0), Q_1 = (0, 1): A_0 = 1 and B_1 = 1 everywhere, A_1 = B_0 = 0
         for (int i = tid; i < 4 * v_n * NL; i += PROBE_NT) {
             const int q = i / (v_n * NL), r = i - q * (v_n * NL);
             val[((size_t)q * n + v_lo) * NL + r] = (q == 0 || q == 3) ? P.one[r % NL] : 0u;
         }
         __syncthreads();
-        if (c_own && tid < NL) { coef[(size_t)0 * S * NL + tid] = P.one[tid]; coef[(size_t)3 * S * NL + tid] = P.one[tid]; }   // Q_0 = 1, Q_1 = Y
+        if (tid < NL) {                                     // Q_0 = 1, Q_1 = Y
+            if (cp_lo <= 0 && 0 < cp_hi) coef[(size_t)0 * S * NL + tid] = P.one[tid];
+            if (cp_lo <= 1 && 1 < cp_hi) coef[(size_t)3 * S * NL + tid] = P.one[tid];
+        }
         if (tid == 0) { deg[0] = 0; deg[1] = -1; deg[2] = -1; deg[3] = 0; ctl[6] = 0; }
     } else if (G > 1) {
         // this workgroup's part of the state: the coefficients, or its parties' rows of the four value tables
-        for (size_t i = tid; c_own && i < cwords; i += PROBE_NT) coef[i] = state[i];
+        for (int i = tid; i < 2 * cp_n * S * NL; i += PROBE_NT) {
+            const int b_ = i / (S * NL), r = i - b_ * (S * NL), q = 2 * (b_ / cp_n) + cp_lo + b_ % cp_n;
+            coef[(size_t)q * S * NL + r] = state[(size_t)q * S * NL + r];
+        }
         for (int i = tid; i < 4 * v_n * NL; i += PROBE_NT) {
             const int q = i / (v_n * NL), r = i - q * (v_n * NL);
             const size_t o = ((size_t)q * n + v_lo) * NL + r;
@@ -593,7 +618,7 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
         }
         if (tid < 4) deg[tid] = st_i[tid];
         if (tid == 0) ctl[6] = st_i[4];
-        if (c_own && tid < PROBE_MAXN) fedl[tid] = (uint16_t)st_i[8 + tid];
+        if (leader && tid < PROBE_MAXN) fedl[tid] = (uint16_t)st_i[8 + tid];
     } else {
         // (val follows coef in LDS as in the state; both are multiples of four words.)  Several loads in flight per thread: one word at a
         // time this prologue was a chain of dependent round trips
@@ -625,44 +650,56 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
         stg<NL>(yml + (size_t)pt * NL, ym);
     }
     __syncthreads();
-    for (int pt = 0; pt < count; pt++) {
-        const int a = ix.idx[pt];
-        uint32_t xa[NL];
-        ldg<NL>(xa, xl + (size_t)a * NL);
-        const bool d_own = a >= v_lo && a < v_hi;             // the values at the new party are this workgroup's
-        if (d_own && tid < 2) {
-            // discrepancy of Q_tid at the new point: A(x_a) + y B(x_a) from the value table
+    // The discrepancies of ALL the points of this launch, once: D_j[pt] = A_j(x) + y B_j(x) at the point's party, from the value table.  They are
+    // linear in the pair like everything else, so a point's update carries the not-yet-fed ones along (one more item each) and the
+    // discrepancy of the next point is a look-up again -- no multiplication between one point's update and the next one's pivot.
+    uint32_t *Dl = yml + (size_t)n * NL;                     // [2][count][NL]; a point's two are its party's workgroup's
+    __shared__ uint16_t own_pts[PROBE_MAXN];                  // this workgroup's points of the launch, in order
+    __shared__ int own_cnt;
+    if (tid == 0) {
+        int c_ = 0;
+        for (int pt = 0; pt < count; pt++) { const int a_ = ix.idx[pt]; if (a_ >= v_lo && a_ < v_hi) own_pts[c_++] = (uint16_t)pt; }
+        own_cnt = c_;
+    }
+    for (int e = tid; e < 2 * count; e += PROBE_NT) {
+        const int j = e & 1, pt = e >> 1, a_ = ix.idx[pt];
+        if (a_ >= v_lo && a_ < v_hi) {
             uint32_t ym[NL], va[NL], vb[NL], m[NL], dd[NL];
             ldg<NL>(ym, yml + (size_t)pt * NL);
-            ldg<NL>(va, val + ((size_t)(2 * tid) * n + a) * NL);
-            ldg<NL>(vb, val + ((size_t)(2 * tid + 1) * n + a) * NL);
+            ldg<NL>(va, val + ((size_t)(2 * j) * n + a_) * NL);
+            ldg<NL>(vb, val + ((size_t)(2 * j + 1) * n + a_) * NL);
             mont_mul(m, ym, vb, P);
             fp_add(dd, va, m, P);
+            stg<NL>(Dl + ((size_t)j * count + pt) * NL, dd);
+        }
+    }
+    __syncthreads();
+    int own_done = 0;                                         // own points fed so far (the same in every thread)
+    for (int pt = 0; pt < count; pt++) {
+        const int a = ix.idx[pt];
+        const bool d_own = a >= v_lo && a < v_hi;             // the values at the new party are this workgroup's
+        if (tid == 0) ctl[3] = 0;                             // (set by whoever sees a leading coefficient cancel in this point's update)
+        if (d_own && tid < 2) {
+            uint32_t dd[NL];
+            ldg<NL>(dd, Dl + ((size_t)tid * count + pt) * NL);
             stg<NL>(dl[tid], dd);
             ctl[tid] = fp_is_zero(dd) ? 0 : 1;
         }
+        if (d_own) own_done++;
         __syncthreads();
         if (G > 1) {
             uint32_t *dm = dmsg + (size_t)pt * PROBE_DW;
             const uint32_t q = q0 + (uint32_t)pt + 1;
             if (d_own) {
-                if (tid < 2 * NL) dm[tid] = dl[tid / NL][tid % NL];
-                else if (tid < 2 * NL + 2) dm[tid] = (uint32_t)ctl[tid - 2 * NL];
-                __syncthreads();
-                if (tid == 0) probe_post(dm + PROBE_DW - 1, q);
+                if (tid < 2 * NL) probe_send(dm, tid, q, dl[tid / NL][tid % NL]);
+                else if (tid < 2 * NL + 2) probe_send(dm, tid, q, (uint32_t)ctl[tid - 2 * NL]);
             } else {
-                if (tid == 0) probe_wait(dm + PROBE_DW - 1, q);
-                __syncthreads();
-                if (tid < 2 * NL) dl[tid / NL][tid % NL] = __builtin_nontemporal_load(dm + tid);
-                else if (tid < 2 * NL + 2) ctl[tid - 2 * NL] = (int)__builtin_nontemporal_load(dm + tid);
+                if (tid < 2 * NL) dl[tid / NL][tid % NL] = probe_recv(dm, tid, q);
+                else if (tid < 2 * NL + 2) ctl[tid - 2 * NL] = (int)probe_recv(dm, tid, q);
             }
-            if (!c_own && pt > 0) {
-                // the degrees the previous point left (only the coefficients can tell when a leading one cancelled)
-                const uint32_t *gm = gmsg + (size_t)(pt - 1) * PROBE_GW;
-                if (tid == 0) probe_wait(gm + PROBE_GW - 1, q - 1);
-                __syncthreads();
-                if (tid < 4) deg[tid] = (int)__builtin_nontemporal_load(gm + tid);
-            }
+            // the degrees the previous point left (only the coefficients can tell when a leading one cancelled)
+            if (pt > 0 && tid >= 64 && tid < 68 && !(((tid - 64) & 1) >= cp_lo && ((tid - 64) & 1) < cp_hi))
+                deg[tid - 64] = (int)probe_recv(gmsg + (size_t)(pt - 1) * PROBE_GW, tid - 64, q - 1);
             __syncthreads();
         }
         // the pair of smaller leading monomial among those with a discrepancy; (1, k-1)-weighted degree, ties: Y terms larger
@@ -677,94 +714,108 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
                 if (js < 0 || w < best_w || (w == best_w && yy < best_y)) { js = j; best_w = w; best_y = yy; }
             }
         }
-        if (tid == 0) { if (c_own) fedl[ctl[6]] = (uint16_t)a; ctl[6] += 1; }
+        if (tid == 0) { if (leader) fedl[ctl[6]] = (uint16_t)a; ctl[6] += 1; }
         if (js >= 0) {
             const int jo = 1 - js;
             const int top = max(max(deg[0], deg[1]), max(deg[2], deg[3])) + 1;      // highest index any polynomial reaches after this step
             const bool upd_o = ctl[jo] != 0;
-            uint32_t ds[NL], ndj[NL];
+            // the degrees after the step, as they follow from the degrees before it: the pivot's parts grow by one, the other pair's parts
+            // become the larger of the two.  Only where the two are EQUAL can the leading coefficients cancel (d_js u - d_jo v with both
+            // non-zero); the thread that computes that coefficient looks (an event of probability ~1/p for random data, but exactness does
+            // not gamble) and a scan finds the degrees then
+            // (scalars, not an array: an array indexed by the pivot's number lives in scratch memory -- a round trip to L2 per access)
+            const int djs0 = deg[2 * js], djs1 = deg[2 * js + 1], djo0 = deg[2 * jo], djo1 = deg[2 * jo + 1];
+            const int nds0 = djs0 >= 0 ? djs0 + 1 : -1, nds1 = djs1 >= 0 ? djs1 + 1 : -1;
+            const int ndo0 = upd_o ? max(djs0, djo0) : djo0, ndo1 = upd_o ? max(djs1, djo1) : djo1;
+            // Units of work: an ITEM is coefficient i of part `part` (A or B) for i <= top, the value at party i of part `part`, or the pair of
+            // discrepancies of a point of this launch still to come; each item is two units, for two threads -- Q_jo <- d_js Q_jo - d_jo Q_js
+            // (two products, one reduction) and Q_js <- (X - x_a) Q_js (one product; a coefficient takes its lower neighbour) -- so a point's
+            // update is as long as the longer of them, not their sum.  Every unit reads the state as the last point left it; results wait in
+            // registers until all have read (a thread has at most two: 2 (2 (n + 3) + 2 n + n) <= 2 PROBE_NT)
+            const int nce = cp_n * (top + 1), nD = own_cnt - own_done, U = nce + 2 * v_n + nD;
+            uint32_t xa[NL], ds[NL], ndj[NL];
+            ldg<NL>(xa, xl + (size_t)a * NL);
             ldg<NL>(ds, dl[js]);
             {
                 uint32_t dj[NL];
                 ldg<NL>(dj, dl[jo]);
                 fp_neg(ndj, dj, P);
             }
-            // items: coefficient i of part `part` (A or B) for i <= top, then the value at party i of part `part`.  Q_jo's item is
-            // rewritten in place (it reads its own index of both pairs); the value of Q_js too; the COEFFICIENT of Q_js takes its
-            // lower neighbour, so it is held back until every thread has read: at most one a thread (2 (n + 3) <= PROBE_NT)
-            const int nce = c_own ? 2 * (top + 1) : 0, nitems = nce + 2 * v_n;
-            // (ONE held-back coefficient a thread: 2 (top + 1) <= 2 (n + 3) < PROBE_NT coefficient items, so a thread's second item, if any,
-            // is a value.  An array indexed by a counter here lived in scratch memory: 80 bytes a lane, a round trip to L2 per access)
-            uint32_t keep[NL];
-            bool kept = false;
-            for (int e = tid; e < nitems; e += PROBE_NT) {
-                const bool is_coef = e < nce;
-                const int ee = is_coef ? e : e - nce, span = is_coef ? top + 1 : v_n;
-                const int part = ee / span, i = ee - part * span + (is_coef ? 0 : v_lo);
-                uint32_t *po = (is_coef ? coef + ((size_t)(2 * jo + part) * S + i) * NL : val + ((size_t)(2 * jo + part) * n + i) * NL);
-                uint32_t *ps = (is_coef ? coef + ((size_t)(2 * js + part) * S + i) * NL : val + ((size_t)(2 * js + part) * n + i) * NL);
+            // (two named results, not an array over the unit's number: that array lived in scratch memory)
+            auto unit = [&](int e, uint32_t (&res)[NL], uint32_t *&dst) {
+                dst = nullptr;
+                if (e >= 2 * U) return;
+                const int sub = e >= U ? 1 : 0, it = e - sub * U;
+                if (sub == 0 && !upd_o) return;
+                // where the item's two elements live (po: of Q_jo, ps: of Q_js), and what the pivot's element is multiplied by
+                uint32_t *po, *ps;
+                int ci = -1, cpart = 0;                               // a coefficient item's index and part
+                const uint32_t *xi = nullptr;                         // a value's / a coming point's party point
+                if (it < nce) {
+                    cpart = it / (top + 1); ci = it - cpart * (top + 1); cpart += cp_lo;
+                    po = coef + ((size_t)(2 * jo + cpart) * S + ci) * NL;
+                    ps = coef + ((size_t)(2 * js + cpart) * S + ci) * NL;
+                } else if (it < nce + 2 * v_n) {
+                    const int ee = it - nce, part = ee / v_n, i = v_lo + ee - part * v_n;
+                    po = val + ((size_t)(2 * jo + part) * n + i) * NL;
+                    ps = val + ((size_t)(2 * js + part) * n + i) * NL;
+                    xi = xl + (size_t)i * NL;
+                } else {
+                    const int p2 = own_pts[own_done + (it - nce - 2 * v_n)];
+                    po = Dl + ((size_t)jo * count + p2) * NL;
+                    ps = Dl + ((size_t)js * count + p2) * NL;
+                    xi = xl + (size_t)ix.idx[p2] * NL;
+                }
                 uint32_t v[NL];
                 ldg<NL>(v, ps);
-                if (upd_o) {
+                if (sub == 0) {
                     // Q_jo <- d_js Q_jo - d_jo Q_js: one reduction for the two products
-                    uint32_t u[NL], r[NL];
+                    uint32_t u[NL];
                     uint64_t col[2 * NL];
                     ldg<NL>(u, po);
                     col_zero(col);
                     mac<NL>(col, ds, u);
                     mac<NL>(col, ndj, v);
-                    redc(r, col, P);
-                    cond_sub_p(r, P);
-                    stg<NL>(po, r);
-                }
-                if (is_coef) {
-                    // Q_js <- (X - x_a) Q_js
+                    redc(res, col, P);
+                    cond_sub_p(res, P);
+                    dst = po;
+                    if (ci >= 0 && (cpart ? (djs1 == djo1 && ci == djo1) : (djs0 == djo0 && ci == djo0)) && fp_is_zero(res)) ctl[3] = 1;
+                } else if (ci >= 0) {
+                    // Q_js <- (X - x_a) Q_js, a coefficient
                     uint32_t prev[NL], m[NL];
-                    if (i > 0) ldg<NL>(prev, ps - NL);
+                    if (ci > 0) ldg<NL>(prev, ps - NL);
                     else {
 #pragma unroll
                         for (int w = 0; w < NL; w++) prev[w] = 0;
                     }
                     mont_mul(m, xa, v, P);
-                    fp_sub(keep, prev, m, P);
-                    kept = true;
+                    fp_sub(res, prev, m, P);
+                    dst = ps;
                 } else {
-                    uint32_t xi[NL], df[NL], m[NL];
-                    ldg<NL>(xi, xl + (size_t)i * NL);
-                    fp_sub(df, xi, xa, P);
-                    mont_mul(m, df, v, P);
-                    stg<NL>(ps, m);
+                    uint32_t xv[NL], df[NL];
+                    ldg<NL>(xv, xi);
+                    fp_sub(df, xv, xa, P);
+                    mont_mul(res, df, v, P);
+                    dst = ps;
                 }
-            }
+            };
+            uint32_t res0[NL], res1[NL];
+            uint32_t *dst0, *dst1;
+            unit(tid, res0, dst0);
+            unit(tid + PROBE_NT, res1, dst1);
             __syncthreads();
-            if (kept) {                                   // (tid < nce: its one coefficient item)
-                const int part = tid / (top + 1), i = tid - part * (top + 1);
-                stg<NL>(coef + ((size_t)(2 * js + part) * S + i) * NL, keep);
-            }
+            const bool rescan = ctl[3] != 0;                  // (read before the stores' barrier: thread 0 clears the flag for the next point after it)
+            if (dst0) stg<NL>(dst0, res0);
+            if (dst1) stg<NL>(dst1, res1);
+            if (!rescan && tid < 4) deg[tid] = (tid >> 1) == js ? ((tid & 1) ? nds1 : nds0) : ((tid & 1) ? ndo1 : ndo0);
             __syncthreads();
-            // new degrees: the pivot's parts grow by one, the other pair's parts become the larger of the two; a scan only when a
-            // leading coefficient cancelled (an event of probability ~1/p for random data, but exactness does not gamble)
-            if (tid == 0 && c_own) {
-                int nd[4], rescan = 0;
-                for (int part = 0; part < 2; part++) {
-                    const int djs = deg[2 * js + part], djo = deg[2 * jo + part];
-                    nd[2 * js + part] = djs >= 0 ? djs + 1 : -1;
-                    nd[2 * jo + part] = upd_o ? (djs > djo ? djs : djo) : djo;
-                }
-                for (int x = 0; x < 4; x++) {
-                    if (nd[x] >= 0 && !lds_nonzero<NL>(coef + ((size_t)x * S + nd[x]) * NL)) rescan = 1;
-                    deg[x] = nd[x];
-                }
-                ctl[3] = rescan;
-            }
-            if (tid == 0 && !c_own) ctl[3] = 0;
-            __syncthreads();
-            if (ctl[3]) {
-                if (tid < 4) deg[tid] = -1;
+            if (rescan) {
+                // (of the parts this workgroup holds: the others' degrees arrive with the next point)
+                if (tid < 4 && (tid & 1) >= cp_lo && (tid & 1) < cp_hi) deg[tid] = -1;
                 __syncthreads();
-                for (int e = tid; e < 4 * (top + 1); e += PROBE_NT) {
-                    const int part = e / (top + 1), i = e - part * (top + 1);
-                    if (lds_nonzero<NL>(coef + ((size_t)part * S + i) * NL)) atomicMax(&deg[part], i);
+                for (int e = tid; e < 2 * cp_n * (top + 1); e += PROBE_NT) {
+                    const int b_ = e / (top + 1), i = e - b_ * (top + 1), q = 2 * (b_ / cp_n) + cp_lo + b_ % cp_n;
+                    if (lds_nonzero<NL>(coef + ((size_t)q * S + i) * NL)) atomicMax(&deg[q], i);
                 }
                 __syncthreads();
             }
@@ -772,12 +823,12 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
             __syncthreads();          // (the list of fed parties and the flags are read again by the next point)
         }
         if (G > 1 && c_own) {
-            uint32_t *gm = gmsg + (size_t)pt * PROBE_GW;
-            if (tid < 4) gm[tid] = (uint32_t)deg[tid];
-            __syncthreads();
-            if (tid == 0) probe_post(gm + PROBE_GW - 1, q0 + (uint32_t)pt + 1);
+            if (tid < 4 && (tid & 1) >= cp_lo && (tid & 1) < cp_hi) probe_send(gmsg + (size_t)pt * PROBE_GW, tid, q0 + (uint32_t)pt + 1, (uint32_t)deg[tid]);
         }
     }
+    // (the degrees of the parts another workgroup holds, as the last point left them)
+    if (G > 1 && leader && count > 0 && tid >= 64 && tid < 68 && !(((tid - 64) & 1) >= cp_lo && ((tid - 64) & 1) < cp_hi))
+        deg[tid - 64] = (int)probe_recv(gmsg + (size_t)(count - 1) * PROBE_GW, tid - 64, q0 + (uint32_t)count);
     // persistent state back (the decision below works on copies)
     __syncthreads();
     if (G == 1) {
@@ -786,14 +837,17 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
         const int nq = (int)(words / 4);
         for (int i = tid; i < nq; i += PROBE_NT) dst[i] = src[i];
     } else {
-        for (size_t i = tid; c_own && i < cwords; i += PROBE_NT) state[i] = coef[i];
+        for (int i = tid; i < 2 * cp_n * S * NL; i += PROBE_NT) {
+            const int b_ = i / (S * NL), r = i - b_ * (S * NL), q = 2 * (b_ / cp_n) + cp_lo + b_ % cp_n;
+            state[(size_t)q * S * NL + r] = coef[(size_t)q * S * NL + r];
+        }
         for (int i = tid; i < 4 * v_n * NL; i += PROBE_NT) {
             const int q = i / (v_n * NL), r = i - q * (v_n * NL);
             const size_t o = ((size_t)q * n + v_lo) * NL + r;
             state[cwords + o] = val[o];
         }
     }
-    if (c_own) {
+    if (leader) {
         if (tid < 4) st_i[tid] = deg[tid];
         if (tid == 0) st_i[4] = ctl[6];
         if (tid < PROBE_MAXN) st_i[8 + tid] = fedl[tid];
@@ -801,11 +855,15 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
     if (G > 1) {
         // a value workgroup is done once its slice is back in the state; the deciding one reads the whole table from there
         __syncthreads();
-        if (!c_own) { if (tid == 0) probe_post(gdone + g, uq); return; }
+        if (!leader) { if (tid == 0) probe_post(gdone + g, uq); return; }
         if (!decide) return;
         if (tid > 0 && tid < G) probe_wait(gdone + tid, uq);
         __syncthreads();
         for (size_t i = tid; i < vwords; i += PROBE_NT) val[i] = __builtin_nontemporal_load(state + cwords + i);
+        for (int i = tid; G >= 3 && i < 2 * S * NL; i += PROBE_NT) {       // the B parts' coefficients
+            const size_t o = (size_t)(2 * (i / (S * NL)) + 1) * S * NL + i % (S * NL);
+            coef[o] = __builtin_nontemporal_load(state + o);
+        }
     }
     if (!decide) return;
     __syncthreads();
@@ -1019,7 +1077,7 @@ struct hb_probe {
     std::vector<int32_t> fed;
     int64_t poly;
     int seq;                      // launches so far: the kernel echoes it into res_host->seq when its verdict is complete
-    int wgs;                      // workgroups of a launch: 1, or 4 above PROBE_SPLIT_N points (HB_PROBE_WGS overrides: tests)
+    int wgs;                      // workgroups of a launch: 1, or 6 above PROBE_SPLIT_N points (HB_PROBE_WGS overrides: tests)
 };
 
 extern "C" {
@@ -1428,13 +1486,14 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     pt->refs++;                                // this probe's reference: the table outlives its cache entry while the probe lives
     hb_probe *pr = new hb_probe();
     pr->ctx = ctx; pr->n = n; pr->k = k; pr->pt = pt; pr->poly = -1; pr->seq = 0;
-    pr->wgs = n > PROBE_SPLIT_N ? 4 : 1;
+    pr->wgs = n > PROBE_SPLIT_N ? 6 : 1;
     if (const char *e = getenv("HB_PROBE_WGS")) { const int v = atoi(e); if (v == 1 || (v >= 2 && v <= PROBE_MAXG)) pr->wgs = v; }
+    if (n > PROBE_SPLIT_N && pr->wgs < 2) pr->wgs = 2;       // (one workgroup's 1024 threads hold two units of a point's update each: 5 n + 6 items are 2 x 1286 units at n = 256)
     pr->state_bytes = ((size_t)4 * (pt->S + n) * ctx->nl() + 8 + PROBE_MAXN) * 4;
     // pooled states are all of the largest size: coefficients + values, the fed list, the workgroups' messages (probe_msgs)
     const size_t pool_bytes = (PROBE_STATE_WORDS + PROBE_MSG_WORDS) * 4;
     {
-        // (5 S + 4 n + 256) NL words of LDS: 92 KB at the 256-point limit -- above the 64 KB a launch may ask for without saying so.  Per
+        // (5 S + 8 n) NL words of LDS: 120 KB at the 256-point limit -- above the 64 KB a launch may ask for without saying so.  Per
         // device, not per process: set whenever a probe is created
         const int lim = 128 * 1024;
         hipError_t ae = ctx->n_limbs == 4 ? hipFuncSetAttribute(reinterpret_cast<const void *>(k_probe_feed<9, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, lim)
@@ -1489,7 +1548,7 @@ static int probe_launch(hb_probe *pr, const int32_t *idx, int count, const uint6
     const uint32_t uq = (launches.fetch_add(1) + 1) & 0x7fffffu;
     uint32_t *msgs = pr->state + PROBE_STATE_WORDS;
     const unsigned grid = pr->wgs > 1 ? 8u * (unsigned)(pr->wgs - 1) + 1u : 1u;
-    const size_t lds = ((size_t)(5 * S + 6 * pr->n) * NLr) * 4;      // coefficients, values, the decision's scratch polynomial, the points, this launch's symbols
+    const size_t lds = ((size_t)(5 * S + 8 * pr->n) * NLr) * 4;      // coefficients, values, the decision's scratch polynomial, the points, this launch's symbols and discrepancies
     if (ctx->n_limbs == 4)
         k_probe_feed<9, 8><<<grid, PROBE_NT, lds, s>>>(ctx->pw, pr->pt->xm, pr->pt->pw, pr->n, S, pr->state, ix, count, reset ? 1 : 0,
                                                (const uint32_t *)cols_dev, C, poly, pr->k, decide ? 1 : 0, pr->res_dev, seq, msgs, uq);

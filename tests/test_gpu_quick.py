@@ -228,7 +228,7 @@ def test_probe_at_config3_shape_with_21_liars():
 
 @pytest.mark.parametrize("n,t,liars", [(256, 85, "spread"), (200, 66, "first"), (130, 43, "spread")])
 def test_probe_over_several_workgroups_at_full_size(n, t, liars):
-    """point sets above 128 parties: the probe's launches are four workgroups.  t liars (after every two honest senders, or the first t arrivals),
+    """point sets above 128 parties: the probe's launches are three workgroups.  t liars (after every two honest senders, or the first t arrivals),
     d + t points at once and then one at a time: every verdict and error set equal the oracle's Gao over the same prefix; a reset and
     all points in one launch give the last verdict again."""
     from honeybadgermpc_amd._capi import Context
