@@ -127,6 +127,34 @@ def test_vandermonde_points_with_and_without_high_digits_in_the_first_terms(hip,
     assert hip.vandermonde_batch_evaluate(x, polys, P) == oracle.vandermonde_batch_evaluate(x, polys, P)
 
 
+@pytest.mark.parametrize("p", [P, (1 << 256) - 189, (1 << 64) - 59, 257])
+def test_vandermonde_a_few_polynomials(hip, monkeypatch, p):
+    """up to eight polynomials of eight or more coefficients (what the device decoder evaluates: ONE candidate at all parties' points) take
+    k_eval_few -- a workgroup per (polynomial, point), powers by square and multiply, a tree of additions -- instead of the batched kernels'
+    lane-per-polynomial: the oracle's values at random and structured points, and the batched kernels' (HB_NO_EVAL_FEW=1)"""
+    rnd = random.Random(p % 4093)
+    for n, d, c in [(256, 86, 1), (64, 22, 1), (64, 22, 8), (100, 34, 3), (16, 8, 2), (200, 200, 1), (31, 9, 7), (130, 129, 2)]:
+        if n >= p:
+            n, d = p - 1, min(d, p - 1)
+        x = list(range(1, n + 1))
+        if rnd.random() < 0.5:
+            pts = set()
+            while len(pts) < n:
+                pts.add(rnd.randrange(1, min(p, 1 << 70)))
+            x = sorted(pts)
+            rnd.shuffle(x)
+        polys = rand_rows(rnd, p, c, d)
+        polys[0][-1] = p - 1
+        if c > 1:
+            polys[1] = [0] * d
+        want = oracle.vandermonde_batch_evaluate(x, polys, p)
+        monkeypatch.delenv("HB_NO_EVAL_FEW", raising=False)
+        assert hip.vandermonde_batch_evaluate(x, polys, p) == want
+        if x[0] == 1 and x[-1] == n and n <= 100:            # (the batched kernels tabulate a point set first: the ones other tests have tabulated)
+            monkeypatch.setenv("HB_NO_EVAL_FEW", "1")
+            assert hip.vandermonde_batch_evaluate(x, polys, p) == want
+
+
 def test_vandermonde_edge_cases(hip):
     # ragged rows are zero padded to the longest (pyx:217,232-233); tuples accepted; values reduced mod p
     x = [1, 2, 3]
