@@ -30,8 +30,8 @@ using namespace hb;
 namespace {
 
 constexpr int WB_THREADS = 256;
-constexpr int WB_MAXROWS = 256;   // n' + 1 <= 256
-constexpr int WB_MAXCOLS = 264;
+constexpr int WB_MAXROWS = 264;   // n' + 1 <= 264: config 5's 256 parties with every symbol present are 257 rows
+constexpr int WB_MAXCOLS = 272;
 
 template <int NL> __device__ __forceinline__ void mget(uint32_t (&d)[NL], const uint32_t *p) {
 #pragma unroll
@@ -109,13 +109,13 @@ __global__ void __launch_bounds__(WB_THREADS) k_wb(const FpParams<NL> P, const u
         for (int ee = e; ee >= 1; ee--) {
             const int env = ee + 1, qnv = ee + k, cols = env + qnv + 1, rows = np + 1;
             // ---- build the system ---------------------------------------------------
-            if (tid < np) {
+            for (int r_ = tid; r_ < np; r_ += WB_THREADS) {
                 uint32_t a[NL], bd[NL], b[NL], pw[NL];
-                mget<NL>(a, xm + (size_t)s_idx[tid] * NL);
-                load_digits<NL, NW>(bd, y + (size_t)s_idx[tid] * NW);
+                mget<NL>(a, xm + (size_t)s_idx[r_] * NL);
+                load_digits<NL, NW>(bd, y + (size_t)s_idx[r_] * NW);
                 to_mont(b, bd, P);
                 fp_set(pw, P.one);
-                uint32_t *row = M + (size_t)tid * cols * NL;
+                uint32_t *row = M + (size_t)r_ * cols * NL;
                 for (int j = 0; j < qnv; j++) {
                     if (j < env) { uint32_t v[NL]; mont_mul(v, b, pw, P); mput<NL>(row + (size_t)j * NL, v); }
                     uint32_t ng[NL]; fp_neg(ng, pw, P); mput<NL>(row + (size_t)(env + j) * NL, ng);
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(WB_THREADS) k_wb(const FpParams<NL> P, const u
                     mput<NL>(row + (size_t)j * NL, v);
                 }
             }
-            if (tid < rows) s_perm[tid] = (int16_t)tid;
+            for (int r = tid; r < rows; r += WB_THREADS) s_perm[r] = (int16_t)r;
             __syncthreads();
             // ---- fraction-free Gauss-Jordan ----------------------------------------------
             int ipos = 0, nfree = 0;
@@ -388,7 +388,7 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
     if (!ctx || !x_host || n < 1 || k < 1 || k > n || C < 0) return HB_ERR_BAD_ARG;
     if (C == 0) return HB_OK;
     if (!ys_dev || !present_dev || !coeffs_dev || !coeff_len_dev || !status_dev) return HB_ERR_BAD_ARG;
-    if (n + 1 > WB_MAXROWS || n + 4 > WB_MAXCOLS) return fail(ctx, HB_ERR_UNSUPPORTED, "welch-berlekamp: n > 255");
+    if (n + 1 > WB_MAXROWS || n + 4 > WB_MAXCOLS) return fail(ctx, HB_ERR_UNSUPPORTED, "welch-berlekamp: n > 263");
     hipStream_t s = (hipStream_t)stream;
     const int NLr = ctx->nl();
     // every temporary of this call is released on every way out (the HB_HIP / launch checks return early);

@@ -19,7 +19,7 @@ runs = fails = raised = robust_runs = 0
 while time.time() < t_end:
     n = rnd.choice([7, 10, 13, 16, 22, 31])
     if rnd.random() < 0.08:
-        n = rnd.choice([40, 64, 64, 100, 130])          # three K-blocks on the small-entry kernel; n = 100 and 130: full-size entries, 130: the builder's helper workgroups
+        n = rnd.choice([40, 64, 64, 100, 130, 130, 200, 256])   # three K-blocks on the small-entry kernel; n >= 100: full-size entries; n >= 130: the builder's helper workgroups, the probe over six workgroups
     t = rnd.randrange(3, (n - 1) // 3 + 1) if (n - 1) // 3 >= 3 else (n - 1) // 3
     if t < 3:
         continue

@@ -911,7 +911,7 @@ def test_gao_large_batches_pair_up_by_themselves(hip, monkeypatch):
     assert hip.gao_interpolate_batch(x, words, k, P) == got
 
 
-@pytest.mark.parametrize("p,n,k,reps", [(P, 100, 34, 6), (P, 64, 22, 8), (53, 22, 8, 40), (13, 10, 3, 40), (P, 7, 1, 6)])
+@pytest.mark.parametrize("p,n,k,reps", [(P, 100, 34, 6), (P, 64, 22, 8), (53, 22, 8, 40), (13, 10, 3, 40), (P, 7, 1, 6), (P, 256, 86, 2), (P, 256, 128, 5), (P, 262, 130, 5)])
 def test_wb_batch_vs_oracle(p, n, k, reps):
     from honeybadgermpc_amd.device import wb_decode_batch
 
