@@ -519,10 +519,18 @@ struct ProbeResult { int32_t ok, n_err, npts, seq; uint8_t err[PROBE_MAXN]; };  
 constexpr int PROBE_SPLIT_N = 128;
 constexpr int PROBE_MAXG = 8;
 constexpr int PROBE_DW = 40, PROBE_GW = 8;
-constexpr size_t PROBE_MSG_WORDS = (size_t)PROBE_MAXN * (PROBE_DW + PROBE_GW) + PROBE_MAXG;
+constexpr size_t PROBE_MSG_WORDS = (size_t)PROBE_MAXN * (PROBE_DW + PROBE_GW) + PROBE_MAXG + 8;      // (+ the abort word)
 constexpr size_t PROBE_STATE_WORDS = (size_t)4 * (2 * PROBE_MAXN + 2) * 9 + 8 + PROBE_MAXN;      // the largest state: coefficients + values of 256 points, degrees, the fed list
-__device__ __forceinline__ void probe_wait(const uint32_t *flag, uint32_t want) {
-    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(1);
+// (every wait is bounded: a workgroup that never shows up -- a launch that lost a workgroup, a bug -- must not hang the device.  ~2^22 polls
+// of >= 64 cycles are tenths of a second where a message takes microseconds; the waiter then raises the launch's abort word, which the
+// deciding workgroup hands to the host as a failed launch)
+constexpr int PROBE_SPIN_MAX = 1 << 22;
+__device__ __forceinline__ void probe_wait(const uint32_t *flag, uint32_t want, uint32_t *abort_word, uint32_t abort_value) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > PROBE_SPIN_MAX) { __hip_atomic_store(abort_word, abort_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
     __threadfence();
 }
 __device__ __forceinline__ void probe_post(uint32_t *flag, uint32_t value) {
@@ -532,10 +540,14 @@ __device__ __forceinline__ void probe_post(uint32_t *flag, uint32_t value) {
 __device__ __forceinline__ void probe_send(uint32_t *slot, int word, uint32_t q, uint32_t payload) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(slot) + word, ((unsigned long long)q << 32) | payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ uint32_t probe_recv(const uint32_t *slot, int word, uint32_t q) {
+__device__ __forceinline__ uint32_t probe_recv(const uint32_t *slot, int word, uint32_t q, uint32_t *abort_word, uint32_t abort_value) {
     const unsigned long long *w = reinterpret_cast<const unsigned long long *>(slot) + word;
     unsigned long long v;
-    while ((uint32_t)((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != q) __builtin_amdgcn_s_sleep(1);
+    int spins = 0;
+    while ((uint32_t)((v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != q) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > PROBE_SPIN_MAX) { __hip_atomic_store(abort_word, abort_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
     return (uint32_t)v;
 }
 
@@ -574,7 +586,9 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
     const bool c_own = cp_n > 0;
     const int v_per = G > 1 ? (n + G - NC - 1) / (G - NC) : n;     // ... and the values at the parties [v_lo, v_hi)
     const int v_lo = G > 1 ? (c_own ? 0 : min(n, (g - NC) * v_per)) : 0, v_hi = G > 1 ? (c_own ? 0 : min(n, (g - NC + 1) * v_per)) : n, v_n = v_hi - v_lo;
-    uint32_t *dmsg = msgs, *gmsg = msgs + (size_t)PROBE_MAXN * PROBE_DW, *gdone = gmsg + (size_t)PROBE_MAXN * PROBE_GW;
+    uint32_t *dmsg = msgs, *gmsg = msgs + (size_t)PROBE_MAXN * PROBE_DW, *gdone = gmsg + (size_t)PROBE_MAXN * PROBE_GW, *gabort = gdone + PROBE_MAXG;
+    const uint32_t abort_v = 0x80000000u | uq;               // what a waiter that gave up leaves in the abort word (cleared by a reset)
+    if (G > 1 && leader && reset && threadIdx.x == 0) __hip_atomic_store(gabort, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t q0 = uq << 9;                             // sequence numbers of this launch's points: q0 + 1 .. (uq: unique among the launches that use this buffer)
     // coef[q][i][NL], q: 0 = A_0, 1 = B_0, 2 = A_1, 3 = B_1; val[q][party][NL]; a scratch polynomial for the decision; the reduction buffer
     uint32_t *coef = p_lds;
@@ -694,12 +708,12 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
                 if (tid < 2 * NL) probe_send(dm, tid, q, dl[tid / NL][tid % NL]);
                 else if (tid < 2 * NL + 2) probe_send(dm, tid, q, (uint32_t)ctl[tid - 2 * NL]);
             } else {
-                if (tid < 2 * NL) dl[tid / NL][tid % NL] = probe_recv(dm, tid, q);
-                else if (tid < 2 * NL + 2) ctl[tid - 2 * NL] = (int)probe_recv(dm, tid, q);
+                if (tid < 2 * NL) dl[tid / NL][tid % NL] = probe_recv(dm, tid, q, gabort, abort_v);
+                else if (tid < 2 * NL + 2) ctl[tid - 2 * NL] = (int)probe_recv(dm, tid, q, gabort, abort_v);
             }
             // the degrees the previous point left (only the coefficients can tell when a leading one cancelled)
             if (pt > 0 && tid >= 64 && tid < 68 && !(((tid - 64) & 1) >= cp_lo && ((tid - 64) & 1) < cp_hi))
-                deg[tid - 64] = (int)probe_recv(gmsg + (size_t)(pt - 1) * PROBE_GW, tid - 64, q - 1);
+                deg[tid - 64] = (int)probe_recv(gmsg + (size_t)(pt - 1) * PROBE_GW, tid - 64, q - 1, gabort, abort_v);
             __syncthreads();
         }
         // the pair of smaller leading monomial among those with a discrepancy; (1, k-1)-weighted degree, ties: Y terms larger
@@ -828,7 +842,7 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
     }
     // (the degrees of the parts another workgroup holds, as the last point left them)
     if (G > 1 && leader && count > 0 && tid >= 64 && tid < 68 && !(((tid - 64) & 1) >= cp_lo && ((tid - 64) & 1) < cp_hi))
-        deg[tid - 64] = (int)probe_recv(gmsg + (size_t)(count - 1) * PROBE_GW, tid - 64, q0 + (uint32_t)count);
+        deg[tid - 64] = (int)probe_recv(gmsg + (size_t)(count - 1) * PROBE_GW, tid - 64, q0 + (uint32_t)count, gabort, abort_v);
     // persistent state back (the decision below works on copies)
     __syncthreads();
     if (G == 1) {
@@ -857,7 +871,7 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
         __syncthreads();
         if (!leader) { if (tid == 0) probe_post(gdone + g, uq); return; }
         if (!decide) return;
-        if (tid > 0 && tid < G) probe_wait(gdone + tid, uq);
+        if (tid > 0 && tid < G) probe_wait(gdone + tid, uq, gabort, abort_v);
         __syncthreads();
         for (size_t i = tid; i < vwords; i += PROBE_NT) val[i] = __builtin_nontemporal_load(state + cwords + i);
         for (int i = tid; G >= 3 && i < 2 * S * NL; i += PROBE_NT) {       // the B parts' coefficients
@@ -961,7 +975,10 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
     // one wave hands the verdict over: its stores, a system-scope fence, then the sequence number the host is polling
     if (tid < 64) {
         reinterpret_cast<uint32_t *>(result->err)[tid] = fine ? serr[tid] : 0u;
-        if (tid == 0) { result->ok = fine ? 1 : 0; result->npts = npts; result->n_err = fine ? ctl[0] : 0; }
+        if (tid == 0) {
+            const bool gave_up = G > 1 && (__hip_atomic_load(gabort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 31) != 0;      // (in this launch or in one since the reset: the state is void either way)
+            result->ok = gave_up ? -1 : (fine ? 1 : 0); result->npts = npts; result->n_err = fine ? ctl[0] : 0;
+        }
         __threadfence_system();
         if (tid == 0) *reinterpret_cast<volatile int32_t *>(&result->seq) = seq;
     }
@@ -1595,6 +1612,7 @@ int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *c
         std::atomic_thread_fence(std::memory_order_acquire);
         if (*flag != seq) return fail(ctx, HB_ERR_HIP, "probe: the kernel finished without a verdict");
     }
+    if (pr->res_host->ok < 0) { pr->fed.clear(); pr->poly = -1; return fail(ctx, HB_ERR_HIP, "probe: a workgroup of the launch waited in vain for another (the launch is void; the probe starts from a reset)"); }
     *ok = pr->res_host->ok;
     memcpy(err_mask, pr->res_host->err, (size_t)pr->n);
     if (!*ok) memset(err_mask, 0, (size_t)pr->n);
