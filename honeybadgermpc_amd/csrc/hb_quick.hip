@@ -766,11 +766,11 @@ __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, c
                 int ci = -1, cpart = 0;                               // a coefficient item's index and part
                 const uint32_t *xi = nullptr;                         // a value's / a coming point's party point
                 if (it < nce) {
-                    cpart = it / (top + 1); ci = it - cpart * (top + 1); cpart += cp_lo;
+                    cpart = it >= top + 1 ? 1 : 0; ci = it - cpart * (top + 1); cpart += cp_lo;      // (at most two parts: no division)
                     po = coef + ((size_t)(2 * jo + cpart) * S + ci) * NL;
                     ps = coef + ((size_t)(2 * js + cpart) * S + ci) * NL;
                 } else if (it < nce + 2 * v_n) {
-                    const int ee = it - nce, part = ee / v_n, i = v_lo + ee - part * v_n;
+                    const int ee = it - nce, part = ee >= v_n ? 1 : 0, i = v_lo + ee - part * v_n;
                     po = val + ((size_t)(2 * jo + part) * n + i) * NL;
                     ps = val + ((size_t)(2 * js + part) * n + i) * NL;
                     xi = xl + (size_t)i * NL;
