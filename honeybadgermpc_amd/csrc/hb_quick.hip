@@ -559,17 +559,22 @@ template <int NL> __device__ __forceinline__ bool lds_nonzero(const uint32_t *p)
 }
 
 // The state of a probe: the four polynomials by their COEFFICIENTS (the decision reads degrees and the locator's roots off them) and by
-// their VALUES at all n party points.  With the values at hand the discrepancy of a new point is a look-up, A_j(x_a) + y_a B_j(x_a),
-// and a point costs two dependent multiplications (discrepancy, update) where evaluating the polynomials at it cost four and a
-// 64-lane reduction (round 3: 9 us a point at n = 64, 20 at n = 256); the update
+// their VALUES at all n party points.  With the values at hand the discrepancy of a new point is a look-up, A_j(x_a) + y_a B_j(x_a) (round
+// 3 evaluated the polynomials at it: four multiplications and a 64-lane reduction, 9 us a point at n = 64, 20 at n = 256); the update
 //     Q_jo <- d_js Q_jo - d_jo Q_js,     Q_js <- (X - x_a) Q_js
-// acts on values pointwise (val_js[i] <- (x_i - x_a) val_js[i]) and on coefficients as before, all items of a point in one phase.
+// acts on values pointwise (val_js[i] <- (x_i - x_a) val_js[i]) and on coefficients as before.  A point's critical path, as round 5 left it:
+//   * the discrepancies of ALL the points of a launch are formed up front and carried along by every update like any other value: the
+//     pivot of a point is picked from a look-up, no multiplication after the previous point's update;
+//   * an item (a coefficient, a value, a pending discrepancy) is two UNITS for two threads -- Q_jo's two products and one reduction, Q_js's one
+//     product -- every unit reads the state as the last point left it, results wait in registers until all have read;
+//   * the degrees after a point follow from the degrees before it; the thread that computes a leading coefficient that may cancel (equal
+//     degrees of the two pairs) looks, and only then are the degrees found by a scan.
 //
-// One workgroup does all of it up to PROBE_SPLIT_N points.  Above (config 5's 256 parties: 2 (n + 3) coefficient items and 2 n value items of
-// three multiplications each are 3.3 waves a SIMD of ONE CU, 8.4 us a point) the launch is G workgroups -- the grid is 8 (G - 1) + 1 and
-// only the workgroups whose index is a multiple of 8 stay, so that they sit on ONE XCD and talk through its L2 -- and a point is: the
-// workgroup holding the values at the new party computes the discrepancies and posts them; everybody picks the pivot from them and the
-// degrees and updates its own items; workgroup 0 posts the degrees that result.
+// One workgroup does all of it up to PROBE_SPLIT_N points (4.0 us a point at n = 64).  Above (config 5's 256 parties: 2 (n + 3) coefficient
+// items, 2 n value items and the pending discrepancies are 3+ waves a SIMD of ONE CU, 8.4 us a point) the launch is G workgroups -- the grid is
+// 8 (G - 1) + 1 and only the workgroups whose index is a multiple of 8 stay, so that they sit on ONE XCD and talk through its L2 -- and a
+// point is: the workgroup holding the values at the new party posts the two discrepancies; everybody picks the pivot from them and the
+// degrees and updates its own items; the workgroups holding coefficients post the degrees that result (3.8 us a point with six).
 template <int NL, int NW>
 __global__ void __launch_bounds__(PROBE_NT) k_probe_feed(const FpParams<NL> P, const uint32_t *__restrict__ xm, const uint32_t *__restrict__ pw, int n, int S,
                                                     uint32_t *__restrict__ state, const ProbeIdx ix, int count, int reset,
