@@ -76,6 +76,8 @@ SYMBOLS = {
     "hb_dec_arrivals_list": (_i, [_vp, _vp, _i, _vp]),
     "hb_dec_destroy": (None, [_vp]),
     "hb_symbols_fetch": (_i, [_vp, _vp, _i, _i64, _i64, _vp, _i, _vp, _vp]),
+    "hb_candidate_check": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "hb_stream_after": (_i, [_vp, _vp, _vp]),
     "hb_probe_create": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
     "hb_probe_feed": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _vp, _vp]),
     "hb_probe_reset": (_i, [_vp]),

@@ -108,6 +108,10 @@ struct hb_ctx {
     std::map<std::string, std::pair<void *, size_t>> scratch;
     void *fetch_host = nullptr, *fetch_dev = nullptr; // hb_symbols_fetch: pinned, device-visible hand-over buffer (hb::SymFetch)
     int fetch_seq = 0;
+    void *cand_host = nullptr, *cand_dev = nullptr;   // hb_candidate_check: pinned hand-over buffer (hb::CandCheck) and its ticket counter on the device
+    int32_t *cand_ticket = nullptr;
+    int cand_seq = 0;
+    void *after_event = nullptr;                      // hb_stream_after: one event, recorded and waited for under the context's mutex
     std::map<int, void *> wide_shared;                // d -> hb::Mm8wShared *
     std::map<std::string, std::vector<int>> wide_shapes;   // launch geometry per (row tiles, K-blocks, chunk tiles)
     void *mm8_shared = nullptr;                       // hb::Mm8Shared *: constants of the small-entry matrix-core kernels (hb_mm8.hpp)

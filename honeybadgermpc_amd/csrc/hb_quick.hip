@@ -1071,6 +1071,11 @@ void point_tables_free(hb_ctx *ctx) {
     ctx->probe_host_pool.clear();
     if (ctx->fetch_host) (void)hipHostFree(ctx->fetch_host);
     ctx->fetch_host = ctx->fetch_dev = nullptr;
+    if (ctx->cand_host) (void)hipHostFree(ctx->cand_host);
+    if (ctx->cand_ticket) (void)hipFree(ctx->cand_ticket);
+    ctx->cand_host = ctx->cand_dev = nullptr; ctx->cand_ticket = nullptr;
+    if (ctx->after_event) (void)hipEventDestroy((hipEvent_t)ctx->after_event);
+    ctx->after_event = nullptr;
 }
 
 // hb_symbols_fetch: a few symbols of one polynomial cross to the host through pinned memory, the sequence number last
@@ -1084,6 +1089,65 @@ __global__ void __launch_bounds__(256) k_symbols_fetch(const uint64_t *__restric
     __threadfence_system();
     __syncthreads();
     if (t == 0) *reinterpret_cast<volatile int32_t *>(&out->seq) = seq;
+}
+
+// A candidate against the arrived symbols of its chunk, in one launch: workgroup i evaluates the polynomial at party i's point (thread l the
+// powers l, l + 128, ... by square and multiply, a tree of additions -- k_eval_few's arithmetic), writes the value to pinned memory and says
+// whether the party's symbol of the chunk differs; the last workgroup to finish (a ticket) writes the sequence number the host polls.
+constexpr int CAND_MAXN = 1024;
+struct CandCheck { uint64_t vals[CAND_MAXN * 4]; uint8_t differs[CAND_MAXN]; int32_t seq; };
+template <int NL, int NW>
+__global__ void __launch_bounds__(128) k_candidate_check(const FpParams<NL> P, const uint32_t *__restrict__ x, int n, const uint32_t *__restrict__ poly, int d,
+                                                         const uint32_t *__restrict__ cols, int64_t C, int64_t chunk, CandCheck *__restrict__ out,
+                                                         int32_t *__restrict__ ticket, int seq) {
+    __shared__ uint32_t red[128][NL];
+    const int i = blockIdx.x, tid = threadIdx.x;
+    uint32_t xd[NL], xm[NL], acc[NL];
+    load_digits<NL, NW>(xd, x + (size_t)i * NW);
+    to_mont(xm, xd, P);
+#pragma unroll
+    for (int q = 0; q < NL; q++) acc[q] = 0;
+    for (int l = tid; l < d; l += 128) {
+        uint32_t pw[NL], cd[NL], m[NL];
+        fp_pow_u32(pw, xm, (uint32_t)l, P);
+        load_digits<NL, NW>(cd, poly + (size_t)l * NW);
+        mont_mul(m, cd, pw, P);
+        fp_add(acc, acc, m, P);
+    }
+#pragma unroll
+    for (int q = 0; q < NL; q++) red[tid][q] = acc[q];
+    __syncthreads();
+    for (int w = 64; w >= 1; w >>= 1) {
+        if (tid < w) {
+            uint32_t a[NL], b[NL], r[NL];
+#pragma unroll
+            for (int q = 0; q < NL; q++) { a[q] = red[tid][q]; b[q] = red[tid + w][q]; }
+            fp_add(r, a, b, P);
+#pragma unroll
+            for (int q = 0; q < NL; q++) red[tid][q] = r[q];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        uint32_t r[NL], w[NW], got[NW];
+#pragma unroll
+        for (int q = 0; q < NL; q++) r[q] = red[0][q];
+        pack<NL, NW>(w, r);
+        load_words<NW>(got, cols + ((size_t)i * (size_t)C + (size_t)chunk) * NW);
+        uint32_t df = 0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) df |= w[q] ^ got[q];
+        uint32_t *o = reinterpret_cast<uint32_t *>(out->vals) + (size_t)i * NW;      // (a narrow context's element is one 64-bit word: NW = 2)
+#pragma unroll
+        for (int q = 0; q < NW; q++) o[q] = w[q];
+        out->differs[i] = df ? 1 : 0;
+        __threadfence_system();
+        if (atomicAdd(ticket, 1) == n - 1) {
+            *ticket = 0;
+            __threadfence_system();
+            *reinterpret_cast<volatile int32_t *>(&out->seq) = seq;
+        }
+    }
 }
 
 }  // namespace hb
@@ -1656,6 +1720,73 @@ int hb_symbols_fetch(hb_ctx *ctx, const uint64_t *cols_dev, int n, int64_t C, in
     std::atomic_thread_fence(std::memory_order_acquire);
     if (*flag != seq) return fail(ctx, HB_ERR_HIP, "symbols_fetch: the kernel finished without handing over");
     memcpy(out_host, host->w, (size_t)count * L * sizeof(uint64_t));
+    return HB_OK;
+}
+
+int hb_candidate_check(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_t *coeffs_dev, int d, const uint64_t *cols_dev, int64_t C, int64_t chunk,
+                       uint64_t *out_values_host, uint8_t *out_differs_host, void *stream) { HB_API_GUARD(ctx);
+    if (!ctx || !x_host || !coeffs_dev || !cols_dev || !out_values_host || !out_differs_host || n < 1 || d < 1 || C < 1 || chunk < 0 || chunk >= C)
+        return fail(ctx, HB_ERR_BAD_ARG, "candidate_check: arguments");
+    if (n > CAND_MAXN) return fail(ctx, HB_ERR_UNSUPPORTED, "candidate_check: more than 1024 points");
+    hipStream_t s = (hipStream_t)stream;
+    if (!ctx->cand_host) {
+        void *h = nullptr, *dv = nullptr;
+        HB_HIP(ctx, hipHostMalloc(&h, sizeof(CandCheck), hipHostMallocMapped));
+        if (hipHostGetDevicePointer(&dv, h, 0) != hipSuccess || hipMalloc(&ctx->cand_ticket, sizeof(int32_t)) != hipSuccess ||
+            hipMemsetAsync(ctx->cand_ticket, 0, sizeof(int32_t), s) != hipSuccess) {
+            (void)hipHostFree(h);
+            if (ctx->cand_ticket) { (void)hipFree(ctx->cand_ticket); ctx->cand_ticket = nullptr; }
+            return fail(ctx, HB_ERR_HIP, "candidate_check: buffers");
+        }
+        memset(h, 0, sizeof(CandCheck));
+        ctx->cand_host = h; ctx->cand_dev = dv;
+    }
+    // the party points on the device: a table of the context, keyed by the points (shared with hb_vandermonde_batch_evaluate's few-polynomial path)
+    std::string key = table_key("xs", ctx, x_host, n, 0);
+    uint32_t *xd = nullptr;
+    auto it = ctx->dcache.find(key);
+    if (it != ctx->dcache.end()) { xd = (uint32_t *)it->second; cache_touch(ctx, "d|" + key); }
+    else {
+        const int rcx = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rcx) return rcx;
+        ctx->dcache[key] = xd;
+        cache_note(ctx, "d|" + key, [ctx, key]() { auto f = ctx->dcache.find(key); if (f != ctx->dcache.end()) { (void)hipFree(f->second); ctx->dcache.erase(f); } });
+    }
+    CandCheck *host = static_cast<CandCheck *>(ctx->cand_host);
+    const int seq = ++ctx->cand_seq;
+    if (ctx->n_limbs == 4)
+        k_candidate_check<9, 8><<<(unsigned)n, 128, 0, s>>>(ctx->pw, xd, n, (const uint32_t *)coeffs_dev, d, (const uint32_t *)cols_dev, C, chunk, static_cast<CandCheck *>(ctx->cand_dev), ctx->cand_ticket, seq);
+    else
+        k_candidate_check<3, 2><<<(unsigned)n, 128, 0, s>>>(ctx->pn, xd, n, (const uint32_t *)coeffs_dev, d, (const uint32_t *)cols_dev, C, chunk, static_cast<CandCheck *>(ctx->cand_dev), ctx->cand_ticket, seq);
+    HB_LAUNCH_CHECK(ctx);
+    // (the buffer belongs to the context: the wait stays inside its mutex -- it is some tens of microseconds; past 5 ms, synchronise)
+    volatile int32_t *flag = &host->seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    int spins = 0;
+    while (*flag != seq) {
+        if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) {
+            HB_HIP(ctx, hipStreamSynchronize(s));
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (*flag != seq) return fail(ctx, HB_ERR_HIP, "candidate_check: the kernel finished without handing over");
+    memcpy(out_values_host, host->vals, (size_t)n * ctx->n_limbs * sizeof(uint64_t));
+    memcpy(out_differs_host, host->differs, (size_t)n);
+    return HB_OK;
+}
+
+// `stream` goes on only after everything enqueued on `after` so far (one event of the context, recorded and waited for here: what
+// torch's Stream.wait_stream does in 30 us of Python)
+int hb_stream_after(hb_ctx *ctx, void *stream, void *after) { HB_API_GUARD(ctx);
+    if (!ctx) return HB_ERR_BAD_ARG;
+    if (stream == after) return HB_OK;
+    if (!ctx->after_event) {
+        hipEvent_t ev = nullptr;
+        HB_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ctx->after_event = ev;
+    }
+    HB_HIP(ctx, hipEventRecord((hipEvent_t)ctx->after_event, (hipStream_t)after));
+    HB_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ctx->after_event, 0));
     return HB_OK;
 }
 

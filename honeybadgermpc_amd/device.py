@@ -286,6 +286,7 @@ class _Probe:
         self._mask = np.zeros(n, dtype=np.uint8)
         with ctx.torch.cuda.device(ctx.tdev):
             self.side = ctx.torch.cuda.Stream()
+        self._side_raw = ctypes.c_void_p(self.side.cuda_stream)
 
     def _feed(self, z, cols, c, poly, decide, after_current):
         if poly != self.poly or z[: len(self.fed)] != self.fed:
@@ -297,10 +298,10 @@ class _Probe:
         if after_current:
             # the columns were written on the caller's stream -- copied in by add(idx, column), or received in place and reduced there
             # (ctx.reduce_) before add(idx): the probe's stream always waits for it (one event)
-            self.side.wait_stream(self.ctx.torch.cuda.current_stream())
+            self.ctx.check(self.ctx.lib.hb_stream_after(self.ctx.h, self._side_raw, self.ctx.stream()), "hb_stream_after")
         ia = np.array(new if new else [0], dtype=np.int32)
         rc = self.ctx.lib.hb_probe_feed(self.h, np_ptr(ia), len(new), self.ctx.ptr(cols), c, poly, 1 if decide else 0, ctypes.byref(self._ok), np_ptr(self._mask),
-                                        ctypes.c_void_p(self.side.cuda_stream))
+                                        self._side_raw)
         self.ctx.check(rc, "hb_probe_feed")
         self.fed = list(z)
 
@@ -867,6 +868,14 @@ class DeviceIncrementalDecoder:
     def _candidate_errors(self, coeffs, chunk):
         """-> (the arrived senders whose symbol of `chunk` differs from the candidate at their point, the candidate's values at the n points
         on the host): one small evaluation, its values and the arrived symbols of the chunk brought over, compared there"""
+        ctx = self.ctx
+        if self.n <= 1024:
+            # one launch: the candidate at every party's point and, per party, whether its symbol of the chunk differs -- through pinned memory
+            ev = np.empty((self.n, self.L), dtype=np.int64)
+            diff = np.empty(self.n, dtype=np.uint8)
+            ctx.check(ctx.lib.hb_candidate_check(ctx.h, np_ptr(self._xh_all), self.n, ctx.ptr(coeffs.contiguous()), self.degree + 1, ctx.ptr(self._cols),
+                                                 self.batch_size, chunk, np_ptr(ev), np_ptr(diff), ctx.stream()), "hb_candidate_check")
+            return [s_ for s_ in self._z if diff[s_]], ev
         ev = self._disagreeing(coeffs).cpu().numpy()
         sym = self._symbols(chunk, self._z)
         differs = (sym != ev[np.asarray(self._z, dtype=np.int64)]).any(axis=1)

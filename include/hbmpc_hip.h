@@ -193,6 +193,15 @@ void hb_dec_destroy(hb_dec *dec);
  * the guess is a candidate for ONE polynomial (device.py _candidate_cap).  One launch that writes pinned memory the call polls: the answer
  * is on the host a few microseconds after the columns are, where a synchronous 32-byte copy costs a stream synchronisation. */
 int hb_symbols_fetch(hb_ctx *ctx, const uint64_t *cols_dev, int n, int64_t C, int64_t chunk, const int32_t *idx, int count, uint64_t *out_host, void *stream);
+/* A candidate polynomial (coeffs_dev: d packed coefficients) against the received symbols of its chunk: the values it takes at the n party points
+ * -> out_values_host[n][limbs] (the host keeps them for the senders still to come) and, per party, whether the symbol of `chunk` in its row of
+ * the party-major buffer differs -> out_differs_host[n] (rows of parties that have not arrived hold whatever they hold: the caller looks at the
+ * arrived ones).  IncrementalDecoder's comparison of the guess with the received shares (reed_solomon.py:316-326) for ONE polynomial: one launch, the
+ * answer through pinned memory.  n <= 1024 (HB_ERR_UNSUPPORTED above). */
+int hb_candidate_check(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_t *coeffs_dev, int d, const uint64_t *cols_dev, int64_t C, int64_t chunk,
+                       uint64_t *out_values_host, uint8_t *out_differs_host, void *stream);
+/* plumbing: `stream` goes on only after everything enqueued on `after` so far (an event of the context) */
+int hb_stream_after(hb_ctx *ctx, void *stream, void *after);
 
 /* gao_interpolate for ONE codeword, incremental in its points (rsdecode_impl.h:325-363 as GaoRobustDecoder.robust_decode
  * runs it per polynomial, reed_solomon.py:151-186, 334-365): the probe keeps a reduced basis of the interpolation module of

@@ -264,6 +264,40 @@ def test_probe_over_several_workgroups_at_full_size(n, t, liars):
     pr.close()
 
 
+@pytest.mark.parametrize("p,n,d,c", [(P, 64, 22, 5), (P, 256, 86, 3), (P, 100, 34, 2), ((1 << 64) - 59, 40, 11, 4), (P, 7, 3, 1)])
+def test_candidate_check_vs_oracle(p, n, d, c):
+    """hb_candidate_check: one polynomial at all n points and, per party, whether its symbol of the chunk differs from that value -- the
+    oracle's evaluation, symbols altered at known parties (one word of one limb, the top limb), every chunk of a small buffer in turn"""
+    from honeybadgermpc_amd._capi import Context, np_ptr
+
+    ctx = Context.get(p)
+    rnd = random.Random(n * 7 + d)
+    x = list(range(1, n + 1)) if n != 100 else rnd.sample(range(1, 10 ** 6), n)
+    xh = ctx.host_elems(x)
+    L = ctx.n_limbs
+    for chunk in range(c):
+        f = [rnd.randrange(p) for _ in range(d)]
+        if chunk == 1:
+            f = [0] * d
+        want = oracle.vandermonde_batch_evaluate(x, [f], p)[0]
+        vals = [[rnd.randrange(p) for _ in range(c)] for _ in range(n)]
+        liars = set(rnd.sample(range(n), rnd.randrange(0, n // 2 + 1)))
+        for i in range(n):
+            vals[i][chunk] = want[i] if i not in liars else (want[i] + 1 + rnd.randrange(p - 1)) % p
+        one_bit = rnd.randrange(n)
+        if one_bit not in liars:
+            liars.add(one_bit)
+            vals[one_bit][chunk] = want[one_bit] ^ (1 << (64 * L - 8)) if (want[one_bit] ^ (1 << (64 * L - 8))) < p else (want[one_bit] + 1) % p
+        cols = ctx.upload_ints([v for row in vals for v in row])
+        coeffs = ctx.upload_ints(f)
+        ev = np.empty((n, L), dtype=np.int64)
+        diff = np.empty(n, dtype=np.uint8)
+        ctx.check(ctx.lib.hb_candidate_check(ctx.h, np_ptr(xh), n, ctx.ptr(coeffs), d, ctx.ptr(cols), c, chunk, np_ptr(ev), np_ptr(diff), ctx.stream()), "hb_candidate_check")
+        got = [sum((int(ev[i, j]) & ((1 << 64) - 1)) << (64 * j) for j in range(L)) for i in range(n)]
+        assert got == want
+        assert set(np.nonzero(diff)[0].tolist()) == liars
+
+
 def test_point_tables_are_cache_entries():
     """the per-point-set tables (n^2 inverse differences) are entries of the context's bounded table cache: hundreds of point sets
     leave at most the cap resident, a probe keeps its own table alive across a clear, and results stay right"""
