@@ -25,4 +25,4 @@ done
 timeout 500 python scratch/stress_decoder.py 400 61 > "$OUT/stress_decoder.txt" 2>&1
 timeout 300 python scratch/stress_gao.py 200 62 > "$OUT/stress_gao.txt" 2>&1
 timeout 300 python scratch/stress_open_paths.py 90 63 > "$OUT/stress_open_paths.txt" 2>&1
-tail -3 "$OUT/stress_decoder.txt" "$OUT/stress_gao.txt" "$OUT/stress_open_paths.txt" "$OUT/probe_workgroups_sweep.txt"
+tail -n 3 "$OUT/stress_decoder.txt" "$OUT/stress_gao.txt" "$OUT/stress_open_paths.txt" "$OUT/probe_workgroups_sweep.txt"

@@ -28,7 +28,7 @@ data = cols.clone()
 for i in range(t):
     data[i] = rand(C)
 order = list(range(n))
-if len(sys.argv) > 3 and sys.argv[3] == 'spread':
+if len(sys.argv) > 3 and sys.argv[3] == 'spread':  # (argv[4]: first | mid | last -- which add() is profiled)
     honest = list(range(t, n)); step = len(honest) // (t + 1); order = []
     for i in range(t):
         order += honest[i * step:(i + 1) * step] + [i]
@@ -40,8 +40,9 @@ prof = cProfile.Profile()
 for rep in range(8):
     dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, columns=data, use_omega_powers=omega)
     torch.cuda.synchronize()
+    which = sys.argv[4] if len(sys.argv) > 4 else "first"
     for k_, idx in enumerate(order):
-        if rep >= 3 and k_ == need - 1:
+        if rep >= 3 and ((which == "first" and k_ == need - 1) or (which == "last" and k_ == n - 1) or (which == "mid" and k_ == need + (n - need) // 2)):
             prof.enable(); dec.add(idx); prof.disable()
         else:
             dec.add(idx)
