@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void k_mv64(const uint2 *__restrict__ M, const
     }
 }
 
-static int mv64_dt(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 24 ? 24 : (d <= 32 ? 32 : MV64_DMAX))); }
+// rows are padded to DT terms; 22 is config 3's degree + 1 (a row of 24 is 9 % of multiply-adds on zeros)
+static int mv64_dt(int d) { return d <= 8 ? 8 : (d <= 16 ? 16 : (d <= 22 ? 22 : (d <= 24 ? 24 : (d <= 32 ? 32 : MV64_DMAX)))); }
 
 struct Mv64Matrix {
     int n_out, d;
@@ -232,6 +233,7 @@ int launch_mv64(hb_ctx *ctx, const Mv64Matrix *m, const uint64_t *in, hb_view iv
     } while (0)
     if (m->d <= 8) MV64_LAUNCH(8);
     else if (m->d <= 16) MV64_LAUNCH(16);
+    else if (m->d <= 22) MV64_LAUNCH(22);
     else if (m->d <= 24) MV64_LAUNCH(24);
     else if (m->d <= 32) MV64_LAUNCH(32);
     else MV64_LAUNCH(40);
