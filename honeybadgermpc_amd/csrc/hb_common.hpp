@@ -28,6 +28,44 @@ struct Narrow { static constexpr int NL = 3, NW = 2; };
 
 constexpr int OT = 4;  // outputs per wave tile in the mat-vec kernel
 
+// ONE polynomial (d packed coefficients, whatever words the caller packed: below R) at ONE point (packed), by the 128 threads of a
+// workgroup: thread l raises the point to its powers l, l + 128, ... by square and multiply, multiplies by the coefficients, and a tree
+// over `red` adds up -- ~20 dependent multiplications whatever d.  The canonical value comes back in every thread's r (read from red[0]).
+// (k_eval_few, k_candidate_check: what the device decoder asks for a candidate, where the batched kernels' lane-per-polynomial is one lane.)
+template <int NL, int NW>
+__device__ __forceinline__ void eval_at_point_128(uint32_t (&r)[NL], const uint32_t *__restrict__ x_packed, const uint32_t *__restrict__ poly, int d,
+                                                  const FpParams<NL> &P, uint32_t (*red)[NL]) {
+    const int tid = threadIdx.x;
+    uint32_t xd[NL], xm[NL], acc[NL];
+    load_digits<NL, NW>(xd, x_packed);
+    to_mont(xm, xd, P);
+#pragma unroll
+    for (int q = 0; q < NL; q++) acc[q] = 0;
+    for (int l = tid; l < d; l += 128) {
+        uint32_t pw[NL], cd[NL], m[NL];
+        fp_pow_u32(pw, xm, (uint32_t)l, P);                       // Montgomery form of x^l
+        load_digits<NL, NW>(cd, poly + (size_t)l * NW);
+        mont_mul(m, cd, pw, P);                                   // coefficient x Montgomery power -> the canonical product
+        fp_add(acc, acc, m, P);
+    }
+#pragma unroll
+    for (int q = 0; q < NL; q++) red[tid][q] = acc[q];
+    __syncthreads();
+    for (int w = 64; w >= 1; w >>= 1) {
+        if (tid < w) {
+            uint32_t a[NL], b[NL], t[NL];
+#pragma unroll
+            for (int q = 0; q < NL; q++) { a[q] = red[tid][q]; b[q] = red[tid + w][q]; }
+            fp_add(t, a, b, P);
+#pragma unroll
+            for (int q = 0; q < NL; q++) red[tid][q] = t[q];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NL; q++) r[q] = red[0][q];
+}
+
 // word index of digit q of element (i, l) of an n_out x n_in matrix in kernel layout
 // [tile][l][digit][OT], tile = i / OT: the OT outputs of one digit form one aligned uint4
 __host__ __device__ inline size_t m_index(int i, int l, int n_in, int nl, int q) {
@@ -328,6 +366,7 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
 int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout &L, uint8_t *base, int32_t *status_dev, hipStream_t s, bool with_z = false);
 // ---- word-size primes (one-limb contexts): the 8-byte mat-vec of hb_narrow.hip -------------------------------------------------
 struct Mv64Matrix;
+int points_on_device(hb_ctx *ctx, const uint64_t *x_host, int n, uint32_t **out, hipStream_t s);
 bool mv64_applies(const hb_ctx *ctx, int d);
 int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const int32_t *mode_host, Mv64Matrix **out, hipStream_t s);
 void mv64_free(Mv64Matrix *m);

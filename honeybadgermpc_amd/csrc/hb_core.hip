@@ -469,6 +469,19 @@ int upload_elems(hb_ctx *ctx, const uint64_t *host, size_t count, uint32_t **dev
     return rc;
 }
 
+// the party points as packed elements on the device: a table of the context like every other, keyed by the points
+int points_on_device(hb_ctx *ctx, const uint64_t *x_host, int n, uint32_t **out, hipStream_t s) {
+    std::string key = table_key("xs", ctx, x_host, n, 0);
+    auto it = ctx->dcache.find(key);
+    if (it != ctx->dcache.end()) { *out = (uint32_t *)it->second; cache_touch(ctx, "d|" + key); return HB_OK; }
+    uint32_t *xd = nullptr;
+    const int rc = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rc) return rc;
+    ctx->dcache[key] = xd;
+    cache_note(ctx, "d|" + key, [ctx, key]() { auto f = ctx->dcache.find(key); if (f != ctx->dcache.end()) { (void)hipFree(f->second); ctx->dcache.erase(f); } });
+    *out = xd;
+    return HB_OK;
+}
+
 std::string table_key(const char *kind, hb_ctx *ctx, const uint64_t *x, int n, int d) {
     std::string k(kind);
     k += ":" + std::to_string(n) + ":" + std::to_string(d) + ":";
@@ -481,45 +494,15 @@ std::string table_key(const char *kind, hb_ctx *ctx, const uint64_t *x, int n, i
 // A handful of polynomials at n points (what the device decoder asks for a candidate: one polynomial of degree t at all parties' points,
 // reed_solomon.py:316-326 for ONE codeword): the batched kernels put a chunk on a lane, so a single polynomial is one lane of one wave walking
 // its d terms one after the other (99 us at n = 256, d = 86, behind a scratch allocation and a stream synchronisation).  Here a workgroup takes
-// one (polynomial, point): thread l raises the point to its powers l, l + 128, ... by square and multiply, multiplies by the coefficients and
-// the workgroup adds up: ~20 dependent multiplications instead of d, no table, no scratch, nothing waited for.
+// one (polynomial, point) (eval_at_point_128, hb_common.hpp): ~20 dependent multiplications instead of d, no table, no scratch, nothing waited for.
 template <int NL, int NW>
 __global__ void __launch_bounds__(128) k_eval_few(const FpParams<NL> P, const uint32_t *__restrict__ x, int n, const uint32_t *__restrict__ polys, int d,
                                                   uint32_t *__restrict__ out) {
     __shared__ uint32_t red[128][NL];
-    const int c = blockIdx.x / n, i = blockIdx.x - c * n, tid = threadIdx.x;
-    uint32_t xd[NL], xm[NL], acc[NL];
-    load_digits<NL, NW>(xd, x + (size_t)i * NW);
-    to_mont(xm, xd, P);
-#pragma unroll
-    for (int q = 0; q < NL; q++) acc[q] = 0;
-    for (int l = tid; l < d; l += 128) {
-        uint32_t pw[NL], cd[NL], m[NL];
-        fp_pow_u32(pw, xm, (uint32_t)l, P);                       // Montgomery form of x^l
-        load_digits<NL, NW>(cd, polys + ((size_t)c * d + l) * NW);
-        mont_mul(m, cd, pw, P);                                   // coefficient (whatever words the caller packed: below R) x Montgomery power -> the canonical product
-        fp_add(acc, acc, m, P);
-    }
-#pragma unroll
-    for (int q = 0; q < NL; q++) red[tid][q] = acc[q];
-    __syncthreads();
-    for (int w = 64; w >= 1; w >>= 1) {
-        if (tid < w) {
-            uint32_t a[NL], b[NL], r[NL];
-#pragma unroll
-            for (int q = 0; q < NL; q++) { a[q] = red[tid][q]; b[q] = red[tid + w][q]; }
-            fp_add(r, a, b, P);
-#pragma unroll
-            for (int q = 0; q < NL; q++) red[tid][q] = r[q];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        uint32_t r[NL];
-#pragma unroll
-        for (int q = 0; q < NL; q++) r[q] = red[0][q];
-        store_digits<NL, NW>(out + ((size_t)c * n + i) * NW, r);
-    }
+    const int c = blockIdx.x / n, i = blockIdx.x - c * n;
+    uint32_t r[NL];
+    eval_at_point_128<NL, NW>(r, x + (size_t)i * NW, polys + (size_t)c * d * NW, d, P, red);
+    if (threadIdx.x == 0) store_digits<NL, NW>(out + ((size_t)c * n + i) * NW, r);
 }
 
 extern "C" {
@@ -892,16 +875,8 @@ int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, co
     hipStream_t s = (hipStream_t)stream;
     if (d == 0) { HB_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)C * n * ctx->elem_words() * 4, s)); return HB_OK; }
     if (C <= 8 && C * n <= 4096 && d >= 8 && !getenv("HB_NO_EVAL_FEW")) {
-        // the party points on the device: a table of the context like every other, keyed by the points
-        std::string key = table_key("xs", ctx, x_host, n, 0);
         uint32_t *xd = nullptr;
-        auto it = ctx->dcache.find(key);
-        if (it != ctx->dcache.end()) { xd = (uint32_t *)it->second; cache_touch(ctx, "d|" + key); }
-        else {
-            const int rcx = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rcx) return rcx;
-            ctx->dcache[key] = xd;
-            cache_note(ctx, "d|" + key, [ctx, key]() { auto f = ctx->dcache.find(key); if (f != ctx->dcache.end()) { (void)hipFree(f->second); ctx->dcache.erase(f); } });
-        }
+        const int rcx = points_on_device(ctx, x_host, n, &xd, s); if (rcx) return rcx;
         if (ctx->n_limbs == 4) k_eval_few<9, 8><<<(unsigned)(C * n), 128, 0, s>>>(ctx->pw, xd, n, (const uint32_t *)polys_dev, d, (uint32_t *)out_dev);
         else k_eval_few<3, 2><<<(unsigned)(C * n), 128, 0, s>>>(ctx->pn, xd, n, (const uint32_t *)polys_dev, d, (uint32_t *)out_dev);
         HB_LAUNCH_CHECK(ctx);

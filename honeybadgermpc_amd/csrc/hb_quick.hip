@@ -1091,8 +1091,8 @@ __global__ void __launch_bounds__(256) k_symbols_fetch(const uint64_t *__restric
     if (t == 0) *reinterpret_cast<volatile int32_t *>(&out->seq) = seq;
 }
 
-// A candidate against the arrived symbols of its chunk, in one launch: workgroup i evaluates the polynomial at party i's point (thread l the
-// powers l, l + 128, ... by square and multiply, a tree of additions -- k_eval_few's arithmetic), writes the value to pinned memory and says
+// A candidate against the arrived symbols of its chunk, in one launch: workgroup i evaluates the polynomial at party i's point
+// (eval_at_point_128, hb_common.hpp: k_eval_few's arithmetic), writes the value to pinned memory and says
 // whether the party's symbol of the chunk differs; the last workgroup to finish (a ticket) writes the sequence number the host polls.
 constexpr int CAND_MAXN = 1024;
 struct CandCheck { uint64_t vals[CAND_MAXN * 4]; uint8_t differs[CAND_MAXN]; int32_t seq; };
@@ -1102,36 +1102,10 @@ __global__ void __launch_bounds__(128) k_candidate_check(const FpParams<NL> P, c
                                                          int32_t *__restrict__ ticket, int seq) {
     __shared__ uint32_t red[128][NL];
     const int i = blockIdx.x, tid = threadIdx.x;
-    uint32_t xd[NL], xm[NL], acc[NL];
-    load_digits<NL, NW>(xd, x + (size_t)i * NW);
-    to_mont(xm, xd, P);
-#pragma unroll
-    for (int q = 0; q < NL; q++) acc[q] = 0;
-    for (int l = tid; l < d; l += 128) {
-        uint32_t pw[NL], cd[NL], m[NL];
-        fp_pow_u32(pw, xm, (uint32_t)l, P);
-        load_digits<NL, NW>(cd, poly + (size_t)l * NW);
-        mont_mul(m, cd, pw, P);
-        fp_add(acc, acc, m, P);
-    }
-#pragma unroll
-    for (int q = 0; q < NL; q++) red[tid][q] = acc[q];
-    __syncthreads();
-    for (int w = 64; w >= 1; w >>= 1) {
-        if (tid < w) {
-            uint32_t a[NL], b[NL], r[NL];
-#pragma unroll
-            for (int q = 0; q < NL; q++) { a[q] = red[tid][q]; b[q] = red[tid + w][q]; }
-            fp_add(r, a, b, P);
-#pragma unroll
-            for (int q = 0; q < NL; q++) red[tid][q] = r[q];
-        }
-        __syncthreads();
-    }
+    uint32_t r[NL];
+    eval_at_point_128<NL, NW>(r, x + (size_t)i * NW, poly, d, P, red);
     if (tid == 0) {
-        uint32_t r[NL], w[NW], got[NW];
-#pragma unroll
-        for (int q = 0; q < NL; q++) r[q] = red[0][q];
+        uint32_t w[NW], got[NW];
         pack<NL, NW>(w, r);
         load_words<NW>(got, cols + ((size_t)i * (size_t)C + (size_t)chunk) * NW);
         uint32_t df = 0;
@@ -1741,16 +1715,8 @@ int hb_candidate_check(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_
         memset(h, 0, sizeof(CandCheck));
         ctx->cand_host = h; ctx->cand_dev = dv;
     }
-    // the party points on the device: a table of the context, keyed by the points (shared with hb_vandermonde_batch_evaluate's few-polynomial path)
-    std::string key = table_key("xs", ctx, x_host, n, 0);
     uint32_t *xd = nullptr;
-    auto it = ctx->dcache.find(key);
-    if (it != ctx->dcache.end()) { xd = (uint32_t *)it->second; cache_touch(ctx, "d|" + key); }
-    else {
-        const int rcx = upload_elems(ctx, x_host, (size_t)n, &xd, s); if (rcx) return rcx;
-        ctx->dcache[key] = xd;
-        cache_note(ctx, "d|" + key, [ctx, key]() { auto f = ctx->dcache.find(key); if (f != ctx->dcache.end()) { (void)hipFree(f->second); ctx->dcache.erase(f); } });
-    }
+    { const int rcx = points_on_device(ctx, x_host, n, &xd, s); if (rcx) return rcx; }
     CandCheck *host = static_cast<CandCheck *>(ctx->cand_host);
     const int seq = ++ctx->cand_seq;
     if (ctx->n_limbs == 4)
