@@ -11,6 +11,8 @@ batches, no new arithmetic.
                        (reference :95-123).
 * random_elements   -- uniform field elements drawn on the device (rejection from 2^bits).
 
+* extract_at_omega_powers -- the randomness extractor of progs/random_refinement.py for any number of contribution vectors.
+
 Element layout as in honeybadgermpc_amd.device: int64 tensors (count, 4), little-endian limbs.
 """
 import ctypes
@@ -129,3 +131,25 @@ class HyperInvertible:
             self.ctx.lib.hb_matrix_destroy(self._v)
         except Exception:
             pass
+
+
+def extract_at_omega_powers(field, n, t, batches):
+    """Randomness extraction (reference progs/random_refinement.py:5-19) for a list of contribution vectors.
+
+    Each vector holds k contributions (n - t <= k <= n, n >= 3 t + 1), read as the coefficients of a polynomial; the result
+    keeps its values at the first k - t omega points.  All vectors of one length go through ONE batched encode."""
+    from .polynomial import EvalPoint
+    from .reed_solomon import EncoderFactory
+
+    if n < 3 * t + 1:
+        raise AssertionError(f"randomness extraction needs n >= 3 t + 1 (n = {n}, t = {t})")
+    for vec in batches:
+        if not n - t <= len(vec) <= n:
+            raise AssertionError(f"randomness extraction: {len(vec)} contributions with n = {n}, t = {t}")
+    codec = EncoderFactory.get(EvalPoint(field, n, use_omega_powers=True))
+    out = [None] * len(batches)
+    for k in sorted({len(vec) for vec in batches}):
+        which = [i for i, vec in enumerate(batches) if len(vec) == k]
+        for i, row in zip(which, codec.encode([list(batches[i]) for i in which])):
+            out[i] = row[: k - t]
+    return out

@@ -1,19 +1,13 @@
 """
-Randomness extraction through the codec
-(reference: honeybadgermpc/progs/random_refinement.py:5-19).
+Randomness extraction through the codec (replaces honeybadgermpc/progs/random_refinement.py:5-19).
 
-k contributed random shares are read as the coefficients of a polynomial, which is evaluated at
-the omega powers; dropping t outputs removes whatever t corrupt contributors could bias.  One
-encoder call, so it runs on the same kernels as the R1 encode.
+The k contributed shares are the coefficients of a polynomial; its values at the first k - t omega points are the refined
+shares (t fewer than were contributed: that many contributors may be corrupt and could bias as many outputs).  It is one
+encode on the kernels of an open's R1 encode: `offline.extract_at_omega_powers` does it for lists of ints and for device
+tensors of many batches alike.
 """
-from ..polynomial import EvalPoint
-from ..reed_solomon import EncoderFactory
+from ..offline import extract_at_omega_powers
 
 
 def refine_randoms(n, t, field, random_shares_int):
-    assert 3 * t + 1 <= n
-    k = len(random_shares_int)          # contributors to this batch
-    assert k >= n - t and k <= n
-    encoder = EncoderFactory.get(EvalPoint(field, n, use_omega_powers=True))
-    output_shares_int = encoder.encode(random_shares_int)
-    return output_shares_int[: k - t]
+    return extract_at_omega_powers(field, n, t, [random_shares_int])[0]
