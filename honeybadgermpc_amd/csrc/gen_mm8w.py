@@ -81,7 +81,7 @@ SPREAD = float(os.environ.get("HB_GEN_MM8W_SPREAD", "1"))       # room of a fold
 class Ops:
     """operand numbering of the asm statement"""
 
-    def __init__(self, check, nout=4):
+    def __init__(self, check, nout=4, select=False):
         self.outs, self.ins = [], []
         self.nout = nout           # outputs per lane that are kept: 4 (16-row tiles) or 3 (12-row tiles: the fourth row of every group of
                                    # the MFMA tile is padding -- a matrix of 22 rows is two tiles either way, and a pass reduces 3 sums, not 4)
@@ -97,6 +97,8 @@ class Ops:
             self.ins.append((f"ADDR{r}", '"v"', f"addr[{r}]"))
         for r in range(nout):
             self.ins.append((f"MODE{r}", '"v"', f"mode[{r}]"))
+        if select:
+            self.ins.append(("SEL", '"s"', "sel"))       # which of the bodies of a multi-body statement runs (multi_lines)
         self.idx = {name: i for i, (name, _, _) in enumerate(self.outs + self.ins)}
 
     def __call__(self, name):
@@ -464,12 +466,12 @@ def split(units, parts):
     return out
 
 
-def pass_lines(check, peel, nout=4):
+def pass_lines(check, peel, nout=4, select=False):
     """`peel` K-blocks are straight-line code carrying the reduction of the pass before, in equal shares (one wave per SIMD
     issues an instruction every ~5.5 cycles at best -- profiles/r01_mad_issue_rate_vs_occupancy.txt, r02_mm8w_phase_timing.txt --
     so everything a pass executes counts); the other nkb - peel K-blocks run as a loop of two-block bodies in the middle (the digit
     buffers alternate by block parity, so the launcher picks peel = nkb for nkb <= 2, else 3 for odd and 4 for even nkb)."""
-    o = Ops(check, nout)
+    o = Ops(check, nout, select)
     L = consts(o)
     # positions that are read but never written stay zero: k = -2 and k = 8
     for s in range(2):
@@ -506,12 +508,31 @@ def reduce_lines(check, nout=4):
     return o, resolve_waits(L)
 
 
+def multi_lines(check, peels=(2, 3, 4), nout=4):
+    """ONE statement holding the passes written out for 2, 3 and 4 K-blocks; the scalar operand SEL picks the body.  k_mm8w_flat runs
+    pieces of a pass of any length >= 2 (SEL = 2: two K-blocks; 3 / 4: odd / even lengths, CNT two-block loop bodies in the middle).
+    Three statements behind an if / else cost the kernel ~80 spilled registers a round: the compiler shuffles the 68 words of the sums
+    between the branches; one statement it cannot look into has one register assignment."""
+    o = None
+    L = []
+    for i, peel in enumerate(peels):
+        o, lines = pass_lines(check, peel, nout, select=True)
+        lines = [ln.replace(".Lmm8w_", f".Lmm8w_b{peel}_") for ln in lines]
+        if i + 1 < len(peels):
+            L += [f"s_cmp_lg_u32 {o('SEL')}, {peel}", f"s_cbranch_scc1 .Lmm8w_skip{peel}_%="]
+        L += lines
+        if i + 1 < len(peels):
+            L += ["s_branch .Lmm8w_end_%=", f".Lmm8w_skip{peel}_%=:"]
+    L.append(".Lmm8w_end_%=:")
+    return o, L
+
+
 def emit_fn(name, o, lines, check):
     out = []
     n = o.nout
     sig = (f"uint32_t (&w)[{n}][17], uint32_t &xa, uint32_t &va, uint32_t &cnt, uint64_t &flag, uint64_t abase, int32_t k256, int32_t k64k, "
            f"int32_t k16m, int64_t bias4, int64_t bias3, uint64_t wpa, uint32_t crl_addr, uint32_t atb_addr, const uint64_t (&addr)[{n}], "
-           f"const uint32_t (&mode)[{n}]")
+           f"const uint32_t (&mode)[{n}]" + (", int32_t sel" if "SEL" in o.idx else ""))
     out.append(f"static __device__ __forceinline__ void {name}({sig}) {{")
     if not check:
         out.append("    (void)flag;")
@@ -540,6 +561,8 @@ def emit():
                 out += emit_fn(f"mm8w_pass{sfx}_p{peel}_k{nout}", o, lines, check)
             o, lines = reduce_lines(check, nout)
             out += emit_fn(f"mm8w_reduce{sfx}_k{nout}", o, lines, check)
+        o, lines = multi_lines(check)
+        out += emit_fn(f"mm8w_pass{sfx}_multi_k4", o, lines, check)
     return "\n".join(out)
 
 

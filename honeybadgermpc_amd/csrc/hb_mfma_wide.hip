@@ -56,7 +56,7 @@ struct Mm8wMatrix {
     int n_out, d, nkb, n_rt;
     int tile_rows;     // 16, or 12 / 8 when that makes fewer or cheaper passes (three / two sums per lane instead of four)
     mutable int64_t shape_tiles;                 // the launch geometry chosen for the last batch size (mm8w_shape simulates: not per launch)
-    mutable int shape_tpw, shape_nbuf, shape_rq;
+    mutable int shape_tpw, shape_nbuf, shape_rq, shape_flat;   // shape_flat: ring slots of the balanced launch (k_mm8w_flat), 0 = the unit launch
     int4 *a8;          // [n_rt][nkb][4 digit groups][64 lanes] 16 bytes each (+ one block of padding): lane (r, g) = row
                        // 16 rt + 4 (r % 4) + r / 4, terms 8 kb + 2 g and + 1, eight digits of group G each
     uint32_t *crow;    // [n_rt * 16][16]: 9 radix-2^29 digits of the per-row constant (in [0, p); the kernel turns them into words + column bias)
@@ -341,6 +341,279 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The balanced launch (round 6).  k_mm8w above deals UNITS (a chunk tile x a group of row tiles) to the workgroups: at config 5's
+// shard the fused R2 launch is 382 tiles x 11 row tiles = 4202 passes for 1024 waves -- 4.1 a wave, so a fifth of the launch is the
+// waves that take a fifth pass while nine tenths of the chip are done (R1: 2292 passes, 2.24 a wave, three rounds).  Here the passes
+// are ONE list, tile-major, cut into contiguous ranges of floor / ceil (N / G) passes, one range a workgroup; a workgroup walks its
+// range four passes a round (one a wave; a round may straddle two chunk tiles: the tiles live in a ring of LDS slots, the next
+// round's new tile is requested behind this round's passes).  What is left after the full rounds is ONE short round:
+//   3 passes  three waves take one each;
+//   2 passes  two waves a pass, each half of the K-blocks;
+//   1 pass    the four waves take a quarter of its K-blocks each
+// -- the pieces of a pass run the ordinary pass statements on their share of the K-blocks (every statement starts its columns
+// from zero), leave their sums as 17 words an output like any pass, and the followers hand theirs to the pass's leader through LDS
+// (over ring slots no tile of the round lives in); the leader adds them word by word, takes the accumulator bias the extra pieces
+// added back out (FlatCorr: 2^544 - (pieces - 1) bias sum_c 2^(8c)) and reduces / stores / compares the total in the drain.
+// 4 + ~0.4 rounds instead of 5 (R2), 2 + ~0.4 instead of 3 (R1).  Row tiles of 16 rows, at least 4 row tiles and 8 K-blocks.
+constexpr int MM8W_PART_Q = 4 * 17 * 64 / 4;        // a wave's partial sums in uint4: 4 outputs x 17 words x 64 lanes
+struct FlatCorr { uint32_t w[2][17]; };              // [0]: two pieces, [1]: four
+
+template <bool CHECK>
+__global__ __launch_bounds__(256, 1) void k_mm8w_flat(const int4 *__restrict__ a8, const uint32_t *__restrict__ crowd,
+                                                      const uint32_t *__restrict__ zero_src,
+                                                      const uint32_t *__restrict__ in_pk, int64_t in_sc, int64_t in_sl,
+                                                      const int32_t *__restrict__ in_rows, int64_t in_count, int d,
+                                                      uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
+                                                      const int32_t *__restrict__ check_mask, int32_t *__restrict__ mismatch,
+                                                      const uint32_t *__restrict__ cmp_pk, int64_t cmp_sc, int64_t cmp_sl, int mask_is_map, int n_store,
+                                                      int n_out, int n_rt, int nkb, int nb, int64_t n_chunks, int64_t n_pass,
+                                                      uint32_t bias, const WideParams *__restrict__ wpp, int32_t *__restrict__ first_bad, uint32_t *__restrict__ bad_map,
+                                                      const FsDone done, const FlatCorr corr) {
+    constexpr int K = 4;
+    extern __shared__ uint4 mm8w_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    uint4 *tlds = mm8w_lds;                                                 // the fold table
+    uint32_t *crl = reinterpret_cast<uint32_t *>(mm8w_lds + MM8W_FOLD_Q);   // [n_rt * 16][16]
+    uint4 *xbuf = mm8w_lds + MM8W_FOLD_Q + n_rt * 64;                       // the ring: nb x [nkb][2 elements][2 halves][64] uint4, then 2 KB of slack
+    const int bufsz = nkb * 4 * 64;
+    int64_t *rowoff = reinterpret_cast<int64_t *>(xbuf + (size_t)nb * bufsz + 128);
+    uint64_t *rowdst = reinterpret_cast<uint64_t *>(rowoff + 8 * nkb);
+    for (int l = threadIdx.x; l < 8 * nkb; l += 256) {
+        const int lc = l < d ? l : d - 1;
+        rowoff[l] = (int64_t)(in_rows ? in_rows[lc] : lc) * in_sl;
+    }
+    __syncthreads();
+    // this workgroup's range of the pass list.  Block b runs on XCD b % 8 (observed; a speed assumption only): neighbouring ranges --
+    // they share the chunk tile their border cuts -- go to blocks that agree mod 8, so that tile comes from HBM once
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    const int rho = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b;
+    const int64_t q_lo = n_pass / G, q_rem = n_pass - q_lo * G;
+    const int64_t p_first = rho * q_lo + (rho < q_rem ? rho : q_rem);
+    const int q = (int)(q_lo + (rho < q_rem ? 1 : 0));
+    const int64_t t0 = p_first / n_rt;
+    auto issue_tile = [&](int64_t tile, int slot) {
+        const int e = (wave >> 1) & 1, h = wave & 1;
+        const uint4 *base = reinterpret_cast<const uint4 *>(in_pk) + h;
+        const uint4 *zsrc = reinterpret_cast<const uint4 *>(zero_src) + h;
+        int64_t chunk = tile * 16 + n;
+        if (chunk >= n_chunks) chunk = n_chunks - 1;
+        const int64_t cbase = chunk * in_sc;
+        int64_t ro = rowoff[2 * g + e];
+        for (int kb = 0; kb < nkb; kb++) {
+            const int64_t idx = cbase + ro;
+            ro = rowoff[8 * (kb + 1 < nkb ? kb + 1 : kb) + 2 * g + e];
+            const uint4 *src = (idx < in_count) ? base + idx * 2 : zsrc;
+            const int s = (kb * 2 + e) * 2 + h;
+            const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(
+                (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void *)(xbuf + (size_t)slot * bufsz + s * 64));
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+        }
+    };
+    int64_t issued_hi = t0 - 1;
+    auto tiles_upto = [&](int64_t t_hi) {
+        while (issued_hi < t_hi) { issued_hi++; issue_tile(issued_hi, (int)((issued_hi - t0) % nb)); }
+    };
+    // rounds: `full` of four passes, then at most one short one
+    const int full = q >> 2, left = q & 3, n_rounds = full + (left ? 1 : 0);
+    auto round_last_tile = [&](int r) -> int64_t { return (p_first + 4 * (int64_t)r + (r < full ? 4 : left) - 1) / n_rt; };
+    const int32_t k256 = 256, k64k = 1 << 16, k16m = 1 << 24;
+    const int64_t bias4 = (int64_t)bias * 0x01010101ll, bias3 = (int64_t)bias * 0x00010101ll;
+    const uint64_t wpa = (uint64_t)(uintptr_t)wpp;
+    const uint64_t out_lim = out_count >= (int64_t)1 << 56 ? ~(uint64_t)0 : (uint64_t)(uintptr_t)(out_pk + out_count * 8);
+    uint32_t w[K][17];
+    uint32_t crl_addr, mode[K];
+    const uint32_t atb_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)tlds + (g == (n >> 2) ? 16u * (uint32_t)n : 256u);
+    uint64_t addr[K];
+    crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)crl;
+#pragma unroll
+    for (int r = 0; r < K; r++) {
+#pragma unroll
+        for (int j = 0; j < 17; j++) w[r][j] = 0;
+        mode[r] = 0; addr[r] = 0;
+    }
+    int64_t cmp_chunk0 = 0, bad_chunk = -1;
+    uint64_t any_bad = 0;
+    if (n_rounds > 0) tiles_upto(round_last_tile(0));
+    {
+        const uint4 *fsrc = reinterpret_cast<const uint4 *>(wpp->fold);
+        for (int i = threadIdx.x; i < MM8W_FOLD_Q; i += 256) tlds[i] = fsrc[i];
+    }
+    for (int i = threadIdx.x; i < n_rt * 16 * 8; i += 256) {
+        const int row = i >> 3, j = i & 7, bit = 32 * j, k = bit / 29, sft = bit - 29 * k;
+        const uint32_t *dg = crowd + row * 16;
+        uint64_t v = (uint64_t)dg[k] >> sft;
+        v |= (uint64_t)dg[k + 1] << (29 - sft);
+        if (k + 2 < 9 && 58 - sft < 32) v |= (uint64_t)dg[k + 2] << (58 - sft);
+        const uint64_t pair = (v & 0xffffffffull) + ((0x1010ull << 32) | 0x10100000ull);
+        crl[row * 16 + 2 * j] = (uint32_t)pair;
+        crl[row * 16 + 2 * j + 1] = (uint32_t)(pair >> 32);
+    }
+    for (int i = threadIdx.x; i < n_rt * 16; i += 256) {
+        uint64_t e = 0;
+        const int row = (i >> 4) * 16 + (i & 15);
+        if (row < n_out) {
+            int erow = 0;
+            if constexpr (CHECK) erow = mask_is_map ? check_mask[row] : (check_mask[row] ? row + 1 : 0);
+            if (erow) e = (uint64_t)(uintptr_t)(cmp_pk + (int64_t)(erow - 1) * cmp_sl * 8) | 2u;
+            else if (!CHECK || row < n_store) e = (uint64_t)(uintptr_t)(out_pk + (int64_t)row * out_sl * 8) | 1u;
+        }
+        rowdst[i] = e;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // where follower k (0, 1, 2) of a short round leaves its sums: the k-th MM8W_PART_Q uint4 of the ring outside the slots busy_a, busy_b
+    auto part_off = [&](int k, int busy_a, int busy_b) -> int {
+        int off = 0;
+        for (int i = 0;; i++) {
+            for (int rep = 0; rep < 2; rep++) {
+                if (busy_a >= 0 && off < (busy_a + 1) * bufsz && off + MM8W_PART_Q > busy_a * bufsz) off = (busy_a + 1) * bufsz;
+                if (busy_b >= 0 && off < (busy_b + 1) * bufsz && off + MM8W_PART_Q > busy_b * bufsz) off = (busy_b + 1) * bufsz;
+            }
+            if (i == k) return off;
+            off += MM8W_PART_Q;
+        }
+    };
+    for (int r = 0; r < n_rounds; r++) {
+        const int64_t pf = p_first + 4 * (int64_t)r;
+        const int cnt_r = r < full ? 4 : left;
+        const int pieces = (r < full || cnt_r == 3) ? 1 : (cnt_r == 1 ? 4 : 2);     // waves a pass of this round
+        // this wave's share: pass pf + po, K-blocks [kb0, kb0 + len)
+        int po = wave, kb0 = 0, len = nkb, part = 0;
+        if (pieces == 4) {
+            const int bl = nkb >> 2, ex = nkb & 3;
+            po = 0; part = wave; len = bl + (wave < ex ? 1 : 0); kb0 = wave * bl + (wave < ex ? wave : ex);
+        } else if (pieces == 2) {
+            const int l0 = (nkb + 1) >> 1;
+            po = wave >> 1; part = wave & 1; len = part ? nkb - l0 : l0; kb0 = part ? l0 : 0;
+        }
+        const bool have = pieces > 1 || wave < cnt_r;
+        if (have) {
+            const int64_t pass = pf + po, tile = pass / n_rt;
+            const int rt = (int)(pass - tile * n_rt), slot = (int)((tile - t0) % nb);
+            const int64_t chunk = tile * 16 + n;
+            uint64_t flag = 0;
+            {
+                uint32_t xa = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(xbuf + (size_t)slot * bufsz + (size_t)kb0 * 256 + lane);
+                uint32_t va = (uint32_t)lane * 16u;
+                const uint64_t abase = (uint64_t)(uintptr_t)(a8 + ((size_t)rt * nkb + kb0) * 4 * 64);
+                // the statement for `len` K-blocks: 2 written out; or 3 / 4 written out and a loop of two-block bodies between them
+                const int var = len == 2 ? 2 : ((len & 1) ? 3 : 4);
+                uint32_t cnt = (uint32_t)((len - var) >> 1);
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#define MM8W_ARGS w, xa, va, cnt, flag, abase, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, atb_addr, addr, mode, var
+                if constexpr (CHECK) mm8w_pass_check_multi_k4(MM8W_ARGS); else mm8w_pass_multi_k4(MM8W_ARGS);
+#undef MM8W_ARGS
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (CHECK) {
+                if (flag != 0) {
+                    const uint32_t m16 = (uint32_t)((flag | (flag >> 16) | (flag >> 32) | (flag >> 48)) & 0xffffu);
+                    if (bad_chunk < 0) bad_chunk = cmp_chunk0 + (__builtin_ctz(m16));
+                    if (bad_map && lane == 0) atomicOr(bad_map + (cmp_chunk0 >> 5), m16 << (cmp_chunk0 & 16));
+                    any_bad = 1;
+                }
+                cmp_chunk0 = chunk - n;
+            }
+            if (part == 0) {
+                // where this pass's outputs go (a leader's: once the followers' sums have joined them)
+                crl_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)(crl + (size_t)(16 * rt + g) * 16);
+                const bool in_batch = chunk < n_chunks;
+                const uint64_t c_out = (uint64_t)(chunk * out_sc) * 32u, c_cmp = (uint64_t)(chunk * cmp_sc) * 32u;
+#pragma unroll
+                for (int o = 0; o < K; o++) {
+                    const uint64_t e = rowdst[16 * rt + 4 * o + g];
+                    const uint32_t m = (uint32_t)e & 3u;
+                    const uint64_t a = (e & ~(uint64_t)3) + (m == 2 ? c_cmp : c_out);
+                    const bool ok = in_batch && m != 0 && (m == 2 || a < out_lim);
+                    mode[o] = ok ? m : 0;
+                    addr[o] = ok ? a : 0;
+                }
+            }
+        }
+        if (r + 1 < n_rounds) tiles_upto(round_last_tile(r + 1));
+        if (pieces > 1) {
+            // (the last round: no tile is in flight, and only the slots of this round's one or two tiles are read by anybody)
+            const int sa = (int)((pf / n_rt - t0) % nb), sb = (int)(((pf + cnt_r - 1) / n_rt - t0) % nb);
+            const int fol = pieces == 4 ? wave - 1 : (wave >> 1);        // follower number of this wave (when part != 0)
+            if (part != 0) {
+                uint32_t *dst = reinterpret_cast<uint32_t *>(xbuf + part_off(fol, sa, sb)) + lane;
+#pragma unroll
+                for (int o = 0; o < K; o++) {
+#pragma unroll
+                    for (int j = 0; j < 17; j++) dst[(o * 17 + j) * 64] = w[o][j];
+                    mode[o] = 0; addr[o] = 0;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (part == 0) {
+                const int f_lo = pieces == 4 ? 0 : (wave >> 1), f_n = pieces == 4 ? 3 : 1;
+                for (int f = f_lo; f < f_lo + f_n; f++) {
+                    const uint32_t *src = reinterpret_cast<const uint32_t *>(xbuf + part_off(f, sa, sb)) + lane;
+#pragma unroll
+                    for (int o = 0; o < K; o++) {
+                        unsigned cy = 0;
+#pragma unroll
+                        for (int j = 0; j < 17; j++) w[o][j] = __builtin_addc(w[o][j], src[(o * 17 + j) * 64], cy, &cy);
+                    }
+                }
+                const uint32_t *cw = corr.w[pieces == 4 ? 1 : 0];
+#pragma unroll
+                for (int o = 0; o < K; o++) {
+                    unsigned cy = 0;
+#pragma unroll
+                    for (int j = 0; j < 17; j++) w[o][j] = __builtin_addc(w[o][j], cw[j], cy, &cy);
+                }
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    // drain: the last pass's sums
+    uint64_t flag = 0;
+    {
+        uint32_t xa = 0, va = 0, cnt = 0;
+        __builtin_amdgcn_sched_barrier(0);
+#define MM8W_ARGS w, xa, va, cnt, flag, 0, k256, k64k, k16m, bias4, bias3, wpa, crl_addr, atb_addr, addr, mode
+        if constexpr (CHECK) mm8w_reduce_check_k4(MM8W_ARGS); else mm8w_reduce_k4(MM8W_ARGS);
+#undef MM8W_ARGS
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (CHECK) {
+        if (flag != 0) {
+            const uint32_t m16 = (uint32_t)((flag | (flag >> 16) | (flag >> 32) | (flag >> 48)) & 0xffffu);
+            if (bad_chunk < 0) bad_chunk = cmp_chunk0 + (__builtin_ctz(m16));
+            if (bad_map && lane == 0) atomicOr(bad_map + (cmp_chunk0 >> 5), m16 << (cmp_chunk0 & 16));
+        }
+        if ((flag | any_bad) != 0 && lane == 0) {
+            atomicOr(mismatch, 1);
+            if (first_bad) atomicMin(first_bad, (int32_t)(bad_chunk > 0x7fffffff ? 0x7fffffff : bad_chunk));
+        }
+        if (done.counter) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
+                    const int32_t fl = mismatch ? atomicExch(mismatch, 0) : 0;
+                    const int32_t fb = first_bad ? atomicExch(first_bad, INT32_MAX) : INT32_MAX;
+                    atomicExch(done.counter, 0);
+                    done.host->flag = fl;
+                    done.host->first = fb;
+                    __threadfence_system();
+                    *reinterpret_cast<volatile int32_t *>(&done.host->seq) = done.seq;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace hb
 
 #ifdef HB_MM8_TIMING
@@ -488,7 +761,7 @@ constexpr size_t MM8W_LDS_LIMIT = 156 * 1024;
 // Tiles per unit, row tiles per unit and buffers.  A workgroup's four waves take the (tile, row tile) passes of a unit in rounds,
 // units go round-robin over the workgroups: the candidates are simulated (pass-times of the slowest workgroup) and the fastest
 // wins; ties go to the larger row group (a tile is loaded once per row group), then to double buffering.
-bool mm8w_shape(int n_rt, int nkb, int64_t n_tiles, int n_cus, int *tpw, int *nbuf, int *rq) {
+bool mm8w_shape(int n_rt, int nkb, int64_t n_tiles, int n_cus, int *tpw, int *nbuf, int *rq, double *cost_out = nullptr) {
     double best_cost = 0.0;
     int best_t = 0, best_rq = 0, best_nbuf = 0;
     int rqs[3] = {n_rt, 8, 4};
@@ -528,7 +801,54 @@ bool mm8w_shape(int n_rt, int nkb, int64_t n_tiles, int n_cus, int *tpw, int *nb
     }
     if (!best_t) return false;
     *tpw = best_t; *rq = best_rq; *nbuf = best_nbuf;
+    if (cost_out) *cost_out = best_cost;
     return true;
+}
+
+// uint4 offset of follower k's sums in the ring of a short round whose tiles live in slots busy_a, busy_b (k_mm8w_flat: part_off)
+int mm8w_flat_part_off(int k, int busy_a, int busy_b, int bufsz) {
+    int off = 0;
+    for (int i = 0;; i++) {
+        for (int rep = 0; rep < 2; rep++) {
+            if (busy_a >= 0 && off < (busy_a + 1) * bufsz && off + 1088 > busy_a * bufsz) off = (busy_a + 1) * bufsz;
+            if (busy_b >= 0 && off < (busy_b + 1) * bufsz && off + 1088 > busy_b * bufsz) off = (busy_b + 1) * bufsz;
+        }
+        if (i == k) return off;
+        off += 1088;
+    }
+}
+
+// The balanced launch (k_mm8w_flat): ring slots, or 0 when the shape does not qualify or promises nothing over `unit_cost`, the
+// pass-times of the slowest workgroup of the unit launch (mm8w_shape).  A range of q passes is q / 4 full rounds and a short one:
+// three passes -> a pass-time; two -> half the K-blocks a wave, their sums joined through LDS; one -> a quarter.
+// HB_MM8W_FLAT=0 / 1: never / whenever the shape qualifies (A-B runs: profiles/r06_mm8w_balanced_launch.txt).
+int mm8w_flat_slots(int n_rt, int nkb, int tile_rows, int64_t n_tiles, int n_cus, double unit_cost) {
+    static const int force = [] { const char *e = getenv("HB_MM8W_FLAT"); return e ? atoi(e) : -1; }();
+    if (force == 0 || tile_rows != 16 || n_rt < 4 || nkb < 8) return 0;
+    const int64_t n_pass = n_tiles * n_rt;
+    if (n_pass < 4 * (int64_t)n_cus) return 0;
+    const int bufsz = nkb * 4 * 64;
+    int nb = 0;
+    for (int cand = 3; cand <= 8 && !nb; cand++) {
+        if (mm8w_lds_bytes(n_rt, nkb, 1, cand) > MM8W_LDS_LIMIT) break;
+        bool ok = true;
+        for (int a = 0; a < cand && ok; a++) {
+            // one tile (three followers) or two neighbouring tiles (two followers) busy
+            if (mm8w_flat_part_off(2, a, -1, bufsz) + 1088 > cand * bufsz + 128) ok = false;
+            if (mm8w_flat_part_off(1, a, (a + 1) % cand, bufsz) + 1088 > cand * bufsz + 128) ok = false;
+        }
+        if (ok) nb = cand;
+    }
+    if (!nb) return 0;
+    if (force == 1) return nb;
+    auto rounds = [&](int64_t q) {
+        const int left = (int)(q & 3);
+        const double tail = left == 0 ? 0.0 : left == 3 ? 1.0 : left == 2 ? (double)((nkb + 1) / 2) / nkb + 0.12 : (double)((nkb + 3) / 4) / nkb + 0.15;
+        return (double)(q >> 2) + tail + 0.06 * (double)((q >> 2) + (left ? 1 : 0));
+    };
+    const int64_t q_lo = n_pass / n_cus;
+    const double cost = (n_pass % n_cus) ? std::max(rounds(q_lo), rounds(q_lo + 1)) : rounds(q_lo);
+    return cost < 0.97 * unit_cost ? nb : 0;
 }
 
 int mm8w_num_cus() {
@@ -675,20 +995,61 @@ static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in
     FsDone done;
     memset(&done, 0, sizeof done);
     if (done_p) done = *done_p;
-    int tpw = 1, nbuf = 1, rq = m->n_rt;
+    int tpw = 1, nbuf = 1, rq = m->n_rt, flat_nb = 0;
     const int64_t n_tiles = (C + 15) / 16;
-    if (m->shape_tiles == n_tiles) { tpw = m->shape_tpw; nbuf = m->shape_nbuf; rq = m->shape_rq; }
+    if (m->shape_tiles == n_tiles) { tpw = m->shape_tpw; nbuf = m->shape_nbuf; rq = m->shape_rq; flat_nb = m->shape_flat; }
     else {
         // the simulation costs tens of microseconds: remembered per matrix, and per context for images that live for one launch
-        const std::string sk = std::to_string(m->n_rt) + ":" + std::to_string(m->nkb) + ":" + std::to_string((long long)n_tiles);
+        const std::string sk = std::to_string(m->n_rt) + ":" + std::to_string(m->nkb) + ":" + std::to_string(m->tile_rows) + ":" + std::to_string((long long)n_tiles);
         auto hit = ctx->wide_shapes.find(sk);
-        if (hit != ctx->wide_shapes.end()) { tpw = hit->second[0]; nbuf = hit->second[1]; rq = hit->second[2]; }
+        if (hit != ctx->wide_shapes.end()) { tpw = hit->second[0]; nbuf = hit->second[1]; rq = hit->second[2]; flat_nb = hit->second[3]; }
         else {
-            if (!mm8w_shape(m->n_rt, m->nkb, n_tiles, mm8w_num_cus(), &tpw, &nbuf, &rq)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: shape");
+            double unit_cost = 0.0;
+            if (!mm8w_shape(m->n_rt, m->nkb, n_tiles, mm8w_num_cus(), &tpw, &nbuf, &rq, &unit_cost)) return fail(ctx, HB_ERR_UNSUPPORTED, "mm8w: shape");
+            flat_nb = mm8w_flat_slots(m->n_rt, m->nkb, m->tile_rows, n_tiles, mm8w_num_cus(), unit_cost);
             if (ctx->wide_shapes.size() > 4096) ctx->wide_shapes.clear();
-            ctx->wide_shapes[sk] = std::vector<int>{tpw, nbuf, rq};
+            ctx->wide_shapes[sk] = std::vector<int>{tpw, nbuf, rq, flat_nb};
         }
-        m->shape_tiles = n_tiles; m->shape_tpw = tpw; m->shape_nbuf = nbuf; m->shape_rq = rq;
+        m->shape_tiles = n_tiles; m->shape_tpw = tpw; m->shape_nbuf = nbuf; m->shape_rq = rq; m->shape_flat = flat_nb;
+    }
+    if (flat_nb) {
+        // the balanced launch: one range of the pass list a workgroup (k_mm8w_flat)
+        const int64_t n_pass = n_tiles * m->n_rt;
+        FlatCorr corr;
+        {   // 2^544 - (pieces - 1) bias sum_c 2^(8c), pieces = 2 and 4: what a pass's extra pieces added to its sum
+            Big biasall(17, 0);
+            for (int c = 0; c < MM8W_NC; c++) {
+                const int bit = 8 * c, j = bit >> 5, sft = bit & 31;
+                Big t(17, 0);
+                const uint64_t v = (uint64_t)m->bias << sft;
+                t[j] = (uint32_t)v; t[j + 1] = (uint32_t)(v >> 32);
+                big_add(biasall, t);
+            }
+            for (int k = 0; k < 2; k++) {
+                Big x = big_mul(biasall, Big(1, k == 0 ? 1u : 3u));
+                x.resize(17);
+                unsigned cy = 1;
+                for (int j = 0; j < 17; j++) { const uint64_t t = (uint64_t)(uint32_t)~x[j] + cy; corr.w[k][j] = (uint32_t)t; cy = (unsigned)(t >> 32); }
+            }
+        }
+        const size_t lds_f = mm8w_lds_bytes(m->n_rt, m->nkb, 1, flat_nb);
+        const bool chk = check_mask_dev != nullptr;
+#define MM8W_FLAT_LAUNCH(CHK)                                                                                                              \
+    do {                                                                                                                                   \
+        static std::atomic<unsigned long long> attr_done{0};                                                                               \
+        if (!((attr_done.load() >> (ctx->device & 63)) & 1ull)) {                                                                          \
+            HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8w_flat<CHK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+            attr_done.fetch_or(1ull << (ctx->device & 63));                                                                                \
+        }                                                                                                                                  \
+        hipLaunchKernelGGL((k_mm8w_flat<CHK>), dim3((unsigned)mm8w_num_cus()), dim3(256), lds_f, s, m->a8, m->crow, m->zero, in, iv.stride_c, iv.stride_l, \
+                           in_rows_dev, in_count, m->d, out, ov.stride_c, ov.stride_l, out_count, check_mask_dev, mismatch_dev,           \
+                           cmp ? cmp : out, cmp ? cv.stride_c : ov.stride_c, cmp ? cv.stride_l : ov.stride_l, cmp ? 1 : 0, cmp ? n_store : 0, \
+                           m->n_out, m->n_rt, m->nkb, flat_nb, C, n_pass, m->bias, m->wp, first_bad_dev, bad_map_dev, done, corr);         \
+    } while (0)
+        if (chk) MM8W_FLAT_LAUNCH(true); else MM8W_FLAT_LAUNCH(false);
+#undef MM8W_FLAT_LAUNCH
+        HB_LAUNCH_CHECK(ctx);
+        return HB_OK;
     }
     const int64_t n_units = ((n_tiles + tpw - 1) / tpw) * ((m->n_rt + rq - 1) / rq);
     int64_t blocks = mm8w_num_cus();
@@ -804,7 +1165,7 @@ int launch_mm8w_raw(hb_ctx *ctx, int n_out, int d, int tile_rows, const void *a8
                     int32_t *first_bad_dev, uint32_t *bad_map_dev, const FsDone *done) {
     Mm8wMatrix m;
     m.n_out = n_out; m.d = d; m.nkb = (d + 7) / 8; m.tile_rows = tile_rows; m.n_rt = (n_out + tile_rows - 1) / tile_rows;
-    m.shape_tiles = -1; m.shape_tpw = m.shape_nbuf = m.shape_rq = 0;
+    m.shape_tiles = -1; m.shape_tpw = m.shape_nbuf = m.shape_rq = m.shape_flat = 0;
     m.a8 = (int4 *)const_cast<void *>(a8); m.crow = const_cast<uint32_t *>(crow); m.zero = sh->zero; m.bias = sh->bias; m.wp = (WideParams *)sh->wp;
     return launch_mm8w_impl(ctx, &m, in, iv, in_rows_dev, in_count, out, ov, out_count, check_mask_dev, mismatch_dev, C, s, cmp, cv, n_store, first_bad_dev, bad_map_dev, done);
 }

@@ -39,7 +39,7 @@ sh = torch.randint(0, 1 << 62, (B_, 4), dtype=torch.int64, device='cuda', genera
 cols = op.r1_encode(sh)
 out.append("R1 %.1f" % timed(lambda: op.r1_decode(cols, B_)))
 out.append("R2 %.1f" % timed(lambda: op.r2_decode(cols, B_)))
-for nn, dd, CC in [(64, 22, 47663), (86, 86, 6097)]:
+for nn, dd, CC in [(64, 22, 47663), (86, 86, 6097), (171, 86, 6097), (256, 86, 6097)]:
     M = [[rnd.randrange(P) for _ in range(dd)] for _ in range(nn)]
     h = ctypes.c_void_p()
     ctx.check(lib.hb_matrix_from_host(ctx.h, np_ptr(ctx.host_elems([v for r in M for v in r])), nn, dd, ctypes.byref(h), ctx.stream()), "from_host")
