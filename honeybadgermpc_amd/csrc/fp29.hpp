@@ -252,6 +252,22 @@ template <int NW> HB_HD void store_words(uint32_t* __restrict__ p, const uint32_
         *reinterpret_cast<uint2*>(p) = make_uint2(w[0], w[1]);
     }
 }
+// streaming forms for data a launch touches once (the outputs of an encode, the columns a decode reads): the non-temporal hint keeps
+// them from displacing what the next launch of the open reads (NW a multiple of 4)
+typedef uint32_t hb_u4v __attribute__((ext_vector_type(4)));
+template <int NW> __device__ __forceinline__ void load_words_nt(uint32_t (&w)[NW], const uint32_t* __restrict__ p) {
+    static_assert(NW % 4 == 0, "whole dwordx4 accesses");
+#pragma unroll
+    for (int q = 0; q < NW / 4; q++) {
+        const hb_u4v v = __builtin_nontemporal_load(reinterpret_cast<const hb_u4v*>(p) + q);
+        w[4 * q] = v[0]; w[4 * q + 1] = v[1]; w[4 * q + 2] = v[2]; w[4 * q + 3] = v[3];
+    }
+}
+template <int NW> __device__ __forceinline__ void store_words_nt(uint32_t* __restrict__ p, const uint32_t (&w)[NW]) {
+    static_assert(NW % 4 == 0, "whole dwordx4 accesses");
+#pragma unroll
+    for (int q = 0; q < NW / 4; q++) __builtin_nontemporal_store(hb_u4v{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]}, reinterpret_cast<hb_u4v*>(p) + q);
+}
 template <int NL, int NW> HB_HD void load_digits(uint32_t (&d)[NL], const uint32_t* __restrict__ p) {
     uint32_t w[NW];
     load_words<NW>(w, p);

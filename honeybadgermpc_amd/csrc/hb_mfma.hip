@@ -211,7 +211,12 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 v4i acc[24];
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                // the MFMA phase yields to its neighbour's reduction: whatever runs outside the two phases (the reductions, the DMA issue) has the
+                // higher priority -- a wave in a phase loses little by waiting a slot (the matrix pipe is 16 cycles an MFMA whatever rides beside
+                // it), a wave in its reduction holds the unit's barrier (round 6: the open 136.5 -> 133.3 us; the phases ABOVE the rest: 135.5)
+                __builtin_amdgcn_s_setprio(0);
                 Mm8Phase<NKB, 0, SKIP>::run(acc, xs_addr, as_addr, biasv);
+                __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
                 MM8_T(3);   // MFMA half 0
 #pragma unroll
@@ -232,7 +237,9 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 MM8_T(4);   // parking of half 0
+                __builtin_amdgcn_s_setprio(0);
                 Mm8Phase<NKB, 1, SKIP>::run(acc, xs_addr, as_addr, biasv);
+                __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
                 MM8_T(5);   // MFMA half 1
                 // next unit's DMA (issued a pass ago) must have landed before this wave reaches the barrier; waiting
@@ -345,7 +352,16 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
                         // keep the reduction outside the store's exec mask: hipcc otherwise wraps the whole output in a
                         // divergent branch, and the register copies at its join spill
                         asm volatile("" ::"v"(ow[0]), "v"(ow[1]), "v"(ow[2]), "v"(ow[3]), "v"(ow[4]), "v"(ow[5]), "v"(ow[6]), "v"(ow[7]));
-                        if (chunk < n_chunks && i < n_out && oidx < out_count) store_words<8>(out_pk + oidx * 8, ow);
+                        // party-major outputs (an encode: the wave's sixteen chunks of a row are 512 contiguous bytes) leave with the streaming
+                        // hint: nobody on this GPU reads them next, and 97 MB of them parked in the caches held up the loads of the launch
+                        // behind (config 3's open 134.5 -> 128.0 us, round 6).  Chunk-major outputs are 128-byte pieces: the hint costs there
+                        // (k_mm8f's R2 launch 49.6 -> 57 us with it), so they stay ordinary stores
+                        if (chunk < n_chunks && i < n_out && oidx < out_count) {
+                            bool stream_out = false;
+                            if constexpr (SKIP && !RAGGED) stream_out = out_sc == 1;      // (SKIP: Vandermonde matrices at small points -- the encodes)
+                            if (stream_out) store_words_nt<8>(out_pk + oidx * 8, ow);
+                            else store_words<8>(out_pk + oidx * 8, ow);
+                        }
                     }
                     if (reg & 1) __builtin_amdgcn_sched_barrier(0);   // two reductions at a time: ILP for the carry chains
                 }

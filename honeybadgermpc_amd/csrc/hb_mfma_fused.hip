@@ -45,6 +45,12 @@ namespace hb {
 #include "hb_mm8_body.inc"
 
 constexpr int FS_WAVES = 8, FS_TPW = 4;
+#ifdef HB_MM8_TIMING
+__device__ unsigned long long g_fs_t[256 * 8 * 8];
+#define FS_T(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tlast; tlast = tn_; } while (0)
+#else
+#define FS_T(k) do { } while (0)
+#endif
 constexpr int FS_MAXD = 24, FS_MAXC = 104;      // terms (three K-blocks), compared rows
 constexpr size_t FS_LDS_LIMIT = 156 * 1024;
 
@@ -52,6 +58,10 @@ struct FsIdx { uint16_t z[FS_MAXD], xz[FS_MAXD], zc[FS_MAXC], xzc[FS_MAXC]; };
 // the compared senders of a launch whose rows come from the per-party candidate store (k_fs_cand): rows n_coef .. n_coef + nc - 1 of the
 // matrix are the candidates of parties zc[0 .. nc)
 struct FsPick { const uint4 *cand; const uint32_t *cand_crow; int n_coef, nc; uint16_t zc[FS_MAXC]; };
+// which waves scale which terms of the NEXT unit while a unit's passes run (bit l of terms[w]: wave w takes term l): dealt on the host so
+// that the two waves of a SIMD (w and w + 4) reach the unit's barrier together -- a wave that waits leaves its SIMD to ONE wave, and one
+// wave issues at 0.7 of the rate two reach (fs_split)
+struct FsSplit { uint32_t terms[FS_WAVES]; };
 constexpr int FS_CAND_MAXN = 128;               // parties a candidate store is built for (n d 128-bit entries in the builder's LDS)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -71,7 +81,8 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
                                                           int64_t in_count, int d, const int32_t *__restrict__ rowmode,
                                                           uint32_t *__restrict__ out_pk, int64_t out_sc, int64_t out_sl, int64_t out_count,
                                                           int32_t *__restrict__ mismatch, int32_t *__restrict__ first_bad, uint32_t *__restrict__ bad_map,
-                                                          int n_out, int n_rt, int64_t n_chunks, int64_t n_units, BarrettParams bp, const FsDone done, const FsPick pick) {
+                                                          int n_out, int n_rt, int64_t n_chunks, int64_t n_units, BarrettParams bp, const FsDone done, const FsPick pick,
+                                                          const FsSplit split) {
     constexpr int NT = 64 * FS_WAVES, NL = 9, NW = 8;
     extern __shared__ uint4 fs_lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -112,15 +123,12 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
     }
     __syncthreads();
 
-    // (tile, row tile) pairs of a unit: wave w takes w, w + 8, ...; the waves with a pass less than the others scale the next
-    // unit's elements (all of them when the passes divide evenly)
+    // (tile, row tile) pairs of a unit: wave w takes w, w + 8, ...; which terms of the next unit a wave scales beside its passes: split.terms
     const int n_pairs = FS_TPW * n_rt;
-    const int extra = n_pairs % FS_WAVES;                         // waves [0, extra) have one pass more
-    const int pre_first = extra, pre_waves = FS_WAVES - extra;
-    const bool pre_wave = wave >= pre_first;
+    const uint32_t my_terms = (uint32_t)__builtin_amdgcn_readfirstlane((int)split.terms[wave]);
 
     // one task = term l of the unit's 64 chunks: lane = chunk (tile lane >> 4, column lane & 15); T_q of this term wave-uniform
-    auto scale_unit = [&](int64_t unit, uint4 *dst, int l0, int lstep) {
+    auto scale_unit = [&](int64_t unit, uint4 *dst, uint32_t terms) {
         int64_t chunk = unit * 64 + lane;
         if (chunk >= n_chunks) chunk = n_chunks - 1;              // (results of padding chunks are never stored or compared)
         const int t = lane >> 4;
@@ -131,10 +139,12 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
             okk = idx < in_count;
             load_words<NW>(w, in_pk + (okk ? idx : 0) * NW);
         };
-        int l = l0;
+        terms &= d < 32 ? (1u << d) - 1u : ~0u;
+        int l = terms ? __builtin_ctz(terms) : d;
         if (l < d) fetch(l, xw, ok);
         while (l < d) {
-            const int ln = l + lstep;
+            terms &= terms - 1u;
+            const int ln = terms ? __builtin_ctz(terms) : d;
             uint32_t xn[NW];
             bool okn = false;
             if (ln < d) fetch(ln, xn, okn);
@@ -173,8 +183,12 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
             }
             uint32_t w[NW];
             pack<NL, NW>(w, r);
-            {
-                // r < 2p: made canonical only because 2p may pass 2^256 (p > 2^255), where the packed words would drop bit 256
+            if (PP.pneg[NW - 1] >> 31) {
+                // p < 2^255: r < 2p < 2^256 is a 256-bit representative as it is, and the GEMM takes any
+#pragma unroll
+                for (int k = 0; k < NW; k++) w[k] = ok ? w[k] : 0u;
+            } else {
+                // r < 2p may pass 2^256, where the packed words would drop bit 256: made canonical
                 uint32_t u[NW];
                 unsigned cy = 0;
 #pragma unroll
@@ -204,12 +218,19 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
 
     int buf = 0;
     int64_t unit = blockIdx.x;
-    if (unit < n_units) scale_unit(unit, xbuf, wave, FS_WAVES);       // the first unit: every wave takes its share
+#ifdef HB_MM8_TIMING
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memtime();
+#endif
+    if (unit < n_units) scale_unit(unit, xbuf, 0x01010101u << wave);  // the first unit: every wave takes its share
+    FS_T(0);
     for (; unit < n_units; unit += gridDim.x, buf ^= 1) {
         // every wave's share of this unit's elements is in LDS, and nobody reads the other buffer any more
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FS_T(7);
         __builtin_amdgcn_s_barrier();
-        if (pre_wave && unit + gridDim.x < n_units) scale_unit(unit + gridDim.x, xbuf + (size_t)(buf ^ 1) * bufsz, wave - pre_first, pre_waves);
+        FS_T(1);
+        if (my_terms && unit + gridDim.x < n_units) scale_unit(unit + gridDim.x, xbuf + (size_t)(buf ^ 1) * bufsz, my_terms);
+        FS_T(2);
         for (int pidx = wave; pidx < n_pairs; pidx += FS_WAVES) {
             // two row tiles: the waves of one SIMD (w and w + 4) get one of each, so the ragged second tile's shorter passes spread evenly
             const int tl = n_rt == 2 ? (pidx >> 1) : pidx / n_rt;
@@ -227,8 +248,11 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
                 v4i acc[24];
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(0);        // (the phases yield to reductions and scaling: hb_mfma.hip, k_mm8)
                 Mm8Phase<NKB, 0, false>::run(acc, xs_addr, as_addr, biasv);
+                __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
+                FS_T(3);
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     if (reg >= 2 && reg >= nreg) break;
@@ -244,8 +268,12 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
                 v4i acc[24];
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                FS_T(4);
+                __builtin_amdgcn_s_setprio(0);
                 Mm8Phase<NKB, 1, false>::run(acc, xs_addr, as_addr, biasv);
+                __builtin_amdgcn_s_setprio(2);
                 __builtin_amdgcn_sched_barrier(0);
+                FS_T(5);
 #pragma unroll
                 for (int reg = 0; reg < 4; reg++) {
                     if (reg >= 2 && reg >= nreg) break;
@@ -349,8 +377,12 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
                     if (reg & 1) __builtin_amdgcn_sched_barrier(0);   // two reductions at a time: ILP for the carry chains
                 }
             }
+            FS_T(6);
         }
     }
+#ifdef HB_MM8_TIMING
+    if (lane == 0 && blockIdx.x < 256) for (int k = 0; k < 8; k++) g_fs_t[(blockIdx.x * 8 + wave) * 8 + k] = tacc[k];
+#endif
     // a caller that waits for the verdict: the last workgroup to finish hands the status words to pinned host memory (and resets
     // them for the next launch), the sequence number last -- the host polls that word instead of synchronising the stream
     if (done.counter) {
@@ -713,6 +745,35 @@ int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout 
     return HB_OK;
 }
 
+// The terms of the next unit dealt to the waves.  A wave's load in a unit: its passes (wave w takes pairs w, w + 8, ... of the 4 n_rt; a pass
+// over a ragged last row tile with at most 8 rows reduces two of the four outputs a lane holds) plus its terms; measured on config 3's R2
+// launch (scratch/fs_phase_timing.py) a pass is 9.5 k cycles of a wave's time and a term 3.6 k when two waves share the SIMD.  Each term goes
+// to the wave with the least load so far (ties: the higher wave -- the older waves 0..3 win the issue arbitration anyway).
+static FsSplit fs_split(int d, int n_rt, int n_out) {
+    constexpr int PASS = 95, RAGGED = 70, TERM = 36;
+    FsSplit sp;
+    int load[FS_WAVES];
+    const int n_pairs = FS_TPW * n_rt;
+    const bool ragged = n_out - 16 * (n_rt - 1) <= 8;
+    for (int w = 0; w < FS_WAVES; w++) {
+        sp.terms[w] = 0;
+        load[w] = 0;
+        for (int pidx = w; pidx < n_pairs; pidx += FS_WAVES) {
+            const int tl = n_rt == 2 ? (pidx >> 1) : pidx / n_rt;
+            const int rt = n_rt == 2 ? ((pidx ^ (pidx >> 2)) & 1) : pidx - tl * n_rt;
+            load[w] += (ragged && rt == n_rt - 1) ? RAGGED : PASS;
+        }
+    }
+    for (int l = 0; l < d; l++) {
+        int best = FS_WAVES - 1;
+        for (int w = FS_WAVES - 2; w >= 0; w--)
+            if (load[w] < load[best]) best = w;
+        sp.terms[best] |= 1u << l;
+        load[best] += TERM;
+    }
+    return sp;
+}
+
 // the launch over a built image: rows with a store mode go to `out` (view ov, clipped at out_count), rows with a compare mode are
 // checked against the rows of `cols` they name
 int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_t *cols, hb_view cv, uint32_t *out, hb_view ov, int64_t out_count,
@@ -735,13 +796,14 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
     int64_t blocks = fs_num_cus();
     if (blocks > n_units) blocks = n_units;
     const size_t lds = fs_lds_bytes(L.n_rt, L.nkb);
+    const FsSplit split = fs_split(L.d, L.n_rt, L.n_out);
 #define FS_LAUNCH(NKB)                                                                                                                     \
     do {                                                                                                                                   \
         static std::atomic<unsigned long long> attr_done{0};   /* one bit per device: the attribute is per device */                                                                                                     \
         if (!((attr_done.load() >> (ctx->device & 63)) & 1ull)) { HB_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mm8f<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_done.fetch_or(1ull << (ctx->device & 63)); } \
         k_mm8f<NKB><<<dim3((unsigned)blocks), dim3(64 * FS_WAVES), lds, s>>>((const int4 *)(base + L.o_a8), (const uint32_t *)(base + L.o_crow), sh->fold_dev,        \
             (const uint32_t *)(base + L.o_kt), ctx->psc, cols, cv.stride_c, cv.stride_l, (const int32_t *)(base + L.o_z), INT64_MAX, L.d, (const int32_t *)(base + L.o_mode), \
-            out, ov.stride_c, ov.stride_l, out_count, mismatch_dev, first_bad_dev, bad_map_dev, L.n_out, L.n_rt, C, n_units, sh->bp, done, pick); \
+            out, ov.stride_c, ov.stride_l, out_count, mismatch_dev, first_bad_dev, bad_map_dev, L.n_out, L.n_rt, C, n_units, sh->bp, done, pick, split); \
     } while (0)
     switch (L.nkb) {
         case 1: FS_LAUNCH(1); break;
@@ -755,3 +817,9 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
 }
 
 }  // namespace hb
+
+#ifdef HB_MM8_TIMING
+extern "C" int hb_debug_fs_timing(unsigned long long *out, int count) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(hb::g_fs_t), sizeof(unsigned long long) * (size_t)count) == hipSuccess ? 0 : 1;
+}
+#endif
