@@ -1402,26 +1402,48 @@ def main():
     # an arrival set are built on the device while the columns come in, as the reference rebuilds V^-1 inside every
     # vandermonde_batch_interpolate call, hbmpc_ntl_helpers.pyx:139-197).  The columns are received in place (`columns=`): the
     # decoder is told which row of the party-major buffer has landed.
-    dt_first, first_cols, adv = None, None, None
+    dt_first, dt_first_early, first_cols, adv = None, None, None, None
     if world == 1 and not args.no_matrix_cores:
         from honeybadgermpc_amd.device import DeviceIncrementalDecoder
 
         r1v, r2v = r1_cols.view(n, C, 4), r2_cols.view(n, C, 4)
         rng = np.random.Generator(np.random.PCG64(77))
 
-        def first_sight(order1, order2):
+        def make_dec(cols_, want_, busy_):
+            return DeviceIncrementalDecoder(BLS, n, t, batch_size=C, use_omega_powers=use_omega, device=local_rank, columns=cols_, want=want_, defer_verdict=True,
+                                            stream_busy=busy_)
+
+        def first_sight(order1, order2, r2_early=False):
+            """r2_early False: no R2 column is announced before R1's verdict is in (nobody can have sent one before SOME party finished R1; the
+            R2 decoder OBJECT exists before, as the reference subscribes to both rounds before it decodes the first,
+            batch_reconstruction.py:158-176).  True: the R2 columns of parties that were faster than this one are already there."""
             op.r1_encode(shares0, out=r1_out)
             used = 0
-            outs_ = []
-            for order_, cols_, want_ in ((order1, r1v, "constant"), (order2, r2v, "all")):
-                dec_ = DeviceIncrementalDecoder(BLS, n, t, batch_size=C, use_omega_powers=use_omega, device=local_rank, columns=cols_, want=want_)
-                for idx_ in order_:
-                    dec_.add(idx_)
+            dec1, dec2 = make_dec(r1v, "constant", True), None            # (the encode is running while R1's columns come in)
+            for idx_ in order1:
+                dec1.add(idx_)
+                used += 1
+                if dec1.pending():
+                    # decode + validate of R1 is enqueued: while it runs, the next round's decoder is made
+                    dec2 = make_dec(r2v, "all", r2_early)
+                    if r2_early:
+                        for jdx_ in order2:
+                            dec2.add(jdx_)
+                            used += 1
+                            if dec2.pending():
+                                break
+                if dec1.done():
+                    break
+            msg_1 = dec1.get_results()[0]
+            if dec2 is None:
+                dec2 = make_dec(r2v, "all", False)
+            if not dec2.pending():
+                for idx_ in order2:
+                    dec2.add(idx_)
                     used += 1
-                    if dec_.done():
+                    if dec2.done():
                         break
-                outs_.append(dec_.get_results()[0])
-            return outs_[0], outs_[1], used
+            return msg_1, dec2.get_results()[0], used
 
         orders = [(rng.permutation(n).tolist(), rng.permutation(n).tolist()) for _ in range(args.steps + 3)]
         for o_ in orders[:3]:
@@ -1440,6 +1462,13 @@ def main():
         dt_first = time.perf_counter() - t3
         assert msg_ is not None and res_ is not None, "a fault-free open did not finish"
         assert torch.equal(res_.reshape(-1, 4)[:B], secrets) and torch.equal(msg_[:, 0, :], r2_cols[:C]), "first-sight open differs from the secrets"
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for o_ in orders[3:]:
+            msg_e, res_e, _ = first_sight(*o_, r2_early=True)
+        torch.cuda.synchronize()
+        dt_first_early = time.perf_counter() - t3
+        assert torch.equal(res_e.reshape(-1, 4)[:B], secrets) and torch.equal(msg_e[:, 0, :], r2_cols[:C]), "first-sight open (R2 columns early) differs from the secrets"
 
         # The same R2 decode under attack, at first sight: t senders send garbage in every chunk -- arriving FIRST (a candidate from the
         # newest columns decides, device.py _candidate_cap) or SPREAD over the arrival list (the probe decides); every column is needed,
@@ -1589,7 +1618,13 @@ def main():
                 "first_sight_note": "(gc.freeze() after set-up: the interpreter's full collections are kept out of the timed loop) R1 encode + one DeviceIncrementalDecoder per round fed column by column in a fresh seeded arrival order every step "
                                     "(its optimistic phase is an hb_dec object behind the C ABI: add(idx) is one call of hb_dec_arrived1, the verdict is waited for in C) "
                                     f"({first_cols} columns announced per open), columns received in place, nothing cached per arrival pattern: what "
-                                    "batch_reconstruct_device runs; `value` is the same open through an open plan whose arrival set is fixed at plan creation",
+                                    "batch_reconstruct_device runs; `value` is the same open through an open plan whose arrival set is fixed at plan creation.  "
+                                    "Round 6: decoders with defer_verdict -- the quorum's add() enqueues decode + validate and returns, so the R2 decoder object is made while R1's launch runs "
+                                    "(the reference subscribes to both rounds before decoding the first, batch_reconstruction.py:158-176); NO R2 column is announced before R1's verdict is in; "
+                                    "what depends on the first degree+1 arrivals alone is built on the decoder's own stream, beside the encode (the persistent launches leave workgroup slots free)",
+                "shares_per_s_per_gpu_first_sight_r2_columns_early": (B * args.steps / dt_first_early) if dt_first_early else None,
+                "first_sight_r2_columns_early_note": "the same opens when the R2 columns of faster parties are already there while this party's R1 launch runs: they are announced at once, "
+                                                     "R2's first half runs beside R1's launch and R2's launch queues behind it (an upper bound for a party that is not the slowest)",
                 "r2_decode_under_attack_first_sight": adv if dt_first else None,
                 "under_attack_note": f"ONE DeviceIncrementalDecoder decode of the R2 columns with t = {t} senders sending garbage in every chunk, fed column by column, nothing "
                                      "cached: liars_first = they arrive before every honest sender (the reference's worst case: all n columns are needed); "

@@ -19,7 +19,8 @@ LIB_PATH = os.environ.get("HBMPC_HIP_LIB") or os.path.join(_HERE, "lib", "libhbm
 
 HB_OK, HB_ERR_SINGULAR, HB_ERR_BAD_ARG, HB_ERR_UNSUPPORTED = 0, 1, 2, 3
 HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_MISMATCH = 4, 5, 6
-HB_DEC_COLLECTING, HB_DEC_DONE, HB_DEC_DISAGREE, HB_DEC_UNSUPPORTED = 0, 1, 2, 3
+HB_DEC_COLLECTING, HB_DEC_DONE, HB_DEC_DISAGREE, HB_DEC_UNSUPPORTED, HB_DEC_PENDING = 0, 1, 2, 3, 4
+HB_DEC_OPT_DEFER, HB_DEC_OPT_BESIDE = 1, 2
 
 _STATUS_NAMES = {
     1: "HB_ERR_SINGULAR",
@@ -67,10 +68,15 @@ SYMBOLS = {
     "hb_quick_dec_create": (_i, [_vp, _vp, _i, _pp, _vp]),
     "hb_quick_dec_arrivals": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "hb_quick_dec_decide": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "hb_quick_dec_launch": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "hb_quick_dec_verdict": (_i, [_vp, _vp, _vp]),
+    "hb_quick_dec_beside": (_i, [_vp, _i]),
     "hb_quick_dec_destroy": (None, [_vp]),
     "hb_dec_create": (_i, [_vp, _vp, _i, _i, _i, _pp, _vp]),
     "hb_dec_begin": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _i, _vp]),
     "hb_dec_arrived1": (_i, [_vp, _i]),
+    "hb_dec_options": (_i, [_vp, _i]),
+    "hb_dec_settle": (_i, [_vp]),
     "hb_dec_arrived": (_i, [_vp, _vp, _i, _vp, _vp]),
     "hb_dec_verdict": (_i, [_vp, _vp, _vp]),
     "hb_dec_arrivals_list": (_i, [_vp, _vp, _i, _vp]),

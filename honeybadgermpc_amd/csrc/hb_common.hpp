@@ -141,6 +141,8 @@ struct hb_ctx {
     std::vector<QuickSlot> qslots;
     unsigned qnext = 0;
     std::vector<void *> probe_pool, probe_host_pool;
+    void *side_stream = nullptr;                      // hipStream_t: ONE stream for every decoder's builds beside the caller's stream (a process has four
+                                                      // hardware queues: a stream per decoder object would share them with the caller's)
     // Scratch of the batched robust decoders (hb_gao_decode / hb_wb_decode: interpolants, locators, side records -- 0.85 GB each at config 4),
     // kept with the context and reused by the next call: ctx_scratch() below
     std::map<std::string, std::pair<void *, size_t>> scratch;
@@ -305,8 +307,34 @@ int launch_mm8w(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in, hb_view iv
 bool fold_tables(hb_ctx *ctx, int n_bytes, uint8_t *fold, uint32_t *top8, uint32_t *mu, uint32_t *shift8);
 // completion signal of a launch whose caller waits for the verdict: a device counter of finished workgroups, the pinned (device-visible)
 // record the last one fills in, the sequence number it writes last
-struct FsVerdict { int32_t flag, first, seq, pad; };
+// The hand-over is ONE 64-bit store -- [63:32] the sequence number, [31] some compared column disagrees, [30] a matrix entry left its range
+// (FS_OVERFLOW), [29:0] the first disagreeing chunk (all ones: none) -- so the host reads a verdict that is whole the moment it sees the
+// number (rounds 4-5: three words with a system-scope fence between the last two, a PCIe round trip on the path of every decode)
+struct FsVerdict { unsigned long long word; unsigned long long pad; };
 struct FsDone { int32_t *counter; FsVerdict *host; int32_t seq; };
+constexpr int32_t FS_VERDICT_NONE = 0x3fffffff;              // launches a caller waits for take fewer chunks than this (hb_quick.hip)
+#ifdef __HIPCC__
+// called by the last workgroup of a launch (every other one has fenced and counted itself): read the status words, publish, reset them
+__device__ __forceinline__ void fs_publish_verdict(int32_t *mismatch, int32_t *first_bad, int32_t *counter, FsVerdict *host, int32_t seq) {
+    const int32_t fl = mismatch ? __hip_atomic_load(mismatch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const int32_t fb = first_bad ? __hip_atomic_load(first_bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INT32_MAX;
+    const uint32_t low = ((fl & 1) ? 0x80000000u : 0u) | ((fl & 0x40000000) ? 0x40000000u : 0u) | (uint32_t)((fb < 0 || fb > FS_VERDICT_NONE) ? FS_VERDICT_NONE : fb);
+    // (relaxed: the host reads nothing but this word; what the launch wrote to HBM is ordered for the stream's next launch by the launch's end, and
+    // for the device at large by every workgroup's fence before it counted itself -- a system-scope release here would write back the L2)
+    __hip_atomic_store(&host->word, ((unsigned long long)(uint32_t)seq << 32) | low, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (mismatch) __hip_atomic_store(mismatch, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (first_bad) __hip_atomic_store(first_bad, INT32_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (counter) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+// host side of the same word
+inline bool fs_verdict_is(const FsVerdict *host, int32_t seq) { return (int32_t)(*reinterpret_cast<const volatile unsigned long long *>(&host->word) >> 32) == seq; }
+inline void fs_verdict_read(const FsVerdict *host, int32_t *flag, int32_t *first) {
+    const uint32_t low = (uint32_t)*reinterpret_cast<const volatile unsigned long long *>(&host->word);
+    *flag = ((low >> 31) ? 1 : 0) | ((low & 0x40000000u) ? 0x40000000 : 0);
+    const int32_t f = (int32_t)(low & 0x3fffffffu);
+    *first = f == FS_VERDICT_NONE ? INT32_MAX : f;
+}
 struct Mm8wShared { uint32_t bias; uint32_t c80r[9], biasmod[9]; void *wp; uint32_t *zero; };
 int mm8w_geometry(int n_out, int d, int *tile_rows, int *n_rt, int *nkb, size_t *a8_bytes, size_t *crow_words);
 int mm8w_shared(hb_ctx *ctx, int d, const Mm8wShared **out, hipStream_t s);

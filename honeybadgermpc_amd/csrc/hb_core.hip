@@ -549,6 +549,7 @@ void hb_ctx_destroy(hb_ctx *ctx) {
     for (auto &kv : ctx->fcache) fast_matrix_free(kv.second);
     for (auto &kv : ctx->m8cache) mm8_free(kv.second);
     if (ctx->flag_dev) (void)hipFree(ctx->flag_dev);
+    if (ctx->side_stream) (void)hipStreamDestroy((hipStream_t)ctx->side_stream);
     point_tables_free(ctx);
     mm8w_shared_free(ctx);
     mm8_shared_free(ctx);

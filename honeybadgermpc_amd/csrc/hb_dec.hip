@@ -21,6 +21,10 @@
 //                       hb_dec_verdict names the first disagreeing chunk (everything before it is settled)
 //   HB_DEC_UNSUPPORTED  this shape / point set / modulus is outside the plan-free kernels (found when the first degree + 1 arrivals
 //                       were known): the caller decodes the arrival list some other way
+//   HB_DEC_PENDING      (only with HB_DEC_OPT_DEFER) the quorum is complete and decode + validate is enqueued, the verdict not read
+//                       yet: hb_dec_settle waits for it.  The caller's thread is free meanwhile -- batch_reconstruct makes the next
+//                       round's decoder and takes its first messages while this round's launch runs (batch_reconstruction.py:158-227
+//                       subscribes to both rounds up front for the same reason)
 #include <stdlib.h>
 
 #include <vector>
@@ -44,6 +48,7 @@ struct hb_dec {
     int state;
     int32_t first;
     bool begun;
+    bool deferred;                      // the quorum's arrival returns HB_DEC_PENDING instead of waiting for the verdict
 };
 
 extern "C" {
@@ -59,7 +64,7 @@ int hb_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, int degree, int ma
     dec->cols = nullptr; dec->C = 0; dec->coeffs = nullptr; dec->n_coef = 0; dec->need = 0; dec->nc = 0; dec->stream = nullptr;
     dec->seen.assign((size_t)n, 0);
     dec->z.reserve((size_t)n);
-    dec->state = HB_DEC_COLLECTING; dec->first = INT32_MAX; dec->begun = false;
+    dec->state = HB_DEC_COLLECTING; dec->first = INT32_MAX; dec->begun = false; dec->deferred = false;
     *out = dec;
     return HB_OK;
 }
@@ -67,9 +72,8 @@ int hb_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, int degree, int ma
 int hb_dec_begin(hb_dec *dec, const uint64_t *cols_dev, int64_t C, int n_coef, uint64_t *coeffs_dev, const int32_t *excluded, int n_excluded, void *stream) {
     if (!dec) return HB_ERR_BAD_ARG;
     const int d = dec->degree + 1;
-    // a round abandoned between its (degree + 1)-th arrival and its verdict has a build enqueued on ITS stream: the next round's build into the
-    // same buffers must not overtake it
-    if (dec->begun && dec->state == HB_DEC_COLLECTING && (int)dec->z.size() >= d && dec->stream != stream) (void)hipStreamSynchronize((hipStream_t)dec->stream);
+    // (a round abandoned after its (degree + 1)-th arrival has a build enqueued: every build of this object runs on the quick decoder's own
+    // stream, in order, and a decode launch nobody waited for is waited for by the next build -- hb_quick.hip)
     dec->begun = false;                       // (a begin that fails leaves no round in progress)
     if (!cols_dev || !coeffs_dev || C < 1 || n_excluded < 0 || (n_excluded > 0 && !excluded)) return HB_ERR_BAD_ARG;
     if (n_coef != 1 && n_coef != d) return HB_ERR_BAD_ARG;
@@ -109,8 +113,31 @@ int hb_dec_arrived1(hb_dec *dec, int32_t idx) {
         return HB_DEC_COLLECTING;
     }
     if (k < dec->need) return HB_DEC_COLLECTING;
+    if (dec->deferred) {
+        const int rc = hb_quick_dec_launch(dec->qd, dec->z.data() + d, dec->nc, dec->cols, dec->C, 0, dec->C, dec->coeffs, dec->stream);
+        if (rc) return -rc;
+        return dec->state = HB_DEC_PENDING;
+    }
     int32_t flag = 0, first = INT32_MAX;
     const int rc = hb_quick_dec_decide(dec->qd, dec->z.data() + d, dec->nc, dec->cols, dec->C, 0, dec->C, dec->coeffs, &flag, &first, dec->stream);
+    if (rc) return -rc;
+    if (flag & 0x40000000) { (void)fail(dec->ctx, HB_ERR_HIP, "fused decode: a matrix entry left the range its host-side bound promised"); return -HB_ERR_HIP; }
+    dec->first = flag ? first : INT32_MAX;
+    return dec->state = flag ? HB_DEC_DISAGREE : HB_DEC_DONE;
+}
+
+int hb_dec_options(hb_dec *dec, int flags) {
+    if (!dec || (flags & ~(HB_DEC_OPT_DEFER | HB_DEC_OPT_BESIDE))) return HB_ERR_BAD_ARG;
+    if (dec->begun && dec->state == HB_DEC_PENDING) return fail(dec->ctx, HB_ERR_BAD_ARG, "decoder: a verdict is pending (hb_dec_settle first)");
+    dec->deferred = (flags & HB_DEC_OPT_DEFER) != 0;
+    return hb_quick_dec_beside(dec->qd, (flags & HB_DEC_OPT_BESIDE) ? 1 : 0);
+}
+
+int hb_dec_settle(hb_dec *dec) {
+    if (!dec || !dec->begun) return -HB_ERR_BAD_ARG;
+    if (dec->state != HB_DEC_PENDING) return dec->state;
+    int32_t flag = 0, first = INT32_MAX;
+    const int rc = hb_quick_dec_verdict(dec->qd, &flag, &first);
     if (rc) return -rc;
     if (flag & 0x40000000) { (void)fail(dec->ctx, HB_ERR_HIP, "fused decode: a matrix entry left the range its host-side bound promised"); return -HB_ERR_HIP; }
     dec->first = flag ? first : INT32_MAX;

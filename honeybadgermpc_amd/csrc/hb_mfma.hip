@@ -374,6 +374,12 @@ __global__ __launch_bounds__(256, 2) void k_mm8(const int4 *__restrict__ a8, con
 #endif
 }
 
+int64_t mm8_trimmed_grid(int64_t n_units, int64_t blocks) {
+    if (blocks < 1 || n_units < 1) return blocks;
+    const int64_t rounds = (n_units + blocks - 1) / blocks;
+    return (n_units + rounds - 1) / rounds;
+}
+
 }  // namespace hb
 
 using namespace hb;
@@ -659,6 +665,10 @@ int launch_mm8(hb_ctx *ctx, const Mm8Matrix *m, const uint32_t *in, hb_view iv, 
     const int64_t n_units = (n_tiles + tpw - 1) / tpw;
     int64_t blocks = 2 * (int64_t)mm8_num_cus();
     if (blocks > n_units) blocks = n_units;
+    // no more workgroups than the launch's length needs: with the slowest workgroup at `rounds` units, ceil(n_units / rounds) of them do --
+    // config 3's encode is 497 of 512 -- and the slots left free are where a decoder's small launches on other streams (the builder of the
+    // next decode, a symbol fetch, the probe) run beside this one instead of behind it
+    blocks = mm8_trimmed_grid(n_units, blocks);
     const size_t lds = mm8_lds_bytes(m->n_rt, m->nkb, tpw);
     const bool check = check_mask_dev != nullptr;
     // the last row tile holds at most 8 rows: its outputs 2 and 3 are padding and their reduction can be skipped

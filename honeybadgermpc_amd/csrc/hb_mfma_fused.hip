@@ -100,25 +100,43 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
         const int lc = (int)threadIdx.x < d ? (int)threadIdx.x : d - 1;
         rowl[threadIdx.x] = in_rows ? in_rows[lc] : lc;
     }
+    // the rows of the compared senders were built per PARTY when the first d arrivals were known (k_fs_cand); which of them this launch
+    // compares, and in which row, is only known now: their digit pieces and row constants are FETCHED here, ahead of the tables' copy (two
+    // dependent loads, the sender's number and then its row: they ride under the copy), and written over the image's empty rows behind it
+    uint4 pk_piece = make_uint4(0, 0, 0, 0), pk_crow = make_uint4(0, 0, 0, 0);
+    const int pk_e = threadIdx.x;
+    const bool pk_has_piece = pick.cand && pk_e < pick.nc * NKB * 8, pk_has_crow = pick.cand && pk_e < pick.nc * 4;
+    static_assert(FS_MAXC * 3 * 8 <= 5 * NT, "a thread fetches at most five pieces");
+    uint4 pk_more[4];
+    if (pk_has_piece) {
+        const int j = pk_e / (NKB * 8), pc = pk_e - j * (NKB * 8);
+        pk_piece = pick.cand[(size_t)pick.zc[j] * (NKB * 8) + pc];
+    }
+    if (pick.cand)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int e = pk_e + (r + 1) * NT;
+            if (e < pick.nc * NKB * 8) { const int j = e / (NKB * 8), pc = e - j * (NKB * 8); pk_more[r] = pick.cand[(size_t)pick.zc[j] * (NKB * 8) + pc]; }
+        }
+    if (pk_has_crow) pk_crow = reinterpret_cast<const uint4 *>(pick.cand_crow)[(size_t)pick.zc[pk_e >> 2] * 4 + (pk_e & 3)];
     for (int i = threadIdx.x; i < n_rt * 16; i += NT) maskl[i] = i < n_out ? rowmode[i] : 0;
     for (int i = threadIdx.x; i < n_rt * 64; i += NT) fs_lds[i] = reinterpret_cast<const uint4 *>(crowd)[i];
     for (int i = threadIdx.x; i < n_rt * NKB * 2 * 64; i += NT) abuf[i] = a8[i];
     for (int i = threadIdx.x; i < 2 * bufsz; i += NT) xbuf[i] = make_uint4(0, 0, 0, 0);
     if (threadIdx.x < MM8_FOLD_Q) foldl[threadIdx.x] = foldg[threadIdx.x];
     if (pick.cand) {
-        // the rows of the compared senders were built per PARTY when the first d arrivals were known (k_fs_cand); which of them this
-        // launch compares, and in which row, is only known now: gather their digit pieces, row constants and compare targets
         __syncthreads();
-        for (int e = threadIdx.x; e < pick.nc * NKB * 8; e += NT) {
+        auto put = [&](int e, const uint4 &v) {
             const int j = e / (NKB * 8), pc = e - j * (NKB * 8);
             const int ri = pick.n_coef + j, rt = ri >> 4, r16 = ri & 15, r = 4 * (r16 & 3) + (r16 >> 2);
             const int kb = pc >> 3, grp = (pc >> 2) & 1, gg = pc & 3;
-            reinterpret_cast<uint4 *>(abuf)[((rt * NKB + kb) * 2 + grp) * 64 + r + 16 * gg] = pick.cand[(size_t)pick.zc[j] * (NKB * 8) + pc];
-        }
-        for (int e = threadIdx.x; e < pick.nc * 4; e += NT) {
-            const int j = e >> 2, q = e & 3;
-            fs_lds[(pick.n_coef + j) * 4 + q] = reinterpret_cast<const uint4 *>(pick.cand_crow)[(size_t)pick.zc[j] * 4 + q];
-        }
+            reinterpret_cast<uint4 *>(abuf)[((rt * NKB + kb) * 2 + grp) * 64 + r + 16 * gg] = v;
+        };
+        if (pk_has_piece) put(pk_e, pk_piece);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (pk_e + (r + 1) * NT < pick.nc * NKB * 8) put(pk_e + (r + 1) * NT, pk_more[r]);
+        if (pk_has_crow) fs_lds[(pick.n_coef + (pk_e >> 2)) * 4 + (pk_e & 3)] = pk_crow;
         for (int j = threadIdx.x; j < pick.nc; j += NT) maskl[pick.n_coef + j] = (int32_t)pick.zc[j] + 1;
     }
     __syncthreads();
@@ -390,13 +408,7 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
         if (threadIdx.x == 0) {
             __threadfence();
             if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
-                const int32_t fl = mismatch ? atomicExch(mismatch, 0) : 0;
-                const int32_t fb = first_bad ? atomicExch(first_bad, INT32_MAX) : INT32_MAX;
-                atomicExch(done.counter, 0);
-                done.host->flag = fl;
-                done.host->first = fb;
-                __threadfence_system();
-                *reinterpret_cast<volatile int32_t *>(&done.host->seq) = done.seq;
+                fs_publish_verdict(mismatch, first_bad, done.counter, done.host, done.seq);
             }
         }
     }
@@ -795,6 +807,7 @@ int fs_launch(hb_ctx *ctx, const FsLayout &L, const uint8_t *base, const uint32_
     const int64_t n_units = (C + 63) / 64;
     int64_t blocks = fs_num_cus();
     if (blocks > n_units) blocks = n_units;
+    blocks = mm8_trimmed_grid(n_units, blocks);          // (config 3: 249 of 256 -- seven CUs stay free for what other streams launch meanwhile)
     const size_t lds = fs_lds_bytes(L.n_rt, L.nkb);
     const FsSplit split = fs_split(L.d, L.n_rt, L.n_out);
 #define FS_LAUNCH(NKB)                                                                                                                     \

@@ -328,13 +328,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
             if (threadIdx.x == 0) {
                 __threadfence();
                 if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
-                    const int32_t fl = mismatch ? atomicExch(mismatch, 0) : 0;
-                    const int32_t fb = first_bad ? atomicExch(first_bad, INT32_MAX) : INT32_MAX;
-                    atomicExch(done.counter, 0);
-                    done.host->flag = fl;
-                    done.host->first = fb;
-                    __threadfence_system();
-                    *reinterpret_cast<volatile int32_t *>(&done.host->seq) = done.seq;
+                    fs_publish_verdict(mismatch, first_bad, done.counter, done.host, done.seq);
                 }
             }
         }
@@ -601,13 +595,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w_flat(const int4 *__restrict__ a
             if (threadIdx.x == 0) {
                 __threadfence();
                 if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
-                    const int32_t fl = mismatch ? atomicExch(mismatch, 0) : 0;
-                    const int32_t fb = first_bad ? atomicExch(first_bad, INT32_MAX) : INT32_MAX;
-                    atomicExch(done.counter, 0);
-                    done.host->flag = fl;
-                    done.host->first = fb;
-                    __threadfence_system();
-                    *reinterpret_cast<volatile int32_t *>(&done.host->seq) = done.seq;
+                    fs_publish_verdict(mismatch, first_bad, done.counter, done.host, done.seq);
                 }
             }
         }

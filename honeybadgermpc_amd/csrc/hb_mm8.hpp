@@ -43,6 +43,8 @@ struct Mm8Shared {
     v4i *fold_dev;
 };
 int mm8_shared(hb_ctx *ctx, const Mm8Shared **out, hipStream_t s);
+// persistent launches: the fewest workgroups that finish in as many units a workgroup as `blocks` would (hb_mfma.hip)
+int64_t mm8_trimmed_grid(int64_t n_units, int64_t blocks);
 void mm8_shared_free(hb_ctx *ctx);
 
 }  // namespace hb

@@ -1334,13 +1334,7 @@ int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const 
 
 // the verdict of a launch that cannot hand it over itself (the full-size kernel): status words -> pinned record, sequence number last
 __global__ void k_publish_verdict(int32_t *status, FsVerdict *host, int seq) {
-    const int32_t fl = status[0], fb = status[1];
-    status[0] = 0;
-    status[1] = INT32_MAX;
-    host->flag = fl;
-    host->first = fb;
-    __threadfence_system();
-    *reinterpret_cast<volatile int32_t *>(&host->seq) = seq;
+    fs_publish_verdict(status, status + 1, nullptr, host, seq);
 }
 
 struct hb_quick_dec {
@@ -1359,6 +1353,15 @@ struct hb_quick_dec {
     int seq;
     bool prepared;
     std::vector<int32_t> z;
+    // What depends on the first d arrivals alone reads no column: it is enqueued on a stream of the decoder's own (highest priority), so it runs
+    // BESIDE whatever the caller's stream is busy with (the open's encode while R1's columns come in: the persistent launches leave a few
+    // workgroup slots free for exactly this, mm8_trimmed_grid) instead of behind it; the decode launch waits for `built`.
+    hipStream_t bstream;
+    hipEvent_t built, launched;
+    bool launch_open;             // a decode launch whose verdict nobody has read yet may still read `buf`: the next build waits for `launched`
+    hipStream_t launch_stream;
+    bool beside;                  // hb_quick_dec_beside: builds go to bstream
+    bool built_beside;            // the last build went there and no launch has waited for it yet
 };
 
 namespace hb {
@@ -1391,9 +1394,22 @@ int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec
     if (e == hipSuccess) e = hipStreamSynchronize(s);          // (init is on this stack)
     if (e == hipSuccess) e = hipHostMalloc((void **)&qd->res_host, sizeof(FsVerdict), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&qd->res_dev, qd->res_host, 0);
+    qd->bstream = nullptr; qd->built = qd->launched = nullptr; qd->launch_open = false; qd->launch_stream = nullptr; qd->beside = qd->built_beside = false;
+    if (e == hipSuccess && !ctx->side_stream) {
+        int lo_prio = 0, hi_prio = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+        hipStream_t ss = nullptr;
+        e = hipStreamCreateWithPriority(&ss, hipStreamNonBlocking, hi_prio);
+        if (e == hipSuccess) ctx->side_stream = ss;
+    }
+    qd->bstream = (hipStream_t)ctx->side_stream;              // the context's, shared by its decoders
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&qd->built, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&qd->launched, hipEventDisableTiming);
     if (e != hipSuccess) {
         if (qd->status) (void)hipFree(qd->status);
         if (qd->res_host) (void)hipHostFree(qd->res_host);
+        if (qd->built) (void)hipEventDestroy(qd->built);
+        if (qd->launched) (void)hipEventDestroy(qd->launched);
         delete qd;
         ctx->err = std::string("quick decoder: ") + hipGetErrorString(e);
         return HB_ERR_HIP;
@@ -1409,6 +1425,17 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
     hb_ctx *ctx = qd->ctx;
     hipStream_t s = (hipStream_t)stream;
     qd->prepared = false;
+    // Where the build goes: in order on the caller's stream, or -- hb_quick_dec_beside(qd, 1): the caller knows its stream is busy (the open's
+    // encode while R1's columns come in; R1's decode launch while R2's first columns come in) -- on the decoder's OWN stream, beside that work
+    // (the persistent launches leave workgroup slots free, mm8_trimmed_grid).  It reads no column and nothing the caller's stream produces.
+    // The decode launch then waits for an event: ~12 us before the waiting queue moves again (round 6, kernel trace) -- a gain where the
+    // build hides behind more than that, a loss on an idle stream, hence the caller's choice.  (Built and dropped, round 6: the builder counting
+    // its workgroups in and out and the decode launch polling the count instead of the event -- the launch started as late with two queues
+    // active, and an acquire per poll, an invalidation of the XCD's L2, made it 15 us longer.)
+    hipStream_t bs = qd->beside ? qd->bstream : s;
+    qd->built_beside = false;
+    // (a decode launch of this object that nobody has waited for -- an abandoned round -- may still read the buffers a build writes)
+    if (qd->launch_open && qd->launch_stream != bs) { HB_HIP(ctx, hipStreamWaitEvent(bs, qd->launched, 0)); }
     FsLayout L;
     int rc = fs_layout(ctx, qd->pt, d, nc, n_coef, &L);
     if (rc) {
@@ -1418,12 +1445,13 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
         if (rc) return rc;
         (void)quick_layout_cand(ctx, &Q);          // a row per party with the first half, where the point set allows it: nothing is built behind the last column
         if (qd->cap < Q.need) {
-            if (qd->buf) { HB_HIP(ctx, hipStreamSynchronize(s)); HB_HIP(ctx, hipFree(qd->buf)); }
+            if (qd->buf) { HB_HIP(ctx, hipStreamSynchronize(s)); HB_HIP(ctx, hipStreamSynchronize(qd->bstream)); HB_HIP(ctx, hipFree(qd->buf)); }
             qd->buf = nullptr; qd->cap = 0;
             HB_HIP(ctx, hipMalloc(&qd->buf, Q.need));
             qd->cap = Q.need;
         }
-        rc = quick_build(ctx, qd->x.data(), z, nullptr, Q, qd->buf, &qd->qsh, s, 1 | 4); if (rc) return rc;
+        rc = quick_build(ctx, qd->x.data(), z, nullptr, Q, qd->buf, &qd->qsh, bs, 1 | 4); if (rc) return rc;
+        if (bs != s) { HB_HIP(ctx, hipEventRecord(qd->built, bs)); qd->built_beside = true; }
         qd->Q = Q;
         qd->wide = true;
         qd->z.assign(z, z + d);
@@ -1433,13 +1461,14 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
     qd->wide = false;
     if (qd->cap < L.need) {
         // (a launch of this decoder may still read the old buffer: decide() waits for its verdict, so only an abandoned one can)
-        if (qd->buf) { HB_HIP(ctx, hipStreamSynchronize(s)); HB_HIP(ctx, hipFree(qd->buf)); }
+        if (qd->buf) { HB_HIP(ctx, hipStreamSynchronize(s)); HB_HIP(ctx, hipStreamSynchronize(qd->bstream)); HB_HIP(ctx, hipFree(qd->buf)); }
         qd->buf = nullptr; qd->cap = 0;
         HB_HIP(ctx, hipMalloc(&qd->buf, L.need));
         qd->cap = L.need;
     }
-    if (L.o_cand && nc > 0) { rc = fs_build_cand(ctx, qd->pt, z, L, qd->buf, qd->status, s, true); if (rc) return rc; }      // one launch, two workgroups
-    else { rc = fs_build(ctx, qd->pt, z, nullptr, L, qd->buf, FS_BUILD_Z, qd->status, s); if (rc) return rc; }
+    if (L.o_cand && nc > 0) { rc = fs_build_cand(ctx, qd->pt, z, L, qd->buf, qd->status, bs, true); if (rc) return rc; }      // one launch, two workgroups
+    else { rc = fs_build(ctx, qd->pt, z, nullptr, L, qd->buf, FS_BUILD_Z, qd->status, bs); if (rc) return rc; }
+    if (bs != s) { HB_HIP(ctx, hipEventRecord(qd->built, bs)); qd->built_beside = true; }
     qd->L = L;
     qd->z.assign(z, z + d);
     qd->prepared = true;
@@ -1450,8 +1479,10 @@ int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int
 static int quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
                             uint64_t *coeffs_dev, void *stream, int *seq_out) { HB_API_GUARD((qd ? qd->ctx : nullptr));
     if (!qd || !qd->prepared || nc != (qd->wide ? qd->Q.nc : qd->L.nc) || (nc > 0 && !zc) || !cols_dev || C < 1 || chunk_lo < 0 || chunk_hi > C || chunk_lo >= chunk_hi) return HB_ERR_BAD_ARG;
+    if (chunk_hi - chunk_lo >= FS_VERDICT_NONE) return fail(qd->ctx, HB_ERR_UNSUPPORTED, "quick decoder: more than 2^30 - 2 chunks a launch");
     hb_ctx *ctx = qd->ctx;
     hipStream_t s = (hipStream_t)stream;
+    if (qd->built_beside) { HB_HIP(ctx, hipStreamWaitEvent(s, qd->built, 0)); qd->built_beside = false; }      // the first half, on the decoder's own stream
     if (qd->wide) {
         const QuickLayout &Q = qd->Q;
         int rc = HB_OK;
@@ -1466,6 +1497,8 @@ static int quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const u
                           qd->status, qd->status + 1, cnt, s, nullptr, &done);
         if (rc) return rc;
         if (Q.nc == 0) { k_publish_verdict<<<1, 1, 0, s>>>(qd->status, qd->res_dev, qd->seq + 1); HB_LAUNCH_CHECK(ctx); }
+        HB_HIP(ctx, hipEventRecord(qd->launched, s));
+        qd->launch_open = true; qd->launch_stream = s;
         qd->seq += 1;
         qd->prepared = false;
         *seq_out = qd->seq;
@@ -1492,35 +1525,53 @@ static int quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const u
     rc = fs_launch(ctx, L, qd->buf, in, pm, out, ov, coeffs_dev ? (L.n_coef == 1 ? cnt : cnt * (int64_t)L.d) : 0, qd->status, qd->status + 1, nullptr, cnt, s, &done,
                    picked ? zc : nullptr);
     if (rc) return rc;
+    HB_HIP(ctx, hipEventRecord(qd->launched, s));
+    qd->launch_open = true; qd->launch_stream = s;
     qd->seq += 1;
     qd->prepared = false;                      // one verdict per set of arrivals
     *seq_out = qd->seq;
     return HB_OK;
 }
 
-int hb_quick_dec_decide(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
-                        uint64_t *coeffs_dev, int32_t *flag, int32_t *first, void *stream) {
-    if (!flag || !first) return HB_ERR_BAD_ARG;
+int hb_quick_dec_beside(hb_quick_dec *qd, int on) { HB_API_GUARD((qd ? qd->ctx : nullptr));
+    if (!qd) return HB_ERR_BAD_ARG;
+    qd->beside = on != 0;
+    return HB_OK;
+}
+
+int hb_quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
+                        uint64_t *coeffs_dev, void *stream) {
     int seq = 0;
-    const int rc = quick_dec_launch(qd, zc, nc, cols_dev, C, chunk_lo, chunk_hi, coeffs_dev, stream, &seq);
-    if (rc) return rc;
+    return quick_dec_launch(qd, zc, nc, cols_dev, C, chunk_lo, chunk_hi, coeffs_dev, stream, &seq);
+}
+
+int hb_quick_dec_verdict(hb_quick_dec *qd, int32_t *flag, int32_t *first) {
+    if (!qd || !flag || !first) return HB_ERR_BAD_ARG;
     hb_ctx *ctx = qd->ctx;
-    hipStream_t s = (hipStream_t)stream;
+    if (!qd->launch_open) return fail(ctx, HB_ERR_BAD_ARG, "quick decoder: no launch is waiting for its verdict");
+    const int seq = qd->seq;
     // outside the context's mutex: poll the sequence number the last workgroup writes after the verdict; past 2 ms, synchronise
-    volatile int32_t *word = &qd->res_host->seq;
     const auto t0 = std::chrono::steady_clock::now();
     int spins = 0;
-    while (*word != seq) {
+    while (!fs_verdict_is(qd->res_host, seq)) {
         if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
-            HB_HIP(ctx, hipStreamSynchronize(s));
+            HB_HIP(ctx, hipStreamSynchronize(qd->launch_stream));
             break;
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    if (*word != seq) return fail(ctx, HB_ERR_HIP, "quick decoder: the kernel finished without a verdict");
-    *flag = qd->res_host->flag;
-    *first = qd->res_host->first;
+    if (!fs_verdict_is(qd->res_host, seq)) return fail(ctx, HB_ERR_HIP, "quick decoder: the kernel finished without a verdict");
+    qd->launch_open = false;                   // the launch has ended: nothing reads the image any more
+    fs_verdict_read(qd->res_host, flag, first);
     return HB_OK;
+}
+
+int hb_quick_dec_decide(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
+                        uint64_t *coeffs_dev, int32_t *flag, int32_t *first, void *stream) {
+    if (!flag || !first) return HB_ERR_BAD_ARG;
+    const int rc = hb_quick_dec_launch(qd, zc, nc, cols_dev, C, chunk_lo, chunk_hi, coeffs_dev, stream);
+    if (rc) return rc;
+    return hb_quick_dec_verdict(qd, flag, first);
 }
 
 void hb_quick_dec_destroy(hb_quick_dec *qd) { HB_API_GUARD((qd ? qd->ctx : nullptr));
@@ -1529,6 +1580,8 @@ void hb_quick_dec_destroy(hb_quick_dec *qd) { HB_API_GUARD((qd ? qd->ctx : nullp
     if (qd->buf) (void)hipFree(qd->buf);
     if (qd->status) (void)hipFree(qd->status);
     if (qd->res_host) (void)hipHostFree(qd->res_host);
+    if (qd->built) (void)hipEventDestroy(qd->built);
+    if (qd->launched) (void)hipEventDestroy(qd->launched);
     point_table_unref(qd->pt);
     delete qd;
 }

@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from ._capi import HB_DEC_DISAGREE, HB_DEC_DONE, HB_DEC_UNSUPPORTED, HB_ERR_MISMATCH, HB_ERR_UNSUPPORTED, HB_OK, Context, _marshal, np_ptr
+from ._capi import HB_DEC_DISAGREE, HB_DEC_DONE, HB_DEC_OPT_BESIDE, HB_DEC_OPT_DEFER, HB_DEC_PENDING, HB_DEC_UNSUPPORTED, HB_ERR_MISMATCH, HB_ERR_UNSUPPORTED, HB_OK, Context, _marshal, np_ptr
 
 
 def wb_decode_batch(x, k, rows, modulus):
@@ -352,8 +352,16 @@ class _CDec:
         self._zptr = np_ptr(self._zbuf)
         self._cnt = ctypes.c_int32(0)
         self._state, self._first = ctypes.c_int32(0), ctypes.c_int32(0)
+        self._options = 0
 
-    def begin(self, cols, c, n_coef, out, excluded):
+    def settle(self):
+        """wait for the verdict of the launch the quorum's arrival enqueued (deferred rounds): -> the state it leads to"""
+        return self.ctx.lib.hb_dec_settle(self.h)
+
+    def begin(self, cols, c, n_coef, out, excluded, options=0):
+        if options != self._options:
+            self.ctx.check(self.ctx.lib.hb_dec_options(self.h, options), "hb_dec_options")
+            self._options = options
         ex = np.array(sorted(excluded), dtype=np.int32) if excluded else None
         rc = self.ctx.lib.hb_dec_begin(self.h, self.ctx.ptr(cols), c, n_coef, self.ctx.ptr(out), np_ptr(ex) if ex is not None else None,
                                        len(excluded) if excluded else 0, self.ctx.stream())
@@ -435,6 +443,8 @@ class DeviceIncrementalDecoder:
     # state with an immutable initial value lives on the class until an instance changes it (a decoder is made per open and per round:
     # its constructor is on the path of every open)
     _ch = None                 # address of the hb_dec that runs this round's optimistic phase (None: the Python state machine below)
+    _pending = False           # defer_verdict: the quorum's launch is enqueued, its verdict not read yet (_settle)
+    _late = None               # ... and the senders announced since, in order
     _cdec = None
     _fetch1 = None
     _z_epoch = 0               # bumps whenever senders LEAVE the arrival list (between bumps it only grows at the end)
@@ -463,12 +473,18 @@ class DeviceIncrementalDecoder:
     quick_launches = 0         # plan-free interpolate-and-check launches (diagnostic)
 
     def __init__(self, modulus, n, t, degree=None, batch_size=1, use_omega_powers=False, confirmed_errors=None, device=None, robust="gao",
-                 columns=None, want="all"):
+                 columns=None, want="all", defer_verdict=False, stream_busy=False):
         """columns: an (n, batch_size, limbs) party-major tensor the transport receives into (row j = what party j sent); a column that
         has landed there is announced with add(j) -- no copy.  Without it the decoder keeps a buffer of its own, `slot(j)` is row j of it,
         and add(j, column) copies.
         want: "all" -- get_results() yields every coefficient, (C, degree+1, limbs); "constant" -- only the constant terms are needed
-        (what R1 forwards, batch_reconstruction.py:194): a decoder that finishes on its optimistic step then yields (C, 1, limbs)."""
+        (what R1 forwards, batch_reconstruction.py:194): a decoder that finishes on its optimistic step then yields (C, 1, limbs).
+        defer_verdict: the add() that completes the quorum enqueues decode + validate and returns; `pending()` is True until `done()` or
+        `get_results()` (or the next `add`) waits for the verdict.  The reference's coroutine subscribes to both rounds up front
+        (batch_reconstruction.py:158-176): with this, the next round's decoder is made -- and its first columns announced -- while this
+        round's launch runs.  Same results, same decisions; only where the host waits moves.
+        stream_busy: the caller's stream has work enqueued that this round's columns do not wait for (the open's encode; the previous
+        round's launch): what depends on the first degree+1 arrivals is built on a stream of the decoder's own, beside it."""
         if robust not in ("gao", "wb"):
             raise ValueError("robust must be 'gao' or 'wb'")
         self.ctx = ctx = Context.get(modulus, device)
@@ -511,6 +527,8 @@ class DeviceIncrementalDecoder:
         self._confirmed_errors = set() if confirmed_errors is None else confirmed_errors
         self._avl = set()               # senders counted (reference: _available_points); a property while the C decoder counts them
         self._zl = []                   # ... in arrival order (reference: _z)
+        self._defer = bool(defer_verdict)
+        self._options = (HB_DEC_OPT_DEFER if defer_verdict else 0) | (HB_DEC_OPT_BESIDE if stream_busy else 0)
         self._fast = ctx.n_limbs == 4 and (self.degree + 1) >= 4 and not os.environ.get("HB_NO_QUICK")   # cleared at the first UNSUPPORTED
         if self._fast:
             self._c_begin()
@@ -536,7 +554,7 @@ class DeviceIncrementalDecoder:
         n_coef = self.degree + 1 if self._want_all else 1
         out = self.ctx.empty(self.batch_size * n_coef)
         excluded = [i for i in self._confirmed_errors if 0 <= i < self.n]
-        if not cd.begin(self._cols, self.batch_size, n_coef, out, excluded):
+        if not cd.begin(self._cols, self.batch_size, n_coef, out, excluded, self._options):
             idle.append(cd)                  # this shape (nothing to compare, too many coefficients, ...): the Python path; the object serves others
             return
         self._cdec, self._ch, self._cout, self._ckey = cd, cd.addr, out, key
@@ -574,6 +592,12 @@ class DeviceIncrementalDecoder:
         """hb_dec_arrived1 left HB_DEC_COLLECTING at the arrival of `idx` (or failed: state < 0)"""
         if state < 0:
             self.ctx.check(-state, "hb_dec_arrived1")
+        if state == HB_DEC_PENDING:
+            if self._pending:
+                self._late.append(idx)           # announced while the verdict is out: counted once it is in (if the round goes on)
+            else:
+                self._pending, self._late = True, []
+            return
         d = self.degree + 1
         if state == HB_DEC_DONE:
             # (the hb_dec stays with this object until it goes away: its arrival list is only fetched if somebody asks for _z)
@@ -624,6 +648,8 @@ class DeviceIncrementalDecoder:
     def accepts(self, idx):
         """would add(idx) count this sender's column?  (not once the decoder is done, nor a sender already counted or confirmed in error:
         reference reed_solomon.py:369-372) -- a transport that receives in place asks BEFORE it writes into slot(idx)"""
+        if self._pending and idx in self._late:
+            return False
         return self._result is None and idx not in self._confirmed_errors and idx not in self._available_points
 
     # -- kernels ---------------------------------------------------------------------------------
@@ -780,6 +806,8 @@ class DeviceIncrementalDecoder:
         try:
             self._return_probe()
             if self._cdec is not None:
+                if self._pending:
+                    self._cdec.settle()          # (the launch writes this round's result tensor: it must have ended before the tensor goes)
                 self._leave_c(fetch=False)
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
@@ -1256,10 +1284,29 @@ class DeviceIncrementalDecoder:
                 break
         self._z, self._available_points = saved_z, saved_av
 
+    def pending(self):
+        """defer_verdict: True while the quorum's launch is enqueued and nobody has waited for its verdict"""
+        return self._pending
+
+    def _settle(self):
+        """wait for the pending verdict and act on it as the add() that completed the quorum would have; the senders announced meanwhile
+        follow in order (an agreeing verdict ends the round: they are ignored, as the reference ignores arrivals after done)"""
+        self._pending = False
+        late, self._late = self._late, None
+        self._c_event(self._cdec.settle(), None)
+        for idx in late:
+            if self._result is not None:
+                break
+            self.add(idx)
+
     def done(self):
+        if self._pending:
+            self._settle()
         return self._result is not None
 
     def get_results(self):
+        if self._pending:
+            self._settle()
         if self._result is not None:
             return self._result, self._confirmed_errors
         return None, None

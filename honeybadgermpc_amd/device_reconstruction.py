@@ -101,10 +101,13 @@ async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_
     for dest in range(n):
         send(dest, ("R1", wire.tensor_to_wire(encoded[dest])))
 
+    # both rounds' decoders exist before the first message is looked at, as both rounds are subscribed above (reference :158-176): R2's
+    # constructor (a result tensor, a pooled hb_dec begun) is off the path between R1's verdict and R2's first column
+    dec_r1, dec_r2 = make_decoder("constant"), make_decoder()
     recons_r2 = None
     try:
         # R1 only forwards the constant terms (batch_reconstruction.py:194): the optimistic step computes nothing else
-        recons_r2 = await _incremental_decode_device(data_r1, lambda: make_decoder("constant"), ctx.tdev)
+        recons_r2 = await _incremental_decode_device(data_r1, lambda: dec_r1, ctx.tdev)
     except asyncio.CancelledError:
         # the reference falls through here with recons_r2 unbound (batch_reconstruction.py:178-183); cancelling the
         # open must cancel it: clean up and let the cancellation propagate
@@ -122,7 +125,7 @@ async def batch_reconstruct_device(shares, p, t, n, myid, send, recv, use_omega_
 
     recons_p = None
     try:
-        recons_p = await _incremental_decode_device(data_r2, make_decoder, ctx.tdev)
+        recons_p = await _incremental_decode_device(data_r2, lambda: dec_r2, ctx.tdev)
     except asyncio.CancelledError:
         cancel_all()
         raise

@@ -152,6 +152,14 @@ int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec
 int hb_quick_dec_arrivals(hb_quick_dec *qd, const int32_t *z, int d, int nc, int n_coef, void *stream);
 int hb_quick_dec_decide(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
                         uint64_t *coeffs_dev, int32_t *flag, int32_t *first, void *stream);
+/* hb_quick_dec_decide in its two halves: _launch enqueues (the compared senders' rows, decode + validate) and returns, _verdict waits for
+ * the last launch's verdict.  Between the two the calling thread is free (the next round's decoder, the next messages). */
+int hb_quick_dec_launch(hb_quick_dec *qd, const int32_t *zc, int nc, const uint64_t *cols_dev, int64_t C, int64_t chunk_lo, int64_t chunk_hi,
+                        uint64_t *coeffs_dev, void *stream);
+int hb_quick_dec_verdict(hb_quick_dec *qd, int32_t *flag, int32_t *first);
+/* on: hb_quick_dec_arrivals enqueues its build on a stream of the decoder's own (the caller's stream is busy with something the build does
+ * not depend on -- it reads no column) and the next launch waits for it; off (default): in order on the caller's stream */
+int hb_quick_dec_beside(hb_quick_dec *qd, int on);
 void hb_quick_dec_destroy(hb_quick_dec *qd);
 
 /* ---- IncrementalDecoder's optimistic phase as an object (hb_dec.hip) ------------------------------------------------------------
@@ -174,6 +182,7 @@ void hb_quick_dec_destroy(hb_quick_dec *qd);
                                  hb_dec_arrivals_list; with n_coef = degree + 1 the refuted guess is in coeffs_dev and hb_dec_verdict
                                  gives the first disagreeing chunk */
 #define HB_DEC_UNSUPPORTED 3  /* found at the (degree + 1)-th arrival: decode the arrival list another way */
+#define HB_DEC_PENDING 4      /* only with HB_DEC_OPT_DEFER: decode + validate is enqueued, its verdict not read yet (hb_dec_settle) */
 typedef struct hb_dec hb_dec;
 int hb_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, int degree, int max_errors, hb_dec **out, void *stream);
 int hb_dec_begin(hb_dec *dec, const uint64_t *cols_dev, int64_t C, int n_coef, uint64_t *coeffs_dev, const int32_t *excluded, int n_excluded,
@@ -181,6 +190,22 @@ int hb_dec_begin(hb_dec *dec, const uint64_t *cols_dev, int64_t C, int n_coef, u
 /* one arrival: returns the state (HB_DEC_*) after it, or -(hb_status) on an error.  A sender already counted or excluded is ignored;
  * so is every arrival once the state has left HB_DEC_COLLECTING.  The call that completes the quorum returns when the verdict is in. */
 int hb_dec_arrived1(hb_dec *dec, int32_t idx);
+/* Options of the rounds to come (they hold across hb_dec_begin):
+ *   HB_DEC_OPT_DEFER   the arrival that completes the quorum enqueues decode + validate and returns HB_DEC_PENDING instead of waiting;
+ *                      hb_dec_settle waits for that verdict and returns the state it leads to (HB_DEC_DONE / HB_DEC_DISAGREE; any other
+ *                      state as it is; -(hb_status) on an error).  While the state is HB_DEC_PENDING further arrivals are NOT counted
+ *                      (hb_dec_arrived1 returns HB_DEC_PENDING): the caller keeps them and, after a HB_DEC_DISAGREE, hands them to its
+ *                      robust phase in order.  What batch_reconstruct gains: its two rounds are subscribed up front
+ *                      (batch_reconstruction.py:158-176), so the next round's decoder can be made, and its first messages taken, while
+ *                      this round's launch runs.
+ *   HB_DEC_OPT_BESIDE  the caller's stream is busy while this round's columns come in (the open's encode; the previous round's launch):
+ *                      what depends on the first degree + 1 arrivals is built on a stream of the decoder's own, beside that work, and
+ *                      the decode launch waits for it (hb_quick_dec_beside).  On an idle stream the dependency between two queues costs
+ *                      more than the build: leave it off there. */
+#define HB_DEC_OPT_DEFER 1
+#define HB_DEC_OPT_BESIDE 2
+int hb_dec_options(hb_dec *dec, int flags);
+int hb_dec_settle(hb_dec *dec);
 /* a burst of arrivals in order; stops at the first one that changes the state (*consumed = how many were taken) */
 int hb_dec_arrived(hb_dec *dec, const int32_t *idx, int count, int32_t *consumed, int32_t *state);
 int hb_dec_verdict(const hb_dec *dec, int32_t *state, int32_t *first_bad);

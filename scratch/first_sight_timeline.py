@@ -57,17 +57,41 @@ op = BatchOpen(P, n, t, max_shares=B, device=0, use_omega_powers=OMEGA)
 r1_out = ctx.empty(n * C)
 r1v, r2v = r1_cols.view(n, C, 4), r2_cols.view(n, C, 4)
 rng = np.random.Generator(np.random.PCG64(77))
+MODE = next((a for a in sys.argv[1:] if a in ("wait", "defer", "early")), "defer")
 def first_sight(o1, o2):
     op.r1_encode(shares0, out=r1_out)
-    outs = []
-    for order_, cols_, want_ in ((o1, r1v, "constant"), (o2, r2v, "all")):
-        dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, device=0, columns=cols_, want=want_, use_omega_powers=OMEGA)
-        for idx in order_:
-            dec.add(idx)
-            if dec.done():
+    if MODE == "wait":             # rounds 4-5: every quorum's add() waits for its verdict
+        outs = []
+        for order_, cols_, want_ in ((o1, r1v, "constant"), (o2, r2v, "all")):
+            dec = DeviceIncrementalDecoder(P, n, t, batch_size=C, device=0, columns=cols_, want=want_, use_omega_powers=OMEGA)
+            for idx in order_:
+                dec.add(idx)
+                if dec.done():
+                    break
+            outs.append(dec.get_results()[0])
+        return outs
+    mk = lambda cols_, want_, busy_: DeviceIncrementalDecoder(P, n, t, batch_size=C, device=0, columns=cols_, want=want_, use_omega_powers=OMEGA, defer_verdict=True, stream_busy=busy_)
+    dec1, dec2 = mk(r1v, "constant", "--r1-in-order" not in sys.argv), None
+    for idx in o1:
+        dec1.add(idx)
+        if dec1.pending():
+            dec2 = mk(r2v, "all", MODE == "early")
+            if MODE == "early":
+                for j in o2:
+                    dec2.add(j)
+                    if dec2.pending():
+                        break
+        if dec1.done():
+            break
+    m1 = dec1.get_results()[0]
+    if dec2 is None:
+        dec2 = mk(r2v, "all", False)
+    if not dec2.pending():
+        for idx in o2:
+            dec2.add(idx)
+            if dec2.done():
                 break
-        outs.append(dec.get_results()[0])
-    return outs
+    return [m1, dec2.get_results()[0]]
 orders = [(rng.permutation(n).tolist(), rng.permutation(n).tolist()) for _ in range(120)]
 for o in orders[:10]:
     first_sight(*o)
@@ -79,5 +103,17 @@ for o in orders[10:]:
     res = first_sight(*o)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 110
-print(f"first-sight open: {dt*1e6:.1f} us = {B/dt/1e9:.2f} G shares/s")
+print(f"first-sight open [{MODE}]: {dt*1e6:.1f} us = {B/dt/1e9:.2f} G shares/s")
 assert torch.equal(res[1].reshape(-1, 4)[:B], secrets)
+if "--timing" in sys.argv:          # the timing build (scratch/build_variant2.sh timing ... -DHB_MM8_TIMING): phases of the LAST k_mm8f launch (R2)
+    import ctypes
+    fs = ctx.lib.hb_debug_fs_timing
+    fs.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = np.zeros(256 * 8 * 8, dtype=np.uint64)
+    assert fs(buf.ctypes.data, buf.size) == 0
+    tt = buf.reshape(256 * 8, 8).astype(np.float64)
+    names = ["prologue+unit 0 scaled", "barrier wait", "scale next unit", "MFMA half 0", "park half 0", "MFMA half 1", "words+reduce+store/compare", "lgkm wait before barrier"]
+    tot = tt.sum(axis=1)
+    print(f"R2 launch of the last open: per-wave total ticks mean {tot.mean():.0f} min {tot.min():.0f} max {tot.max():.0f}")
+    for k, nm in enumerate(names):
+        print(f"  {nm:28s} {tt[:, k].mean():9.0f}  (min {tt[:, k].min():.0f}, max {tt[:, k].max():.0f})")

@@ -258,3 +258,130 @@ def test_device_decoder_on_the_c_object_equals_the_host_mirror(n, t, omega, want
         assert [list(r) + [0] * (d - len(r)) for r in res_h] == polys
         del dev
     torch.cuda.synchronize()
+
+
+PENDING = 4
+OPT_DEFER, OPT_BESIDE = 1, 2
+
+
+@pytest.mark.parametrize("beside", [False, True])
+def test_dec_object_with_the_verdict_deferred(beside):
+    """HB_DEC_OPT_DEFER (reference reed_solomon.py:302-330 unchanged in what is decided): the quorum's arrival returns HB_DEC_PENDING with decode +
+    validate enqueued, arrivals announced meanwhile are not counted, hb_dec_settle gives the state the waiting call would have returned; with
+    HB_DEC_OPT_BESIDE the first half is built on the decoder's own stream.  Bad flags and options while a verdict is out are refused."""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+
+    ctx = Context.get(P)
+    lib = ctx.lib
+    rnd = random.Random(12 + beside)
+    n, t, c = 64, 21, 70
+    d = t + 1
+    x = list(range(1, n + 1))
+    polys = _structured_polys(rnd, d, c, P)
+    enc = oracle.vandermonde_batch_evaluate(x, polys, P)
+    dec = _Dec(ctx, x, t, t)
+    assert dec.rc == 0
+    assert lib.hb_dec_options(dec.h, 8) != 0
+    assert lib.hb_dec_options(dec.h, OPT_DEFER | (OPT_BESIDE if beside else 0)) == 0
+    for liar_at in (None, d + 3):
+        cols_int = [[enc[k][j] for k in range(c)] for j in range(n)]
+        order = list(range(n))
+        rnd.shuffle(order)
+        if liar_at is not None:
+            for m in (7, 31):
+                cols_int[order[liar_at]][m] = (cols_int[order[liar_at]][m] + 5) % P
+        buf = ctx.upload_ints([v for col in cols_int for v in col]).view(n, c, 4)
+        assert dec.begin(buf, c, d) == 0
+        need = d + t
+        for k, idx in enumerate(order[:need]):
+            st = dec.add(idx)
+            assert st == (PENDING if k == need - 1 else COLLECTING), (k, st)
+        assert lib.hb_dec_options(dec.h, 0) != 0                          # a verdict is out
+        assert dec.add(order[need]) == PENDING and dec.arrivals() == order[:need]      # announced meanwhile: not counted
+        st = lib.hb_dec_settle(dec.h)
+        assert st == (DONE if liar_at is None else DISAGREE)
+        assert lib.hb_dec_settle(dec.h) == st                             # (settling twice: the state as it is)
+        if liar_at is None:
+            torch.cuda.synchronize()
+            assert ctx.download_ints(dec.out) == [v for row in polys for v in row]
+        else:
+            assert dec.verdict() == (DISAGREE, 7)
+    # a round abandoned with its verdict out: the next round's build waits for that launch by itself
+    buf = ctx.upload_ints([v for col in [[enc[k][j] for k in range(c)] for j in range(n)] for v in col]).view(n, c, 4)
+    assert dec.begin(buf, c, d) == 0
+    for idx in range(d + t):
+        dec.add(idx)
+    assert dec.begin(buf, c, d) == 0
+    for k, idx in enumerate(reversed(range(n))):
+        if dec.add(idx) == PENDING:
+            break
+    assert lib.hb_dec_settle(dec.h) == DONE
+    torch.cuda.synchronize()
+    assert ctx.download_ints(dec.out) == [v for row in polys for v in row]
+    dec.close()
+
+
+@pytest.mark.parametrize("n,t,omega", [(64, 21, False), (16, 5, True)])
+def test_device_decoder_with_deferred_verdicts_equals_the_host_mirror(n, t, omega):
+    """DeviceIncrementalDecoder(defer_verdict=True, stream_busy=True): columns announced while the verdict is out are replayed in order once it
+    is in -- same arrival list, same errors, same results as the host mirror of the reference's class fed the same messages"""
+    import torch
+
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import DeviceIncrementalDecoder
+    from honeybadgermpc_amd.field import GF
+    from honeybadgermpc_amd.polynomial import EvalPoint
+    from honeybadgermpc_amd.reed_solomon import DecoderFactory, EncoderFactory, IncrementalDecoder, RobustDecoderFactory
+
+    ctx = Context.get(P)
+    rnd = random.Random(n * 17 + t)
+    d, c = t + 1, 60
+    point = EvalPoint(GF(P), n, use_omega_powers=omega)
+    x = [point(i).value for i in range(n)]
+    polys = _structured_polys(rnd, d, c, P)
+    enc = oracle.vandermonde_batch_evaluate(x, polys, P)
+    for scenario in ("clean", "liar_compared", "liar_first", "two_liars"):
+        cols_int = [[enc[k][j] for k in range(c)] for j in range(n)]
+        order = list(range(n))
+        rnd.shuffle(order)
+        liars = {"clean": [], "liar_compared": [order[d + 2]], "liar_first": [order[1]], "two_liars": [order[0], order[d + t + 1]]}[scenario]
+        for liar in liars:
+            for m in rnd.sample(range(c), 4):
+                cols_int[liar][m] = (cols_int[liar][m] + 1 + rnd.randrange(P - 1)) % P
+        buf = ctx.upload_ints([v for col in cols_int for v in col]).view(n, c, 4)
+        dev = DeviceIncrementalDecoder(P, n, t, batch_size=c, use_omega_powers=omega, columns=buf, defer_verdict=True, stream_busy=True)
+        assert dev._ch is not None, "the C decoder was not engaged"
+        host = IncrementalDecoder(EncoderFactory.get(point), DecoderFactory.get(point), RobustDecoderFactory.get(t, point), degree=t, batch_size=c, max_errors=t)
+        fed = 0
+        for idx in order:
+            dev.add(idx)
+            fed += 1
+            if dev.pending():
+                # three more messages come in while the launch runs; a duplicate among them must not be taken twice
+                late = order[fed:fed + 3]
+                for j in late:
+                    assert dev.accepts(j)
+                    dev.add(j)
+                assert not dev.accepts(late[0]) and not dev.accepts(order[0])
+                assert dev.pending()
+                break
+        for idx in order:                          # the host mirror sees the same messages in the same order
+            host.add(idx, cols_int[idx])
+            if host.done():
+                break
+        done_now = dev.done()                      # waits for the verdict, replays the late columns
+        for idx in order[fed + 3:]:
+            if dev.done():
+                break
+            dev.add(idx)
+        assert dev.done() and host.done(), scenario
+        res_d, errs_d = dev.get_results()
+        res_h, errs_h = host.get_results()
+        assert errs_d == errs_h, (scenario, errs_d, errs_h)
+        assert ctx.download_ints(res_d.reshape(-1, 4)) == [v for row in res_h for v in list(row) + [0] * (d - len(row))], scenario
+        if scenario == "clean":
+            assert done_now
+        del dev
+    torch.cuda.synchronize()
