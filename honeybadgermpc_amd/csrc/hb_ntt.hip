@@ -305,7 +305,14 @@ __global__ void __launch_bounds__(256) k_ntt_lds(const FpParams<NL> P, const uin
                 if (diff) atomicOr(mismatch, 1);
             }
         } else {
-            if (e < out_count) store_digits<NL, NW>(out + e * NW, dg);
+            // party-major outputs (consecutive lanes = consecutive polynomials: an encode's rows) leave with the streaming hint, as k_mm8's do
+            // (hb_mfma.hip): config 3 at omega points 230 -> 222 us an open, config 2 86.3 -> 84.0 (round 6)
+            if (e < out_count) {
+                uint32_t w_[NW];
+                pack<NL, NW>(w_, dg);
+                if constexpr (NW % 4 == 0) { if (out_poly_fast) store_words_nt<NW>(out + e * NW, w_); else store_words<NW>(out + e * NW, w_); }
+                else store_words<NW>(out + e * NW, w_);
+            }
         }
     }
 }
