@@ -113,6 +113,7 @@ DEBUG_SYMBOLS = {
     "hb_debug_mm8_create": (_i, [_vp, _vp, _i, _i, _pp]),
     "hb_debug_mm8_apply": (_i, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "hb_debug_occupancy": (_i, [_i, _i, _vp, _vp]),
+    "hb_debug_reload_env": (None, []),
 }
 
 _lib = None

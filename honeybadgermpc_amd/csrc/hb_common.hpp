@@ -103,6 +103,38 @@ struct PrescaleParams {
     uint32_t m0, m1;
 };
 }
+// Environment hooks (diagnostics and A/B runs; DESIGN section 7 says which profile or test cites each): read ONCE, at the first question any
+// of them is asked, not on every call of the data path (rounds 1-5: 28 getenv calls, two of them per hb_wb_decode).  env_hook returns the
+// value (nullptr: unset) as it was then; hb_debug_reload_env() (include/hbmpc_hip_debug.h) reads them again -- the tests that flip a hook
+// inside one process call it.
+namespace hb {
+enum EnvHook {
+    ENV_CACHE_CAP,
+    ENV_GAO_PAIR,
+    ENV_MM8W_FLAT,
+    ENV_MM8W_RQ,
+    ENV_MM8W_TILE16,
+    ENV_MM8_NO_SKIP,
+    ENV_NO_EVAL_FEW,
+    ENV_NO_FUSED_SMALL,
+    ENV_NO_FUSED_VALIDATE,
+    ENV_NO_MFMA,
+    ENV_NO_MFMA_DECODE,
+    ENV_NO_MFMA_WIDE,
+    ENV_NO_NARROW_FAST,
+    ENV_NO_QUICK,
+    ENV_NO_QUICK_PLAN,
+    ENV_NTT_STAGE_LOOP,
+    ENV_PROBE_WGS,
+    ENV_QUICK_NO_CAND,
+    ENV_UPLOAD_MODE,
+    ENV_WB_NO_GAO,
+    ENV_WB_NO_UNIFORM,
+    ENV_COUNT
+};
+const char *env_hook(EnvHook h);
+void env_reload();
+}
 struct hb_ctx {
     int device;
     int n_limbs;        // 1 or 4 (uint64 limbs per element at the ABI)

@@ -11,6 +11,9 @@
 //   chunk_data / transpose / flatten  utils/misc.py:33-73                           -> hb_view strides, k_copy_view
 #include <algorithm>
 
+#include <mutex>
+#include <string>
+
 #include "hb_common.hpp"
 
 using namespace hb;
@@ -438,7 +441,7 @@ int upload_table(hb_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes,
     // HB_UPLOAD_MODE=memcpy: the round-2 defect's upload path (copy engine straight into the table, stream synchronise), kept
     // ONLY so that the stale-read experiment can be repeated (tests/test_gpu_full_size.py::test_table_recycling_first_launch,
     // DESIGN section 9); never set in production
-    static const int legacy = [] { const char *e = getenv("HB_UPLOAD_MODE"); return e && !strcmp(e, "memcpy") ? 1 : 0; }();
+    static const int legacy = [] { const char *e = env_hook(ENV_UPLOAD_MODE); return e && !strcmp(e, "memcpy") ? 1 : 0; }();
     if (legacy) {
         hipError_t e = hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
@@ -505,6 +508,33 @@ __global__ void __launch_bounds__(128) k_eval_few(const FpParams<NL> P, const ui
     if (threadIdx.x == 0) store_digits<NL, NW>(out + ((size_t)c * n + i) * NW, r);
 }
 
+
+// ---- environment hooks: one snapshot ---------------------------------------------------------------------------
+namespace hb {
+static const char *const ENV_NAMES[ENV_COUNT] = {"HB_CACHE_CAP", "HB_GAO_PAIR", "HB_MM8W_FLAT", "HB_MM8W_RQ", "HB_MM8W_TILE16", "HB_MM8_NO_SKIP", "HB_NO_EVAL_FEW", "HB_NO_FUSED_SMALL", "HB_NO_FUSED_VALIDATE", "HB_NO_MFMA", "HB_NO_MFMA_DECODE", "HB_NO_MFMA_WIDE", "HB_NO_NARROW_FAST", "HB_NO_QUICK", "HB_NO_QUICK_PLAN", "HB_NTT_STAGE_LOOP", "HB_PROBE_WGS", "HB_QUICK_NO_CAND", "HB_UPLOAD_MODE", "HB_WB_NO_GAO", "HB_WB_NO_UNIFORM"};
+static std::string g_env_val[ENV_COUNT];
+static bool g_env_set[ENV_COUNT];
+static std::once_flag g_env_once;
+static std::mutex g_env_mu;
+static void env_read() {
+    for (int i = 0; i < ENV_COUNT; i++) {
+        const char *e = ::getenv(ENV_NAMES[i]);
+        g_env_set[i] = e != nullptr;
+        g_env_val[i] = e ? e : "";
+    }
+}
+const char *env_hook(EnvHook h) {
+    std::call_once(g_env_once, env_read);
+    return g_env_set[h] ? g_env_val[h].c_str() : nullptr;
+}
+void env_reload() {
+    std::call_once(g_env_once, env_read);
+    std::lock_guard<std::mutex> lk(g_env_mu);
+    env_read();
+}
+}  // namespace hb
+extern "C" void hb_debug_reload_env() { hb::env_reload(); }
+
 extern "C" {
 
 int hb_version(void) { return 100; }
@@ -531,7 +561,7 @@ int hb_ctx_create(hb_ctx **out, const uint64_t *p_limbs, int n_limbs, int device
     memset(ctx->p_limbs, 0, sizeof ctx->p_limbs);
     memcpy(ctx->p_limbs, p_limbs, (size_t)n_limbs * 8);
     if (n_limbs == 4) make_params<9>(ctx->pw, p_limbs, 4); else make_params<3>(ctx->pn, p_limbs, 1);
-    if (const char *e = getenv("HB_CACHE_CAP")) { long v = atol(e); if (v >= 1) ctx->cache_cap = (size_t)v; }
+    if (const char *e = env_hook(ENV_CACHE_CAP)) { long v = atol(e); if (v >= 1) ctx->cache_cap = (size_t)v; }
     ctx->flag_dev = nullptr;
     if (hipMalloc(&ctx->flag_dev, 64 * sizeof(int32_t)) != hipSuccess) { delete ctx; return HB_ERR_HIP; }
     (void)hipMemset(ctx->flag_dev, 0, 64 * sizeof(int32_t));
@@ -763,7 +793,7 @@ const Mm8wMatrix *matrix_wide(hb_ctx *ctx, const hb_matrix *cm, hipStream_t s) {
     hb_matrix *m = const_cast<hb_matrix *>(cm);
     if (m->wide_tried) return m->wide;
     m->wide_tried = true;
-    if (ctx->n_limbs != 4 || getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE")) return nullptr;
+    if (ctx->n_limbs != 4 || env_hook(ENV_NO_MFMA) || env_hook(ENV_NO_MFMA_WIDE)) return nullptr;
     std::vector<uint64_t> host((size_t)m->n_out * m->n_in * 4);
     if (hb_matrix_to_host(ctx, m, host.data(), (void *)s) != HB_OK) return nullptr;
     Mm8wMatrix *w = nullptr;
@@ -875,7 +905,7 @@ int hb_vandermonde_batch_evaluate(hb_ctx *ctx, const uint64_t *x_host, int n, co
     cache_trim(ctx);
     hipStream_t s = (hipStream_t)stream;
     if (d == 0) { HB_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)C * n * ctx->elem_words() * 4, s)); return HB_OK; }
-    if (C <= 8 && C * n <= 4096 && d >= 8 && !getenv("HB_NO_EVAL_FEW")) {
+    if (C <= 8 && C * n <= 4096 && d >= 8 && !env_hook(ENV_NO_EVAL_FEW)) {
         uint32_t *xd = nullptr;
         const int rcx = points_on_device(ctx, x_host, n, &xd, s); if (rcx) return rcx;
         if (ctx->n_limbs == 4) k_eval_few<9, 8><<<(unsigned)(C * n), 128, 0, s>>>(ctx->pw, xd, n, (const uint32_t *)polys_dev, d, (uint32_t *)out_dev);

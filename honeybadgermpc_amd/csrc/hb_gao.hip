@@ -946,7 +946,7 @@ int hb::gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const u
     // point sets of at most 64 points, batches that fill the chip several times over: two codewords a wave (k_gao_pair: 19 % fewer vector
     // instructions a codeword, 11 % less time at n = 64; a wave's own run is 1.4 times longer, so a batch that leaves SIMDs idle anyway keeps
     // one codeword a wave).  HB_GAO_PAIR=1 / 0 forces the choice (same values either way: tests/test_gpu_parity.py)
-    const char *pair_env = getenv("HB_GAO_PAIR");
+    const char *pair_env = env_hook(ENV_GAO_PAIR);
     const bool pair = npts <= 64 && C >= 2 && (pair_env ? pair_env[0] == '1' : C >= 12288);
     const size_t pair_lds = (size_t)(2 * (2 * (npts + 1) + 2 * (npts - (npts + k) / 2 + 3) + 6) + 2) * NLr * 4;
     // side record per codeword (cs, lc(V), dq, df) between the Euclid kernel and the finishing one

@@ -553,7 +553,7 @@ void mm8_shared_free(hb_ctx *ctx) {
 // 2^126 or more, more than 32 terms, a modulus outside [2^254, 2^256), or tables that exceed the LDS budget.
 int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t s, const int32_t *rows, int n_rows) {
     *out = nullptr;
-    if (getenv("HB_NO_MFMA")) return HB_ERR_UNSUPPORTED;
+    if (env_hook(ENV_NO_MFMA)) return HB_ERR_UNSUPPORTED;
     if (ctx->n_limbs != 4 || f->n_in < 1 || f->n_in > 32 || f->n_out < 1) return HB_ERR_UNSUPPORTED;
     if ((ctx->p_limbs[3] >> 62) == 0) return HB_ERR_UNSUPPORTED;      // Barrett constants assume 2^254 <= p
     // rows != nullptr: the matrix made of rows[0 .. n_rows) of f (a compact check matrix)
@@ -585,7 +585,7 @@ int mm8_from_fast(hb_ctx *ctx, const FastMatrix *f, Mm8Matrix **out, hipStream_t
     }
 
     std::vector<int8_t> a((size_t)n_rt * nkb * 2 * 64 * 16, 0);
-    bool skip01 = nkb >= 2 && !getenv("HB_MM8_NO_SKIP");
+    bool skip01 = nkb >= 2 && !env_hook(ENV_MM8_NO_SKIP);
     std::vector<uint32_t> cr((size_t)n_rt * 16 * 16 + (size_t)MM8_FOLD_Q * 4, 0);
     memcpy(&cr[(size_t)n_rt * 16 * 16], foldtab.data(), foldtab.size());
     // rows beyond n_out: the bias pairs alone (their outputs are never stored)

@@ -664,7 +664,7 @@ static int fs_num_cus() {
 int fs_layout(hb_ctx *ctx, const PointTable *pt, int d, int nc, int n_coef, FsLayout *L) {
     if (ctx->n_limbs != 4 || !pt || !pt->usable || !pt->small) return HB_ERR_UNSUPPORTED;
     if (d < 4 || d > 22 || nc < 0 || nc > FS_MAXC || n_coef < 1 || n_coef > d) return HB_ERR_UNSUPPORTED;
-    if (getenv("HB_NO_MFMA") || getenv("HB_NO_FUSED_SMALL") || getenv("HB_NO_QUICK") || !prescale_params(ctx)) return HB_ERR_UNSUPPORTED;
+    if (env_hook(ENV_NO_MFMA) || env_hook(ENV_NO_FUSED_SMALL) || env_hook(ENV_NO_QUICK) || !prescale_params(ctx)) return HB_ERR_UNSUPPORTED;
     // 128 * (16 digits of at most 128 in each of d terms) must stay below the accumulator bias
     if ((int64_t)d * 16 * 128 * 128 > MM8_BIAS) return HB_ERR_UNSUPPORTED;
     std::vector<uint16_t> xs(pt->xs);

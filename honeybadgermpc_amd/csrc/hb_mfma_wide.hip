@@ -755,7 +755,7 @@ bool mm8w_shape(int n_rt, int nkb, int64_t n_tiles, int n_cus, int *tpw, int *nb
     int rqs[3] = {n_rt, 8, 4};
     // HB_MM8W_RQ=all: no row groups (every unit takes all row tiles of its chunk tiles) -- the traffic experiment of
     // profiles/r03_pmc_cfg5-shard_row_groups.txt; never set in production
-    static const bool rq_all = [] { const char *e = getenv("HB_MM8W_RQ"); return e && !strcmp(e, "all"); }();
+    static const bool rq_all = [] { const char *e = env_hook(ENV_MM8W_RQ); return e && !strcmp(e, "all"); }();
     if (rq_all) rqs[1] = rqs[2] = n_rt;
     for (int t = 1; t <= 4; t++) {
         if (mm8w_lds_bytes(n_rt, nkb, t, 1) > MM8W_LDS_LIMIT) break;
@@ -811,7 +811,7 @@ int mm8w_flat_part_off(int k, int busy_a, int busy_b, int bufsz) {
 // three passes -> a pass-time; two -> half the K-blocks a wave, their sums joined through LDS; one -> a quarter.
 // HB_MM8W_FLAT=0 / 1: never / whenever the shape qualifies (A-B runs: profiles/r06_mm8w_balanced_launch.txt).
 int mm8w_flat_slots(int n_rt, int nkb, int tile_rows, int64_t n_tiles, int n_cus, double unit_cost) {
-    static const int force = [] { const char *e = getenv("HB_MM8W_FLAT"); return e ? atoi(e) : -1; }();
+    static const int force = [] { const char *e = env_hook(ENV_MM8W_FLAT); return e ? atoi(e) : -1; }();
     if (force == 0 || tile_rows != 16 || n_rt < 4 || nkb < 8) return 0;
     const int64_t n_pass = n_tiles * n_rt;
     if (n_pass < 4 * (int64_t)n_cus) return 0;
@@ -877,7 +877,7 @@ int mm8w_tile_rows(int n_out, int nkb);
 // dimension beyond the LDS budget, HB_NO_MFMA / HB_NO_MFMA_WIDE set).
 int mm8w_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int n_in, Mm8wMatrix **out, hipStream_t s) {
     *out = nullptr;
-    if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE")) return HB_ERR_UNSUPPORTED;
+    if (env_hook(ENV_NO_MFMA) || env_hook(ENV_NO_MFMA_WIDE)) return HB_ERR_UNSUPPORTED;
     if (ctx->n_limbs != 4 || n_out < 1 || n_in < 1) return HB_ERR_UNSUPPORTED;
     if (!prescale_params(ctx)) return HB_ERR_UNSUPPORTED;              // 2^254 <= p < 2^256
     const int d = n_in, nkb = (d + 7) / 8;                                 // K-blocks of 8 terms
@@ -1069,7 +1069,7 @@ static int launch_mm8w_impl(hb_ctx *ctx, const Mm8wMatrix *m, const uint32_t *in
 
 int mm8w_tile_rows(int n_out, int nkb) {
     int tile_rows = 16;
-    if (!getenv("HB_MM8W_TILE16")) {
+    if (!env_hook(ENV_MM8W_TILE16)) {
         double best = 0.0;
         for (int tr = 16; tr >= 8; tr -= 4) {
             const double cost = (double)((n_out + tr - 1) / tr) * (228.0 * nkb + 160 + (tr / 4) * 490);

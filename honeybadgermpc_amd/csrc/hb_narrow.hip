@@ -170,7 +170,7 @@ struct Mv64Matrix {
 static inline uint64_t mulmod_u64(uint64_t a, uint64_t b, uint64_t p) { return (uint64_t)(((unsigned __int128)a * b) % p); }
 
 bool mv64_applies(const hb_ctx *ctx, int d) {
-    return ctx->n_limbs == 1 && ctx->p_limbs[0] >= 3 && d >= 1 && d <= MV64_DMAX && !getenv("HB_NO_NARROW_FAST");
+    return ctx->n_limbs == 1 && ctx->p_limbs[0] >= 3 && d >= 1 && d <= MV64_DMAX && !env_hook(ENV_NO_NARROW_FAST);
 }
 
 void mv64_free(Mv64Matrix *m) {

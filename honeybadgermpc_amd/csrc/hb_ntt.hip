@@ -543,7 +543,7 @@ int hb_fft_batch_evaluate(hb_ctx *ctx, const uint64_t *omega_host, int order, co
         return launch_ntt_lds(ctx, tw, n, (const uint32_t *)coeffs_dev, iv, INT64_MAX, d, k, (uint32_t *)out_dev, ov, INT64_MAX, nullptr, nullptr, C, s);
     }
     // large order: four steps over the LDS kernel (n = n1 n2, both factors at most 2048), one polynomial at a time
-    if (logn <= 22 && !getenv("HB_NTT_STAGE_LOOP")) {
+    if (logn <= 22 && !env_hook(ENV_NTT_STAGE_LOOP)) {
         const int l1 = (logn + 1) / 2, l2 = logn - l1, n1 = 1 << l1, n2 = 1 << l2;
         uint64_t w1[4] = {0, 0, 0, 0}, w2[4] = {0, 0, 0, 0};           // omega^n2 (order n1), omega^n1 (order n2)
         if (ctx->n_limbs == 4) { host_pow2<9, 8>(ctx->pw, omega_host, l2, w1); host_pow2<9, 8>(ctx->pw, omega_host, l1, w2); }

@@ -82,7 +82,7 @@ struct hb_open_plan {
 // the device-built images of the full-size kernel (q1, q2); failures leave the plan as it is
 static void build_quick_wide(hb_open_plan *pl, hipStream_t s) {
     hb_ctx *ctx = pl->ctx;
-    if (pl->q1 || getenv("HB_NO_QUICK_PLAN")) return;
+    if (pl->q1 || env_hook(ENV_NO_QUICK_PLAN)) return;
     QuickLayout a, b;
     const int n = pl->n, d = pl->d, n_check = pl->n_check;
     if (quick_layout(ctx, n, d, n_check, 1, &a) == HB_OK && quick_layout(ctx, n, d, n_check, d, &b) == HB_OK) {
@@ -102,7 +102,7 @@ static void build_quick_wide(hb_open_plan *pl, hipStream_t s) {
 // the device-built images of the small-entry kernel (fs1, fs2); failures leave the plan as it is
 static void build_fused_small(hb_open_plan *pl, hipStream_t s) {
     hb_ctx *ctx = pl->ctx;
-    if (pl->fs1 || getenv("HB_NO_QUICK_PLAN") || getenv("HB_NO_QUICK")) return;
+    if (pl->fs1 || env_hook(ENV_NO_QUICK_PLAN) || env_hook(ENV_NO_QUICK)) return;
     PointTable *pt = nullptr;
     FsLayout a, b;
     if (point_table(ctx, pl->x.data(), pl->n, &pt, s) == HB_OK && fs_layout(ctx, pt, pl->d, pl->n_check, 1, &a) == HB_OK &&
@@ -180,7 +180,7 @@ static int build_fused(hb_open_plan *pl, const uint64_t *x_host, hipStream_t s) 
 // does not take leave the plan as it is
 static int ensure_fused(hb_open_plan *pl, hipStream_t s) {
     pl->fused_pending = 0;
-    if (pl->q1 || pl->F1 || pl->d < 4 || pl->n < 4 || getenv("HB_NO_MFMA_DECODE")) return HB_OK;
+    if (pl->q1 || pl->F1 || pl->d < 4 || pl->n < 4 || env_hook(ENV_NO_MFMA_DECODE)) return HB_OK;
     hb_ctx *ctx = pl->ctx;
     const int L = ctx->n_limbs;
     if (!pl->Winv) {
@@ -254,7 +254,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         rc = HB_OK;
         if (pl->V8) {
             PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
-            rc = getenv("HB_NO_MFMA_DECODE") ? HB_ERR_UNSUPPORTED : mm8_from_fast(ctx, pl->Vinv, &pl->Vinv8, s);
+            rc = env_hook(ENV_NO_MFMA_DECODE) ? HB_ERR_UNSUPPORTED : mm8_from_fast(ctx, pl->Vinv, &pl->Vinv8, s);
             if (rc && rc != HB_ERR_UNSUPPORTED) goto done;
             rc = HB_OK;
             if (pl->Vinv8) PLAN_HIP(hipMalloc(&pl->scaled_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
@@ -265,7 +265,7 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     // [V^-1 rows ; V[zc] V^-1] once it has decoded twice -- ensure_fused; it beats pre-scale + decode + validating re-encode on
     // k_mm8 at every size: n = 64, t = 21: 0.127 against 0.200 ms for the two decodes, n = 8, t = 3: 0.170 against 0.180;
     // scratch/fused_vs_default.py.)
-    if (!pl->V8 && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE")) {
+    if (!pl->V8 && d >= 4 && n >= 4 && !env_hook(ENV_NO_MFMA_DECODE)) {
         std::vector<uint64_t> xz((size_t)d * L);
         for (int i = 0; i < d; i++) memcpy(&xz[(size_t)i * L], x_host + (size_t)z_host[i] * L, (size_t)L * 8);
         rc = hb_vand_inverse_create(ctx, xz.data(), d, &pl->Winv, stream); if (rc) goto done;
@@ -297,8 +297,8 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
     }
     // the fused matrices: built on the device right now where hb_quick.hip takes the shape; otherwise on the host when the plan decodes
     // for the third time (ensure_fused), or at once on request (set_option)
-    pl->fused_pending = ((pl->V8 || pl->Winv8) && d >= 4 && n >= 4 && !getenv("HB_NO_MFMA_DECODE") && !getenv("HB_NO_FUSED_VALIDATE") &&
-                         !getenv("HB_NO_MFMA_WIDE") && ctx->n_limbs == 4 && prescale_params(ctx)) ? 1 : 0;
+    pl->fused_pending = ((pl->V8 || pl->Winv8) && d >= 4 && n >= 4 && !env_hook(ENV_NO_MFMA_DECODE) && !env_hook(ENV_NO_FUSED_VALIDATE) &&
+                         !env_hook(ENV_NO_MFMA_WIDE) && ctx->n_limbs == 4 && prescale_params(ctx)) ? 1 : 0;
     PLAN_HIP(hipMalloc(&pl->mismatch_dev, sizeof(int32_t)));
     PLAN_HIP(hipMemsetAsync(pl->mismatch_dev, 0, sizeof(int32_t), s));
     if (pl->fused_pending) {

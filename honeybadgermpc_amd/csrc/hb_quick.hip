@@ -1150,7 +1150,7 @@ namespace hb {
 // image | row constants | (build scratch: w_j, prod_q (x_i - x_zq), N_j, canonical entries) | z as int32 | the row map
 int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L) {
     if (ctx->n_limbs != 4 || d < 4 || d > QUICK_MAX || nc < 0 || nc > QUICK_MAXC || n > 65535 || n_coef < 1 || n_coef > d) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: shape");
-    if (getenv("HB_NO_MFMA") || getenv("HB_NO_MFMA_WIDE") || getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: disabled");
+    if (env_hook(ENV_NO_MFMA) || env_hook(ENV_NO_MFMA_WIDE) || env_hook(ENV_NO_QUICK)) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: disabled");
     // entries below p must fit 32 balanced base-256 digits: top byte of p at most 0x7e
     if (!prescale_params(ctx) || (ctx->p_limbs[3] >> 56) > 0x7e) return fail(ctx, HB_ERR_UNSUPPORTED, "quick: modulus");
     L->n = n; L->d = d; L->nc = nc; L->n_coef = n_coef; L->n_out = n_coef + nc;
@@ -1169,7 +1169,7 @@ int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L) 
 
 int quick_layout_cand(hb_ctx *ctx, QuickLayout *L) {
     (void)ctx;
-    if (L->nc < 1 || L->n > 1024 || L->d > QF_NT || getenv("HB_QUICK_NO_CAND")) return HB_ERR_UNSUPPORTED;
+    if (L->nc < 1 || L->n > 1024 || L->d > QF_NT || env_hook(ENV_QUICK_NO_CAND)) return HB_ERR_UNSUPPORTED;
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     // full_i for every party takes the place of the compared senders' (o_full is sized for nc): moved to the end with the store
     L->o_full = L->need;
@@ -1297,7 +1297,7 @@ int hb_quick_interp_check_map(hb_ctx *ctx, const uint64_t *x_host, int n, const 
     const uint32_t *in = (const uint32_t *)cols_dev + (size_t)chunk_lo * 8;
     hb_view pm{1, C}, dv{d, 1};
     // points that are small integers: [N ; P] on the small-entry kernel, the inputs divided by den_j inside it (hb_mfma_fused.hip)
-    if (ctx->n_limbs == 4 && !getenv("HB_NO_QUICK")) {
+    if (ctx->n_limbs == 4 && !env_hook(ENV_NO_QUICK)) {
         PointTable *pt = nullptr;
         FsLayout F;
         int rc = point_table(ctx, x_host, n, &pt, s); if (rc) return rc;
@@ -1379,7 +1379,7 @@ extern "C" {
 int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec **out, void *stream) { HB_API_GUARD(ctx);
     if (!ctx || !x_host || !out || n < 1) return HB_ERR_BAD_ARG;
     *out = nullptr;
-    if (ctx->n_limbs != 4 || getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "quick decoder: narrow context or disabled");
+    if (ctx->n_limbs != 4 || env_hook(ENV_NO_QUICK)) return fail(ctx, HB_ERR_UNSUPPORTED, "quick decoder: narrow context or disabled");
     hipStream_t s = (hipStream_t)stream;
     cache_trim(ctx);
     PointTable *pt = nullptr;
@@ -1590,7 +1590,7 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     if (!ctx || !x_host || !out || n < 1 || k < 1 || k > n) return HB_ERR_BAD_ARG;
     *out = nullptr;
     if (n > PROBE_MAXN) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: more than 256 points");
-    if (getenv("HB_NO_QUICK")) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: disabled");
+    if (env_hook(ENV_NO_QUICK)) return fail(ctx, HB_ERR_UNSUPPORTED, "probe: disabled");
     hipStream_t s = (hipStream_t)stream;
     cache_trim(ctx);
     PointTable *pt = nullptr;
@@ -1600,7 +1600,7 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
     hb_probe *pr = new hb_probe();
     pr->ctx = ctx; pr->n = n; pr->k = k; pr->pt = pt; pr->poly = -1; pr->seq = 0;
     pr->wgs = n > PROBE_SPLIT_N ? 6 : 1;
-    if (const char *e = getenv("HB_PROBE_WGS")) { const int v = atoi(e); if (v == 1 || (v >= 2 && v <= PROBE_MAXG)) pr->wgs = v; }
+    if (const char *e = env_hook(ENV_PROBE_WGS)) { const int v = atoi(e); if (v == 1 || (v >= 2 && v <= PROBE_MAXG)) pr->wgs = v; }
     if (n > PROBE_SPLIT_N && pr->wgs < 2) pr->wgs = 2;       // (one workgroup's 1024 threads hold two units of a point's update each: 5 n + 6 items are 2 x 1286 units at n = 256)
     pr->state_bytes = ((size_t)4 * (pt->S + n) * ctx->nl() + 8 + PROBE_MAXN) * 4;
     // pooled states are all of the largest size: coefficients + values, the fed list, the workgroups' messages (probe_msgs)

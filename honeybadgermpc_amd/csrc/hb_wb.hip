@@ -417,22 +417,22 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
     uint8_t *gao_ok = nullptr;
     int32_t *todo = nullptr;
     int64_t rejected = C;                            // codewords the row reduction still has to look at
-    if (!getenv("HB_WB_NO_GAO") && n - k >= 1 && 2 * (k - 1) + 1 <= n) {
+    if (!env_hook(ENV_WB_NO_GAO) && n - k >= 1 && 2 * (k - 1) + 1 <= n) {
         int32_t erased = 0;
         HB_HIP(ctx, hipMemsetAsync(ctx->flag_dev, 0, 2 * sizeof(int32_t), s));
         const int64_t tot = C * n;
         k_wb_erasure_pattern<<<(unsigned)((tot + 255) / 256), 256, 0, s>>>(present_dev, tot, n, ctx->flag_dev);
         HB_LAUNCH_CHECK(ctx);
+        // the verdict and -- in case there is a shared pattern -- the first codeword's presence bytes, behind ONE synchronisation
+        std::vector<uint8_t> pat((size_t)n);
         HB_HIP(ctx, hipMemcpyAsync(&erased, ctx->flag_dev, sizeof erased, hipMemcpyDeviceToHost, s));
+        HB_HIP(ctx, hipMemcpyAsync(pat.data(), present_dev, (size_t)n, hipMemcpyDeviceToHost, s));
         HB_HIP(ctx, hipStreamSynchronize(s));
         // the shared pattern, if there is one: the points that are left, in party order (as the reference enumerates them)
         std::vector<int32_t> sel;
         std::vector<uint64_t> xsel;
         int ns = n;
-        if (erased == 1 && !getenv("HB_WB_NO_UNIFORM")) {
-            std::vector<uint8_t> pat((size_t)n);
-            HB_HIP(ctx, hipMemcpyAsync(pat.data(), present_dev, (size_t)n, hipMemcpyDeviceToHost, s));
-            HB_HIP(ctx, hipStreamSynchronize(s));
+        if (erased == 1 && !env_hook(ENV_WB_NO_UNIFORM)) {
             for (int i = 0; i < n; i++)
                 if (pat[i]) { sel.push_back(i); for (int q = 0; q < ctx->n_limbs; q++) xsel.push_back(x_host[(size_t)i * ctx->n_limbs + q]); }
             ns = (int)sel.size();
@@ -479,6 +479,8 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
                                                               (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, todo)));
         HB_LAUNCH_CHECK(ctx);
     }
-    HB_HIP(ctx, hipStreamSynchronize(s));
+    // (the row reduction's temporaries go with this scope: the stream must have let go of them.  A batch Gao's kernels settled entirely has
+    // none, and the call returns with its last launch enqueued, like every other entry point)
+    if (!tmp.bufs.empty()) HB_HIP(ctx, hipStreamSynchronize(s));
     return HB_OK;
 }

@@ -20,6 +20,9 @@ int hb_debug_mm8_apply(hb_ctx *ctx, void *mat, const void *in_dev, int64_t in_sc
                        void *out_dev, int64_t out_sc, int64_t out_sl, int64_t out_count, int64_t n_chunks,
                        const int32_t *check_mask_dev, int32_t *mismatch_dev);
 int hb_debug_occupancy(int n_in, int nl, int *mv3, int *dc);
+/* The library reads its environment hooks (HB_NO_QUICK, HB_GAO_PAIR, ...: DESIGN.md section 7) once, at the first question any of them is
+ * asked.  A test that flips one inside a process calls this to have them read again. */
+void hb_debug_reload_env(void);
 
 
 #ifdef __cplusplus

@@ -106,3 +106,28 @@ def polynomial(galois_field):
     from honeybadgermpc_amd.polynomial import polynomials_over
 
     return polynomials_over(galois_field)
+
+
+def set_hook(monkeypatch, name, value):
+    """flip an environment hook of the library inside this process: the library reads its hooks once (hb_common.hpp, env_hook), so it is
+    told to read them again -- and again when the test is over (the fixture below)"""
+    monkeypatch.setenv(name, value)
+    _reload_env()
+
+
+def clear_hook(monkeypatch, name):
+    monkeypatch.delenv(name, raising=False)
+    _reload_env()
+
+
+def _reload_env():
+    from honeybadgermpc_amd import _capi
+
+    if _capi._lib is not None:
+        _capi._lib.hb_debug_reload_env()
+
+
+@pytest.fixture(autouse=True)
+def _hooks_as_the_environment_says():
+    yield
+    _reload_env()          # (torn down after monkeypatch has restored the environment)

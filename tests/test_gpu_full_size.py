@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import BLS
+from conftest import BLS, clear_hook, set_hook
 
 pytestmark = pytest.mark.gpu
 
@@ -452,7 +452,7 @@ def test_table_caches_are_bounded(monkeypatch):
     from honeybadgermpc_amd._capi import Context
 
     p = (1 << 255) - 19                      # a modulus no other test holds a context for: the cap is read at context creation
-    monkeypatch.setenv("HB_CACHE_CAP", "16")
+    set_hook(monkeypatch, "HB_CACHE_CAP", "16")
     Context._cache.pop((p, 0, 4), None)
     ctx = Context.get(p, 0)
     rnd = random.Random(8)
@@ -497,7 +497,7 @@ def test_one_context_shared_by_concurrent_threads(monkeypatch):
     from honeybadgermpc_amd.device import BatchOpen
 
     p = 0xFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFFEBAAEDCE6AF48A03BBFD25E8CD0364141   # secp256k1's group order: a prime no other test holds a context for
-    monkeypatch.setenv("HB_CACHE_CAP", "8")
+    set_hook(monkeypatch, "HB_CACHE_CAP", "8")
     Context._cache.pop((p, 0, 4), None)
     ctx = Context.get(p, 0)
     n, t = 24, 5
@@ -574,16 +574,16 @@ def test_open_plans_are_cached_per_thread(monkeypatch):
     th = threading.Thread(target=lambda: seen.setdefault("other", cached_batch_open(P, n, t, list(range(d)), list(range(d, d + t)), max_shares=c * d)))
     th.start(); th.join()
     assert seen["other"] is not a                   # never across threads
-    monkeypatch.setenv("HB_PLAN_CACHE", "2")
+    set_hook(monkeypatch, "HB_PLAN_CACHE", "2")
     for s in range(5):
         cached_batch_open(P, n, t, list(range(s, s + d)), [], max_shares=c * d)
     assert len(device._plan_cache.plans) <= 2
-    monkeypatch.setenv("HB_PLAN_CACHE", "0")
+    set_hook(monkeypatch, "HB_PLAN_CACHE", "0")
     assert cached_batch_open(P, n, t, list(range(d)), [], max_shares=c * d) is not cached_batch_open(P, n, t, list(range(d)), [], max_shares=c * d)
     monkeypatch.delenv("HB_PLAN_CACHE")
     # same arrival pattern twice, the second time with a liar: the shared plans must not leak the first run's verdict
     # (the plan-based decoder path: contexts / shapes the plan-free kernels do not take, or HB_NO_QUICK=1)
-    monkeypatch.setenv("HB_NO_QUICK", "1")
+    set_hook(monkeypatch, "HB_NO_QUICK", "1")
     device._plan_cache.plans.clear()
     for liar in (None, 2):
         dec = DeviceIncrementalDecoder(P, n, t, batch_size=c)
@@ -599,7 +599,7 @@ def test_open_plans_are_cached_per_thread(monkeypatch):
         assert errs == (set() if liar is None else {liar})
     assert len(device._plan_cache.plans) >= 1
     # the default, plan-free path builds no plan at all for the same two runs
-    monkeypatch.delenv("HB_NO_QUICK")
+    clear_hook(monkeypatch, "HB_NO_QUICK")
     device._plan_cache.plans.clear()
     for liar in (None, 2):
         dec = DeviceIncrementalDecoder(P, n, t, batch_size=c)

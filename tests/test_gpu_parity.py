@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import BLS
+from conftest import BLS, clear_hook, set_hook
 
 pytestmark = pytest.mark.gpu
 
@@ -121,7 +121,7 @@ def test_vandermonde_points_with_and_without_high_digits_in_the_first_terms(hip,
         polys = rand_rows(rnd, P, c, d)
         want = oracle.vandermonde_batch_evaluate(x, polys, P)
         assert hip.vandermonde_batch_evaluate(x, polys, P) == want
-    monkeypatch.setenv("HB_MM8_NO_SKIP", "1")
+    set_hook(monkeypatch, "HB_MM8_NO_SKIP", "1")
     x, d, c = list(range(2, 66)), 22, 300          # a point set no test has used: a fresh image, built with the switch set
     polys = rand_rows(rnd, P, c, d)
     assert hip.vandermonde_batch_evaluate(x, polys, P) == oracle.vandermonde_batch_evaluate(x, polys, P)
@@ -148,10 +148,10 @@ def test_vandermonde_a_few_polynomials(hip, monkeypatch, p):
         if c > 1:
             polys[1] = [0] * d
         want = oracle.vandermonde_batch_evaluate(x, polys, p)
-        monkeypatch.delenv("HB_NO_EVAL_FEW", raising=False)
+        clear_hook(monkeypatch, "HB_NO_EVAL_FEW")
         assert hip.vandermonde_batch_evaluate(x, polys, p) == want
         if x[0] == 1 and x[-1] == n and n <= 100:            # (the batched kernels tabulate a point set first: the ones other tests have tabulated)
-            monkeypatch.setenv("HB_NO_EVAL_FEW", "1")
+            set_hook(monkeypatch, "HB_NO_EVAL_FEW", "1")
             assert hip.vandermonde_batch_evaluate(x, polys, p) == want
 
 
@@ -638,7 +638,7 @@ def test_fft_four_step_equals_the_stage_loop_and_narrow_contexts(hip, monkeypatc
     rnd = random.Random(14)
     rows = rand_rows(rnd, P, 2, 9000)
     got = hip.fft_batch_evaluate(rows, omega, P, n, n)
-    monkeypatch.setenv("HB_NTT_STAGE_LOOP", "1")
+    set_hook(monkeypatch, "HB_NTT_STAGE_LOOP", "1")
     assert hip.fft_batch_evaluate(rows, omega, P, n, n) == got
     monkeypatch.delenv("HB_NTT_STAGE_LOOP")
     gold = (1 << 64) - (1 << 32) + 1
@@ -870,7 +870,7 @@ def test_gao_two_codewords_a_wave_vs_oracle(hip, monkeypatch, p, n, k):
     degree anomalies make a codeword step alone, words beyond the radius that end early, an odd batch (the last wave holds one codeword)."""
     from structured import KINDS, coordinated_errors, structured_message
 
-    monkeypatch.setenv("HB_GAO_PAIR", "1")
+    set_hook(monkeypatch, "HB_GAO_PAIR", "1")
     rnd = random.Random(n * 131 + k)
     x = list(range(1, n + 1)) if p > n else list(range(n))
     emax = (n - k) // 2
@@ -885,7 +885,7 @@ def test_gao_two_codewords_a_wave_vs_oracle(hip, monkeypatch, p, n, k):
             words.append(_corrupt(rnd, enc, ne, 0, p)[0])
     got = hip.gao_interpolate_batch(x, words, k, p)
     assert got == oracle.gao_interpolate_batch(x, words, k, p)
-    monkeypatch.setenv("HB_GAO_PAIR", "0")
+    set_hook(monkeypatch, "HB_GAO_PAIR", "0")
     assert hip.gao_interpolate_batch(x, words, k, p) == got
 
 
@@ -907,7 +907,7 @@ def test_gao_large_batches_pair_up_by_themselves(hip, monkeypatch):
     got = hip.gao_interpolate_batch(x, words, k, P)
     assert got[:96] == oracle.gao_interpolate_batch(x, words[:96], k, P)
     assert sum(g[0] is None for g in got) > 1000 and sum(g[0] is not None for g in got) > 1000
-    monkeypatch.setenv("HB_GAO_PAIR", "0")
+    set_hook(monkeypatch, "HB_GAO_PAIR", "0")
     assert hip.gao_interpolate_batch(x, words, k, P) == got
 
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import BLS as P
+from conftest import BLS as P, set_hook
 
 pytestmark = pytest.mark.gpu
 
@@ -154,7 +154,7 @@ def test_probe_equals_gao_on_every_prefix(monkeypatch, p, wgs):
     from honeybadgermpc_amd._capi import Context
 
     if wgs:
-        monkeypatch.setenv("HB_PROBE_WGS", wgs)
+        set_hook(monkeypatch, "HB_PROBE_WGS", wgs)
     ctx = Context.get(p)
     rnd = random.Random(p % 1009)
     trials = decoded = beyond = 0
