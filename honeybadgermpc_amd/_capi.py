@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HBMPC_HIP_LIB") or os.path.join(_HERE, "lib", "libhbmpc_hip.so")
 
 HB_OK, HB_ERR_SINGULAR, HB_ERR_BAD_ARG, HB_ERR_UNSUPPORTED = 0, 1, 2, 3
-HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_MISMATCH = 4, 5, 6
+HB_ERR_NO_DEVICE, HB_ERR_HIP, HB_ERR_MISMATCH, HB_ERR_RETRY = 4, 5, 6, 7
 HB_DEC_COLLECTING, HB_DEC_DONE, HB_DEC_DISAGREE, HB_DEC_UNSUPPORTED, HB_DEC_PENDING = 0, 1, 2, 3, 4
 HB_DEC_OPT_DEFER, HB_DEC_OPT_BESIDE = 1, 2
 
@@ -29,6 +29,7 @@ _STATUS_NAMES = {
     4: "HB_ERR_NO_DEVICE",
     5: "HB_ERR_HIP",
     6: "HB_ERR_MISMATCH",
+    7: "HB_ERR_RETRY",
 }
 
 
@@ -87,6 +88,7 @@ SYMBOLS = {
     "hb_probe_create": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
     "hb_probe_feed": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _vp, _vp]),
     "hb_probe_reset": (_i, [_vp]),
+    "hb_probe_workgroups": (_i, [_vp, _i]),
     "hb_probe_points_fed": (_i, [_vp]),
     "hb_probe_destroy": (None, [_vp]),
     "hb_matvec": (_i, [_vp, _vp, _vp, HbView, _vp, _vp, HbView, _i64, _vp]),

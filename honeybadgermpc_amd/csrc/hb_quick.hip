@@ -1708,7 +1708,7 @@ int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *c
         std::atomic_thread_fence(std::memory_order_acquire);
         if (*flag != seq) return fail(ctx, HB_ERR_HIP, "probe: the kernel finished without a verdict");
     }
-    if (pr->res_host->ok < 0) { pr->fed.clear(); pr->poly = -1; return fail(ctx, HB_ERR_HIP, "probe: a workgroup of the launch waited in vain for another (the launch is void; the probe starts from a reset)"); }
+    if (pr->res_host->ok < 0) { pr->fed.clear(); pr->poly = -1; return fail(ctx, HB_ERR_RETRY, "probe: a workgroup of the launch waited in vain for another (the launch is void; the probe starts from a reset)"); }
     *ok = pr->res_host->ok;
     memcpy(err_mask, pr->res_host->err, (size_t)pr->n);
     if (!*ok) memset(err_mask, 0, (size_t)pr->n);
@@ -1806,6 +1806,15 @@ int hb_stream_after(hb_ctx *ctx, void *stream, void *after) { HB_API_GUARD(ctx);
     }
     HB_HIP(ctx, hipEventRecord((hipEvent_t)ctx->after_event, (hipStream_t)after));
     HB_HIP(ctx, hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ctx->after_event, 0));
+    return HB_OK;
+}
+
+int hb_probe_workgroups(hb_probe *pr, int wgs) { HB_API_GUARD((pr ? pr->ctx : nullptr));
+    if (!pr) return HB_ERR_BAD_ARG;
+    const int least = pr->n > PROBE_SPLIT_N ? 2 : 1;
+    if (wgs == 0) wgs = least;
+    if (wgs < least || wgs > PROBE_MAXG || !pr->fed.empty()) return fail(pr->ctx, HB_ERR_BAD_ARG, "probe: workgroup count (or points already fed)");
+    pr->wgs = wgs;
     return HB_OK;
 }
 

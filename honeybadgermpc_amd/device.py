@@ -13,7 +13,7 @@ from collections import OrderedDict
 
 import numpy as np
 
-from ._capi import HB_DEC_DISAGREE, HB_DEC_DONE, HB_DEC_OPT_BESIDE, HB_DEC_OPT_DEFER, HB_DEC_PENDING, HB_DEC_UNSUPPORTED, HB_ERR_MISMATCH, HB_ERR_UNSUPPORTED, HB_OK, Context, _marshal, np_ptr
+from ._capi import HB_DEC_DISAGREE, HB_DEC_DONE, HB_DEC_OPT_BESIDE, HB_DEC_OPT_DEFER, HB_DEC_PENDING, HB_DEC_UNSUPPORTED, HB_ERR_MISMATCH, HB_ERR_RETRY, HB_ERR_UNSUPPORTED, HB_OK, Context, _marshal, np_ptr
 
 
 def wb_decode_batch(x, k, rows, modulus):
@@ -288,7 +288,9 @@ class _Probe:
             self.side = ctx.torch.cuda.Stream()
         self._side_raw = ctypes.c_void_p(self.side.cuda_stream)
 
-    def _feed(self, z, cols, c, poly, decide, after_current):
+    void_launches = 0
+
+    def _feed(self, z, cols, c, poly, decide, after_current, retried=False):
         if poly != self.poly or z[: len(self.fed)] != self.fed:
             self.ctx.check(self.ctx.lib.hb_probe_reset(self.h), "hb_probe_reset")
             self.fed, self.poly = [], poly
@@ -302,6 +304,16 @@ class _Probe:
         ia = np.array(new if new else [0], dtype=np.int32)
         rc = self.ctx.lib.hb_probe_feed(self.h, np_ptr(ia), len(new), self.ctx.ptr(cols), c, poly, 1 if decide else 0, ctypes.byref(self._ok), np_ptr(self._mask),
                                         self._side_raw)
+        if rc == HB_ERR_RETRY:
+            # a void launch: the workgroups of a probe talk through memory and one gave up waiting for another (a crowded chip).  Nothing
+            # was fed and the probe is reset: once more over the whole list on the fewest workgroups the point set allows; a second void
+            # launch is the caller's to route around (_ProbeVoid: the batched decoder gives the same verdict)
+            self.fed, self.poly = [], -1
+            if retried:
+                raise _ProbeVoid()
+            self.ctx.check(self.ctx.lib.hb_probe_workgroups(self.h, 0), "hb_probe_workgroups")
+            self.void_launches += 1
+            return self._feed(z, cols, c, poly, decide, False, retried=True)
         self.ctx.check(rc, "hb_probe_feed")
         self.fed = list(z)
 
@@ -389,6 +401,10 @@ class _CDec:
             self.close()
         except Exception:  # noqa: BLE001 - interpreter shutdown
             pass
+
+
+class _ProbeVoid(Exception):
+    """two launches of a probe in a row were void (hb_probe_feed: HB_ERR_RETRY): the caller takes the verdict from the batched decoder"""
 
 
 class _Unsupported(Exception):
@@ -831,7 +847,10 @@ class DeviceIncrementalDecoder:
         if self.robust != "gao" or not self._fast or poly >= self.batch_size:
             return
         try:
-            self._borrow_probe().feed_ahead(self._z, self._cols, self.batch_size, poly)
+            try:
+                self._borrow_probe().feed_ahead(self._z, self._cols, self.batch_size, poly)
+            except _ProbeVoid:
+                pass                                         # (nothing was fed: the next verdict feeds the whole list)
         except _Unsupported:
             pass
 
@@ -994,7 +1013,12 @@ class DeviceIncrementalDecoder:
                         return
                     pr = self._borrow_probe()
                     self.probes += 1
-                    errors = pr.decide(self._z, self._cols, self.batch_size, lo)
+                    try:
+                        errors = pr.decide(self._z, self._cols, self.batch_size, lo)
+                    except _ProbeVoid:
+                        # never out of add(): Gao's verdict for this one polynomial from the batched kernels (same decision, ~0.7 ms)
+                        ok, _, errs = self._robust_batch(1)
+                        errors = t.nonzero(errs[0]).flatten().tolist() if bool(ok[0].item()) else None
                     if errors is None:
                         self._probe_next = (lo, self._z_epoch, self._min_points_required() + (len(self._z) - d) // 2 + 1)
                         return                               # (None, None): more columns needed

@@ -42,7 +42,10 @@ typedef enum {
     HB_ERR_UNSUPPORTED = 3,  /* even modulus, size beyond a kernel's limits */
     HB_ERR_NO_DEVICE = 4,    /* no usable gfx950 device: the product path fails loudly, there is no CPU fallback */
     HB_ERR_HIP = 5,          /* a HIP runtime call failed; see hb_last_error() */
-    HB_ERR_MISMATCH = 6      /* hb_batch_open: re-encoded guess disagrees with a received column (reed_solomon.py:316-326) */
+    HB_ERR_MISMATCH = 6,     /* hb_batch_open: re-encoded guess disagrees with a received column (reed_solomon.py:316-326) */
+    HB_ERR_RETRY = 7         /* hb_probe_feed: the launch was void (a workgroup of a probe over several workgroups waited in vain for another: they
+                                talk through memory and need each other resident); nothing was fed, the probe has been reset -- feed the whole list
+                                again, after hb_probe_workgroups(pr, 0) if the chip is crowded */
 } hb_status;
 
 typedef struct hb_ctx hb_ctx;        /* modulus + Montgomery constants + device + table cache */
@@ -240,6 +243,9 @@ int hb_probe_create(hb_ctx *ctx, const uint64_t *x_host, int n, int k, hb_probe 
 int hb_probe_feed(hb_probe *pr, const int32_t *idx, int count, const uint64_t *cols_dev, int64_t C, int64_t poly, int decide,
                   int32_t *ok, uint8_t *err_mask, void *stream);
 int hb_probe_reset(hb_probe *pr);          /* start over: another polynomial, or another arrival list */
+/* workgroups a launch of this probe spreads over from now on (the probe must be reset: hb_probe_reset, or a HB_ERR_RETRY just returned): 0 = the
+ * fewest the point set allows (1 up to 128 points, 2 above), otherwise 1 or 2 .. 8.  HB_ERR_BAD_ARG for a count the point set does not allow. */
+int hb_probe_workgroups(hb_probe *pr, int wgs);
 int hb_probe_points_fed(hb_probe *pr);
 void hb_probe_destroy(hb_probe *pr);
 
