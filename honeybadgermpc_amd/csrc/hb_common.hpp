@@ -358,6 +358,17 @@ __device__ __forceinline__ void fs_publish_verdict(int32_t *mismatch, int32_t *f
     if (first_bad) __hip_atomic_store(first_bad, INT32_MAX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (counter) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// The end of a workgroup of such a launch.  Its flag atomics (and stores) must have been ACKNOWLEDGED before it counts itself -- s_waitcnt in every
+// wave, then the barrier: the atomics execute at the coherence point, so the last workgroup's reads of the status words are final.  Rounds
+// 4-5 had a __threadfence() here: an agent-scope release, i.e. a write-back of the XCD's L2 per workgroup -- 8 us of config 3's R2 launch
+// (round 6, kernel trace: 62.2 -> 54.4 us).  What the launch wrote to HBM is ordered for the caller's stream by the launch's end, as for any
+// launch; a consumer on ANOTHER stream orders itself behind the caller's stream (hb_stream_after), not behind the verdict.
+__device__ __forceinline__ void fs_workgroup_done(const FsDone &done, int32_t *mismatch, int32_t *first_bad) {
+    if (!done.counter) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(done.counter, 1) == (int)gridDim.x - 1) fs_publish_verdict(mismatch, first_bad, done.counter, done.host, done.seq);
+}
 #endif
 // host side of the same word
 inline bool fs_verdict_is(const FsVerdict *host, int32_t seq) { return (int32_t)(*reinterpret_cast<const volatile unsigned long long *>(&host->word) >> 32) == seq; }

@@ -403,15 +403,7 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
 #endif
     // a caller that waits for the verdict: the last workgroup to finish hands the status words to pinned host memory (and resets
     // them for the next launch), the sequence number last -- the host polls that word instead of synchronising the stream
-    if (done.counter) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
-                fs_publish_verdict(mismatch, first_bad, done.counter, done.host, done.seq);
-            }
-        }
-    }
+    fs_workgroup_done(done, mismatch, first_bad);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -323,15 +323,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w(const int4 *__restrict__ a8, co
     // status words to pinned host memory and resets them, the sequence number last -- as k_mm8f does (a one-thread kernel behind this launch
     // did it until round 5: a dispatch and its gap on the path of every first-sight decode)
     if constexpr (CHECK) {
-        if (done.counter) {
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __threadfence();
-                if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
-                    fs_publish_verdict(mismatch, first_bad, done.counter, done.host, done.seq);
-                }
-            }
-        }
+        fs_workgroup_done(done, mismatch, first_bad);
     }
 }
 
@@ -590,15 +582,7 @@ __global__ __launch_bounds__(256, 1) void k_mm8w_flat(const int4 *__restrict__ a
             atomicOr(mismatch, 1);
             if (first_bad) atomicMin(first_bad, (int32_t)(bad_chunk > 0x7fffffff ? 0x7fffffff : bad_chunk));
         }
-        if (done.counter) {
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                __threadfence();
-                if (atomicAdd(done.counter, 1) == (int)gridDim.x - 1) {
-                    fs_publish_verdict(mismatch, first_bad, done.counter, done.host, done.seq);
-                }
-            }
-        }
+        fs_workgroup_done(done, mismatch, first_bad);
     }
 }
 
