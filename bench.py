@@ -987,20 +987,27 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
     # exactly n_err distinct positions per codeword: the n_err smallest of n seeded uniforms (erased positions pushed to the end)
     n_era = max(0, min(int(args.erasures), n - k - 1))
     n_err = t if n_era == 0 else (n - n_era - k) // 2
-    erased_pos = sorted(np.random.Generator(np.random.PCG64(404)).choice(n, size=n_era, replace=False).tolist()) if n_era else []
+    n_pat = max(1, int(getattr(args, "erasure_patterns", 1))) if n_era else 1
+    rng_e = np.random.Generator(np.random.PCG64(404))
+    pats = [sorted(rng_e.choice(n, size=n_era, replace=False).tolist()) for _ in range(n_pat)] if n_era else []
+    erased_pos = pats[0] if pats else []
     keys = torch.rand((C, n), device="cuda", generator=gen)
+    # codeword c lost the symbols of pattern c mod n_pat (one pattern: the protocol's case, the parties that have not arrived)
+    era_mask = torch.zeros((C, n), dtype=torch.bool, device="cuda")
+    for pi, ep_ in enumerate(pats):
+        era_mask[pi::n_pat, torch.tensor(ep_, device="cuda")] = True
     if n_era:
-        keys[:, torch.tensor(erased_pos, device="cuda")] = 2.0
+        keys[era_mask] = 2.0
     pos = keys.argsort(dim=1)[:, :n_err]
     idx = (torch.arange(C, device="cuda").unsqueeze(1) * n + pos).reshape(-1)
     bad = code.clone()
     bad[idx] = rand_elements(torch, C * n_err, gen)
     present = torch.ones((C, n), dtype=torch.uint8, device="cuda")
     if n_era:
-        ep = torch.tensor(erased_pos, device="cuda")
-        present[:, ep] = 0
-        bad.view(C, n, 4)[:, ep] = rand_elements(torch, C * n_era, gen).view(C, n_era, 4)      # what lies in an erased slot is never read
+        present[era_mask] = 0
+        bad.view(C * n, 4)[era_mask.reshape(-1)] = rand_elements(torch, C * n_era, gen)      # what lies in an erased slot is never read
     present = present.reshape(-1)
+    del era_mask
     del code, pos, keys
     out = ctx.empty(C * k)
     olen = torch.zeros(C, dtype=torch.int32, device="cuda")
@@ -1073,8 +1080,8 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
         "n_gpus": world, "steps": steps, "warmup": max(1, min(args.warmup, 3)), "ms_per_step": dt * 1e3 / steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u256 (integer mod p, 9 x 29-bit digits in u32, 64-bit accumulators; the interpolant on the int8 matrix cores)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: batched robust decode of {C} codewords per GPU, n={n}, k={k}, exactly {n_err} random positions of each codeword "
-                               f"replaced by random field elements, {'no erasures' if not n_era else str(n_era) + ' symbols of every codeword erased (the same positions)'}, points 1..n, p=BLS12-381 r",
-                   "erasures": n_era, "errors_per_codeword": n_err,
+                               f"replaced by random field elements, {'no erasures' if not n_era else str(n_era) + ' symbols of every codeword erased (' + ('the same positions' if n_pat == 1 else str(n_pat) + ' distinct patterns, codeword c has pattern c mod ' + str(n_pat)) + ')'}, points 1..n, p=BLS12-381 r",
+                   "erasures": n_era, "erasure_patterns": n_pat, "errors_per_codeword": n_err,
                    "n": n, "t": t, "codewords_per_gpu": C, "parallelism": f"codeword-sharded x{world}, no data-path collective"},
         "distributed": dist_info(torch, dist, backend, args, world),
         "roofline": {
@@ -1133,6 +1140,8 @@ def main():
     ap.add_argument("--no-matrix-cores", action="store_true", help="time the integer-VALU kernels instead of the int8 matrix-core path")
     ap.add_argument("--timeout-s", type=float, default=900.0,
                     help="multi-rank runs: seconds after which every rank's watchdog ends the run and names the rank that fell behind (0 = none)")
+    ap.add_argument("--erasure-patterns", type=int, default=1, help="cfg4 with --erasures: this many distinct erasure patterns in the batch (codeword c has pattern c mod P; "
+                    "1 = the protocol's shared pattern)")
     ap.add_argument("--erasures", type=int, default=0,
                     help="cfg4: this many symbols of EVERY codeword are erased (the same positions: the parties that have not arrived, reed_solomon.py:201-204) "
                          "and floor((n - erasures - k) / 2) of the others replaced by random field elements")

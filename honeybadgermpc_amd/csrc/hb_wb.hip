@@ -382,6 +382,46 @@ __global__ void k_wb_take_gao(const uint8_t *__restrict__ ok, const int32_t *__r
     status[c] = 0;
 }
 
+// ---- per-codeword erasure patterns: a batch with a FEW distinct patterns is a few batches with a shared one ---------------------------
+// presence bytes -> a bitmask per codeword (W = ceil(n / 64) words)
+__global__ void k_wb_masks(const uint8_t *__restrict__ present, int64_t C, int n, int W, unsigned long long *__restrict__ masks) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * W) return;
+    const int64_t c = i / W;
+    const int w = (int)(i - c * W);
+    unsigned long long m = 0;
+    for (int b = 0; b < 64 && 64 * w + b < n; b++)
+        if (present[c * n + 64 * w + b]) m |= 1ull << b;
+    masks[i] = m;
+}
+// the group's codewords (all their n symbols: the interpolant's launch picks the surviving ones by its row map) next to each other
+__global__ void k_wb_gather(const unsigned long long *__restrict__ ys, const int32_t *__restrict__ idx, int64_t Cg, int row_q, unsigned long long *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cg * row_q) return;
+    const int64_t g = i / row_q;
+    out[i] = ys[(size_t)idx[g] * row_q + (i - g * row_q)];
+}
+// k_wb_take_gao for a gathered group: codeword g of the group is codeword idx[g] of the batch; an accepted row is copied to its place
+template <int NW>
+__global__ void k_wb_take_gao_group(const uint8_t *__restrict__ ok, const int32_t *__restrict__ errlen, int emax, const uint32_t *__restrict__ gcoeffs, int k, int64_t Cg,
+                                    const int32_t *__restrict__ idx, uint32_t *__restrict__ coeffs, int32_t *__restrict__ coeff_len, int32_t *__restrict__ status,
+                                    int32_t *__restrict__ rejected, int32_t *__restrict__ todo) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= Cg) return;
+    const int32_t c = idx[g];
+    if (!ok[g] || errlen[g] - 1 > emax) { todo[atomicAdd(rejected, 1)] = c; return; }
+    int len = 0;
+    for (int j = 0; j < k; j++) {
+        uint32_t o = 0;
+        for (int q = 0; q < NW; q++) { const uint32_t v = gcoeffs[((size_t)g * k + j) * NW + q]; coeffs[((size_t)c * k + j) * NW + q] = v; o |= v; }
+        if (o) len = j + 1;
+    }
+    coeff_len[c] = len;
+    status[c] = 0;
+}
+constexpr int WB_MAX_PATTERNS = 64;        // distinct erasure patterns a batch is cut into; more: the row reduction, as before
+constexpr int WB_MIN_GROUP = 64;           // a pattern's codewords go through Gao's kernels from this many on (its tables cost ~a millisecond)
+
 extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, const uint64_t *ys_dev,
                             const uint8_t *present_dev, int64_t C, uint64_t *coeffs_dev, int32_t *coeff_len_dev,
                             int32_t *status_dev, void *stream) { HB_API_GUARD(ctx);
@@ -438,6 +478,100 @@ extern "C" int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, c
             ns = (int)sel.size();
             if (ns - k < 1 || 2 * (k - 1) + 1 > ns) { sel.clear(); ns = n; erased = 3; }          // too few points left: the row reduction's refusals
             else erased = 0;
+        }
+        if ((erased & 2) && !env_hook(ENV_WB_NO_UNIFORM) && C >= WB_MIN_GROUP && C <= 0x7fffffffLL) {
+            // Per-codeword patterns (reed_solomon_wb.py:129-151 takes any): the batch is cut by pattern.  A pattern shared by at least WB_MIN_GROUP
+            // codewords is a batch over the points that are left -- gathered, decoded by Gao's kernels on the reduced point set, accepted within
+            // the radius floor((n' - k) / 2) exactly as a shared pattern is; what is left (small groups, patterns with too few points, whatever
+            // Gao's kernels reject) is the row reduction's work list.  Round 5: any second pattern sent the whole batch through the row reduction.
+            const int W = (n + 63) / 64;
+            unsigned long long *masks_dev = nullptr;
+            rc = ctx_scratch(ctx, "wb.masks", (size_t)C * W * 8, (void **)&masks_dev); if (rc) return rc;
+            k_wb_masks<<<(unsigned)((C * W + 255) / 256), 256, 0, s>>>(present_dev, C, n, W, masks_dev);
+            HB_LAUNCH_CHECK(ctx);
+            std::vector<unsigned long long> masks((size_t)C * W);
+            HB_HIP(ctx, hipMemcpyAsync(masks.data(), masks_dev, masks.size() * 8, hipMemcpyDeviceToHost, s));
+            HB_HIP(ctx, hipStreamSynchronize(s));
+            // group ids by exact mask: an open-addressing table of (first codeword of the pattern, group)
+            std::vector<std::vector<int32_t>> groups;
+            {
+                const size_t cap = 256;                  // > 2 x WB_MAX_PATTERNS slots
+                std::vector<int32_t> slot_first(cap, -1), slot_group(cap, -1);
+                bool too_many = false;
+                for (int64_t c = 0; c < C && !too_many; c++) {
+                    const unsigned long long *m = &masks[(size_t)c * W];
+                    unsigned long long h = 0x9e3779b97f4a7c15ull;
+                    for (int w = 0; w < W; w++) { h ^= m[w]; h *= 0xff51afd7ed558ccdull; h ^= h >> 29; }
+                    size_t at = (size_t)h & (cap - 1);
+                    for (;;) {
+                        if (slot_first[at] < 0) {
+                            if ((int)groups.size() >= WB_MAX_PATTERNS) { too_many = true; break; }
+                            slot_first[at] = (int32_t)c; slot_group[at] = (int32_t)groups.size();
+                            groups.emplace_back();
+                            groups.back().push_back((int32_t)c);
+                            break;
+                        }
+                        if (!memcmp(&masks[(size_t)slot_first[at] * W], m, (size_t)W * 8)) { groups[slot_group[at]].push_back((int32_t)c); break; }
+                        at = (at + 1) & (cap - 1);
+                    }
+                }
+                if (too_many) groups.clear();
+            }
+            if (!groups.empty()) {
+                int32_t *errlen = nullptr, *gidx = nullptr;
+                unsigned long long *gys = nullptr;
+                uint32_t *gco = nullptr;
+                size_t maxg = 0;
+                for (auto &g : groups) maxg = std::max(maxg, g.size());
+                const int row_q = n * ctx->n_limbs;                           // 64-bit words per codeword
+                rc = ctx_scratch(ctx, "wb.gao_ok", (size_t)C, (void **)&gao_ok); if (rc) return rc;
+                rc = ctx_scratch(ctx, "wb.errlen", (size_t)C * sizeof(int32_t), (void **)&errlen); if (rc) return rc;
+                rc = ctx_scratch(ctx, "wb.todo", (size_t)C * sizeof(int32_t), (void **)&todo); if (rc) return rc;
+                rc = ctx_scratch(ctx, "wb.gidx", maxg * sizeof(int32_t), (void **)&gidx); if (rc) return rc;
+                rc = ctx_scratch(ctx, "wb.gys", maxg * (size_t)row_q * 8, (void **)&gys); if (rc) return rc;
+                rc = ctx_scratch(ctx, "wb.gco", maxg * (size_t)k * ctx->n_limbs * 8, (void **)&gco); if (rc) return rc;
+                // the row reduction's list starts with what no group decodes: small groups, patterns that leave too few points
+                std::vector<int32_t> direct;
+                std::vector<char> by_gao(groups.size(), 0);
+                for (size_t gi = 0; gi < groups.size(); gi++) {
+                    int ns_g = 0;
+                    const unsigned long long *m = &masks[(size_t)groups[gi][0] * W];
+                    for (int i = 0; i < n; i++) ns_g += (int)((m[i >> 6] >> (i & 63)) & 1);
+                    if ((int64_t)groups[gi].size() >= WB_MIN_GROUP && ns_g - k >= 1 && 2 * (k - 1) + 1 <= ns_g) by_gao[gi] = 1;
+                    else direct.insert(direct.end(), groups[gi].begin(), groups[gi].end());
+                }
+                const int32_t n_direct = (int32_t)direct.size();
+                if (n_direct) HB_HIP(ctx, hipMemcpyAsync(todo, direct.data(), (size_t)n_direct * 4, hipMemcpyHostToDevice, s));
+                HB_HIP(ctx, hipMemcpyAsync(ctx->flag_dev + 1, &n_direct, sizeof n_direct, hipMemcpyHostToDevice, s));
+                HB_HIP(ctx, hipStreamSynchronize(s));                           // (the two sources are this stack's)
+                for (size_t gi = 0; gi < groups.size(); gi++) {
+                    if (!by_gao[gi]) continue;
+                    const std::vector<int32_t> &g = groups[gi];
+                    const int64_t Cg = (int64_t)g.size();
+                    const unsigned long long *m = &masks[(size_t)g[0] * W];
+                    std::vector<int32_t> gsel;
+                    std::vector<uint64_t> gx;
+                    for (int i = 0; i < n; i++)
+                        if ((m[i >> 6] >> (i & 63)) & 1) { gsel.push_back(i); for (int q = 0; q < ctx->n_limbs; q++) gx.push_back(x_host[(size_t)i * ctx->n_limbs + q]); }
+                    const int ns_g = (int)gsel.size();
+                    HB_HIP(ctx, hipMemcpyAsync(gidx, g.data(), (size_t)Cg * 4, hipMemcpyHostToDevice, s));
+                    HB_HIP(ctx, hipStreamSynchronize(s));
+                    k_wb_gather<<<(unsigned)((Cg * row_q + 255) / 256), 256, 0, s>>>((const unsigned long long *)ys_dev, gidx, Cg, row_q, gys);
+                    HB_LAUNCH_CHECK(ctx);
+                    if (ns_g == n) rc = hb::gao_decode(ctx, x_host, n, k, (const uint64_t *)gys, Cg, (uint64_t *)gco, nullptr, errlen, gao_ok, stream);
+                    else rc = hb::gao_decode(ctx, gx.data(), ns_g, k, (const uint64_t *)gys, Cg, (uint64_t *)gco, nullptr, errlen, gao_ok, stream, n, gsel.data());
+                    if (rc) return rc;
+                    if (ctx->n_limbs == 4) k_wb_take_gao_group<8><<<(unsigned)((Cg + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (ns_g - k) / 2, gco, k, Cg, gidx, (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
+                    else k_wb_take_gao_group<2><<<(unsigned)((Cg + 255) / 256), 256, 0, s>>>(gao_ok, errlen, (ns_g - k) / 2, gco, k, Cg, gidx, (uint32_t *)coeffs_dev, coeff_len_dev, status_dev, ctx->flag_dev + 1, todo);
+                    HB_LAUNCH_CHECK(ctx);
+                    HB_HIP(ctx, hipStreamSynchronize(s));                       // (gidx, gys, gco are the next group's too)
+                }
+                int32_t rej = 0;
+                HB_HIP(ctx, hipMemcpyAsync(&rej, ctx->flag_dev + 1, sizeof rej, hipMemcpyDeviceToHost, s));
+                HB_HIP(ctx, hipStreamSynchronize(s));
+                rejected = rej;
+                erased = -1;                               // settled here: not the shared-pattern branch below
+            }
         }
         if (!erased) {
             int32_t *errlen = nullptr;

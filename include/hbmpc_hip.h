@@ -272,11 +272,14 @@ int hb_gao_decode(hb_ctx *ctx, const uint64_t *x_host, int npts, int k, const ui
 /* Welch-Berlekamp (reed_solomon_wb.py:129-151), batched.  ys_dev [C][n], present_dev [C][n]
  * (0 = erasure).  coeffs_dev [C][k] zero padded, coeff_len_dev[c] = length after stripping
  * trailing zeros (polynomial.py:14-20), status_dev[c]: 0 ok, 1 "found no divisors!",
- * 2 "No solution", 3 too few points.  Complete words with at most floor((n - k) / 2) errors are
- * settled by Gao's kernels (there the reference's solver can only return the closest codeword's
- * polynomial); every other word -- erasures, more errors, also those Gao would still decode because
- * the message has leading zeros -- goes through the reference's own elimination, its descending-e
- * loop and its particular solution (reed_solomon_wb.py:79-127, 157-273). */
+ * 2 "No solution", 3 too few points.  Words with at most floor((n' - k) / 2) errors over their n' surviving
+ * points are settled by Gao's kernels (there the reference's solver can only return the closest codeword's
+ * polynomial): complete words; words that all lost the SAME symbols (the protocol's case: the parties that
+ * have not arrived, reed_solomon.py:201-204) as one batch over the points that are left; and, round 6, a batch
+ * with up to 64 distinct patterns cut by pattern (groups of at least 64 codewords).  Every other word -- more
+ * errors, small groups, also those Gao would still decode because the message has leading zeros -- goes through
+ * the reference's own elimination, its descending-e loop and its particular solution (reed_solomon_wb.py:79-127,
+ * 157-273).  The call returns with its last launch enqueued when Gao's kernels settled the whole batch. */
 int hb_wb_decode(hb_ctx *ctx, const uint64_t *x_host, int n, int k, const uint64_t *ys_dev,
                  const uint8_t *present_dev, int64_t C, uint64_t *coeffs_dev, int32_t *coeff_len_dev,
                  int32_t *status_dev, void *stream);

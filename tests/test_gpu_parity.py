@@ -1055,3 +1055,38 @@ def test_wb_batches_with_one_erasure_pattern_vs_oracle(p, n, k, words):
             extra = next(i for i in range(n) if mixed[0][i] is not None)
             mixed[0][extra] = None
             assert wb_decode_batch(x, k, mixed, p)[1:] == want[1:]
+
+
+@pytest.mark.parametrize("p,n,k,words", [(BLS, 25, 8, 400), (BLS, 100, 34, 330), ((1 << 61) - 1, 30, 7, 300)])
+def test_wb_batches_with_a_few_erasure_patterns_vs_oracle(p, n, k, words):
+    """Per-codeword erasure patterns (reed_solomon_wb.py:129-151 takes any): a batch with a few distinct patterns is cut by pattern; groups of at
+    least 64 codewords run Gao's kernels on their reduced point sets, the rest (small groups, patterns that leave too few points, words beyond the
+    reduced radius) the row reduction -- every outcome (coefficients, lengths, the reference's refusals) as the oracle's restatement of the
+    reference's decoder gives it.  Patterns here: none erased, three large groups, one group of 5 codewords, one pattern with too few points."""
+    from structured import structured_message
+
+    from honeybadgermpc_amd.device import wb_decode_batch
+
+    rnd = random.Random(n * 977 + k)
+    x = list(range(1, n + 1))
+    cmax = n - 2 * (k - 1) - 1
+    pats = [[], rnd.sample(range(n), max(1, cmax // 3)), rnd.sample(range(n), max(1, cmax // 2)), rnd.sample(range(n), max(1, cmax)),
+            rnd.sample(range(n), 2), rnd.sample(range(n), min(n - k, cmax + 3))]
+    sizes = [words // 4, words // 4, words // 4, words - 3 * (words // 4) - 5 - 70, 5, 70]
+    which = [gi for gi, sz in enumerate(sizes) for _ in range(sz)]
+    rnd.shuffle(which)
+    rows = []
+    for w, gi in enumerate(which):
+        erased = set(pats[gi])
+        msg = structured_message(rnd, k, p)
+        enc = oracle.vandermonde_batch_evaluate(x, [msg], p)[0]
+        alive = [i for i in range(n) if i not in erased]
+        emax = max(0, (len(alive) - k) // 2)
+        ne = min(len(alive), [0, emax, emax // 2, emax + 1, 1, emax][w % 6])
+        for i in rnd.sample(alive, ne):
+            enc[i] = (enc[i] + rnd.randrange(1, p)) % p
+        rows.append([None if i in erased else enc[i] for i in range(n)])
+    got = wb_decode_batch(x, k, rows, p)
+    want = oracle.wb_decode_batch(x, k, rows, p)
+    bad = [i for i in range(len(rows)) if got[i] != want[i]]
+    assert not bad, (len(bad), bad[:5], [which[i] for i in bad[:5]])
