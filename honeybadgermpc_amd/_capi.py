@@ -85,6 +85,7 @@ SYMBOLS = {
     "hb_symbols_fetch": (_i, [_vp, _vp, _i, _i64, _i64, _vp, _i, _vp, _vp]),
     "hb_candidate_check": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _vp, _vp, _vp]),
     "hb_stream_after": (_i, [_vp, _vp, _vp]),
+    "hb_side_stream": (_i, [_vp, _pp]),
     "hb_probe_create": (_i, [_vp, _vp, _i, _i, _pp, _vp]),
     "hb_probe_feed": (_i, [_vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _vp, _vp]),
     "hb_probe_reset": (_i, [_vp]),

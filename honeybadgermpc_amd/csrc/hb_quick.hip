@@ -1337,6 +1337,29 @@ __global__ void k_publish_verdict(int32_t *status, FsVerdict *host, int seq) {
     fs_publish_verdict(status, status + 1, nullptr, host, seq);
 }
 
+// the context's ONE side stream (highest priority, non-blocking): builds beside a busy caller's stream, the probes' feeds.  One, because a
+// process has four hardware queues: a stream per decoder / probe object shares them with the caller's, and what was meant to run beside it
+// queues behind it (round 6: bench.py's first-sight leg 5.4 -> 4.5 G once its two-streams leg had made its streams)
+static hipError_t ctx_side_stream(hb_ctx *ctx, hipStream_t *out) {
+    if (!ctx->side_stream) {
+        int lo_prio = 0, hi_prio = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
+        hipStream_t ss = nullptr;
+        const hipError_t e = hipStreamCreateWithPriority(&ss, hipStreamNonBlocking, hi_prio);
+        if (e != hipSuccess) return e;
+        ctx->side_stream = ss;
+    }
+    *out = (hipStream_t)ctx->side_stream;
+    return hipSuccess;
+}
+extern "C" int hb_side_stream(hb_ctx *ctx, void **stream) { HB_API_GUARD(ctx);
+    if (!ctx || !stream) return HB_ERR_BAD_ARG;
+    hipStream_t ss = nullptr;
+    HB_HIP(ctx, ctx_side_stream(ctx, &ss));
+    *stream = ss;
+    return HB_OK;
+}
+
 struct hb_quick_dec {
     hb_ctx *ctx;
     int n;
@@ -1395,14 +1418,7 @@ int hb_quick_dec_create(hb_ctx *ctx, const uint64_t *x_host, int n, hb_quick_dec
     if (e == hipSuccess) e = hipHostMalloc((void **)&qd->res_host, sizeof(FsVerdict), hipHostMallocMapped);
     if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&qd->res_dev, qd->res_host, 0);
     qd->bstream = nullptr; qd->built = qd->launched = nullptr; qd->launch_open = false; qd->launch_stream = nullptr; qd->beside = qd->built_beside = false;
-    if (e == hipSuccess && !ctx->side_stream) {
-        int lo_prio = 0, hi_prio = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo_prio, &hi_prio);
-        hipStream_t ss = nullptr;
-        e = hipStreamCreateWithPriority(&ss, hipStreamNonBlocking, hi_prio);
-        if (e == hipSuccess) ctx->side_stream = ss;
-    }
-    qd->bstream = (hipStream_t)ctx->side_stream;              // the context's, shared by its decoders
+    if (e == hipSuccess) e = ctx_side_stream(ctx, &qd->bstream);             // the context's, shared by its decoders and probes
     if (e == hipSuccess) e = hipEventCreateWithFlags(&qd->built, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&qd->launched, hipEventDisableTiming);
     if (e != hipSuccess) {

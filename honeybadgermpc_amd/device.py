@@ -269,7 +269,7 @@ _checked_columns = {}       # id(receive buffer) -> (weak reference to it, the s
 
 class _Probe:
     """hb_probe_*: the reference's per-polynomial Gao decode (reed_solomon.py:151-186) for ONE codeword of the party-major
-    buffer, incremental in the arrivals (include/hbmpc_hip.h).  A probe works on a stream of its own: its kernels (one workgroup)
+    buffer, incremental in the arrivals (include/hbmpc_hip.h).  A probe works on the context's side stream: its kernels (one workgroup)
     only read the columns, so feeding it can start -- `feed_ahead` -- while the decoder's own launches and bookkeeping go on."""
 
     def __init__(self, ctx, xh_all, n, k):
@@ -284,9 +284,10 @@ class _Probe:
         self.fed, self.poly = [], -1
         self._ok = ctypes.c_int32(0)
         self._mask = np.zeros(n, dtype=np.uint8)
-        with ctx.torch.cuda.device(ctx.tdev):
-            self.side = ctx.torch.cuda.Stream()
-        self._side_raw = ctypes.c_void_p(self.side.cuda_stream)
+        # (the context's one side stream, not a stream per probe: a process has four hardware queues, and a probe that shares one with the
+        # caller's stream feeds behind the decoder's launches instead of beside them)
+        self._side_raw = ctypes.c_void_p()
+        ctx.check(ctx.lib.hb_side_stream(ctx.h, ctypes.byref(self._side_raw)), "hb_side_stream")
 
     void_launches = 0
 

@@ -230,6 +230,9 @@ int hb_candidate_check(hb_ctx *ctx, const uint64_t *x_host, int n, const uint64_
                        uint64_t *out_values_host, uint8_t *out_differs_host, void *stream);
 /* plumbing: `stream` goes on only after everything enqueued on `after` so far (an event of the context) */
 int hb_stream_after(hb_ctx *ctx, void *stream, void *after);
+/* plumbing: the context's side stream (made on first use, highest priority, non-blocking) -- where hb_dec / hb_quick_dec build beside a busy caller's
+ * stream (HB_DEC_OPT_BESIDE) and where a caller may feed its probes (hb_probe_feed's `stream`): ONE for the context, a process has few hardware queues */
+int hb_side_stream(hb_ctx *ctx, void **stream);
 
 /* gao_interpolate for ONE codeword, incremental in its points (rsdecode_impl.h:325-363 as GaoRobustDecoder.robust_decode
  * runs it per polynomial, reed_solomon.py:151-186, 334-365): the probe keeps a reduced basis of the interpolation module of
