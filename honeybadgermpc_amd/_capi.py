@@ -82,6 +82,11 @@ SYMBOLS = {
     "hb_dec_verdict": (_i, [_vp, _vp, _vp]),
     "hb_dec_arrivals_list": (_i, [_vp, _vp, _i, _vp]),
     "hb_dec_destroy": (None, [_vp]),
+    "hb_wait_create": (_i, [_vp, _i, _pp]),
+    "hb_wait_begin": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "hb_wait_arrived1": (_i, [_vp, _i, _i]),
+    "hb_wait_result": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "hb_wait_destroy": (None, [_vp]),
     "hb_symbols_fetch": (_i, [_vp, _vp, _i, _i64, _i64, _vp, _i, _vp, _vp]),
     "hb_candidate_check": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i64, _i64, _vp, _vp, _vp]),
     "hb_stream_after": (_i, [_vp, _vp, _vp]),
@@ -150,6 +155,8 @@ def load_library():
     _lib = lib
     if _marshal is not None and hasattr(_marshal, "bind_dec"):
         _marshal.bind_dec(ctypes.cast(lib.hb_dec_arrived1, ctypes.c_void_p).value)      # DeviceIncrementalDecoder.add calls it without ctypes
+        if hasattr(_marshal, "bind_wait"):
+            _marshal.bind_wait(ctypes.cast(lib.hb_wait_arrived1, ctypes.c_void_p).value)
     return lib
 
 

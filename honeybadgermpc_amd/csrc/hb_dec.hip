@@ -26,6 +26,9 @@
 //                       round's decoder and takes its first messages while this round's launch runs (batch_reconstruction.py:158-227
 //                       subscribes to both rounds up front for the same reason)
 #include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include <vector>
 
@@ -168,6 +171,88 @@ int hb_dec_arrivals_list(const hb_dec *dec, int32_t *out, int cap, int32_t *coun
     for (int i = 0; i < k && i < cap; i++) out[i] = dec->z[i];
     return HB_OK;
 }
+
+// ---- a candidate's waiting phase (reference reed_solomon.py:334-346) ---------------------------------------------------------------
+// After the first disagreement the decoder holds candidates for the disagreeing polynomial: polynomials that few enough arrived senders
+// contradict (device.py _candidate_cap has the proof that, while a candidate's contradictions stay within max_errors - confirmed, "accept it
+// once |z| - E >= need, else wait" IS the reference's behaviour).  Until then every arrival is ONE question -- does the new sender's symbol of
+// that chunk equal the candidate's value at its point? -- and rounds 4-5 asked it from Python: ~4 of an arrival's 13 us, 85 times in a row at
+// n = 256 with the liars first.  This object asks it in C: the candidates' values at the n points stay here, an arrival is a symbol fetch
+// (hb_symbols_fetch) and a compare, and the host hears about it only when something is to be DONE (a candidate can be accepted, or none is
+// left) -- HB_WAIT_EVENT; the caller then reads the contradictions counted here (hb_wait_result) and goes on as before.
+struct hb_wait {
+    hb_ctx *ctx;
+    int n, L;
+    const uint64_t *cols;
+    int64_t C, chunk;
+    void *stream;
+    int degree, max_errors, zlen, n_cands;
+    std::vector<uint64_t> ev;                       // [n_cands][n][L]: the candidates at the parties' points
+    std::vector<int32_t> base_err;                  // contradictions each had when the wait began
+    std::vector<std::vector<int32_t>> new_err;      // ... and the senders that contradicted it since
+    std::vector<uint8_t> dead;                      // left the cap at some arrival: gone for good (as the host's list drops it)
+    bool armed;
+};
+
+int hb_wait_create(hb_ctx *ctx, int n, hb_wait **out) {
+    if (!ctx || !out || n < 1) return HB_ERR_BAD_ARG;
+    hb_wait *w = new hb_wait();
+    w->ctx = ctx; w->n = n; w->L = ctx->n_limbs; w->cols = nullptr; w->C = 0; w->chunk = 0; w->stream = nullptr;
+    w->degree = w->max_errors = w->zlen = w->n_cands = 0; w->armed = false;
+    *out = w;
+    return HB_OK;
+}
+
+int hb_wait_begin(hb_wait *w, const uint64_t *cols_dev, int64_t C, int64_t chunk, int degree, int max_errors, int zlen, int n_cands,
+                  const uint64_t *values_host, const int32_t *contradictions, void *stream) {
+    if (!w) return HB_ERR_BAD_ARG;
+    w->armed = false;
+    if (!cols_dev || !values_host || !contradictions || C < 1 || chunk < 0 || chunk >= C || degree < 0 || max_errors < 0 || zlen < 0 || n_cands < 1 || n_cands > 8)
+        return fail(w->ctx, HB_ERR_BAD_ARG, "candidate wait: arguments");
+    w->cols = cols_dev; w->C = C; w->chunk = chunk; w->degree = degree; w->max_errors = max_errors; w->zlen = zlen; w->n_cands = n_cands; w->stream = stream;
+    w->ev.assign(values_host, values_host + (size_t)n_cands * w->n * w->L);
+    w->base_err.assign(contradictions, contradictions + n_cands);
+    w->new_err.assign((size_t)n_cands, std::vector<int32_t>());
+    w->dead.assign((size_t)n_cands, 0);
+    w->armed = true;
+    return HB_OK;
+}
+
+// one arrival (the caller has filtered duplicates and confirmed errors, reed_solomon.py:369-372): HB_WAIT_ON -- nothing to do but wait for the
+// next; HB_WAIT_EVENT -- a candidate can be accepted or none is left; -(hb_status) on an error.  n_confirmed: |confirmed errors| now.
+int hb_wait_arrived1(hb_wait *w, int32_t idx, int n_confirmed) {
+    if (!w || !w->armed || idx < 0 || idx >= w->n || n_confirmed < 0) return -HB_ERR_BAD_ARG;
+    uint64_t sym[4];
+    const int rc = hb_symbols_fetch(w->ctx, w->cols, w->n, w->C, w->chunk, &idx, 1, sym, w->stream);
+    if (rc) return -rc;
+    w->zlen += 1;
+    const int need = w->degree + 1 + w->max_errors - n_confirmed;
+    const int cap = std::max((w->zlen - w->degree - 1) / 2, w->max_errors - n_confirmed);      // (Gao: device.py _candidate_cap)
+    bool alive = false, accept = false;
+    for (int c = 0; c < w->n_cands; c++) {
+        if (w->dead[c]) continue;
+        if (memcmp(sym, &w->ev[((size_t)c * w->n + idx) * w->L], (size_t)w->L * 8) != 0) w->new_err[c].push_back(idx);
+        const int e = w->base_err[c] + (int)w->new_err[c].size();
+        if (e > cap) { w->dead[c] = 1; continue; }
+        alive = true;
+        if (w->zlen - e >= need) accept = true;
+    }
+    if (alive && !accept) return HB_WAIT_ON;
+    w->armed = false;
+    return HB_WAIT_EVENT;
+}
+
+// candidate `cand`: is it still standing, and the senders that contradicted it since hb_wait_begin (the first min(cap, *count) of them)
+int hb_wait_result(const hb_wait *w, int cand, int32_t *standing, int32_t *senders, int cap, int32_t *count) {
+    if (!w || cand < 0 || cand >= w->n_cands || !standing || !count || cap < 0 || (cap > 0 && !senders)) return HB_ERR_BAD_ARG;
+    *standing = w->dead[cand] ? 0 : 1;
+    const int k = (int)w->new_err[cand].size();
+    *count = k;
+    for (int i = 0; i < k && i < cap; i++) senders[i] = w->new_err[cand][i];
+    return HB_OK;
+}
+
+void hb_wait_destroy(hb_wait *w) { delete w; }
 
 void hb_dec_destroy(hb_dec *dec) {
     if (!dec) return;

@@ -79,7 +79,9 @@ static PyObject *hb_unpack(PyObject *self, PyObject *args) {
 /* ---- DeviceIncrementalDecoder.add ------------------------------------------------------------------------------------------- */
 typedef int (*hb_dec_arrived1_fn)(void *, int);
 static hb_dec_arrived1_fn g_arrived1 = NULL;
-static PyObject *s_ch, *s_slow, *s_event;
+typedef int (*hb_wait_arrived1_fn)(void *, int, int);
+static hb_wait_arrived1_fn g_wait1 = NULL;
+static PyObject *s_ch, *s_slow, *s_event, *s_wh, *s_wevent, *s_confirmed, *s_avl, *s_zl;
 
 /* bind_dec(address of hb_dec_arrived1) */
 static PyObject *hb_bind_dec(PyObject *self, PyObject *arg) {
@@ -87,6 +89,56 @@ static PyObject *hb_bind_dec(PyObject *self, PyObject *arg) {
     if (!p && PyErr_Occurred()) return NULL;
     g_arrived1 = (hb_dec_arrived1_fn)p;
     Py_RETURN_NONE;
+}
+
+/* bind_wait(address of hb_wait_arrived1) */
+static PyObject *hb_bind_wait(PyObject *self, PyObject *arg) {
+    void *p = PyLong_AsVoidPtr(arg);
+    if (!p && PyErr_Occurred()) return NULL;
+    g_wait1 = (hb_wait_arrived1_fn)p;
+    Py_RETURN_NONE;
+}
+
+/* A decoder whose candidates wait (decoder._wh = the hb_wait handle as an int; columns received in place): the arrival is filtered as
+ * IncrementalDecoder.add filters it (reed_solomon.py:369-372: a sender already counted or confirmed in error is ignored), judged by
+ * hb_wait_arrived1 with the GIL released, appended to the decoder's arrival list; only an event goes to decoder._w_event(state, idx).
+ * Returns NULL with an error set, Py_None's new reference when handled, or (PyObject *)1 when this path does not apply. */
+static PyObject *wait_add(PyObject *dec, PyObject *idxobj) {
+    if (!g_wait1) return (PyObject *)1;
+    PyObject *h = PyObject_GetAttr(dec, s_wh);
+    if (!h) return NULL;
+    if (h == Py_None) { Py_DECREF(h); return (PyObject *)1; }
+    void *p = PyLong_AsVoidPtr(h);
+    Py_DECREF(h);
+    if (!p && PyErr_Occurred()) return NULL;
+    long idx = PyLong_AsLong(idxobj);
+    if (idx == -1 && PyErr_Occurred()) return NULL;
+    PyObject *conf = PyObject_GetAttr(dec, s_confirmed), *avl = NULL, *zl = NULL, *ret = NULL;
+    if (!conf) return NULL;
+    avl = PyObject_GetAttr(dec, s_avl);
+    zl = avl ? PyObject_GetAttr(dec, s_zl) : NULL;
+    if (!avl || !zl) goto out;
+    if (!PyAnySet_Check(conf) || !PyAnySet_Check(avl) || !PyList_Check(zl) || idx < 0 || idx > 2147483647L) { ret = (PyObject *)1; goto out; }
+    {
+        int in = PySet_Contains(conf, idxobj);
+        if (in < 0) goto out;
+        if (!in) { in = PySet_Contains(avl, idxobj); if (in < 0) goto out; }
+        if (in) { Py_INCREF(Py_None); ret = Py_None; goto out; }
+        const int nconf = (int)PySet_GET_SIZE(conf);
+        int st;
+        Py_BEGIN_ALLOW_THREADS
+        st = g_wait1(p, (int)idx, nconf);
+        Py_END_ALLOW_THREADS
+        if (st >= 0 && (PySet_Add(avl, idxobj) < 0 || PyList_Append(zl, idxobj) < 0)) goto out;
+        if (st == 0) { Py_INCREF(Py_None); ret = Py_None; goto out; }
+        PyObject *sto = PyLong_FromLong(st);
+        if (!sto) goto out;
+        ret = PyObject_CallMethodObjArgs(dec, s_wevent, sto, idxobj, NULL);
+        Py_DECREF(sto);
+    }
+out:
+    Py_XDECREF(conf); Py_XDECREF(avl); Py_XDECREF(zl);
+    return ret;
 }
 
 /* dec_add(decoder, idx, column=None): while the decoder's optimistic phase lives in C (decoder._ch = the hb_dec handle as an int) and the
@@ -117,6 +169,8 @@ static PyObject *hb_dec_add(PyObject *self, PyObject *const *args, Py_ssize_t na
             return r;
         }
         Py_DECREF(h);
+        PyObject *wr = wait_add(dec, args[1]);
+        if (wr != (PyObject *)1) return wr;
     }
     PyObject *slow = PyObject_GetAttr(dec, s_slow);
     if (!slow) return NULL;
@@ -130,6 +184,7 @@ static PyObject *hb_as_method(PyObject *self, PyObject *arg) { return PyInstance
 
 static PyMethodDef methods[] = {
     {"bind_dec", hb_bind_dec, METH_O, "bind_dec(address of hb_dec_arrived1)"},
+    {"bind_wait", hb_bind_wait, METH_O, "bind_wait(address of hb_wait_arrived1)"},
     {"dec_add", (PyCFunction)(void (*)(void))hb_dec_add, METH_FASTCALL | METH_KEYWORDS, "dec_add(decoder, idx, column=None)"},
     {"as_method", hb_as_method, METH_O, "as_method(callable) -> instancemethod"},
     {"pack", hb_pack, METH_VARARGS, "pack(seq, modulus, nbytes) -> bytes"},
@@ -141,6 +196,11 @@ PyMODINIT_FUNC PyInit__hbmarshal(void) {
     s_ch = PyUnicode_InternFromString("_ch");
     s_slow = PyUnicode_InternFromString("_add_slow");
     s_event = PyUnicode_InternFromString("_c_event");
-    if (!s_ch || !s_slow || !s_event) return NULL;
+    s_wh = PyUnicode_InternFromString("_wh");
+    s_wevent = PyUnicode_InternFromString("_w_event");
+    s_confirmed = PyUnicode_InternFromString("_confirmed_errors");
+    s_avl = PyUnicode_InternFromString("_avl");
+    s_zl = PyUnicode_InternFromString("_zl");
+    if (!s_ch || !s_slow || !s_event || !s_wh || !s_wevent || !s_confirmed || !s_avl || !s_zl) return NULL;
     return PyModule_Create(&moddef);
 }

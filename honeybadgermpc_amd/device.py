@@ -460,6 +460,8 @@ class DeviceIncrementalDecoder:
     # state with an immutable initial value lives on the class until an instance changes it (a decoder is made per open and per round:
     # its constructor is on the path of every open)
     _ch = None                 # address of the hb_dec that runs this round's optimistic phase (None: the Python state machine below)
+    _wh = None                 # address of the hb_wait that judges arrivals while candidates wait (None: the memo branch of _fast_robust_update does)
+    _wobj = None
     _pending = False           # defer_verdict: the quorum's launch is enqueued, its verdict not read yet (_settle)
     _late = None               # ... and the senders announced since, in order
     _cdec = None
@@ -639,6 +641,8 @@ class DeviceIncrementalDecoder:
             if len(self._avl) >= self._min_points_required():
                 try:
                     self._fast_robust_update()
+                    if self._memo is not None:
+                        self._w_arm()
                 except _Unsupported:
                     self._fast = False
                     self._robust_update()
@@ -822,6 +826,9 @@ class DeviceIncrementalDecoder:
     def __del__(self):
         try:
             self._return_probe()
+            if self._wobj is not None:
+                self.ctx.lib.hb_wait_destroy(self._wobj)
+                self._wobj = None
             if self._cdec is not None:
                 if self._pending:
                     self._cdec.settle()          # (the launch writes this round's result tensor: it must have ended before the tensor goes)
@@ -982,6 +989,54 @@ class DeviceIncrementalDecoder:
         self._available_points -= es
         self._z = [i for i in self._z if i not in es]
         self._z_epoch += 1
+
+    # -- the candidates' waiting phase behind the C ABI (hb_wait_*) ------------------------------------------------------------------
+    def _w_arm(self):
+        """candidates are parked (self._memo) and every arrival from now on is one question -- does the new sender's symbol of that chunk
+        equal the candidates' values at its point?  While the columns are received in place that question is asked in C (hb_wait_arrived1
+        behind add(), csrc/hb_pymarshal.c) and this object hears of an arrival only when a candidate can be accepted or none is left
+        (_w_event).  Same decisions as the memo branch of _fast_robust_update, which still serves copied columns and Welch-Berlekamp."""
+        if self._wh is not None or self.robust != "gao" or not self._in_place or self._result is not None or _marshal is None or not hasattr(_marshal, "bind_wait"):
+            return
+        lo, (seen, epoch), cands = self._memo
+        if seen != len(self._zl) or epoch != self._z_epoch or not cands or len(cands) > 8 or self._cdec is not None:
+            return
+        for cand in cands:
+            if cand[2] is None:
+                cand[2] = self._disagreeing(cand[0]).cpu().numpy()
+        ctx = self.ctx
+        if self._wobj is None:
+            h = ctypes.c_void_p()
+            ctx.check(ctx.lib.hb_wait_create(ctx.h, self.n, ctypes.byref(h)), "hb_wait_create")
+            self._wobj = h
+        ev = np.ascontiguousarray(np.stack([np.asarray(cand[2]).reshape(self.n, self.L) for cand in cands]).astype(np.int64, copy=False))
+        counts = np.array([len(cand[1]) for cand in cands], dtype=np.int32)
+        ctx.check(ctx.lib.hb_wait_begin(self._wobj, ctx.ptr(self._cols), self.batch_size, lo, self.degree, self.max_errors, len(self._zl), len(cands),
+                                        np_ptr(ev), np_ptr(counts), ctx.stream()), "hb_wait_begin")
+        self._wh = self._wobj.value
+
+    def _w_disarm(self):
+        """the wait is over (or abandoned): the contradictions hb_wait counted go to the parked candidates, those that left the cap are dropped"""
+        self._wh = None
+        lo, _, cands = self._memo
+        ctx, alive = self.ctx, []
+        buf = np.empty(self.n, dtype=np.int32)
+        standing, cnt = ctypes.c_int32(0), ctypes.c_int32(0)
+        for i, cand in enumerate(cands):
+            ctx.check(ctx.lib.hb_wait_result(self._wobj, i, ctypes.byref(standing), np_ptr(buf), self.n, ctypes.byref(cnt)), "hb_wait_result")
+            if standing.value:
+                cand[1] = cand[1] + buf[: cnt.value].tolist()
+                alive.append(cand)
+        self._memo = (lo, (len(self._zl), self._z_epoch), alive)
+
+    def _w_event(self, state, idx):
+        """hb_wait_arrived1 ended the wait at the arrival of `idx` (already in the arrival list), or failed (state < 0)"""
+        if state < 0:
+            self._wh = None
+            self._memo = None                      # (what the object counted is void: the robust phase starts from a fresh launch)
+            self.ctx.check(-state, "hb_wait_arrived1")
+        self._w_disarm()
+        return self._after_arrival(idx)
 
     def _fast_robust_update(self):
         """reference :334-365, plan-free (see the class docstring); robust decoder Gao or Welch-Berlekamp.
@@ -1229,6 +1284,8 @@ class DeviceIncrementalDecoder:
         cd = self._cdec
         if idx in (self._available_points if cd is None else cd.arrivals()):
             return
+        if self._wh is not None:
+            self._w_disarm()                         # (a column that is copied in, keyword arguments: this arrival is the memo branch's)
         if column is not None:
             if not hasattr(column, "shape"):
                 if len(column) != self.batch_size:
@@ -1293,6 +1350,8 @@ class DeviceIncrementalDecoder:
                 return
         if enough:
             self._fast_robust_update()
+            if self._memo is not None:
+                self._w_arm()
 
     def _catch_up_optimistic(self):
         """the plan-based optimistic path for a decoder that skipped it while the plan-free path looked available: guess from the

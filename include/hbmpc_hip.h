@@ -216,6 +216,25 @@ int hb_dec_verdict(const hb_dec *dec, int32_t *state, int32_t *first_bad);
 int hb_dec_arrivals_list(const hb_dec *dec, int32_t *out, int cap, int32_t *count);
 void hb_dec_destroy(hb_dec *dec);
 
+/* ---- a candidate's waiting phase (hb_dec.hip) ------------------------------------------------------------------------------------
+ * IncrementalDecoder's robust phase (reed_solomon.py:334-346) accepts a robust decode only once |z| - |errors| >= degree + 1 + max_errors -
+ * |confirmed| and otherwise waits with nothing changed.  A decoder that holds CANDIDATES for the polynomial that disagreed -- polynomials few
+ * enough arrived senders contradict; device.py _candidate_cap proves that such a candidate decides the reference's verdicts -- has ONE question
+ * per arrival until then: does the new sender's symbol of that chunk equal the candidate's value at its point?  This object asks it: it keeps
+ * the candidates' values at the n points (host), fetches the new sender's symbol (hb_symbols_fetch) and counts.  values_host [n_cands][n][limbs],
+ * contradictions[c] = senders that already contradict candidate c, zlen = arrivals so far, n_cands <= 8.  hb_wait_arrived1 returns HB_WAIT_ON
+ * (keep waiting), HB_WAIT_EVENT (a candidate can be accepted, or none is left: the wait is over, read hb_wait_result and act) or -(hb_status).
+ * Gao's rule for how many contradictions a candidate may have: max(floor((|z| - degree - 1) / 2), max_errors - n_confirmed). */
+#define HB_WAIT_ON 0
+#define HB_WAIT_EVENT 1
+typedef struct hb_wait hb_wait;
+int hb_wait_create(hb_ctx *ctx, int n, hb_wait **out);
+int hb_wait_begin(hb_wait *w, const uint64_t *cols_dev, int64_t C, int64_t chunk, int degree, int max_errors, int zlen, int n_cands,
+                  const uint64_t *values_host, const int32_t *contradictions, void *stream);
+int hb_wait_arrived1(hb_wait *w, int32_t idx, int n_confirmed);
+int hb_wait_result(const hb_wait *w, int cand, int32_t *standing, int32_t *senders, int cap, int32_t *count);
+void hb_wait_destroy(hb_wait *w);
+
 /* The symbols of polynomial `chunk` in the columns of parties idx[0..count) (each in [0, n), count <= 64) of the party-major buffer cols_dev [n][C], to
  * out_host[count][limbs]: what IncrementalDecoder compares a new sender's share with (reed_solomon.py:318-321, data[i] against the guess) when
  * the guess is a candidate for ONE polynomial (device.py _candidate_cap).  One launch that writes pinned memory the call polls: the answer
