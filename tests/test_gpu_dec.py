@@ -385,3 +385,55 @@ def test_device_decoder_with_deferred_verdicts_equals_the_host_mirror(n, t, omeg
             assert done_now
         del dev
     torch.cuda.synchronize()
+
+
+def test_wait_object_counts_contradictions_like_the_reference_waits():
+    """hb_wait_* through the C ABI (reference reed_solomon.py:334-346: a robust decode is accepted only once |z| - |errors| >= degree + 1 + max_errors
+    - confirmed; until then nothing changes): two candidates for one chunk -- the shared polynomial and a wrong one -- judged arrival by arrival.
+    HB_WAIT_ON while the true candidate lacks support; the wrong one leaves the cap for good; HB_WAIT_EVENT exactly at the arrival that gives the
+    true one need columns; its contradictions are exactly the liars that arrived."""
+    from honeybadgermpc_amd._capi import Context, np_ptr
+
+    ctx = Context.get(P)
+    lib = ctx.lib
+    rnd = random.Random(404)
+    n, t, c, chunk = 40, 13, 6, 4
+    d = t + 1
+    x = list(range(1, n + 1))
+    polys = [[rnd.randrange(P) for _ in range(d)] for _ in range(c)]
+    enc = oracle.vandermonde_batch_evaluate(x, polys, P)                       # [c][n]
+    wrong = oracle.vandermonde_batch_evaluate(x, [[rnd.randrange(P) for _ in range(d)]], P)[0]
+    order = list(range(n))
+    rnd.shuffle(order)
+    first, rest = order[:d + 3], order[d + 3:]                                 # the wait begins with d + 3 arrivals in
+    liars = set(rnd.sample(rest, 5))
+    cols_int = [[enc[k][j] for k in range(c)] for j in range(n)]
+    for j in liars:
+        cols_int[j][chunk] = (cols_int[j][chunk] + 1 + rnd.randrange(P - 1)) % P
+    buf = ctx.upload_ints([v for col in cols_int for v in col]).view(n, c, 4)
+    ev = np.stack([ctx.host_elems(enc[chunk]).reshape(n, 4), ctx.host_elems(wrong).reshape(n, 4)]).astype(np.uint64)
+    counts = np.array([0, len(first) - d], dtype=np.int32)                     # (the wrong one agrees with at most d - 1 of the arrived... say d of them)
+    w = ctypes.c_void_p()
+    assert lib.hb_wait_create(ctx.h, n, ctypes.byref(w)) == 0
+    assert lib.hb_wait_arrived1(w, rest[0], 0) < 0                             # not begun
+    assert lib.hb_wait_begin(w, ctx.ptr(buf), c, chunk, t, t, len(first), 2, np_ptr(ev), np_ptr(counts), ctx.stream()) == 0
+    need = d + t
+    zlen, errs, ended_at = len(first), 0, None
+    for k, j in enumerate(rest):
+        st = lib.hb_wait_arrived1(w, j, 0)
+        zlen += 1
+        errs += j in liars
+        if zlen - errs >= need:
+            assert st == 1, (k, st)
+            ended_at = k
+            break
+        assert st == 0, (k, st)
+    assert ended_at is not None
+    standing, cnt = ctypes.c_int32(-1), ctypes.c_int32(-1)
+    out = np.full(n, -1, dtype=np.int32)
+    assert lib.hb_wait_result(w, 0, ctypes.byref(standing), np_ptr(out), n, ctypes.byref(cnt)) == 0
+    assert standing.value == 1 and out[: cnt.value].tolist() == [j for j in rest[: ended_at + 1] if j in liars]
+    assert lib.hb_wait_result(w, 1, ctypes.byref(standing), np_ptr(out), n, ctypes.byref(cnt)) == 0
+    assert standing.value == 0                                                 # contradicted by (almost) every arrival: beyond the cap, gone for good
+    assert lib.hb_wait_arrived1(w, rest[-1], 0) < 0                            # the wait is over
+    lib.hb_wait_destroy(w)
