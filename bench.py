@@ -225,6 +225,36 @@ def prewarm(step, sync, seconds, agree=None):
             return n, el * 1e3
 
 
+class StepEvents:
+    """HIP events around segments of a step, on every `stride`-th step of the timed region (about twenty samples), every event object recorded
+    once before the region starts (`warm`): round 6 met a runtime state in which the FIRST record of an event object costs ~100 us on the
+    GPU's queue -- with 200 steps x 2 fresh events the bracketed launch read 250 us and `value` 3 G, where the kernel trace of the same run
+    has 50 us launches and the event-free pre-warm 130 us a step.  A measuring instrument must not be what is measured."""
+
+    def __init__(self, torch, steps, marks):
+        self.stride = max(1, steps // 20)
+        self.n = (steps + self.stride - 1) // self.stride
+        self.ev = [[torch.cuda.Event(enable_timing=True) for _ in range(self.n)] for _ in range(marks)]
+        self.torch = torch
+
+    def warm(self):
+        for row in self.ev:
+            for e in row:
+                e.record()
+        self.torch.cuda.synchronize()
+
+    def slot(self, i):
+        """the sample index of step i, or None when step i carries no events"""
+        return i // self.stride if i is not None and i % self.stride == 0 else None
+
+    def mark(self, m, k):
+        if k is not None:
+            self.ev[m][k].record()
+
+    def mean_ms(self, a, b):
+        return sum(x.elapsed_time(y) for x, y in zip(self.ev[a], self.ev[b])) / self.n
+
+
 def valu_roofline(workload, launch_ms):
     """Second roofline of a kernel that HBM does not bind: VALU issue.  Instructions per launch come from the committed PMC
     pass (SQ_INSTS_VALU: VALU + MFMA wave-instructions), the duration is this run's; the ceiling is one wave-instruction per
@@ -627,21 +657,18 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
             print(f"bench.py: gather mode = {pick} ({gather_report})", file=sys.stderr, flush=True)
     gather_used = gather_report["used"]
 
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] for _ in range(4)]
+    evs = StepEvents(torch, args.steps, 4)
 
     def step(i=None):
-        if i is not None:
-            evs[0][i].record()
+        k = evs.slot(i)
+        evs.mark(0, k)
         so.r1_encode(shares0, out=r1_out)
-        if i is not None:
-            evs[1][i].record()
+        evs.mark(1, k)
         so.r1_decode(r1_cols, out=r2_msg)
         so.r2_decode(r2_cols, out=result)
-        if i is not None:
-            evs[2][i].record()
+        evs.mark(2, k)
         res = gather(result, full)
-        if i is not None:
-            evs[3][i].record()
+        evs.mark(3, k)
         return res
 
     def agree(done):
@@ -656,6 +683,7 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
     for _ in range(args.warmup):
         step()
     assert so.ok(), "validation mismatch during warmup"
+    evs.warm()                                        # (every event object's first record: outside the timed region)
     PROGRESS.note("timed steps")
 
     def barrier():
@@ -671,9 +699,7 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
     barrier()
     dt = time.perf_counter() - t0
     times = torch.tensor([dt,
-                          sum(a.elapsed_time(b) for a, b in zip(evs[0], evs[2])) / args.steps,
-                          sum(a.elapsed_time(b) for a, b in zip(evs[2], evs[3])) / args.steps,
-                          sum(a.elapsed_time(b) for a, b in zip(evs[0], evs[1])) / args.steps], dtype=torch.float64)
+                          evs.mean_ms(0, 2), evs.mean_ms(2, 3), evs.mean_ms(0, 1)], dtype=torch.float64)
     per_rank = [[float(v) for v in times]]
     if dist is not None:
         PROGRESS.note("reducing the times")
@@ -782,25 +808,23 @@ def main_p64(args, torch, dist, backend, rank, local_rank, world, n, t, B):
     z, zc = order[:d], order[d : d + t]
     op = BatchOpen(P64, n, t, z=z, zc=zc, max_shares=B, device=local_rank)
     r1_out, r2_msg, result = ctx.empty(n * C), ctx.empty(C), ctx.empty(B)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(args.steps)] for _ in range(4)]
+    evs = StepEvents(torch, args.steps, 4)
 
     def step(i=None):
-        if i is not None:
-            evs[0][i].record()
+        k = evs.slot(i)
+        evs.mark(0, k)
         op.r1_encode(shares0, out=r1_out)
-        if i is not None:
-            evs[1][i].record()
+        evs.mark(1, k)
         op.r1_decode(r1_cols, B, out=r2_msg)
-        if i is not None:
-            evs[2][i].record()
+        evs.mark(2, k)
         op.r2_decode(r2_cols, B, out=result)
-        if i is not None:
-            evs[3][i].record()
+        evs.mark(3, k)
 
     pre_steps, pre_ms = prewarm(step, torch.cuda.synchronize, args.prewarm)
     for _ in range(args.warmup):
         step()
     assert op.ok(), "validation mismatch during warmup"
+    evs.warm()                                        # (every event object's first record: outside the timed region)
 
     def barrier():
         if dist is not None:
@@ -819,7 +843,7 @@ def main_p64(args, torch, dist, backend, rank, local_rank, world, n, t, B):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     assert ok and torch.equal(result, secrets) and torch.equal(r2_msg, r2_cols[:C]), "the 64-bit open differs from the secrets"
-    seg_ms = [sum(a.elapsed_time(b) for a, b in zip(evs[k], evs[k + 1])) / args.steps for k in range(3)]
+    seg_ms = [evs.mean_ms(k, k + 1) for k in range(3)]
     seg_bytes = [8 * C * (d + n), 8 * C * (3 * d + n), 8 * C * (3 * d + n)]      # SURVEY 8d at 8-byte elements: encode 8 C (d + n); decode 8 C 2d + validating re-encode 8 C (d + n)
     names = ["R1 encode (n x d Vandermonde mat-vec)", "R1 decode + validating re-encode + compare", "R2 decode + validating re-encode + compare"]
     dom = max(range(3), key=lambda k: seg_ms[k])
@@ -1027,6 +1051,8 @@ def main_robust(args, torch, dist, backend, rank, local_rank, world, n, t, C):
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
     for _ in range(max(1, min(args.warmup, 3))):
         wb()
+    for e_ in ev0 + ev1:
+        e_.record()                                   # (an event object's first record can be slow: StepEvents)
     torch.cuda.synchronize()
     assert bool((st == 0).all().item()) and torch.equal(out, msg), "Welch-Berlekamp: a codeword did not decode to its generating polynomial"
 
@@ -1243,33 +1269,31 @@ def main():
     r2_msg = ctx.empty(C)
     result = ctx.empty(B)
 
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-
-    ev2 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev3 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    evs = StepEvents(torch, args.steps, 4)           # marks 0-1: the R1 encode, 2-3: the R2 launch (one pair is used)
 
     # HIP events bracket the roofline kernel only (every record is a packet the GPU processes between two dependent launches):
     # the R2 launch for plans that decode + validate in one launch, the R1 encode otherwise
     time_r2 = bool(op.uses_fused_validate()) and not args.no_matrix_cores
 
     def step(i=None):
-        if i is not None and not time_r2:
-            ev0[i].record()
+        k = evs.slot(i)
+        if not time_r2:
+            evs.mark(0, k)
         op.r1_encode(shares0, out=r1_out)            # dominant kernel of small-entry plans: the n x d encode
-        if i is not None and not time_r2:
-            ev1[i].record()
+        if not time_r2:
+            evs.mark(1, k)
         op.r1_decode(r1_cols, B, out=r2_msg)
-        if i is not None and time_r2:
-            ev2[i].record()
+        if time_r2:
+            evs.mark(2, k)
         op.r2_decode(r2_cols, B, out=result)         # dominant kernel of fused plans: decode + validate in one launch
-        if i is not None and time_r2:
-            ev3[i].record()
+        if time_r2:
+            evs.mark(3, k)
 
     pre_steps, pre_ms = prewarm(step, torch.cuda.synchronize, args.prewarm)
     for _ in range(args.warmup):
         step()
     assert op.ok(), "validation mismatch during warmup"
+    evs.warm()                                        # (every event object's first record: outside the timed region)
 
     def barrier():
         if dist is not None:
@@ -1522,8 +1546,8 @@ def main():
     fused_default = dt_unfused is not None         # the plan decodes + validates in one launch by default
     fused_kernel = op.fused_validate_kernel() if fused_default else None      # "small": k_mm8f (hb_mfma_fused.hip); "wide": k_mm8w
     assert fused_default == time_r2 or args.no_matrix_cores, "the events bracketed the wrong launch"
-    enc_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps if not time_r2 else None
-    r2_ms = sum(a.elapsed_time(b) for a, b in zip(ev2, ev3)) / args.steps if time_r2 else None
+    enc_ms = evs.mean_ms(0, 1) if not time_r2 else None
+    r2_ms = evs.mean_ms(2, 3) if time_r2 else None
     ms_per_step = dt * 1e3 / args.steps
     value = world * B * args.steps / dt
     alg_bytes_open = 32 * C * (3 * n + 7 * d)

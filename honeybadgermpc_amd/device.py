@@ -462,6 +462,7 @@ class DeviceIncrementalDecoder:
     _ch = None                 # address of the hb_dec that runs this round's optimistic phase (None: the Python state machine below)
     _wh = None                 # address of the hb_wait that judges arrivals while candidates wait (None: the memo branch of _fast_robust_update does)
     _wobj = None
+    _wbuf = None
     _pending = False           # defer_verdict: the quorum's launch is enqueued, its verdict not read yet (_settle)
     _late = None               # ... and the senders announced since, in order
     _cdec = None
@@ -1009,10 +1010,15 @@ class DeviceIncrementalDecoder:
             h = ctypes.c_void_p()
             ctx.check(ctx.lib.hb_wait_create(ctx.h, self.n, ctypes.byref(h)), "hb_wait_create")
             self._wobj = h
-        ev = np.ascontiguousarray(np.stack([np.asarray(cand[2]).reshape(self.n, self.L) for cand in cands]).astype(np.int64, copy=False))
-        counts = np.array([len(cand[1]) for cand in cands], dtype=np.int32)
+        wb = self._wbuf
+        if wb is None:
+            ev, counts = np.empty((8, self.n, self.L), dtype=np.int64), np.empty(8, dtype=np.int32)
+            wb = self._wbuf = (ev, counts, np_ptr(ev), np_ptr(counts))
+        for i, cand in enumerate(cands):
+            wb[0][i] = cand[2]
+            wb[1][i] = len(cand[1])
         ctx.check(ctx.lib.hb_wait_begin(self._wobj, ctx.ptr(self._cols), self.batch_size, lo, self.degree, self.max_errors, len(self._zl), len(cands),
-                                        np_ptr(ev), np_ptr(counts), ctx.stream()), "hb_wait_begin")
+                                        wb[2], wb[3], ctx.stream()), "hb_wait_begin")
         self._wh = self._wobj.value
 
     def _w_disarm(self):
