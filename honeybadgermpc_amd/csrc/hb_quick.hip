@@ -120,8 +120,7 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
                                                       const QuickIdx ix, int d, int nc, int n_coef, uint32_t *__restrict__ wj, uint32_t *__restrict__ full,
                                                       uint32_t *__restrict__ nraw, int32_t *__restrict__ z_dev, int32_t *__restrict__ fmap, int flags,
                                                       uint4 *__restrict__ zero_base, int zero_q, uint4 *__restrict__ zero2_base, int zero2_q,
-                                                      int nh, int nw, int nf, uint32_t *__restrict__ Ag, unsigned long long *__restrict__ a_flag, unsigned long long token,
-                                                      const uint32_t *__restrict__ pwt, int S) {
+                                                      int nh, int nw, int nf, const uint32_t *__restrict__ pwt, int S) {
     // Three workgroups, each a set of SHORT chains of dependent multiplications (rounds 3 and 4 ran one workgroup of d-step chains: A(X) by
     // d sequential multiplications by (X - x_q) with two barriers each, then d-step Horner / product chains per thread -- 177 us at d = 86):
     //   block 0: A(X) = prod (X - x_q) by a PRODUCT TREE in LDS (log2 d levels; a level multiplies adjacent monic polynomials, one output
@@ -136,8 +135,8 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
     // flags & 4 (with QUICK_Z): block 2 computes full_i for EVERY party (a decoder's candidate store: k_quick_fill makes a row of each), not
     // for the compared senders, who are not known yet.
     // Round 5: the chains of ONE workgroup are issue-bound on their CU once there are a thousand of them (config 5's shard: 256 parties x 86
-    // factors of full_i = 49 us of multiply-adds on one CU; 86 x 8 Horner segments = 29 us).  So: workgroups 0 .. nh - 1 share the N_j (block 0
-    // builds A(X), publishes it through `Ag` + `a_flag` and the helpers wait for it: the grid is a dozen workgroups, all resident); workgroup nh
+    // factors of full_i = 49 us of multiply-adds on one CU; 86 x 8 Horner segments = 29 us).  So: workgroups 0 .. nh - 1 share the N_j (each
+    // builds A(X) for itself: round 6, below -- no workgroup of the launch waits for another); workgroup nh
     // is the w_j; workgroups nh + 1 .. nh + nf take QM_FPB parties' full_i each (QM_FSEG partial products joined by a tree); the last one zeroes.
     extern __shared__ uint32_t q_lds[];
     const int tid = threadIdx.x;
@@ -198,7 +197,10 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
         uint32_t *B0 = xz + (size_t)d * NL, *B1 = B0 + (size_t)d * NL;      // [d][NL] each: the level's monic polynomials without their leading 1
         uint32_t *Ac = B1 + (size_t)d * NL;                                   // [d + 1][NL]
         uint32_t *Tb = Ac + (size_t)(d + 1) * NL;                             // [d][QM_SEG][NL]: segment sums
-      if (blockIdx.x == 0) {
+      // EVERY workgroup of the Horner phase builds A(X) itself, by the same product tree in its own LDS.  Rounds 5-6 had block 0 build it and
+      // publish it through global memory, a token telling the helpers when: they waited as long as the tree takes anyway (measured with every
+      // helper building its own: config 5's first-sight open 379.8 -> 374.5 us), and no workgroup of this launch depends on another any more.
+      {
         if (tid < d) {
             uint32_t x[NL], nx[NL];
             ldg<NL>(x, xz + (size_t)tid * NL);
@@ -248,21 +250,8 @@ __global__ void __launch_bounds__(QM_NT) k_quick_matrix(const FpParams<NL> P, co
             __syncthreads();
             uint32_t *t_ = src; src = dst; dst = t_;
         }
-        if (tid < d) { uint32_t v[NL]; ldg<NL>(v, src + (size_t)tid * NL); stg<NL>(Ac + (size_t)tid * NL, v); if (nh > 1) stg<NL>(Ag + (size_t)tid * NL, v); }
-        if (tid == 0) { stg<NL>(Ac + (size_t)d * NL, P.one); if (nh > 1) stg<NL>(Ag + (size_t)d * NL, P.one); }
-        __syncthreads();
-        if (nh > 1 && tid == 0) {
-            __threadfence();                                                 // A(X) is in memory before the token is
-            __hip_atomic_store(a_flag, token, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      } else {
-        // a helper: wait for block 0's A(X) (every workgroup of this launch is resident: a dozen of them)
-        if (tid == 0) {
-            while (__hip_atomic_load(a_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != token) __builtin_amdgcn_s_sleep(4);
-            __threadfence();
-        }
-        __syncthreads();
-        for (int e = tid; e < (d + 1) * NL; e += QM_NT) Ac[e] = __builtin_nontemporal_load(Ag + e);
+        if (tid < d) { uint32_t v[NL]; ldg<NL>(v, src + (size_t)tid * NL); stg<NL>(Ac + (size_t)tid * NL, v); }
+        if (tid == 0) stg<NL>(Ac + (size_t)d * NL, P.one);
         __syncthreads();
       }
         // N(m) := N_j[m - 1] = sum_{k >= m} A[k] x_j^(k - m), m = 1 .. d; segment g holds k in [lo, hi); this workgroup's share of the j
@@ -1162,7 +1151,7 @@ int quick_layout(hb_ctx *ctx, int n, int d, int nc, int n_coef, QuickLayout *L) 
     L->o_a8 = 0; L->o_crow = L->o_a8 + al(a8_bytes); L->o_wj = L->o_crow + al(crow_words * 4); L->o_full = L->o_wj + al((size_t)d * 36);
     L->o_nraw = L->o_full + al((size_t)(nc ? nc : 1) * 36); L->o_mcan = L->o_nraw + al((size_t)n_coef * d * 36);
     L->o_z = L->o_mcan + al((size_t)L->n_out * d * 32); L->o_map = L->o_z + al((size_t)d * 4); L->o_sync = L->o_map + al((size_t)(L->n_out + 2) * 4);
-    L->need = L->o_sync + al((size_t)(d + 1) * 36 + 64);                    // A(X) for the builder's helper workgroups, and their token
+    L->need = L->o_sync + al((size_t)(d + 1) * 36 + 64);                    // (until round 6: A(X) for the builder's helper workgroups, and their token)
     L->o_cand = L->o_cand_crow = 0;
     return HB_OK;
 }
@@ -1218,14 +1207,11 @@ int quick_build(hb_ctx *ctx, const uint64_t *x_host, const int32_t *z, const int
         // (the image and the row constants are zeroed by the launch's last workgroup when it builds the first half: padding rows / terms)
         const int nw = (d + QM_FPB - 1) / QM_FPB, nf = std::max(1, (frows + QM_FPB - 1) / QM_FPB);
         const int nh = L.n_coef == 1 ? nw : ((do_z && d > 40) ? 4 : 1);
-        static std::atomic<unsigned long long> token_ctr{0};
-        const unsigned long long token = 0xA5C3000000000000ull ^ (++token_ctr);
         const size_t lds = (size_t)std::max((4 + QM_SEG) * d + 1, d + QM_FSEG * QM_FPB) * 36;
-        uint32_t *Ag = (uint32_t *)(base + L.o_sync + 64);
         k_quick_matrix<9><<<nh + nw + nf + (do_z ? 1 : 0), QM_NT, lds, s>>>(ctx->pw, pt->xm, pt->inv, n, ix, d, nc, L.n_coef, wj, full, nraw, (int32_t *)(base + L.o_z),
                                                           (int32_t *)(base + L.o_map), (flags & 3) | (cand && do_z ? 4 : 0), (uint4 *)base, (int)(L.o_wj / 16),
                                                           (uint4 *)(base + L.o_cand), (cand && do_z) ? (int)((L.o_cand_crow - L.o_cand) / 16) : 0,
-                                                          nh, nw, nf, Ag, (unsigned long long *)(base + L.o_sync), token, pt->pw, pt->S);
+                                                          nh, nw, nf, pt->pw, pt->S);
     }
     HB_LAUNCH_CHECK(ctx);
     if (cand && do_z) {
