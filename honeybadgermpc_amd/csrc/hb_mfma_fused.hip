@@ -106,18 +106,12 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
     uint4 pk_piece = make_uint4(0, 0, 0, 0), pk_crow = make_uint4(0, 0, 0, 0);
     const int pk_e = threadIdx.x;
     const bool pk_has_piece = pick.cand && pk_e < pick.nc * NKB * 8, pk_has_crow = pick.cand && pk_e < pick.nc * 4;
-    static_assert(FS_MAXC * 3 * 8 <= 5 * NT, "a thread fetches at most five pieces");
-    uint4 pk_more[4];
+    // (one piece a thread ahead of the copy: config 3's 21 compared rows are 504 pieces for the 512 threads; what a larger launch has beyond
+    // that is fetched behind the copy, below -- five pieces a thread in registers went to scratch memory)
     if (pk_has_piece) {
         const int j = pk_e / (NKB * 8), pc = pk_e - j * (NKB * 8);
         pk_piece = pick.cand[(size_t)pick.zc[j] * (NKB * 8) + pc];
     }
-    if (pick.cand)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int e = pk_e + (r + 1) * NT;
-            if (e < pick.nc * NKB * 8) { const int j = e / (NKB * 8), pc = e - j * (NKB * 8); pk_more[r] = pick.cand[(size_t)pick.zc[j] * (NKB * 8) + pc]; }
-        }
     if (pk_has_crow) pk_crow = reinterpret_cast<const uint4 *>(pick.cand_crow)[(size_t)pick.zc[pk_e >> 2] * 4 + (pk_e & 3)];
     for (int i = threadIdx.x; i < n_rt * 16; i += NT) maskl[i] = i < n_out ? rowmode[i] : 0;
     for (int i = threadIdx.x; i < n_rt * 64; i += NT) fs_lds[i] = reinterpret_cast<const uint4 *>(crowd)[i];
@@ -133,9 +127,10 @@ __global__ __launch_bounds__(64 * FS_WAVES, 2) void k_mm8f(const int4 *__restric
             reinterpret_cast<uint4 *>(abuf)[((rt * NKB + kb) * 2 + grp) * 64 + r + 16 * gg] = v;
         };
         if (pk_has_piece) put(pk_e, pk_piece);
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (pk_e + (r + 1) * NT < pick.nc * NKB * 8) put(pk_e + (r + 1) * NT, pk_more[r]);
+        for (int e = pk_e + NT; e < pick.nc * NKB * 8; e += NT) {
+            const int j = e / (NKB * 8), pc = e - j * (NKB * 8);
+            put(e, pick.cand[(size_t)pick.zc[j] * (NKB * 8) + pc]);
+        }
         if (pk_has_crow) fs_lds[(pick.n_coef + (pk_e >> 2)) * 4 + (pk_e & 3)] = pk_crow;
         for (int j = threadIdx.x; j < pick.nc; j += NT) maskl[pick.n_coef + j] = (int32_t)pick.zc[j] + 1;
     }
