@@ -202,20 +202,25 @@ __global__ __launch_bounds__(256, 2) void k_mv64m(const uint4 *__restrict__ a8, 
     // Persistent waves over items = (tile of 16 chunks, pair of row tiles): a launch is a few items a wave, and an item's serial chain -- elements from
     // HBM, the products, eight reductions, stores -- is hidden under the wave's NEXT item's loads (issued ahead) and the SIMD's other wave.  (A wave
     // per chunk tile and all its rows, one round of workgroups: 2.9 waves a SIMD at two resident = two rounds of that chain, slower than k_mv64.)
-    // this lane's two elements of every K-block: terms 8 kb + 2 g and + 1 of its chunk, biased (low, high dword)
+    // this lane's two elements of every K-block: terms 8 kb + 2 g and + 1 of its chunk, biased (low, high dword); their rows' offsets are the lane's own
+    // for the whole launch (a gathered decode looks its rows up once, not a fetch)
+    int64_t toff[NKB][2];
+#pragma unroll
+    for (int kb = 0; kb < NKB; kb++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const int t = 8 * kb + 2 * g + e;
+            toff[kb][e] = t < d ? (int64_t)(in_rows ? in_rows[t] : t) * in_sl : INT64_MIN;
+        }
     auto fetch = [&](int64_t item, uint32_t (&X)[NKB][2][2]) {
         const int64_t ch = (item / n_pairs) * 16 + n;
-        const int64_t cq = ch < C ? ch : C - 1;
+        const int64_t base = (ch < C ? ch : C - 1) * in_sc;
 #pragma unroll
         for (int kb = 0; kb < NKB; kb++)
 #pragma unroll
             for (int e = 0; e < 2; e++) {
-                const int t = 8 * kb + 2 * g + e;
-                uint64_t v = 0;
-                if (t < d) {
-                    const int64_t idx = cq * in_sc + (int64_t)(in_rows ? in_rows[t] : t) * in_sl;
-                    if (idx < in_count) v = in[idx];
-                }
+                const int64_t idx = base + toff[kb][e];
+                const uint64_t v = (toff[kb][e] != INT64_MIN && idx < in_count) ? in[idx] : 0ull;
                 X[kb][e][0] = (uint32_t)v ^ 0x80808080u;
                 X[kb][e][1] = (uint32_t)(v >> 32) ^ 0x80808080u;
             }
