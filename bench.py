@@ -771,7 +771,7 @@ def main_sharded(args, torch, dist, backend, rank, local_rank, world, n, t, B, u
 
 def main_p64(args, torch, dist, backend, rank, local_rank, world, n, t, B):
     """Config 3's per-party open over the 64-bit prime p = 2^64 - 59 (north star: "the 64/256-bit prime"): the 1-limb instantiation of every
-    kernel (3 digits of 29 bits, 8-byte elements, integer VALU -- the matrix-core kernels are built for 256-bit elements).  Same call
+    kernel; the three mat-vecs run on k_mv64m (round 6: byte windows of the 8-byte elements against int8 matrix digits on the matrix cores).  Same call
     sequence and checks as the headline: R1 encode, R1 decode + validate, R2 decode + validate through an open plan, results bit-exact
     against the secrets; here the path moves 8 C (3 n + 7 d) = 132 MB per 2^20 shares and should sit much closer to the HBM roofline."""
     from honeybadgermpc_amd._capi import Context, HbView, np_ptr
@@ -852,16 +852,18 @@ def main_p64(args, torch, dist, backend, rank, local_rank, world, n, t, B):
             dist.destroy_process_group()
         return
     alg_open = 8 * C * (3 * n + 7 * d)
+    by_seg = profile_counters(args.workload).get("by_segment") or {}
+    seg_traffic = by_seg.get(["R1 encode", "R1 decode + validate", "R2 decode + validate"][dom], traffic_from_profiles(args.workload) if dom == 0 else None)
     achieved = seg_bytes[dom] / (seg_ms[dom] * 1e-3) / 1e9
     line = {
         "metric": f"shares reconstructed/sec (batch open, n={n} t={t}, 64-bit prime)", "value": world * B * args.steps / dt, "unit": "shares/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "u64 (integer mod p < 2^64, 3 x 29-bit digits in u32, 64-bit accumulators)", "data": "synthetic",
+        "dtype": "u64 (integer mod p < 2^64: int8 digits x byte windows on v_mfma_i32_16x16x64_i8, int32 accumulators, 32-bit Montgomery steps)", "data": "synthetic",
         "config": {"workload": f"{args.workload}: batch_reconstruct per-party open, n={n}, t={t}, B={B} shares per GPU, points=i+1, p=2^64-59 (8-byte elements, 1-limb context)",
                    "n": n, "t": t, "shares_per_gpu": B, "chunks": C, "parallelism": f"chunk-sharded x{world}, no data-path collective"},
         "distributed": dist_info(torch, dist, backend, args, world),
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_from_profiles(args.workload),
-                     "kernel": f"the slowest of the open's three segments: {names[dom]} (integer-VALU family at one limb: k_matvec3 / k_decode_check / k_matvec2, hb_fast.hip, hb_core.hip)",
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": seg_traffic,
+                     "kernel": f"the slowest of the open's three segments: {names[dom]} (one launch of k_mv64m, hb_narrow.hip: the 8-byte elements' mat-vec on the int8 matrix cores)",
                      "algorithmic_bytes_per_launch": seg_bytes[dom], "avg_launch_ms": seg_ms[dom],
                      "launch_note": "HIP events on the plan's stream around each of the three calls of a step; a segment may be more than one kernel (pre-scale + mat-vec): "
                                     "the kernel-by-kernel split is in profiles/",

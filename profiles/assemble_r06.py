@@ -36,6 +36,20 @@ def main(src):
         "# traffic_cfg3.json (what bench.py copies into roofline.traffic / roofline.second) is the R2 row that writes 32 C d bytes, asserted by make_traffic.py.  Round 5's rows of the same kernels: r05_pmc_cfg3.txt",
         "# (k_mm8f R2: SQ_INSTS_VALU 15.45 M, SQ_WAIT_ANY 31.8 M; k_mm8 encode: 12.8 M)."],
         read(src, "pmc_summary_cfg3.txt"))
+    if os.path.exists(os.path.join(src, "kernel_stats_cfg3-p64.txt")):
+        jp = last_json(os.path.join(src, "bench_cfg3-p64.json"))
+        segs = jp["roofline"]["segments"]
+        put("r06_bench_cfg3-p64_kernel_stats.txt", [
+            f"# rocprofv3 --kernel-trace --stats -- python bench.py --workload cfg3-p64 --cpu-sample 0   (MI355X, round 6, collection {tag}): config 3's open over p = 2^64 - 59, 8-byte elements,",
+            f"# three launches of hb::k_mv64m<3> (hb_narrow.hip: int8 matrix cores).  The un-profiled line of the same collection: {jp['value'] / 1e9:.2f} G shares/s, {jp['ms_per_step'] * 1e3:.1f} us an open "
+            f"(encode {segs[0]['ms'] * 1e3:.1f}, R1 {segs[1]['ms'] * 1e3:.1f}, R2 {segs[2]['ms'] * 1e3:.1f} us).",
+            "# Round 5, the integer-VALU kernel k_mv64: r05_bench_cfg3-p64_kernel_stats.txt (14.2 G shares/s as this round's bench.py measures it)."],
+            read(src, "kernel_stats_cfg3-p64.txt"))
+        put("r06_pmc_cfg3-p64.txt", ["# rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ counters (separate passes) -- python bench.py --workload cfg3-p64 --steps 3 --warmup 1 --prewarm 0 --cpu-sample 0   (MI355X, round 6)"],
+            read(src, "pmc_summary_cfg3-p64.txt"))
+        name = "traffic_cfg3-p64.json"
+        if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)) > 10:
+            shutil.copy(os.path.join(src, name), os.path.join(HERE, name))
     other = ""
     for w in ("cfg5-shard", "cfg3-omega", "cfg2", "cfg5", "cfg4", "cfg4_erasures10", "cfg3-p64"):
         p = os.path.join(src, f"bench_{w}.json")
@@ -49,6 +63,7 @@ def main(src):
                                        "(what bench.py's value_first_sight_protocol_path runs); early = R2's columns announced while R1's launch runs"),
              ("first_sight_timeline.txt", "the same under rocprofv3 --kernel-trace: kernels of one first-sight open in START order, idle gap before each (negative: it started before the previous one ended)"),
              ("first_sight_host.txt", "scratch/first_sight_host.py: when, after the open's start, each step of the host loop returns (flow `defer`; averages of 200 opens, us)"),
+             ("open_p64.txt", "scratch/time_open_p64.py 100 (the same over the 64-bit prime: k_mv64m, then with HB_NO_MFMA=1 the integer-VALU kernel k_mv64)"),
              ("dec21_cfg3.txt", "scratch/dec21.py (the 21-liar open at config 3's shape alone: wall clock of the sixth, add() times)"),
              ("dec21_cfg5.txt", "scratch/dec21.py 256 85 (the 85-liar open at config 5's shard shape)"),
              ("dec21_cfg3_spread.txt", "scratch/dec21.py 64 21 spread freeze (the 21 liars one after every two honest senders: no candidate stands, the probe decides)"),

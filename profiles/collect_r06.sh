@@ -34,6 +34,10 @@ done
 timeout 900 python bench.py --workload cfg4 --cpu-sample 0 > "$OUT/bench_cfg4.json" 2> "$OUT/bench_cfg4.err"
 timeout 900 python bench.py --workload cfg4 --erasures 10 --cpu-sample 0 > "$OUT/bench_cfg4_erasures10.json" 2> "$OUT/bench_cfg4_erasures10.err"
 timeout 900 python bench.py --workload cfg3-p64 --cpu-sample 0 > "$OUT/bench_cfg3-p64.json" 2> "$OUT/bench_cfg3-p64.err"
+stats cfg3-p64 python bench.py --workload cfg3-p64 --cpu-sample 0
+pmc cfg3-p64
+timeout 300 python scratch/time_open_p64.py 100 > "$OUT/open_p64.txt" 2>&1
+HB_NO_MFMA=1 timeout 300 python scratch/time_open_p64.py 100 >> "$OUT/open_p64.txt" 2>&1
 {
 for m in wait "defer --r1-in-order" defer early; do timeout 300 python scratch/first_sight_timeline.py $m; done
 for m in wait "defer --r1-in-order" defer early; do timeout 300 python scratch/first_sight_timeline.py $m; done

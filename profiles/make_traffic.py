@@ -52,15 +52,21 @@ def main(path, workload, source):
                           "hb_gao_decode_call": {"hbm_bytes_per_launch": sum(gao.values()) * 1e6, "per_kernel_MB": gao}, "source": source}, indent=1))
         return
     if workload.startswith("cfg3-p64"):
-        # the 64-bit prime: three launches of k_mv64 an open (encode, R1, R2); bench.py's roofline segment is the slowest one -- the encode, the row
-        # that writes the most (n C 8 bytes)
-        rows = parse(("hb::k_mv64<",))
+        # the 64-bit prime: three launches of k_mv64m (k_mv64 where the matrix-core image is not built) an open -- encode, R1, R2 -- told apart by what
+        # they write (8 n C, 8 C, 8 C d bytes); bench.py's roofline segment is the slowest of the three: `by_segment` holds each one's bytes
+        rows = parse(("hb::k_mv64m<", "hb::k_mv64<"))
         if not rows:
-            raise SystemExit("no k_mv64 row in " + path)
-        rows = [r for r in rows if r[1].get("hbm_mb") is not None and r[1].get("WRITE_SIZE", 0) > 1000]
-        name, v = max(rows, key=lambda r: r[1].get("WRITE_SIZE", 0.0))
+            raise SystemExit("no k_mv64m / k_mv64 row in " + path)
+        rows = [r for r in rows if r[1].get("hbm_mb") is not None]
+        order = sorted(rows, key=lambda r: r[1].get("WRITE_SIZE", 0.0))
+        name, v = order[-1]
+        seg = {"R1 encode": order[-1][1]["hbm_mb"] * 1e6}
+        if len(order) >= 3:
+            seg["R2 decode + validate"] = order[-2][1]["hbm_mb"] * 1e6
+            seg["R1 decode + validate"] = order[-3][1]["hbm_mb"] * 1e6
         print(json.dumps({"workload": workload, "kernel": f"{name} (the R1 encode: n x d mat-vec at 8-byte elements, hb_narrow.hip)", "hbm_bytes_per_launch": v["hbm_mb"] * 1e6,
-                          "launches_averaged": v.get("launches"), "per_launch_MB": {f"{n} [{int(x.get('WRITE_SIZE', 0))} KB written]": x["hbm_mb"] for n, x in rows}, "source": source}, indent=1))
+                          "by_segment": seg, "launches_averaged": v.get("launches"),
+                          "per_launch_MB": {f"{n} [{int(x.get('WRITE_SIZE', 0))} KB written]": x["hbm_mb"] for n, x in rows}, "source": source}, indent=1))
         return
     # plans at small-integer points decode + validate on k_mm8f (hb_mfma_fused.hip); the others on k_mm8w<true, PEEL>
     rows = parse(("hb::k_mm8f<",))

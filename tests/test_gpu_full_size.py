@@ -443,6 +443,56 @@ def test_narrow_context_every_entry_point(p):
     assert errs == {liar} and ctx.download_ints(res.reshape(-1, 1)) == [v for row in p2 for v in row]
 
 
+@pytest.mark.parametrize("p", [(1 << 64) - 59, 0xFFFFFFFF00000001, (1 << 61) - 1, 1000003])
+def test_narrow_matrix_core_kernel_equals_the_integer_kernel(p, monkeypatch):
+    """k_mv64m (hb_narrow.hip: the 8-byte elements' mat-vec on the int8 matrix cores, round 6 -- the three launches of an open plan over a prime
+    below 2^64) against the oracle and against k_mv64 (the integer-VALU kernel: the same plan with HB_NO_MFMA=1): row counts that are not
+    multiples of 16 (odd numbers of row tiles: a pair's second tile is absent), one to three K-blocks of 8 terms, chunk counts that are not
+    multiples of 16, a single chunk, plans at omega powers (the narrow mat-vec kernels stand aside there: the plan's NTT), elements whose bytes
+    sit on the edges of the windows' bias, and a lie in a compared row (both kernels must refuse it)."""
+    from honeybadgermpc_amd._capi import Context
+    from honeybadgermpc_amd.device import BatchOpen
+
+    ctx = Context.get(p)
+    rnd = random.Random(p % 7919 + 6)
+    omega_ok = (p - 1) % 128 == 0
+    edge = [0, p - 1, 0x8080808080808080 % p, 0x7f7f7f7f7f7f7f7f % p, 0x80 % p, 0xff00000000000000 % p]
+    lim = lambda rows: oracle._limbs([v for r in rows for v in r], p)  # noqa: E731
+    for nn, t, b, om in ((4, 1, 7, False), (16, 5, 200, False), (33, 7, 8, False), (40, 13, 3000, False), (64, 21, 22 * 1000 + 5, False), (70, 23, 999, False),
+                         (64, 21, 4000, True), (24, 7, 129, True)):
+        if om and not omega_ok:
+            continue
+        dq = t + 1
+        cq = (b + dq - 1) // dq
+        shares = [rnd.choice(edge) if rnd.random() < 0.05 else rnd.randrange(p) for _ in range(b)]
+        p1 = [[rnd.choice(edge) if rnd.random() < 0.05 else rnd.randrange(p) for _ in range(dq)] for _ in range(cq)]
+        p2 = [[rnd.randrange(p) for _ in range(dq)] for _ in range(cq)]
+        order_ = list(range(nn))
+        rnd.shuffle(order_)
+        z, zc = order_[:dq], order_[dq : dq + t]
+        flat = lambda cc: ctx.upload_ints([v for col in cc for v in col])  # noqa: E731
+        for hook in (None, "1"):
+            if hook:
+                set_hook(monkeypatch, "HB_NO_MFMA", hook)
+            else:
+                clear_hook(monkeypatch, "HB_NO_MFMA")
+            op = BatchOpen(p, nn, t, z=z, zc=zc, use_omega_powers=om, max_shares=b)
+            xq = op.x          # (omega powers: a prime whose seeded candidate root is not primitive draws again UNSEEDED, as the reference does -- the plan's own points)
+            e1, e2 = oracle.vandermonde_batch_evaluate(xq, p1, p), oracle.vandermonde_batch_evaluate(xq, p2, p)
+            r1c = [[e1[k][j] for k in range(cq)] for j in range(nn)]
+            r2c = [[e2[k][j] for k in range(cq)] for j in range(nn)]
+            rc, o_r1, o_msg, o_res = oracle.batch_open_limbs(p, nn, dq, xq, oracle._limbs(shares, p), lim(r1c), lim(r2c), z, zc)
+            assert rc == 0
+            lied = [list(col) for col in r2c]
+            lied[zc[-1]][cq - 1] = (lied[zc[-1]][cq - 1] + 1) % p
+            assert ctx.download_ints(op.r1_encode(ctx.upload_ints(shares))) == oracle._ints(o_r1), (nn, t, b, om, hook)
+            assert ctx.download_ints(op.r1_decode(flat(r1c), b)) == oracle._ints(o_msg), (nn, t, b, om, hook)
+            assert ctx.download_ints(op.r2_decode(flat(r2c), b)) == oracle._ints(o_res), (nn, t, b, om, hook)
+            assert op.ok(), (nn, t, b, om, hook)
+            op.r2_decode(flat(lied), b)
+            assert not op.ok(), (nn, t, b, om, hook)
+
+
 # ---------------------------------------------------------------------------------------------- bounded caches
 def test_table_caches_are_bounded(monkeypatch):
     """the per-context caches are keyed by the arrival set of every asynchronous open.  With a cap of 16 entries,
