@@ -40,13 +40,15 @@ struct Mv64Params { uint32_t p0, p1, pinv32; };          // p = p1 2^32 + p0; pi
 
 // the six accumulators of a row -> the canonical residue -> stored or compared (shared by the kernels)
 struct Mv64Out { const uint64_t *in; int64_t in_sc, in_sl; uint64_t *out; int64_t out_sc, out_sl, out_count; int32_t *mismatch, *first_bad; };
-// S = sum_k w[k] 2^(32 k) (five words; S < p 2^128) -> (S 2^-128 + addend) mod p, canonical -> stored as output row -md - 1 or compared with row md - 1
+// S = sum_k w[k] 2^(32 k) (five words; S < p 2^128) -> S 2^-128 mod p, canonical -> stored as output row -md - 1 or compared with row md - 1
 // (got: the compared row's value when the caller has fetched it ahead -- have_got; otherwise it is loaded here)
-// S (five words, < 2^136 + slack) -> S 2^-128 mod p, canonical
+// S (five words) -> S 2^(-32 STEPS) mod p, canonical, where S / 2^(32 STEPS) < p: four steps for k_mv64's sums (< 40 p 2^64), three for k_mv64m's
+// (< 2^136 and p >= 2^41)
+template <int STEPS = 4>
 __device__ __forceinline__ uint64_t mv64_montgomery(uint32_t (&w)[6], const Mv64Params &prm) {
-    // four Montgomery steps of 32 bits: S <- (S + u p) / 2^32, u = w0 pinv32 mod 2^32
+    // Montgomery steps of 32 bits: S <- (S + u p) / 2^32, u = w0 pinv32 mod 2^32
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < STEPS; k++) {
         const uint32_t u = w[0] * prm.pinv32;
         uint64_t t = (uint64_t)u * prm.p0 + w[0];                        // low word becomes 0
         t = (t >> 32) + (uint64_t)u * prm.p1 + w[1];
@@ -59,7 +61,7 @@ __device__ __forceinline__ uint64_t mv64_montgomery(uint32_t (&w)[6], const Mv64
         w[3] = (uint32_t)t;
         w[4] = (uint32_t)(t >> 32);
     }
-    // result < S / 2^128 + p < 2 p in (w0, w1, w2 <= 1)
+    // result < S / 2^(32 STEPS) + p < 2 p in (w0, w1, w2 <= 1)
     uint64_t r = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
     const uint64_t pp = (uint64_t)prm.p0 | ((uint64_t)prm.p1 << 32);
     if (w[2] || r >= pp) r -= pp;
@@ -164,13 +166,13 @@ __global__ __launch_bounds__(256) void k_mv64(const uint2 *__restrict__ M, const
 // k_mv64m (round 6): the same product on the int8 MATRIX CORES, as k_mm8 does it for 32-byte elements (hb_mfma.hip).
 //
 //   out(c, i) = sum_l M[i][l] in(c, l) mod p:   in = sum_a X_a 2^(8a), a < 8 (the element's bytes as they lie in HBM, biased by XOR 0x80);
-//   M 2^128 mod p -- the Montgomery factor mv64_reduce_emit takes out again -- as EIGHT balanced base-256 digits: the digits' range,
+//   M 2^96 mod p -- the factor three Montgomery steps take out again (a sum here is < 2^136: three suffice for p >= 2^41) -- as EIGHT balanced base-256 digits: the digits' range,
 //   [-128 S, 127 S] with S = (2^64 - 1) / 255, is 2^64 - 1 wide, so every residue of a p < 2^64 has a representative in it;
 //   S = sum_c col_c 2^(8c), col_c = sum_l sum_b M_b[l] X_(c-b)[l], c < 15: for a column the sum over (l, b) is an int8 dot product of a constant row and
 //   an 8-byte WINDOW of every input element (bytes c - 7 .. c, zeros outside the element).  v_mfma_i32_16x16x64_i8 contracts 64 products: a K-block
 //   is 8 terms x 8 digits, lane (n, g) of the B operand holds the windows of terms 8 kb + 2 g, + 1 of chunk n, lane (r, g) of the A operand the
 //   digits of row r at those terms (one dwordx4 of the image, the same for all 15 columns: the window slides on the B side).  15 MFMAs a K-block
-//   and 16 x 16 outputs where k_mv64 issues 144 multiply-adds a row and thread; no fold -- a sum is 136 bits, five words, straight into the four
+//   and 16 x 16 outputs where k_mv64 issues 144 multiply-adds a row and thread; no fold -- a sum is 136 bits, five words, straight into the three
 //   Montgomery steps.  Accumulators start from a bias (columns non-negative: pairs of them fit 32 bits); bias and XOR correction are one residue a row.
 // A wave takes a tile of 16 chunks through the row tiles two at a time (120 accumulator registers).  d <= 24 (three K-blocks), any number of rows.
 constexpr int MV64M_BIAS = 3200000;          // >= 24 terms x 8 digit pairs x 128 x 128 = |column|, and 2 x BIAS x 257 < 2^32
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void k_mv64m(const uint4 *__restrict__ a8, 
 #ifdef MVM_NO_EPI
                 uint64_t res = (uint64_t)w[0] | ((uint64_t)(w[1] ^ w[2] ^ w[3] ^ w[4]) << 32);
 #else
-                uint64_t res = mv64_montgomery(w, prm);
+                uint64_t res = mv64_montgomery<3>(w, prm);
                 const uint64_t r2 = res + cr[j];                           // (the row's constant: a canonical residue)
                 res = (r2 < res || r2 >= pp) ? r2 - pp : r2;
 #endif
@@ -399,9 +401,9 @@ int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const 
     int rc = upload_table(ctx, m->M, img.data(), img.size() * sizeof(uint2), s);
     if (!rc) rc = upload_table(ctx, m->mode, mode_host, (size_t)n_out * 4, s);
     if (rc) { mv64_free(m); return rc; }
-    if (d <= 24 && (p >> 16) && !env_hook(ENV_NO_MFMA)) {
-        // the matrix-core image: every entry's representative in the eight balanced digits' range, the row constants.  (p >= 2^16: a sum there is
-        // bounded by the digits, ~2^136, not by p -- four Montgomery steps leave S / 2^128 + p, which is below 2 p only for p > 2^8)
+    if (d <= 24 && (p >> 41) && !env_hook(ENV_NO_MFMA)) {
+        // the matrix-core image: every entry's representative in the eight balanced digits' range, the row constants.  A sum there is bounded by
+        // the digits, < 2^136, not by p: THREE Montgomery steps leave S / 2^96 + p < 2 p once p >= 2^41 (entries are kept as M 2^96 mod p)
         const int nkb = (d + 7) / 8, n_rt = (n_out + 15) / 16;
         std::vector<uint8_t> dig((size_t)n_rt * nkb * 64 * 16, 0);
         std::vector<uint64_t> cr((size_t)n_rt * 16, 0);
@@ -421,6 +423,7 @@ int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const 
             }
             return (uint64_t)(t % P);
         };
+        const uint64_t r96 = (uint64_t)((((unsigned __int128)1 << 96)) % P);
         const uint64_t k8 = S255;                                           // sum_{a < 8} 256^a
         unsigned __int128 k15 = 0;
         for (int c = 0; c < 15; c++) k15 += (unsigned __int128)1 << (8 * c);
@@ -429,7 +432,7 @@ int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const 
             const int rt = i >> 4, r = i & 15;
             uint64_t sum_mod = 0;                                           // sum_l (the representative) mod p
             for (int l = 0; l < d; l++) {
-                const uint64_t v = mulmod_u64(m_host[(size_t)i * d + l] % p, r128, p);
+                const uint64_t v = mulmod_u64(m_host[(size_t)i * d + l] % p, r96, p);
                 sum_mod = (uint64_t)(((unsigned __int128)sum_mod + v) % P);
                 // the representative: v where eight balanced digits hold it, else v - p (>= -128 S: the digits' range is 2^64 - 1 >= p - 1 wide)
                 __int128 val = (unsigned __int128)v > hi_max ? (__int128)v - (__int128)P : (__int128)v;
@@ -448,10 +451,10 @@ int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const 
                     lane16[4 * (2 * (k >> 2) + e) + (k & 3)] = (uint8_t)(int8_t)dg[b];
                 }
             }
-            // out = REDC(S_mfma) + (128 K8 sum_l rep - BIAS K15) 2^-128:  sum_l rep = sum_mod (mod p)
+            // out = REDC(S_mfma) + (128 K8 sum_l rep - BIAS K15) 2^-96:  sum_l rep = sum_mod (mod p);  2^-96 = 2^-128 2^32
             const uint64_t corr = (uint64_t)((((unsigned __int128)128 * (k8 % p)) % P * sum_mod) % P);
             const uint64_t tot = corr >= bias_mod ? corr - bias_mod : corr + (p - bias_mod);
-            cr[(size_t)i] = inv128(tot);
+            cr[(size_t)i] = inv128(mulmod_u64(tot, (uint64_t)1 << 32, p));
         }
         hipError_t e2 = hipMalloc(&m->a8, dig.size());
         if (e2 == hipSuccess) e2 = hipMalloc(&m->crow, cr.size() * 8);
