@@ -77,7 +77,8 @@ def main(src):
     body = []
     for name, what in (("stress_decoder.txt", "scratch/stress_decoder.py 100 61 (the device decoder, its optimistic phase in C, against the host mirror after every column)"),
                        ("stress_gao.txt", "scratch/stress_gao.py 80 62 (hb_gao_decode / hb_wb_decode against the oracle: structured messages, coordinated liars, per-word and shared erasure patterns)"),
-                       ("stress_open_paths.txt", "scratch/stress_open_paths.py 60 63")):
+                       ("stress_open_paths.txt", "scratch/stress_open_paths.py 60 63"),
+                       ("stress_narrow.txt", "scratch/stress_narrow.py 60 64 (opens over word-size primes: k_mv64m against the generic one-limb kernels and exact integers)")):
         p = os.path.join(src, name)
         if os.path.exists(p):
             body.append(f"## {what}\n" + "\n".join(clean(p).splitlines()[-3:]) + "\n")

@@ -56,4 +56,5 @@ timeout 300 python scratch/dec21.py 256 85 spread freeze > "$OUT/dec21_cfg5_spre
 timeout 300 python scratch/stress_decoder.py 100 61 > "$OUT/stress_decoder.txt" 2>&1
 timeout 300 python scratch/stress_gao.py 80 62 > "$OUT/stress_gao.txt" 2>&1
 timeout 300 python scratch/stress_open_paths.py 60 63 > "$OUT/stress_open_paths.txt" 2>&1
+timeout 300 python scratch/stress_narrow.py 60 64 > "$OUT/stress_narrow.txt" 2>&1
 tail -1 "$OUT/bench_default.json" | cut -c1-300
