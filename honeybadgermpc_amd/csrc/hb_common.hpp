@@ -439,6 +439,7 @@ int fs_build_cand(hb_ctx *ctx, PointTable *pt, const int32_t *z, const FsLayout 
 struct Mv64Matrix;
 int points_on_device(hb_ctx *ctx, const uint64_t *x_host, int n, uint32_t **out, hipStream_t s);
 bool mv64_applies(const hb_ctx *ctx, int d);
+bool mv64_matrix_cores(const hb_ctx *ctx, int d);
 int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const int32_t *mode_host, Mv64Matrix **out, hipStream_t s);
 void mv64_free(Mv64Matrix *m);
 int launch_mv64(hb_ctx *ctx, const Mv64Matrix *m, const uint64_t *in, hb_view iv, const int32_t *in_rows_dev, int64_t in_count, uint64_t *out, hb_view ov,

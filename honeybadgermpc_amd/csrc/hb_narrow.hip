@@ -371,6 +371,11 @@ bool mv64_applies(const hb_ctx *ctx, int d) {
     return ctx->n_limbs == 1 && ctx->p_limbs[0] >= 3 && d >= 1 && d <= MV64_DMAX && !env_hook(ENV_NO_NARROW_FAST);
 }
 
+// the matrix-core image is built (k_mv64m): rows of up to 24 terms, p >= 2^41 (three Montgomery steps bring its sums below 2 p)
+bool mv64_matrix_cores(const hb_ctx *ctx, int d) {
+    return mv64_applies(ctx, d) && d <= 24 && (ctx->p_limbs[0] >> 41) != 0 && !env_hook(ENV_NO_MFMA);
+}
+
 void mv64_free(Mv64Matrix *m) {
     if (!m) return;
     if (m->M) (void)hipFree(m->M);
@@ -401,7 +406,7 @@ int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const 
     int rc = upload_table(ctx, m->M, img.data(), img.size() * sizeof(uint2), s);
     if (!rc) rc = upload_table(ctx, m->mode, mode_host, (size_t)n_out * 4, s);
     if (rc) { mv64_free(m); return rc; }
-    if (d <= 24 && (p >> 41) && !env_hook(ENV_NO_MFMA)) {
+    if (mv64_matrix_cores(ctx, d)) {
         // the matrix-core image: every entry's representative in the eight balanced digits' range, the row constants.  A sum there is bounded by
         // the digits, < 2^136, not by p: THREE Montgomery steps leave S / 2^96 + p < 2 p once p >= 2^41 (entries are kept as M 2^96 mod p)
         const int nkb = (d + 7) / 8, n_rt = (n_out + 15) / 16;

@@ -276,7 +276,9 @@ int hb_open_plan_create(hb_ctx *ctx, int n, int d, int use_omega_powers, const u
         }
         if ((pl->Winv8 || pl->Vw8) && !pl->coef_pk) PLAN_HIP(hipMalloc(&pl->coef_pk, (size_t)pl->max_C * d * ctx->elem_words() * 4));
     }
-    if (mv64_applies(ctx, d) && !use_omega_powers) {
+    // (plans at omega powers keep their NTT encode on the integer kernel; on the matrix cores an entry is full-size whatever the points are --
+    //  M 2^96 mod p -- and the mat-vec kernel is the faster of the two)
+    if (mv64_applies(ctx, d) && (!use_omega_powers || mv64_matrix_cores(ctx, d))) {
         std::vector<uint64_t> Vh, Vi, Ph;
         rc = mv64_plan_tables(ctx, x_host, n, d, z_host, zc_host, n_check, Vh, Vi, Ph);
         if (rc) goto done;

@@ -47,7 +47,7 @@ def main():
         if is_prime(q):
             primes.append(q)
     t_end = time.time() + budget
-    trials = 0
+    trials = n_om = 0
     as_np = lambda tns: tns.cpu().numpy().view(np.uint64)  # noqa: E731
     while time.time() < t_end:
         p = rnd.choice(primes)
@@ -65,7 +65,9 @@ def main():
         pick = lambda: rnd.choice(edge) if rnd.random() < frac else rnd.randrange(p)  # noqa: E731
         shares = [pick() for _ in range(b)]
         polys = [[pick() for _ in range(d)] for _ in range(c)]
-        x = list(range(1, n + 1))
+        order2 = 2 * (n if n & (n - 1) == 0 else 2 ** n.bit_length())
+        om = (p - 1) % order2 == 0 and rnd.random() < 0.5          # plans at omega powers where the prime has the roots
+        x = BatchOpen(p, n, t, z=z, zc=zc, use_omega_powers=om, max_shares=b).x if om else list(range(1, n + 1))
         cols = [[sum(pow(x[j], l, p) * polys[k][l] for l in range(d)) % p for k in range(c)] for j in range(n)]
         flat = ctx.upload_ints([v for col in cols for v in col])
         sh = ctx.upload_ints(shares)
@@ -73,13 +75,15 @@ def main():
         pad = shares + [0] * (c * d - b)
         outs = []
         for cores in (True, False):
-            op = BatchOpen(p, n, t, z=z, zc=zc, max_shares=b)
+            op = BatchOpen(p, n, t, z=z, zc=zc, use_omega_powers=om, max_shares=b)
+            if om and op.x != x:
+                break                 # (a prime whose seeded root is not primitive draws again unseeded, as the reference does: other points, skip)
             if not cores:
                 op.set_matrix_cores(False)
             enc = ctx.download_ints(op.r1_encode(sh))
             for _ in range(6):
                 i, k = rnd.randrange(n), rnd.randrange(c)
-                assert enc[i * c + k] == sum(pow(i + 1, l, p) * pad[k * d + l] for l in range(d)) % p, ("encode exact", p, n, t, b, i, k, cores)
+                assert enc[i * c + k] == sum(pow(x[i], l, p) * pad[k * d + l] for l in range(d)) % p, ("encode exact", p, n, t, b, i, k, cores)
             msg = ctx.download_ints(op.r1_decode(flat, b))
             assert msg == [polys[k][0] for k in range(c)], ("r1", p, n, t, b, cores)
             res = ctx.download_ints(op.r2_decode(flat, b))
@@ -92,9 +96,11 @@ def main():
                 lied[j][k] = (lied[j][k] + 1 + rnd.randrange(p - 1)) % p
                 op.r2_decode(ctx.upload_ints([v for col in lied for v in col]), b)
                 assert not op.ok(), ("lie accepted", p, n, t, b, j, k, cores)
-        assert outs[0] == outs[1], ("encode differs", p, n, t, b)
+        if len(outs) == 2:
+            assert outs[0] == outs[1], ("encode differs", p, n, t, b)
         trials += 1
-    print(f"stress_narrow: {trials} random opens over {len(primes)} primes (42 .. 64 bits), k_mv64m == generic kernels == exact integers, every planted lie refused; 0 differences")
+        n_om += 1 if om and len(outs) == 2 else 0
+    print(f"stress_narrow: {trials} random opens ({n_om} at omega powers) over {len(primes)} primes (42 .. 64 bits), k_mv64m == generic kernels == exact integers, every planted lie refused; 0 differences")
 
 
 main()

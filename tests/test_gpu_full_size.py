@@ -448,7 +448,7 @@ def test_narrow_matrix_core_kernel_equals_the_integer_kernel(p, monkeypatch):
     """k_mv64m (hb_narrow.hip: the 8-byte elements' mat-vec on the int8 matrix cores, round 6 -- the three launches of an open plan over a prime
     below 2^64) against the oracle and against k_mv64 (the integer-VALU kernel: the same plan with HB_NO_MFMA=1): row counts that are not
     multiples of 16 (odd numbers of row tiles: a pair's second tile is absent), one to three K-blocks of 8 terms, chunk counts that are not
-    multiples of 16, a single chunk, plans at omega powers (the narrow mat-vec kernels stand aside there: the plan's NTT), elements whose bytes
+    multiples of 16, a single chunk, plans at omega powers (full-size points: the matrix-core kernel takes those too), elements whose bytes
     sit on the edges of the windows' bias, and a lie in a compared row (both kernels must refuse it).  The primes either side of 2^41 are
     the first that takes the matrix-core kernel (three Montgomery steps bring a sum below 2 p from there on) and the last that does not."""
     from honeybadgermpc_amd._capi import Context
