@@ -406,7 +406,8 @@ int mv64_from_host(hb_ctx *ctx, const uint64_t *m_host, int n_out, int d, const 
     int rc = upload_table(ctx, m->M, img.data(), img.size() * sizeof(uint2), s);
     if (!rc) rc = upload_table(ctx, m->mode, mode_host, (size_t)n_out * 4, s);
     if (rc) { mv64_free(m); return rc; }
-    if (mv64_matrix_cores(ctx, d)) {
+    // (the image and the row tables of a launch live in LDS: matrices whose image passes the 64 KB a launch gets without asking stay on k_mv64)
+    if (mv64_matrix_cores(ctx, d) && (size_t)((n_out + 15) / 16) * (((size_t)(d + 7) / 8) * 64 * 16 + 16 * (8 + 8 + 4)) <= 64 * 1024) {
         // the matrix-core image: every entry's representative in the eight balanced digits' range, the row constants.  A sum there is bounded by
         // the digits, < 2^136, not by p: THREE Montgomery steps leave S / 2^96 + p < 2 p once p >= 2^41 (entries are kept as M 2^96 mod p)
         const int nkb = (d + 7) / 8, n_rt = (n_out + 15) / 16;

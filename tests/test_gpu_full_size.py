@@ -460,7 +460,7 @@ def test_narrow_matrix_core_kernel_equals_the_integer_kernel(p, monkeypatch):
     edge = [0, p - 1, 0x8080808080808080 % p, 0x7f7f7f7f7f7f7f7f % p, 0x80 % p, 0xff00000000000000 % p]
     lim = lambda rows: oracle._limbs([v for r in rows for v in r], p)  # noqa: E731
     for nn, t, b, om in ((4, 1, 7, False), (16, 5, 200, False), (33, 7, 8, False), (40, 13, 3000, False), (64, 21, 22 * 1000 + 5, False), (70, 23, 999, False),
-                         (64, 21, 4000, True), (24, 7, 129, True)):
+                         (64, 21, 4000, True), (24, 7, 129, True), (320, 21, 500, False)):     # (the last: an encode image beyond a launch's 64 KB of LDS -- k_mv64)
         if om and not omega_ok:
             continue
         dq = t + 1
