@@ -200,6 +200,8 @@ __global__ __launch_bounds__(256, 2) void k_mv64m(const uint4 *__restrict__ a8, 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // (uniform, and the compiler is told: items, row tiles
     const int n = lane & 15, g = lane >> 4;                                                            //  and every branch on them are scalar)
     const int n_pairs = (n_rt + 1) >> 1;
+    const int64_t n_tiles = (C + 15) >> 4;
+    const bool pair_major = (n_rt & 1) && n_pairs > 1;      // (see the item loop)
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     // Persistent waves over items = (tile of 16 chunks, pair of row tiles): a launch is a few items a wave, and an item's serial chain -- elements from
     // HBM, the products, eight reductions, stores -- is hidden under the wave's NEXT item's loads (issued ahead) and the SIMD's other wave.  (A wave
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void k_mv64m(const uint4 *__restrict__ a8, 
             toff[kb][e] = t < d ? (int64_t)(in_rows ? in_rows[t] : t) * in_sl : INT64_MIN;
         }
     auto fetch = [&](int64_t item, uint32_t (&X)[NKB][2][2]) {
-        const int64_t ch = (item / n_pairs) * 16 + n;
+        const int64_t ch = (pair_major ? item % n_tiles : item / n_pairs) * 16 + n;
         const int64_t base = (ch < C ? ch : C - 1) * in_sc;
 #pragma unroll
         for (int kb = 0; kb < NKB; kb++)
@@ -232,8 +234,11 @@ __global__ __launch_bounds__(256, 2) void k_mv64m(const uint4 *__restrict__ a8, 
     if (item < n_items) fetch(item, X);
     __syncthreads();                                  // (the image's copy above and the first elements' loads are in flight together)
     for (; item < n_items; item += n_waves) {
-        const int64_t tile = item / n_pairs;
-        const int rp = 2 * (int)(item - tile * n_pairs);
+        // An odd tile count's last pair is half the work of the others: dealt tile-major with an even number of waves it went to the same waves --
+        // the same SIMDs -- every time (R2's 43 rows: SIMDs 0 and 2 of every CU did twice the work of 1 and 3).  Those launches are dealt
+        // pair-major, the light items last; the others tile-major (the two pairs of a tile read the same elements: neighbours in time)
+        const int64_t pair = pair_major ? item / n_tiles : item % n_pairs, tile = pair_major ? item - pair * n_tiles : item / n_pairs;
+        const int rp = 2 * (int)pair;
         const int64_t chunk = tile * 16 + n;
         const bool live = chunk < C;
         const int64_t cc = live ? chunk : C - 1;
@@ -277,7 +282,8 @@ __global__ __launch_bounds__(256, 2) void k_mv64m(const uint4 *__restrict__ a8, 
                     else if (q == 2) B = (mv_v4i)__builtin_shufflevector(F, F, 4, 5, 6, 7);
                     else B = (mv_v4i)__builtin_shufflevector(F, F, 6, 7, 8, 9);
                     acc[0][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0, B, acc[0][c], 0, 0, 0);
-                    acc[1][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1, B, acc[1][c], 0, 0, 0);      // (an odd tile count's last pair: the first tile again, not used)
+                    acc[1][c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1, B, acc[1][c], 0, 0, 0);      // (an odd tile count's last pair: the first tile again, not used;
+                                                                                                       //  behind a scalar branch the MFMAs no longer issue back to back: encode 24.0 -> 25.8 us)
                 }
             }
         }
