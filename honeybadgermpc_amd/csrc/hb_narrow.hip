@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void k_mv64(const uint2 *__restrict__ M, const
 //   digits of row r at those terms (one dwordx4 of the image, the same for all 15 columns: the window slides on the B side).  15 MFMAs a K-block
 //   and 16 x 16 outputs where k_mv64 issues 144 multiply-adds a row and thread; no fold -- a sum is 136 bits, five words, straight into the three
 //   Montgomery steps.  Accumulators start from a bias (columns non-negative: pairs of them fit 32 bits); bias and XOR correction are one residue a row.
-// A wave takes a tile of 16 chunks through the row tiles two at a time (120 accumulator registers).  d <= 24 (three K-blocks), any number of rows.
+// A work item is a tile of 16 chunks and a pair of row tiles (120 accumulator registers); persistent waves take the items round-robin.  d <= 24
+// (three K-blocks); any number of rows whose image fits a launch's 64 KB of LDS (mv64_from_host).
 constexpr int MV64M_BIAS = 3200000;          // >= 24 terms x 8 digit pairs x 128 x 128 = |column|, and 2 x BIAS x 257 < 2^32
 typedef int mv_v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t mv_v16u __attribute__((ext_vector_type(16)));
